@@ -1,0 +1,704 @@
+/*
+ * mtfjsp_oracle.c — CPU restatement of the reference's MT-FJSP disjunctive-graph
+ * environment path (SURVEY.md §8a rows A1–A12).
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this.  The product path
+ * (the HIP sources under e2e-mappo-for-mt-fjsp_amd/csrc behind include/mtfjsp.h) never calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function
+ * below against tests/golden/trace_*.npz, which were captured by running the
+ * reference itself (oracle/ref_harness/gen_golden.py).
+ *
+ * Deliberately written against the reference's *graph* semantics (a simple
+ * digraph with overwrite-on-add edges and explicit per-node in-edge lists,
+ * explicit per-machine route arrays) — NOT the closed-form/linked-route state
+ * the HIP kernels use — so that the two implementations are independent.
+ *
+ * All reals are IEEE-754 binary64 evaluated in the written order
+ * (compile with -ffp-contract=off, no -ffast-math).
+ *
+ * Reference citations: "env:" = graph-jsp-env/src/graph_jsp_env/
+ * disjunctive_graph_jsp_env_singlestep.py, "dg:" = trainer/DGenv_func.py,
+ * "pe:" = trainer/parallel_env.py, "pt:" = algorithm/ppo_trick.py,
+ * "ppo:" = algorithm/ppo_algorithm.py.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+
+#define MAX_IN 3
+
+typedef struct {
+    int J, M, T, left_shift;
+    double w_mk, w_ec, w_tt, divisor, gamma;
+    /* instance (owned copies) */
+    double *t, *p, *tt;            /* [T*M], [T*M], [M*M] */
+    int *shop;                     /* [M] 0-based shop of machine */
+    double *min_dur, *min_pt;      /* [T] */
+    /* graph: node ids 0=src, 1..T tasks, T+1 sink (sink edges are never observed) */
+    int *mach;                     /* [T+2] */
+    double *dur, *st, *ft;         /* [T+2] */
+    unsigned char *sched;          /* [T+2] */
+    int *in_n, *in_src;            /* [T+2], [(T+2)*MAX_IN] */
+    double *in_w;                  /* [(T+2)*MAX_IN] */
+    int *route, *rlen;             /* [M*T] node ids, [M] */
+    int *selected, *selected_m, nsel;
+} Hdr;
+
+typedef struct {
+    Hdr h;
+    double *mfea;                  /* [M*8] */
+    double w3[3];
+    double idle_this, trans_this, e1_this;
+    double mk_prev, e1_prev, trans_prev, idle_prev;
+    double *st_e, *ft_e, *pt_e;    /* [T] last estimate */
+    double last_rewards[5];
+    int last_path;                 /* 0 empty,1 front,2 between,3 append,-1 invalid */
+    /* A8 scaler */
+    double sc_R[4], sc_mean[4], sc_S[4], sc_std[4];
+    long sc_n;
+    /* A11 caller-side mask bookkeeping (ppo:60-110,202-316) */
+    int *remaining, *pool;         /* [J] */
+    unsigned char *base_mask;      /* [J] */
+} Env;
+
+/* ---------------------------------------------------------------- helpers */
+/* numpy's float64 add.reduce: identity 0 + pairwise_sum (8 accumulators, block 128).
+ * Determined empirically against numpy 2.2.6. Used by np.sum
+ * (env:896) and np.mean (pe:176-183). */
+static double pw_sum(const double *a, long n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (long i = 0; i < n; i++) r += a[i];
+        return r;
+    } else if (n <= 128) {
+        double r[8];
+        long i;
+        for (i = 0; i < 8; i++) r[i] = a[i];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return pw_sum(a, n2) + pw_sum(a + n2, n - n2);
+    }
+}
+double or_np_sum(const double *a, long n) { return 0.0 + pw_sum(a, n); }
+
+static inline int job_of(const Env *e, int node) { return (node - 1) / e->h.M; }
+static inline int op_of(const Env *e, int node) { return (node - 1) % e->h.M; }
+static inline int is_task(const Env *e, int node) { return node >= 1 && node <= e->h.T; }
+
+/* dg:74-98 — src/sink are "found" in no row, which leaves job index 0 */
+static int same_job(const Env *e, int u, int v)
+{
+    int ju = is_task(e, u) ? job_of(e, u) : 0;
+    int jv = is_task(e, v) ? job_of(e, v) : 0;
+    return ju == jv;
+}
+static inline double tt_at(const Env *e, int mu, int mv)
+{   /* python negative indexing on the MxM table */
+    int M = e->h.M;
+    if (mu < 0) mu += M;
+    if (mv < 0) mv += M;
+    return e->h.tt[mu * M + mv];
+}
+/* dg:108-128 find_transportT */
+static double tr(const Env *e, int u, int v)
+{
+    double x;
+    if (e->h.mach[v] >= 0) x = tt_at(e, e->h.mach[u], e->h.mach[v]); else x = 0.0;
+    if (e->h.mach[u] < 0) x = 0.0;
+    if (!same_job(e, u, v)) x = 0.0;
+    return x;
+}
+/* dg:46-66 find_max_arrivaTime_for_currentNode — over the CURRENT in-edges */
+static double arrival(const Env *e, int n)
+{
+    double best = 0.0;
+    int cnt = e->h.in_n[n];
+    for (int i = 0; i < cnt; i++) {
+        int u = e->h.in_src[n * MAX_IN + i];
+        double x = tt_at(e, e->h.mach[u], e->h.mach[n]);
+        if (e->h.mach[u] < 0) x = 0.0;
+        if (!same_job(e, u, n)) x = 0.0;
+        double v = e->h.ft[u] + x;
+        if (i == 0 || v > best) best = v;
+    }
+    return best;
+}
+/* nx.DiGraph.add_edge: overwrite when present */
+static void add_edge(Env *e, int u, int v, double w)
+{
+    int cnt = e->h.in_n[v];
+    for (int i = 0; i < cnt; i++)
+        if (e->h.in_src[v * MAX_IN + i] == u) { e->h.in_w[v * MAX_IN + i] = w; return; }
+    if (cnt >= MAX_IN) abort();
+    e->h.in_src[v * MAX_IN + cnt] = u;
+    e->h.in_w[v * MAX_IN + cnt] = w;
+    e->h.in_n[v] = cnt + 1;
+}
+static void remove_edge(Env *e, int u, int v)
+{
+    int cnt = e->h.in_n[v];
+    for (int i = 0; i < cnt; i++)
+        if (e->h.in_src[v * MAX_IN + i] == u) {
+            for (int j = i; j + 1 < cnt; j++) {
+                e->h.in_src[v * MAX_IN + j] = e->h.in_src[v * MAX_IN + j + 1];
+                e->h.in_w[v * MAX_IN + j] = e->h.in_w[v * MAX_IN + j + 1];
+            }
+            e->h.in_n[v] = cnt - 1;
+            return;
+        }
+}
+static void route_insert(Env *e, int m, int idx, int node)
+{
+    int *r = e->h.route + (long)m * e->h.T;
+    int n = e->h.rlen[m];
+    for (int i = n; i > idx; i--) r[i] = r[i - 1];
+    r[idx] = node;
+    e->h.rlen[m] = n + 1;
+}
+
+/* ---------------------------------------------------------------- A4 estimate (env:1920-1999) */
+static void estimate(Env *e)
+{
+    int J = e->h.J, M = e->h.M;
+    for (int j = 0; j < J; j++)
+        for (int c = 0; c < M; c++) {
+            int a = j * M + c, k = a + 1;
+            int s = e->h.sched[k];
+            /* "unscheduled" is tested as (ft * if_schedule) == 0 (env:1965-1968) */
+            double begin_ft = s ? e->h.ft[k] : 0.0;
+            if (begin_ft == 0.0)
+                e->ft_e[a] = (c ? e->ft_e[a - 1] : 0.0) + e->h.min_dur[a];
+            else
+                e->ft_e[a] = begin_ft;
+        }
+    for (int j = 0; j < J; j++)
+        for (int c = 0; c < M; c++) {
+            int a = j * M + c, k = a + 1;
+            if (!e->h.sched[k]) {
+                e->st_e[a] = c ? e->ft_e[a - 1] : 0.0;
+                e->pt_e[a] = e->h.min_pt[a];
+            } else {
+                e->st_e[a] = e->h.st[k];
+                e->pt_e[a] = e->h.t[a * M + e->h.mach[k]] * e->h.p[a * M + e->h.mach[k]];   /* env:356,2175 */
+            }
+        }
+}
+
+/* ---------------------------------------------------------------- A1 create / reset */
+Env *or_env_create(int J, int M, int left_shift, const double *t, const double *p, const double *tt,
+                   const int *shop, double w_mk, double w_ec, double w_tt, double divisor, double gamma)
+{
+    Env *e = (Env *)calloc(1, sizeof(Env));
+    int T = J * M;
+    e->h.J = J; e->h.M = M; e->h.T = T; e->h.left_shift = left_shift;
+    e->h.w_mk = w_mk; e->h.w_ec = w_ec; e->h.w_tt = w_tt; e->h.divisor = divisor; e->h.gamma = gamma;
+    e->h.t = (double *)malloc(sizeof(double) * T * M);  memcpy(e->h.t, t, sizeof(double) * T * M);
+    e->h.p = (double *)malloc(sizeof(double) * T * M);  memcpy(e->h.p, p, sizeof(double) * T * M);
+    e->h.tt = (double *)malloc(sizeof(double) * M * M); memcpy(e->h.tt, tt, sizeof(double) * M * M);
+    e->h.shop = (int *)malloc(sizeof(int) * M);         memcpy(e->h.shop, shop, sizeof(int) * M);
+    e->h.min_dur = (double *)malloc(sizeof(double) * T);
+    e->h.min_pt = (double *)malloc(sizeof(double) * T);
+    /* env:1932-1950: negative entries -> +inf, row minimum */
+    for (int a = 0; a < T; a++) {
+        double md = INFINITY, mp = INFINITY;
+        for (int m = 0; m < M; m++) {
+            double d = t[a * M + m];
+            double q = t[a * M + m] * fabs(p[a * M + m]);
+            if (d < 0) d = INFINITY;
+            if (q < 0) q = INFINITY;
+            if (d < md) md = d;
+            if (q < mp) mp = q;
+        }
+        e->h.min_dur[a] = md; e->h.min_pt[a] = mp;
+    }
+    int N = T + 2;
+    e->h.mach = (int *)malloc(sizeof(int) * N);
+    e->h.dur = (double *)malloc(sizeof(double) * N);
+    e->h.st = (double *)malloc(sizeof(double) * N);
+    e->h.ft = (double *)malloc(sizeof(double) * N);
+    e->h.sched = (unsigned char *)malloc(N);
+    e->h.in_n = (int *)malloc(sizeof(int) * N);
+    e->h.in_src = (int *)malloc(sizeof(int) * N * MAX_IN);
+    e->h.in_w = (double *)malloc(sizeof(double) * N * MAX_IN);
+    e->h.route = (int *)malloc(sizeof(int) * M * T);
+    e->h.rlen = (int *)malloc(sizeof(int) * M);
+    e->h.selected = (int *)malloc(sizeof(int) * (T + 8));
+    e->h.selected_m = (int *)malloc(sizeof(int) * (T + 8));
+    e->mfea = (double *)calloc(M * 8, sizeof(double));
+    e->st_e = (double *)malloc(sizeof(double) * T);
+    e->ft_e = (double *)malloc(sizeof(double) * T);
+    e->pt_e = (double *)malloc(sizeof(double) * T);
+    e->remaining = (int *)malloc(sizeof(int) * J);
+    e->pool = (int *)malloc(sizeof(int) * J);
+    e->base_mask = (unsigned char *)malloc(J);
+    return e;
+}
+void or_env_destroy(Env *e)
+{
+    if (!e) return;
+    free(e->h.t); free(e->h.p); free(e->h.tt); free(e->h.shop); free(e->h.min_dur); free(e->h.min_pt);
+    free(e->h.mach); free(e->h.dur); free(e->h.st); free(e->h.ft); free(e->h.sched);
+    free(e->h.in_n); free(e->h.in_src); free(e->h.in_w); free(e->h.route); free(e->h.rlen);
+    free(e->h.selected); free(e->h.selected_m); free(e->mfea); free(e->st_e); free(e->ft_e); free(e->pt_e);
+    free(e->remaining); free(e->pool); free(e->base_mask);
+    free(e);
+}
+/* ppo:60-110 / set_to_0 (ppo:1126-1172): caller-side bookkeeping reset */
+void or_mask_reset(Env *e)
+{
+    for (int j = 0; j < e->h.J; j++) { e->remaining[j] = e->h.M; e->pool[j] = 1 + e->h.M * j; e->base_mask[j] = 0; }
+}
+/* pe:70-85 new scaler / pt:123 per-episode reset of R */
+void or_scaler_init(Env *e)
+{
+    for (int i = 0; i < 4; i++) e->sc_R[i] = e->sc_mean[i] = e->sc_S[i] = e->sc_std[i] = 0.0;
+    e->sc_n = 0;
+}
+void or_scaler_reset_returns(Env *e) { for (int i = 0; i < 4; i++) e->sc_R[i] = 0.0; }
+
+/* env:1183-1245 reset (+ load_instance env:397-714); w3 drawn by the caller (env:1253-1259) */
+void or_env_reset(Env *e, const double *w3)
+{
+    int J = e->h.J, M = e->h.M, T = e->h.T;
+    for (int k = 0; k < T + 2; k++) {
+        e->h.mach[k] = -1; e->h.dur[k] = 0.0; e->h.st[k] = 0.0; e->h.ft[k] = 0.0;
+        e->h.sched[k] = 0; e->h.in_n[k] = 0;
+    }
+    e->h.mach[0] = -2; e->h.sched[0] = 1;           /* src: env:500-510 */
+    e->h.mach[T + 1] = -2;
+    for (int j = 0; j < J; j++)
+        for (int c = 0; c < M; c++) {
+            int k = j * M + c + 1;
+            if (c == 0) add_edge(e, 0, k, 0.0);       /* env:604-609 */
+            else add_edge(e, k - 1, k, 1.0);          /* env:617-644 */
+        }
+    for (int m = 0; m < M; m++) e->h.rlen[m] = 0;
+    e->h.nsel = 0;
+    for (int i = 0; i < M * 8; i++) e->mfea[i] = 0.0;
+    e->w3[0] = w3[0]; e->w3[1] = w3[1]; e->w3[2] = w3[2];
+    for (int m = 0; m < M; m++) { e->mfea[m * 8 + 5] = w3[0]; e->mfea[m * 8 + 6] = w3[1]; e->mfea[m * 8 + 7] = w3[2]; }
+    e->idle_this = e->trans_this = e->e1_this = 0.0;
+    estimate(e);
+    /* env:683-705 initial "previous" values */
+    double mk = e->ft_e[0];
+    for (int a = 1; a < T; a++) if (e->ft_e[a] > mk) mk = e->ft_e[a];
+    e->mk_prev = mk;
+    e->e1_prev = or_np_sum(e->pt_e, T);
+    e->trans_prev = e->idle_prev = 0.0;
+    e->last_path = -1;
+    for (int i = 0; i < 5; i++) e->last_rewards[i] = 0.0;
+}
+
+/* ---------------------------------------------------------------- A3 schedule (env:1476-1685) */
+static void refresh_job_edges(Env *e)
+{   /* env:1356-1434 (edges into the sink are never observed and are skipped) */
+    int T = e->h.T;
+    for (int k = 1; k <= T; k++) {
+        if (op_of(e, k) == 0) continue;
+        double x = tr(e, k - 1, k);
+        if (e->h.dur[k - 1] != 0.0) add_edge(e, k - 1, k, e->h.dur[k - 1] + x);
+    }
+}
+static void append_end(Env *e, int k, int m)
+{   /* env:1689-1775 */
+    int *r = e->h.route + (long)m * e->h.T;
+    int last = r[e->h.rlen[m] - 1];
+    route_insert(e, m, e->h.rlen[m], k);
+    double a = arrival(e, k);
+    double x = tr(e, last, k);
+    double c = e->h.ft[last] + x;
+    double st = a > c ? a : c;                  /* python max(a, c): first wins on ties */
+    e->h.st[k] = st; e->h.ft[k] = st + e->h.dur[k]; e->h.sched[k] = 1;
+    double blank = e->h.st[k] - e->h.ft[last];
+    add_edge(e, last, k, e->h.dur[last] + x + blank);
+}
+static void insert_front(Env *e, int k, int m)
+{   /* env:1777-1809 */
+    route_insert(e, m, 0, k);
+    double st = arrival(e, k);
+    e->h.st[k] = st; e->h.ft[k] = st + e->h.dur[k]; e->h.sched[k] = 1;
+}
+static int schedule(Env *e, int k, int m, double d)
+{
+    e->h.mach[k] = m; e->h.dur[k] = d;           /* env:1496-1498 */
+    refresh_job_edges(e);                        /* env:1502 */
+    if (e->h.sched[k]) return -1;                /* env:1504 */
+    int pj = e->h.in_src[k * MAX_IN + 0];        /* env:1518 first in-edge */
+    if (!e->h.sched[pj]) return -1;              /* env:1520-1528 */
+    int n = e->h.rlen[m];
+    int *r = e->h.route + (long)m * e->h.T;
+    if (!n) { insert_front(e, k, m); return 0; }                 /* env:1684 */
+    if (!e->h.left_shift) { append_end(e, k, m); return 3; }     /* env:1680 */
+    double lb_st = arrival(e, k);
+    double lb_ft = lb_st + d;
+    int f = r[0];
+    double f_st = arrival(e, f);
+    if (lb_ft <= f_st) {                                         /* env:1548-1576 */
+        insert_front(e, k, m);
+        double x = tr(e, k, f);
+        double blank = e->h.st[f] - e->h.ft[k];
+        add_edge(e, k, f, d + x + blank);
+        return 1;
+    }
+    if (n == 1) { append_end(e, k, m); return 3; }               /* env:1577 */
+    for (int i = 0; i + 1 < n; i++) {                            /* env:1587-1675 */
+        int P = r[i], N = r[i + 1];
+        double nst = arrival(e, N);
+        if (lb_ft > nst) continue;
+        double gap = nst - e->h.ft[P];
+        if (gap < d) continue;
+        double a = arrival(e, k);
+        double x = tr(e, P, k);
+        double c = e->h.ft[P] + x;
+        double st = a > c ? a : c;
+        e->h.st[k] = st; e->h.ft[k] = st + d; e->h.sched[k] = 1;
+        double blank = e->h.st[k] - e->h.ft[P];
+        add_edge(e, P, k, e->h.dur[P] + x + blank);
+        double x2 = tr(e, k, N);
+        double blank2 = e->h.st[N] - e->h.ft[k];
+        add_edge(e, k, N, d + x2 + blank2);
+        remove_edge(e, P, N);
+        route_insert(e, m, i + 1, k);
+        return 2;
+    }
+    append_end(e, k, m);                                         /* env:1676 */
+    return 3;
+}
+
+/* dg:144-170 */
+static double idle_sum(const Env *e)
+{
+    double sum = 0.0;
+    for (int m = 0; m < e->h.M; m++) {
+        int n = e->h.rlen[m];
+        const int *r = e->h.route + (long)m * e->h.T;
+        if (n >= 1) {
+            double blank = e->h.st[r[0]] - 0;
+            blank = blank * 1.0;                                  /* idle power p2 == 1 (env:371) */
+            sum = sum + blank;
+            for (int i = 0; i + 1 < n; i++) {
+                blank = e->h.st[r[i + 1]] - e->h.ft[r[i]];
+                blank = blank * 1.0;
+                sum = sum + blank;
+            }
+        }
+    }
+    return sum;
+}
+
+/* ---------------------------------------------------------------- A2 step (env:716-974) + A7 rewards (env:1051-1171) */
+/* out5 = reward, r_mk, r_idle, r_pt, r_tt ; returns done (0/1), *path = scheduling path */
+int or_env_step(Env *e, int a, int m, double *out5, int *path)
+{
+    int T = e->h.T, M = e->h.M;
+    int k = a + 1;
+    e->h.selected[e->h.nsel] = a; e->h.selected_m[e->h.nsel] = m; e->h.nsel++;
+    double d = e->h.t[a * M + m];
+    int pth = schedule(e, k, m, d);
+    e->last_path = pth;
+    if (path) *path = pth;
+    int total = 0;
+    for (int i = 0; i < M; i++) total += e->h.rlen[i];
+    int done = total == T;                                        /* env:797-800 */
+    e->idle_this = idle_sum(e);                                   /* env:857 */
+    double new_tr = (a % M == 0) ? 0.0 : tr(e, a, a + 1);         /* env:872-876 (node ids a = pred, a+1 = k) */
+    e->trans_this += new_tr;
+    /* A5 machine features (env:2315-2354) — part of _state_array, before rewards */
+    estimate(e);
+    if (e->h.rlen[m] > 0) {
+        int last = e->h.route[(long)m * T + e->h.rlen[m] - 1];
+        double *row = e->mfea + m * 8;
+        row[0] = e->h.ft[last];
+        row[1] += (e->h.p[a * M + m] * e->h.t[a * M + m]) / (double)T;
+        row[2] += new_tr;
+        row[3] += e->idle_this - e->idle_prev;
+        row[4] += 1;
+    }
+    double mk = e->ft_e[0];
+    for (int i = 1; i < T; i++) if (e->ft_e[i] > mk) mk = e->ft_e[i];   /* env:894 */
+    e->e1_this = or_np_sum(e->pt_e, T);                                  /* env:896 */
+    double r_t = 1.0 * e->mk_prev - mk;
+    double r_pt = 1.0 * e->e1_prev - e->e1_this;
+    r_pt = r_pt / (double)T;
+    double r_tt = 1.0 * e->trans_prev - e->trans_this;
+    double r_idle = 1.0 * e->idle_prev - e->idle_this;
+    double total_r = e->h.w_mk * r_t + e->h.w_ec * (r_pt + 1 * r_idle) + e->h.w_tt * r_tt * 1;   /* env:1164 */
+    out5[0] = total_r / e->h.divisor; out5[1] = r_t; out5[2] = r_idle; out5[3] = r_pt; out5[4] = r_tt;
+    memcpy(e->last_rewards, out5, sizeof(double) * 5);
+    e->mk_prev = mk; e->e1_prev = e->e1_this; e->trans_prev = e->trans_this; e->idle_prev = e->idle_this;  /* env:932-936 */
+    if (done) { e->e1_this = 0; e->idle_this = 0; e->trans_this = 0; }    /* env:950-960 (the *_prev values stay) */
+    return done;
+}
+
+/* ---------------------------------------------------------------- A5 observation (env:2001-2515) */
+/* ELL form: for each task v two in-edge slots (col = source task index or -1, val) — self loop implicit (value 1).
+ * deg[v] = len(G.in_edges) (feature col 4; counts the src edge). */
+void or_env_observe_ell(const Env *e, int *ell_col, double *ell_val, double *tfea, double *mfea2)
+{
+    int T = e->h.T, M = e->h.M;
+    for (int a = 0; a < T; a++) {
+        int k = a + 1, slot = 0;
+        ell_col[a * 2] = ell_col[a * 2 + 1] = -1;
+        ell_val[a * 2] = ell_val[a * 2 + 1] = 0.0;
+        for (int i = 0; i < e->h.in_n[k]; i++) {
+            int u = e->h.in_src[k * MAX_IN + i];
+            if (u < 1) continue;                                  /* src row/col removed (env:2019) */
+            long A = (long)e->h.in_w[k * MAX_IN + i];             /* astype(int): trunc toward zero */
+            if (A != 0) {
+                double nd = e->h.mach[u] < 0 ? 1.0 : e->h.dur[u]; /* env:2052-2058 */
+                A = (long)((double)A - nd);                       /* int-array item assignment truncates again */
+                A += 1;
+                if (slot >= 2) abort();
+                ell_col[a * 2 + slot] = u - 1;
+                ell_val[a * 2 + slot] = (double)A;
+                slot++;
+            }
+        }
+        double *f = tfea + (long)a * 12;
+        int s = e->h.sched[k];
+        f[0] = e->st_e[a]; f[1] = e->ft_e[a]; f[2] = e->pt_e[a]; f[3] = s;
+        f[4] = e->h.in_n[k];
+        if (s) {
+            f[5] = e->h.mach[k] + 1;
+            f[6] = e->h.t[a * M + e->h.mach[k]];
+            f[7] = e->h.p[a * M + e->h.mach[k]];
+        } else { f[5] = f[6] = f[7] = 0; }
+        f[8] = job_of(e, k) + 1;
+        f[9] = e->w3[0]; f[10] = e->w3[1]; f[11] = e->w3[2];
+    }
+    memcpy(mfea2, e->mfea, sizeof(double) * M * 8);
+}
+/* dense adj_wrk [T][T], row = destination (env:2066-2073) */
+void or_env_observe_dense_adj(const Env *e, double *adj)
+{
+    int T = e->h.T;
+    memset(adj, 0, sizeof(double) * T * T);
+    for (int a = 0; a < T; a++) {
+        int k = a + 1;
+        adj[(long)a * T + a] = 1.0;
+        for (int i = 0; i < e->h.in_n[k]; i++) {
+            int u = e->h.in_src[k * MAX_IN + i];
+            if (u < 1) continue;
+            long A = (long)e->h.in_w[k * MAX_IN + i];
+            if (A != 0) {
+                double nd = e->h.mach[u] < 0 ? 1.0 : e->h.dur[u];
+                A = (long)((double)A - nd);
+                A += 1;
+                adj[(long)a * T + (u - 1)] += (double)A;
+            }
+        }
+    }
+}
+
+/* state read-back for tests: mach/sched/st/ft per task, routes [M*T] (task index, -1 pad), prev4 */
+void or_env_state(const Env *e, int *mach, unsigned char *sched, double *st, double *ft, int *routes, double *prev4)
+{
+    int T = e->h.T, M = e->h.M;
+    for (int a = 0; a < T; a++) {
+        mach[a] = e->h.mach[a + 1]; sched[a] = e->h.sched[a + 1];
+        st[a] = e->h.sched[a + 1] ? e->h.st[a + 1] : NAN;
+        ft[a] = e->h.sched[a + 1] ? e->h.ft[a + 1] : NAN;
+    }
+    for (int m = 0; m < M; m++)
+        for (int i = 0; i < T; i++)
+            routes[m * T + i] = i < e->h.rlen[m] ? e->h.route[(long)m * T + i] - 1 : -1;
+    prev4[0] = e->mk_prev; prev4[1] = e->e1_prev; prev4[2] = e->trans_prev; prev4[3] = e->idle_prev;
+}
+
+/* ---------------------------------------------------------------- A8 reward scaling (pt:54-83,108-124; pe:255-260) */
+void or_scaler_apply(Env *e, const double *x4, double *out4)
+{
+    e->sc_n += 1;
+    for (int i = 0; i < 4; i++) {
+        e->sc_R[i] = e->h.gamma * e->sc_R[i] + x4[i];
+        double R = e->sc_R[i];
+        if (e->sc_n == 1) { e->sc_mean[i] = R; e->sc_std[i] = fabs(R); }
+        else {
+            double old = e->sc_mean[i];
+            e->sc_mean[i] = old + (R - old) / (double)e->sc_n;
+            e->sc_S[i] = e->sc_S[i] + (R - old) * (R - e->sc_mean[i]);
+            e->sc_std[i] = sqrt(e->sc_S[i] / (double)e->sc_n);
+        }
+        out4[i] = x4[i] / (e->sc_std[i] + 1e-8);
+    }
+}
+void or_scaler_state(const Env *e, double *out17)
+{
+    for (int i = 0; i < 4; i++) { out17[i] = e->sc_R[i]; out17[5 + i] = e->sc_mean[i]; out17[9 + i] = e->sc_S[i]; out17[13 + i] = e->sc_std[i]; }
+    out17[4] = (double)e->sc_n;
+}
+
+/* ---------------------------------------------------------------- A9 m_fea1 (pe:152-214) */
+/* prev_mach_p1 = tasks_fea[a-1][5] of the observation handed in by the caller (machine id + 1, 0 if unscheduled) */
+void or_mfea1(const Env *e, int a, const unsigned char *mmask, double prev_mach_p1, double *out /*[M*6]*/)
+{
+    int M = e->h.M;
+    long n[3] = {0, 0, 0};
+    double *tbuf = (double *)malloc(sizeof(double) * M * 3);
+    for (int m = 0; m < M; m++) {
+        double tv = e->h.t[a * M + m], pv = e->h.p[a * M + m];
+        double ptv = tv * fabs(pv);
+        if (tv > 0) tbuf[n[0]++] = tv;
+        if (ptv > 0) tbuf[M + n[1]++] = ptv;
+        if (pv > 0) tbuf[2 * M + n[2]++] = pv;
+    }
+    double mean_t = or_np_sum(tbuf, n[0]) / (double)n[0];
+    double mean_pt = or_np_sum(tbuf + M, n[1]) / (double)n[1];
+    double mean_p = or_np_sum(tbuf + 2 * M, n[2]) / (double)n[2];
+    free(tbuf);
+    for (int m = 0; m < M; m++) {
+        double tv = e->h.t[a * M + m], pv = e->h.p[a * M + m];
+        double ptv = tv * fabs(pv);
+        double *o = out + m * 6;
+        o[0] = tv > 0 ? tv : mean_t;
+        o[1] = ptv > 0 ? ptv : mean_pt;
+        if (a % M == 0) o[2] = 0;
+        else o[2] = tt_at(e, (int)prev_mach_p1 - 1, m);
+        o[3] = 1 - (int)mmask[m];
+        o[4] = pv > 0 ? pv : mean_p;
+        o[5] = e->h.shop[m] + 1;
+    }
+}
+
+/* ---------------------------------------------------------------- A11 candidate + job mask (ppo:202-316) */
+void or_job_mask_update(Env *e, int job_action, int *cand /*[J]*/, unsigned char *mask /*[J]*/)
+{
+    int J = e->h.J, M = e->h.M;
+    if (e->remaining[job_action] != 0) e->remaining[job_action] -= 1;
+    if (e->remaining[job_action] != 0) e->pool[job_action] += 1;
+    for (int j = 0; j < J; j++) if (e->remaining[j] == 0) e->base_mask[j] = 1;
+    for (int j = 0; j < J; j++) mask[j] = e->base_mask[j];
+    /* finish_time is not None  <=>  scheduled */
+    double *rowmax = (double *)malloc(sizeof(double) * J);
+    int *colsum = (int *)calloc(M, sizeof(int));
+    for (int j = 0; j < J; j++) {
+        double mx = 0.0;
+        for (int c = 0; c < M; c++) {
+            int k = j * M + c + 1;
+            double f = e->h.sched[k] ? e->h.ft[k] : 0.0;
+            if (c == 0 || f > mx) mx = f;
+            colsum[c] += e->h.sched[k] ? 1 : 0;
+        }
+        rowmax[j] = mx;
+    }
+    for (int c = 0; c < M; c++) {
+        if (c != 0) {
+            if (colsum[c - 1] == J && colsum[c] != J) {
+                for (int j = 0; j < J; j++) if (e->base_mask[j]) rowmax[j] = INFINITY;
+                double mn = rowmax[0];
+                for (int j = 1; j < J; j++) if (rowmax[j] < mn) mn = rowmax[j];
+                for (int j = 0; j < J; j++) mask[j] = !(rowmax[j] == mn);
+            }
+        } else if (colsum[0] != J) {
+            for (int j = 0; j < J; j++) mask[j] = e->h.sched[j * M + 1];
+        }
+    }
+    for (int j = 0; j < J; j++) cand[j] = e->pool[j] - 1;
+    free(rowmax); free(colsum);
+}
+void or_job_mask_state(const Env *e, int *cand, unsigned char *mask)
+{
+    for (int j = 0; j < e->h.J; j++) { cand[j] = e->pool[j] - 1; mask[j] = e->base_mask[j]; }
+}
+
+/* ---------------------------------------------------------------- A12 valid_action_mask (env:2535-2575) */
+void or_valid_action_mask(const Env *e, unsigned char *mask /*[T]*/)
+{
+    for (int k = 1; k <= e->h.T; k++) {
+        mask[k - 1] = 0;
+        if (e->h.sched[k]) continue;
+        int pj = e->h.in_src[k * MAX_IN + 0];
+        if (!e->h.sched[pj]) continue;
+        mask[k - 1] = 1;
+    }
+}
+
+/* ================================================================ batched façade (Parallel_env semantics, pe:19-282)
+ * plain loops over B envs — this is also the CPU baseline that bench.py times ("port"). */
+typedef struct { int B; Env **env; } Batch;
+
+Batch *or_batch_create(int B, int J, int M, int left_shift, const double *t, const double *p, const double *tt,
+                       const int *shop, double w_mk, double w_ec, double w_tt, double divisor, double gamma)
+{
+    Batch *b = (Batch *)malloc(sizeof(Batch));
+    int T = J * M;
+    b->B = B; b->env = (Env **)malloc(sizeof(Env *) * B);
+    for (int i = 0; i < B; i++) {
+        b->env[i] = or_env_create(J, M, left_shift, t + (long)i * T * M, p + (long)i * T * M, tt + (long)i * M * M,
+                                  shop + (long)i * M, w_mk, w_ec, w_tt, divisor, gamma);
+        or_scaler_init(b->env[i]);
+        or_mask_reset(b->env[i]);
+    }
+    return b;
+}
+void or_batch_destroy(Batch *b) { for (int i = 0; i < b->B; i++) or_env_destroy(b->env[i]); free(b->env); free(b); }
+Env *or_batch_env(Batch *b, int i) { return b->env[i]; }
+void or_batch_scaler_init(Batch *b) { for (int i = 0; i < b->B; i++) or_scaler_init(b->env[i]); }
+void or_batch_scaler_reset_returns(Batch *b) { for (int i = 0; i < b->B; i++) or_scaler_reset_returns(b->env[i]); }
+void or_batch_reset(Batch *b, const double *w3 /*[B*3]*/)
+{
+    for (int i = 0; i < b->B; i++) { or_env_reset(b->env[i], w3 + i * 3); or_mask_reset(b->env[i]); }
+}
+/* step all envs; info6 [B*6] = reward, done, mk_s, idle_s, pt_s, tt_s (pe:262) ; raw5 [B*5] optional ; paths optional */
+void or_batch_step(Batch *b, const int *task_idx, const int *mach_idx, double *info6, double *raw5, int *paths)
+{
+    for (int i = 0; i < b->B; i++) {
+        double r5[5], s4[4];
+        int path;
+        int done = or_env_step(b->env[i], task_idx[i], mach_idx[i], r5, &path);
+        or_scaler_apply(b->env[i], r5 + 1, s4);
+        info6[i * 6 + 0] = r5[0]; info6[i * 6 + 1] = done;
+        info6[i * 6 + 2] = s4[0]; info6[i * 6 + 3] = s4[1]; info6[i * 6 + 4] = s4[2]; info6[i * 6 + 5] = s4[3];
+        if (raw5) memcpy(raw5 + i * 5, r5, sizeof(r5));
+        if (paths) paths[i] = path;
+    }
+}
+void or_batch_observe_ell(Batch *b, int *ell_col, double *ell_val, double *tfea, double *mfea2)
+{
+    for (int i = 0; i < b->B; i++) {
+        int T = b->env[i]->h.T, M = b->env[i]->h.M;
+        or_env_observe_ell(b->env[i], ell_col + (long)i * T * 2, ell_val + (long)i * T * 2, tfea + (long)i * T * 12, mfea2 + (long)i * M * 8);
+    }
+}
+void or_batch_observe_dense_adj(Batch *b, double *adj)
+{
+    for (int i = 0; i < b->B; i++) { int T = b->env[i]->h.T; or_env_observe_dense_adj(b->env[i], adj + (long)i * T * T); }
+}
+void or_batch_mfea1(Batch *b, const int *task_idx, const unsigned char *mmask /*[B*M]*/, const double *tfea /*[B*T*12]*/, double *out)
+{
+    for (int i = 0; i < b->B; i++) {
+        int T = b->env[i]->h.T, M = b->env[i]->h.M, a = task_idx[i];
+        double pm = a > 0 ? tfea[((long)i * T + a - 1) * 12 + 5] : 0.0;
+        or_mfea1(b->env[i], a, mmask + (long)i * M, pm, out + (long)i * M * 6);
+    }
+}
+void or_batch_job_mask_update(Batch *b, const int *job_action, int *cand, unsigned char *mask)
+{
+    for (int i = 0; i < b->B; i++) { int J = b->env[i]->h.J; or_job_mask_update(b->env[i], job_action[i], cand + (long)i * J, mask + (long)i * J); }
+}
+void or_batch_job_mask_state(Batch *b, int *cand, unsigned char *mask)
+{
+    for (int i = 0; i < b->B; i++) { int J = b->env[i]->h.J; or_job_mask_state(b->env[i], cand + (long)i * J, mask + (long)i * J); }
+}
+void or_batch_state(Batch *b, int *mach, unsigned char *sched, double *st, double *ft, int *routes, double *prev4, double *scaler17)
+{
+    for (int i = 0; i < b->B; i++) {
+        int T = b->env[i]->h.T, M = b->env[i]->h.M;
+        or_env_state(b->env[i], mach + (long)i * T, sched + (long)i * T, st + (long)i * T, ft + (long)i * T, routes + (long)i * M * T, prev4 + i * 4);
+        if (scaler17) or_scaler_state(b->env[i], scaler17 + i * 17);
+    }
+}
+void or_batch_valid_action_mask(Batch *b, unsigned char *mask)
+{
+    for (int i = 0; i < b->B; i++) { int T = b->env[i]->h.T; or_valid_action_mask(b->env[i], mask + (long)i * T); }
+}
