@@ -1,0 +1,168 @@
+"""DeviceBatchEnv — device-resident batch of MT-FJSP instances over the C ABI.
+
+torch is used ONLY as plumbing (device buffers + stream handle); every computation
+is a HIP kernel in libmtfjsp.so.  Method names follow the reference's
+trainer/parallel_env.py so the parity tests read like the reference's call sites.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+def shop_of_machine(edge):
+    """reference `edge` table [B,E,M/E] (machine ids per shop, generate…py:219-233) -> [B,M] shop index."""
+    edge = np.asarray(edge)
+    B, E, W = edge.shape
+    out = np.zeros((B, E * W), np.int32)
+    for e in range(E):
+        np.put_along_axis(out, edge[:, e, :].astype(np.int64), e, axis=1)
+    return out
+
+
+class DeviceBatchEnv:
+    def __init__(self, n_job, n_machine, n_edge, batch, left_shift=True, obs_dtype="f64", device=0,
+                 gamma=0.99, w_cfg=(0.4, 0.4, 0.2), scaling_divisor=1.0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("DeviceBatchEnv needs a GPU (MI355X); there is no CPU fallback")
+        self.L = capi.lib()
+        self.J, self.M, self.E, self.B = int(n_job), int(n_machine), int(n_edge), int(batch)
+        self.T = self.J * self.M
+        self.obs_f32 = obs_dtype in ("f32", torch.float32, np.float32)
+        self.device = torch.device("cuda", device)
+        cfg = capi.Config(self.J, self.M, self.E, self.B, int(bool(left_shift)), capi.OBS_F32 if self.obs_f32 else capi.OBS_F64,
+                          device, 0, gamma, w_cfg[0], w_cfg[1], w_cfg[2], scaling_divisor)
+        h = C.c_void_p()
+        capi.check(self.L.mtfjsp_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        odt = torch.float32 if self.obs_f32 else torch.float64
+        B, T, M, J = self.B, self.T, self.M, self.J
+        dev = self.device
+        # observation buffers are torch tensors so the rollout / PPO update can consume them zero-copy
+        self.tasks_fea = torch.zeros(B * T, 12, dtype=odt, device=dev)
+        self.ell_col = torch.full((B * T, 2), -1, dtype=torch.int32, device=dev)
+        self.ell_val = torch.zeros(B * T, 2, dtype=torch.float32, device=dev)
+        self.m_fea2 = torch.zeros(B, M, 8, dtype=odt, device=dev)
+        self.info = torch.zeros(B, 6, dtype=torch.float64, device=dev)
+        self.raw = torch.zeros(B, 5, dtype=torch.float64, device=dev)
+        self.candidate = torch.zeros(B, J, dtype=torch.int32, device=dev)
+        self.job_mask = torch.zeros(B, J, dtype=torch.uint8, device=dev)
+        self.status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.m_fea1 = torch.zeros(B, M, 6, dtype=odt, device=dev)
+        self.mmask = torch.zeros(B, M, dtype=torch.uint8, device=dev)
+        obs = capi.Obs(*[x.data_ptr() for x in (self.tasks_fea, self.ell_col, self.ell_val, self.m_fea2, self.info,
+                                                  self.raw, self.candidate, self.job_mask, self.status)])
+        capi.check(self.L.mtfjsp_bind_obs(self.h, C.byref(obs)), self.h)
+        self.use_current_stream()
+
+    def use_current_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        capi.check(self.L.mtfjsp_set_stream(self.h, C.c_void_p(s)), self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mtfjsp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- instances (= get_batch, pe:39-66)
+    def load_instances(self, t, p, tt, edge=None, shop=None):
+        t = np.ascontiguousarray(t, np.float64); p = np.ascontiguousarray(p, np.float64)
+        tt = np.ascontiguousarray(tt, np.float64)
+        assert t.shape == (self.B, self.T, self.M) and p.shape == t.shape and tt.shape == (self.B, self.M, self.M)
+        shop = shop_of_machine(edge) if shop is None else np.ascontiguousarray(shop, np.int32)
+        self._host_t = t
+        capi.check(self.L.mtfjsp_load_instances_host(self.h, t.ctypes.data, p.ctypes.data, tt.ctypes.data, shop.ctypes.data), self.h)
+
+    def load_instances_device(self, t, p, tt, shop):
+        for x in (t, p, tt):
+            assert x.is_cuda and x.dtype == torch.float64 and x.is_contiguous()
+        assert shop.dtype == torch.int32
+        capi.check(self.L.mtfjsp_load_instances(self.h, t.data_ptr(), p.data_ptr(), tt.data_ptr(), shop.data_ptr()), self.h)
+
+    def scaler_init(self):
+        capi.check(self.L.mtfjsp_scaler_init(self.h), self.h)
+
+    def scaler_reset_returns(self):
+        capi.check(self.L.mtfjsp_scaler_reset_returns(self.h), self.h)
+
+    def scaler_reset_returns_masked(self, mask):
+        m = np.ascontiguousarray(mask, np.uint8)
+        assert m.shape == (self.B,)
+        capi.check(self.L.mtfjsp_scaler_reset_returns_masked_host(self.h, m.ctypes.data), self.h)
+
+    # ---- reset / step
+    def reset(self, w3):
+        if torch.is_tensor(w3):
+            assert w3.is_cuda and w3.dtype == torch.float64 and w3.is_contiguous()
+            self._w3 = w3
+            capi.check(self.L.mtfjsp_reset(self.h, w3.data_ptr()), self.h)
+        else:
+            w3 = np.ascontiguousarray(w3, np.float64)
+            assert w3.shape == (self.B, 3)
+            capi.check(self.L.mtfjsp_reset_host(self.h, w3.ctypes.data), self.h)
+
+    def step(self, task_idx, mach_idx):
+        """device tensors (int32) -> asynchronous launch; numpy/list -> host variant (raises on invalid actions)."""
+        if torch.is_tensor(task_idx):
+            assert task_idx.is_cuda and task_idx.dtype == torch.int32 and mach_idx.dtype == torch.int32
+            capi.check(self.L.mtfjsp_step(self.h, task_idx.data_ptr(), mach_idx.data_ptr()), self.h)
+        else:
+            a = np.ascontiguousarray(task_idx, np.int32); m = np.ascontiguousarray(mach_idx, np.int32)
+            assert a.shape == (self.B,) and m.shape == (self.B,)
+            capi.check(self.L.mtfjsp_step_host(self.h, a.ctypes.data, m.ctypes.data), self.h)
+
+    def observe_mfea1(self, task_idx, mmask=None):
+        if not torch.is_tensor(task_idx):
+            task_idx = torch.as_tensor(np.ascontiguousarray(task_idx, np.int32), device=self.device)
+        mm = 0
+        if mmask is not None:
+            if not torch.is_tensor(mmask):
+                mmask = torch.as_tensor(np.ascontiguousarray(np.asarray(mmask).reshape(self.B, self.M), np.uint8), device=self.device)
+            mm = mmask.data_ptr()
+        self._keep = (task_idx, mmask)
+        capi.check(self.L.mtfjsp_observe_mfea1(self.h, task_idx.data_ptr(), mm, self.m_fea1.data_ptr(), self.mmask.data_ptr()), self.h)
+        return self.m_fea1
+
+    def random_actions(self, seed, counter, task_idx, mach_idx, job_idx=None):
+        capi.check(self.L.mtfjsp_random_actions(self.h, seed, counter, task_idx.data_ptr(), mach_idx.data_ptr(),
+                                                job_idx.data_ptr() if job_idx is not None else 0), self.h)
+
+    # ---- exports
+    def dense_adj(self):
+        out = torch.empty(self.B, self.T, self.T, dtype=torch.float64, device=self.device)
+        capi.check(self.L.mtfjsp_export_dense_adj(self.h, out.data_ptr()), self.h)
+        return out
+
+    def valid_action_mask(self):
+        out = torch.empty(self.B, self.T, dtype=torch.uint8, device=self.device)
+        capi.check(self.L.mtfjsp_valid_action_mask(self.h, out.data_ptr()), self.h)
+        return out
+
+    def read_state(self, which):
+        B, T, M = self.B, self.T, self.M
+        shape, dt = {capi.STATE_MACHINE: ((B, T), np.int32), capi.STATE_START: ((B, T), np.float64),
+                     capi.STATE_FINISH: ((B, T), np.float64), capi.STATE_ROUTES: ((B, M, T), np.int32),
+                     capi.STATE_PREV_COSTS: ((B, 4), np.float64), capi.STATE_SCALER: ((B, 17), np.float64),
+                     capi.STATE_W3: ((B, 3), np.float64)}[which]
+        out = np.zeros(shape, dt)
+        capi.check(self.L.mtfjsp_read_state_host(self.h, which, out.ctypes.data), self.h)
+        return out
+
+    def synchronize(self):
+        capi.check(self.L.mtfjsp_synchronize(self.h), self.h)
+
+    def timing_begin(self):
+        capi.check(self.L.mtfjsp_timing_begin(self.h), self.h)
+
+    def timing_end(self):
+        ms = C.c_double(); n = C.c_int64()
+        capi.check(self.L.mtfjsp_timing_end(self.h, C.byref(ms), C.byref(n)), self.h)
+        return ms.value, n.value

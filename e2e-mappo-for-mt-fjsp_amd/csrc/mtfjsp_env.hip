@@ -1,0 +1,1048 @@
+// mtfjsp_env.hip — batched MT-FJSP disjunctive-graph environment for MI355X (gfx950 / CDNA4).
+//
+// One 64-lane wavefront (= one 64-thread workgroup, so __syncthreads() is a wave-local
+// fence) owns one instance for the duration of a launch: the instance's whole
+// scheduling state is staged in LDS, lanes are tasks, and the step is
+//   A. left-shift scheduling decision  — gap search evaluated for all route positions in parallel
+//                                        (one ds_min on a (position,task) key), no linked-list walk
+//   B. cost update                     — ordered idle sum, per-job estimated-finish scan (job per lane),
+//                                        makespan max-reduce, numpy-order energy sum, rewards, Welford scaler
+//   C. observation                     — 12 task features + ≤2 in-edges per node (ELL form of adj_wrk),
+//                                        staged through LDS and written with 16-byte coalesced stores
+//   D. candidate / job mask            — derived from the same per-job counters as B
+// in ONE kernel launch (mtfjsp_step).  The graph is never materialised: with a simple digraph the
+// in-edges of node v are exactly {job predecessor, route predecessor}, and every edge weight the
+// reference stores is a closed form of (dur, st, ft, machine) of its two endpoints.
+//
+// Semantics follow the reference bit for bit (binary64, same operation order, no FMA contraction:
+// build with -ffp-contract=off).  "env:" = graph-jsp-env/src/graph_jsp_env/disjunctive_graph_jsp_env_singlestep.py,
+// "dg:" = trainer/DGenv_func.py, "pe:" = trainer/parallel_env.py, "pt:" = algorithm/ppo_trick.py,
+// "ppo:" = algorithm/ppo_algorithm.py.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/mtfjsp.h"
+
+#define WAVE 64
+#define SCAL_N 28          // doubles of per-instance scalar state
+// scalar slots
+#define S_MK_PREV 0
+#define S_E1_PREV 1
+#define S_TR_PREV 2
+#define S_ID_PREV 3
+#define S_TR_THIS 4
+#define S_W3 5             // 5,6,7
+#define S_R 8              // 8..11   RewardScaling.R
+#define S_MEAN 12          // 12..15
+#define S_S 16             // 16..19
+#define S_STD 20           // 20..23
+#define S_N 24             // RunningMeanStd.n
+#define S_NSCHED 25        // number of scheduled tasks
+
+struct __align__(8) Link { short mach, prev, pos, pad; };      // per task: machine (-1), route predecessor (-1), rank in route
+struct __align__(8) MRec { short head, tail, len, pad; };      // per machine
+
+struct EnvParams {
+    int B, J, M, T, left_shift, obs_f32;
+    double w_mk, w_ec, w_tt, divisor, gamma;
+    // instance constants
+    const double *t, *p, *tt;          // [B,T,M] [B,T,M] [B,M,M]
+    const double2 *cst;                // [B,T] {min_dur, min_pt}
+    // dynamic state
+    double *st, *ft, *dur, *psel;      // [B,T]
+    Link *link;                        // [B,T]
+    MRec *mrec;                        // [B,M]
+    double *mfea;                      // [B,M,8] f64 master copy of machines_fea
+    double *scal;                      // [B,SCAL_N]
+    // inputs
+    const int *task_idx, *mach_idx;    // [B]
+    const double *w3;                  // [B,3] (reset)
+    // outputs
+    mtfjsp_obs_t obs;
+};
+
+// ---------------------------------------------------------------------------------------------
+// numpy float64 add.reduce order: 0 + pairwise_sum (8 accumulators, 128-element leaf blocks).
+// env:896 np.sum(pt_est) and pe:176-183 np.mean use it; restated so e1/r_pt are bit-identical.
+__device__ __forceinline__ double pw_leaf(const double *a, int n)
+{
+    if (n < 8) {
+        double r = 0.0;
+        for (int i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    double r0 = a[0], r1 = a[1], r2 = a[2], r3 = a[3], r4 = a[4], r5 = a[5], r6 = a[6], r7 = a[7];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8) {
+        r0 += a[i]; r1 += a[i + 1]; r2 += a[i + 2]; r3 += a[i + 3];
+        r4 += a[i + 4]; r5 += a[i + 5]; r6 += a[i + 6]; r7 += a[i + 7];
+    }
+    double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+    for (; i < n; i++) res += a[i];
+    return res;
+}
+template <int DEPTH>
+__device__ __noinline__ double pw_sum(const double *a, int n)
+{
+    if (n <= 128) return pw_leaf(a, n);
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return pw_sum<DEPTH - 1>(a, n2) + pw_sum<DEPTH - 1>(a + n2, n - n2);
+}
+template <>
+__device__ __noinline__ double pw_sum<0>(const double *a, int n) { return pw_leaf(a, n); }
+__device__ __forceinline__ double np_sum(const double *a, int n) { return 0.0 + pw_sum<6>(a, n); }   // n <= 8192
+
+__device__ __forceinline__ long trunc_l(double x) { return (long)x; }   // numpy astype(int): toward zero
+
+// ---------------------------------------------------------------------------------------------
+// Fused reset / step kernel.  grid = B workgroups of 64 threads.
+template <bool RESET, typename OBS>
+__global__ __launch_bounds__(WAVE) void k_env(EnvParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int J = P.J, M = P.M, T = P.T;
+
+    // ---- LDS carve (doubles first, 16-B aligned stage, then ints)
+    double *s_st = reinterpret_cast<double *>(smem);
+    double *s_ft = s_st + T;
+    double *s_dur = s_ft + T;
+    double *s_psel = s_dur + T;
+    double *s_mind = s_psel + T;
+    double *s_minp = s_mind + T;
+    double *s_ste = s_minp + T;
+    double *s_fte = s_ste + T;
+    double *s_pte = s_fte + T;
+    double *s_term = s_pte + T;
+    double *s_tt = s_term + T;                 // M*M
+    double *s_mf = s_tt + M * M;               // M*8
+    double *s_rowmax = s_mf + M * 8;           // J   max finish time of scheduled ops per job
+    double *s_jmax = s_rowmax + J;             // J   max estimated finish per job
+    double *s_sc = s_jmax + J;                 // SCAL_N
+    double *s_r = s_sc + SCAL_N;               // 8: reward,r_mk,r_idle,r_pt,r_tt, idle_delta, new_tr, -
+    size_t off = (size_t)((10 * T + M * M + M * 8 + 2 * J + SCAL_N + 8) * sizeof(double));
+    off = (off + 15) & ~(size_t)15;
+    const int stage_rows = T < WAVE ? T : WAVE;
+    OBS *s_stage = reinterpret_cast<OBS *>(smem + off);
+    off += (size_t)stage_rows * 12 * sizeof(OBS);
+    off = (off + 15) & ~(size_t)15;
+    int *s_mach = reinterpret_cast<int *>(smem + off);
+    int *s_prev = s_mach + T;
+    int *s_pos = s_prev + T;
+    int *s_cnt = s_pos + T;                    // J scheduled ops per job
+    int *s_head = s_cnt + J;                   // M
+    int *s_tail = s_head + M;
+    int *s_len = s_tail + M;
+    int *s_mstart = s_len + M;                 // M+1
+    int *s_misc = s_mstart + M + 1;            // [0] best key
+
+    const size_t bT = (size_t)b * T;
+    // ---- stage the instance into LDS
+    for (int v = lane; v < T; v += WAVE) {
+        double2 c = P.cst[bT + v];
+        s_mind[v] = c.x; s_minp[v] = c.y;
+        if (RESET) {
+            s_st[v] = 0.0; s_ft[v] = 0.0; s_dur[v] = 0.0; s_psel[v] = 0.0;
+            s_mach[v] = -1; s_prev[v] = -1; s_pos[v] = 0;
+        } else {
+            s_st[v] = P.st[bT + v]; s_ft[v] = P.ft[bT + v]; s_dur[v] = P.dur[bT + v]; s_psel[v] = P.psel[bT + v];
+            Link l = P.link[bT + v];
+            s_mach[v] = l.mach; s_prev[v] = l.prev; s_pos[v] = l.pos;
+        }
+    }
+    for (int i = lane; i < M * M; i += WAVE) s_tt[i] = P.tt[(size_t)b * M * M + i];
+    for (int i = lane; i < M * 8; i += WAVE) {
+        if (RESET) {
+            int f = i & 7;
+            s_mf[i] = f >= 5 ? P.w3[b * 3 + (f - 5)] : 0.0;            // env:2343-2354
+        } else s_mf[i] = P.mfea[(size_t)b * M * 8 + i];
+    }
+    for (int i = lane; i < M; i += WAVE) {
+        if (RESET) { s_head[i] = -1; s_tail[i] = -1; s_len[i] = 0; }
+        else { MRec r = P.mrec[(size_t)b * M + i]; s_head[i] = r.head; s_tail[i] = r.tail; s_len[i] = r.len; }
+    }
+    if (lane < SCAL_N) {
+        double v = 0.0;
+        if (!RESET) v = P.scal[(size_t)b * SCAL_N + lane];
+        else if (lane >= S_R && lane <= S_N) v = P.scal[(size_t)b * SCAL_N + lane];     // the scaler survives resets (pe:70-85)
+        else if (lane >= S_W3 && lane < S_W3 + 3) v = P.w3[b * 3 + (lane - S_W3)];
+        s_sc[lane] = v;
+    }
+    if (lane == 0) s_misc[0] = 0x7fffffff;
+
+    int a = 0, m = 0, status = 0;
+    double d = 0.0, pk = 0.0;
+    bool valid = false;
+    if (!RESET) {
+        a = P.task_idx[b];
+        m = P.mach_idx[b];
+        bool in_range = a >= 0 && a < T && m >= 0 && m < M;
+        if (in_range) {
+            d = P.t[(bT + a) * M + m];
+            pk = P.p[(bT + a) * M + m];
+        }
+        valid = in_range;
+    }
+    __syncthreads();
+
+    // =========================================================================================
+    // A. scheduling (env:1476-1685)
+    int path = 0;
+    if (!RESET) {
+        const int op = valid ? a % M : 0;
+        if (valid) {
+            if (s_mach[a] >= 0) valid = false;                         // already scheduled (env:1504)
+            else if (op != 0 && s_mach[a - 1] < 0) valid = false;      // job predecessor unscheduled (env:1520)
+        }
+        if (valid) {
+            if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;               // pe:246-248
+            const double ttmm = s_tt[m * M + m];
+            // arrival over the single in-edge of the unscheduled node (job predecessor or src) (dg:46-66)
+            const double arr_k = op == 0 ? 0.0 : s_ft[a - 1] + s_tt[s_mach[a - 1] * M + m];
+            const int len = s_len[m], head = s_head[m], tail = s_tail[m];
+            double st_k;
+            int ipos, Pk, Nk = -1;
+            bool do_append = false;
+            if (len == 0) { path = MTFJSP_PATH_EMPTY; st_k = arr_k; ipos = 0; Pk = -1; }                 // env:1684
+            else if (!P.left_shift) do_append = true;                                                     // env:1680
+            else {
+                const double lb_ft = arr_k + d;
+                const double arr_f = (head % M == 0) ? 0.0 : s_ft[head - 1] + s_tt[s_mach[head - 1] * M + m];
+                if (lb_ft <= arr_f) { path = MTFJSP_PATH_FRONT; st_k = arr_k; ipos = 0; Pk = -1; Nk = head; }   // env:1548
+                else if (len == 1) do_append = true;                                                     // env:1577
+                else {
+                    // gap search over all consecutive (P,N) of the route at once (env:1587-1604)
+                    int key = 0x7fffffff;
+                    for (int v = lane; v < T; v += WAVE) {
+                        if (s_mach[v] == m && s_prev[v] >= 0) {
+                            const int Pp = s_prev[v];
+                            const double ja = (v % M == 0) ? 0.0 : s_ft[v - 1] + s_tt[s_mach[v - 1] * M + m];
+                            const double x = (Pp / M == v / M) ? ttmm : 0.0;
+                            const double nst = fmax(ja, s_ft[Pp] + x);            // arrival(N) over its current in-edges
+                            const bool ok = !(lb_ft > nst) && !((nst - s_ft[Pp]) < d);
+                            if (ok) { int kk = (s_pos[v] << 16) | v; key = kk < key ? kk : key; }
+                        }
+                    }
+                    if (key != 0x7fffffff) atomicMin(&s_misc[0], key);
+                    __syncthreads();
+                    const int best = s_misc[0];
+                    if (best != 0x7fffffff) {
+                        path = MTFJSP_PATH_BETWEEN;
+                        Nk = best & 0xffff; ipos = best >> 16; Pk = s_prev[Nk];
+                        const double x = (Pk / M == a / M) ? ttmm : 0.0;
+                        st_k = fmax(arr_k, s_ft[Pk] + x);                          // env:1619
+                    } else do_append = true;                                       // env:1676
+                }
+            }
+            if (do_append) {                                                       // env:1689-1775
+                path = MTFJSP_PATH_APPEND;
+                const double x = (tail / M == a / M) ? ttmm : 0.0;
+                st_k = fmax(arr_k, s_ft[tail] + x);
+                ipos = len; Pk = tail;
+            }
+            const double ft_k = st_k + d;
+            __syncthreads();
+            // apply: shift ranks behind the insertion point, then write task k and its neighbours
+            for (int v = lane; v < T; v += WAVE)
+                if (s_mach[v] == m && s_pos[v] >= ipos) s_pos[v] += 1;
+            __syncthreads();
+            if (lane == 0) {
+                s_mach[a] = m; s_prev[a] = Pk; s_pos[a] = ipos;
+                s_st[a] = st_k; s_ft[a] = ft_k; s_dur[a] = d; s_psel[a] = pk;
+                if (Nk >= 0) s_prev[Nk] = a;
+                if (ipos == 0) s_head[m] = a;
+                if (ipos == len) s_tail[m] = a;
+                s_len[m] = len + 1;
+                s_sc[S_NSCHED] += 1.0;
+            }
+            status |= path;
+        } else {
+            status |= MTFJSP_ST_INVALID;
+        }
+        __syncthreads();
+    }
+
+    // =========================================================================================
+    // B. costs
+    // per-job sequential pass: estimated start/finish/energy (env:1920-1999), scheduled count,
+    // max finish time of scheduled ops (ppo:265-275).  Exact left-to-right adds (job per lane).
+    for (int j = lane; j < J; j += WAVE) {
+        double fe_prev = 0.0, rmax = 0.0, jmax = 0.0;
+        int cnt = 0;
+        for (int c = 0; c < M; c++) {
+            const int v = j * M + c;
+            const bool s = s_mach[v] >= 0;
+            const double bf = s ? s_ft[v] : 0.0;
+            double fe;
+            if (bf == 0.0) fe = (c ? fe_prev : 0.0) + s_mind[v];      // "ft*scheduled == 0" test of env:1968
+            else fe = bf;
+            s_ste[v] = s ? s_st[v] : (c ? fe_prev : 0.0);
+            s_fte[v] = fe;
+            s_pte[v] = s ? s_dur[v] * s_psel[v] : s_minp[v];          // t*p of the chosen machine (env:356,2175)
+            const double f0 = s ? s_ft[v] : 0.0;
+            if (c == 0 || f0 > rmax) rmax = f0;
+            if (c == 0 || fe > jmax) jmax = fe;
+            cnt += s ? 1 : 0;
+            fe_prev = fe;
+        }
+        s_rowmax[j] = rmax; s_jmax[j] = jmax; s_cnt[j] = cnt;
+    }
+    if (lane == 0) {
+        int acc = 0;
+        for (int i = 0; i < M; i++) { s_mstart[i] = acc; acc += s_len[i]; }
+        s_mstart[M] = acc;
+    }
+    __syncthreads();
+    // idle-time terms in (machine, route position) order (dg:144-170)
+    for (int v = lane; v < T; v += WAVE)
+        if (s_mach[v] >= 0) {
+            const int pr = s_prev[v];
+            s_term[s_mstart[s_mach[v]] + s_pos[v]] = pr < 0 ? s_st[v] : s_st[v] - s_ft[pr];
+        }
+    __syncthreads();
+
+    bool done = false;
+    if (lane == 0) {
+        double mk = s_jmax[0];
+        for (int j = 1; j < J; j++) mk = s_jmax[j] > mk ? s_jmax[j] : mk;              // env:894 np.amax
+        const double e1 = np_sum(s_pte, T);                                              // env:896 np.sum
+        if (RESET) {
+            s_sc[S_MK_PREV] = mk; s_sc[S_E1_PREV] = e1; s_sc[S_TR_PREV] = 0.0; s_sc[S_ID_PREV] = 0.0;   // env:683-705
+            s_sc[S_TR_THIS] = 0.0; s_sc[S_NSCHED] = 0.0;
+            for (int i = 0; i < 8; i++) s_r[i] = 0.0;
+        } else if (valid) {
+            const int nsched = s_mstart[M];
+            double idle = 0.0;
+            for (int i = 0; i < nsched; i++) idle = idle + s_term[i];                    // same order as dg:147-168
+            const double new_tr = (a % M == 0) ? 0.0 : s_tt[s_mach[a - 1] * M + m];      // env:872-876
+            const double trans_this = s_sc[S_TR_THIS] + new_tr;
+            const double mk_prev = s_sc[S_MK_PREV], e1_prev = s_sc[S_E1_PREV];
+            const double tr_prev = s_sc[S_TR_PREV], id_prev = s_sc[S_ID_PREV];
+            const double r_t = 1.0 * mk_prev - mk;                                       // env:1066
+            double r_pt = 1.0 * e1_prev - e1;
+            r_pt = r_pt / (double)T;                                                     // env:1073-1076
+            const double r_tt = 1.0 * tr_prev - trans_this;                              // env:1083
+            const double r_idle = 1.0 * id_prev - idle;                                  // env:1088
+            const double tot = P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1;   // env:1164
+            s_r[0] = tot / P.divisor; s_r[1] = r_t; s_r[2] = r_idle; s_r[3] = r_pt; s_r[4] = r_tt;
+            s_r[5] = idle - id_prev; s_r[6] = new_tr;
+            done = nsched == T;                                                          // env:797-800
+            s_sc[S_MK_PREV] = mk; s_sc[S_E1_PREV] = e1; s_sc[S_TR_PREV] = trans_this; s_sc[S_ID_PREV] = idle;   // env:932-936
+            s_sc[S_TR_THIS] = done ? 0.0 : trans_this;                                   // env:950-960
+            // machine features of the acting machine (env:2315-2340)
+            double *row = s_mf + m * 8;
+            row[0] = s_ft[s_tail[m]];
+            row[1] += (pk * d) / (double)T;
+            row[2] += new_tr;
+            row[3] += s_r[5];
+            row[4] += 1;
+            s_r[7] = done ? 1.0 : 0.0;
+        } else {
+            for (int i = 0; i < 8; i++) s_r[i] = 0.0;
+            s_r[7] = (s_mstart[M] == T) ? 1.0 : 0.0;
+        }
+    }
+    __syncthreads();
+    // reward scaling, one channel per lane (pt:54-83,108-124; pe:255-260)
+    if (!RESET && lane < 4 && valid) {
+        const double x = s_r[1 + lane];
+        const double n = s_sc[S_N] + 1.0;
+        const double R = P.gamma * s_sc[S_R + lane] + x;
+        double mean, S = s_sc[S_S + lane], sd;
+        if (n == 1.0) { mean = R; sd = fabs(R); }
+        else {
+            const double old = s_sc[S_MEAN + lane];
+            mean = old + (R - old) / n;
+            S = S + (R - old) * (R - mean);
+            sd = sqrt(S / n);
+        }
+        const double scaled = x / (sd + 1e-8);
+        s_sc[S_R + lane] = R; s_sc[S_MEAN + lane] = mean; s_sc[S_S + lane] = S; s_sc[S_STD + lane] = sd;
+        P.obs.info[(size_t)b * 6 + 2 + lane] = scaled;
+    }
+    if (!RESET && lane == 4) {
+        if (valid) {
+            P.obs.info[(size_t)b * 6 + 0] = s_r[0];
+            P.obs.info[(size_t)b * 6 + 1] = s_r[7];
+        } else {
+            for (int i = 0; i < 6; i++) P.obs.info[(size_t)b * 6 + i] = i == 1 ? s_r[7] : 0.0;
+        }
+        if (P.obs.raw) for (int i = 0; i < 5; i++) P.obs.raw[(size_t)b * 5 + i] = s_r[i];
+    }
+    if (RESET && lane < 6) P.obs.info[(size_t)b * 6 + lane] = 0.0;
+    if (RESET && lane < 5 && P.obs.raw) P.obs.raw[(size_t)b * 5 + lane] = 0.0;
+    if (lane == 5) P.obs.status[b] = status;
+    __syncthreads();
+    if (!RESET && valid && lane == 0) s_sc[S_N] += 1.0;
+
+    // =========================================================================================
+    // C. observation (env:2001-2515)
+    const double w30 = s_sc[S_W3], w31 = s_sc[S_W3 + 1], w32 = s_sc[S_W3 + 2];
+    for (int c0 = 0; c0 < T; c0 += WAVE) {
+        const int v = c0 + lane;
+        const int rows = (T - c0) < WAVE ? (T - c0) : WAVE;
+        if (v < T) {
+            const int mv = s_mach[v];
+            const bool s = mv >= 0;
+            const int opv = v % M;
+            const int pr = s_prev[v];
+            const bool merged = pr >= 0 && opv != 0 && pr == v - 1;          // route predecessor == job predecessor: ONE edge
+            // ---- in-edges -> ELL slots
+            int c_job = -1, c_mch = -1;
+            float a_job = 0.f, a_mch = 0.f;
+            if (opv != 0) {
+                const int u = v - 1;
+                const int mu = s_mach[u];
+                double w, nd;
+                if (mu < 0) { w = 1.0; nd = 1.0; }                           // never refreshed: initial weight 1 (env:617-644)
+                else {
+                    nd = s_dur[u];
+                    if (merged && !RESET && v == a && valid) {
+                        // machine edge written AFTER this step's refresh wins (env:1607-1675,1703-1765)
+                        const double x = s_tt[mu * M + mv];
+                        w = s_dur[u] + x + (s_st[v] - s_ft[u]);
+                    } else {
+                        const double x = s ? s_tt[mu * M + mv] : 0.0;        // env:1384-1422 job-edge refresh
+                        w = s_dur[u] + x;
+                    }
+                }
+                long A = trunc_l(w);                                          // env:2019 astype(int)
+                if (A != 0) {
+                    A = trunc_l((double)A - nd) + 1;                          // env:2060-2062 (int-array item assignment)
+                    c_job = u; a_job = (float)A;
+                }
+            }
+            if (pr >= 0 && !merged) {
+                const double x = (pr / M == v / M) ? s_tt[s_mach[pr] * M + mv] : 0.0;
+                const double w = s_dur[pr] + x + (s_st[v] - s_ft[pr]);
+                long A = trunc_l(w);
+                if (A != 0) {
+                    A = trunc_l((double)A - s_dur[pr]) + 1;
+                    c_mch = pr; a_mch = (float)A;
+                }
+            }
+            reinterpret_cast<int2 *>(P.obs.ell_col)[bT + v] = make_int2(c_job, c_mch);
+            reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(a_job, a_mch);
+            // ---- 12 task features (env:2245-2277)
+            OBS *f = s_stage + lane * 12;
+            f[0] = (OBS)s_ste[v]; f[1] = (OBS)s_fte[v]; f[2] = (OBS)s_pte[v];
+            f[3] = (OBS)(s ? 1.0 : 0.0);
+            f[4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));                // len(G.in_edges): src/job edge + machine edge
+            f[5] = (OBS)(s ? mv + 1 : 0);
+            f[6] = (OBS)(s ? s_dur[v] : 0.0);
+            f[7] = (OBS)(s ? s_psel[v] : 0.0);
+            f[8] = (OBS)(v / M + 1);
+            f[9] = (OBS)w30; f[10] = (OBS)w31; f[11] = (OBS)w32;
+        }
+        __syncthreads();
+        {   // coalesced 16-byte copy-out of rows [c0, c0+rows)
+            const int n16 = rows * 12 * (int)sizeof(OBS) / 16;
+            const uint4 *src = reinterpret_cast<const uint4 *>(s_stage);
+            uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + c0) * 12);
+            for (int i = lane; i < n16; i += WAVE) dst[i] = src[i];
+        }
+        __syncthreads();
+    }
+    for (int i = lane; i < M * 8; i += WAVE)
+        reinterpret_cast<OBS *>(P.obs.m_fea2)[(size_t)b * M * 8 + i] = (OBS)s_mf[i];
+
+    // =========================================================================================
+    // D. candidate + job mask (ppo:202-316), from the per-job counters
+    {
+        int cmin = M;
+        for (int j = 0; j < J; j++) cmin = s_cnt[j] < cmin ? s_cnt[j] : cmin;
+        double mn = INFINITY;
+        if (cmin > 0 && cmin < M)
+            for (int j = 0; j < J; j++) {
+                const double r = s_cnt[j] == M ? INFINITY : s_rowmax[j];
+                mn = r < mn ? r : mn;
+            }
+        for (int j = lane; j < J; j += WAVE) {
+            const int cnt = s_cnt[j];
+            unsigned char mk;
+            if (cmin == 0) mk = cnt >= 1;                                    // column 0 not full: mask = scheduled[:,0]
+            else if (cmin == M) mk = 1;                                      // everything scheduled
+            else mk = !((cnt == M ? INFINITY : s_rowmax[j]) == mn);          // only the earliest-finishing jobs
+            P.obs.job_mask[(size_t)b * J + j] = mk;
+            P.obs.candidate[(size_t)b * J + j] = j * M + (cnt < M ? cnt : M - 1);
+        }
+    }
+
+    // =========================================================================================
+    // write back the state that changed
+    if (RESET || valid) {
+        for (int v = lane; v < T; v += WAVE) {
+            Link l; l.mach = (short)s_mach[v]; l.prev = (short)s_prev[v]; l.pos = (short)s_pos[v]; l.pad = 0;
+            P.link[bT + v] = l;
+            if (RESET) { P.st[bT + v] = 0.0; P.ft[bT + v] = 0.0; P.dur[bT + v] = 0.0; P.psel[bT + v] = 0.0; }
+        }
+        if (!RESET && lane == 0) { P.st[bT + a] = s_st[a]; P.ft[bT + a] = s_ft[a]; P.dur[bT + a] = s_dur[a]; P.psel[bT + a] = s_psel[a]; }
+        for (int i = lane; i < M; i += WAVE) {
+            MRec r; r.head = (short)s_head[i]; r.tail = (short)s_tail[i]; r.len = (short)s_len[i]; r.pad = 0;
+            P.mrec[(size_t)b * M + i] = r;
+        }
+        if (RESET) { for (int i = lane; i < M * 8; i += WAVE) P.mfea[(size_t)b * M * 8 + i] = s_mf[i]; }
+        else if (lane < 8) P.mfea[((size_t)b * M + m) * 8 + lane] = s_mf[m * 8 + lane];
+        if (lane < SCAL_N) P.scal[(size_t)b * SCAL_N + lane] = s_sc[lane];
+    }
+}
+
+static size_t env_lds_bytes(int J, int M, int T, bool f32)
+{
+    size_t off = (size_t)(10 * T + M * M + M * 8 + 2 * J + SCAL_N + 8) * sizeof(double);
+    off = (off + 15) & ~(size_t)15;
+    int rows = T < WAVE ? T : WAVE;
+    off += (size_t)rows * 12 * (f32 ? 4 : 8);
+    off = (off + 15) & ~(size_t)15;
+    off += (size_t)(3 * T + J + 4 * M + 1 + 4) * sizeof(int);
+    return off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// instance preparation: min_dur/min_pt (env:1932-1950) and the means of pe:176-183. thread = (b,task)
+__global__ void k_prepare(int B, int T, int M, const double *t, const double *p, double2 *cst, double *mean3)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const double *tr = t + (size_t)i * M, *pr = p + (size_t)i * M;
+    double md = INFINITY, mp = INFINITY;
+    double bt[64], bpt[64], bp[64];
+    int nt = 0, npt = 0, np_ = 0;
+    for (int m = 0; m < M; m++) {
+        const double tv = tr[m], pv = pr[m];
+        const double q = tv * fabs(pv);
+        const double dd = tv < 0 ? INFINITY : tv;
+        const double qq = q < 0 ? INFINITY : q;
+        md = dd < md ? dd : md;
+        mp = qq < mp ? qq : mp;
+        if (tv > 0) bt[nt++] = tv;
+        if (q > 0) bpt[npt++] = q;
+        if (pv > 0) bp[np_++] = pv;
+    }
+    cst[i] = make_double2(md, mp);
+    mean3[(size_t)i * 3 + 0] = np_sum(bt, nt) / (double)nt;
+    mean3[(size_t)i * 3 + 1] = np_sum(bpt, npt) / (double)npt;
+    mean3[(size_t)i * 3 + 2] = np_sum(bp, np_) / (double)np_;
+}
+
+// m_fea1 (pe:152-214): thread = (b, machine)
+template <typename OBS>
+__global__ void k_mfea1(int B, int T, int M, const double *t, const double *p, const double *tt, const double *mean3,
+                        const int *shop, const Link *link, const int *task_idx, const uint8_t *mmask_in, OBS *out,
+                        uint8_t *mmask_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * M) return;
+    const int b = i / M, m = i % M;
+    int a = task_idx[b];
+    if (a < 0 || a >= T) a = 0;
+    const size_t row = ((size_t)b * T + a);
+    const double tv = t[row * M + m], pv = p[row * M + m];
+    const double ptv = tv * fabs(pv);
+    const uint8_t mk = mmask_in ? mmask_in[i] : (uint8_t)!(tv >= 0);          // run:258-259 ~(t >= 0)
+    double x = 0.0;
+    if (a % M != 0) {
+        int pm = link[row - 1].mach;                                          // == tasks_fea[a-1][5] - 1 (pe:206)
+        if (pm < 0) pm += M;                                                  // python negative index on an unscheduled predecessor
+        x = tt[((size_t)b * M + pm) * M + m];
+    }
+    OBS *o = out + (size_t)i * 6;
+    o[0] = (OBS)(tv > 0 ? tv : mean3[row * 3 + 0]);
+    o[1] = (OBS)(ptv > 0 ? ptv : mean3[row * 3 + 1]);
+    o[2] = (OBS)x;
+    o[3] = (OBS)(1 - (int)mk);
+    o[4] = (OBS)(pv > 0 ? pv : mean3[row * 3 + 2]);
+    o[5] = (OBS)(shop[i] + 1);
+    if (mmask_out) mmask_out[i] = mk;
+}
+
+// dense adj_wrk export (compat path, pe:136): thread = (b, dst task); out must be zero-filled first
+__global__ void k_dense_adj(int B, int T, const int *ell_col, const float *ell_val, double *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int v = i % T;
+    double *row = out + (size_t)i * T;
+    row[v] = 1.0;
+    for (int s = 0; s < 2; s++) {
+        const int c = ell_col[(size_t)i * 2 + s];
+        if (c >= 0) row[c] += (double)ell_val[(size_t)i * 2 + s];
+    }
+}
+
+// env.valid_action_mask (env:2535-2575): thread = (b, task)
+__global__ void k_valid_mask(int B, int T, int M, const Link *link, uint8_t *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    const int v = i % T;
+    bool ok = link[i].mach < 0 && (v % M == 0 || link[i - 1].mach >= 0);
+    out[i] = ok;
+}
+
+// Philox4x32-10 (counter-based; Salmon et al. 2011)
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// uniform random valid action per instance: thread = instance
+__global__ void k_random_actions(int B, int J, int M, int T, const double *t, const int *cand, const uint8_t *jmask,
+                                 uint64_t seed, uint64_t counter, int *task_idx, int *mach_idx, int *job_idx)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)counter, (uint32_t)(counter >> 32), 0x6d746a73u};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    int n = 0;
+    for (int j = 0; j < J; j++) n += jmask[(size_t)b * J + j] ? 0 : 1;
+    int a = 0, jj = 0;
+    if (n > 0) {
+        int pick = (int)(((uint64_t)c[0] * (uint64_t)n) >> 32);
+        for (int j = 0; j < J; j++)
+            if (!jmask[(size_t)b * J + j]) { if (pick == 0) { jj = j; break; } pick--; }
+        a = cand[(size_t)b * J + jj];
+    }
+    const double *tr = t + ((size_t)b * T + a) * M;
+    int nf = 0;
+    for (int m = 0; m < M; m++) nf += tr[m] >= 0 ? 1 : 0;
+    int mm = 0;
+    if (nf > 0) {
+        int pick = (int)(((uint64_t)c[1] * (uint64_t)nf) >> 32);
+        for (int m = 0; m < M; m++)
+            if (tr[m] >= 0) { if (pick == 0) { mm = m; break; } pick--; }
+    }
+    task_idx[b] = a; mach_idx[b] = mm;
+    if (job_idx) job_idx[b] = jj;
+}
+
+// scaler init / per-episode reset (pe:70-85, pt:123)
+__global__ void k_scaler(int B, int full, double *scal, const uint8_t *mask)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    if (mask && !mask[b]) return;
+    double *s = scal + (size_t)b * SCAL_N;
+    for (int i = 0; i < 4; i++) s[S_R + i] = 0.0;
+    if (full) { for (int i = 0; i < 4; i++) { s[S_MEAN + i] = 0.0; s[S_S + i] = 0.0; s[S_STD + i] = 0.0; } s[S_N] = 0.0; }
+}
+
+// =================================================================================================
+// host side
+struct mtfjsp_env {
+    mtfjsp_config_t cfg;
+    int T;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool loaded = false, was_reset = false;
+    // device memory
+    double *t = nullptr, *p = nullptr, *tt = nullptr, *mean3 = nullptr;
+    double2 *cst = nullptr;
+    int *shop = nullptr;
+    double *st = nullptr, *ft = nullptr, *dur = nullptr, *psel = nullptr, *mfea = nullptr, *scal = nullptr;
+    Link *link = nullptr;
+    MRec *mrec = nullptr;
+    int *d_task = nullptr, *d_mach = nullptr;
+    double *d_w3 = nullptr;
+    mtfjsp_obs_t obs{};
+    bool obs_bound = false;
+    std::vector<void *> owned;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    size_t ev_used = 0;
+};
+
+static thread_local std::string g_create_err;
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return MTFJSP_ERR_HIP;                                                              \
+        }                                                                                       \
+    } while (0)
+
+template <typename Tp>
+static int dalloc(mtfjsp_env *h, Tp **ptr, size_t n)
+{
+    HIPCHK(h, hipMalloc((void **)ptr, n * sizeof(Tp)));
+    h->owned.push_back(*ptr);
+    return 0;
+}
+
+extern "C" const char *mtfjsp_last_error(mtfjsp_handle_t h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
+{
+    if (!cfg || !out) { g_create_err = "null argument"; return MTFJSP_ERR_ARG; }
+    if (cfg->n_job < 1 || cfg->n_machine < 2 || cfg->n_machine > 64 || cfg->batch < 1 ||
+        (long)cfg->n_job * cfg->n_machine > 32767 || (cfg->obs_dtype != MTFJSP_OBS_F64 && cfg->obs_dtype != MTFJSP_OBS_F32) ||
+        cfg->scaling_divisor == 0.0) {
+        g_create_err = "bad configuration (need n_job>=1, 2<=n_machine<=64, n_job*n_machine<=32767, batch>=1, divisor!=0)";
+        return MTFJSP_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device available"; return MTFJSP_ERR_HIP; }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) { g_create_err = "device_id out of range"; return MTFJSP_ERR_ARG; }
+    if (hipSetDevice(cfg->device_id) != hipSuccess) { g_create_err = "hipSetDevice failed"; return MTFJSP_ERR_HIP; }
+    mtfjsp_env *h = new mtfjsp_env();
+    h->cfg = *cfg;
+    h->T = cfg->n_job * cfg->n_machine;
+    const size_t B = cfg->batch, T = h->T, M = cfg->n_machine;
+    size_t lds = env_lds_bytes(cfg->n_job, cfg->n_machine, h->T, cfg->obs_dtype == MTFJSP_OBS_F32);
+    if (lds > 160 * 1024) { g_create_err = "instance too large for one CU's LDS"; delete h; return MTFJSP_ERR_ARG; }
+    int rc = 0;
+    rc |= dalloc(h, &h->t, B * T * M); rc |= dalloc(h, &h->p, B * T * M); rc |= dalloc(h, &h->tt, B * M * M);
+    rc |= dalloc(h, &h->mean3, B * T * 3); rc |= dalloc(h, &h->cst, B * T); rc |= dalloc(h, &h->shop, B * M);
+    rc |= dalloc(h, &h->st, B * T); rc |= dalloc(h, &h->ft, B * T); rc |= dalloc(h, &h->dur, B * T); rc |= dalloc(h, &h->psel, B * T);
+    rc |= dalloc(h, &h->mfea, B * M * 8); rc |= dalloc(h, &h->scal, B * SCAL_N);
+    rc |= dalloc(h, &h->link, B * T); rc |= dalloc(h, &h->mrec, B * M);
+    rc |= dalloc(h, &h->d_task, B); rc |= dalloc(h, &h->d_mach, B); rc |= dalloc(h, &h->d_w3, B * 3);
+    if (rc) { g_create_err = h->err; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
+    if (hipMemset(h->scal, 0, B * SCAL_N * sizeof(double)) != hipSuccess) { g_create_err = "memset failed"; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
+    // opt in to large dynamic LDS
+    (void)hipFuncSetAttribute((const void *)k_env<false, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_env<true, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_env<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_env<true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    *out = h;
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_destroy(mtfjsp_handle_t h)
+{
+    if (!h) return MTFJSP_OK;
+    (void)hipSetDevice(h->cfg.device_id);
+    (void)hipDeviceSynchronize();
+    for (void *p : h->owned) (void)hipFree(p);
+    for (auto &e : h->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete h;
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_set_stream(mtfjsp_handle_t h, void *s) { if (!h) return MTFJSP_ERR_ARG; h->stream = (hipStream_t)s; return MTFJSP_OK; }
+extern "C" int mtfjsp_synchronize(mtfjsp_handle_t h) { if (!h) return MTFJSP_ERR_ARG; HIPCHK(h, hipStreamSynchronize(h->stream)); return MTFJSP_OK; }
+
+extern "C" int mtfjsp_alloc_obs(mtfjsp_handle_t h, mtfjsp_obs_t *out)
+{
+    if (!h || !out) return MTFJSP_ERR_ARG;
+    const size_t B = h->cfg.batch, T = h->T, M = h->cfg.n_machine, J = h->cfg.n_job;
+    const size_t es = h->cfg.obs_dtype == MTFJSP_OBS_F32 ? 4 : 8;
+    mtfjsp_obs_t o{};
+    unsigned char *tf, *mf;
+    if (dalloc(h, &tf, B * T * 12 * es) || dalloc(h, &mf, B * M * 8 * es) || dalloc(h, &o.ell_col, B * T * 2) ||
+        dalloc(h, &o.ell_val, B * T * 2) || dalloc(h, &o.info, B * 6) || dalloc(h, &o.raw, B * 5) ||
+        dalloc(h, &o.candidate, B * J) || dalloc(h, &o.job_mask, B * J) || dalloc(h, &o.status, B))
+        return MTFJSP_ERR_HIP;
+    o.tasks_fea = tf; o.m_fea2 = mf;
+    *out = o;
+    return mtfjsp_bind_obs(h, &o);
+}
+
+extern "C" int mtfjsp_bind_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *o)
+{
+    if (!h || !o) return MTFJSP_ERR_ARG;
+    if (!o->tasks_fea || !o->ell_col || !o->ell_val || !o->m_fea2 || !o->info || !o->candidate || !o->job_mask || !o->status) {
+        h->err = "bind_obs: every field except raw must be non-NULL"; return MTFJSP_ERR_ARG;
+    }
+    h->obs = *o; h->obs_bound = true;
+    return MTFJSP_OK;
+}
+
+static int load_common(mtfjsp_env *h, const double *t, const double *p, const double *tt, const int32_t *shop, hipMemcpyKind kind)
+{
+    const size_t B = h->cfg.batch, T = h->T, M = h->cfg.n_machine;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipMemcpyAsync(h->t, t, B * T * M * 8, kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->p, p, B * T * M * 8, kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->tt, tt, B * M * M * 8, kind, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->shop, shop, B * M * 4, kind, h->stream));
+    const int n = (int)(B * T);
+    hipLaunchKernelGGL(k_prepare, dim3((n + 127) / 128), dim3(128), 0, h->stream, (int)B, (int)T, (int)M, h->t, h->p, h->cst, h->mean3);
+    HIPCHK(h, hipGetLastError());
+    if (kind == hipMemcpyHostToDevice) HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->loaded = true; h->was_reset = false;
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_load_instances(mtfjsp_handle_t h, const double *t, const double *p, const double *tt, const int32_t *shop)
+{
+    if (!h || !t || !p || !tt || !shop) return MTFJSP_ERR_ARG;
+    return load_common(h, t, p, tt, shop, hipMemcpyDeviceToDevice);
+}
+extern "C" int mtfjsp_load_instances_host(mtfjsp_handle_t h, const double *t, const double *p, const double *tt, const int32_t *shop)
+{
+    if (!h || !t || !p || !tt || !shop) return MTFJSP_ERR_ARG;
+    return load_common(h, t, p, tt, shop, hipMemcpyHostToDevice);
+}
+
+static int scaler_launch(mtfjsp_env *h, int full, const uint8_t *mask = nullptr)
+{
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    hipLaunchKernelGGL(k_scaler, dim3((h->cfg.batch + 127) / 128), dim3(128), 0, h->stream, h->cfg.batch, full, h->scal, mask);
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_scaler_init(mtfjsp_handle_t h) { return h ? scaler_launch(h, 1) : MTFJSP_ERR_ARG; }
+extern "C" int mtfjsp_scaler_reset_returns(mtfjsp_handle_t h) { return h ? scaler_launch(h, 0) : MTFJSP_ERR_ARG; }
+extern "C" int mtfjsp_scaler_reset_returns_masked_host(mtfjsp_handle_t h, const uint8_t *mask_host)
+{
+    if (!h || !mask_host) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    uint8_t *dm = reinterpret_cast<uint8_t *>(h->d_task);            // scratch: B int32 >= B bytes
+    HIPCHK(h, hipMemcpyAsync(dm, mask_host, (size_t)h->cfg.batch, hipMemcpyHostToDevice, h->stream));
+    int rc = scaler_launch(h, 0, dm);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MTFJSP_OK;
+}
+
+static EnvParams make_params(mtfjsp_env *h)
+{
+    EnvParams P{};
+    P.B = h->cfg.batch; P.J = h->cfg.n_job; P.M = h->cfg.n_machine; P.T = h->T;
+    P.left_shift = h->cfg.left_shift; P.obs_f32 = h->cfg.obs_dtype == MTFJSP_OBS_F32;
+    P.w_mk = h->cfg.w_mk; P.w_ec = h->cfg.w_ec; P.w_tt = h->cfg.w_tt; P.divisor = h->cfg.scaling_divisor; P.gamma = h->cfg.gamma;
+    P.t = h->t; P.p = h->p; P.tt = h->tt; P.cst = h->cst;
+    P.st = h->st; P.ft = h->ft; P.dur = h->dur; P.psel = h->psel; P.link = h->link; P.mrec = h->mrec; P.mfea = h->mfea; P.scal = h->scal;
+    P.obs = h->obs;
+    return P;
+}
+
+static int check_ready(mtfjsp_env *h, bool need_reset)
+{
+    if (!h->loaded) { h->err = "load_instances has not been called"; return MTFJSP_ERR_STATE; }
+    if (!h->obs_bound) { h->err = "no observation buffers bound (mtfjsp_alloc_obs / mtfjsp_bind_obs)"; return MTFJSP_ERR_STATE; }
+    if (need_reset && !h->was_reset) { h->err = "reset has not been called"; return MTFJSP_ERR_STATE; }
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_reset(mtfjsp_handle_t h, const double *w3)
+{
+    if (!h || !w3) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    EnvParams P = make_params(h);
+    P.w3 = w3;
+    const size_t lds = env_lds_bytes(P.J, P.M, P.T, P.obs_f32);
+    if (P.obs_f32) hipLaunchKernelGGL((k_env<true, float>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
+    else hipLaunchKernelGGL((k_env<true, double>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    h->was_reset = true;
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_reset_host(mtfjsp_handle_t h, const double *w3_host)
+{
+    if (!h || !w3_host) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipMemcpyAsync(h->d_w3, w3_host, (size_t)h->cfg.batch * 3 * 8, hipMemcpyHostToDevice, h->stream));
+    int rc = mtfjsp_reset(h, h->d_w3);
+    if (rc) return rc;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_step(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx)
+{
+    if (!h || !task_idx || !mach_idx) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    EnvParams P = make_params(h);
+    P.task_idx = task_idx; P.mach_idx = mach_idx;
+    const size_t lds = env_lds_bytes(P.J, P.M, P.T, P.obs_f32);
+    std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+    if (h->timing) {
+        if (h->ev_used == h->ev_pool.size()) {
+            hipEvent_t a, b;
+            HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
+            h->ev_pool.push_back({a, b});
+        }
+        ev = &h->ev_pool[h->ev_used++];
+        HIPCHK(h, hipEventRecord(ev->first, h->stream));
+    }
+    if (P.obs_f32) hipLaunchKernelGGL((k_env<false, float>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
+    else hipLaunchKernelGGL((k_env<false, double>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
+    if (ev) HIPCHK(h, hipEventRecord(ev->second, h->stream));
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_step_host(mtfjsp_handle_t h, const int32_t *task_host, const int32_t *mach_host)
+{
+    if (!h || !task_host || !mach_host) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const size_t B = h->cfg.batch;
+    HIPCHK(h, hipMemcpyAsync(h->d_task, task_host, B * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->d_mach, mach_host, B * 4, hipMemcpyHostToDevice, h->stream));
+    int rc = mtfjsp_step(h, h->d_task, h->d_mach);
+    if (rc) return rc;
+    std::vector<int32_t> st(B);
+    HIPCHK(h, hipMemcpyAsync(st.data(), h->obs.status, B * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < B; i++)
+        if (st[i] & MTFJSP_ST_INVALID) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "invalid action for instance %zu: task %d machine %d (already scheduled, job predecessor unscheduled, or out of range)", i, task_host[i], mach_host[i]);
+            h->err = buf;
+            return MTFJSP_ERR_ACTION;
+        }
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_observe_mfea1(mtfjsp_handle_t h, const int32_t *task_idx, const uint8_t *mmask_in, void *out, uint8_t *mmask_out)
+{
+    if (!h || !task_idx || !out) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int B = h->cfg.batch, M = h->cfg.n_machine, n = B * M;
+    if (h->cfg.obs_dtype == MTFJSP_OBS_F32)
+        hipLaunchKernelGGL((k_mfea1<float>), dim3((n + 255) / 256), dim3(256), 0, h->stream, B, h->T, M, h->t, h->p, h->tt, h->mean3, h->shop, h->link, task_idx, mmask_in, (float *)out, mmask_out);
+    else
+        hipLaunchKernelGGL((k_mfea1<double>), dim3((n + 255) / 256), dim3(256), 0, h->stream, B, h->T, M, h->t, h->p, h->tt, h->mean3, h->shop, h->link, task_idx, mmask_in, (double *)out, mmask_out);
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_random_actions(mtfjsp_handle_t h, uint64_t seed, uint64_t counter, int32_t *task_idx, int32_t *mach_idx, int32_t *job_idx)
+{
+    if (!h || !task_idx || !mach_idx) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int B = h->cfg.batch;
+    hipLaunchKernelGGL(k_random_actions, dim3((B + 127) / 128), dim3(128), 0, h->stream, B, h->cfg.n_job, h->cfg.n_machine, h->T,
+                       h->t, h->obs.candidate, h->obs.job_mask, seed, counter, task_idx, mach_idx, job_idx);
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_export_dense_adj(mtfjsp_handle_t h, double *out)
+{
+    if (!h || !out) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const size_t B = h->cfg.batch, T = h->T;
+    HIPCHK(h, hipMemsetAsync(out, 0, B * T * T * 8, h->stream));
+    const int n = (int)(B * T);
+    hipLaunchKernelGGL(k_dense_adj, dim3((n + 255) / 256), dim3(256), 0, h->stream, (int)B, (int)T, h->obs.ell_col, h->obs.ell_val, out);
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_valid_action_mask(mtfjsp_handle_t h, uint8_t *out)
+{
+    if (!h || !out) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int n = h->cfg.batch * h->T;
+    hipLaunchKernelGGL(k_valid_mask, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->cfg.batch, h->T, h->cfg.n_machine, h->link, out);
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_copy_to_host(mtfjsp_handle_t h, void *dst, const void *src, size_t n)
+{
+    if (!h || !dst || !src) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_read_state_host(mtfjsp_handle_t h, int which, void *out)
+{
+    if (!h || !out) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const size_t B = h->cfg.batch, T = h->T, M = h->cfg.n_machine;
+    std::vector<Link> link(B * T);
+    HIPCHK(h, hipMemcpyAsync(link.data(), h->link, B * T * sizeof(Link), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    switch (which) {
+    case MTFJSP_STATE_MACHINE: {
+        int32_t *o = (int32_t *)out;
+        for (size_t i = 0; i < B * T; i++) o[i] = link[i].mach;
+        return MTFJSP_OK;
+    }
+    case MTFJSP_STATE_START:
+    case MTFJSP_STATE_FINISH: {
+        double *o = (double *)out;
+        rc = mtfjsp_copy_to_host(h, o, which == MTFJSP_STATE_START ? h->st : h->ft, B * T * 8);
+        if (rc) return rc;
+        for (size_t i = 0; i < B * T; i++) if (link[i].mach < 0) o[i] = NAN;
+        return MTFJSP_OK;
+    }
+    case MTFJSP_STATE_ROUTES: {
+        int32_t *o = (int32_t *)out;
+        for (size_t i = 0; i < B * M * T; i++) o[i] = -1;
+        for (size_t b = 0; b < B; b++)
+            for (size_t v = 0; v < T; v++) {
+                const Link &l = link[b * T + v];
+                if (l.mach >= 0) o[(b * M + l.mach) * T + l.pos] = (int32_t)v;
+            }
+        return MTFJSP_OK;
+    }
+    case MTFJSP_STATE_PREV_COSTS:
+    case MTFJSP_STATE_SCALER:
+    case MTFJSP_STATE_W3: {
+        std::vector<double> sc(B * SCAL_N);
+        rc = mtfjsp_copy_to_host(h, sc.data(), h->scal, B * SCAL_N * 8);
+        if (rc) return rc;
+        double *o = (double *)out;
+        for (size_t b = 0; b < B; b++) {
+            const double *s = &sc[b * SCAL_N];
+            if (which == MTFJSP_STATE_PREV_COSTS) { for (int i = 0; i < 4; i++) o[b * 4 + i] = s[S_MK_PREV + i]; }
+            else if (which == MTFJSP_STATE_W3) { for (int i = 0; i < 3; i++) o[b * 3 + i] = s[S_W3 + i]; }
+            else {
+                for (int i = 0; i < 4; i++) { o[b * 17 + i] = s[S_R + i]; o[b * 17 + 5 + i] = s[S_MEAN + i]; o[b * 17 + 9 + i] = s[S_S + i]; o[b * 17 + 13 + i] = s[S_STD + i]; }
+                o[b * 17 + 4] = s[S_N];
+            }
+        }
+        return MTFJSP_OK;
+    }
+    default:
+        h->err = "read_state: unknown selector";
+        return MTFJSP_ERR_ARG;
+    }
+}
+
+extern "C" int mtfjsp_timing_begin(mtfjsp_handle_t h)
+{
+    if (!h) return MTFJSP_ERR_ARG;
+    h->timing = true; h->ev_used = 0;
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_timing_end(mtfjsp_handle_t h, double *ms_total, int64_t *launches)
+{
+    if (!h) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < h->ev_used; i++) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev_pool[i].first, h->ev_pool[i].second));
+        tot += ms;
+    }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = (int64_t)h->ev_used;
+    h->timing = false; h->ev_used = 0;
+    return MTFJSP_OK;
+}

@@ -1,0 +1,93 @@
+"""Synthetic MT-FJSP instance generator — same distribution AND same legacy-numpy random stream as the
+reference's Instance_Dataset (instance/generate_allsize_mofjsp_dataset.py:133-296, scope = instance/config_ins.json),
+so that seeds 0/1/3 reproduce the reference's train/eval/test sets bit for bit
+(pinned by tests/test_instances.py against tests/golden/instances_generator.npz).
+
+Layout returned: t, p [S,T,M] f64 (negative = machine infeasible for the task), tt [S,M,M] f64 symmetric with zero
+diagonal, edge [S,E,M/E] int (machine ids per shop).  T = n_job * n_machine (ops per job == n_machine).
+"""
+import numpy as np
+
+DEFAULT_SCOPE = dict(t_low=1, t_high=99, p_low=1, p_high=20, transT_in_low=1, transT_in_high=10,
+                     transT_out_low=1, transT_out_high=20, equal_edge=True, weight_low=0.8, weight_high=1.2)
+
+
+def split_machines(n_machine, n_edge):
+    """machines in index order, evenly; the last shop takes the remainder (generate…py:330-345)."""
+    avg = n_machine // n_edge
+    out, lst = [], list(range(n_machine))
+    for i in range(n_edge):
+        size = len(lst) if i == n_edge - 1 else avg
+        out.append(lst[:size])
+        lst = lst[size:]
+    return out
+
+
+def generate_instances(samples, n_job=6, n_machine=6, n_edge=2, seed=None, scope=None):
+    sc = dict(DEFAULT_SCOPE)
+    if scope:
+        sc.update(scope)
+    S, J, M, E = int(samples), int(n_job), int(n_machine), int(n_edge)
+    T = J * M
+    rs = np.random.RandomState(seed) if seed is not None else np.random.mtrand._rand
+    # draw order of generate…py:161-176
+    avg_t = rs.uniform(sc["t_low"], sc["t_high"], (S, T))
+    avg_p = rs.uniform(sc["p_low"], sc["p_high"], (S, T))
+    t_w = rs.uniform(sc["weight_low"], sc["weight_high"], (S, T, M))
+    p_w = rs.uniform(sc["weight_low"], sc["weight_high"], (S, T, M))
+    rs.uniform(1, 5, (S, 1, M))                       # idle powers m_p2: drawn, never used downstream (env:371 forces 1)
+    t = avg_t[:, :, None] * t_w
+    p = avg_p[:, :, None] * p_w
+    # generate…py:204-216: per task a uniform number k in [0,M) of machines made infeasible
+    for s in range(S):
+        ts = t[s]
+        for row in range(T):
+            k = rs.randint(0, M)
+            idx = rs.choice(M, size=k, replace=False)
+            ts[row, idx] *= -1
+    neg = t < 0
+    p[neg] = -p[neg]
+    shops = split_machines(M, E)
+    if len({len(x) for x in shops}) != 1:
+        raise ValueError("n_machine must be divisible by n_edge (the reference stacks the shop lists into an array)")
+    edge = np.tile(np.array(shops, dtype=np.int64)[None], (S, 1, 1))
+    shop_of = np.zeros(M, np.int64)
+    for e, ms in enumerate(shops):
+        shop_of[ms] = e
+    tt = np.zeros((S, M, M))
+    in_lo, in_hi, out_hi = sc["transT_in_low"], sc["transT_in_high"], sc["transT_out_high"]
+    for s in range(S):
+        a = np.zeros((M, M))
+        for i in range(M):
+            for j in range(M):
+                if i == j:
+                    continue
+                d = abs(int(shop_of[i]) - int(shop_of[j]))
+                if d == 0:
+                    a[i, j] = rs.uniform(low=in_lo, high=in_hi, size=1).item()
+                else:
+                    a[i, j] = rs.uniform(low=in_hi * d, high=out_hi * d, size=1).item()   # generate…py:262-266
+        U = np.triu(a, k=1)
+        tt[s] = U + U.T - np.diag(np.diag(a))
+    return t, p, tt, edge
+
+
+def random_weights(batch, rng=None, kind="01", config_weights=(0.4, 0.4, 0.2)):
+    """Reward weights w3 [B,3] exactly as env.generate_random_weights (env:1253-1270): three python
+    `random.uniform(0,1)` draws per instance in instance order, normalised by their numpy sum."""
+    import random as _random
+    r = rng if rng is not None else _random
+    out = np.zeros((batch, 3))
+    for b in range(batch):
+        if kind == "01":
+            w = np.array([r.uniform(0, 1) for _ in range(3)])
+            out[b] = w / np.sum(w, axis=-1)
+        elif kind == "0.1":
+            nums = [round(r.uniform(0, 1), 1) for _ in range(3)]
+            tot = sum(nums)
+            out[b] = np.array([round(x / tot, 1) for x in nums])
+        elif kind == "eval":
+            out[b] = np.array(config_weights)
+        else:
+            raise ValueError(kind)
+    return out

@@ -1,0 +1,220 @@
+"""Parallel_env — drop-in for the reference's trainer/parallel_env.py::Parallel_env (pe:19-282).
+
+Same constructor argument (the `args` dict), same method names, same numpy return shapes and dtypes, same
+`paral_env_DG[i]` / `paral_Rscaling_instance[i]` members that Run.py, algorithm/ppo_algorithm.py and
+trainer/validate.py touch — but every instance lives in HBM and every method is one HIP kernel
+launch through libmtfjsp.so (include/mtfjsp.h).  Use DeviceBatchEnv directly for the zero-copy rollout; this
+class is the compatibility surface for unmodified reference callers (it copies observations to host numpy,
+like the reference returns them).
+
+Differences that are deliberate (documented in DESIGN.md §6):
+  * an action that is already scheduled / whose job predecessor is unscheduled raises ValueError instead of
+    silently corrupting node attributes (env:1496-1528); never reached under the reference's masks;
+  * per-env `.step()` / `.render()` of the proxies are not available (the batch steps together).
+"""
+import random
+
+import numpy as np
+import torch
+
+from . import capi
+from .batch_env import DeviceBatchEnv
+from .instances import random_weights
+
+
+class _NodeView:
+    """G.nodes[k] -> dict with the attributes callers read (ppo:271-273, validate.py:142,222)."""
+
+    def __init__(self, proxy):
+        self._p = proxy
+
+    def __getitem__(self, k):
+        p = self._p
+        T = p._env.T
+        if k == 0 or k == T + 1:
+            return {"machine": -2, "duration": 0, "scheduled": k == 0, "start_time": 0 if k == 0 else None,
+                    "finish_time": 0 if k == 0 else None, "job": -1}
+        a = k - 1
+        par = p._parent
+        mach = int(par._mirror(capi.STATE_MACHINE)[p._i, a])
+        sched = mach >= 0
+        return {
+            "machine": mach if sched else -1,
+            "scheduled": sched,
+            "start_time": float(par._mirror(capi.STATE_START)[p._i, a]) if sched else None,
+            "finish_time": float(par._mirror(capi.STATE_FINISH)[p._i, a]) if sched else None,
+            "duration": float(par.ability_instance[p._i][0][a, mach]) if sched else 0,
+            "job": a // p._env.M,
+        }
+
+
+class _GraphView:
+    def __init__(self, proxy):
+        self.nodes = _NodeView(proxy)
+
+
+class _EnvProxy:
+    """Stand-in for one DisjunctiveGraphJspEnv_singleStep inside `paral_env_DG` (read-only view of instance i)."""
+
+    def __init__(self, parent, i):
+        self._parent, self._i, self._env = parent, i, parent._dev
+        self.G = _GraphView(self)
+
+    @property
+    def reward_random_weight(self):
+        return self._parent._w3[self._i].copy()
+
+    def _prev(self, c):
+        return float(self._parent._mirror(capi.STATE_PREV_COSTS)[self._i, c])
+
+    makespan_previous_step = property(lambda s: s._prev(0))
+    total_e1_previous_step = property(lambda s: s._prev(1))
+    trans_t_previous_step = property(lambda s: s._prev(2))
+    idle_t_previous_step = property(lambda s: s._prev(3))
+
+    @property
+    def machine_routes(self):
+        r = self._parent._mirror(capi.STATE_ROUTES)[self._i]
+        return {m: (r[m][r[m] >= 0] + 1).astype(np.float64) for m in range(self._env.M)}   # node ids, like the reference
+
+    def valid_action_mask(self, action_mode=None):
+        return [bool(x) for x in self._parent._valid_mask()[self._i]]
+
+    def reset(self, Random_weight_type="01"):
+        """env.reset() (env:1183-1245) as Run.py:660 calls it after `done`: consumes the same three
+        `random.uniform` draws; the instance itself is re-initialised by the next init_DGFJSPEnv_state0()."""
+        w = random_weights(1, kind=Random_weight_type, config_weights=self._parent._w_cfg)[0]
+        self._parent._w3[self._i] = w
+        return None
+
+    def step(self, *a, **k):
+        raise NotImplementedError("instances of a device batch step together: use Parallel_env.DGFJSPEnv_paral_step")
+
+    def render(self, *a, **k):
+        raise NotImplementedError("rendering is outside the accelerated hot path")
+
+
+class _ScalerProxy:
+    """paral_Rscaling_instance[i] — only .reset() (zero the discounted return R, pt:123) is used by callers."""
+
+    def __init__(self, parent, i):
+        self._parent, self._i = parent, i
+
+    def reset(self):
+        self._parent._scaler_pending[self._i] = True
+
+
+class Parallel_env(object):
+    def __init__(self, args):
+        self.njobs = args['n_job']
+        self.nmachines = args['n_machine']
+        self.ntasks = self.njobs * self.nmachines
+        self.nedges = args['n_edge']
+        self.batch_size = args['env_batch']
+        self.m_scaling = args['m_scaling']
+        self.reward_dict = args['reward_scaling']
+        self.args = args
+        self.ability_instance = []
+        self.paral_Rscaling_instance = []
+        self.paral_env_DG = []
+        self.oenv_info = []
+        self._w_cfg = (args['weight_mk'], args['weight_ec'], args['weight_tt'])
+        self._left_shift = bool(args.get('perform_left_shift_if_possible', True))
+        self._device = int(args.get('hip_device', 0))
+        self._dev = DeviceBatchEnv(self.njobs, self.nmachines, self.nedges, self.batch_size, left_shift=self._left_shift,
+                                   obs_dtype="f64", device=self._device, gamma=args['GAMMA'], w_cfg=self._w_cfg,
+                                   scaling_divisor=self.reward_dict['scaling_divisor'])
+        self._w3 = np.zeros((self.batch_size, 3))
+        self._cache = {}
+        self._scaler_pending = np.zeros(self.batch_size, bool)
+
+    # -- host mirrors of device state, refreshed lazily once per step
+    def _mirror(self, which):
+        if which not in self._cache:
+            self._cache[which] = self._dev.read_state(which)
+        return self._cache[which]
+
+    def _valid_mask(self):
+        if "vmask" not in self._cache:
+            self._cache["vmask"] = self._dev.valid_action_mask().cpu().numpy()
+        return self._cache["vmask"]
+
+    def _flush_scaler_resets(self):
+        if self._scaler_pending.any():
+            if self._scaler_pending.all():
+                self._dev.scaler_reset_returns()
+            else:
+                self._dev.scaler_reset_returns_masked(self._scaler_pending)
+            self._scaler_pending[:] = False
+
+    @staticmethod
+    def _np(x):
+        return x.numpy() if torch.is_tensor(x) else np.asarray(x)
+
+    def get_batch(self, dataset_dict):
+        """pe:39-66"""
+        t = self._np(dataset_dict["t"]).astype(np.float64)
+        p = self._np(dataset_dict["p"]).astype(np.float64)
+        tt = self._np(dataset_dict["transT"]).astype(np.float64)
+        edge = self._np(dataset_dict["edge"])
+        B = self.batch_size
+        self.ability_instance = [[t[i].copy(), p[i].copy(), tt[i].copy(), edge[i].copy()] for i in range(B)]
+        self._dev.load_instances(t[:B], p[:B], tt[:B], edge=edge[:B])
+
+    def init_RewardScaling_sameBATCH(self, shape):
+        """pe:70-85"""
+        assert shape == 4
+        self._dev.scaler_init()
+        self._scaler_pending[:] = False
+        self.paral_Rscaling_instance = [_ScalerProxy(self, i) for i in range(self.batch_size)]
+
+    def _host_obs(self):
+        d = self._dev
+        adj = d.dense_adj().cpu().numpy()
+        return adj, d.m_fea2.cpu().numpy().copy(), d.tasks_fea.cpu().numpy().copy()
+
+    def init_DGFJSPEnv_state0(self):
+        """pe:87-149 -> (adj [B,T,T], m_fea2 [B,M,8], tasks_fea [B*T,12]) float64"""
+        kind = self.args.get('random_weight_type', "01") if isinstance(self.args, dict) else "01"
+        self._w3 = random_weights(self.batch_size, kind="01" if kind not in ("01", "0.1", "eval") else "01",
+                                  config_weights=self._w_cfg)           # env.reset() default type is "01" (env:1183)
+        self._dev.reset(self._w3)
+        self._cache = {}
+        self.paral_env_DG = [_EnvProxy(self, i) for i in range(self.batch_size)]
+        return self._host_obs()
+
+    def cal_cur_task_machine_feature(self, task_index, m_mask, all_task_fea):
+        """pe:152-214 -> ndarray [B,M,6] float64.  `all_task_fea` is accepted for signature compatibility; the
+        predecessor's machine is read from device state, which equals all_task_fea[a-1][5]-1 for the observation
+        returned by the latest reset/step (the only way Run.py:347 and validate.py call it)."""
+        ti = self._np(task_index.cpu() if torch.is_tensor(task_index) else task_index).astype(np.int32).reshape(-1)
+        mm = self._np(m_mask.cpu() if torch.is_tensor(m_mask) else m_mask).reshape(self.batch_size, self.nmachines).astype(np.uint8)
+        out = self._dev.observe_mfea1(ti, mm)
+        return out.cpu().numpy().copy()
+
+    def DGFJSPEnv_paral_step(self, joint_actions):
+        """pe:217-268 -> (adj_, oenv_info, m_fea2_, tasks_fea_)"""
+        a = np.array([ja[0] for ja in joint_actions], np.int32)
+        m = np.array([ja[1] for ja in joint_actions], np.int32)
+        self._flush_scaler_resets()
+        try:
+            self._dev.step(a, m)
+        except capi.MtfjspError as e:
+            if e.code == capi.ERR_ACTION:
+                raise ValueError(str(e)) from None
+            raise
+        self._cache = {}
+        status = self._dev.status.cpu().numpy()
+        for l in np.flatnonzero(status & capi.ST_INFEASIBLE):          # pe:246-248
+            print("!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!")
+            print(f"============= 'DGFJSPEnv_paral_step' occur error: chose Minus: t={self.ability_instance[l][0][a[l]][m[l]]}, p= {self.ability_instance[l][1][a[l]][m[l]]}")
+        info = self._dev.info.cpu().numpy()
+        self.oenv_info = [[info[i, 0], bool(info[i, 1]), info[i, 2], info[i, 3], info[i, 4], info[i, 5]]
+                          for i in range(self.batch_size)]
+        adj, mfea2, tfea = self._host_obs()
+        return adj, self.oenv_info, mfea2, tfea
+
+    def reset_data(self):
+        """pe:271-282"""
+        self.paral_env_DG = []
+        self.oenv_info = []

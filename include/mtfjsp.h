@@ -1,0 +1,205 @@
+/*
+ * mtfjsp.h — C ABI of libmtfjsp.so: MI355X-native batched MT-FJSP disjunctive-graph
+ * environment (reset / step / observe / masks) and the rollout forward passes of
+ * the GIN + GAT actors.  This is the drop-in boundary for the hot path of
+ * RKWin93/E2E-MAPPO-for-MT-FJSP; every entry point cites the reference interface
+ * it replaces ("pe:" = trainer/parallel_env.py, "env:" = graph-jsp-env/src/
+ * graph_jsp_env/disjunctive_graph_jsp_env_singlestep.py, "ppo:" =
+ * algorithm/ppo_algorithm.py, "ac:" = model/actor_critic.py, "agent:" =
+ * algorithm/agent_func.py, "run:" = Run.py).  The reference-side ctypes binding
+ * is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C types only; every function returns 0 (MTFJSP_OK) or a negative
+ *    mtfjsp_status; mtfjsp_last_error(h) describes the last failure on h.
+ *  - One handle per GPU.  A handle is not thread-safe; distinct handles are.
+ *  - All array arguments are DEVICE pointers unless the name ends in _host.
+ *    Work is enqueued on the handle's stream (mtfjsp_set_stream; default: the
+ *    NULL stream) and is asynchronous; *_host variants synchronise that stream.
+ *  - Task index a in [0,T), T = n_job*n_machine, job = a / n_machine,
+ *    op = a % n_machine (square instances: ops per job == n_machine, as in the
+ *    reference generator).  Machine index m in [0,M).
+ *  - Scheduling state and all times/rewards are IEEE binary64, evaluated in the
+ *    reference's operation order without FMA contraction.
+ */
+#ifndef MTFJSP_H
+#define MTFJSP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mtfjsp_env *mtfjsp_handle_t;
+typedef struct mtfjsp_encoder *mtfjsp_encoder_t;
+
+typedef enum {
+    MTFJSP_OK = 0,
+    MTFJSP_ERR_ARG = -1,      /* bad argument / configuration */
+    MTFJSP_ERR_STATE = -2,    /* call order (e.g. step before load_instances/reset) */
+    MTFJSP_ERR_HIP = -3,      /* HIP runtime error (no device, launch failure, OOM) */
+    MTFJSP_ERR_ACTION = -4    /* *_host step: at least one action was invalid */
+} mtfjsp_status;
+
+enum { MTFJSP_OBS_F64 = 0, MTFJSP_OBS_F32 = 1 };
+
+/* per-instance status word written by mtfjsp_step (bound obs.status) */
+enum {
+    MTFJSP_PATH_MASK = 0x7,          /* scheduling path taken (env:1531-1685): */
+    MTFJSP_PATH_EMPTY = 0,           /*   machine route was empty */
+    MTFJSP_PATH_FRONT = 1,           /*   left-shifted to the front of the route */
+    MTFJSP_PATH_BETWEEN = 2,         /*   left-shifted into a gap */
+    MTFJSP_PATH_APPEND = 3,          /*   appended */
+    MTFJSP_ST_INVALID = 0x100,       /* already scheduled / job predecessor unscheduled / index out of range:
+                                        the instance is left untouched (the reference silently corrupts node
+                                        attributes here, env:1496-1528; never reached under the masks) */
+    MTFJSP_ST_INFEASIBLE = 0x200     /* t[a,m] < 0 chosen (pe:246-248 prints a warning and carries on; so do we) */
+};
+
+typedef struct {
+    int32_t n_job, n_machine, n_edge;   /* pe:22-25 */
+    int32_t batch;                      /* env_batch, pe:26 */
+    int32_t left_shift;                 /* perform_left_shift_if_possible (pe:116; tester/pdrs.py:669 uses 0) */
+    int32_t obs_dtype;                  /* MTFJSP_OBS_F64: observations as the reference returns them (f64)
+                                           MTFJSP_OBS_F32: the same values rounded once to f32 — what ac:143,377
+                                           `.float()` would produce — for the device-resident rollout */
+    int32_t device_id;
+    int32_t reserved;
+    double gamma;                       /* GAMMA for RewardScaling, pe:81 */
+    double w_mk, w_ec, w_tt;            /* config weights in the scalar reward, env:1119-1132 */
+    double scaling_divisor;             /* reward_function_parameters['scaling_divisor'], env:1164 */
+} mtfjsp_config_t;
+
+/* Observation / step outputs, all DEVICE pointers, caller- or library-allocated.
+ * Shapes use B = batch, T, M, J.                                                                  replaces        */
+typedef struct {
+    void *tasks_fea;      /* [B*T,12] obs_dtype: st_est, ft_est, pt_est, scheduled, in_degree,      env:2245-2277   */
+                          /*          machine+1|0, t|0, p|0, job+1, w3[0..2]                                         */
+    int32_t *ell_col;     /* [B*T,2]  in-edge sources of node v (task index inside the instance,   env:2019-2073   */
+                          /*          -1 = none): slot 0 job edge, slot 1 machine edge                               */
+    float *ell_val;       /* [B*T,2]  adj_wrk values of those edges (small integers); the self      (dense: see     */
+                          /*          loop (value 1) is implicit                                     export below)   */
+    void *m_fea2;         /* [B,M,8]  obs_dtype                                                     env:2315-2354   */
+    double *info;         /* [B,6]    reward, done, mk_s, idle_s, pt_s, tt_s (scaled components)    pe:255-262      */
+    double *raw;          /* [B,5]    reward, r_mk, r_idle, r_pt, r_tt (unscaled); may be NULL      env:1051-1171   */
+    int32_t *candidate;   /* [B,J]    next selectable task of each job                              ppo:306-309     */
+    uint8_t *job_mask;    /* [B,J]    1 = job not selectable                                        ppo:238-297     */
+    int32_t *status;      /* [B]      see MTFJSP_PATH_* / MTFJSP_ST_*                                               */
+} mtfjsp_obs_t;
+
+/* ------------------------------------------------------------------ lifecycle */
+/* = Parallel_env.__init__ (pe:20-37). Allocates all device state for `batch` instances. */
+int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out);
+int mtfjsp_destroy(mtfjsp_handle_t h);
+const char *mtfjsp_last_error(mtfjsp_handle_t h);      /* h may be NULL: last create() error */
+int mtfjsp_set_stream(mtfjsp_handle_t h, void *hip_stream);
+int mtfjsp_synchronize(mtfjsp_handle_t h);
+
+/* Library-owned observation buffers (freed by destroy) / caller-owned ones. */
+int mtfjsp_alloc_obs(mtfjsp_handle_t h, mtfjsp_obs_t *out);
+int mtfjsp_bind_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *obs);
+
+/* ------------------------------------------------------------------ instances */
+/* = Parallel_env.get_batch (pe:39-66): t,p [B,T,M] (negative = machine infeasible), tt [B,M,M],
+ * shop_of_machine [B,M] (0-based shop id; the reference's edge[E,M/E] table inverted).
+ * Precomputes min_dur/min_pt (env:1932-1950) and the per-task means used by m_fea1 (pe:176-183). */
+int mtfjsp_load_instances(mtfjsp_handle_t h, const double *t, const double *p, const double *tt,
+                          const int32_t *shop_of_machine);
+int mtfjsp_load_instances_host(mtfjsp_handle_t h, const double *t_host, const double *p_host,
+                               const double *tt_host, const int32_t *shop_host);
+
+/* = init_RewardScaling_sameBATCH (pe:70-85) and RewardScaling.reset() per episode (run:283-284). */
+int mtfjsp_scaler_init(mtfjsp_handle_t h);
+int mtfjsp_scaler_reset_returns(mtfjsp_handle_t h);
+/* same, only for instances with mask_host[b] != 0 (run:283-284 resets them one by one) */
+int mtfjsp_scaler_reset_returns_masked_host(mtfjsp_handle_t h, const uint8_t *mask_host);
+
+/* ------------------------------------------------------------------ reset / step */
+/* = init_DGFJSPEnv_state0 (pe:87-149) = env.reset() on every instance (env:1183-1245).
+ * w3 [B,3]: normalised reward weights; the host draws them (env:1253-1259 uses python `random`). */
+int mtfjsp_reset(mtfjsp_handle_t h, const double *w3);
+int mtfjsp_reset_host(mtfjsp_handle_t h, const double *w3_host);
+
+/* = DGFJSPEnv_paral_step (pe:217-268): env.step (env:716-974) + RewardScaling (pe:255-260), fused with
+ * the candidate / job-mask update of ppo:202-316.  One launch; writes every bound obs field. */
+int mtfjsp_step(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx);
+/* host variant: returns MTFJSP_ERR_ACTION if any status word carries MTFJSP_ST_INVALID */
+int mtfjsp_step_host(mtfjsp_handle_t h, const int32_t *task_idx_host, const int32_t *mach_idx_host);
+
+/* = cal_cur_task_machine_feature (pe:152-214): out [B,M,6] obs_dtype, mmask_out [B,M] (1 = infeasible; may be
+ * NULL).  mmask_in [B,M] may be NULL (then feasibility t>=0 is used, which is what run:335 passes). */
+int mtfjsp_observe_mfea1(mtfjsp_handle_t h, const int32_t *task_idx, const uint8_t *mmask_in,
+                         void *out, uint8_t *mmask_out);
+
+/* Uniform random valid actions on device (benchmark / property-test policy, SURVEY §8d "on-device Philox allowed
+ * for perf runs"): job uniform over unmasked jobs of the bound job_mask, machine uniform over feasible ones. */
+int mtfjsp_random_actions(mtfjsp_handle_t h, uint64_t seed, uint64_t counter, int32_t *task_idx,
+                          int32_t *mach_idx, int32_t *job_idx);
+
+/* ------------------------------------------------------------------ exports (compat / tests) */
+/* dense adj_wrk [B,T,T] f64, row = destination, diagonal 1 (env:2066-2073) — what pe:136 returns. */
+int mtfjsp_export_dense_adj(mtfjsp_handle_t h, double *out);
+/* gym-style valid_action_mask (env:2535-2575): [B,T] 1 = selectable */
+int mtfjsp_valid_action_mask(mtfjsp_handle_t h, uint8_t *out);
+enum {
+    MTFJSP_STATE_MACHINE = 0,   /* int32 [B,T]   machine of task, -1 unscheduled       (G.nodes[k]['machine'])      */
+    MTFJSP_STATE_START = 1,     /* f64   [B,T]   start time, NaN unscheduled           (…['start_time'])            */
+    MTFJSP_STATE_FINISH = 2,    /* f64   [B,T]   finish time, NaN unscheduled          (…['finish_time'], ppo:271)  */
+    MTFJSP_STATE_ROUTES = 3,    /* int32 [B,M,T] task indices in processing order, -1 padded (env.machine_routes)   */
+    MTFJSP_STATE_PREV_COSTS = 4,/* f64   [B,4]   makespan/e1/trans/idle _previous_step  (run:632-633)               */
+    MTFJSP_STATE_SCALER = 5,    /* f64   [B,17]  R[4], n, mean[4], S[4], std[4]         (pt:54-124)                 */
+    MTFJSP_STATE_W3 = 6         /* f64   [B,3]   reward_random_weight                   (run:478)                   */
+};
+int mtfjsp_read_state_host(mtfjsp_handle_t h, int which, void *out_host);
+/* copy `nbytes` from a device buffer of this handle's context to host (synchronises the stream) */
+int mtfjsp_copy_to_host(mtfjsp_handle_t h, void *dst_host, const void *src_dev, size_t nbytes);
+
+/* kernel timing hook for bench.py: HIP events recorded on the handle's stream around every step launch
+ * between begin/end; returns accumulated milliseconds and launch count. */
+int mtfjsp_timing_begin(mtfjsp_handle_t h);
+int mtfjsp_timing_end(mtfjsp_handle_t h, double *step_ms_total, int64_t *step_launches);
+
+/* ------------------------------------------------------------------ encoder (rollout forward passes) */
+typedef struct {
+    int32_t n_job, n_machine, batch;
+    int32_t hidden;            /* gcn_hidden_dim == machine_hidden_dim == 128 (parameters.py:106,109) */
+    int32_t obs_dtype;         /* dtype of tasks_fea / m_fea1 / m_fea2 handed to the forwards */
+    int32_t device_id;
+} mtfjsp_encoder_config_t;
+
+int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_encoder_t *out);
+int mtfjsp_encoder_destroy(mtfjsp_encoder_t e);
+const char *mtfjsp_encoder_last_error(mtfjsp_encoder_t e);
+int mtfjsp_encoder_set_stream(mtfjsp_encoder_t e, void *hip_stream);
+/* Weights by the reference's state_dict key, prefixed "job_actor." or "machine_actor."
+ * (e.g. "job_actor.encoder.feature_extract.mlps.0.linears.0.weight"); f32, row-major as in torch. */
+int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *name, const float *data_host, int64_t numel);
+int mtfjsp_encoder_weights_ready(mtfjsp_encoder_t e);     /* 0 when every required tensor has been loaded */
+
+/* = Operation_Actor_JointAction_selfCritic.forward (ac:104-296) without the sampling:
+ * GIN encoder (gcn:109-197, training-mode BatchNorm over all B*T rows), candidate scorer, masked softmax,
+ * local critic.  h_m_prev may be NULL (first step: learned `_input`, ac:229-233).
+ * Outputs (f32): prob [B,J], h_pooled [B,H], job_v [B,2]; h_nodes [B*T,H] optional (NULL = keep internal). */
+int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col,
+                             const float *ell_val, const int32_t *candidate, const uint8_t *job_mask,
+                             const float *h_m_prev, float *prob, float *h_pooled, float *job_v, float *h_nodes);
+/* = Machine_Actor_JointAction_selfGAT_selfCritic.forward (ac:359-498; GATLayer gat:82-159).
+ * Outputs (f32): prob [B,M], h_pooled [B,H], machine_v [B,2]. */
+int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fea1, const void *m_fea2,
+                                 const float *h_pooled_o, const uint8_t *mmask, float *prob, float *h_pooled,
+                                 float *machine_v);
+/* = select_operation_action / greedy_select_action / select_machine_action (agent:22-72):
+ * categorical sample (Philox, (seed,counter)) or argmax from prob [B,N]; idx_out [B], logp_out [B];
+ * gather_from (optional, [B,N] int32, e.g. candidate) -> gathered_out [B] (task index). */
+int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *prob, int32_t n, int32_t greedy, uint64_t seed,
+                              uint64_t counter, int32_t *idx_out, float *logp_out, const int32_t *gather_from,
+                              int32_t *gathered_out);
+int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
+int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTFJSP_H */

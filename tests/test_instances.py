@@ -1,0 +1,48 @@
+"""Instance generator vs the reference generator's stream (golden captured from the reference). CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import mtfjsp_amd
+from importlib import import_module
+
+inst = import_module("e2e-mappo-for-mt-fjsp_amd.instances")
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "instances_generator.npz"))
+
+
+@pytest.mark.parametrize("tag", ["j6m6e2_s0", "j10m10e2_s5", "j20m20e4_s7", "j10m6e2_s2"])
+def test_generator_reproduces_reference_stream(tag):
+    s, j, m, e, seed = [int(x) for x in G[tag + "_args"]]
+    t, p, tt, edge = inst.generate_instances(s, j, m, e, seed)
+    assert np.array_equal(t, G[tag + "_t"])
+    assert np.array_equal(p, G[tag + "_p"])
+    assert np.array_equal(tt, G[tag + "_tt"])
+    assert np.array_equal(edge, G[tag + "_edge"])
+
+
+def test_generator_reproduces_shipped_eval_set():
+    t, p, tt, edge = inst.generate_instances(100, 6, 6, 2, 1)
+    for k, a in zip(("t", "p", "tt", "edge"), (t, p, tt, edge)):
+        assert np.array_equal(a[:3], G["eval100_s1_head_" + k])
+        assert np.array_equal(a[-2:], G["eval100_s1_tail_" + k])
+
+
+def test_instance_invariants():
+    t, p, tt, edge = inst.generate_instances(5, 6, 6, 2, 42)
+    assert ((t < 0) == (p < 0)).all()
+    assert (t >= 0).any(axis=2).all()          # at least one feasible machine per task
+    assert np.allclose(tt, tt.transpose(0, 2, 1)) and (np.diagonal(tt, axis1=1, axis2=2) == 0).all()
+
+
+def test_random_weights_stream():
+    import random
+    random.seed(0)
+    w = inst.random_weights(4)
+    random.seed(0)
+    ref = []
+    for _ in range(4):
+        x = np.array([random.uniform(0, 1) for _ in range(3)])
+        ref.append(x / np.sum(x))
+    assert np.array_equal(w, np.array(ref))
+    assert np.allclose(w.sum(1), 1.0)
