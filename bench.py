@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/sec of the batched MT-FJSP hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one pass of the hot path over one batch: every one of the B instances on this GPU takes one
+(task, machine) decision — policy forward passes (when --policy actor), m_fea1, the fused env step kernel
+(state transition + rewards + reward scaling + next observation + candidate/job mask) — with all inputs resident
+in HBM.  Episodes end every T steps; the batched reset (new reward weights) is part of the timed region.
+Instances shard across GPUs with no data-path collective (weak scaling: B per GPU fixed).
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP events on the launch stream) and
+`cpu_baseline` (the C oracle port timed on the host cores; N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_MEASURED_GBPS = 6290.0
+
+
+def env_bytes(J, M):
+    """algorithmic bytes per env-step of the step kernel."""
+    T = J * M
+    return 136 * T + 156 * M + 483
+
+
+def cpu_baseline(J, M, E, seconds_target=12.0):
+    """Time the CPU oracle port (oracle/mtfjsp_oracle.c, scalar C, 1 core) on a bounded sample of the same workload."""
+    from oracle.env_oracle import OracleBatch
+    from importlib import import_module
+    inst = import_module("e2e-mappo-for-mt-fjsp_amd.instances")
+    B, T = 256, J * M
+    t, p, tt, edge = inst.generate_instances(B, J, M, E, seed=0)
+    orc = OracleBatch(t, p, tt, edge)
+    orc.scaler_init()
+    rs = np.random.RandomState(0)
+    feas = t >= 0
+    w3 = np.full((B, 3), 1.0 / 3)
+    n = 0
+    t_step = 0.0
+    t_start = time.perf_counter()
+    episodes = 0
+    while time.perf_counter() - t_start < seconds_target:
+        orc.reset(w3)
+        cand, mask = orc.job_mask_state()
+        for s in range(T):
+            # uniform random valid action (host side, not timed)
+            job = np.array([rs.choice(np.flatnonzero(mask[b] == 0)) for b in range(B)], np.int32)
+            task = cand[np.arange(B), job].astype(np.int32)
+            mach = np.array([rs.choice(np.flatnonzero(feas[b, task[b]])) for b in range(B)], np.int32)
+            t0 = time.perf_counter()
+            orc.step(task, mach)
+            cand, mask = orc.job_mask_update(job)
+            orc.observe(dense=False)
+            t_step += time.perf_counter() - t0
+            n += B
+        episodes += 1
+    return {"value": n / t_step, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"J{J}M{M}E{E}, B=256, {episodes} episodes ({n} env-steps), step+reward scaling+job mask+observe (ELL adj), "
+                      f"random valid actions; oracle/mtfjsp_oracle.c -O2 scalar"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=360)
+    ap.add_argument("--warmup", type=int, default=36)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--size", default="6x6x2")
+    ap.add_argument("--policy", default="auto", choices=["auto", "actor", "random"])
+    ap.add_argument("--obs", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from importlib import import_module
+    import mtfjsp_amd  # noqa: F401
+    rollout_mod = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    J, M, E = [int(x) for x in args.size.split("x")]
+    T = J * M
+    B = args.batch
+    policy = args.policy
+    if policy == "auto":
+        policy = "actor" if rollout_mod.actor_available() else "random"
+    ro = rollout_mod.Rollout(J, M, E, B, device=local_rank, policy=policy, obs_dtype=args.obs,
+                             instance_seed=rank, rank=rank, world=world)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ro.step()
+    sync()
+    ro.timing_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ro.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    ktimes = ro.timing_end()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ro.check_finished_cleanly()
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        # dominant kernel by measured device time
+        dom = max(ktimes, key=lambda k: ktimes[k]["ms_total"])
+        kd = ktimes[dom]
+        avg_s = kd["ms_total"] / max(kd["launches"], 1) * 1e-3
+        if dom == "env_step":
+            achieved = B * env_bytes(J, M) / avg_s / 1e9
+            roof = {"kernel": "k_env<step> (fused state transition + rewards + scaler + observation + job mask)",
+                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": achieved / HBM_MEASURED_GBPS,
+                    "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": kd["launches"],
+                    "algorithmic_bytes_per_launch": B * env_bytes(J, M)}
+        else:
+            roof = ro.roofline(dom, kd)
+        out = {
+            "metric": "env-steps/sec (batched J%dM%dE%d)" % (J, M, E), "value": value, "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"J{J}M{M}E{E}, {B} parallel instances per GPU, {ro.describe()}",
+                       "instances_per_gpu": B, "obs_dtype": args.obs, "policy": policy,
+                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+            "roofline": roof,
+            "kernel_times_ms": {k: v for k, v in ktimes.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(J, M, E)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
