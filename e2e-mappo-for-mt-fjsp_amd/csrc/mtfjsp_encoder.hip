@@ -1,7 +1,21 @@
 // mtfjsp_encoder.hip — rollout forward passes of the job actor (GIN encoder + candidate scorer + local critic)
-// and the machine actor (3x shared 2-node GAT + BatchNorm + scorer + local critic) for MI355X (gfx950).
-// WORK IN PROGRESS in this commit: handle + weight management are real, the forward kernels land next.
+// and the machine actor (3x shared 2-node GAT + BatchNorm + scorer + local critic) for MI355X (gfx950 / CDNA4).
+//
+// Everything [rows,128] x [128,128] runs on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA
+// chains, so parity with the reference's f32 modules is round-off only).  One persistent 256-thread workgroup per
+// CU keeps W^T (64 KB) in LDS; each wave owns 32-row tiles:
+//     prologue : coalesced 16-B loads of the producer's pre-activation rows, transformed on the fly
+//                (training-mode BatchNorm + ReLU from the producer's column sums, or the GIN neighbour
+//                aggregation over the ELL adjacency in f64) -> wave-private LDS tile (row stride 129: conflict-free)
+//     main     : 64 k-steps x 4 column blocks of MFMA (K is permuted so each lane half streams its own half row)
+//     epilogue : + bias [+ per-instance row bias] [tanh], store, and per-column sum / sum-of-squares for the
+//                consumer's BatchNorm (f32 per tile -> f64 per wave -> one f64 atomic per column per workgroup)
+// so every BatchNorm boundary costs exactly one write + one read of the [rows,128] f32 activations
+// (SURVEY.md §8d ENC_BYTES) and no separate normalisation pass exists.
+//
+// "gcn:" = model/gcn_mlp.py, "gat:" = model/gat.py, "ac:" = model/actor_critic.py, "agent:" = algorithm/agent_func.py
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdint.h>
 #include <string.h>
 #include <map>
@@ -10,38 +24,788 @@
 
 #include "../../include/mtfjsp.h"
 
+#define HD 128
+#define LDA 129
+#define BN_EPS 1e-5
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2 };
+
+struct GemmArgs {
+    const float *in;        // [N,128] producer output (pre-activation for PRO_BNRELU / PRO_AGG)
+    int N;
+    const float *Wt;        // [128(k),128(n)] = W^T of a torch Linear weight [out,in]
+    const float *bias;      // [128] or NULL
+    float *out;             // [N,128]
+    // prologue: BatchNorm of `in` from the producer's column sums
+    const double *pro_stats;   // [256] sum | sumsq
+    const float *pro_gamma, *pro_beta;
+    double pro_inv_rows;
+    const int *ell_col;     // PRO_AGG: [N,2]
+    const float *ell_val;   // PRO_AGG: [N,2]
+    int T;                  // PRO_AGG: rows per instance
+    // epilogue
+    double *epi_stats;      // EPI_STATS: [256] accumulated with atomics (zeroed by the host per forward)
+    const float *rowbias;   // optional [N/rowbias_div,128] added to row r: rowbias[(r / rowbias_div)]
+    int rowbias_div;
+    int accumulate;         // C initialised from `out` (K > 128 as a sum of 128-wide GEMMs)
+};
+
+__device__ __forceinline__ float bn_relu(float x, float mean, float rstd, float g, float b)
+{
+    float y = (x - mean) * rstd * g + b;
+    return y > 0.f ? y : 0.f;
+}
+
+template <int PRO, int EPI>
+__global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_w = reinterpret_cast<float *>(smem);                 // 128*128
+    float *s_a = s_w + HD * HD;                                   // 4 * 32 * LDA
+    float *s_bn = s_a + 4 * 32 * LDA;                             // mean | rstd | gamma | beta  (4*128)
+    double *s_red = reinterpret_cast<double *>(s_bn + 4 * HD);    // 4 waves * 256
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+
+    {   // W^T -> LDS (coalesced float4)
+        const float4 *src = reinterpret_cast<const float4 *>(A.Wt);
+        float4 *dst = reinterpret_cast<float4 *>(s_w);
+        for (int i = tid; i < HD * HD / 4; i += 256) dst[i] = src[i];
+    }
+    if (PRO != PRO_PLAIN && tid < HD) {
+        const double mean = A.pro_stats[tid] * A.pro_inv_rows;
+        double var = A.pro_stats[HD + tid] * A.pro_inv_rows - mean * mean;      // biased variance (training-mode BN)
+        if (var < 0) var = 0;
+        s_bn[tid] = (float)mean;
+        s_bn[HD + tid] = (float)(1.0 / sqrt(var + BN_EPS));
+        s_bn[2 * HD + tid] = A.pro_gamma[tid];
+        s_bn[3 * HD + tid] = A.pro_beta[tid];
+    }
+    __syncthreads();
+
+    float *my_a = s_a + wave * 32 * LDA;
+    const int ntiles = (A.N + 31) / 32;
+    const int stride = gridDim.x * 4;
+    const int iters = (ntiles + stride - 1) / stride;
+    double st_sum[4] = {0, 0, 0, 0}, st_sq[4] = {0, 0, 0, 0};   // per column block (lane j, block cb), EPI_STATS
+    const int c4 = j * 4;
+    float mean4[4], rstd4[4], g4[4], b4[4];
+    if (PRO != PRO_PLAIN)
+        for (int q = 0; q < 4; q++) { mean4[q] = s_bn[c4 + q]; rstd4[q] = s_bn[HD + c4 + q]; g4[q] = s_bn[2 * HD + c4 + q]; b4[q] = s_bn[3 * HD + c4 + q]; }
+
+    for (int it = 0; it < iters; it++) {
+        const int tile = (blockIdx.x * 4 + wave) + it * stride;
+        const bool live = tile < ntiles;
+        const int row0 = tile * 32;
+        // ------------------------------------------------------------------ prologue -> LDS tile
+        if (live) {
+            for (int p = 0; p < 16; p++) {
+                const int r = 2 * p + h;
+                const int g = row0 + r;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (g < A.N) {
+                    const float4 x = *reinterpret_cast<const float4 *>(A.in + (size_t)g * HD + c4);
+                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+                    if (PRO == PRO_BNRELU) {
+                        for (int q = 0; q < 4; q++) v[q] = bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
+                    } else if (PRO == PRO_AGG) {
+                        // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
+                        double acc[4];
+                        for (int q = 0; q < 4; q++) acc[q] = (double)bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
+                        const int2 cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2);
+                        const float2 vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2);
+                        const int base = (g / A.T) * A.T;
+                        int deg = 1;
+                        if (cc.x >= 0) {
+                            const float4 y = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.x) * HD + c4);
+                            const float yy[4] = {y.x, y.y, y.z, y.w};
+                            for (int q = 0; q < 4; q++) acc[q] += (double)vv.x * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
+                            deg++;
+                        }
+                        if (cc.y >= 0) {
+                            const float4 y = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.y) * HD + c4);
+                            const float yy[4] = {y.x, y.y, y.z, y.w};
+                            for (int q = 0; q < 4; q++) acc[q] += (double)vv.y * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
+                            deg++;
+                        }
+                        for (int q = 0; q < 4; q++) v[q] = (float)(acc[q] / (double)deg);
+                    }
+                }
+                float *d = my_a + r * LDA + c4;
+                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            }
+        }
+        __syncthreads();
+        // ------------------------------------------------------------------ main loop
+        f32x16 acc[4];
+        for (int cb = 0; cb < 4; cb++)
+            for (int i = 0; i < 16; i++) acc[cb][i] = 0.f;
+        if (live) {
+            if (A.accumulate) {
+                for (int cb = 0; cb < 4; cb++)
+                    for (int i = 0; i < 16; i++) {
+                        const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                        if (r < A.N) acc[cb][i] = A.out[(size_t)r * HD + cb * 32 + j];
+                    }
+            }
+            const float *ap = my_a + j * LDA + 64 * h;            // A[row j][k = 64h + s]
+            const float *bp = s_w + (64 * h) * HD + j;            // B[k = 64h + s][col cb*32 + j]
+#pragma unroll 4
+            for (int s = 0; s < 64; s++) {
+                const float a = ap[s];
+                const float b0 = bp[s * HD], b1 = bp[s * HD + 32], b2 = bp[s * HD + 64], b3 = bp[s * HD + 96];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+            }
+            // -------------------------------------------------------------- epilogue
+            for (int cb = 0; cb < 4; cb++) {
+                const int col = cb * 32 + j;
+                const float bias = (A.bias && !A.accumulate) ? A.bias[col] : 0.f;
+                float ts = 0.f, tq = 0.f;
+                for (int i = 0; i < 16; i++) {
+                    const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                    if (r < A.N) {
+                        float v = acc[cb][i] + bias;
+                        if (A.rowbias) v += A.rowbias[(size_t)(r / A.rowbias_div) * HD + col];
+                        if (EPI == EPI_TANH) v = tanhf(v);
+                        A.out[(size_t)r * HD + col] = v;
+                        if (EPI == EPI_STATS) { ts += v; tq += v * v; }
+                    }
+                }
+                if (EPI == EPI_STATS) { st_sum[cb] += (double)ts; st_sq[cb] += (double)tq; }
+            }
+        }
+        __syncthreads();
+    }
+    if (EPI == EPI_STATS) {
+        for (int cb = 0; cb < 4; cb++) {
+            double a = st_sum[cb], q = st_sq[cb];
+            a += __shfl_xor(a, 32);
+            q += __shfl_xor(q, 32);
+            if (h == 0) { s_red[wave * 256 + cb * 32 + j] = a; s_red[wave * 256 + HD + cb * 32 + j] = q; }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const double v = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
+            atomicAdd(&A.epi_stats[tid], v);
+        }
+    }
+}
+static size_t gemm_lds_bytes() { return (size_t)(HD * HD + 4 * 32 * LDA + 4 * HD) * 4 + 4 * 256 * 8; }
+
+// ---------------------------------------------------------------------------------------------
+// GIN layer 0, first Linear (12 -> 128) fused with the neighbour aggregation of the raw task features
+// (gcn:125-153).  thread = (column c, row group); persistent blocks, column stats in registers.
+template <typename OBS>
+__global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, const int *ell_col, const float *ell_val,
+                                              const float *W /*[128,12]*/, const float *bias, float *out, double *stats)
+{
+    __shared__ float s_p[32 * 12];
+    const int tid = threadIdx.x, c = tid & 127, half = tid >> 7;
+    float w[12];
+    for (int k = 0; k < 12; k++) w[k] = W[c * 12 + k];
+    const float bc = bias[c];
+    double ssum = 0, ssq = 0;
+    const int ntiles = (N + 31) / 32;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * 32;
+        __syncthreads();
+        for (int i = tid; i < 32 * 12; i += 256) {
+            const int r = i / 12, k = i % 12, g = row0 + r;
+            float v = 0.f;
+            if (g < N) {
+                const int base = (g / T) * T;
+                double acc = (double)(float)tfea[(size_t)g * 12 + k];            // ac:143 .float(), gcn:125 .double()
+                int deg = 1;
+                const int c0 = ell_col[(size_t)g * 2], c1 = ell_col[(size_t)g * 2 + 1];
+                if (c0 >= 0) { acc += (double)ell_val[(size_t)g * 2] * (double)(float)tfea[(size_t)(base + c0) * 12 + k]; deg++; }
+                if (c1 >= 0) { acc += (double)ell_val[(size_t)g * 2 + 1] * (double)(float)tfea[(size_t)(base + c1) * 12 + k]; deg++; }
+                v = (float)(acc / (double)deg);
+            }
+            s_p[i] = v;
+        }
+        __syncthreads();
+        for (int rr = 0; rr < 16; rr++) {
+            const int r = half * 16 + rr, g = row0 + r;
+            if (g < N) {
+                float a = 0.f;
+                for (int k = 0; k < 12; k++) a = fmaf(s_p[r * 12 + k], w[k], a);
+                a += bc;
+                out[(size_t)g * HD + c] = a;
+                ssum += (double)a; ssq += (double)a * (double)a;
+            }
+        }
+    }
+    atomicAdd(&stats[c], ssum);
+    atomicAdd(&stats[HD + c], ssq);
+}
+
+// ---------------------------------------------------------------------------------------------
+// After the last GIN BatchNorm: h = relu(bn(z)); graph mean pool (gcn:192) and candidate gather (ac:197-207).
+// One 128-thread block per instance, thread = column.
+__global__ __launch_bounds__(128) void k_job_pool_gather(int B, int T, int J, const float *z, const double *stats, double inv_rows,
+                                                        const float *gamma, const float *beta, const int *cand,
+                                                        float *h_pooled, float *cand_feat, float *h_nodes)
+{
+    const int b = blockIdx.x, c = threadIdx.x;
+    const double mean_d = stats[c] * inv_rows;
+    double var = stats[HD + c] * inv_rows - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + BN_EPS)), g = gamma[c], be = beta[c];
+    float acc = 0.f;
+    for (int v = 0; v < T; v++) {
+        const float hv = bn_relu(z[((size_t)b * T + v) * HD + c], mean, rstd, g, be);
+        acc += hv;
+        if (h_nodes) h_nodes[((size_t)b * T + v) * HD + c] = hv;
+    }
+    h_pooled[(size_t)b * HD + c] = acc * (1.0f / (float)T);                     // sparse mm with 1/T entries
+    for (int jj = 0; jj < J; jj++) {
+        const int v = cand[b * J + jj];
+        cand_feat[((size_t)b * J + jj) * HD + c] = bn_relu(z[((size_t)b * T + v) * HD + c], mean, rstd, g, be);
+    }
+}
+
+// broadcast a [128] vector to [B,128] (first step: learned `_input` instead of h_m_prev, ac:229-233)
+__global__ void k_bcast128(int B, const float *v, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * HD) out[i] = v[i & 127];
+}
+
+// Final 128 -> 1 scorer + mask + softmax over the R rows of each instance, and the 128 -> 2 critic head.
+// One 64-thread block per instance.  score = scale * (w2 . s2_row + b2)   (ac:256-278 / ac:476-491)
+__global__ __launch_bounds__(64) void k_score_softmax(int B, int R, const float *s2 /*[B*R,128]*/, const float *w2, const float *b2, float scale,
+                                                     const uint8_t *mask /*[B,R]*/, float *prob /*[B,R]*/,
+                                                     const float *c2 /*[B,128]*/, const float *wc /*[2,128]*/, const float *bc /*[2]*/, float *value /*[B,2]*/)
+{
+    __shared__ float s_score[64];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float wa = w2[lane], wb = w2[lane + 64];
+    for (int r = 0; r < R; r++) {
+        const float *row = s2 + ((size_t)b * R + r) * HD;
+        float p = row[lane] * wa + row[lane + 64] * wb;
+        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+        if (lane == 0) s_score[r] = (p + b2[0]) * scale;
+    }
+    for (int o2 = 0; o2 < 2; o2++) {
+        const float *row = c2 + (size_t)b * HD;
+        float p = row[lane] * wc[o2 * HD + lane] + row[lane + 64] * wc[o2 * HD + lane + 64];
+        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
+        if (lane == 0) value[b * 2 + o2] = p + bc[o2];
+    }
+    __syncthreads();
+    float sc = -INFINITY;
+    if (lane < R && !mask[(size_t)b * R + lane]) sc = s_score[lane];
+    float mx = sc;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float e = (lane < R && sc > -INFINITY) ? expf(sc - mx) : 0.f;
+    float sum = e;
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane < R) prob[(size_t)b * R + lane] = e / sum;
+}
+
+// ---------------------------------------------------------------------------------------------
+// machine actor input projections (ac:383-384): X0 = m_fea1 W1^T (6->128), X1 = m_fea2 W2^T (8->128); rows = B*M
+template <typename OBS>
+__global__ void k_mach_in(int rows, const OBS *f1, const OBS *f2, const float *W1 /*[128,6]*/, const float *W2 /*[128,8]*/, float *X /*[2,rows,128]*/)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)rows * HD) return;
+    const int r = (int)(i >> 7), c = (int)(i & 127);
+    float a = 0.f, b = 0.f;
+    for (int k = 0; k < 6; k++) a = fmaf((float)f1[(size_t)r * 6 + k], W1[c * 6 + k], a);
+    for (int k = 0; k < 8; k++) b = fmaf((float)f2[(size_t)r * 8 + k], W2[c * 8 + k], b);
+    X[i] = a;
+    X[(size_t)rows * HD + i] = b;
+}
+
+// One GAT pass on the fixed 2-node graph [[1,1],[0,1]] given Z = X W (gat:68-159), one wave per machine row:
+//   e0j = LeakyReLU_0.2(a_src.z0 + a_dst.zj) ; (al0,al1) = softmax(e00,e01) ; n0' = al0 z0 + al1 z1 ; n1' = z1
+//   mode 0: ELU on both, write X (next pass input)   mode 1: node = (n0'+n1')/2 -> out + column stats (ac:420-434)
+__global__ __launch_bounds__(256) void k_gat_combine(int rows, const float *Z /*[2,rows,128]*/, const float *a /*[256]*/, int mode,
+                                                    float *X /*[2,rows,128]*/, float *node /*[rows,128]*/, double *stats)
+{
+    __shared__ double s_red[4 * 256];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float as0 = a[lane], as1 = a[lane + 64], ad0 = a[HD + lane], ad1 = a[HD + lane + 64];
+    double ssum0 = 0, ssum1 = 0, ssq0 = 0, ssq1 = 0;
+    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
+        const float *z0 = Z + (size_t)r * HD, *z1 = Z + ((size_t)rows + r) * HD;
+        const float z00 = z0[lane], z01 = z0[lane + 64], z10 = z1[lane], z11 = z1[lane + 64];
+        float s0 = z00 * as0 + z01 * as1, d0 = z00 * ad0 + z01 * ad1, d1 = z10 * ad0 + z11 * ad1;
+        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
+        float e00 = s0 + d0, e01 = s0 + d1;
+        e00 = e00 > 0.f ? e00 : 0.2f * e00;
+        e01 = e01 > 0.f ? e01 : 0.2f * e01;
+        const float mx = fmaxf(e00, e01);
+        const float x0 = expf(e00 - mx), x1 = expf(e01 - mx);
+        const float al0 = x0 / (x0 + x1), al1 = x1 / (x0 + x1);
+        float n00 = al0 * z00 + al1 * z10, n01 = al0 * z01 + al1 * z11;
+        float n10 = z10, n11 = z11;
+        if (mode == 0) {
+            n00 = n00 > 0.f ? n00 : expm1f(n00); n01 = n01 > 0.f ? n01 : expm1f(n01);      // ELU (ac:409-413)
+            n10 = n10 > 0.f ? n10 : expm1f(n10); n11 = n11 > 0.f ? n11 : expm1f(n11);
+            X[(size_t)r * HD + lane] = n00; X[(size_t)r * HD + lane + 64] = n01;
+            X[((size_t)rows + r) * HD + lane] = n10; X[((size_t)rows + r) * HD + lane + 64] = n11;
+        } else {
+            const float m0 = (n00 + n10) * 0.5f, m1 = (n01 + n11) * 0.5f;                 // mean over the 2 nodes (ac:420)
+            node[(size_t)r * HD + lane] = m0; node[(size_t)r * HD + lane + 64] = m1;
+            ssum0 += m0; ssq0 += (double)m0 * m0; ssum1 += m1; ssq1 += (double)m1 * m1;
+        }
+    }
+    if (mode == 1) {
+        s_red[wave * 256 + lane] = ssum0; s_red[wave * 256 + 64 + lane] = ssum1;
+        s_red[wave * 256 + 128 + lane] = ssq0; s_red[wave * 256 + 192 + lane] = ssq1;
+        __syncthreads();
+        const double v = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
+        atomicAdd(&stats[tid], v);
+    }
+}
+
+// machine nodes: BatchNorm over all B*M rows (ac:434) and mean over M (ac:444). block = instance, thread = column
+__global__ __launch_bounds__(128) void k_mach_bn_pool(int B, int M, float *node /*in: pre-BN, out: normalised*/, const double *stats, double inv_rows,
+                                                     const float *gamma, const float *beta, float *h_pooled)
+{
+    const int b = blockIdx.x, c = threadIdx.x;
+    const double mean_d = stats[c] * inv_rows;
+    double var = stats[HD + c] * inv_rows - mean_d * mean_d;
+    if (var < 0) var = 0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + BN_EPS)), g = gamma[c], be = beta[c];
+    float acc = 0.f;
+    for (int m = 0; m < M; m++) {
+        const size_t i = ((size_t)b * M + m) * HD + c;
+        const float y = (node[i] - mean) * rstd * g + be;
+        node[i] = y;
+        acc += y;
+    }
+    h_pooled[(size_t)b * HD + c] = acc / (float)M;
+}
+
+// ---------------------------------------------------------------------------------------------
+// categorical sampling / argmax (agent:22-72). thread = instance. Philox4x32-10.
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__global__ void k_sample(int B, int n, const float *prob, int greedy, uint64_t seed, uint64_t counter, int *idx_out, float *logp_out,
+                         const int *gather_from, int *gathered_out)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float *p = prob + (size_t)b * n;
+    int pick = 0;
+    if (greedy) {
+        float best = p[0];
+        for (int i = 1; i < n; i++) if (p[i] > best) { best = p[i]; pick = i; }
+    } else {
+        uint32_t c[4] = {(uint32_t)b, (uint32_t)counter, (uint32_t)(counter >> 32), 0x73616d70u};
+        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);      // [0,1)
+        float tot = 0.f;
+        for (int i = 0; i < n; i++) tot += p[i];
+        float acc = 0.f;
+        const float thr = u * tot;
+        pick = -1;
+        int last = 0;
+        for (int i = 0; i < n; i++) {
+            if (p[i] > 0.f) {
+                last = i;
+                acc += p[i];
+                if (pick < 0 && thr < acc) pick = i;
+            }
+        }
+        if (pick < 0) pick = last;
+    }
+    idx_out[b] = pick;
+    if (logp_out) logp_out[b] = logf(p[pick]);
+    if (gather_from && gathered_out) gathered_out[b] = gather_from[(size_t)b * n + pick];
+}
+
+// =================================================================================================
+// host side
 struct mtfjsp_encoder {
     mtfjsp_encoder_config_t cfg;
+    int T = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    std::map<std::string, float *> w;
-    std::map<std::string, int64_t> wn;
+    std::map<std::string, float *> w;       // device copies, torch layout
+    std::map<std::string, float *> wt;      // transposed [in,out] copies of the 128-wide Linear weights (split per 128-block of `in`)
     std::vector<void *> owned;
+    int num_cu = 256;
+    // workspaces
+    float *zA = nullptr, *zB = nullptr;     // [B*T,128] ping-pong
+    float *cand_feat = nullptr, *s1 = nullptr, *s2 = nullptr;   // [B*max(J,M),128]
+    float *u = nullptr, *c1 = nullptr, *c2 = nullptr, *hm_b = nullptr, *pooled_int = nullptr;   // [B,128]
+    float *X = nullptr, *Z = nullptr;       // [2,B*M,128]
+    float *node = nullptr;                  // [B*M,128]
+    double *stats = nullptr;                // [8,256]
+    // timing
+    bool timing = false;
+    std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> ev;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
 };
 static thread_local std::string g_enc_err;
 
+#define HIPCHK(e, call)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) {                                                                 \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(e_);                       \
+            return MTFJSP_ERR_HIP;                                                              \
+        }                                                                                       \
+    } while (0)
+
+template <typename Tp>
+static int dalloc(mtfjsp_encoder *e, Tp **ptr, size_t n)
+{
+    HIPCHK(e, hipMalloc((void **)ptr, n * sizeof(Tp)));
+    e->owned.push_back(*ptr);
+    return 0;
+}
+
+static const char *REQUIRED[] = {
+    "job_actor._input",
+    "job_actor.encoder.feature_extract.mlps.0.linears.0.weight", "job_actor.encoder.feature_extract.mlps.0.linears.0.bias",
+    "job_actor.encoder.feature_extract.mlps.0.linears.1.weight", "job_actor.encoder.feature_extract.mlps.0.linears.1.bias",
+    "job_actor.encoder.feature_extract.mlps.0.linears.2.weight", "job_actor.encoder.feature_extract.mlps.0.linears.2.bias",
+    "job_actor.encoder.feature_extract.mlps.0.batch_norms.0.weight", "job_actor.encoder.feature_extract.mlps.0.batch_norms.0.bias",
+    "job_actor.encoder.feature_extract.mlps.0.batch_norms.1.weight", "job_actor.encoder.feature_extract.mlps.0.batch_norms.1.bias",
+    "job_actor.encoder.feature_extract.mlps.1.linears.0.weight", "job_actor.encoder.feature_extract.mlps.1.linears.0.bias",
+    "job_actor.encoder.feature_extract.mlps.1.linears.1.weight", "job_actor.encoder.feature_extract.mlps.1.linears.1.bias",
+    "job_actor.encoder.feature_extract.mlps.1.linears.2.weight", "job_actor.encoder.feature_extract.mlps.1.linears.2.bias",
+    "job_actor.encoder.feature_extract.mlps.1.batch_norms.0.weight", "job_actor.encoder.feature_extract.mlps.1.batch_norms.0.bias",
+    "job_actor.encoder.feature_extract.mlps.1.batch_norms.1.weight", "job_actor.encoder.feature_extract.mlps.1.batch_norms.1.bias",
+    "job_actor.encoder.feature_extract.batch_norms.0.weight", "job_actor.encoder.feature_extract.batch_norms.0.bias",
+    "job_actor.encoder.feature_extract.batch_norms.1.weight", "job_actor.encoder.feature_extract.batch_norms.1.bias",
+    "job_actor.o_policy.linears.0.weight", "job_actor.o_policy.linears.0.bias",
+    "job_actor.o_policy.linears.1.weight", "job_actor.o_policy.linears.1.bias",
+    "job_actor.o_policy.linears.2.weight", "job_actor.o_policy.linears.2.bias",
+    "job_actor.job_critic.linears.0.weight", "job_actor.job_critic.linears.0.bias",
+    "job_actor.job_critic.linears.1.weight", "job_actor.job_critic.linears.1.bias",
+    "job_actor.job_critic.linears.2.weight", "job_actor.job_critic.linears.2.bias",
+    "machine_actor.bn.weight", "machine_actor.bn.bias", "machine_actor.m_fea_1_fcl.weight", "machine_actor.m_fea_2_fcl.weight",
+    "machine_actor.gat_layer.W", "machine_actor.gat_layer.a",
+    "machine_actor.m_policy.linears.0.weight", "machine_actor.m_policy.linears.0.bias",
+    "machine_actor.m_policy.linears.1.weight", "machine_actor.m_policy.linears.1.bias",
+    "machine_actor.m_policy.linears.2.weight", "machine_actor.m_policy.linears.2.bias",
+    "machine_actor.machine_critic.linears.0.weight", "machine_actor.machine_critic.linears.0.bias",
+    "machine_actor.machine_critic.linears.1.weight", "machine_actor.machine_critic.linears.1.bias",
+    "machine_actor.machine_critic.linears.2.weight", "machine_actor.machine_critic.linears.2.bias",
+};
+
 extern "C" const char *mtfjsp_encoder_last_error(mtfjsp_encoder_t e) { return e ? e->err.c_str() : g_enc_err.c_str(); }
+
 extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_encoder_t *out)
 {
     if (!cfg || !out) { g_enc_err = "null argument"; return MTFJSP_ERR_ARG; }
+    if (cfg->hidden != HD || cfg->n_job < 1 || cfg->n_job > 64 || cfg->n_machine < 2 || cfg->n_machine > 64 || cfg->batch < 1) {
+        g_enc_err = "bad encoder configuration (hidden must be 128, n_job<=64, 2<=n_machine<=64)"; return MTFJSP_ERR_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_enc_err = "no HIP device available"; return MTFJSP_ERR_HIP; }
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) { g_enc_err = "device_id out of range"; return MTFJSP_ERR_ARG; }
+    if (hipSetDevice(cfg->device_id) != hipSuccess) { g_enc_err = "hipSetDevice failed"; return MTFJSP_ERR_HIP; }
     mtfjsp_encoder *e = new mtfjsp_encoder();
     e->cfg = *cfg;
+    e->T = cfg->n_job * cfg->n_machine;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess) e->num_cu = prop.multiProcessorCount;
+    const size_t B = cfg->batch, T = e->T, M = cfg->n_machine, J = cfg->n_job, R = J > M ? J : M;
+    int rc = 0;
+    rc |= dalloc(e, &e->zA, B * T * HD); rc |= dalloc(e, &e->zB, B * T * HD);
+    rc |= dalloc(e, &e->cand_feat, B * R * HD); rc |= dalloc(e, &e->s1, B * R * HD); rc |= dalloc(e, &e->s2, B * R * HD);
+    rc |= dalloc(e, &e->u, B * HD); rc |= dalloc(e, &e->c1, B * HD); rc |= dalloc(e, &e->c2, B * HD); rc |= dalloc(e, &e->hm_b, B * HD);
+    rc |= dalloc(e, &e->pooled_int, B * HD);
+    rc |= dalloc(e, &e->X, 2 * B * M * HD); rc |= dalloc(e, &e->Z, 2 * B * M * HD); rc |= dalloc(e, &e->node, B * M * HD);
+    rc |= dalloc(e, &e->stats, 8 * 256);
+    if (rc) { g_enc_err = e->err; mtfjsp_encoder_destroy(e); return MTFJSP_ERR_HIP; }
+    const int lds = (int)gemm_lds_bytes();
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_BNRELU, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_AGG, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     *out = e;
     return MTFJSP_OK;
 }
+
 extern "C" int mtfjsp_encoder_destroy(mtfjsp_encoder_t e)
 {
     if (!e) return MTFJSP_OK;
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipDeviceSynchronize();
     for (void *p : e->owned) (void)hipFree(p);
+    for (auto &kv : e->ev) for (auto &p : kv.second) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    for (auto &p : e->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete e;
     return MTFJSP_OK;
 }
 extern "C" int mtfjsp_encoder_set_stream(mtfjsp_encoder_t e, void *s) { if (!e) return MTFJSP_ERR_ARG; e->stream = (hipStream_t)s; return MTFJSP_OK; }
-extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *, const float *, int64_t) { if (!e) return MTFJSP_ERR_ARG; e->err = "encoder kernels not built yet"; return MTFJSP_ERR_STATE; }
-extern "C" int mtfjsp_encoder_weights_ready(mtfjsp_encoder_t e) { if (!e) return MTFJSP_ERR_ARG; return MTFJSP_ERR_STATE; }
-extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *, const int32_t *, const float *, const int32_t *, const uint8_t *,
-                                        const float *, float *, float *, float *, float *) { if (!e) return MTFJSP_ERR_ARG; e->err = "encoder kernels not built yet"; return MTFJSP_ERR_STATE; }
-extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *, const void *, const float *, const uint8_t *, float *, float *, float *) { if (!e) return MTFJSP_ERR_ARG; e->err = "encoder kernels not built yet"; return MTFJSP_ERR_STATE; }
-extern "C" int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *, int32_t, int32_t, uint64_t, uint64_t, int32_t *, float *, const int32_t *, int32_t *) { if (!e) return MTFJSP_ERR_ARG; e->err = "encoder kernels not built yet"; return MTFJSP_ERR_STATE; }
-extern "C" int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e) { return e ? MTFJSP_OK : MTFJSP_ERR_ARG; }
-extern "C" int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms, int64_t *n) { if (!e) return MTFJSP_ERR_ARG; if (ms) *ms = 0; if (n) *n = 0; return MTFJSP_OK; }
+
+extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *name, const float *data, int64_t numel)
+{
+    if (!e || !name || !data || numel <= 0) return MTFJSP_ERR_ARG;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    std::string key(name);
+    float *d = nullptr;
+    auto it = e->w.find(key);
+    if (it != e->w.end()) d = it->second;
+    else { if (dalloc(e, &d, (size_t)numel)) return MTFJSP_ERR_HIP; e->w[key] = d; }
+    HIPCHK(e, hipMemcpy(d, data, (size_t)numel * 4, hipMemcpyHostToDevice));
+    // 128-wide Linear weights [out=128, in=128*k] and gat W [in,out]: keep GEMM-ready [in-block][k][n] copies
+    const bool is_w = key.size() > 7 && key.compare(key.size() - 7, 7, ".weight") == 0 && key.find("linears") != std::string::npos;
+    if ((is_w && numel % (HD * HD) == 0) || key == "machine_actor.gat_layer.W") {
+        const int blocks = (int)(numel / (HD * HD));
+        std::vector<float> t((size_t)numel);
+        if (key == "machine_actor.gat_layer.W") memcpy(t.data(), data, (size_t)numel * 4);     // already [in,out] (gat:82 h @ W)
+        else {
+            const int in = blocks * HD;
+            for (int blk = 0; blk < blocks; blk++)
+                for (int k = 0; k < HD; k++)
+                    for (int n = 0; n < HD; n++) t[((size_t)blk * HD + k) * HD + n] = data[(size_t)n * in + blk * HD + k];
+        }
+        float *dt = nullptr;
+        auto jt = e->wt.find(key);
+        if (jt != e->wt.end()) dt = jt->second;
+        else { if (dalloc(e, &dt, (size_t)numel)) return MTFJSP_ERR_HIP; e->wt[key] = dt; }
+        HIPCHK(e, hipMemcpy(dt, t.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
+    }
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_encoder_weights_ready(mtfjsp_encoder_t e)
+{
+    if (!e) return MTFJSP_ERR_ARG;
+    for (const char *k : REQUIRED)
+        if (!e->w.count(k)) { e->err = std::string("missing weight: ") + k; return MTFJSP_ERR_STATE; }
+    return MTFJSP_OK;
+}
+
+// ---- timed launch helper
+struct Timed {
+    mtfjsp_encoder *e; std::pair<hipEvent_t, hipEvent_t> ev; bool on;
+    Timed(mtfjsp_encoder *e_, const char *name) : e(e_), on(e_->timing)
+    {
+        if (!on) return;
+        if (e->ev_free.empty()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); ev = {a, b}; }
+        else { ev = e->ev_free.back(); e->ev_free.pop_back(); }
+        (void)hipEventRecord(ev.first, e->stream);
+        e->ev[name].push_back(ev);
+    }
+    ~Timed() { if (on) (void)hipEventRecord(ev.second, e->stream); }
+};
+
+template <int PRO, int EPI>
+static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
+{
+    Timed t(e, name);
+    const int ntiles = (a.N + 31) / 32;
+    int grid = (ntiles + 3) / 4;
+    if (grid > e->num_cu) grid = e->num_cu;
+    hipLaunchKernelGGL((k_gemm128<PRO, EPI>), dim3(grid), dim3(256), gemm_lds_bytes(), e->stream, a);
+}
+
+static GemmArgs gemm_args(const float *in, int N, const float *Wt, const float *bias, float *out)
+{
+    GemmArgs a{};
+    a.in = in; a.N = N; a.Wt = Wt; a.bias = bias; a.out = out; a.rowbias_div = 1;
+    return a;
+}
+
+extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
+                                        const int32_t *candidate, const uint8_t *job_mask, const float *h_m_prev,
+                                        float *prob, float *h_pooled, float *job_v, float *h_nodes)
+{
+    if (!e || !tasks_fea || !ell_col || !ell_val || !candidate || !job_mask || !prob || !h_pooled || !job_v) return MTFJSP_ERR_ARG;
+    int rc = mtfjsp_encoder_weights_ready(e);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    const int B = e->cfg.batch, T = e->T, J = e->cfg.n_job, N = B * T;
+    const std::string P = "job_actor.encoder.feature_extract.";
+    auto W = [&](const std::string &k) { return e->w.at(k); };
+    auto WT = [&](const std::string &k) { return e->wt.at(k); };
+    double *st = e->stats;
+    HIPCHK(e, hipMemsetAsync(st, 0, 8 * 256 * sizeof(double), e->stream));
+    const double invN = 1.0 / (double)N;
+    const int pgrid = e->num_cu * 4;
+    {   // layer 0 / linear 0 with aggregation of the raw features
+        Timed t(e, "gin0_agg_linear12");
+        if (e->cfg.obs_dtype == MTFJSP_OBS_F32)
+            hipLaunchKernelGGL((k_gin0<float>), dim3(pgrid), dim3(256), 0, e->stream, N, T, (const float *)tasks_fea, ell_col, ell_val,
+                               W(P + "mlps.0.linears.0.weight"), W(P + "mlps.0.linears.0.bias"), e->zA, st + 0 * 256);
+        else
+            hipLaunchKernelGGL((k_gin0<double>), dim3(pgrid), dim3(256), 0, e->stream, N, T, (const double *)tasks_fea, ell_col, ell_val,
+                               W(P + "mlps.0.linears.0.weight"), W(P + "mlps.0.linears.0.bias"), e->zA, st + 0 * 256);
+    }
+    auto bn_gemm = [&](const float *in, float *out, int sin, const std::string &bn, const std::string &lin, int sout) {
+        GemmArgs a = gemm_args(in, N, WT(P + lin + ".weight"), W(P + lin + ".bias"), out);
+        a.pro_stats = st + sin * 256; a.pro_gamma = W(P + bn + ".weight"); a.pro_beta = W(P + bn + ".bias"); a.pro_inv_rows = invN;
+        a.epi_stats = st + sout * 256;
+        launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_bn_relu");
+    };
+    bn_gemm(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1);
+    bn_gemm(e->zB, e->zA, 1, "mlps.0.batch_norms.1", "mlps.0.linears.2", 2);
+    {   // layer 1 / linear 0: aggregation of h = relu(bn_outer0(z)) over the ELL adjacency
+        GemmArgs a = gemm_args(e->zA, N, WT(P + "mlps.1.linears.0.weight"), W(P + "mlps.1.linears.0.bias"), e->zB);
+        a.pro_stats = st + 2 * 256; a.pro_gamma = W(P + "batch_norms.0.weight"); a.pro_beta = W(P + "batch_norms.0.bias"); a.pro_inv_rows = invN;
+        a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
+        a.epi_stats = st + 3 * 256;
+        launch_gemm<PRO_AGG, EPI_STATS>(e, a, "gin_gemm_agg");
+    }
+    bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4);
+    bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5);
+    {
+        Timed t(e, "job_pool_gather");
+        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(128), 0, e->stream, B, T, J, e->zB, st + 5 * 256, invN,
+                           W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, e->cand_feat, h_nodes);
+    }
+    // ---- heads (ac:205-293): score = L2 tanh(L1 tanh(Wa cand + Wb pooled + Wc hm + b0))
+    const float *hm = h_m_prev;
+    if (!hm) {
+        Timed t(e, "small");
+        hipLaunchKernelGGL(k_bcast128, dim3((B * HD + 255) / 256), dim3(256), 0, e->stream, B, W("job_actor._input"), e->hm_b);
+        hm = e->hm_b;
+    }
+    const float *W0t = WT("job_actor.o_policy.linears.0.weight");       // 3 blocks of [128,128]: cand | pooled | hm
+    {
+        GemmArgs a = gemm_args(h_pooled, B, W0t + 1 * HD * HD, W("job_actor.o_policy.linears.0.bias"), e->u);
+        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, a, "head_gemm");
+        GemmArgs b = gemm_args(hm, B, W0t + 2 * HD * HD, nullptr, e->u);
+        b.accumulate = 1;
+        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, b, "head_gemm");
+        GemmArgs c = gemm_args(e->cand_feat, B * J, W0t, nullptr, e->s1);
+        c.rowbias = e->u; c.rowbias_div = J;
+        launch_gemm<PRO_PLAIN, EPI_TANH>(e, c, "head_gemm");
+        GemmArgs d = gemm_args(e->s1, B * J, WT("job_actor.o_policy.linears.1.weight"), W("job_actor.o_policy.linears.1.bias"), e->s2);
+        launch_gemm<PRO_PLAIN, EPI_TANH>(e, d, "head_gemm");
+        GemmArgs f = gemm_args(h_pooled, B, WT("job_actor.job_critic.linears.0.weight"), W("job_actor.job_critic.linears.0.bias"), e->c1);
+        launch_gemm<PRO_PLAIN, EPI_TANH>(e, f, "head_gemm");
+        GemmArgs g = gemm_args(e->c1, B, WT("job_actor.job_critic.linears.1.weight"), W("job_actor.job_critic.linears.1.bias"), e->c2);
+        launch_gemm<PRO_PLAIN, EPI_TANH>(e, g, "head_gemm");
+    }
+    {
+        Timed t(e, "score_softmax");
+        hipLaunchKernelGGL(k_score_softmax, dim3(B), dim3(64), 0, e->stream, B, J, e->s2, W("job_actor.o_policy.linears.2.weight"),
+                           W("job_actor.o_policy.linears.2.bias"), 1.0f, job_mask, prob, e->c2, W("job_actor.job_critic.linears.2.weight"),
+                           W("job_actor.job_critic.linears.2.bias"), job_v);
+    }
+    HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fea1, const void *m_fea2, const float *h_pooled_o,
+                                            const uint8_t *mmask, float *prob, float *h_pooled, float *machine_v)
+{
+    if (!e || !m_fea1 || !m_fea2 || !h_pooled_o || !mmask || !prob || !h_pooled || !machine_v) return MTFJSP_ERR_ARG;
+    int rc = mtfjsp_encoder_weights_ready(e);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
+    auto W = [&](const std::string &k) { return e->w.at(k); };
+    auto WT = [&](const std::string &k) { return e->wt.at(k); };
+    double *st = e->stats + 6 * 256;
+    HIPCHK(e, hipMemsetAsync(st, 0, 256 * sizeof(double), e->stream));
+    {
+        Timed t(e, "mach_in");
+        const size_t n = (size_t)R * HD;
+        if (e->cfg.obs_dtype == MTFJSP_OBS_F32)
+            hipLaunchKernelGGL((k_mach_in<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, R, (const float *)m_fea1, (const float *)m_fea2,
+                               W("machine_actor.m_fea_1_fcl.weight"), W("machine_actor.m_fea_2_fcl.weight"), e->X);
+        else
+            hipLaunchKernelGGL((k_mach_in<double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, R, (const double *)m_fea1, (const double *)m_fea2,
+                               W("machine_actor.m_fea_1_fcl.weight"), W("machine_actor.m_fea_2_fcl.weight"), e->X);
+    }
+    for (int pass = 0; pass < 3; pass++) {                                    // the SAME GATLayer three times (ac:409-414)
+        GemmArgs a = gemm_args(e->X, 2 * R, WT("machine_actor.gat_layer.W"), nullptr, e->Z);
+        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, a, "gat_gemm");
+        Timed t(e, "gat_combine");
+        hipLaunchKernelGGL(k_gat_combine, dim3(e->num_cu * 2), dim3(256), 0, e->stream, R, e->Z, W("machine_actor.gat_layer.a"), pass == 2 ? 1 : 0,
+                           e->X, e->node, st);
+    }
+    {
+        Timed t(e, "mach_bn_pool");
+        hipLaunchKernelGGL(k_mach_bn_pool, dim3(B), dim3(128), 0, e->stream, B, M, e->node, st, 1.0 / (double)R, W("machine_actor.bn.weight"),
+                           W("machine_actor.bn.bias"), h_pooled);
+    }
+    const float *W0t = WT("machine_actor.m_policy.linears.0.weight");         // node | pooled_m | pooled_o
+    {
+        GemmArgs a = gemm_args(h_pooled, B, W0t + 1 * HD * HD, W("machine_actor.m_policy.linears.0.bias"), e->u);
+        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, a, "head_gemm");
+        GemmArgs b = gemm_args(h_pooled_o, B, W0t + 2 * HD * HD, nullptr, e->u);
+        b.accumulate = 1;
+        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, b, "head_gemm");
+        GemmArgs c = gemm_args(e->node, R, W0t, nullptr, e->s1);
+        c.rowbias = e->u; c.rowbias_div = M;
+        launch_gemm<PRO_PLAIN, EPI_TANH>(e, c, "head_gemm");
+        GemmArgs d = gemm_args(e->s1, R, WT("machine_actor.m_policy.linears.1.weight"), W("machine_actor.m_policy.linears.1.bias"), e->s2);
+        launch_gemm<PRO_PLAIN, EPI_TANH>(e, d, "head_gemm");
+        GemmArgs f = gemm_args(h_pooled, B, WT("machine_actor.machine_critic.linears.0.weight"), W("machine_actor.machine_critic.linears.0.bias"), e->c1);
+        launch_gemm<PRO_PLAIN, EPI_TANH>(e, f, "head_gemm");
+        GemmArgs g = gemm_args(e->c1, B, WT("machine_actor.machine_critic.linears.1.weight"), W("machine_actor.machine_critic.linears.1.bias"), e->c2);
+        launch_gemm<PRO_PLAIN, EPI_TANH>(e, g, "head_gemm");
+    }
+    {
+        Timed t(e, "score_softmax");
+        hipLaunchKernelGGL(k_score_softmax, dim3(B), dim3(64), 0, e->stream, B, M, e->s2, W("machine_actor.m_policy.linears.2.weight"),
+                           W("machine_actor.m_policy.linears.2.bias"), 10.0f, mmask, prob, e->c2, W("machine_actor.machine_critic.linears.2.weight"),
+                           W("machine_actor.machine_critic.linears.2.bias"), machine_v);
+    }
+    HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *prob, int32_t n, int32_t greedy, uint64_t seed, uint64_t counter,
+                                         int32_t *idx_out, float *logp_out, const int32_t *gather_from, int32_t *gathered_out)
+{
+    if (!e || !prob || !idx_out || n < 1) return MTFJSP_ERR_ARG;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    Timed t(e, "sample");
+    const int B = e->cfg.batch;
+    hipLaunchKernelGGL(k_sample, dim3((B + 127) / 128), dim3(128), 0, e->stream, B, n, prob, greedy, seed, counter, idx_out, logp_out, gather_from, gathered_out);
+    HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e)
+{
+    if (!e) return MTFJSP_ERR_ARG;
+    for (auto &kv : e->ev) { for (auto &p : kv.second) e->ev_free.push_back(p); kv.second.clear(); }
+    e->timing = true;
+    return MTFJSP_OK;
+}
+// total over all kernels; per-kernel-family numbers via mtfjsp_encoder_timing_query
+extern "C" int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches)
+{
+    if (!e) return MTFJSP_ERR_ARG;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    double tot = 0; int64_t n = 0;
+    for (auto &kv : e->ev)
+        for (auto &p : kv.second) { float ms = 0; HIPCHK(e, hipEventElapsedTime(&ms, p.first, p.second)); tot += ms; n++; }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = n;
+    e->timing = false;
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_encoder_timing_query(mtfjsp_encoder_t e, const char *family, double *ms_total, int64_t *launches)
+{
+    if (!e || !family) return MTFJSP_ERR_ARG;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    double tot = 0; int64_t n = 0;
+    auto it = e->ev.find(family);
+    if (it != e->ev.end())
+        for (auto &p : it->second) { float ms = 0; HIPCHK(e, hipEventElapsedTime(&ms, p.first, p.second)); tot += ms; n++; }
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = n;
+    return MTFJSP_OK;
+}

@@ -1,0 +1,204 @@
+"""Host side of the encoder half of the C ABI: the job actor (GIN + candidate scorer + local critic) and the
+machine actor (GAT + scorer + local critic) of model/actor_critic.py as HIP kernels (csrc/mtfjsp_encoder.hip).
+
+Weights are addressed by the reference's state_dict key names, so the shipped checkpoints
+(trained_model/can_use/*/PPO_{job,machine}_actor_*.pth -> torch.load -> dict) load unchanged.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import capi
+
+H = 128
+FAMILIES = ["gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg", "job_pool_gather", "head_gemm", "score_softmax",
+            "mach_in", "gat_gemm", "gat_combine", "mach_bn_pool", "sample", "small"]
+
+
+def available():
+    try:
+        capi.lib()
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def random_init_weights(seed=0):
+    """Random weights with the reference modules' default initialisers (nn.Linear: U(+-1/sqrt(in)); BatchNorm: 1/0;
+    `_input`: U(-1,1) ac:76-77; GAT W, a: xavier normal gat:60-66) under the reference's state_dict key names."""
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(out, inp, bias=True):
+        b = 1.0 / math.sqrt(inp)
+        w = (torch.rand(out, inp, generator=g) * 2 - 1) * b
+        return (w, (torch.rand(out, generator=g) * 2 - 1) * b) if bias else (w, None)
+
+    ja, ma = {}, {}
+    pre = "encoder.feature_extract."
+    for l, inp in ((0, 12), (1, H)):
+        for i, (o, k) in enumerate(((H, inp), (H, H), (H, H))):
+            w, b = lin(o, k)
+            ja[f"{pre}mlps.{l}.linears.{i}.weight"], ja[f"{pre}mlps.{l}.linears.{i}.bias"] = w, b
+        for i in range(2):
+            ja[f"{pre}mlps.{l}.batch_norms.{i}.weight"] = torch.ones(H); ja[f"{pre}mlps.{l}.batch_norms.{i}.bias"] = torch.zeros(H)
+        ja[f"{pre}batch_norms.{l}.weight"] = torch.ones(H); ja[f"{pre}batch_norms.{l}.bias"] = torch.zeros(H)
+    ja["_input"] = torch.rand(H, generator=g) * 2 - 1
+    for name, d, out_last in (("o_policy", ja, 1), ("job_critic", ja, 2), ("m_policy", ma, 1), ("machine_critic", ma, 2)):
+        first_in = 3 * H if "policy" in name else H
+        for i, (o, k) in enumerate(((H, first_in), (H, H), (out_last, H))):
+            w, b = lin(o, k)
+            d[f"{name}.linears.{i}.weight"], d[f"{name}.linears.{i}.bias"] = w, b
+    ma["bn.weight"] = torch.ones(H); ma["bn.bias"] = torch.zeros(H)
+    ma["m_fea_1_fcl.weight"] = lin(H, 6, False)[0]; ma["m_fea_2_fcl.weight"] = lin(H, 8, False)[0]
+    ma["gat_layer.W"] = torch.randn(H, H, generator=g) * math.sqrt(2.0 / (H + H))
+    ma["gat_layer.a"] = torch.randn(1, 2 * H, 1, generator=g) * math.sqrt(2.0 / (2 * H + 1 * 1))
+    return {k: v.numpy() for k, v in ja.items()}, {k: v.numpy() for k, v in ma.items()}
+
+
+class Encoder:
+    def __init__(self, n_job, n_machine, batch, device=0, obs_dtype="f32"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("the encoder needs a GPU (MI355X); there is no CPU fallback")
+        self.L = capi.lib()
+        self.J, self.M, self.B = n_job, n_machine, batch
+        self.T = n_job * n_machine
+        self.device = torch.device("cuda", device)
+        self.obs_f32 = obs_dtype in ("f32", torch.float32, np.float32)
+        cfg = capi.EncoderConfig(n_job, n_machine, batch, H, capi.OBS_F32 if self.obs_f32 else capi.OBS_F64, device)
+        h = C.c_void_p()
+        capi.check(self.L.mtfjsp_encoder_create(C.byref(cfg), C.byref(h)), None, enc=True)
+        self.h = h
+        B, J, M = batch, n_job, n_machine
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.job_prob = torch.zeros(B, J, **f32); self.h_pooled_o = torch.zeros(B, H, **f32); self.job_v = torch.zeros(B, 2, **f32)
+        self.mch_prob = torch.zeros(B, M, **f32); self.h_pooled_m = torch.zeros(B, H, **f32); self.mach_v = torch.zeros(B, 2, **f32)
+        self.use_current_stream()
+
+    def use_current_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        capi.check(self.L.mtfjsp_encoder_set_stream(self.h, C.c_void_p(s)), self.h, enc=True)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mtfjsp_encoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weights(self, job_actor, machine_actor):
+        """dicts keyed by the reference's state_dict names (numpy arrays or torch tensors)."""
+        for prefix, d in (("job_actor.", job_actor), ("machine_actor.", machine_actor)):
+            for k, v in d.items():
+                if "running_" in k or "num_batches_tracked" in k:
+                    continue
+                a = v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+                a = np.ascontiguousarray(a, np.float32)
+                capi.check(self.L.mtfjsp_encoder_load_weight_host(self.h, (prefix + k).encode(), a.ctypes.data, a.size), self.h, enc=True)
+        capi.check(self.L.mtfjsp_encoder_weights_ready(self.h), self.h, enc=True)
+
+    def job_actor_forward(self, tasks_fea, ell_col, ell_val, candidate, job_mask, h_m_prev=None, h_nodes=None):
+        """-> (prob [B,J], h_pooled [B,H], job_v [B,2]) device f32 tensors (owned by this object)."""
+        capi.check(self.L.mtfjsp_job_actor_forward(
+            self.h, tasks_fea.data_ptr(), ell_col.data_ptr(), ell_val.data_ptr(), candidate.data_ptr(), job_mask.data_ptr(),
+            h_m_prev.data_ptr() if h_m_prev is not None else 0, self.job_prob.data_ptr(), self.h_pooled_o.data_ptr(),
+            self.job_v.data_ptr(), h_nodes.data_ptr() if h_nodes is not None else 0), self.h, enc=True)
+        return self.job_prob, self.h_pooled_o, self.job_v
+
+    def machine_actor_forward(self, m_fea1, m_fea2, h_pooled_o, mmask):
+        capi.check(self.L.mtfjsp_machine_actor_forward(
+            self.h, m_fea1.data_ptr(), m_fea2.data_ptr(), h_pooled_o.data_ptr(), mmask.data_ptr(), self.mch_prob.data_ptr(),
+            self.h_pooled_m.data_ptr(), self.mach_v.data_ptr()), self.h, enc=True)
+        return self.mch_prob, self.h_pooled_m, self.mach_v
+
+    def sample(self, prob, greedy, seed, counter, idx_out, logp_out=None, gather_from=None, gathered_out=None):
+        capi.check(self.L.mtfjsp_sample_categorical(
+            self.h, prob.data_ptr(), prob.shape[1], int(greedy), seed, counter, idx_out.data_ptr(),
+            logp_out.data_ptr() if logp_out is not None else 0, gather_from.data_ptr() if gather_from is not None else 0,
+            gathered_out.data_ptr() if gathered_out is not None else 0), self.h, enc=True)
+
+    def timing_begin(self):
+        capi.check(self.L.mtfjsp_encoder_timing_begin(self.h), self.h, enc=True)
+
+    def timing_end(self):
+        out = {}
+        for fam in FAMILIES:
+            ms = C.c_double(); n = C.c_int64()
+            capi.check(self.L.mtfjsp_encoder_timing_query(self.h, fam.encode(), C.byref(ms), C.byref(n)), self.h, enc=True)
+            if n.value:
+                out[fam] = {"ms_total": ms.value, "launches": n.value}
+        ms = C.c_double(); n = C.c_int64()
+        capi.check(self.L.mtfjsp_encoder_timing_end(self.h, C.byref(ms), C.byref(n)), self.h, enc=True)
+        return out
+
+
+class ActorPair:
+    """The two actors wired as Run.py:290-412 wires them: the job actor sees the machine actor's graph embedding of the
+    previous step (the learned `_input` on the first step of an episode), the machine actor sees the job actor's of this step."""
+
+    def __init__(self, n_job, n_machine, batch, device=0, obs_dtype="f32", weights=None, greedy=False, seed=0):
+        self.enc = Encoder(n_job, n_machine, batch, device=device, obs_dtype=obs_dtype)
+        ja, ma = weights if weights is not None else random_init_weights(seed)
+        self.enc.load_weights(ja, ma)
+        self.greedy, self.seed = greedy, seed
+        dev = self.enc.device
+        self.job_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.mch_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
+        self.have_hm = False
+
+    def begin_episode(self):
+        self.have_hm = False                                    # run:280 h_mch_pooled = None
+
+    def act(self, env, counter, task_idx, mach_idx, job_idx):
+        e = self.enc
+        prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask,
+                                           e.h_pooled_m if self.have_hm else None)
+        e.sample(prob, self.greedy, self.seed, 2 * counter, job_idx, self.job_logp, env.candidate, task_idx)
+        env.observe_mfea1(task_idx)                             # -> env.m_fea1, env.mmask
+        mprob, _, _ = e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask)
+        e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, self.mch_logp)
+        self.have_hm = True
+
+    def timing_begin(self):
+        self.enc.timing_begin()
+
+    def timing_end(self):
+        return self.enc.timing_end()
+
+    def roofline(self, name, kd, B):
+        """f32 MFMA roofline for the GEMM families; HBM for the rest."""
+        J, M, T = self.enc.J, self.enc.M, self.enc.T
+        avg_s = kd["ms_total"] / max(kd["launches"], 1) * 1e-3
+        rows = {"gin_gemm_bn_relu": B * T, "gin_gemm_agg": B * T, "gat_gemm": 2 * B * M}.get(name)
+        if rows is not None:
+            flops = 2.0 * rows * H * H
+            ach = flops / avg_s / 1e12
+            return {"kernel": f"k_gemm128<{name}> ([{rows},128]x[128,128] f32 MFMA 32x32x2, fused BN/aggregation prologue + stats epilogue)",
+                    "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
+                    "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_flops_per_launch": flops,
+                    "hbm_GBps_same_launch": rows * H * 4 * 2 / avg_s / 1e9}
+        return {"kernel": name, "bound": "hbm", "achieved": None, "peak": 8000.0, "unit": "GB/s", "frac": None, "traffic": None,
+                "avg_launch_us": avg_s * 1e6, "launches": kd["launches"]}
+
+
+def smoke():
+    """tiny forward of both actors on cuda:0 (shape/finite check; parity is in tests/test_encoder_hip.py)."""
+    from .batch_env import DeviceBatchEnv
+    from .instances import generate_instances, random_weights
+    J, M, E, B = 6, 6, 2, 8
+    t, p, tt, edge = generate_instances(B, J, M, E, seed=0)
+    env = DeviceBatchEnv(J, M, E, B, obs_dtype="f32")
+    env.load_instances(t, p, tt, edge=edge); env.scaler_init(); env.reset(random_weights(B))
+    ap = ActorPair(J, M, B, obs_dtype="f32", seed=0)
+    a = torch.zeros(B, dtype=torch.int32, device=env.device); m = torch.zeros_like(a); j = torch.zeros_like(a)
+    for s in range(J * M):
+        ap.act(env, s, a, m, j)
+        env.step(a, m)
+    torch.cuda.synchronize()
+    assert bool(env.info[:, 1].all()) and int((env.status & capi.ST_INVALID).sum()) == 0
+    assert torch.isfinite(ap.enc.job_prob).all() and torch.isfinite(ap.enc.mch_prob).all()

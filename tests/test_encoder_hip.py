@@ -1,0 +1,92 @@
+"""PARITY (GPU): HIP job-actor / machine-actor forwards vs (a) the reference modules' own outputs stored in
+tests/golden/encoder_*.npz and (b) the fp32 oracle restatement.
+
+Tolerances (floating-point kernel; SURVEY.md §7 'f64 vs f32'): probabilities 1e-4 absolute, embeddings 1e-4 of the
+tensor's scale, critic values 1e-3 relative (+1e-3 abs).  Greedy decisions must be identical.
+"""
+import os
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _t(x, dt=None):
+    import torch
+    t = torch.as_tensor(np.ascontiguousarray(x)).cuda()
+    return t.to(dt) if dt is not None else t
+
+
+@pytest.mark.parametrize("name", ["encoder_j6m6e2_top1", "encoder_j6m6e2_rand"])
+@pytest.mark.parametrize("obs", ["f64", "f32"])
+def test_actor_forwards_match_reference_outputs(name, obs):
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    from oracle import encoder_oracle as eo
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    J, M, E, B = [int(x) for x in g["meta"]]
+    T = J * M
+    ja, ma = eo.split_weights(g)
+    enc = enc_mod.Encoder(J, M, B, obs_dtype=obs)
+    enc.load_weights(ja, ma)
+    odt = torch.float32 if obs == "f32" else torch.float64
+    for s in g["steps"]:
+        p = f"s{int(s)}_"
+        col, val = eo.ell_from_dense(g[p + "adj"])
+        h_nodes = torch.zeros(B * T, 128, dtype=torch.float32, device="cuda")
+        hm_in = g[p + "h_m_in"]
+        prob, h_o, job_v = enc.job_actor_forward(
+            _t(g[p + "tfea"], odt), _t(col.reshape(B * T, 2).astype(np.int32)), _t(val.reshape(B * T, 2).astype(np.float32)),
+            _t(g[p + "cand"].astype(np.int32)), _t(g[p + "mask"].astype(np.uint8)),
+            None if hm_in.size == 0 else _t(hm_in.astype(np.float32)), h_nodes=h_nodes)
+        torch.cuda.synchronize()
+        prob, h_o, job_v, hn = prob.cpu().numpy(), h_o.cpu().numpy(), job_v.cpu().numpy(), h_nodes.cpu().numpy()
+        scale = max(1.0, float(np.abs(g[p + "h_nodes"]).max()))
+        np.testing.assert_allclose(hn, g[p + "h_nodes"], rtol=0, atol=1e-4 * scale)
+        np.testing.assert_allclose(h_o, g[p + "h_o"], rtol=0, atol=1e-4 * scale)
+        np.testing.assert_allclose(prob, g[p + "job_prob"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(job_v, g[p + "job_v"], rtol=1e-3, atol=1e-3)
+        assert np.array_equal(prob.argmax(1), g[p + "job_index"])
+        # oracle restatement agrees as well (same inputs)
+        o = eo.job_actor_forward(ja, g[p + "tfea"], col, val, g[p + "cand"], g[p + "mask"], hm_in, B, T)
+        np.testing.assert_allclose(prob, o["prob"], rtol=0, atol=1e-4)
+        # greedy sampling kernel == agent_func.greedy_select_action
+        idx = torch.zeros(B, dtype=torch.int32, device="cuda"); task = torch.zeros_like(idx); logp = torch.zeros(B, device="cuda")
+        enc.sample(enc.job_prob, True, 0, 0, idx, logp, _t(g[p + "cand"].astype(np.int32)), task)
+        assert np.array_equal(idx.cpu().numpy(), g[p + "job_index"]) and np.array_equal(task.cpu().numpy(), g[p + "task_index"])
+        np.testing.assert_allclose(logp.cpu().numpy(), g[p + "job_logp"], rtol=0, atol=1e-4)
+        # machine actor, fed with the reference's own job embedding
+        mprob, h_m, mach_v = enc.machine_actor_forward(_t(g[p + "mfea1"], odt), _t(g[p + "mfea2"], odt), _t(g[p + "h_o"].astype(np.float32)),
+                                                       _t(g[p + "mmask"].reshape(B, M).astype(np.uint8)))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(mprob.cpu().numpy(), g[p + "mch_prob"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(h_m.cpu().numpy(), g[p + "h_m"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(mach_v.cpu().numpy(), g[p + "mach_v"], rtol=1e-3, atol=1e-3)
+
+
+def test_sampling_follows_the_distribution():
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    B = 4096
+    enc = enc_mod.Encoder(6, 6, B)
+    p = torch.tensor([0.5, 0.0, 0.25, 0.125, 0.125, 0.0], device="cuda").repeat(B, 1).contiguous()
+    idx = torch.zeros(B, dtype=torch.int32, device="cuda"); logp = torch.zeros(B, device="cuda")
+    counts = np.zeros(6)
+    for c in range(20):
+        enc.sample(p, False, 99, c, idx, logp)
+        counts += np.bincount(idx.cpu().numpy(), minlength=6)
+    freq = counts / counts.sum()
+    assert counts[1] == 0 and counts[5] == 0
+    np.testing.assert_allclose(freq, [0.5, 0, 0.25, 0.125, 0.125, 0], atol=0.01)
+    np.testing.assert_allclose(logp.cpu().numpy(), np.log(p.cpu().numpy()[np.arange(B), idx.cpu().numpy()]), atol=1e-6)
+
+
+def test_full_rollout_with_actors_runs_clean():
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    enc_mod.smoke()
