@@ -1,0 +1,65 @@
+"""Multi-GPU: one process per GPU, instances sharded in contiguous blocks, no collective on the env/encoder path.
+
+The only exchange of the rollout->update hand-off is the all-gather of per-shard advantages/returns before the global
+advantage normalisation `(adv - mean) / (std + 1e-5)` of ppo:485,532 (RCCL over xGMI on the GPU box — backend "nccl";
+gloo in the CPU tests).  GAE itself (ppo:438-536) is a reverse scan over the S stored steps and is per-instance,
+so it runs on each shard locally.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, rank, world):
+    """contiguous block of instances owned by `rank` (rows [B_local*g, B_local*(g+1)))."""
+    if total % world:
+        raise ValueError("instances must divide evenly over the GPUs")
+    per = total // world
+    return rank * per, (rank + 1) * per
+
+
+def gae(rewards, values, next_values, dones, gamma, lam):
+    """ppo:444-457 / 500-510: delta = r + gamma*v' - v ; gae_t = delta_t + gamma*lam*gae_{t+1}*(1-done_t).
+    All [S,B_local]; returns the UN-normalised advantages [S,B_local]."""
+    deltas = rewards + gamma * next_values - values
+    adv = torch.empty_like(deltas)
+    g = torch.zeros_like(deltas[0])
+    for t in range(deltas.shape[0] - 1, -1, -1):
+        g = deltas[t] + gamma * lam * g * (1.0 - dones[t])
+        adv[t] = g
+    return adv
+
+
+def all_gather_columns(x, group=None):
+    """[S,B_local] on every rank -> [S,B_total] (rank-major column blocks) on every rank."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x
+    world = dist.get_world_size(group)
+    xs = x.contiguous()
+    out = torch.empty((world * xs.shape[0],) + tuple(xs.shape[1:]), dtype=xs.dtype, device=xs.device)   # dim-0 concat form
+    dist.all_gather_into_tensor(out, xs, group=group)
+    out = out.view((world,) + tuple(xs.shape))
+    return torch.cat(list(out.unbind(0)), dim=1)
+
+
+def all_gather_advantages(tensors, group=None):
+    """One collective for a list of [S,B_local] tensors (4 global + 4 local advantages and their 8 value targets in
+    the reference's update): packed into a single [K,S,B_local] buffer so that xGMI sees one large all-gather."""
+    if not tensors:
+        return []
+    packed = torch.stack([t.contiguous() for t in tensors], 0)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return list(packed.unbind(0))
+    world = dist.get_world_size(group)
+    out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    out = out.view((world,) + tuple(packed.shape))
+    full = torch.cat(list(out.unbind(0)), dim=2)          # [K,S,B_total]
+    return list(full.unbind(0))
+
+
+def normalize_advantages_global(adv_local, group=None, eps=1e-5):
+    """`(adv - adv.mean()) / (adv.std() + 1e-5)` over the GLOBAL [S,B_total] tensor (unbiased std, as torch's default in
+    ppo:485), returning this rank's columns."""
+    full = all_gather_columns(adv_local, group)
+    mean, std = full.mean(), full.std()
+    return (adv_local - mean) / (std + eps)
