@@ -40,5 +40,16 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_variant(tag, extra_flags, verbose=False):
+    """diagnostic builds (never used by the product path): libmtfjsp_<tag>.so, selected with MTFJSP_LIB=<path>"""
+    out = os.path.join(PKG, f"libmtfjsp_{tag}.so")
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc()] + FLAGS + list(extra_flags) + srcs + ["-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))

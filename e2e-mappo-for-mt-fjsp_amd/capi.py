@@ -76,7 +76,7 @@ PROTOTYPES = {
 
 
 def lib_path():
-    return _build.LIB
+    return os.environ.get("MTFJSP_LIB") or _build.LIB          # MTFJSP_LIB: diagnostic builds only (tools/)
 
 
 def lib():

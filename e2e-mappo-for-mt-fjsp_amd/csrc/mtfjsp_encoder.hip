@@ -17,6 +17,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <map>
 #include <string>
@@ -50,6 +52,8 @@ struct GemmArgs {
     const float *rowbias;   // optional [N/rowbias_div,128] added to row r: rowbias[(r / rowbias_div)]
     int rowbias_div;
     int accumulate;         // C initialised from `out` (K > 128 as a sum of 128-wide GEMMs)
+    unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
+    int dbg;                // timing-only ablation bits (MTFJSP_GEMM_DBG): 1 skip prologue loads, 2 skip MFMA, 4 skip epilogue stores
 };
 
 __device__ __forceinline__ float bn_relu(float x, float mean, float rstd, float g, float b)
@@ -57,6 +61,20 @@ __device__ __forceinline__ float bn_relu(float x, float mean, float rstd, float 
     float y = (x - mean) * rstd * g + b;
     return y > 0.f ? y : 0.f;
 }
+
+#ifdef MTFJSP_STAMP
+#define STAMP(slot)                                                                      \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        unsigned long long t_;                                                           \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        ph[slot] += t_ - t_last; t_last = t_;                                            \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+#define STAT_REP 8            // replicated BatchNorm accumulators: <=32 adders per address keeps f64 atomics at full rate
 
 template <int PRO, int EPI>
 __global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
@@ -68,6 +86,10 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
     double *s_red = reinterpret_cast<double *>(s_bn + 4 * HD);    // 4 waves * 256
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
+#ifdef MTFJSP_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
 
     {   // W^T -> LDS (coalesced float4)
         const float4 *src = reinterpret_cast<const float4 *>(A.Wt);
@@ -75,8 +97,10 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
         for (int i = tid; i < HD * HD / 4; i += 256) dst[i] = src[i];
     }
     if (PRO != PRO_PLAIN && tid < HD) {
-        const double mean = A.pro_stats[tid] * A.pro_inv_rows;
-        double var = A.pro_stats[HD + tid] * A.pro_inv_rows - mean * mean;      // biased variance (training-mode BN)
+        double su = 0, sq = 0;
+        for (int r = 0; r < STAT_REP; r++) { su += A.pro_stats[r * 256 + tid]; sq += A.pro_stats[r * 256 + HD + tid]; }
+        const double mean = su * A.pro_inv_rows;
+        double var = sq * A.pro_inv_rows - mean * mean;           // biased variance (training-mode BN)
         if (var < 0) var = 0;
         s_bn[tid] = (float)mean;
         s_bn[HD + tid] = (float)(1.0 / sqrt(var + BN_EPS));
@@ -84,102 +108,138 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
         s_bn[3 * HD + tid] = A.pro_beta[tid];
     }
     __syncthreads();
-
+    STAMP(0);
+    // From here on the four waves never synchronise again: each owns its LDS tile, LDS operations of one wave
+    // execute in issue order, and the waves are free to drift apart so that one wave's loads/stores overlap
+    // another's MFMA phase (they would otherwise hit HBM in lock-step bursts).
     float *my_a = s_a + wave * 32 * LDA;
     const int ntiles = (A.N + 31) / 32;
     const int stride = gridDim.x * 4;
-    const int iters = (ntiles + stride - 1) / stride;
     double st_sum[4] = {0, 0, 0, 0}, st_sq[4] = {0, 0, 0, 0};   // per column block (lane j, block cb), EPI_STATS
     const int c4 = j * 4;
     float mean4[4], rstd4[4], g4[4], b4[4];
     if (PRO != PRO_PLAIN)
         for (int q = 0; q < 4; q++) { mean4[q] = s_bn[c4 + q]; rstd4[q] = s_bn[HD + c4 + q]; g4[q] = s_bn[2 * HD + c4 + q]; b4[q] = s_bn[3 * HD + c4 + q]; }
 
-    for (int it = 0; it < iters; it++) {
-        const int tile = (blockIdx.x * 4 + wave) + it * stride;
-        const bool live = tile < ntiles;
+    float bias4[4];                                               // hoisted: a load inside the epilogue would force vmcnt(0)
+    for (int cb = 0; cb < 4; cb++) bias4[cb] = (A.bias && !A.accumulate) ? A.bias[cb * 32 + j] : 0.f;
+    float4 pre[16];                                               // raw rows of the NEXT tile, in flight during the MFMA phase
+    int2 pre_c[PRO == PRO_AGG ? 16 : 1];
+    float2 pre_v[PRO == PRO_AGG ? 16 : 1];
+    auto prefetch = [&](int tile) {
         const int row0 = tile * 32;
-        // ------------------------------------------------------------------ prologue -> LDS tile
-        if (live) {
-            for (int p = 0; p < 16; p++) {
-                const int r = 2 * p + h;
-                const int g = row0 + r;
-                float v[4] = {0.f, 0.f, 0.f, 0.f};
-                if (g < A.N) {
-                    const float4 x = *reinterpret_cast<const float4 *>(A.in + (size_t)g * HD + c4);
-                    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
-                    if (PRO == PRO_BNRELU) {
-                        for (int q = 0; q < 4; q++) v[q] = bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
-                    } else if (PRO == PRO_AGG) {
-                        // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
-                        double acc[4];
-                        for (int q = 0; q < 4; q++) acc[q] = (double)bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
-                        const int2 cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2);
-                        const float2 vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2);
-                        const int base = (g / A.T) * A.T;
-                        int deg = 1;
-                        if (cc.x >= 0) {
-                            const float4 y = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.x) * HD + c4);
-                            const float yy[4] = {y.x, y.y, y.z, y.w};
-                            for (int q = 0; q < 4; q++) acc[q] += (double)vv.x * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
-                            deg++;
-                        }
-                        if (cc.y >= 0) {
-                            const float4 y = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.y) * HD + c4);
-                            const float yy[4] = {y.x, y.y, y.z, y.w};
-                            for (int q = 0; q < 4; q++) acc[q] += (double)vv.y * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
-                            deg++;
-                        }
-                        for (int q = 0; q < 4; q++) v[q] = (float)(acc[q] / (double)deg);
-                    }
-                }
-                float *d = my_a + r * LDA + c4;
-                d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            const int g = row0 + 2 * p + h;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < A.N && !(A.dbg & 1)) x = *reinterpret_cast<const float4 *>(A.in + (size_t)g * HD + c4);
+            pre[p] = x;
+            if (PRO == PRO_AGG) {
+                int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
+                if (g < A.N) { cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
+                pre_c[p] = cc; pre_v[p] = vv;
             }
         }
-        __syncthreads();
+    };
+    int tile = blockIdx.x * 4 + wave;
+    if (tile < ntiles) prefetch(tile);
+    STAMP(1);
+    for (; tile < ntiles; tile += stride) {
+        const int row0 = tile * 32;
+        // ------------------------------------------------------------------ transform the prefetched rows -> LDS tile
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            const int r = 2 * p + h;
+            const int g = row0 + r;
+            float v[4] = {pre[p].x, pre[p].y, pre[p].z, pre[p].w};
+            if (g < A.N) {
+                if (PRO == PRO_BNRELU) {
+                    for (int q = 0; q < 4; q++) v[q] = bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
+                } else if (PRO == PRO_AGG) {
+                    // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
+                    double acc[4];
+                    for (int q = 0; q < 4; q++) acc[q] = (double)bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
+                    const int2 cc = pre_c[p];
+                    const float2 vv = pre_v[p];
+                    const int base = (g / A.T) * A.T;
+                    int deg = 1;
+                    if (cc.x >= 0) {
+                        const float4 y = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.x) * HD + c4);
+                        const float yy[4] = {y.x, y.y, y.z, y.w};
+                        for (int q = 0; q < 4; q++) acc[q] += (double)vv.x * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
+                        deg++;
+                    }
+                    if (cc.y >= 0) {
+                        const float4 y = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.y) * HD + c4);
+                        const float yy[4] = {y.x, y.y, y.z, y.w};
+                        for (int q = 0; q < 4; q++) acc[q] += (double)vv.y * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
+                        deg++;
+                    }
+                    for (int q = 0; q < 4; q++) v[q] = (float)(acc[q] / (double)deg);
+                }
+            }
+            float *d = my_a + r * LDA + c4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // tile complete before this wave reads it back (also a compiler fence)
+        STAMP(2);
+        if (tile + stride < ntiles) prefetch(tile + stride);      // asynchronous: lands while the matrix cores run
+        STAMP(3);
         // ------------------------------------------------------------------ main loop
         f32x16 acc[4];
         for (int cb = 0; cb < 4; cb++)
             for (int i = 0; i < 16; i++) acc[cb][i] = 0.f;
-        if (live) {
-            if (A.accumulate) {
-                for (int cb = 0; cb < 4; cb++)
-                    for (int i = 0; i < 16; i++) {
-                        const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                        if (r < A.N) acc[cb][i] = A.out[(size_t)r * HD + cb * 32 + j];
-                    }
-            }
-            const float *ap = my_a + j * LDA + 64 * h;            // A[row j][k = 64h + s]
-            const float *bp = s_w + (64 * h) * HD + j;            // B[k = 64h + s][col cb*32 + j]
-#pragma unroll 4
-            for (int s = 0; s < 64; s++) {
-                const float a = ap[s];
-                const float b0 = bp[s * HD], b1 = bp[s * HD + 32], b2 = bp[s * HD + 64], b3 = bp[s * HD + 96];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
-                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
-            }
-            // -------------------------------------------------------------- epilogue
-            for (int cb = 0; cb < 4; cb++) {
-                const int col = cb * 32 + j;
-                const float bias = (A.bias && !A.accumulate) ? A.bias[col] : 0.f;
-                float ts = 0.f, tq = 0.f;
+        if (A.accumulate) {
+            for (int cb = 0; cb < 4; cb++)
                 for (int i = 0; i < 16; i++) {
                     const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (r < A.N) {
-                        float v = acc[cb][i] + bias;
-                        if (A.rowbias) v += A.rowbias[(size_t)(r / A.rowbias_div) * HD + col];
-                        if (EPI == EPI_TANH) v = tanhf(v);
-                        A.out[(size_t)r * HD + col] = v;
-                        if (EPI == EPI_STATS) { ts += v; tq += v * v; }
-                    }
+                    if (r < A.N) acc[cb][i] = A.out[(size_t)r * HD + cb * 32 + j];
                 }
-                if (EPI == EPI_STATS) { st_sum[cb] += (double)ts; st_sq[cb] += (double)tq; }
+        }
+        // per-instance row bias (scorer input thirds computed once per instance): fetched BEFORE the matrix phase so the
+        // epilogue issues stores only (vmcnt is in-order: any load there would wait for every store before it)
+        float rb[4][16];
+        if (A.rowbias) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                const float *rp = A.rowbias + (size_t)((r < A.N ? r : 0) / A.rowbias_div) * HD + j;
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++) rb[cb][i] = rp[cb * 32];
             }
         }
-        __syncthreads();
+        const float *ap = my_a + j * LDA + 64 * h;                // A[row j][k = 64h + s]
+        const float *bp = s_w + (64 * h) * HD + j;                // B[k = 64h + s][col cb*32 + j]
+#pragma unroll 8
+        for (int s = 0; s < 64; s++) {
+            const float a = ap[s];
+            const float b0 = bp[s * HD], b1 = bp[s * HD + 32], b2 = bp[s * HD + 64], b3 = bp[s * HD + 96];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");                            // keep next iteration's LDS writes behind these reads
+        STAMP(4);
+        // ------------------------------------------------------------------ epilogue
+        for (int cb = 0; cb < 4; cb++) {
+            const int col = cb * 32 + j;
+            const float bias = bias4[cb];
+            float ts = 0.f, tq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (r < A.N && !(A.dbg & 4)) {
+                    float v = acc[cb][i] + bias;
+                    if (A.rowbias) v += rb[cb][i];
+                    if (EPI == EPI_TANH) v = tanhf(v);
+                    A.out[(size_t)r * HD + col] = v;
+                    if (EPI == EPI_STATS) { ts += v; tq += v * v; }
+                }
+            }
+            if (EPI == EPI_STATS) { st_sum[cb] += (double)ts; st_sq[cb] += (double)tq; }
+        }
+        STAMP(5);
     }
     if (EPI == EPI_STATS) {
         for (int cb = 0; cb < 4; cb++) {
@@ -189,11 +249,15 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
             if (h == 0) { s_red[wave * 256 + cb * 32 + j] = a; s_red[wave * 256 + HD + cb * 32 + j] = q; }
         }
         __syncthreads();
-        if (tid < 256) {
-            const double v = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
-            atomicAdd(&A.epi_stats[tid], v);
-        }
+        const double v = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
+        atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
     }
+#ifdef MTFJSP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(6);
+    if (A.stamps && lane == 0)
+        for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
+#endif
 }
 static size_t gemm_lds_bytes() { return (size_t)(HD * HD + 4 * 32 * LDA + 4 * HD) * 4 + 4 * 256 * 8; }
 
@@ -204,6 +268,7 @@ template <typename OBS>
 __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, const int *ell_col, const float *ell_val,
                                               const float *W /*[128,12]*/, const float *bias, float *out, double *stats)
 {
+    stats += (blockIdx.x % STAT_REP) * 256;
     __shared__ float s_p[32 * 12];
     const int tid = threadIdx.x, c = tid & 127, half = tid >> 7;
     float w[12];
@@ -252,8 +317,10 @@ __global__ __launch_bounds__(128) void k_job_pool_gather(int B, int T, int J, co
                                                         float *h_pooled, float *cand_feat, float *h_nodes)
 {
     const int b = blockIdx.x, c = threadIdx.x;
-    const double mean_d = stats[c] * inv_rows;
-    double var = stats[HD + c] * inv_rows - mean_d * mean_d;
+    double su = 0, sq = 0;
+    for (int r = 0; r < STAT_REP; r++) { su += stats[r * 256 + c]; sq += stats[r * 256 + HD + c]; }
+    const double mean_d = su * inv_rows;
+    double var = sq * inv_rows - mean_d * mean_d;
     if (var < 0) var = 0;
     const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + BN_EPS)), g = gamma[c], be = beta[c];
     float acc = 0.f;
@@ -362,7 +429,7 @@ __global__ __launch_bounds__(256) void k_gat_combine(int rows, const float *Z /*
         s_red[wave * 256 + 128 + lane] = ssq0; s_red[wave * 256 + 192 + lane] = ssq1;
         __syncthreads();
         const double v = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
-        atomicAdd(&stats[tid], v);
+        atomicAdd(&stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
     }
 }
 
@@ -371,8 +438,10 @@ __global__ __launch_bounds__(128) void k_mach_bn_pool(int B, int M, float *node 
                                                      const float *gamma, const float *beta, float *h_pooled)
 {
     const int b = blockIdx.x, c = threadIdx.x;
-    const double mean_d = stats[c] * inv_rows;
-    double var = stats[HD + c] * inv_rows - mean_d * mean_d;
+    double su = 0, sq = 0;
+    for (int r = 0; r < STAT_REP; r++) { su += stats[r * 256 + c]; sq += stats[r * 256 + HD + c]; }
+    const double mean_d = su * inv_rows;
+    double var = sq * inv_rows - mean_d * mean_d;
     if (var < 0) var = 0;
     const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + BN_EPS)), g = gamma[c], be = beta[c];
     float acc = 0.f;
@@ -527,7 +596,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     rc |= dalloc(e, &e->u, B * HD); rc |= dalloc(e, &e->c1, B * HD); rc |= dalloc(e, &e->c2, B * HD); rc |= dalloc(e, &e->hm_b, B * HD);
     rc |= dalloc(e, &e->pooled_int, B * HD);
     rc |= dalloc(e, &e->X, 2 * B * M * HD); rc |= dalloc(e, &e->Z, 2 * B * M * HD); rc |= dalloc(e, &e->node, B * M * HD);
-    rc |= dalloc(e, &e->stats, 8 * 256);
+    rc |= dalloc(e, &e->stats, 8 * STAT_REP * 256);
     if (rc) { g_enc_err = e->err; mtfjsp_encoder_destroy(e); return MTFJSP_ERR_HIP; }
     const int lds = (int)gemm_lds_bytes();
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -611,13 +680,34 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
     const int ntiles = (a.N + 31) / 32;
     int grid = (ntiles + 3) / 4;
     if (grid > e->num_cu) grid = e->num_cu;
+#ifdef MTFJSP_STAMP
+    static unsigned long long *d_st = nullptr;
+    if (!d_st) (void)hipMalloc((void **)&d_st, 1024 * 8 * 8);
+    (void)hipMemsetAsync(d_st, 0, 1024 * 8 * 8, e->stream);
+    GemmArgs b = a; b.stamps = d_st;
+    hipLaunchKernelGGL((k_gemm128<PRO, EPI>), dim3(grid), dim3(256), gemm_lds_bytes(), e->stream, b);
+    static int printed = 0;
+    if (printed < 40 && getenv("MTFJSP_STAMP_PRINT")) {
+        (void)hipStreamSynchronize(e->stream);
+        std::vector<unsigned long long> hst(1024 * 8);
+        (void)hipMemcpy(hst.data(), d_st, 1024 * 8 * 8, hipMemcpyDeviceToHost);
+        double m[8] = {0};
+        for (int w = 0; w < grid * 4; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i] / (grid * 4);
+        printf("STAMP %-18s N=%d grid=%d  Wload %.0f  prefetch0 %.0f  transform %.0f  prefetch %.0f  mfma %.0f  epilogue %.0f  tail %.0f (cycles/wave, summed over its tiles)\n",
+               name, a.N, grid, m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+        printed++;
+    }
+#else
     hipLaunchKernelGGL((k_gemm128<PRO, EPI>), dim3(grid), dim3(256), gemm_lds_bytes(), e->stream, a);
+#endif
 }
 
 static GemmArgs gemm_args(const float *in, int N, const float *Wt, const float *bias, float *out)
 {
     GemmArgs a{};
     a.in = in; a.N = N; a.Wt = Wt; a.bias = bias; a.out = out; a.rowbias_div = 1;
+    static const int dbg = getenv("MTFJSP_GEMM_DBG") ? atoi(getenv("MTFJSP_GEMM_DBG")) : 0;
+    a.dbg = dbg;
     return a;
 }
 
@@ -634,38 +724,38 @@ extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fe
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
     double *st = e->stats;
-    HIPCHK(e, hipMemsetAsync(st, 0, 8 * 256 * sizeof(double), e->stream));
+    HIPCHK(e, hipMemsetAsync(st, 0, 6 * STAT_REP * 256 * sizeof(double), e->stream));
     const double invN = 1.0 / (double)N;
     const int pgrid = e->num_cu * 4;
     {   // layer 0 / linear 0 with aggregation of the raw features
         Timed t(e, "gin0_agg_linear12");
         if (e->cfg.obs_dtype == MTFJSP_OBS_F32)
             hipLaunchKernelGGL((k_gin0<float>), dim3(pgrid), dim3(256), 0, e->stream, N, T, (const float *)tasks_fea, ell_col, ell_val,
-                               W(P + "mlps.0.linears.0.weight"), W(P + "mlps.0.linears.0.bias"), e->zA, st + 0 * 256);
+                               W(P + "mlps.0.linears.0.weight"), W(P + "mlps.0.linears.0.bias"), e->zA, st + 0 * STAT_REP * 256);
         else
             hipLaunchKernelGGL((k_gin0<double>), dim3(pgrid), dim3(256), 0, e->stream, N, T, (const double *)tasks_fea, ell_col, ell_val,
-                               W(P + "mlps.0.linears.0.weight"), W(P + "mlps.0.linears.0.bias"), e->zA, st + 0 * 256);
+                               W(P + "mlps.0.linears.0.weight"), W(P + "mlps.0.linears.0.bias"), e->zA, st + 0 * STAT_REP * 256);
     }
     auto bn_gemm = [&](const float *in, float *out, int sin, const std::string &bn, const std::string &lin, int sout) {
         GemmArgs a = gemm_args(in, N, WT(P + lin + ".weight"), W(P + lin + ".bias"), out);
-        a.pro_stats = st + sin * 256; a.pro_gamma = W(P + bn + ".weight"); a.pro_beta = W(P + bn + ".bias"); a.pro_inv_rows = invN;
-        a.epi_stats = st + sout * 256;
+        a.pro_stats = st + sin * STAT_REP * 256; a.pro_gamma = W(P + bn + ".weight"); a.pro_beta = W(P + bn + ".bias"); a.pro_inv_rows = invN;
+        a.epi_stats = st + sout * STAT_REP * 256;
         launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_bn_relu");
     };
     bn_gemm(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1);
     bn_gemm(e->zB, e->zA, 1, "mlps.0.batch_norms.1", "mlps.0.linears.2", 2);
     {   // layer 1 / linear 0: aggregation of h = relu(bn_outer0(z)) over the ELL adjacency
         GemmArgs a = gemm_args(e->zA, N, WT(P + "mlps.1.linears.0.weight"), W(P + "mlps.1.linears.0.bias"), e->zB);
-        a.pro_stats = st + 2 * 256; a.pro_gamma = W(P + "batch_norms.0.weight"); a.pro_beta = W(P + "batch_norms.0.bias"); a.pro_inv_rows = invN;
+        a.pro_stats = st + 2 * STAT_REP * 256; a.pro_gamma = W(P + "batch_norms.0.weight"); a.pro_beta = W(P + "batch_norms.0.bias"); a.pro_inv_rows = invN;
         a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
-        a.epi_stats = st + 3 * 256;
+        a.epi_stats = st + 3 * STAT_REP * 256;
         launch_gemm<PRO_AGG, EPI_STATS>(e, a, "gin_gemm_agg");
     }
     bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4);
     bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5);
     {
         Timed t(e, "job_pool_gather");
-        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(128), 0, e->stream, B, T, J, e->zB, st + 5 * 256, invN,
+        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(128), 0, e->stream, B, T, J, e->zB, st + 5 * STAT_REP * 256, invN,
                            W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, e->cand_feat, h_nodes);
     }
     // ---- heads (ac:205-293): score = L2 tanh(L1 tanh(Wa cand + Wb pooled + Wc hm + b0))
@@ -712,8 +802,8 @@ extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fe
     const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
-    double *st = e->stats + 6 * 256;
-    HIPCHK(e, hipMemsetAsync(st, 0, 256 * sizeof(double), e->stream));
+    double *st = e->stats + 6 * STAT_REP * 256;
+    HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
     {
         Timed t(e, "mach_in");
         const size_t n = (size_t)R * HD;
