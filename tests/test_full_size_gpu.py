@@ -1,0 +1,138 @@
+"""PARITY at BASELINE.json's full sizes (GPU): the HIP path vs the C oracle on the SAME seeded inputs and on-device
+random valid actions, plus size-independent properties of a finished schedule.
+
+J6M6E2 x 4096 and J10M10E2 x 8192: every instance is replayed through the oracle (it is fast enough);
+J20M20E4 x 2048 (one GPU's shard of configs[4]): a strided sample of instances is replayed.
+Integer state bit-exact; floats bit-exact as well (same binary64 operation order)."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(J, M, E, B, sample_stride, seed):
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    batch_env = import_module("e2e-mappo-for-mt-fjsp_amd.batch_env")
+    inst = import_module("e2e-mappo-for-mt-fjsp_amd.instances")
+    capi = import_module("e2e-mappo-for-mt-fjsp_amd.capi")
+    from oracle.env_oracle import OracleBatch
+    T = J * M
+    base = min(B, 128)
+    t, p, tt, edge = inst.generate_instances(base, J, M, E, seed)
+    rep = (B + base - 1) // base
+    t, p, tt, edge = [np.concatenate([x] * rep)[:B] for x in (t, p, tt, edge)]
+    rs = np.random.RandomState(seed)
+    w3 = rs.dirichlet([1, 1, 1], size=B)
+    env = batch_env.DeviceBatchEnv(J, M, E, B, obs_dtype="f64")
+    env.load_instances(t, p, tt, edge=edge)
+    env.scaler_init(); env.reset(w3)
+    sel = np.arange(0, B, sample_stride)
+    orc = OracleBatch(t[sel], p[sel], tt[sel], edge[sel])
+    orc.scaler_init(); orc.reset(w3[sel])
+    a = torch.zeros(B, dtype=torch.int32, device=env.device); m = torch.zeros_like(a); j = torch.zeros_like(a)
+    raw_sum = np.zeros((B, 5))
+    prev0 = env.read_state(capi.STATE_PREV_COSTS).copy()
+    for s in range(T):
+        env.random_actions(1234 + seed, s, a, m, j)
+        env.step(a, m)
+        ah, mh, jh = a.cpu().numpy(), m.cpu().numpy(), j.cpu().numpy()
+        info_o, raw_o, paths_o = orc.step(ah[sel], mh[sel])
+        cand_o, mask_o = orc.job_mask_update(jh[sel])
+        info = env.info.cpu().numpy(); raw = env.raw.cpu().numpy(); st = env.status.cpu().numpy()
+        raw_sum += raw
+        assert not (st & capi.ST_INVALID).any()
+        assert np.array_equal(st[sel] & capi.PATH_MASK, paths_o), f"step {s}: scheduling path"
+        assert np.array_equal(info[sel], info_o), f"step {s}: rewards / scaled rewards / done"
+        assert np.array_equal(raw[sel], raw_o)
+        assert np.array_equal(env.candidate.cpu().numpy()[sel], cand_o) and np.array_equal(env.job_mask.cpu().numpy()[sel], mask_o)
+        if s % max(1, T // 6) == 0 or s == T - 1:
+            o = orc.observe(dense=False)
+            tf = env.tasks_fea.cpu().numpy().reshape(B, T, 12)[sel].reshape(-1, 12)
+            assert np.array_equal(tf, o["tfea"]), f"step {s}: tasks_fea"
+            assert np.array_equal(env.m_fea2.cpu().numpy()[sel], o["mfea2"])
+            ec = env.ell_col.cpu().numpy().reshape(B, T, 2)[sel]; ev = env.ell_val.cpu().numpy().reshape(B, T, 2)[sel]
+            # ELL slot order may differ: compare as sets per node
+            for arr_c, arr_v, oc, ov in ((ec, ev, o["ell_col"], o["ell_val"]),):
+                k1 = np.sort(np.where(arr_c >= 0, arr_c * 100000 + arr_v.astype(np.int64), -1), axis=2)
+                k2 = np.sort(np.where(oc >= 0, oc * 100000 + ov.astype(np.int64), -1), axis=2)
+                assert np.array_equal(k1, k2), f"step {s}: adjacency"
+    assert info[:, 1].all()
+    # ---- final state: oracle sample + schedule properties on ALL instances
+    so = orc.state()
+    mach = env.read_state(capi.STATE_MACHINE); stt = env.read_state(capi.STATE_START); ftt = env.read_state(capi.STATE_FINISH)
+    routes = env.read_state(capi.STATE_ROUTES); prev = env.read_state(capi.STATE_PREV_COSTS)
+    assert np.array_equal(mach[sel], so["mach"]) and np.array_equal(stt[sel], so["st"]) and np.array_equal(ftt[sel], so["ft"])
+    assert np.array_equal(routes[sel], so["routes"]) and np.array_equal(prev[sel], so["prev"])
+    assert np.array_equal(env.read_state(capi.STATE_SCALER)[sel], so["scaler"])
+    bi = np.arange(B)[:, None]; ti = np.arange(T)[None, :]
+    assert (mach >= 0).all()
+    dur = t[bi, ti, mach]
+    assert (dur > 0).all(), "only feasible machines were chosen"
+    assert np.array_equal(ftt, stt + dur)                                           # ft = st + t[a, m]
+    # every task appears exactly once in the routes
+    cnt = np.zeros((B, T), np.int32)
+    for mm in range(M):
+        r = routes[:, mm, :]
+        ok = r >= 0
+        np.add.at(cnt, (np.broadcast_to(bi, r.shape)[ok], r[ok]), 1)
+        assert (mach[np.broadcast_to(bi, r.shape)[ok], r[ok]] == mm).all()
+        # machine capacity: no overlap along a route
+        nxt, cur = r[:, 1:], r[:, :-1]
+        both = (nxt >= 0) & (cur >= 0)
+        bb = np.broadcast_to(bi, nxt.shape)[both]
+        assert (stt[bb, nxt[both]] >= ftt[bb, cur[both]]).all()
+    assert (cnt == 1).all()
+    # job precedence incl. transport time
+    op = ti % M
+    has_pred = np.broadcast_to(op > 0, (B, T))
+    pm = np.roll(mach, 1, axis=1)
+    tr = tt[bi, pm, mach]
+    lhs = stt[has_pred]; rhs = (np.roll(ftt, 1, axis=1) + tr)[has_pred]
+    assert (lhs >= rhs).all()
+    # telescoping rewards (env:1066-1088): sum of per-step differences == initial estimate - final cost
+    mk_final = ftt.max(1)
+    assert np.array_equal(prev[:, 0], mk_final)                                     # makespan_previous_step == max finish time
+    np.testing.assert_allclose(raw_sum[:, 1], prev0[:, 0] - mk_final, rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(raw_sum[:, 2], -prev[:, 3], rtol=1e-9, atol=1e-7)     # idle
+    np.testing.assert_allclose(raw_sum[:, 4], -prev[:, 2], rtol=1e-9, atol=1e-7)     # transport
+    np.testing.assert_allclose(raw_sum[:, 3], (prev0[:, 1] - prev[:, 1]) / T, rtol=1e-9, atol=1e-7)
+    np.testing.assert_allclose(prev[:, 2], (tr * has_pred).sum(1), rtol=1e-12)       # cumulated transport time
+    np.testing.assert_allclose(prev[:, 1], (dur * p[bi, ti, mach]).sum(1), rtol=1e-12)
+
+
+def test_j6m6e2_4096_all_instances_vs_oracle():
+    _run(6, 6, 2, 4096, 1, seed=0)
+
+
+def test_j10m10e2_8192_all_instances_vs_oracle():
+    _run(10, 10, 2, 8192, 2, seed=1)
+
+
+def test_j20m20e4_2048_sampled_vs_oracle():
+    _run(20, 20, 4, 2048, 32, seed=2)
+
+
+def test_encoder_full_batch_permutation_equivariance():
+    """B=4096: permuting the instances of a batch permutes the actor outputs (training-mode BatchNorm statistics are
+    permutation invariant; f64 atomics make the sums order-dependent only at 1e-16)."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    J, M, E, B = 6, 6, 2, 4096
+    T = J * M
+    ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32")
+    for _ in range(7):
+        ro.step()
+    env, enc = ro.env, ro.actor.enc
+    prob, h_o, v = [x.clone() for x in enc.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, None)]
+    assert torch.isfinite(prob).all() and torch.allclose(prob.sum(1), torch.ones(B, device=prob.device), atol=1e-5)
+    assert (prob[env.job_mask.bool()] == 0).all()
+    perm = torch.randperm(B, device=prob.device)
+    tf = env.tasks_fea.view(B, T, 12)[perm].reshape(B * T, 12).contiguous()
+    ec = env.ell_col.view(B, T, 2)[perm].reshape(B * T, 2).contiguous()
+    ev = env.ell_val.view(B, T, 2)[perm].reshape(B * T, 2).contiguous()
+    prob2, h_o2, v2 = enc.job_actor_forward(tf, ec, ev, env.candidate[perm].contiguous(), env.job_mask[perm].contiguous(), None)
+    assert torch.allclose(prob2, prob[perm], atol=1e-5) and torch.allclose(h_o2, h_o[perm], atol=1e-4) and torch.allclose(v2, v[perm], atol=1e-4)
