@@ -56,12 +56,6 @@ struct GemmArgs {
     int dbg;                // timing-only ablation bits (MTFJSP_GEMM_DBG): 1 skip prologue loads, 2 skip MFMA, 4 skip epilogue stores
 };
 
-__device__ __forceinline__ float bn_relu(float x, float mean, float rstd, float g, float b)
-{
-    float y = (x - mean) * rstd * g + b;
-    return y > 0.f ? y : 0.f;
-}
-
 #ifdef MTFJSP_STAMP
 #define STAMP(slot)                                                                      \
     do {                                                                                 \
@@ -74,10 +68,33 @@ __device__ __forceinline__ float bn_relu(float x, float mean, float rstd, float 
 #else
 #define STAMP(slot) do { } while (0)
 #endif
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every
+// global prefetch in flight (the next weight block, the next tile) and serialise what is meant to overlap.
+#define LDS_BARRIER()                                              \
+    do {                                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+        __builtin_amdgcn_s_barrier();                              \
+        asm volatile("" ::: "memory");                             \
+    } while (0)
+
+// tanh(x) = 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units: |error| < 3e-7 absolute (the scorer/critic heads are
+// checked against the reference at 1e-4); saturates correctly for |x| large.
+__device__ __forceinline__ float fast_tanh(float x)
+{
+    const float e = __expf(2.0f * x);
+    return 1.0f - __fdividef(2.0f, e + 1.0f);
+}
+
+__device__ __forceinline__ float bn_relu(float x, float mean, float rstd, float g, float b)
+{
+    float y = (x - mean) * rstd * g + b;
+    return y > 0.f ? y : 0.f;
+}
+
 #define STAT_REP 8            // replicated BatchNorm accumulators: <=32 adders per address keeps f64 atomics at full rate
 
 template <int PRO, int EPI>
-__global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
+__global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *s_w = reinterpret_cast<float *>(smem);                 // 128*128
@@ -94,7 +111,8 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
     {   // W^T -> LDS (coalesced float4)
         const float4 *src = reinterpret_cast<const float4 *>(A.Wt);
         float4 *dst = reinterpret_cast<float4 *>(s_w);
-        for (int i = tid; i < HD * HD / 4; i += 256) dst[i] = src[i];
+#pragma unroll
+        for (int i = 0; i < 16; i++) { const int ii = tid + ((i + blockIdx.x) & 15) * 256; dst[ii] = src[ii]; }   // rotated: de-phase the CUs across L2 channels
     }
     if (PRO != PRO_PLAIN && tid < HD) {
         double su = 0, sq = 0;
@@ -126,7 +144,7 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
     float4 pre[16];                                               // raw rows of the NEXT tile, in flight during the MFMA phase
     int2 pre_c[PRO == PRO_AGG ? 16 : 1];
     float2 pre_v[PRO == PRO_AGG ? 16 : 1];
-    auto prefetch = [&](int tile) {
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {
         const int row0 = tile * 32;
 #pragma unroll
         for (int p = 0; p < 16; p++) {
@@ -232,7 +250,7 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
                 if (r < A.N && !(A.dbg & 4)) {
                     float v = acc[cb][i] + bias;
                     if (A.rowbias) v += rb[cb][i];
-                    if (EPI == EPI_TANH) v = tanhf(v);
+                    if (EPI == EPI_TANH) v = fast_tanh(v);
                     A.out[(size_t)r * HD + col] = v;
                     if (EPI == EPI_STATS) { ts += v; tq += v * v; }
                 }
@@ -262,6 +280,242 @@ __global__ __launch_bounds__(256) void k_gemm128(GemmArgs A)
 static size_t gemm_lds_bytes() { return (size_t)(HD * HD + 4 * 32 * LDA + 4 * HD) * 4 + 4 * 256 * 8; }
 
 // ---------------------------------------------------------------------------------------------
+// Fused actor heads (ac:205-293 / ac:444-495): for a group of 16 instances one workgroup computes
+//   u   = Wb pooled + Wc other + b0                      (the per-instance thirds of the 384-wide scorer input)
+//   s1  = tanh(Wa x_row + u[instance]) ; s2 = tanh(W1 s1 + b1) ; score = scale * (w2 . s2 + b2) ; masked softmax
+//   c1  = tanh(Wc0 pooled + bc0) ; c2 = tanh(Wc1 c1 + bc1) ; value = Wc2 c2 + bc2
+// All six [128,128] weight blocks stream once through one 64 KB LDS buffer (next block prefetched into registers
+// while the matrix cores run); a 32-row tile is split by COLUMN block over the four waves (64 MFMAs each), and
+// every intermediate stays in LDS as the next product's A tile.  One launch instead of six GEMMs + a softmax.
+struct W16 { float4 v[16]; };     // one 64 KB weight block spread over 256 threads, by value so it stays in registers
+struct R4 { float4 v[4]; };       // 32 staged rows: 4 x 16 bytes per thread
+__device__ __forceinline__ W16 w_fetch16(const float *Wt, int tid, int rot)
+{
+    W16 w;
+    const float4 *src = reinterpret_cast<const float4 *>(Wt);
+#pragma unroll
+    for (int i = 0; i < 16; i++) w.v[i] = src[tid + ((i + rot) & 15) * 256];   // rotated start: all CUs stream the same 64 KB,
+    return w;                                                                    // so de-phase them across the L2 channels
+}
+__device__ __forceinline__ void w_commit16(float *s_w, const W16 &w, int tid, int rot)
+{
+    float4 *dst = reinterpret_cast<float4 *>(s_w);
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst[tid + ((i + rot) & 15) * 256] = w.v[i];
+}
+__device__ __forceinline__ R4 fetch_rows4(const float *src, int first_row, int nrows, int sr, int sc4)
+{
+    R4 r;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        const int rr = p * 8 + sr;
+        r.v[p] = (rr < nrows) ? *reinterpret_cast<const float4 *>(src + (size_t)(first_row + rr) * HD + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return r;
+}
+__device__ __forceinline__ void commit_rows4(float *tile, const R4 &r, int sr, int sc4)
+{
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+        float *d = tile + (p * 8 + sr) * LDA + sc4;
+        d[0] = r.v[p].x; d[1] = r.v[p].y; d[2] = r.v[p].z; d[3] = r.v[p].w;
+    }
+}
+struct HeadArgs {
+    int B, R;
+    const float *X;                      // [B*R,128] candidate / machine node embeddings
+    const float *pooled, *other;         // [B,128]
+    const float *W0t;                    // [3][128][128] transposed blocks of linears.0: X | pooled | other
+    const float *b0, *W1t, *b1, *w2, *b2;
+    const float *Wc0t, *bc0, *Wc1t, *bc1, *wc2, *bc2;
+    const uint8_t *mask;                 // [B,R]
+    float scale;
+    float *prob, *value;                 // [B,R], [B,2]
+    unsigned long long *stamps;
+};
+#define HG 16                            // instances per workgroup
+#define HTILES 3                         // LDS tiles (the scorer loop below is written for exactly 3)
+
+__global__ __launch_bounds__(256, 1) void k_heads(HeadArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_w = reinterpret_cast<float *>(smem);                  // 128*128
+    float *s_t = s_w + HD * HD;                                    // HTILES * 32 * LDA
+    float *s_u = s_t + HTILES * 32 * LDA;                          // HG * 128
+    float *s_score = s_u + HG * HD;                                // HG * 64
+    float *s_part = s_score + HG * 64;                             // 4 waves * 32 rows
+    float *s_wc2 = s_part + 128;                                   // 2 * 128
+    unsigned char *s_mask = reinterpret_cast<unsigned char *>(s_wc2 + 2 * HD);   // HG * 64
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+#ifdef MTFJSP_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
+    const int g0 = blockIdx.x * HG;
+    const int ng = (A.B - g0) < HG ? (A.B - g0) : HG;
+    const int R = A.R;
+    const unsigned invR = (unsigned)((0x100000000ull + (unsigned)R - 1) / (unsigned)R);
+    float4 w0, w1, w2_, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;   // one 64 KB weight block in flight (named scalars:
+                                                                                     // an array here is not promoted out of scratch)
+    const int rot = blockIdx.x;
+    int cur = 2; (void)cur;
+#define W_SLOT(i) (tid + (((i) + rot) & 15) * 256)              /* rotated start: all CUs stream the same 64 KB, de-phase them across L2 channels */
+#define w_fetch(Wt)                                                                                                   \
+    do {                                                                                                              \
+        const float4 *src_ = reinterpret_cast<const float4 *>(Wt);                                                    \
+        w0 = src_[W_SLOT(0)]; w1 = src_[W_SLOT(1)]; w2_ = src_[W_SLOT(2)]; w3 = src_[W_SLOT(3)];                      \
+        w4 = src_[W_SLOT(4)]; w5 = src_[W_SLOT(5)]; w6 = src_[W_SLOT(6)]; w7 = src_[W_SLOT(7)];                       \
+        w8 = src_[W_SLOT(8)]; w9 = src_[W_SLOT(9)]; w10 = src_[W_SLOT(10)]; w11 = src_[W_SLOT(11)];                   \
+        w12 = src_[W_SLOT(12)]; w13 = src_[W_SLOT(13)]; w14 = src_[W_SLOT(14)]; w15 = src_[W_SLOT(15)];               \
+    } while (0)
+#define w_commit()                                                                                                    \
+    do {                                                                                                              \
+        STAMP(cur);                                                                                                   \
+        float4 *dst_ = reinterpret_cast<float4 *>(s_w);                                                               \
+        dst_[W_SLOT(0)] = w0; dst_[W_SLOT(1)] = w1; dst_[W_SLOT(2)] = w2_; dst_[W_SLOT(3)] = w3;                      \
+        dst_[W_SLOT(4)] = w4; dst_[W_SLOT(5)] = w5; dst_[W_SLOT(6)] = w6; dst_[W_SLOT(7)] = w7;                       \
+        dst_[W_SLOT(8)] = w8; dst_[W_SLOT(9)] = w9; dst_[W_SLOT(10)] = w10; dst_[W_SLOT(11)] = w11;                   \
+        dst_[W_SLOT(12)] = w12; dst_[W_SLOT(13)] = w13; dst_[W_SLOT(14)] = w14; dst_[W_SLOT(15)] = w15;               \
+        STAMP(0);                                                                                                     \
+    } while (0)
+    const int sr = tid >> 5, sc4 = (tid & 31) * 4;                  // staging: thread -> (row sr + 8p, 4 columns)
+    auto tile_gemm = [&](const float *tile, f32x16 acc) __attribute__((always_inline)) -> f32x16 {  // this wave: output columns [32*wave, 32*wave+32)
+        const float *ap = tile + j * LDA + 64 * h;
+        const float *bp = s_w + (64 * h) * HD + 32 * wave + j;
+        STAMP(cur);
+#pragma unroll 8
+        for (int s = 0; s < 64; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s], bp[s * HD], acc, 0, 0, 0);
+        STAMP(1);
+        return acc;
+    };
+    f32x16 zero;
+    for (int i = 0; i < 16; i++) zero[i] = 0.f;
+    const int col = 32 * wave + j;
+    float *t0 = s_t, *t1 = s_t + 32 * LDA, *t2 = s_t + 2 * 32 * LDA;
+    const int nrows = ng * R, ntiles = (nrows + 31) / 32;
+
+    // ---- everything that comes from global memory is requested up front (a load at its point of use would stall the
+    //      whole workgroup for a full memory round trip each time)
+    w_fetch(A.W0t + 1 * HD * HD);
+    R4 r_x0, r_x1, r_x2;
+    const R4 r_pool = fetch_rows4(A.pooled, g0, ng, sr, sc4);
+    const R4 r_oth = fetch_rows4(A.other, g0, ng, sr, sc4);
+    const float b0c = A.b0[col], bc0c = A.bc0[col], bc1c = A.bc1[col], b1c = A.b1[col], w2c = A.w2[col], b2 = A.b2[0];
+    s_wc2[tid] = A.wc2[tid];
+    for (int i = tid; i < ng * R; i += 256) s_mask[i] = A.mask[(size_t)g0 * R + i];
+    r_x0 = fetch_rows4(A.X, g0 * R, nrows, sr, sc4);
+    r_x1 = fetch_rows4(A.X, g0 * R + 32, nrows - 32, sr, sc4);
+    r_x2 = fetch_rows4(A.X, g0 * R + 64, nrows - 64, sr, sc4);
+    commit_rows4(t0, r_pool, sr, sc4);
+    commit_rows4(t1, r_oth, sr, sc4);
+    w_commit();
+    LDS_BARRIER();
+    // ---- u = Wb pooled + Wc other + b0
+    STAMP(2); cur = 3;
+    w_fetch(A.W0t + 2 * HD * HD);
+    f32x16 acc = tile_gemm(t0, zero);
+    LDS_BARRIER();
+    w_commit();
+    LDS_BARRIER();
+    w_fetch(A.Wc0t);
+    acc = tile_gemm(t1, acc);
+    for (int i = 0; i < 16; i++) {
+        const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (r < HG) s_u[r * HD + col] = acc[i] + b0c;
+    }
+    LDS_BARRIER();
+    // ---- critic: c1 = tanh(Wc0 pooled + bc0) -> t1 ; c2 = tanh(Wc1 c1 + bc1) -> t2 ; value = Wc2 c2 + bc2
+    w_commit();
+    LDS_BARRIER();
+    w_fetch(A.Wc1t);
+    acc = tile_gemm(t0, zero);
+    for (int i = 0; i < 16; i++) { const int r = (i & 3) + 8 * (i >> 2) + 4 * h; t1[r * LDA + col] = fast_tanh(acc[i] + bc0c); }
+    LDS_BARRIER();
+    w_commit();
+    LDS_BARRIER();
+    w_fetch(A.W0t);                                                  // Wa for the first group of X tiles
+    acc = tile_gemm(t1, zero);
+    for (int i = 0; i < 16; i++) { const int r = (i & 3) + 8 * (i >> 2) + 4 * h; t2[r * LDA + col] = fast_tanh(acc[i] + bc1c); }
+    LDS_BARRIER();
+    STAMP(3); cur = 4;
+    {   // value head: 16 threads per instance row, 8 columns each, both outputs
+        const int r = tid >> 4, part = tid & 15;
+        float p0 = 0.f, p1 = 0.f;
+        for (int k = 0; k < 8; k++) { const float x = t2[r * LDA + part * 8 + k]; p0 = fmaf(x, s_wc2[part * 8 + k], p0); p1 = fmaf(x, s_wc2[HD + part * 8 + k], p1); }
+        for (int o = 8; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+        if (part == 0 && r < ng) { A.value[(size_t)(g0 + r) * 2] = p0 + A.bc2[0]; A.value[(size_t)(g0 + r) * 2 + 1] = p1 + A.bc2[1]; }
+    }
+    LDS_BARRIER();
+    STAMP(4); cur = 5;
+    // ---- scorer over the ng*R rows of this group, HTILES tiles at a time
+    for (int tb = 0; tb < ntiles; tb += HTILES) {
+        const int nt = (ntiles - tb) < HTILES ? (ntiles - tb) : HTILES;
+        if (tb > 0) {
+            w_fetch(A.W0t);
+            r_x0 = fetch_rows4(A.X, g0 * R + tb * 32, nrows - tb * 32, sr, sc4);
+            r_x1 = fetch_rows4(A.X, g0 * R + (tb + 1) * 32, nrows - (tb + 1) * 32, sr, sc4);
+            r_x2 = fetch_rows4(A.X, g0 * R + (tb + 2) * 32, nrows - (tb + 2) * 32, sr, sc4);
+        }
+        commit_rows4(t0, r_x0, sr, sc4);
+        if (nt > 1) commit_rows4(t1, r_x1, sr, sc4);
+        if (nt > 2) commit_rows4(t2, r_x2, sr, sc4);
+        w_commit();                                                  // Wa
+        LDS_BARRIER();
+        w_fetch(A.W1t);
+        for (int k = 0; k < nt; k++) {
+            float *tile = s_t + k * 32 * LDA;
+            acc = tile_gemm(tile, zero);
+            LDS_BARRIER();                                         // every wave has read the X tile before it is overwritten
+            for (int i = 0; i < 16; i++) {
+                const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
+                const int grow = (tb + k) * 32 + r;
+                const int inst = grow < nrows ? (int)__umulhi((unsigned)grow, invR) : 0;
+                tile[r * LDA + col] = fast_tanh(acc[i] + s_u[inst * HD + col]);
+            }
+        }
+        LDS_BARRIER();
+        STAMP(5); cur = 6;
+        w_commit();                                                  // W1
+        LDS_BARRIER();
+        for (int k = 0; k < nt; k++) {
+            acc = tile_gemm(s_t + k * 32 * LDA, zero);
+            for (int i = 0; i < 16; i++) {
+                float v = fast_tanh(acc[i] + b1c) * w2c;
+                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);          // over the 32 columns of this wave
+                if (j == 0) s_part[wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = v;
+            }
+            LDS_BARRIER();
+            if (tid < 32) {
+                const int grow = (tb + k) * 32 + tid;
+                if (grow < nrows) s_score[grow] = (s_part[tid] + s_part[32 + tid] + s_part[64 + tid] + s_part[96 + tid] + b2) * A.scale;
+            }
+            LDS_BARRIER();
+        }
+    }
+    STAMP(6); cur = 7;
+    // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance
+    {
+        const int r0 = tid >> 4, l = tid & 15;
+        if (r0 < ng) {
+            float mx = -INFINITY;
+            for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) mx = fmaxf(mx, s_score[r0 * R + r]);
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            float sum = 0.f;
+            for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) sum += __expf(s_score[r0 * R + r] - mx);
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            for (int r = l; r < R; r += 16)
+                A.prob[(size_t)(g0 + r0) * R + r] = s_mask[r0 * R + r] ? 0.f : __expf(s_score[r0 * R + r] - mx) / sum;
+        }
+    }
+#ifdef MTFJSP_STAMP
+    STAMP(7);
+    if (A.stamps && lane == 0) for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
+#endif
+}
+static size_t heads_lds_bytes() { return (size_t)(HD * HD + HTILES * 32 * LDA + HG * HD + HG * 64 + 128 + 2 * HD) * 4 + HG * 64; }
+
+// ---------------------------------------------------------------------------------------------
 // GIN layer 0, first Linear (12 -> 128) fused with the neighbour aggregation of the raw task features
 // (gcn:125-153).  thread = (column c, row group); persistent blocks, column stats in registers.
 template <typename OBS>
@@ -278,7 +532,7 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
     const int ntiles = (N + 31) / 32;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * 32;
-        __syncthreads();
+        LDS_BARRIER();
         for (int i = tid; i < 32 * 12; i += 256) {
             const int r = i / 12, k = i % 12, g = row0 + r;
             float v = 0.f;
@@ -293,7 +547,7 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
             }
             s_p[i] = v;
         }
-        __syncthreads();
+        LDS_BARRIER();
         for (int rr = 0; rr < 16; rr++) {
             const int r = half * 16 + rr, g = row0 + r;
             if (g < N) {
@@ -603,6 +857,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_BNRELU, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_AGG, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
     *out = e;
     return MTFJSP_OK;
 }
@@ -765,28 +1020,35 @@ extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fe
         hipLaunchKernelGGL(k_bcast128, dim3((B * HD + 255) / 256), dim3(256), 0, e->stream, B, W("job_actor._input"), e->hm_b);
         hm = e->hm_b;
     }
-    const float *W0t = WT("job_actor.o_policy.linears.0.weight");       // 3 blocks of [128,128]: cand | pooled | hm
     {
-        GemmArgs a = gemm_args(h_pooled, B, W0t + 1 * HD * HD, W("job_actor.o_policy.linears.0.bias"), e->u);
-        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, a, "head_gemm");
-        GemmArgs b = gemm_args(hm, B, W0t + 2 * HD * HD, nullptr, e->u);
-        b.accumulate = 1;
-        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, b, "head_gemm");
-        GemmArgs c = gemm_args(e->cand_feat, B * J, W0t, nullptr, e->s1);
-        c.rowbias = e->u; c.rowbias_div = J;
-        launch_gemm<PRO_PLAIN, EPI_TANH>(e, c, "head_gemm");
-        GemmArgs d = gemm_args(e->s1, B * J, WT("job_actor.o_policy.linears.1.weight"), W("job_actor.o_policy.linears.1.bias"), e->s2);
-        launch_gemm<PRO_PLAIN, EPI_TANH>(e, d, "head_gemm");
-        GemmArgs f = gemm_args(h_pooled, B, WT("job_actor.job_critic.linears.0.weight"), W("job_actor.job_critic.linears.0.bias"), e->c1);
-        launch_gemm<PRO_PLAIN, EPI_TANH>(e, f, "head_gemm");
-        GemmArgs g = gemm_args(e->c1, B, WT("job_actor.job_critic.linears.1.weight"), W("job_actor.job_critic.linears.1.bias"), e->c2);
-        launch_gemm<PRO_PLAIN, EPI_TANH>(e, g, "head_gemm");
-    }
-    {
-        Timed t(e, "score_softmax");
-        hipLaunchKernelGGL(k_score_softmax, dim3(B), dim3(64), 0, e->stream, B, J, e->s2, W("job_actor.o_policy.linears.2.weight"),
-                           W("job_actor.o_policy.linears.2.bias"), 1.0f, job_mask, prob, e->c2, W("job_actor.job_critic.linears.2.weight"),
-                           W("job_actor.job_critic.linears.2.bias"), job_v);
+        Timed t(e, "heads");
+        HeadArgs ha{};
+        ha.B = B; ha.R = J; ha.X = e->cand_feat; ha.pooled = h_pooled; ha.other = hm;
+        ha.W0t = WT("job_actor.o_policy.linears.0.weight"); ha.b0 = W("job_actor.o_policy.linears.0.bias");
+        ha.W1t = WT("job_actor.o_policy.linears.1.weight"); ha.b1 = W("job_actor.o_policy.linears.1.bias");
+        ha.w2 = W("job_actor.o_policy.linears.2.weight"); ha.b2 = W("job_actor.o_policy.linears.2.bias");
+        ha.Wc0t = WT("job_actor.job_critic.linears.0.weight"); ha.bc0 = W("job_actor.job_critic.linears.0.bias");
+        ha.Wc1t = WT("job_actor.job_critic.linears.1.weight"); ha.bc1 = W("job_actor.job_critic.linears.1.bias");
+        ha.wc2 = W("job_actor.job_critic.linears.2.weight"); ha.bc2 = W("job_actor.job_critic.linears.2.bias");
+        ha.mask = job_mask; ha.scale = 1.0f; ha.prob = prob; ha.value = job_v;
+#ifdef MTFJSP_STAMP
+        static unsigned long long *d_st = nullptr;
+        if (!d_st) (void)hipMalloc((void **)&d_st, 4096 * 8 * 8);
+        ha.stamps = d_st;
+#endif
+        hipLaunchKernelGGL(k_heads, dim3((B + HG - 1) / HG), dim3(256), heads_lds_bytes(), e->stream, ha);
+#ifdef MTFJSP_STAMP
+        static int printed = 0;
+        if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
+            (void)hipStreamSynchronize(e->stream);
+            const int nw = ((B + HG - 1) / HG) * 4;
+            std::vector<unsigned long long> hst((size_t)nw * 8);
+            (void)hipMemcpy(hst.data(), d_st, (size_t)nw * 64, hipMemcpyDeviceToHost);
+            double m[8] = {0};
+            for (int w = 0; w < nw; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[(size_t)w * 8 + i] / nw;
+            printf("STAMP k_heads: w_commit %.0f  tile_gemm %.0f  init %.0f  u+critic-epilogues %.0f  value %.0f  scorer-s1 %.0f  scorer-score %.0f  softmax %.0f (cycles/wave)\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+        }
+#endif
     }
     HIPCHK(e, hipGetLastError());
     return MTFJSP_OK;
@@ -826,28 +1088,18 @@ extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fe
         hipLaunchKernelGGL(k_mach_bn_pool, dim3(B), dim3(128), 0, e->stream, B, M, e->node, st, 1.0 / (double)R, W("machine_actor.bn.weight"),
                            W("machine_actor.bn.bias"), h_pooled);
     }
-    const float *W0t = WT("machine_actor.m_policy.linears.0.weight");         // node | pooled_m | pooled_o
     {
-        GemmArgs a = gemm_args(h_pooled, B, W0t + 1 * HD * HD, W("machine_actor.m_policy.linears.0.bias"), e->u);
-        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, a, "head_gemm");
-        GemmArgs b = gemm_args(h_pooled_o, B, W0t + 2 * HD * HD, nullptr, e->u);
-        b.accumulate = 1;
-        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, b, "head_gemm");
-        GemmArgs c = gemm_args(e->node, R, W0t, nullptr, e->s1);
-        c.rowbias = e->u; c.rowbias_div = M;
-        launch_gemm<PRO_PLAIN, EPI_TANH>(e, c, "head_gemm");
-        GemmArgs d = gemm_args(e->s1, R, WT("machine_actor.m_policy.linears.1.weight"), W("machine_actor.m_policy.linears.1.bias"), e->s2);
-        launch_gemm<PRO_PLAIN, EPI_TANH>(e, d, "head_gemm");
-        GemmArgs f = gemm_args(h_pooled, B, WT("machine_actor.machine_critic.linears.0.weight"), W("machine_actor.machine_critic.linears.0.bias"), e->c1);
-        launch_gemm<PRO_PLAIN, EPI_TANH>(e, f, "head_gemm");
-        GemmArgs g = gemm_args(e->c1, B, WT("machine_actor.machine_critic.linears.1.weight"), W("machine_actor.machine_critic.linears.1.bias"), e->c2);
-        launch_gemm<PRO_PLAIN, EPI_TANH>(e, g, "head_gemm");
-    }
-    {
-        Timed t(e, "score_softmax");
-        hipLaunchKernelGGL(k_score_softmax, dim3(B), dim3(64), 0, e->stream, B, M, e->s2, W("machine_actor.m_policy.linears.2.weight"),
-                           W("machine_actor.m_policy.linears.2.bias"), 10.0f, mmask, prob, e->c2, W("machine_actor.machine_critic.linears.2.weight"),
-                           W("machine_actor.machine_critic.linears.2.bias"), machine_v);
+        Timed t(e, "heads");
+        HeadArgs ha{};
+        ha.B = B; ha.R = M; ha.X = e->node; ha.pooled = h_pooled; ha.other = h_pooled_o;
+        ha.W0t = WT("machine_actor.m_policy.linears.0.weight"); ha.b0 = W("machine_actor.m_policy.linears.0.bias");
+        ha.W1t = WT("machine_actor.m_policy.linears.1.weight"); ha.b1 = W("machine_actor.m_policy.linears.1.bias");
+        ha.w2 = W("machine_actor.m_policy.linears.2.weight"); ha.b2 = W("machine_actor.m_policy.linears.2.bias");
+        ha.Wc0t = WT("machine_actor.machine_critic.linears.0.weight"); ha.bc0 = W("machine_actor.machine_critic.linears.0.bias");
+        ha.Wc1t = WT("machine_actor.machine_critic.linears.1.weight"); ha.bc1 = W("machine_actor.machine_critic.linears.1.bias");
+        ha.wc2 = W("machine_actor.machine_critic.linears.2.weight"); ha.bc2 = W("machine_actor.machine_critic.linears.2.bias");
+        ha.mask = mmask; ha.scale = 10.0f; ha.prob = prob; ha.value = machine_v;
+        hipLaunchKernelGGL(k_heads, dim3((B + HG - 1) / HG), dim3(256), heads_lds_bytes(), e->stream, ha);
     }
     HIPCHK(e, hipGetLastError());
     return MTFJSP_OK;

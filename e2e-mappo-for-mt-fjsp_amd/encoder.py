@@ -13,7 +13,7 @@ import torch
 from . import capi
 
 H = 128
-FAMILIES = ["gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg", "job_pool_gather", "head_gemm", "score_softmax",
+FAMILIES = ["gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg", "job_pool_gather", "heads", "head_gemm", "score_softmax",
             "mach_in", "gat_gemm", "gat_combine", "mach_bn_pool", "sample", "small"]
 
 
