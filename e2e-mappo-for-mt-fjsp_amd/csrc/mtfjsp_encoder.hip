@@ -142,10 +142,22 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
     float bias4[4];                                               // hoisted: a load inside the epilogue would force vmcnt(0)
     for (int cb = 0; cb < 4; cb++) bias4[cb] = (A.bias && !A.accumulate) ? A.bias[cb * 32 + j] : 0.f;
     float4 pre[16];                                               // raw rows of the NEXT tile, in flight during the MFMA phase
-    int2 pre_c[PRO == PRO_AGG ? 16 : 1];
-    float2 pre_v[PRO == PRO_AGG ? 16 : 1];
+    // PRO_AGG keeps the two neighbour rows of every row in flight as well, and the ELL entries one tile further ahead
+    // (the neighbour addresses of tile t+1 must be known when its rows are requested, i.e. before the MFMA phase of t)
+    constexpr int NA = (PRO == PRO_AGG) ? 16 : 1;
+    float4 nb0[NA], nb1[NA];
+    // ELL entries: lane l holds those of tile row (l & 31); row 2p+h is read with a cross-lane shuffle
+    int e_cx = -1, e_cy = -1, en_cx = -1, en_cy = -1;              // current tile / next tile
+    float e_vx = 0.f, e_vy = 0.f, en_vx = 0.f, en_vy = 0.f;
+    auto fetch_ell = [&](int tile) __attribute__((always_inline)) {
+        const int g = tile * 32 + j;
+        int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
+        if (g < A.N) { cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
+        en_cx = cc.x; en_cy = cc.y; en_vx = vv.x; en_vy = vv.y;
+    };
     auto prefetch = [&](int tile) __attribute__((always_inline)) {
         const int row0 = tile * 32;
+        if (PRO == PRO_AGG) { e_cx = en_cx; e_cy = en_cy; e_vx = en_vx; e_vy = en_vy; }   // ELL of THIS tile (fetched one iteration earlier)
 #pragma unroll
         for (int p = 0; p < 16; p++) {
             const int g = row0 + 2 * p + h;
@@ -153,14 +165,22 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
             if (g < A.N && !(A.dbg & 1)) x = *reinterpret_cast<const float4 *>(A.in + (size_t)g * HD + c4);
             pre[p] = x;
             if (PRO == PRO_AGG) {
-                int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
-                if (g < A.N) { cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
-                pre_c[p] = cc; pre_v[p] = vv;
+                const int pp = p < NA ? p : 0;
+                const int2 cc = make_int2(__shfl(e_cx, 2 * p + h), __shfl(e_cy, 2 * p + h));
+                const int base = (g / A.T) * A.T;
+                float4 y0 = make_float4(0.f, 0.f, 0.f, 0.f), y1 = y0;
+                if (cc.x >= 0) y0 = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.x) * HD + c4);
+                if (cc.y >= 0) y1 = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.y) * HD + c4);
+                nb0[pp] = y0; nb1[pp] = y1;
             }
         }
     };
     int tile = blockIdx.x * 4 + wave;
-    if (tile < ntiles) prefetch(tile);
+    if (tile < ntiles) {
+        if (PRO == PRO_AGG) fetch_ell(tile);
+        prefetch(tile);
+        if (PRO == PRO_AGG && tile + stride < ntiles) fetch_ell(tile + stride);
+    }
     STAMP(1);
     for (; tile < ntiles; tile += stride) {
         const int row0 = tile * 32;
@@ -175,21 +195,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
                     for (int q = 0; q < 4; q++) v[q] = bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
                 } else if (PRO == PRO_AGG) {
                     // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
+                    const int pp = p < NA ? p : 0;
                     double acc[4];
                     for (int q = 0; q < 4; q++) acc[q] = (double)bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
-                    const int2 cc = pre_c[p];
-                    const float2 vv = pre_v[p];
-                    const int base = (g / A.T) * A.T;
+                    const int2 cc = make_int2(__shfl(e_cx, r), __shfl(e_cy, r));
+                    const float2 vv = make_float2(__shfl(e_vx, r), __shfl(e_vy, r));
                     int deg = 1;
                     if (cc.x >= 0) {
-                        const float4 y = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.x) * HD + c4);
-                        const float yy[4] = {y.x, y.y, y.z, y.w};
+                        const float yy[4] = {nb0[pp].x, nb0[pp].y, nb0[pp].z, nb0[pp].w};
                         for (int q = 0; q < 4; q++) acc[q] += (double)vv.x * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
                         deg++;
                     }
                     if (cc.y >= 0) {
-                        const float4 y = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.y) * HD + c4);
-                        const float yy[4] = {y.x, y.y, y.z, y.w};
+                        const float yy[4] = {nb1[pp].x, nb1[pp].y, nb1[pp].z, nb1[pp].w};
                         for (int q = 0; q < 4; q++) acc[q] += (double)vv.y * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
                         deg++;
                     }
@@ -201,7 +219,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // tile complete before this wave reads it back (also a compiler fence)
         STAMP(2);
-        if (tile + stride < ntiles) prefetch(tile + stride);      // asynchronous: lands while the matrix cores run
+        if (tile + stride < ntiles) {                             // asynchronous: lands while the matrix cores run
+            prefetch(tile + stride);
+            if (PRO == PRO_AGG && tile + 2 * stride < ntiles) fetch_ell(tile + 2 * stride);
+        }
         STAMP(3);
         // ------------------------------------------------------------------ main loop
         f32x16 acc[4];
