@@ -118,13 +118,19 @@ def main():
     for _ in range(args.warmup):
         ro.step()
     sync()
-    ro.timing_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ro.step()
     sync()
     elapsed = time.perf_counter() - t0
+    # second pass of the same steps with HIP events recorded on the launch stream around every kernel launch
+    # (kept out of the timed region above: two event records per launch would perturb `value`)
+    prof_steps = min(args.steps, 4 * T)
+    ro.timing_begin()
+    for _ in range(prof_steps):
+        ro.step()
     ktimes = ro.timing_end()
+    sync()
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -154,7 +160,7 @@ def main():
                        "instances_per_gpu": B, "obs_dtype": args.obs, "policy": policy,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
             "roofline": roof,
-            "kernel_times_ms": {k: v for k, v in ktimes.items()},
+            "kernel_times_ms": {k: v for k, v in ktimes.items()}, "kernel_times_steps": prof_steps,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(J, M, E)
