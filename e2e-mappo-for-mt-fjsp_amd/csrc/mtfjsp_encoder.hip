@@ -32,7 +32,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2 };
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2, EPI_GAT = 3 };
 
 struct GemmArgs {
     const float *in;        // [N,128] producer output (pre-activation for PRO_BNRELU / PRO_AGG)
@@ -51,6 +51,9 @@ struct GemmArgs {
     double *epi_stats;      // EPI_STATS: [256] accumulated with atomics (zeroed by the host per forward)
     const float *rowbias;   // optional [N/rowbias_div,128] added to row r: rowbias[(r / rowbias_div)]
     int rowbias_div;
+    const float *gat_a;     // EPI_GAT: [256] a_src | a_dst of the shared GATLayer (gat:68-79)
+    int gat_last;           // EPI_GAT: 0 = ELU + write the next pass' node pair in place, 1 = mean of the 2 nodes -> gat_node + column stats
+    float *gat_node;        // EPI_GAT last pass: [N/2,128]
     int accumulate;         // C initialised from `out` (K > 128 as a sum of 128-wide GEMMs)
     unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
     int dbg;                // timing-only ablation bits (MTFJSP_GEMM_DBG): 1 skip prologue loads, 2 skip MFMA, 4 skip epilogue stores
@@ -141,6 +144,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
 
     float bias4[4];                                               // hoisted: a load inside the epilogue would force vmcnt(0)
     for (int cb = 0; cb < 4; cb++) bias4[cb] = (A.bias && !A.accumulate) ? A.bias[cb * 32 + j] : 0.f;
+    float asrc[4] = {0, 0, 0, 0}, adst[4] = {0, 0, 0, 0};
+    if (EPI == EPI_GAT) for (int cb = 0; cb < 4; cb++) { asrc[cb] = A.gat_a[cb * 32 + j]; adst[cb] = A.gat_a[HD + cb * 32 + j]; }
     float4 pre[16];                                               // raw rows of the NEXT tile, in flight during the MFMA phase
     // PRO_AGG keeps the two neighbour rows of every row in flight as well, and the ELL entries one tile further ahead
     // (the neighbour addresses of tile t+1 must be known when its rows are requested, i.e. before the MFMA phase of t)
@@ -261,6 +266,45 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
         asm volatile("" ::: "memory");                            // keep next iteration's LDS writes behind these reads
         STAMP(4);
         // ------------------------------------------------------------------ epilogue
+        if (EPI == EPI_GAT) {
+            // One GAT pass on the fixed 2-node graph [[1,1],[0,1]] (gat:82-159, ac:402-414).  Tile rows are
+            // (machine, node) interleaved, so accumulator registers (i, i+1), i even, are z0, z1 of ONE machine:
+            //   e0j = LeakyReLU_0.2(a_src.z0 + a_dst.zj) ; (al0, al1) = softmax(e00, e01) ; n0' = al0 z0 + al1 z1 ; n1' = z1
+#pragma unroll
+            for (int ip = 0; ip < 8; ip++) {
+                const int i = 2 * ip;
+                float s0 = 0.f, d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int cb = 0; cb < 4; cb++) { const float z0 = acc[cb][i], z1 = acc[cb][i + 1]; s0 += asrc[cb] * z0; d0 += adst[cb] * z0; d1 += adst[cb] * z1; }
+                for (int o = 16; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
+                float e00 = s0 + d0, e01 = s0 + d1;
+                e00 = e00 > 0.f ? e00 : 0.2f * e00;
+                e01 = e01 > 0.f ? e01 : 0.2f * e01;
+                const float mx = fmaxf(e00, e01);
+                const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
+                const float inv = 1.0f / (x0 + x1);
+                const float al0 = x0 * inv, al1 = x1 * inv;
+                const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;          // even: node 0 of machine r/2
+                if (r < A.N) {
+#pragma unroll
+                    for (int cb = 0; cb < 4; cb++) {
+                        const int col = cb * 32 + j;
+                        const float z0 = acc[cb][i], z1 = acc[cb][i + 1];
+                        float n0 = al0 * z0 + al1 * z1, n1 = z1;
+                        if (!A.gat_last) {
+                            n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;           // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
+                            n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
+                            A.out[(size_t)r * HD + col] = n0;
+                            A.out[(size_t)(r + 1) * HD + col] = n1;
+                        } else {
+                            const float mv = (n0 + n1) * 0.5f;                // mean over the 2 nodes (ac:420)
+                            A.gat_node[(size_t)(r >> 1) * HD + col] = mv;
+                            st_sum[cb] += (double)mv; st_sq[cb] += (double)mv * (double)mv;
+                        }
+                    }
+                }
+            }
+        } else
         for (int cb = 0; cb < 4; cb++) {
             const int col = cb * 32 + j;
             const float bias = bias4[cb];
@@ -280,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
         }
         STAMP(5);
     }
-    if (EPI == EPI_STATS) {
+    if (EPI == EPI_STATS || (EPI == EPI_GAT && A.gat_last)) {
         for (int cb = 0; cb < 4; cb++) {
             double a = st_sum[cb], q = st_sq[cb];
             a += __shfl_xor(a, 32);
@@ -618,42 +662,10 @@ __global__ void k_bcast128(int B, const float *v, float *out)
     if (i < B * HD) out[i] = v[i & 127];
 }
 
-// Final 128 -> 1 scorer + mask + softmax over the R rows of each instance, and the 128 -> 2 critic head.
-// One 64-thread block per instance.  score = scale * (w2 . s2_row + b2)   (ac:256-278 / ac:476-491)
-__global__ __launch_bounds__(64) void k_score_softmax(int B, int R, const float *s2 /*[B*R,128]*/, const float *w2, const float *b2, float scale,
-                                                     const uint8_t *mask /*[B,R]*/, float *prob /*[B,R]*/,
-                                                     const float *c2 /*[B,128]*/, const float *wc /*[2,128]*/, const float *bc /*[2]*/, float *value /*[B,2]*/)
-{
-    __shared__ float s_score[64];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const float wa = w2[lane], wb = w2[lane + 64];
-    for (int r = 0; r < R; r++) {
-        const float *row = s2 + ((size_t)b * R + r) * HD;
-        float p = row[lane] * wa + row[lane + 64] * wb;
-        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
-        if (lane == 0) s_score[r] = (p + b2[0]) * scale;
-    }
-    for (int o2 = 0; o2 < 2; o2++) {
-        const float *row = c2 + (size_t)b * HD;
-        float p = row[lane] * wc[o2 * HD + lane] + row[lane + 64] * wc[o2 * HD + lane + 64];
-        for (int o = 32; o > 0; o >>= 1) p += __shfl_xor(p, o);
-        if (lane == 0) value[b * 2 + o2] = p + bc[o2];
-    }
-    __syncthreads();
-    float sc = -INFINITY;
-    if (lane < R && !mask[(size_t)b * R + lane]) sc = s_score[lane];
-    float mx = sc;
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    float e = (lane < R && sc > -INFINITY) ? expf(sc - mx) : 0.f;
-    float sum = e;
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane < R) prob[(size_t)b * R + lane] = e / sum;
-}
-
 // ---------------------------------------------------------------------------------------------
 // machine actor input projections (ac:383-384): X0 = m_fea1 W1^T (6->128), X1 = m_fea2 W2^T (8->128); rows = B*M
 template <typename OBS>
-__global__ void k_mach_in(int rows, const OBS *f1, const OBS *f2, const float *W1 /*[128,6]*/, const float *W2 /*[128,8]*/, float *X /*[2,rows,128]*/)
+__global__ void k_mach_in(int rows, const OBS *f1, const OBS *f2, const float *W1 /*[128,6]*/, const float *W2 /*[128,8]*/, float *X /*[rows,2,128]*/)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)rows * HD) return;
@@ -661,51 +673,8 @@ __global__ void k_mach_in(int rows, const OBS *f1, const OBS *f2, const float *W
     float a = 0.f, b = 0.f;
     for (int k = 0; k < 6; k++) a = fmaf((float)f1[(size_t)r * 6 + k], W1[c * 6 + k], a);
     for (int k = 0; k < 8; k++) b = fmaf((float)f2[(size_t)r * 8 + k], W2[c * 8 + k], b);
-    X[i] = a;
-    X[(size_t)rows * HD + i] = b;
-}
-
-// One GAT pass on the fixed 2-node graph [[1,1],[0,1]] given Z = X W (gat:68-159), one wave per machine row:
-//   e0j = LeakyReLU_0.2(a_src.z0 + a_dst.zj) ; (al0,al1) = softmax(e00,e01) ; n0' = al0 z0 + al1 z1 ; n1' = z1
-//   mode 0: ELU on both, write X (next pass input)   mode 1: node = (n0'+n1')/2 -> out + column stats (ac:420-434)
-__global__ __launch_bounds__(256) void k_gat_combine(int rows, const float *Z /*[2,rows,128]*/, const float *a /*[256]*/, int mode,
-                                                    float *X /*[2,rows,128]*/, float *node /*[rows,128]*/, double *stats)
-{
-    __shared__ double s_red[4 * 256];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const float as0 = a[lane], as1 = a[lane + 64], ad0 = a[HD + lane], ad1 = a[HD + lane + 64];
-    double ssum0 = 0, ssum1 = 0, ssq0 = 0, ssq1 = 0;
-    for (int r = blockIdx.x * 4 + wave; r < rows; r += gridDim.x * 4) {
-        const float *z0 = Z + (size_t)r * HD, *z1 = Z + ((size_t)rows + r) * HD;
-        const float z00 = z0[lane], z01 = z0[lane + 64], z10 = z1[lane], z11 = z1[lane + 64];
-        float s0 = z00 * as0 + z01 * as1, d0 = z00 * ad0 + z01 * ad1, d1 = z10 * ad0 + z11 * ad1;
-        for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
-        float e00 = s0 + d0, e01 = s0 + d1;
-        e00 = e00 > 0.f ? e00 : 0.2f * e00;
-        e01 = e01 > 0.f ? e01 : 0.2f * e01;
-        const float mx = fmaxf(e00, e01);
-        const float x0 = expf(e00 - mx), x1 = expf(e01 - mx);
-        const float al0 = x0 / (x0 + x1), al1 = x1 / (x0 + x1);
-        float n00 = al0 * z00 + al1 * z10, n01 = al0 * z01 + al1 * z11;
-        float n10 = z10, n11 = z11;
-        if (mode == 0) {
-            n00 = n00 > 0.f ? n00 : expm1f(n00); n01 = n01 > 0.f ? n01 : expm1f(n01);      // ELU (ac:409-413)
-            n10 = n10 > 0.f ? n10 : expm1f(n10); n11 = n11 > 0.f ? n11 : expm1f(n11);
-            X[(size_t)r * HD + lane] = n00; X[(size_t)r * HD + lane + 64] = n01;
-            X[((size_t)rows + r) * HD + lane] = n10; X[((size_t)rows + r) * HD + lane + 64] = n11;
-        } else {
-            const float m0 = (n00 + n10) * 0.5f, m1 = (n01 + n11) * 0.5f;                 // mean over the 2 nodes (ac:420)
-            node[(size_t)r * HD + lane] = m0; node[(size_t)r * HD + lane + 64] = m1;
-            ssum0 += m0; ssq0 += (double)m0 * m0; ssum1 += m1; ssq1 += (double)m1 * m1;
-        }
-    }
-    if (mode == 1) {
-        s_red[wave * 256 + lane] = ssum0; s_red[wave * 256 + 64 + lane] = ssum1;
-        s_red[wave * 256 + 128 + lane] = ssq0; s_red[wave * 256 + 192 + lane] = ssq1;
-        __syncthreads();
-        const double v = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
-        atomicAdd(&stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
-    }
+    X[((size_t)r * 2) * HD + c] = a;                 // (machine, node) interleaved rows: node 0 = m_fea1 side, node 1 = m_fea2 side
+    X[((size_t)r * 2 + 1) * HD + c] = b;
 }
 
 // machine nodes: BatchNorm over all B*M rows (ac:434) and mean over M (ac:444). block = instance, thread = column
@@ -875,7 +844,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     if (rc) { g_enc_err = e->err; mtfjsp_encoder_destroy(e); return MTFJSP_ERR_HIP; }
     const int lds = (int)gemm_lds_bytes();
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_GAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_BNRELU, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_AGG, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
@@ -1098,11 +1067,9 @@ extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fe
                                W("machine_actor.m_fea_1_fcl.weight"), W("machine_actor.m_fea_2_fcl.weight"), e->X);
     }
     for (int pass = 0; pass < 3; pass++) {                                    // the SAME GATLayer three times (ac:409-414)
-        GemmArgs a = gemm_args(e->X, 2 * R, WT("machine_actor.gat_layer.W"), nullptr, e->Z);
-        launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, a, "gat_gemm");
-        Timed t(e, "gat_combine");
-        hipLaunchKernelGGL(k_gat_combine, dim3(e->num_cu * 2), dim3(256), 0, e->stream, R, e->Z, W("machine_actor.gat_layer.a"), pass == 2 ? 1 : 0,
-                           e->X, e->node, st);
+        GemmArgs a = gemm_args(e->X, 2 * R, WT("machine_actor.gat_layer.W"), nullptr, e->X);      // in place: a wave only rewrites the tile it read
+        a.gat_a = W("machine_actor.gat_layer.a"); a.gat_last = pass == 2; a.gat_node = e->node; a.epi_stats = st;
+        launch_gemm<PRO_PLAIN, EPI_GAT>(e, a, "gat_pass");
     }
     {
         Timed t(e, "mach_bn_pool");

@@ -14,7 +14,7 @@ from . import capi
 
 H = 128
 FAMILIES = ["gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg", "job_pool_gather", "heads", "head_gemm", "score_softmax",
-            "mach_in", "gat_gemm", "gat_combine", "mach_bn_pool", "sample", "small"]
+            "mach_in", "gat_pass", "gat_gemm", "gat_combine", "mach_bn_pool", "sample", "small"]
 
 
 def available():
@@ -174,7 +174,7 @@ class ActorPair:
         """f32 MFMA roofline for the GEMM families; HBM for the rest."""
         J, M, T = self.enc.J, self.enc.M, self.enc.T
         avg_s = kd["ms_total"] / max(kd["launches"], 1) * 1e-3
-        rows = {"gin_gemm_bn_relu": B * T, "gin_gemm_agg": B * T, "gat_gemm": 2 * B * M}.get(name)
+        rows = {"gin_gemm_bn_relu": B * T, "gin_gemm_agg": B * T, "gat_gemm": 2 * B * M, "gat_pass": 2 * B * M}.get(name)
         if rows is not None:
             flops = 2.0 * rows * H * H
             ach = flops / avg_s / 1e12
