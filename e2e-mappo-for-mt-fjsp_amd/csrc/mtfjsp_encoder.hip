@@ -31,7 +31,7 @@
 #define BN_EPS 1e-5
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2 };
+enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2, PRO_MACHIN = 3 };
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2, EPI_GAT = 3 };
 
 struct GemmArgs {
@@ -51,6 +51,9 @@ struct GemmArgs {
     double *epi_stats;      // EPI_STATS: [256] accumulated with atomics (zeroed by the host per forward)
     const float *rowbias;   // optional [N/rowbias_div,128] added to row r: rowbias[(r / rowbias_div)]
     int rowbias_div;
+    const void *f1, *f2;    // PRO_MACHIN: m_fea1 [R,6], m_fea2 [R,8] (obs dtype) — rows are generated, not read (ac:383-384)
+    const float *W1, *W2;   // PRO_MACHIN: m_fea_1_fcl.weight [128,6], m_fea_2_fcl.weight [128,8]
+    int feat_f64;
     const float *gat_a;     // EPI_GAT: [256] a_src | a_dst of the shared GATLayer (gat:68-79)
     int gat_last;           // EPI_GAT: 0 = ELU + write the next pass' node pair in place, 1 = mean of the 2 nodes -> gat_node + column stats
     float *gat_node;        // EPI_GAT last pass: [N/2,128]
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
     float *s_a = s_w + HD * HD;                                   // 4 * 32 * LDA
     float *s_bn = s_a + 4 * 32 * LDA;                             // mean | rstd | gamma | beta  (4*128)
     double *s_red = reinterpret_cast<double *>(s_bn + 4 * HD);    // 4 waves * 256
+    float *s_feat = reinterpret_cast<float *>(s_red + 4 * 256);   // PRO_MACHIN: 4 waves * 32 rows * 8
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
 #ifdef MTFJSP_STAMP
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
 #pragma unroll
         for (int i = 0; i < 16; i++) { const int ii = tid + ((i + blockIdx.x) & 15) * 256; dst[ii] = src[ii]; }   // rotated: de-phase the CUs across L2 channels
     }
-    if (PRO != PRO_PLAIN && tid < HD) {
+    if ((PRO == PRO_BNRELU || PRO == PRO_AGG) && tid < HD) {
         double su = 0, sq = 0;
         for (int r = 0; r < STAT_REP; r++) { su += A.pro_stats[r * 256 + tid]; sq += A.pro_stats[r * 256 + HD + tid]; }
         const double mean = su * A.pro_inv_rows;
@@ -139,11 +143,15 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
     double st_sum[4] = {0, 0, 0, 0}, st_sq[4] = {0, 0, 0, 0};   // per column block (lane j, block cb), EPI_STATS
     const int c4 = j * 4;
     float mean4[4], rstd4[4], g4[4], b4[4];
-    if (PRO != PRO_PLAIN)
+    if (PRO == PRO_BNRELU || PRO == PRO_AGG)
         for (int q = 0; q < 4; q++) { mean4[q] = s_bn[c4 + q]; rstd4[q] = s_bn[HD + c4 + q]; g4[q] = s_bn[2 * HD + c4 + q]; b4[q] = s_bn[3 * HD + c4 + q]; }
 
     float bias4[4];                                               // hoisted: a load inside the epilogue would force vmcnt(0)
     for (int cb = 0; cb < 4; cb++) bias4[cb] = (A.bias && !A.accumulate) ? A.bias[cb * 32 + j] : 0.f;
+    float wf[PRO == PRO_MACHIN ? 4 : 1][8];                        // this lane's 4 output columns of W1 (h = 0) or W2 (h = 1)
+    if (PRO == PRO_MACHIN)
+        for (int q = 0; q < 4; q++)
+            for (int k = 0; k < 8; k++) wf[q][k] = h == 0 ? (k < 6 ? A.W1[(c4 + q) * 6 + k] : 0.f) : A.W2[(c4 + q) * 8 + k];
     float asrc[4] = {0, 0, 0, 0}, adst[4] = {0, 0, 0, 0};
     if (EPI == EPI_GAT) for (int cb = 0; cb < 4; cb++) { asrc[cb] = A.gat_a[cb * 32 + j]; adst[cb] = A.gat_a[HD + cb * 32 + j]; }
     float4 pre[16];                                               // raw rows of the NEXT tile, in flight during the MFMA phase
@@ -162,6 +170,22 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
     };
     auto prefetch = [&](int tile) __attribute__((always_inline)) {
         const int row0 = tile * 32;
+        if (PRO == PRO_MACHIN) {
+            // lane L fetches 4 of the 256 feature words of the tile: row L/2 = (machine, node), words 4*(L&1)..+3
+            const int r = row0 + (lane >> 1), k0 = (lane & 1) * 4;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (r < A.N) {
+                const int q = r >> 1, node = r & 1, width = node ? 8 : 6;
+                for (int k = 0; k < 4; k++)
+                    if (k0 + k < width) {
+                        const size_t idx = (size_t)q * width + k0 + k;
+                        x[k] = A.feat_f64 ? (float)reinterpret_cast<const double *>(node ? A.f2 : A.f1)[idx]
+                                          : reinterpret_cast<const float *>(node ? A.f2 : A.f1)[idx];
+                    }
+            }
+            pre[0] = make_float4(x[0], x[1], x[2], x[3]);
+            return;
+        }
         if (PRO == PRO_AGG) { e_cx = en_cx; e_cy = en_cy; e_vx = en_vx; e_vy = en_vy; }   // ELL of THIS tile (fetched one iteration earlier)
 #pragma unroll
         for (int p = 0; p < 16; p++) {
@@ -190,11 +214,26 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
     for (; tile < ntiles; tile += stride) {
         const int row0 = tile * 32;
         // ------------------------------------------------------------------ transform the prefetched rows -> LDS tile
+        float *my_f = s_feat + wave * 256;
+        if (PRO == PRO_MACHIN) {
+            *reinterpret_cast<float4 *>(my_f + lane * 4) = pre[0];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
 #pragma unroll
         for (int p = 0; p < 16; p++) {
             const int r = 2 * p + h;
             const int g = row0 + r;
             float v[4] = {pre[p].x, pre[p].y, pre[p].z, pre[p].w};
+            if (PRO == PRO_MACHIN) {
+                // node 0 = m_fea_1_fcl(m_fea1) (6 -> 128), node 1 = m_fea_2_fcl(m_fea2) (8 -> 128), no bias (ac:383-384)
+                const float4 fa = *reinterpret_cast<const float4 *>(my_f + r * 8), fb = *reinterpret_cast<const float4 *>(my_f + r * 8 + 4);
+                const float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+                for (int q = 0; q < 4; q++) {
+                    float a = 0.f;
+                    for (int k = 0; k < 8; k++) a = fmaf(ff[k], wf[PRO == PRO_MACHIN ? q : 0][k], a);
+                    v[q] = g < A.N ? a : 0.f;
+                }
+            } else
             if (g < A.N) {
                 if (PRO == PRO_BNRELU) {
                     for (int q = 0; q < 4; q++) v[q] = bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
@@ -342,7 +381,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
         for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
 #endif
 }
-static size_t gemm_lds_bytes() { return (size_t)(HD * HD + 4 * 32 * LDA + 4 * HD) * 4 + 4 * 256 * 8; }
+static size_t gemm_lds_bytes() { return (size_t)(HD * HD + 4 * 32 * LDA + 4 * HD) * 4 + 4 * 256 * 8 + 4 * 32 * 8 * 4; }
 
 // ---------------------------------------------------------------------------------------------
 // Fused actor heads (ac:205-293 / ac:444-495): for a group of 16 instances one workgroup computes
@@ -662,21 +701,6 @@ __global__ void k_bcast128(int B, const float *v, float *out)
     if (i < B * HD) out[i] = v[i & 127];
 }
 
-// ---------------------------------------------------------------------------------------------
-// machine actor input projections (ac:383-384): X0 = m_fea1 W1^T (6->128), X1 = m_fea2 W2^T (8->128); rows = B*M
-template <typename OBS>
-__global__ void k_mach_in(int rows, const OBS *f1, const OBS *f2, const float *W1 /*[128,6]*/, const float *W2 /*[128,8]*/, float *X /*[rows,2,128]*/)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)rows * HD) return;
-    const int r = (int)(i >> 7), c = (int)(i & 127);
-    float a = 0.f, b = 0.f;
-    for (int k = 0; k < 6; k++) a = fmaf((float)f1[(size_t)r * 6 + k], W1[c * 6 + k], a);
-    for (int k = 0; k < 8; k++) b = fmaf((float)f2[(size_t)r * 8 + k], W2[c * 8 + k], b);
-    X[((size_t)r * 2) * HD + c] = a;                 // (machine, node) interleaved rows: node 0 = m_fea1 side, node 1 = m_fea2 side
-    X[((size_t)r * 2 + 1) * HD + c] = b;
-}
-
 // machine nodes: BatchNorm over all B*M rows (ac:434) and mean over M (ac:444). block = instance, thread = column
 __global__ __launch_bounds__(128) void k_mach_bn_pool(int B, int M, float *node /*in: pre-BN, out: normalised*/, const double *stats, double inv_rows,
                                                      const float *gamma, const float *beta, float *h_pooled)
@@ -845,6 +869,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     const int lds = (int)gemm_lds_bytes();
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_GAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_MACHIN, EPI_GAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_BNRELU, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_AGG, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
@@ -1056,20 +1081,15 @@ extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fe
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
     double *st = e->stats + 6 * STAT_REP * 256;
     HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
-    {
-        Timed t(e, "mach_in");
-        const size_t n = (size_t)R * HD;
-        if (e->cfg.obs_dtype == MTFJSP_OBS_F32)
-            hipLaunchKernelGGL((k_mach_in<float>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, R, (const float *)m_fea1, (const float *)m_fea2,
-                               W("machine_actor.m_fea_1_fcl.weight"), W("machine_actor.m_fea_2_fcl.weight"), e->X);
-        else
-            hipLaunchKernelGGL((k_mach_in<double>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, R, (const double *)m_fea1, (const double *)m_fea2,
-                               W("machine_actor.m_fea_1_fcl.weight"), W("machine_actor.m_fea_2_fcl.weight"), e->X);
-    }
     for (int pass = 0; pass < 3; pass++) {                                    // the SAME GATLayer three times (ac:409-414)
         GemmArgs a = gemm_args(e->X, 2 * R, WT("machine_actor.gat_layer.W"), nullptr, e->X);      // in place: a wave only rewrites the tile it read
         a.gat_a = W("machine_actor.gat_layer.a"); a.gat_last = pass == 2; a.gat_node = e->node; a.epi_stats = st;
-        launch_gemm<PRO_PLAIN, EPI_GAT>(e, a, "gat_pass");
+        if (pass == 0) {                                                        // input projections generated in the prologue
+            a.f1 = m_fea1; a.f2 = m_fea2; a.W1 = W("machine_actor.m_fea_1_fcl.weight"); a.W2 = W("machine_actor.m_fea_2_fcl.weight");
+            a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
+            launch_gemm<PRO_MACHIN, EPI_GAT>(e, a, "gat_pass");
+        } else
+            launch_gemm<PRO_PLAIN, EPI_GAT>(e, a, "gat_pass");
     }
     {
         Timed t(e, "mach_bn_pool");
