@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
         double var = sq * A.pro_inv_rows - mean * mean;           // biased variance (training-mode BN)
         if (var < 0) var = 0;
         s_bn[tid] = (float)mean;
-        s_bn[HD + tid] = (float)(1.0 / sqrt(var + BN_EPS));
+        s_bn[HD + tid] = 1.0f / sqrtf((float)(var + BN_EPS));
         s_bn[2 * HD + tid] = A.pro_gamma[tid];
         s_bn[3 * HD + tid] = A.pro_beta[tid];
     }
@@ -663,34 +663,59 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
             }
         }
     }
-    atomicAdd(&stats[c], ssum);
-    atomicAdd(&stats[HD + c], ssq);
+    // one atomic pair per column per block: fold the two row-halves through LDS first
+    __shared__ double s_half[256];
+    if (half == 1) { s_half[c] = ssum; s_half[HD + c] = ssq; }
+    __syncthreads();
+    if (half == 0) {
+        atomicAdd(&stats[c], ssum + s_half[c]);
+        atomicAdd(&stats[HD + c], ssq + s_half[HD + c]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
 // After the last GIN BatchNorm: h = relu(bn(z)); graph mean pool (gcn:192) and candidate gather (ac:197-207).
 // One 128-thread block per instance, thread = column.
-__global__ __launch_bounds__(128) void k_job_pool_gather(int B, int T, int J, const float *z, const double *stats, double inv_rows,
+__global__ __launch_bounds__(256) void k_job_pool_gather(int B, int T, int J, const float *z, const double *stats, double inv_rows,
                                                         const float *gamma, const float *beta, const int *cand,
                                                         float *h_pooled, float *cand_feat, float *h_nodes)
 {
-    const int b = blockIdx.x, c = threadIdx.x;
-    double su = 0, sq = 0;
-    for (int r = 0; r < STAT_REP; r++) { su += stats[r * 256 + c]; sq += stats[r * 256 + HD + c]; }
-    const double mean_d = su * inv_rows;
-    double var = sq * inv_rows - mean_d * mean_d;
-    if (var < 0) var = 0;
-    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + BN_EPS)), g = gamma[c], be = beta[c];
-    float acc = 0.f;
-    for (int v = 0; v < T; v++) {
-        const float hv = bn_relu(z[((size_t)b * T + v) * HD + c], mean, rstd, g, be);
-        acc += hv;
-        if (h_nodes) h_nodes[((size_t)b * T + v) * HD + c] = hv;
+    // one 256-thread block per instance: thread = (row group rg = tid/32 of 8, 4 columns); rows rg, rg+8, ... are
+    // streamed with 16-byte loads, the 8 partial sums are folded through LDS.
+    __shared__ float s_part[8][HD];
+    const int b = blockIdx.x, tid = threadIdx.x, rg = tid >> 5, c4 = (tid & 31) * 4;
+    float mean[4], rstd[4], g[4], be[4];
+    for (int q = 0; q < 4; q++) {
+        const int c = c4 + q;
+        double su = 0, sq = 0;
+        for (int r = 0; r < STAT_REP; r++) { su += stats[r * 256 + c]; sq += stats[r * 256 + HD + c]; }
+        const double mean_d = su * inv_rows;
+        double var = sq * inv_rows - mean_d * mean_d;
+        if (var < 0) var = 0;
+        mean[q] = (float)mean_d; rstd[q] = 1.0f / sqrtf((float)(var + BN_EPS)); g[q] = gamma[c]; be[q] = beta[c];
     }
-    h_pooled[(size_t)b * HD + c] = acc * (1.0f / (float)T);                     // sparse mm with 1/T entries
-    for (int jj = 0; jj < J; jj++) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int v = rg; v < T; v += 8) {
+        const size_t off = ((size_t)b * T + v) * HD + c4;
+        const float4 x = *reinterpret_cast<const float4 *>(z + off);
+        float hv[4] = {bn_relu(x.x, mean[0], rstd[0], g[0], be[0]), bn_relu(x.y, mean[1], rstd[1], g[1], be[1]),
+                       bn_relu(x.z, mean[2], rstd[2], g[2], be[2]), bn_relu(x.w, mean[3], rstd[3], g[3], be[3])};
+        for (int q = 0; q < 4; q++) acc[q] += hv[q];
+        if (h_nodes) *reinterpret_cast<float4 *>(h_nodes + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    }
+    for (int q = 0; q < 4; q++) s_part[rg][c4 + q] = acc[q];
+    for (int jj = rg; jj < J; jj += 8) {                                           // candidate gather (ac:197-207)
         const int v = cand[b * J + jj];
-        cand_feat[((size_t)b * J + jj) * HD + c] = bn_relu(z[((size_t)b * T + v) * HD + c], mean, rstd, g, be);
+        const float4 x = *reinterpret_cast<const float4 *>(z + ((size_t)b * T + v) * HD + c4);
+        *reinterpret_cast<float4 *>(cand_feat + ((size_t)b * J + jj) * HD + c4) =
+            make_float4(bn_relu(x.x, mean[0], rstd[0], g[0], be[0]), bn_relu(x.y, mean[1], rstd[1], g[1], be[1]),
+                        bn_relu(x.z, mean[2], rstd[2], g[2], be[2]), bn_relu(x.w, mean[3], rstd[3], g[3], be[3]));
+    }
+    __syncthreads();
+    if (tid < HD) {
+        float t = 0.f;
+        for (int r = 0; r < 8; r++) t += s_part[r][tid];
+        h_pooled[(size_t)b * HD + tid] = t * (1.0f / (float)T);                    // sparse mm with 1/T entries (gcn:192)
     }
 }
 
@@ -711,7 +736,7 @@ __global__ __launch_bounds__(128) void k_mach_bn_pool(int B, int M, float *node 
     const double mean_d = su * inv_rows;
     double var = sq * inv_rows - mean_d * mean_d;
     if (var < 0) var = 0;
-    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + BN_EPS)), g = gamma[c], be = beta[c];
+    const float mean = (float)mean_d, rstd = 1.0f / sqrtf((float)(var + BN_EPS)), g = gamma[c], be = beta[c];
     float acc = 0.f;
     for (int m = 0; m < M; m++) {
         const size_t i = ((size_t)b * M + m) * HD + c;
@@ -996,7 +1021,7 @@ extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fe
     double *st = e->stats;
     HIPCHK(e, hipMemsetAsync(st, 0, 6 * STAT_REP * 256 * sizeof(double), e->stream));
     const double invN = 1.0 / (double)N;
-    const int pgrid = e->num_cu * 4;
+    const int pgrid = e->num_cu * 8;
     {   // layer 0 / linear 0 with aggregation of the raw features
         Timed t(e, "gin0_agg_linear12");
         if (e->cfg.obs_dtype == MTFJSP_OBS_F32)
@@ -1025,7 +1050,7 @@ extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fe
     bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5);
     {
         Timed t(e, "job_pool_gather");
-        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(128), 0, e->stream, B, T, J, e->zB, st + 5 * STAT_REP * 256, invN,
+        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(256), 0, e->stream, B, T, J, e->zB, st + 5 * STAT_REP * 256, invN,
                            W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, e->cand_feat, h_nodes);
     }
     // ---- heads (ac:205-293): score = L2 tanh(L1 tanh(Wa cand + Wb pooled + Wc hm + b0))
