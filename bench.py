@@ -35,6 +35,17 @@ def env_bytes(J, M):
     return 136 * T + 156 * M + 483
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  PMC
+    collection cannot run inside the timed process, so bench.py reports the last committed measurement (B=4096 J6M6E2)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"][family]
+        return d["traffic_bytes"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(J, M, E, seconds_target=12.0):
     """Time the CPU oracle port (oracle/mtfjsp_oracle.c, scalar C, 1 core) on a bounded sample of the same workload."""
     from oracle.env_oracle import OracleBatch
@@ -148,10 +159,20 @@ def main():
             roof = {"kernel": "k_env<step> (fused state transition + rewards + scaler + observation + job mask)",
                     "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": achieved / HBM_MEASURED_GBPS,
-                    "traffic": None, "avg_launch_us": avg_s * 1e6, "launches": kd["launches"],
+                    "traffic": pmc_traffic("env_step") if (B, J, M) == (4096, 6, 6) else None,
+                    "avg_launch_us": avg_s * 1e6, "launches": kd["launches"],
                     "algorithmic_bytes_per_launch": B * env_bytes(J, M)}
         else:
             roof = ro.roofline(dom, kd)
+            if (B, J, M) == (4096, 6, 6):
+                roof["traffic"] = pmc_traffic(dom)
+        # the north-star kernel is always reported as well (extra key)
+        ke = ktimes["env_step"]
+        es = ke["ms_total"] / max(ke["launches"], 1) * 1e-3
+        roof_env = {"kernel": "k_env<step>", "bound": "hbm", "achieved": B * env_bytes(J, M) / es / 1e9, "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": B * env_bytes(J, M) / es / 1e9 / HBM_PEAK_GBPS,
+                    "frac_of_measured_copy_bw": B * env_bytes(J, M) / es / 1e9 / HBM_MEASURED_GBPS,
+                    "traffic": pmc_traffic("env_step") if (B, J, M) == (4096, 6, 6) else None, "avg_launch_us": es * 1e6}
         out = {
             "metric": "env-steps/sec (batched J%dM%dE%d)" % (J, M, E), "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -159,7 +180,7 @@ def main():
             "config": {"workload": f"J{J}M{M}E{E}, {B} parallel instances per GPU, {ro.describe()}",
                        "instances_per_gpu": B, "obs_dtype": args.obs, "policy": policy,
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
-            "roofline": roof,
+            "roofline": roof, "roofline_env_step": roof_env,
             "kernel_times_ms": {k: v for k, v in ktimes.items()}, "kernel_times_steps": prof_steps,
         }
         if world == 1 and not args.no_cpu_baseline:
