@@ -179,7 +179,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"J{J}M{M}E{E}, {B} parallel instances per GPU, {ro.describe()}",
                        "instances_per_gpu": B, "obs_dtype": args.obs, "policy": policy,
-                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective"},
+                       "parallelism": f"instances sharded over {world} GPU(s); env/encoder path has no collective; one all-gather of advantages per {ro.S}-step buffer (RCCL when world>1)"},
             "roofline": roof, "roofline_env_step": roof_env,
             "kernel_times_ms": {k: v for k, v in ktimes.items()}, "kernel_times_steps": prof_steps,
         }

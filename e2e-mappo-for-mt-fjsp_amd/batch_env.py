@@ -119,6 +119,21 @@ class DeviceBatchEnv:
             assert a.shape == (self.B,) and m.shape == (self.B,)
             capi.check(self.L.mtfjsp_step_host(self.h, a.ctypes.data, m.ctypes.data), self.h)
 
+    def step_record(self, task_idx, mach_idx, r4_out, done_out):
+        """device step that also writes this step's f32 trajectory entries: r4_out [4,B], done_out [B] (contiguous views)"""
+        assert r4_out.is_contiguous() and done_out.is_contiguous() and r4_out.dtype == torch.float32
+        capi.check(self.L.mtfjsp_step_record(self.h, task_idx.data_ptr(), mach_idx.data_ptr(), r4_out.data_ptr(), done_out.data_ptr()), self.h)
+
+    def gae(self, r, v, v_next, done, gamma, lam, out=None):
+        """un-normalised GAE advantages [S,B] for one reward channel (views with arbitrary (s,b) strides allowed for r/v/v_next)"""
+        S = done.shape[0]
+        if out is None:
+            out = torch.empty(S, self.B, dtype=torch.float32, device=self.device)
+        assert done.is_contiguous() and out.is_contiguous()
+        capi.check(self.L.mtfjsp_gae(self.h, S, r.data_ptr(), r.stride(0), r.stride(1), v.data_ptr(), v.stride(0), v.stride(1),
+                                     v_next.data_ptr(), v_next.stride(0), v_next.stride(1), done.data_ptr(), gamma, lam, out.data_ptr()), self.h)
+        return out
+
     def observe_mfea1(self, task_idx, mmask=None):
         if not torch.is_tensor(task_idx):
             task_idx = torch.as_tensor(np.ascontiguousarray(task_idx, np.int32), device=self.device)

@@ -52,6 +52,8 @@ PROTOTYPES = {
     "mtfjsp_reset_host": (_I, [_VP, _VP]),
     "mtfjsp_step": (_I, [_VP, _VP, _VP]),
     "mtfjsp_step_host": (_I, [_VP, _VP, _VP]),
+    "mtfjsp_step_record": (_I, [_VP, _VP, _VP, _VP, _VP]),
+    "mtfjsp_gae": (_I, [_VP, C.c_int32, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int64, _VP, C.c_float, C.c_float, _VP]),
     "mtfjsp_observe_mfea1": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_random_actions": (_I, [_VP, _U64, _U64, _VP, _VP, _VP]),
     "mtfjsp_export_dense_adj": (_I, [_VP, _VP]),

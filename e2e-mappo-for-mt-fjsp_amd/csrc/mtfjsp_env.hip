@@ -68,6 +68,7 @@ struct EnvParams {
     // outputs
     mtfjsp_obs_t obs;
     unsigned long long *stamps;        // diagnostic build only
+    float *rec_r4, *rec_done;          // optional f32 trajectory record of this step ([4,B], [B])
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -430,10 +431,12 @@ __global__ __launch_bounds__(WAVE, 4) void k_env(EnvParams P)
             WSYNC();
             s_sc[S_R + lane] = R; s_sc[S_MEAN + lane] = mean; s_sc[S_S + lane] = S; s_sc[S_STD + lane] = sd;
             P.obs.info[(size_t)b * 6 + 2 + lane] = scaled;
+            if (P.rec_r4) P.rec_r4[(size_t)lane * P.B + b] = (float)scaled;
         }
         if (lane == 4) {
             P.obs.info[(size_t)b * 6 + 0] = tot / P.divisor;
             P.obs.info[(size_t)b * 6 + 1] = done ? 1.0 : 0.0;
+            if (P.rec_done) P.rec_done[b] = done ? 1.f : 0.f;
         }
         if (P.obs.raw && lane >= 8 && lane < 13) {
             const int i = lane - 8;
@@ -718,6 +721,20 @@ __global__ void k_random_actions(int B, int J, int M, int T, const double *t, co
     if (job_idx) job_idx[b] = jj;
 }
 
+// GAE reverse scan (ppo:444-457 / 500-510): thread = instance, coalesced over b at every step
+__global__ void k_gae(int B, int S, const float *r, long r_ss, long r_sb, const float *v, long v_ss, long v_sb, const float *vn, long n_ss, long n_sb,
+                      const float *done, float gamma, float lam, float *adv)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float g = 0.f;
+    for (int s = S - 1; s >= 0; s--) {
+        const float delta = r[s * r_ss + b * r_sb] + gamma * vn[s * n_ss + b * n_sb] - v[s * v_ss + b * v_sb];
+        g = delta + gamma * lam * g * (1.0f - done[(size_t)s * B + b]);
+        adv[(size_t)s * B + b] = g;
+    }
+}
+
 // scaler init / per-episode reset (pe:70-85, pt:123)
 __global__ void k_scaler(int B, int full, double *scal, const uint8_t *mask)
 {
@@ -948,14 +965,21 @@ extern "C" int mtfjsp_reset_host(mtfjsp_handle_t h, const double *w3_host)
     return MTFJSP_OK;
 }
 
-extern "C" int mtfjsp_step(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx)
+static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx, float *r4, float *dn);
+extern "C" int mtfjsp_step(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx) { return step_impl(h, task_idx, mach_idx, nullptr, nullptr); }
+extern "C" int mtfjsp_step_record(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx, float *r4_out, float *done_out)
+{
+    if (!r4_out || !done_out) return MTFJSP_ERR_ARG;
+    return step_impl(h, task_idx, mach_idx, r4_out, done_out);
+}
+static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx, float *r4, float *dn)
 {
     if (!h || !task_idx || !mach_idx) return MTFJSP_ERR_ARG;
     int rc = check_ready(h, true);
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     EnvParams P = make_params(h);
-    P.task_idx = task_idx; P.mach_idx = mach_idx;
+    P.task_idx = task_idx; P.mach_idx = mach_idx; P.rec_r4 = r4; P.rec_done = dn;
     const size_t lds = env_lds_bytes(P.J, P.M, P.T, P.obs_f32);
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (h->timing) {
@@ -1131,6 +1155,18 @@ extern "C" int mtfjsp_read_state_host(mtfjsp_handle_t h, int which, void *out)
         h->err = "read_state: unknown selector";
         return MTFJSP_ERR_ARG;
     }
+}
+
+extern "C" int mtfjsp_gae(mtfjsp_handle_t h, int32_t S, const float *r, int64_t r_ss, int64_t r_sb, const float *v, int64_t v_ss, int64_t v_sb,
+                          const float *v_next, int64_t n_ss, int64_t n_sb, const float *done, float gamma, float lambda, float *adv)
+{
+    if (!h || S < 1 || !r || !v || !v_next || !done || !adv) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int B = h->cfg.batch;
+    hipLaunchKernelGGL(k_gae, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, (int)S, r, (long)r_ss, (long)r_sb, v, (long)v_ss, (long)v_sb,
+                       v_next, (long)n_ss, (long)n_sb, done, gamma, lambda, adv);
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
 }
 
 extern "C" int mtfjsp_timing_begin(mtfjsp_handle_t h)

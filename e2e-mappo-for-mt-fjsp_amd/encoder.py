@@ -102,19 +102,19 @@ class Encoder:
                 capi.check(self.L.mtfjsp_encoder_load_weight_host(self.h, (prefix + k).encode(), a.ctypes.data, a.size), self.h, enc=True)
         capi.check(self.L.mtfjsp_encoder_weights_ready(self.h), self.h, enc=True)
 
-    def job_actor_forward(self, tasks_fea, ell_col, ell_val, candidate, job_mask, h_m_prev=None, h_nodes=None):
+    def job_actor_forward(self, tasks_fea, ell_col, ell_val, candidate, job_mask, h_m_prev=None, h_nodes=None, v_out=None):
         """-> (prob [B,J], h_pooled [B,H], job_v [B,2]) device f32 tensors (owned by this object)."""
         capi.check(self.L.mtfjsp_job_actor_forward(
             self.h, tasks_fea.data_ptr(), ell_col.data_ptr(), ell_val.data_ptr(), candidate.data_ptr(), job_mask.data_ptr(),
             h_m_prev.data_ptr() if h_m_prev is not None else 0, self.job_prob.data_ptr(), self.h_pooled_o.data_ptr(),
-            self.job_v.data_ptr(), h_nodes.data_ptr() if h_nodes is not None else 0), self.h, enc=True)
-        return self.job_prob, self.h_pooled_o, self.job_v
+            (v_out if v_out is not None else self.job_v).data_ptr(), h_nodes.data_ptr() if h_nodes is not None else 0), self.h, enc=True)
+        return self.job_prob, self.h_pooled_o, (v_out if v_out is not None else self.job_v)
 
-    def machine_actor_forward(self, m_fea1, m_fea2, h_pooled_o, mmask):
+    def machine_actor_forward(self, m_fea1, m_fea2, h_pooled_o, mmask, v_out=None):
         capi.check(self.L.mtfjsp_machine_actor_forward(
             self.h, m_fea1.data_ptr(), m_fea2.data_ptr(), h_pooled_o.data_ptr(), mmask.data_ptr(), self.mch_prob.data_ptr(),
-            self.h_pooled_m.data_ptr(), self.mach_v.data_ptr()), self.h, enc=True)
-        return self.mch_prob, self.h_pooled_m, self.mach_v
+            self.h_pooled_m.data_ptr(), (v_out if v_out is not None else self.mach_v).data_ptr()), self.h, enc=True)
+        return self.mch_prob, self.h_pooled_m, (v_out if v_out is not None else self.mach_v)
 
     def sample(self, prob, greedy, seed, counter, idx_out, logp_out=None, gather_from=None, gathered_out=None):
         capi.check(self.L.mtfjsp_sample_categorical(
@@ -154,13 +154,13 @@ class ActorPair:
     def begin_episode(self):
         self.have_hm = False                                    # run:280 h_mch_pooled = None
 
-    def act(self, env, counter, task_idx, mach_idx, job_idx):
+    def act(self, env, counter, task_idx, mach_idx, job_idx, jv_out=None, mv_out=None):
         e = self.enc
         prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask,
-                                           e.h_pooled_m if self.have_hm else None)
+                                           e.h_pooled_m if self.have_hm else None, v_out=jv_out)
         e.sample(prob, self.greedy, self.seed, 2 * counter, job_idx, self.job_logp, env.candidate, task_idx)
         env.observe_mfea1(task_idx)                             # -> env.m_fea1, env.mmask
-        mprob, _, _ = e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask)
+        mprob, _, _ = e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
         e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, self.mch_logp)
         self.have_hm = True
 

@@ -25,7 +25,8 @@ def actor_available():
 
 class Rollout:
     def __init__(self, n_job, n_machine, n_edge, batch, device=0, policy="random", obs_dtype="f32",
-                 instance_seed=0, rank=0, world=1, weights=None, w3_pool_episodes=32, greedy=False, seed=1234):
+                 instance_seed=0, rank=0, world=1, weights=None, w3_pool_episodes=32, greedy=False, seed=1234,
+                 buffer_episodes=5, gamma=0.99, lam=0.98, collect=True):
         self.J, self.M, self.E, self.B = n_job, n_machine, n_edge, batch
         self.T = n_job * n_machine
         self.policy = policy
@@ -50,6 +51,19 @@ class Rollout:
         self.t_in_ep = 0
         self.episode = 0
         self.nsteps = 0
+        # trajectory record of the quantities the advantage computation needs (Appendix A of SURVEY.md, rows 17-20 and
+        # 23-26): 4 scaled reward components, done, local critic values — [S,B] device tensors, S = buffer_episodes*T
+        self.collect = collect and policy == "actor"
+        self.S = buffer_episodes * self.T
+        self.gamma, self.lam = gamma, lam
+        self.buf_pos = 0
+        self.last_adv = None
+        if self.collect:
+            f = dict(dtype=torch.float32, device=dev)
+            self.buf_r = torch.zeros(self.S, 4, batch, **f)          # mk, idle, pt, tt (scaled, pe:255-262 order)
+            self.buf_done = torch.zeros(self.S, batch, **f)
+            self.buf_jv = torch.zeros(self.S + 1, batch, 2, **f)     # job critic: mk, idle   (ac:293)
+            self.buf_mv = torch.zeros(self.S + 1, batch, 2, **f)     # machine critic: pt, tt (ac:495)
         self.actor = None
         if policy == "actor":
             from . import encoder
@@ -70,16 +84,48 @@ class Rollout:
             env.reset(self.w3_pool[self.episode % self.w3_pool.shape[0]])  # pe:87 / run:229
             if self.actor is not None:
                 self.actor.begin_episode()
-        if self.actor is not None:
-            self.actor.act(env, self.nsteps, self.task, self.mach, self.job)
+        if self.collect:
+            k = self.buf_pos                  # critic values and rewards land directly in the trajectory slots (no copies)
+            self.actor.act(env, self.nsteps, self.task, self.mach, self.job, self.buf_jv[k], self.buf_mv[k])
+            env.step_record(self.task, self.mach, self.buf_r[k], self.buf_done[k])
+            self.buf_pos += 1
+            if self.buf_pos == self.S:
+                self.finish_buffer()
         else:
-            env.random_actions(self.seed, self.nsteps, self.task, self.mach, self.job)
-        env.step(self.task, self.mach)
+            if self.actor is not None:
+                self.actor.act(env, self.nsteps, self.task, self.mach, self.job)
+            else:
+                env.random_actions(self.seed, self.nsteps, self.task, self.mach, self.job)
+            env.step(self.task, self.mach)
         self.nsteps += 1
         self.t_in_ep += 1
         if self.t_in_ep == self.T:
             self.t_in_ep = 0
             self.episode += 1
+
+    def finish_buffer(self):
+        """Rollout -> update hand-off (ppo:438-489): local-critic GAE per reward channel on this shard, then the one
+        collective of the data path — all-gather of the per-shard advantages (RCCL over xGMI when world > 1) for the
+        GLOBAL normalisation (adv - mean) / (std + 1e-5) — leaving normalised advantages + value targets on device."""
+        from . import dist as D
+        S = self.S
+        # next-state values: v_ of step s is v of step s+1 (run:451-454); within an episode's last step the reference
+        # runs one extra forward (run:455-475) — its (1-done) factor zeroes that term in the GAE recursion anyway
+        jv, mv = self.buf_jv[:S], self.buf_mv[:S]
+        jv_, mv_ = self.buf_jv[1:S + 1], self.buf_mv[1:S + 1]
+        r = self.buf_r
+        pairs = [(r[:, 0], jv[..., 0], jv_[..., 0]), (r[:, 2], mv[..., 0], mv_[..., 0]),
+                 (r[:, 3], mv[..., 1], mv_[..., 1]), (r[:, 1], jv[..., 1], jv_[..., 1])]        # mk, pt, tt, it (ppo:441-443)
+        advs = [self.env.gae(rr, v, v_, self.buf_done, self.gamma, self.lam) for rr, v, v_ in pairs]     # HIP reverse scan
+        targets = [a + p[1] for a, p in zip(advs, pairs)]
+        full = D.all_gather_advantages(advs)                      # [S,B_total] each
+        norm = []
+        lo = self.rank * self.B
+        for a_full, a_loc in zip(full, advs):
+            mean, std = a_full.mean(), a_full.std()
+            norm.append((a_loc - mean) / (std + 1e-5))
+        self.last_adv = (norm, targets)
+        self.buf_pos = 0
 
     def timing_begin(self):
         self.env.timing_begin()

@@ -125,6 +125,9 @@ int mtfjsp_reset_host(mtfjsp_handle_t h, const double *w3_host);
 /* = DGFJSPEnv_paral_step (pe:217-268): env.step (env:716-974) + RewardScaling (pe:255-260), fused with
  * the candidate / job-mask update of ppo:202-316.  One launch; writes every bound obs field. */
 int mtfjsp_step(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx);
+/* same launch, additionally recording this step's trajectory entries as f32 for the advantage computation
+ * (SURVEY Appendix A rows 11,17-20): r4_out [4,B] = scaled mk, idle, pt, tt (pe:255-262 order) ; done_out [B]. */
+int mtfjsp_step_record(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx, float *r4_out, float *done_out);
 /* host variant: returns MTFJSP_ERR_ACTION if any status word carries MTFJSP_ST_INVALID */
 int mtfjsp_step_host(mtfjsp_handle_t h, const int32_t *task_idx_host, const int32_t *mach_idx_host);
 
@@ -155,6 +158,13 @@ enum {
 int mtfjsp_read_state_host(mtfjsp_handle_t h, int which, void *out_host);
 /* copy `nbytes` from a device buffer of this handle's context to host (synchronises the stream) */
 int mtfjsp_copy_to_host(mtfjsp_handle_t h, void *dst_host, const void *src_dev, size_t nbytes);
+
+/* GAE reverse scan of ppo:438-536 for one reward channel: for every instance b, s = S-1..0:
+ *   delta = r[s,b] + gamma*v_next[s,b] - v[s,b] ; gae = delta + gamma*lambda*gae*(1-done[s,b]) ; adv[s,b] = gae
+ * r, v, v_next are f32 with element strides (stride_s, stride_b) so packed trajectory buffers can be passed as views;
+ * done and adv are [S,B] contiguous.  The result is NOT normalised (that needs the all-gather across GPUs). */
+int mtfjsp_gae(mtfjsp_handle_t h, int32_t S, const float *r, int64_t r_ss, int64_t r_sb, const float *v, int64_t v_ss, int64_t v_sb,
+               const float *v_next, int64_t n_ss, int64_t n_sb, const float *done, float gamma, float lambda, float *adv);
 
 /* kernel timing hook for bench.py: HIP events recorded on the handle's stream around every step launch
  * between begin/end; returns accumulated milliseconds and launch count. */

@@ -90,3 +90,23 @@ def test_full_rollout_with_actors_runs_clean():
     import mtfjsp_amd  # noqa: F401
     enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
     enc_mod.smoke()
+
+
+def test_gae_kernel_matches_reference_recursion():
+    """mtfjsp_gae == the reverse scan of ppo:444-457 (strided views accepted)."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    batch_env = import_module("e2e-mappo-for-mt-fjsp_amd.batch_env")
+    D = import_module("e2e-mappo-for-mt-fjsp_amd.dist")
+    B, S = 512, 36
+    env = batch_env.DeviceBatchEnv(6, 6, 2, B, obs_dtype="f32")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    r4 = torch.randn(S, 4, B, device="cuda", generator=g)
+    vv = torch.randn(S + 1, B, 2, device="cuda", generator=g)
+    done = torch.zeros(S, B, device="cuda"); done[11] = 1; done[-1] = 1
+    for ch, vc in ((0, 0), (2, 1)):
+        r, v, vn = r4[:, ch], vv[:S, :, vc], vv[1:, :, vc]
+        out = env.gae(r, v, vn, done, 0.99, 0.98)
+        ref = D.gae(r, v, vn, done, 0.99, 0.98)
+        torch.cuda.synchronize()
+        assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
