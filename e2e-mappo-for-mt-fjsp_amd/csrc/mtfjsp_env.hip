@@ -60,6 +60,9 @@ struct EnvParams {
     Link *link;                        // [B,T]
     MRec *mrec;                        // [B,M]
     short *jcnt;                       // [B,J] scheduled ops per job (ops of a job are scheduled in order)
+    double *pte;                       // [B,T] estimated / real processing energy per task (env:1995)
+    double *jmax, *jrow;               // [B,J] max estimated finish / max real finish per job
+    int *lastm;                        // [B]   node whose merged job+machine edge was created by the previous step (-1)
     double *mfea;                      // [B,M,8] f64 master copy of machines_fea
     double *scal;                      // [B,SCAL_N]
     // inputs
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_env(EnvParams P)
     // write back the state that changed
     if (RESET || valid) {
         for (int v = lane; v < T; v += WAVE) {
-            Link l; l.mach = (short)s_mach[v]; l.prev = (short)s_prev[v]; l.pos = (short)s_pos[v]; l.pad = 0;
+            Link l; l.mach = (short)s_mach[v]; l.prev = (short)s_prev[v]; l.pos = (short)s_pos[v]; l.pad = -1;   // pad = route successor (k_env_reg)
             P.link[bT + v] = l;
             if (RESET) { P.st[bT + v] = 0.0; P.ft[bT + v] = 0.0; P.dur[bT + v] = 0.0; P.psel[bT + v] = 0.0; }
         }
@@ -573,6 +576,15 @@ __global__ __launch_bounds__(WAVE, 4) void k_env(EnvParams P)
             P.mrec[(size_t)b * M + i] = r;
         }
         for (int i = lane; i < J; i += WAVE) P.jcnt[(size_t)b * J + i] = (short)s_cnt[i];
+        if (RESET) {
+            for (int v = lane; v < T; v += WAVE) P.pte[bT + v] = s_pte[v];
+            for (int j = lane; j < J; j += WAVE) {
+                double fm = s_fte[j * M];
+                for (int c = 1; c < M; c++) fm = fmax(fm, s_fte[j * M + c]);
+                P.jmax[(size_t)b * J + j] = fm; P.jrow[(size_t)b * J + j] = 0.0;
+            }
+            if (lane == 0) P.lastm[b] = -1;
+        }
         if (RESET) { for (int i = lane; i < M * 8; i += WAVE) P.mfea[(size_t)b * M * 8 + i] = s_mf[i]; }
         else if (lane < 8) P.mfea[((size_t)b * M + m) * 8 + lane] = s_mf[m * 8 + lane];
         if (lane < SCAL_N) P.scal[(size_t)b * SCAL_N + lane] = s_sc[lane];
@@ -596,6 +608,717 @@ static size_t env_lds_bytes(int J, int M, int T, bool f32)
     off = (off + 15) & ~(size_t)15;
     off += (size_t)(3 * T + J + 4 * M + 1 + 4) * sizeof(int);
     return off;
+}
+
+// =================================================================================================
+// k_env_step — incremental step kernel (one wavefront per instance, one launch per batched step).
+// Observations are persistent in the bound buffers, and one scheduling decision only changes
+//   * task a and the unscheduled rest of its job (estimated start/finish restart from ft[a])          -> M-op(a) feature rows
+//   * the in-edge slots of a, of its job successor, of its new route successor and of the node whose merged edge
+//     reverts to the job-edge refresh value (§DESIGN 3.1)                                              -> <= 4 ELL rows
+//   * machine row m of m_fea2, candidate[job], the job mask, rewards
+// so only those are rewritten; the per-task state needed for decisions (link, st, ft, dur) and for the two
+// order-sensitive sums (pt_est for numpy's pairwise sum, st/ft for the ordered idle sum) is staged in LDS.
+template <typename OBS>
+__global__ __launch_bounds__(WAVE, 8) void k_env_step(EnvParams P)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int J = P.J, M = P.M, T = P.T;
+    const unsigned invM = P.inv_M;
+#define DIVM(x) ((int)__umulhi((unsigned)(x), invM))
+#ifdef MTFJSP_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
+    const int Tp = (T + 7) & ~7;
+    double *s_st = reinterpret_cast<double *>(smem);
+    double *s_ft = s_st + T;
+    double *s_dur = s_ft + T;
+    double *s_pte = s_dur + T;
+    double *s_term = s_pte + T;                // Tp
+    double *s_tt = s_term + Tp;                // M*M
+    double *s_mind = s_tt + M * M;             // M: min_dur of the acting job's ops
+    double *s_jste = s_mind + M;               // M: estimated start of the acting job's ops
+    double *s_jfte = s_jste + M;               // M
+    double *s_jmax = s_jfte + M;               // J: max estimated finish per job
+    double *s_jrow = s_jmax + J;               // J: max real finish of scheduled ops per job
+    double *s_sc = s_jrow + J;                 // SCAL_N
+    double *s_mfr = s_sc + SCAL_N;             // 8: m_fea2 row of machine m
+    size_t off = (size_t)((4 * T + Tp + M * M + 3 * M + 2 * J + SCAL_N + 8) * sizeof(double));
+    off = (off + 15) & ~(size_t)15;
+    OBS *s_stage = reinterpret_cast<OBS *>(smem + off);        // M rows x 12
+    off += (size_t)M * 12 * sizeof(OBS);
+    off = (off + 15) & ~(size_t)15;
+    int *s_mach = reinterpret_cast<int *>(smem + off);
+    int *s_prev = s_mach + T;
+    int *s_pos = s_prev + T;
+    int *s_cnt = s_pos + T;                    // J
+    int *s_head = s_cnt + J;                   // M
+    int *s_tail = s_head + M;
+    int *s_len = s_tail + M;
+    int *s_mstart = s_len + M;                 // M+1
+
+    const size_t bT = (size_t)b * T;
+    // ---- bulk state first (independent of the action), the action-dependent second hop right behind it
+    for (int v = lane; v < T; v += WAVE) {
+        s_st[v] = P.st[bT + v]; s_ft[v] = P.ft[bT + v]; s_dur[v] = P.dur[bT + v]; s_pte[v] = P.pte[bT + v];
+        const Link l = P.link[bT + v];
+        s_mach[v] = l.mach; s_prev[v] = l.prev; s_pos[v] = l.pos;
+    }
+    for (int i = lane; i < Tp; i += WAVE) s_term[i] = 0.0;
+    for (int i = lane; i < M * M; i += WAVE) s_tt[i] = P.tt[(size_t)b * M * M + i];
+    for (int i = lane; i < M; i += WAVE) { const MRec r = P.mrec[(size_t)b * M + i]; s_head[i] = r.head; s_tail[i] = r.tail; s_len[i] = r.len; }
+    for (int i = lane; i < J; i += WAVE) { s_cnt[i] = (int)P.jcnt[(size_t)b * J + i]; s_jmax[i] = P.jmax[(size_t)b * J + i]; s_jrow[i] = P.jrow[(size_t)b * J + i]; }
+    if (lane < SCAL_N) s_sc[lane] = P.scal[(size_t)b * SCAL_N + lane];
+    const int lastm = P.lastm[b];
+    int a = P.task_idx[b], m = P.mach_idx[b];
+    bool valid = a >= 0 && a < T && m >= 0 && m < M;
+    if (!valid) { a = 0; m = 0; }
+    const int ja = DIVM(a), op = a - ja * M;
+    const double d = P.t[(bT + a) * M + m];
+    const double pk = P.p[(bT + a) * M + m];
+    for (int i = lane; i < M; i += WAVE) s_mind[i] = P.cst[bT + ja * M + i].x;
+    if (lane < 8) s_mfr[lane] = P.mfea[((size_t)b * M + m) * 8 + lane];
+    WSYNC();
+    STAMP(0);
+
+    // =========================================================================================
+    // A. scheduling (env:1476-1685)
+    int status = 0, path = 0;
+    int Pk = -1, Nk = -1, ipos = 0;
+    double st_k = 0.0, ft_k = 0.0;
+    if (valid) {
+        if (s_mach[a] >= 0) valid = false;                         // already scheduled (env:1504)
+        else if (op != 0 && s_mach[a - 1] < 0) valid = false;      // job predecessor unscheduled (env:1520)
+    }
+    if (valid) {
+        if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;               // pe:246-248
+        const double ttmm = s_tt[m * M + m];
+        const double arr_k = op == 0 ? 0.0 : s_ft[a - 1] + s_tt[s_mach[a - 1] * M + m];      // dg:46-66 over the single in-edge
+        const int len = s_len[m], head = s_head[m], tail = s_tail[m];
+        bool do_append = false;
+        if (len == 0) { path = MTFJSP_PATH_EMPTY; st_k = arr_k; ipos = 0; }                      // env:1684
+        else if (!P.left_shift) do_append = true;                                                     // env:1680
+        else {
+            const double lb_ft = arr_k + d;
+            const int jh = DIVM(head);
+            const double arr_f = (head == jh * M) ? 0.0 : s_ft[head - 1] + s_tt[s_mach[head - 1] * M + m];
+            if (lb_ft <= arr_f) { path = MTFJSP_PATH_FRONT; st_k = arr_k; ipos = 0; Nk = head; }   // env:1548
+            else if (len == 1) do_append = true;                                                     // env:1577
+            else {
+                int key = 0x7fffffff;                               // gap search over all consecutive (P,N) at once (env:1587-1604)
+                for (int v = lane; v < T; v += WAVE) {
+                    if (s_mach[v] == m && s_prev[v] >= 0) {
+                        const int Pp = s_prev[v];
+                        const int jv = DIVM(v);
+                        const double jarr = (v == jv * M) ? 0.0 : s_ft[v - 1] + s_tt[s_mach[v - 1] * M + m];
+                        const double x = (DIVM(Pp) == jv) ? ttmm : 0.0;
+                        const double nst = fmax(jarr, s_ft[Pp] + x);
+                        const bool ok = !(lb_ft > nst) && !((nst - s_ft[Pp]) < d);
+                        if (ok) { const int kk = (s_pos[v] << 16) | v; key = kk < key ? kk : key; }
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(key, o); key = other < key ? other : key; }
+                if (key != 0x7fffffff) {
+                    path = MTFJSP_PATH_BETWEEN;
+                    Nk = key & 0xffff; ipos = key >> 16; Pk = s_prev[Nk];
+                    const double x = (DIVM(Pk) == ja) ? ttmm : 0.0;
+                    st_k = fmax(arr_k, s_ft[Pk] + x);                          // env:1619
+                } else do_append = true;                                       // env:1676
+            }
+        }
+        if (do_append) {                                                       // env:1689-1775
+            path = MTFJSP_PATH_APPEND;
+            const double x = (DIVM(tail) == ja) ? ttmm : 0.0;
+            st_k = fmax(arr_k, s_ft[tail] + x);
+            ipos = len; Pk = tail;
+        }
+        ft_k = st_k + d;
+        WSYNC();
+        if (ipos < len)
+            for (int v = lane; v < T; v += WAVE)
+                if (s_mach[v] == m && s_pos[v] >= ipos) s_pos[v] += 1;
+        WSYNC();
+        if (lane == 0) {
+            s_mach[a] = m; s_prev[a] = Pk; s_pos[a] = ipos;
+            s_st[a] = st_k; s_ft[a] = ft_k; s_dur[a] = d; s_pte[a] = d * pk;      // env:356,2175
+            if (Nk >= 0) s_prev[Nk] = a;
+            if (ipos == 0) s_head[m] = a;
+            if (ipos == len) s_tail[m] = a;
+            s_len[m] = len + 1;
+            s_cnt[ja] += 1;
+            s_sc[S_NSCHED] += 1.0;
+        }
+        status |= path;
+        WSYNC();
+    } else status |= MTFJSP_ST_INVALID;
+    STAMP(1);
+    if (!valid) {                                                               // nothing changes; observations persist
+        const bool all_done = s_sc[S_NSCHED] == (double)T;
+        if (lane < 6) P.obs.info[(size_t)b * 6 + lane] = (lane == 1 && all_done) ? 1.0 : 0.0;
+        if (P.obs.raw && lane < 5) P.obs.raw[(size_t)b * 5 + lane] = 0.0;
+        if (P.rec_r4 && lane < 4) P.rec_r4[(size_t)lane * P.B + b] = 0.f;
+        if (P.rec_done && lane == 4) P.rec_done[b] = all_done ? 1.f : 0.f;
+        if (lane == 5) P.obs.status[b] = status;
+        return;
+    }
+
+    // =========================================================================================
+    // B. costs
+    {   // machine route offsets: exclusive scan of the route lengths
+        int x = lane < M ? s_len[lane] : 0, incl = x;
+        for (int o = 1; o < WAVE; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+        if (lane < M) s_mstart[lane] = incl - x;
+        if (lane == M - 1) s_mstart[M] = incl;
+    }
+    // estimated start/finish of the acting job's ops (env:1920-1999): lanes = ops of job ja; every lane replays the
+    // reference's left-to-right add sequence from the last op with a non-zero real finish time
+    double my_fte = -INFINITY, my_rft = 0.0;
+    if (lane < M) {
+        const int c = lane, v = ja * M + c;
+        const bool s = s_mach[v] >= 0;
+        double ste, fte;
+        if (s && s_ft[v] != 0.0) { ste = s_st[v]; fte = s_ft[v]; }
+        else {
+            int k0 = c;
+            while (k0 > 0 && !(s_mach[ja * M + k0 - 1] >= 0 && s_ft[ja * M + k0 - 1] != 0.0)) k0--;
+            double acc = k0 > 0 ? s_ft[ja * M + k0 - 1] : 0.0, prev = acc;
+            for (int k = k0; k <= c; k++) { prev = acc; acc = acc + s_mind[k]; }
+            fte = acc;
+            ste = s ? s_st[v] : (c == 0 ? 0.0 : prev);
+        }
+        s_jste[c] = ste; s_jfte[c] = fte;
+        my_fte = fte;
+        my_rft = s ? s_ft[v] : 0.0;
+    }
+    {   // per-job maxima of the acting job (row maximum of ft_est for the makespan; of real ft for the job mask, ppo:265-275)
+        double fm = my_fte, rm = lane < M ? my_rft : -INFINITY;
+        for (int o = 32; o > 0; o >>= 1) { fm = fmax(fm, __shfl_xor(fm, o)); rm = fmax(rm, __shfl_xor(rm, o)); }
+        if (lane == 0) { s_jmax[ja] = fm; s_jrow[ja] = rm; }
+    }
+    WSYNC();
+    for (int v = lane; v < T; v += WAVE)                                       // idle-time terms in (machine, position) order (dg:144-170)
+        if (s_mach[v] >= 0) {
+            const int pr = s_prev[v];
+            s_term[s_mstart[s_mach[v]] + s_pos[v]] = pr < 0 ? s_st[v] : s_st[v] - s_ft[pr];
+        }
+    double mk = -INFINITY;                                                     // env:894 np.amax over all tasks
+    for (int j0 = 0; j0 < J; j0 += WAVE) { const int j = j0 + lane; if (j < J) mk = fmax(mk, s_jmax[j]); }
+    mk = wave_max(mk);
+    WSYNC();
+    STAMP(2);
+    double e1;                                                                 // env:896 np.sum in numpy's order
+    if (T >= 8 && T <= 128) {
+        double r = 0.0;
+        const int nb = T - (T & 7);
+        if (lane < 8) { r = s_pte[lane]; for (int i = 8 + lane; i < nb; i += 8) r += s_pte[i]; }
+        r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
+        for (int i = nb; i < T; i++) r += s_pte[i];
+        e1 = 0.0 + __shfl(r, 0);
+    } else e1 = np_sum(s_pte, T);
+    const int nsched = s_mstart[M];
+    double idle = 0.0;                                                         // ordered idle sum (dg:147-168)
+    for (int i = 0; i < nsched; i += 8) {
+        const double t0 = s_term[i], t1 = s_term[i + 1], t2 = s_term[i + 2], t3 = s_term[i + 3];
+        const double t4 = s_term[i + 4], t5 = s_term[i + 5], t6 = s_term[i + 6], t7 = s_term[i + 7];
+        idle = idle + t0; idle = idle + t1; idle = idle + t2; idle = idle + t3;
+        idle = idle + t4; idle = idle + t5; idle = idle + t6; idle = idle + t7;
+    }
+    const double new_tr = (op == 0) ? 0.0 : s_tt[s_mach[a - 1] * M + m];      // env:872-876
+    const double trans_this = s_sc[S_TR_THIS] + new_tr;
+    const double mk_prev = s_sc[S_MK_PREV], e1_prev = s_sc[S_E1_PREV];
+    const double tr_prev = s_sc[S_TR_PREV], id_prev = s_sc[S_ID_PREV];
+    const double r_t = 1.0 * mk_prev - mk;                                     // env:1066
+    double r_pt = 1.0 * e1_prev - e1;
+    r_pt = r_pt / (double)T;                                                   // env:1073-1076
+    const double r_tt = 1.0 * tr_prev - trans_this;                            // env:1083
+    const double r_idle = 1.0 * id_prev - idle;                                // env:1088
+    const double tot = (P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1) / P.divisor;   // env:1164
+    const bool done = nsched == T;                                             // env:797-800
+    const double scN = s_sc[S_N];
+    double sR = 0, sMean = 0, sS = 0, sSd = 0, scaled = 0;
+    if (lane < 4) {                                                            // reward scaling, one channel per lane (pt:54-124)
+        const double x = lane == 0 ? r_t : lane == 1 ? r_idle : lane == 2 ? r_pt : r_tt;
+        const double n = scN + 1.0;
+        sR = P.gamma * s_sc[S_R + lane] + x;
+        sS = s_sc[S_S + lane];
+        if (n == 1.0) { sMean = sR; sSd = fabs(sR); }
+        else {
+            const double old = s_sc[S_MEAN + lane];
+            sMean = old + (sR - old) / n;
+            sS = sS + (sR - old) * (sR - sMean);
+            sSd = sqrt(sS / n);
+        }
+        scaled = x / (sSd + 1e-8);
+    }
+    WSYNC();
+    if (lane < 4) {
+        s_sc[S_R + lane] = sR; s_sc[S_MEAN + lane] = sMean; s_sc[S_S + lane] = sS; s_sc[S_STD + lane] = sSd;
+        P.obs.info[(size_t)b * 6 + 2 + lane] = scaled;
+        if (P.rec_r4) P.rec_r4[(size_t)lane * P.B + b] = (float)scaled;
+    }
+    if (lane == 4) {
+        P.obs.info[(size_t)b * 6 + 0] = tot;
+        P.obs.info[(size_t)b * 6 + 1] = done ? 1.0 : 0.0;
+        if (P.rec_done) P.rec_done[b] = done ? 1.f : 0.f;
+        s_sc[S_N] = scN + 1.0;
+        s_sc[S_MK_PREV] = mk; s_sc[S_E1_PREV] = e1; s_sc[S_TR_PREV] = trans_this; s_sc[S_ID_PREV] = idle;   // env:932-936
+        s_sc[S_TR_THIS] = done ? 0.0 : trans_this;                             // env:950-960
+        s_mfr[0] = s_ft[s_tail[m]];                                            // env:2315-2340
+        s_mfr[1] += (pk * d) / (double)T;
+        s_mfr[2] += new_tr;
+        s_mfr[3] += idle - id_prev;
+        s_mfr[4] += 1;
+    }
+    if (P.obs.raw && lane >= 8 && lane < 13) {
+        const int i = lane - 8;
+        P.obs.raw[(size_t)b * 5 + i] = i == 0 ? tot : i == 1 ? r_t : i == 2 ? r_idle : i == 3 ? r_pt : r_tt;
+    }
+    if (lane == 5) P.obs.status[b] = status;
+    WSYNC();
+    STAMP(3);
+
+    // =========================================================================================
+    // C. the observation rows that changed
+    {   // feature rows a .. end of job (env:2245-2277)
+        const int nrow = M - op;
+        if (lane < nrow) {
+            const int c = op + lane, v = a + lane;
+            const int pr = s_prev[a];
+            const bool merged0 = pr >= 0 && op != 0 && pr == a - 1;
+            OBS *f = s_stage + lane * 12;
+            f[0] = (OBS)s_jste[c]; f[1] = (OBS)s_jfte[c]; f[2] = (OBS)s_pte[v];
+            const bool isa = lane == 0;
+            f[3] = (OBS)(isa ? 1.0 : 0.0);
+            f[4] = (OBS)(isa ? (1 + ((pr >= 0 && !merged0) ? 1 : 0)) : 1);    // len(G.in_edges)
+            f[5] = (OBS)(isa ? m + 1 : 0);
+            f[6] = (OBS)(isa ? d : 0.0);
+            f[7] = (OBS)(isa ? pk : 0.0);
+            f[8] = (OBS)(ja + 1);
+            f[9] = (OBS)s_sc[S_W3]; f[10] = (OBS)s_sc[S_W3 + 1]; f[11] = (OBS)s_sc[S_W3 + 2];
+        }
+        WSYNC();
+        const int n16 = nrow * 12 * (int)sizeof(OBS) / 16;
+        const uint4 *src = reinterpret_cast<const uint4 *>(s_stage);
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + a) * 12);
+        for (int i = lane; i < n16; i += WAVE) dst[i] = src[i];
+    }
+    {   // in-edge (ELL) rows: a, its job successor, its new route successor, the node whose merged edge reverts
+        const int merged_now = (Pk >= 0 && op != 0 && Pk == a - 1) ? a : -1;
+        int v = -1;
+        if (lane == 0) v = a;
+        else if (lane == 1) v = (op + 1 < M) ? a + 1 : -1;
+        else if (lane == 2) v = Nk;
+        else if (lane == 3) v = lastm;
+        if (v >= 0) {
+            const int mv = s_mach[v];
+            const bool s = mv >= 0;
+            const int jv = DIVM(v), opv = v - jv * M;
+            const int pr = s_prev[v];
+            const bool merged = pr >= 0 && opv != 0 && pr == v - 1;
+            int c_job = -1, c_mch = -1;
+            float a_job = 0.f, a_mch = 0.f;
+            if (opv != 0) {
+                const int u = v - 1, mu = s_mach[u];
+                double w, nd;
+                if (mu < 0) { w = 1.0; nd = 1.0; }
+                else {
+                    nd = s_dur[u];
+                    if (merged && v == merged_now) w = s_dur[u] + s_tt[mu * M + mv] + (s_st[v] - s_ft[u]);     // env:1607-1675,1703-1765
+                    else w = s_dur[u] + (s ? s_tt[mu * M + mv] : 0.0);                                          // env:1384-1422
+                }
+                long A = trunc_l(w);
+                if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }                   // env:2019, 2060-2062
+            }
+            if (pr >= 0 && !merged) {
+                const double x = (DIVM(pr) == jv) ? s_tt[s_mach[pr] * M + mv] : 0.0;
+                const double w = s_dur[pr] + x + (s_st[v] - s_ft[pr]);
+                long A = trunc_l(w);
+                if (A != 0) { A = trunc_l((double)A - s_dur[pr]) + 1; c_mch = pr; a_mch = (float)A; }
+            }
+            reinterpret_cast<int2 *>(P.obs.ell_col)[bT + v] = make_int2(c_job, c_mch);
+            reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(a_job, a_mch);
+            if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + v) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
+        }
+        if (lane == 6) P.lastm[b] = merged_now;
+    }
+    if (lane < 8) reinterpret_cast<OBS *>(P.obs.m_fea2)[((size_t)b * M + m) * 8 + lane] = (OBS)s_mfr[lane];
+    STAMP(5);
+
+    // =========================================================================================
+    // D. candidate + job mask (ppo:202-316)
+    {
+        int cmin = M;
+        double mn = INFINITY;
+        for (int j0 = 0; j0 < J; j0 += WAVE) {
+            const int j = j0 + lane;
+            int c = j < J ? s_cnt[j] : M;
+            for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(c, o); c = y < c ? y : c; }
+            cmin = c < cmin ? c : cmin;
+        }
+        if (cmin > 0 && cmin < M)
+            for (int j0 = 0; j0 < J; j0 += WAVE) {
+                const int j = j0 + lane;
+                double r = (j < J && s_cnt[j] != M) ? s_jrow[j] : INFINITY;
+                for (int o = 32; o > 0; o >>= 1) r = fmin(r, __shfl_xor(r, o));
+                mn = fmin(mn, r);
+            }
+        for (int j = lane; j < J; j += WAVE) {
+            const int cnt = s_cnt[j];
+            unsigned char mk_;
+            if (cmin == 0) mk_ = cnt >= 1;
+            else if (cmin == M) mk_ = 1;
+            else mk_ = !((cnt == M ? INFINITY : s_jrow[j]) == mn);
+            P.obs.job_mask[(size_t)b * J + j] = mk_;
+        }
+        if (lane == 0) P.obs.candidate[(size_t)b * J + ja] = ja * M + (s_cnt[ja] < M ? s_cnt[ja] : M - 1);
+    }
+    // ---- write back the state that changed
+    for (int v = lane; v < T; v += WAVE) {
+        Link l; l.mach = (short)s_mach[v]; l.prev = (short)s_prev[v]; l.pos = (short)s_pos[v]; l.pad = 0;
+        P.link[bT + v] = l;
+    }
+    if (lane == 0) { P.st[bT + a] = st_k; P.ft[bT + a] = ft_k; P.dur[bT + a] = d; P.psel[bT + a] = pk; P.pte[bT + a] = d * pk; }
+    if (lane == 1) { P.jcnt[(size_t)b * J + ja] = (short)s_cnt[ja]; P.jmax[(size_t)b * J + ja] = s_jmax[ja]; P.jrow[(size_t)b * J + ja] = s_jrow[ja]; }
+    if (lane == 2) { MRec r; r.head = (short)s_head[m]; r.tail = (short)s_tail[m]; r.len = (short)s_len[m]; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+    if (lane >= 8 && lane < 16) P.mfea[((size_t)b * M + m) * 8 + lane - 8] = s_mfr[lane - 8];
+    if (lane < SCAL_N) P.scal[(size_t)b * SCAL_N + lane] = s_sc[lane];
+#ifdef MTFJSP_STAMP
+    STAMP(6);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(7);
+    if (P.stamps && lane == 0) for (int i = 0; i < 8; i++) P.stamps[(size_t)b * 8 + i] = ph[i];
+#endif
+#undef DIVM
+}
+static size_t env_step_lds_bytes(int J, int M, int T, bool f32)
+{
+    const int Tp = (T + 7) & ~7;
+    size_t off = (size_t)(4 * T + Tp + M * M + 3 * M + 2 * J + SCAL_N + 8) * sizeof(double);
+    off = (off + 15) & ~(size_t)15;
+    off += (size_t)M * 12 * (f32 ? 4 : 8);
+    off = (off + 15) & ~(size_t)15;
+    off += (size_t)(3 * T + J + 4 * M + 1 + 4) * sizeof(int);
+    return off;
+}
+
+// =================================================================================================
+// k_env_reg — the step kernel for instances with T <= 64 and M*M <= 64 (J6M6E2 and the like): NO LDS.
+// lane = task: each lane keeps its task's (machine, route links, st, ft, dur, pt_est) in registers; lanes < M also keep
+// a machine record, lanes < J a job record, lanes < M*M one transport-time entry.  The acting task/machine are
+// wave-uniform, so every gather of the scheduling decision is a v_readlane with a scalar index (no memory hop), the
+// left-shift gap test runs on all lanes at once (ballot) and routes are walked by scalar loops.  Same incremental
+// output contract as k_env_step.  The whole step is ~2 global round trips + register/scalar work.
+__device__ __forceinline__ int rl_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+__device__ __forceinline__ double rl_d(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+template <typename OBS>
+__global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
+{
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int J = P.J, M = P.M, T = P.T;
+    const unsigned invM = P.inv_M;
+#define DIVM(x) ((int)__umulhi((unsigned)(x), invM))
+    const size_t bT = (size_t)b * T;
+    const int v = lane;
+    const bool isT = v < T;
+    // ---- bulk state (independent of the action)
+    int mach = -1, prev = -1, next = -1, pos = 0;
+    double st = 0.0, ft = 0.0, dur = 0.0, pte = 0.0;
+    if (isT) {
+        const Link l = P.link[bT + v];
+        mach = l.mach; prev = l.prev; pos = l.pos; next = l.pad;
+        st = P.st[bT + v]; ft = P.ft[bT + v]; dur = P.dur[bT + v]; pte = P.pte[bT + v];
+    }
+    const double ttv = lane < M * M ? P.tt[(size_t)b * M * M + lane] : 0.0;
+    int head_ = -1, tail_ = -1, len_ = 0;
+    if (lane < M) { const MRec r = P.mrec[(size_t)b * M + lane]; head_ = r.head; tail_ = r.tail; len_ = r.len; }
+    int cnt_ = 0; double jmax_ = -INFINITY, jrow_ = 0.0;
+    if (lane < J) { cnt_ = (int)P.jcnt[(size_t)b * J + lane]; jmax_ = P.jmax[(size_t)b * J + lane]; jrow_ = P.jrow[(size_t)b * J + lane]; }
+    const double sc = lane < SCAL_N ? P.scal[(size_t)b * SCAL_N + lane] : 0.0;
+    const int lastm = uni(P.lastm[b]);
+    int a = uni(P.task_idx[b]), m = uni(P.mach_idx[b]);
+    bool valid = a >= 0 && a < T && m >= 0 && m < M;
+    if (!valid) { a = 0; m = 0; }
+    const int ja = DIVM(a), op = a - ja * M;
+    // ---- second hop (depends on the action)
+    const double d = P.t[(bT + a) * M + m];
+    const double pk = P.p[(bT + a) * M + m];
+    const double md = lane < M ? P.cst[bT + ja * M + lane].x : 0.0;
+    double mfr = lane < 8 ? P.mfea[((size_t)b * M + m) * 8 + lane] : 0.0;
+    const int jv = DIVM(v), opv = v - jv * M;
+
+    // =========================================================================================
+    // A. scheduling (env:1476-1685)
+    int status = 0, path = 0, Pk = -1, Nk = -1, ipos = 0;
+    double st_k = 0.0;
+    int mach_p = -1;
+    if (valid) {
+        if (rl_i(mach, a) >= 0) valid = false;                                  // env:1504
+        else if (op != 0) { mach_p = rl_i(mach, a - 1); if (mach_p < 0) valid = false; }   // env:1520
+    }
+    const int len = rl_i(len_, m), head = rl_i(head_, m), tail = rl_i(tail_, m);
+    const double ttmm = rl_d(ttv, m * M + m);
+    if (valid) {
+        if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;                            // pe:246-248
+        const double arr_k = op == 0 ? 0.0 : rl_d(ft, a - 1) + rl_d(ttv, mach_p * M + m);   // dg:46-66
+        bool do_append = false;
+        if (len == 0) { path = MTFJSP_PATH_EMPTY; st_k = arr_k; ipos = 0; }                 // env:1684
+        else if (!P.left_shift) do_append = true;                                               // env:1680
+        else {
+            const double lb_ft = arr_k + d;
+            const int jh = DIVM(head);
+            const double arr_f = (head == jh * M) ? 0.0 : rl_d(ft, head - 1) + rl_d(ttv, rl_i(mach, head - 1) * M + m);
+            if (lb_ft <= arr_f) { path = MTFJSP_PATH_FRONT; st_k = arr_k; ipos = 0; Nk = head; }   // env:1548
+            else if (len == 1) do_append = true;                                                 // env:1577
+            else {
+                // gap test of env:1587-1604 on every lane at once, then the first hit in route order by a scalar walk
+                const int pi = prev >= 0 ? prev : 0, vi = v > 0 ? v - 1 : 0;
+                const double ftP = __shfl(ft, pi), ftj = __shfl(ft, vi);
+                const int mj = __shfl(mach, vi);
+                const double ttj = __shfl(ttv, (mj >= 0 ? mj : 0) * M + m);
+                const double jarr = (opv == 0) ? 0.0 : ftj + ttj;
+                const double x = (DIVM(pi) == jv) ? ttmm : 0.0;
+                const double nst = fmax(jarr, ftP + x);
+                const bool ok = isT && mach == m && prev >= 0 && !(lb_ft > nst) && !((nst - ftP) < d);
+                const unsigned long long okm = __ballot(ok);
+                int cur = rl_i(next, head);
+                while (cur >= 0) {
+                    if ((okm >> cur) & 1ull) { Nk = cur; break; }
+                    cur = rl_i(next, cur);
+                }
+                if (Nk >= 0) {
+                    path = MTFJSP_PATH_BETWEEN;
+                    ipos = rl_i(pos, Nk); Pk = rl_i(prev, Nk);
+                    const double xx = (DIVM(Pk) == ja) ? ttmm : 0.0;
+                    st_k = fmax(arr_k, rl_d(ft, Pk) + xx);                      // env:1619
+                } else do_append = true;                                        // env:1676
+            }
+        }
+        if (do_append) {                                                        // env:1689-1775
+            path = MTFJSP_PATH_APPEND;
+            const double xx = (DIVM(tail) == ja) ? ttmm : 0.0;
+            st_k = fmax(arr_k, rl_d(ft, tail) + xx);
+            ipos = len; Pk = tail;
+        }
+        status |= path;
+    } else status |= MTFJSP_ST_INVALID;
+    if (!valid) {                                                               // nothing changes; observations persist
+        const bool all_done = rl_d(sc, S_NSCHED) == (double)T;
+        if (lane < 6) P.obs.info[(size_t)b * 6 + lane] = (lane == 1 && all_done) ? 1.0 : 0.0;
+        if (P.obs.raw && lane < 5) P.obs.raw[(size_t)b * 5 + lane] = 0.0;
+        if (P.rec_r4 && lane < 4) P.rec_r4[(size_t)lane * P.B + b] = 0.f;
+        if (P.rec_done && lane == 4) P.rec_done[b] = all_done ? 1.f : 0.f;
+        if (lane == 5) P.obs.status[b] = status;
+        return;
+    }
+    const double ft_k = st_k + d;
+    // ---- apply: register updates on the owning lanes
+    if (isT && mach == m && pos >= ipos) pos += 1;
+    if (v == a) { mach = m; prev = Pk; next = Nk; pos = ipos; st = st_k; ft = ft_k; dur = d; pte = d * pk; }    // env:356,2175
+    if (v == Nk) prev = a;
+    if (v == Pk) next = a;
+    if (lane == m) { if (ipos == 0) head_ = a; if (ipos == len) tail_ = a; len_ = len + 1; }
+    if (lane == ja) cnt_ += 1;
+    const int nsched = (int)rl_d(sc, S_NSCHED) + 1;
+
+    // =========================================================================================
+    // B. costs
+    // estimated start/finish of the acting job's ops: the reference's left-to-right loop (env:1965-1995), run with
+    // scalar indices; lane ja*M+c keeps its own (ste, fte)
+    double my_ste = 0.0, my_fte = 0.0, jmax_new = -INFINITY, jrow_new = 0.0, accp = 0.0;
+    for (int c = 0; c < M; c++) {
+        const int vv = ja * M + c;
+        const bool s = rl_i(mach, vv) >= 0;
+        const double f = rl_d(ft, vv);
+        double fte_c, ste_c;
+        if (s && f != 0.0) { fte_c = f; ste_c = rl_d(st, vv); }
+        else {
+            fte_c = (c ? accp : 0.0) + rl_d(md, c);
+            ste_c = s ? rl_d(st, vv) : (c ? accp : 0.0);
+        }
+        accp = fte_c;
+        if (v == vv) { my_ste = ste_c; my_fte = fte_c; }
+        jmax_new = c == 0 ? fte_c : fmax(jmax_new, fte_c);
+        const double f0 = s ? f : 0.0;
+        jrow_new = c == 0 ? f0 : fmax(jrow_new, f0);                            // ppo:265-275 row maximum of real finish times
+    }
+    if (lane == ja) { jmax_ = jmax_new; jrow_ = jrow_new; }
+    double mk = rl_d(jmax_, 0);                                                 // env:894 np.amax
+    for (int j = 1; j < J; j++) mk = fmax(mk, rl_d(jmax_, j));
+    double e1;                                                                  // env:896 np.sum, numpy's pairwise order
+    if (T < 8) { e1 = 0.0; for (int i = 0; i < T; i++) e1 += rl_d(pte, i); }
+    else {
+        double r0 = rl_d(pte, 0), r1 = rl_d(pte, 1), r2 = rl_d(pte, 2), r3 = rl_d(pte, 3);
+        double r4 = rl_d(pte, 4), r5 = rl_d(pte, 5), r6 = rl_d(pte, 6), r7 = rl_d(pte, 7);
+        int i = 8;
+        for (; i < T - (T & 7); i += 8) {
+            r0 += rl_d(pte, i); r1 += rl_d(pte, i + 1); r2 += rl_d(pte, i + 2); r3 += rl_d(pte, i + 3);
+            r4 += rl_d(pte, i + 4); r5 += rl_d(pte, i + 5); r6 += rl_d(pte, i + 6); r7 += rl_d(pte, i + 7);
+        }
+        e1 = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+        for (; i < T; i++) e1 += rl_d(pte, i);
+    }
+    e1 = 0.0 + e1;
+    // idle time (dg:144-170): term per lane, summed in (machine, route) order by a scalar walk
+    const double ftPr = __shfl(ft, prev >= 0 ? prev : 0);
+    const double term = prev < 0 ? st : st - ftPr;
+    double idle = 0.0;
+    for (int mm = 0; mm < M; mm++) {
+        int cur = rl_i(head_, mm);
+        while (cur >= 0) { idle = idle + rl_d(term, cur); cur = rl_i(next, cur); }
+    }
+    const double new_tr = (op == 0) ? 0.0 : rl_d(ttv, mach_p * M + m);          // env:872-876
+    const double trans_this = rl_d(sc, S_TR_THIS) + new_tr;
+    const double mk_prev = rl_d(sc, S_MK_PREV), e1_prev = rl_d(sc, S_E1_PREV), tr_prev = rl_d(sc, S_TR_PREV), id_prev = rl_d(sc, S_ID_PREV);
+    const double r_t = 1.0 * mk_prev - mk;                                      // env:1066
+    double r_pt = 1.0 * e1_prev - e1;
+    r_pt = r_pt / (double)T;                                                    // env:1073-1076
+    const double r_tt = 1.0 * tr_prev - trans_this;                             // env:1083
+    const double r_idle = 1.0 * id_prev - idle;                                 // env:1088
+    const double tot = (P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1) / P.divisor;   // env:1164
+    const bool done = nsched == T;                                              // env:797-800
+    // reward scaling, one channel per lane (pt:54-124): lane c gathers its channel's state slots
+    {
+        const int c = lane & 3;
+        const double sR0 = __shfl(sc, S_R + c), sM0 = __shfl(sc, S_MEAN + c), sS0 = __shfl(sc, S_S + c);
+        const double n = rl_d(sc, S_N) + 1.0;
+        if (lane < 4) {
+            const double x = lane == 0 ? r_t : lane == 1 ? r_idle : lane == 2 ? r_pt : r_tt;
+            const double R = P.gamma * sR0 + x;
+            double mean, S = sS0, sd;
+            if (n == 1.0) { mean = R; sd = fabs(R); }
+            else { mean = sM0 + (R - sM0) / n; S = S + (R - sM0) * (R - mean); sd = sqrt(S / n); }
+            const double scaled = x / (sd + 1e-8);
+            double *s = P.scal + (size_t)b * SCAL_N;
+            s[S_R + lane] = R; s[S_MEAN + lane] = mean; s[S_S + lane] = S; s[S_STD + lane] = sd;
+            P.obs.info[(size_t)b * 6 + 2 + lane] = scaled;
+            if (P.rec_r4) P.rec_r4[(size_t)lane * P.B + b] = (float)scaled;
+        }
+        if (lane == 4) {
+            double *s = P.scal + (size_t)b * SCAL_N;
+            s[S_N] = n; s[S_NSCHED] = (double)nsched;
+            s[S_MK_PREV] = mk; s[S_E1_PREV] = e1; s[S_TR_PREV] = trans_this; s[S_ID_PREV] = idle;    // env:932-936
+            s[S_TR_THIS] = done ? 0.0 : trans_this;                              // env:950-960
+            P.obs.info[(size_t)b * 6 + 0] = tot;
+            P.obs.info[(size_t)b * 6 + 1] = done ? 1.0 : 0.0;
+            if (P.rec_done) P.rec_done[b] = done ? 1.f : 0.f;
+        }
+        if (P.obs.raw && lane >= 8 && lane < 13) {
+            const int i = lane - 8;
+            P.obs.raw[(size_t)b * 5 + i] = i == 0 ? tot : i == 1 ? r_t : i == 2 ? r_idle : i == 3 ? r_pt : r_tt;
+        }
+        if (lane == 5) P.obs.status[b] = status;
+    }
+    // machine features of the acting machine (env:2315-2340): lanes 0..4 own one column each
+    {
+        const double ft_tail = rl_d(ft, rl_i(tail_, m));
+        if (lane == 0) mfr = ft_tail;
+        else if (lane == 1) mfr += (pk * d) / (double)T;
+        else if (lane == 2) mfr += new_tr;
+        else if (lane == 3) mfr += idle - id_prev;
+        else if (lane == 4) mfr += 1;
+        if (lane < 8) {
+            P.mfea[((size_t)b * M + m) * 8 + lane] = mfr;
+            reinterpret_cast<OBS *>(P.obs.m_fea2)[((size_t)b * M + m) * 8 + lane] = (OBS)mfr;
+        }
+    }
+
+    // =========================================================================================
+    // C. the observation rows that changed
+    const double w30 = rl_d(sc, S_W3), w31 = rl_d(sc, S_W3 + 1), w32 = rl_d(sc, S_W3 + 2);
+    const bool merged_a = Pk >= 0 && op != 0 && Pk == a - 1;
+    if (isT && jv == ja && opv >= op) {                                         // feature rows a .. end of job (env:2245-2277)
+        const bool isa = v == a;
+        OBS f[12];
+        f[0] = (OBS)my_ste; f[1] = (OBS)my_fte; f[2] = (OBS)pte;
+        f[3] = (OBS)(isa ? 1.0 : 0.0);
+        f[4] = (OBS)(isa ? (1 + ((Pk >= 0 && !merged_a) ? 1 : 0)) : 1);
+        f[5] = (OBS)(isa ? m + 1 : 0);
+        f[6] = (OBS)(isa ? d : 0.0);
+        f[7] = (OBS)(isa ? pk : 0.0);
+        f[8] = (OBS)(ja + 1);
+        f[9] = (OBS)w30; f[10] = (OBS)w31; f[11] = (OBS)w32;
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + v) * 12);
+        const uint4 *src = reinterpret_cast<const uint4 *>(f);
+        for (int i = 0; i < (int)(12 * sizeof(OBS) / 16); i++) dst[i] = src[i];
+    }
+    {   // in-edge (ELL) rows of a, its job successor, its new route successor, and the node whose merged edge reverts:
+        // all indices are wave-uniform -> computed with scalar-index register reads, written by one lane each
+        const int merged_now = merged_a ? a : -1;
+        const int rows[4] = {a, (op + 1 < M) ? a + 1 : -1, Nk, lastm};
+        for (int q = 0; q < 4; q++) {
+            const int vv = rows[q];
+            if (vv < 0) continue;
+            const int mv = rl_i(mach, vv), pr = rl_i(prev, vv);
+            const bool s = mv >= 0;
+            const int jvv = DIVM(vv), opvv = vv - jvv * M;
+            const bool merged = pr >= 0 && opvv != 0 && pr == vv - 1;
+            int c_job = -1, c_mch = -1;
+            float a_job = 0.f, a_mch = 0.f;
+            if (opvv != 0) {
+                const int u = vv - 1, mu = rl_i(mach, u);
+                double w, nd;
+                if (mu < 0) { w = 1.0; nd = 1.0; }
+                else {
+                    nd = rl_d(dur, u);
+                    if (merged && vv == merged_now) w = nd + rl_d(ttv, mu * M + mv) + (rl_d(st, vv) - rl_d(ft, u));   // env:1607-1675,1703-1765
+                    else w = nd + (s ? rl_d(ttv, mu * M + mv) : 0.0);                                                   // env:1384-1422
+                }
+                long A = trunc_l(w);
+                if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }                           // env:2019, 2060-2062
+            }
+            if (pr >= 0 && !merged) {
+                const double dp = rl_d(dur, pr);
+                const double x = (DIVM(pr) == jvv) ? rl_d(ttv, rl_i(mach, pr) * M + mv) : 0.0;
+                const double w = dp + x + (rl_d(st, vv) - rl_d(ft, pr));
+                long A = trunc_l(w);
+                if (A != 0) { A = trunc_l((double)A - dp) + 1; c_mch = pr; a_mch = (float)A; }
+            }
+            if (lane == q) {
+                reinterpret_cast<int2 *>(P.obs.ell_col)[bT + vv] = make_int2(c_job, c_mch);
+                reinterpret_cast<float2 *>(P.obs.ell_val)[bT + vv] = make_float2(a_job, a_mch);
+                if (q == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + vv) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
+            }
+        }
+        if (lane == 6) P.lastm[b] = merged_now;
+    }
+
+    // =========================================================================================
+    // D. candidate + job mask (ppo:202-316)
+    {
+        int cmin = M;
+        for (int j = 0; j < J; j++) { const int c = rl_i(cnt_, j); cmin = c < cmin ? c : cmin; }
+        double mn = INFINITY;
+        if (cmin > 0 && cmin < M)
+            for (int j = 0; j < J; j++) { const double r = rl_i(cnt_, j) != M ? rl_d(jrow_, j) : INFINITY; mn = fmin(mn, r); }
+        if (lane < J) {
+            unsigned char mk_;
+            if (cmin == 0) mk_ = cnt_ >= 1;
+            else if (cmin == M) mk_ = 1;
+            else mk_ = !((cnt_ == M ? INFINITY : jrow_) == mn);
+            P.obs.job_mask[(size_t)b * J + lane] = mk_;
+            if (lane == ja) {
+                P.obs.candidate[(size_t)b * J + ja] = ja * M + (cnt_ < M ? cnt_ : M - 1);
+                P.jcnt[(size_t)b * J + ja] = (short)cnt_; P.jmax[(size_t)b * J + ja] = jmax_; P.jrow[(size_t)b * J + ja] = jrow_;
+            }
+        }
+    }
+    // ---- write back the state that changed
+    if (isT) {
+        Link l; l.mach = (short)mach; l.prev = (short)prev; l.pos = (short)pos; l.pad = (short)next;
+        P.link[bT + v] = l;
+        if (v == a) { P.st[bT + a] = st; P.ft[bT + a] = ft; P.dur[bT + a] = dur; P.psel[bT + a] = pk; P.pte[bT + a] = pte; }
+    }
+    if (lane == m) { MRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+#undef DIVM
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -762,6 +1485,8 @@ struct mtfjsp_env {
     Link *link = nullptr;
     MRec *mrec = nullptr;
     short *jcnt = nullptr;
+    double *pte = nullptr, *jmax = nullptr, *jrow = nullptr;
+    int *lastm = nullptr;
     int *d_task = nullptr, *d_mach = nullptr;
     double *d_w3 = nullptr;
     mtfjsp_obs_t obs{};
@@ -819,13 +1544,14 @@ extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
     rc |= dalloc(h, &h->st, B * T); rc |= dalloc(h, &h->ft, B * T); rc |= dalloc(h, &h->dur, B * T); rc |= dalloc(h, &h->psel, B * T);
     rc |= dalloc(h, &h->mfea, B * M * 8); rc |= dalloc(h, &h->scal, B * SCAL_N);
     rc |= dalloc(h, &h->link, B * T); rc |= dalloc(h, &h->mrec, B * M); rc |= dalloc(h, &h->jcnt, B * (size_t)cfg->n_job);
+    rc |= dalloc(h, &h->pte, B * T); rc |= dalloc(h, &h->jmax, B * (size_t)cfg->n_job); rc |= dalloc(h, &h->jrow, B * (size_t)cfg->n_job); rc |= dalloc(h, &h->lastm, B);
     rc |= dalloc(h, &h->d_task, B); rc |= dalloc(h, &h->d_mach, B); rc |= dalloc(h, &h->d_w3, B * 3);
     if (rc) { g_create_err = h->err; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
     if (hipMemset(h->scal, 0, B * SCAL_N * sizeof(double)) != hipSuccess) { g_create_err = "memset failed"; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
     // opt in to large dynamic LDS
-    (void)hipFuncSetAttribute((const void *)k_env<false, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_env_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)k_env<true, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void *)k_env<false, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void *)k_env_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)k_env<true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     *out = h;
     return MTFJSP_OK;
@@ -925,7 +1651,7 @@ static EnvParams make_params(mtfjsp_env *h)
     P.left_shift = h->cfg.left_shift; P.obs_f32 = h->cfg.obs_dtype == MTFJSP_OBS_F32;
     P.w_mk = h->cfg.w_mk; P.w_ec = h->cfg.w_ec; P.w_tt = h->cfg.w_tt; P.divisor = h->cfg.scaling_divisor; P.gamma = h->cfg.gamma;
     P.t = h->t; P.p = h->p; P.tt = h->tt; P.cst = h->cst;
-    P.st = h->st; P.ft = h->ft; P.dur = h->dur; P.psel = h->psel; P.link = h->link; P.mrec = h->mrec; P.jcnt = h->jcnt; P.mfea = h->mfea; P.scal = h->scal;
+    P.st = h->st; P.ft = h->ft; P.dur = h->dur; P.psel = h->psel; P.link = h->link; P.mrec = h->mrec; P.jcnt = h->jcnt; P.pte = h->pte; P.jmax = h->jmax; P.jrow = h->jrow; P.lastm = h->lastm; P.mfea = h->mfea; P.scal = h->scal;
     P.inv_M = (unsigned)((0x100000000ull + (unsigned long long)P.M - 1) / (unsigned long long)P.M);
     P.obs = h->obs;
     return P;
@@ -996,8 +1722,15 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
     if (!d_st) (void)hipMalloc((void **)&d_st, (size_t)P.B * 64);
     P.stamps = d_st;
 #endif
-    if (P.obs_f32) hipLaunchKernelGGL((k_env<false, float>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
-    else hipLaunchKernelGGL((k_env<false, double>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
+    static const int force_lds = getenv("MTFJSP_ENV_LDS") ? 1 : 0;        // diagnostic: force the LDS kernel
+    if (P.T <= 64 && P.M * P.M <= 64 && P.J <= 64 && !force_lds) {        // register-resident kernel (no LDS)
+        if (P.obs_f32) hipLaunchKernelGGL((k_env_reg<float>), dim3(P.B), dim3(WAVE), 0, h->stream, P);
+        else hipLaunchKernelGGL((k_env_reg<double>), dim3(P.B), dim3(WAVE), 0, h->stream, P);
+    } else {
+        const size_t lds_s = env_step_lds_bytes(P.J, P.M, P.T, P.obs_f32);
+        if (P.obs_f32) hipLaunchKernelGGL((k_env_step<float>), dim3(P.B), dim3(WAVE), lds_s, h->stream, P);
+        else hipLaunchKernelGGL((k_env_step<double>), dim3(P.B), dim3(WAVE), lds_s, h->stream, P);
+    }
     if (ev) HIPCHK(h, hipEventRecord(ev->second, h->stream));
 #ifdef MTFJSP_STAMP
     static int printed = 0;
