@@ -133,482 +133,83 @@ __device__ __forceinline__ double wave_max(double x)
     return x;
 }
 
-template <bool RESET, typename OBS>
-__global__ __launch_bounds__(WAVE, 4) void k_env(EnvParams P)
+// =================================================================================================
+// k_env_reset — env.reset() of every instance (env:1183-1245 + load_instance env:397-714): all tasks unscheduled,
+// estimated times from the per-job prefix sums of min_dur, full observation written once (the step kernels then
+// only touch the rows a decision changes).  One wavefront per instance.
+template <typename OBS>
+__global__ __launch_bounds__(WAVE) void k_env_reset(EnvParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int b = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int b = blockIdx.x, lane = threadIdx.x;
     const int J = P.J, M = P.M, T = P.T;
-    const unsigned invM = P.inv_M;                      // ceil(2^32 / M): exact v / M for v < 2^16
-#define DIVM(x) ((int)__umulhi((unsigned)(x), invM))
-#ifdef MTFJSP_STAMP
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
-#endif
-
-    // ---- LDS carve (doubles first, 16-B aligned stage, then ints)
-    const int Tp = (T + 7) & ~7;                       // idle terms padded to a multiple of 8
-    double *s_st = reinterpret_cast<double *>(smem);
-    double *s_ft = s_st + T;
-    double *s_dur = s_ft + T;
-    double *s_psel = s_dur + T;
-    double *s_mind = s_psel + T;
-    double *s_minp = s_mind + T;
-    double *s_ste = s_minp + T;
-    double *s_fte = s_ste + T;
-    double *s_pte = s_fte + T;
-    double *s_term = s_pte + T;                // Tp
-    double *s_tt = s_term + Tp;                // M*M
-    double *s_mf = s_tt + M * M;               // M*8
-    double *s_rowmax = s_mf + M * 8;           // J   max finish time of scheduled ops per job
-    double *s_sc = s_rowmax + J;               // SCAL_N
-    double *s_r = s_sc + SCAL_N;               // 8: reward,r_mk,r_idle,r_pt,r_tt, idle_delta, new_tr, done
-    size_t off = (size_t)((10 * T + Tp + M * M + M * 8 + J + SCAL_N + 8) * sizeof(double));
-    off = (off + 15) & ~(size_t)15;
-    const int stage_rows = T < WAVE ? T : WAVE;
-    OBS *s_stage = reinterpret_cast<OBS *>(smem + off);
-    off += (size_t)stage_rows * 12 * sizeof(OBS);
-    off = (off + 15) & ~(size_t)15;
-    int *s_mach = reinterpret_cast<int *>(smem + off);
-    int *s_prev = s_mach + T;
-    int *s_pos = s_prev + T;
-    int *s_cnt = s_pos + T;                    // J scheduled ops per job
-    int *s_head = s_cnt + J;                   // M
-    int *s_tail = s_head + M;
-    int *s_len = s_tail + M;
-    int *s_mstart = s_len + M;                 // M+1
-    int *s_misc = s_mstart + M + 1;            // [0] best key
-
+    const unsigned invM = P.inv_M;
+    double *s_mind = reinterpret_cast<double *>(smem);          // T
+    double *s_pte = s_mind + T;                                 // T
+    double *s_fte = s_pte + T;                                  // T
+    OBS *s_stage = reinterpret_cast<OBS *>(s_fte + T);          // min(T,64) rows x 12
     const size_t bT = (size_t)b * T;
-    // ---- action first: its dependent t/p gather overlaps the bulk state loads
-    int a = 0, m = 0, status = 0;
-    double d = 0.0, pk = 0.0;
-    bool valid = false;
-    if (!RESET) {
-        a = P.task_idx[b];
-        m = P.mach_idx[b];
-        valid = a >= 0 && a < T && m >= 0 && m < M;
-        if (valid) {
-            d = P.t[(bT + a) * M + m];
-            pk = P.p[(bT + a) * M + m];
-        }
-    }
-    // ---- stage the instance into LDS
-    for (int v = lane; v < T; v += WAVE) {
-        const double2 c = P.cst[bT + v];
-        s_mind[v] = c.x; s_minp[v] = c.y;
-        if (RESET) {
-            s_st[v] = 0.0; s_ft[v] = 0.0; s_dur[v] = 0.0; s_psel[v] = 0.0;
-            s_mach[v] = -1; s_prev[v] = -1; s_pos[v] = 0;
-        } else {
-            s_st[v] = P.st[bT + v]; s_ft[v] = P.ft[bT + v]; s_dur[v] = P.dur[bT + v]; s_psel[v] = P.psel[bT + v];
-            const Link l = P.link[bT + v];
-            s_mach[v] = l.mach; s_prev[v] = l.prev; s_pos[v] = l.pos;
-        }
-    }
-    for (int i = lane; i < Tp; i += WAVE) s_term[i] = 0.0;
-    for (int i = lane; i < M * M; i += WAVE) s_tt[i] = P.tt[(size_t)b * M * M + i];
-    for (int i = lane; i < M * 8; i += WAVE) {
-        if (RESET) {
-            const int f = i & 7;
-            s_mf[i] = f >= 5 ? P.w3[b * 3 + (f - 5)] : 0.0;            // env:2343-2354
-        } else s_mf[i] = P.mfea[(size_t)b * M * 8 + i];
-    }
-    for (int i = lane; i < M; i += WAVE) {
-        if (RESET) { s_head[i] = -1; s_tail[i] = -1; s_len[i] = 0; }
-        else { const MRec r = P.mrec[(size_t)b * M + i]; s_head[i] = r.head; s_tail[i] = r.tail; s_len[i] = r.len; }
-    }
-    for (int i = lane; i < J; i += WAVE) s_cnt[i] = RESET ? 0 : (int)P.jcnt[(size_t)b * J + i];
-    if (lane < SCAL_N) {
-        double v = 0.0;
-        if (!RESET) v = P.scal[(size_t)b * SCAL_N + lane];
-        else if (lane >= S_R && lane <= S_N) v = P.scal[(size_t)b * SCAL_N + lane];     // the scaler survives resets (pe:70-85)
-        else if (lane >= S_W3 && lane < S_W3 + 3) v = P.w3[b * 3 + (lane - S_W3)];
-        s_sc[lane] = v;
-    }
-    if (lane == 0) s_misc[0] = 0x7fffffff;
+    for (int v = lane; v < T; v += WAVE) { const double2 c = P.cst[bT + v]; s_mind[v] = c.x; s_pte[v] = c.y; }
+    const double w30 = P.w3[b * 3], w31 = P.w3[b * 3 + 1], w32 = P.w3[b * 3 + 2];
     WSYNC();
-    STAMP(0);
-
-    // =========================================================================================
-    // A. scheduling (env:1476-1685)
-    int path = 0;
-    const int ja = valid ? DIVM(a) : 0;            // job of the acting task
-    if (!RESET) {
-        const int op = valid ? a - ja * M : 0;
-        if (valid) {
-            if (s_mach[a] >= 0) valid = false;                         // already scheduled (env:1504)
-            else if (op != 0 && s_mach[a - 1] < 0) valid = false;      // job predecessor unscheduled (env:1520)
-        }
-        if (valid) {
-            if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;               // pe:246-248
-            const double ttmm = s_tt[m * M + m];
-            // arrival over the single in-edge of the unscheduled node (job predecessor or src) (dg:46-66)
-            const double arr_k = op == 0 ? 0.0 : s_ft[a - 1] + s_tt[s_mach[a - 1] * M + m];
-            const int len = s_len[m], head = s_head[m], tail = s_tail[m];
-            double st_k;
-            int ipos, Pk, Nk = -1;
-            bool do_append = false;
-            if (len == 0) { path = MTFJSP_PATH_EMPTY; st_k = arr_k; ipos = 0; Pk = -1; }                 // env:1684
-            else if (!P.left_shift) do_append = true;                                                     // env:1680
-            else {
-                const double lb_ft = arr_k + d;
-                const int jh = DIVM(head);
-                const double arr_f = (head == jh * M) ? 0.0 : s_ft[head - 1] + s_tt[s_mach[head - 1] * M + m];
-                if (lb_ft <= arr_f) { path = MTFJSP_PATH_FRONT; st_k = arr_k; ipos = 0; Pk = -1; Nk = head; }   // env:1548
-                else if (len == 1) do_append = true;                                                     // env:1577
-                else {
-                    // gap search over all consecutive (P,N) of the route at once (env:1587-1604)
-                    int key = 0x7fffffff;
-                    for (int v = lane; v < T; v += WAVE) {
-                        if (s_mach[v] == m && s_prev[v] >= 0) {
-                            const int Pp = s_prev[v];
-                            const int jv = DIVM(v);
-                            const double jarr = (v == jv * M) ? 0.0 : s_ft[v - 1] + s_tt[s_mach[v - 1] * M + m];
-                            const double x = (DIVM(Pp) == jv) ? ttmm : 0.0;
-                            const double nst = fmax(jarr, s_ft[Pp] + x);          // arrival(N) over its current in-edges
-                            const bool ok = !(lb_ft > nst) && !((nst - s_ft[Pp]) < d);
-                            if (ok) { const int kk = (s_pos[v] << 16) | v; key = kk < key ? kk : key; }
-                        }
-                    }
-                    for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(key, o); key = other < key ? other : key; }
-                    const int best = key;
-                    if (best != 0x7fffffff) {
-                        path = MTFJSP_PATH_BETWEEN;
-                        Nk = best & 0xffff; ipos = best >> 16; Pk = s_prev[Nk];
-                        const double x = (DIVM(Pk) == ja) ? ttmm : 0.0;
-                        st_k = fmax(arr_k, s_ft[Pk] + x);                          // env:1619
-                    } else do_append = true;                                       // env:1676
-                }
-            }
-            if (do_append) {                                                       // env:1689-1775
-                path = MTFJSP_PATH_APPEND;
-                const double x = (DIVM(tail) == ja) ? ttmm : 0.0;
-                st_k = fmax(arr_k, s_ft[tail] + x);
-                ipos = len; Pk = tail;
-            }
-            const double ft_k = st_k + d;
-            WSYNC();
-            // apply: shift ranks behind the insertion point, then write task k and its neighbours
-            if (ipos < len)
-                for (int v = lane; v < T; v += WAVE)
-                    if (s_mach[v] == m && s_pos[v] >= ipos) s_pos[v] += 1;
-            WSYNC();
-            if (lane == 0) {
-                s_mach[a] = m; s_prev[a] = Pk; s_pos[a] = ipos;
-                s_st[a] = st_k; s_ft[a] = ft_k; s_dur[a] = d; s_psel[a] = pk;
-                if (Nk >= 0) s_prev[Nk] = a;
-                if (ipos == 0) s_head[m] = a;
-                if (ipos == len) s_tail[m] = a;
-                s_len[m] = len + 1;
-                s_cnt[ja] += 1;
-                s_sc[S_NSCHED] += 1.0;
-            }
-            status |= path;
-        } else {
-            status |= MTFJSP_ST_INVALID;
-        }
-        WSYNC();
-    }
-    STAMP(1);
-
-    // =========================================================================================
-    // B. costs
-    // machine route offsets (exclusive scan of the route lengths, lanes = machines)
-    {
-        int x = lane < M ? s_len[lane] : 0, incl = x;
-        for (int o = 1; o < WAVE; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
-        if (lane < M) s_mstart[lane] = incl - x;
-        if (lane == M - 1) s_mstart[M] = incl;
-    }
-    // per-job max finish time of the scheduled ops (ppo:265-275) — lanes = jobs
-    for (int j = lane; j < J; j += WAVE) {
-        const int cnt = s_cnt[j];
-        double rmax = 0.0;
-        for (int c = 0; c < cnt; c++) { const double f0 = s_ft[j * M + c]; if (c == 0 || f0 > rmax) rmax = f0; }
-        s_rowmax[j] = rmax;
-    }
-    WSYNC();
-    // estimated start/finish/energy (env:1920-1999) — lanes = tasks.  Ops of a job are scheduled in order, so the
-    // reference's left-to-right scan is: scheduled prefix keeps its real values, the unscheduled suffix accumulates
-    // min_dur left to right from the last real finish time.  Each lane replays exactly that add sequence.
     double mkmax = -INFINITY;
-    {
-        for (int v = lane; v < T; v += WAVE) {
-            const int jv = DIVM(v), c = v - jv * M;
-            double ste, fte, pte;
-            const bool s = s_mach[v] >= 0;
-            if (s && s_ft[v] != 0.0) { ste = s_st[v]; fte = s_ft[v]; pte = s_dur[v] * s_psel[v]; }   // env:356,2175
-            else {
-                // first index of the trailing run this task accumulates from: after the last op with a non-zero real ft
-                int k0 = c;
-                while (k0 > 0 && !(s_mach[jv * M + k0 - 1] >= 0 && s_ft[jv * M + k0 - 1] != 0.0)) k0--;
-                double acc = k0 > 0 ? s_ft[jv * M + k0 - 1] : 0.0, prev = acc;
-                for (int k = k0; k <= c; k++) { prev = acc; acc = acc + s_mind[jv * M + k]; }
-                fte = acc;
-                ste = s ? s_st[v] : (c == 0 ? 0.0 : prev);
-                pte = s ? s_dur[v] * s_psel[v] : s_minp[v];
-            }
-            s_pte[v] = pte;
-            s_ste[v] = ste; s_fte[v] = fte;
-            mkmax = fmax(mkmax, fte);
-            // idle-time terms in (machine, route position) order (dg:144-170)
-            if (s) {
-                const int pr = s_prev[v];
-                s_term[s_mstart[s_mach[v]] + s_pos[v]] = pr < 0 ? s_st[v] : s_st[v] - s_ft[pr];
-            }
-        }
-    }
-    const double mk = wave_max(mkmax);                                               // env:894 np.amax
-    WSYNC();
-    STAMP(2);
-    // energy: numpy add.reduce order (env:896).  n <= 128: the 8 accumulators live on 8 lanes.
-    double e1;
-    if (T >= 8 && T <= 128) {
-        double r = 0.0;
-        const int nb = T - (T & 7);
-        if (lane < 8) { r = s_pte[lane]; for (int i = 8 + lane; i < nb; i += 8) r += s_pte[i]; }
-        r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);          // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
-        for (int i = nb; i < T; i++) r += s_pte[i];
-        e1 = 0.0 + __shfl(r, 0);
-    } else e1 = np_sum(s_pte, T);
-
-    bool done = false;
-    if (RESET) {
-        if (lane == 0) {
-            s_sc[S_MK_PREV] = mk; s_sc[S_E1_PREV] = e1; s_sc[S_TR_PREV] = 0.0; s_sc[S_ID_PREV] = 0.0;   // env:683-705
-            s_sc[S_TR_THIS] = 0.0; s_sc[S_NSCHED] = 0.0;
-        }
-        if (lane < 8) s_r[lane] = 0.0;
-    } else if (valid) {
-        const int nsched = s_mstart[M];
-        // ordered idle sum (dg:147-168): strictly sequential adds; terms are zero-padded to a multiple of 8 (x + 0.0 == x)
-        double idle = 0.0;
-        for (int i = 0; i < nsched; i += 8) {
-            const double t0 = s_term[i], t1 = s_term[i + 1], t2 = s_term[i + 2], t3 = s_term[i + 3];
-            const double t4 = s_term[i + 4], t5 = s_term[i + 5], t6 = s_term[i + 6], t7 = s_term[i + 7];
-            idle = idle + t0; idle = idle + t1; idle = idle + t2; idle = idle + t3;
-            idle = idle + t4; idle = idle + t5; idle = idle + t6; idle = idle + t7;
-        }
-        const int op = a - ja * M;
-        const double new_tr = (op == 0) ? 0.0 : s_tt[s_mach[a - 1] * M + m];      // env:872-876
-        const double trans_this = s_sc[S_TR_THIS] + new_tr;
-        const double mk_prev = s_sc[S_MK_PREV], e1_prev = s_sc[S_E1_PREV];
-        const double tr_prev = s_sc[S_TR_PREV], id_prev = s_sc[S_ID_PREV];
-        const double r_t = 1.0 * mk_prev - mk;                                       // env:1066
-        double r_pt = 1.0 * e1_prev - e1;
-        r_pt = r_pt / (double)T;                                                     // env:1073-1076
-        const double r_tt = 1.0 * tr_prev - trans_this;                              // env:1083
-        const double r_idle = 1.0 * id_prev - idle;                                  // env:1088
-        const double tot = P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1;   // env:1164
-        done = nsched == T;                                                          // env:797-800
-        WSYNC();
-        if (lane == 0) {
-            s_r[0] = tot / P.divisor; s_r[1] = r_t; s_r[2] = r_idle; s_r[3] = r_pt; s_r[4] = r_tt;
-            s_r[5] = idle - id_prev; s_r[6] = new_tr; s_r[7] = done ? 1.0 : 0.0;
-            s_sc[S_MK_PREV] = mk; s_sc[S_E1_PREV] = e1; s_sc[S_TR_PREV] = trans_this; s_sc[S_ID_PREV] = idle;   // env:932-936
-            s_sc[S_TR_THIS] = done ? 0.0 : trans_this;                               // env:950-960
-            // machine features of the acting machine (env:2315-2340)
-            double *row = s_mf + m * 8;
-            row[0] = s_ft[s_tail[m]];
-            row[1] += (pk * d) / (double)T;
-            row[2] += new_tr;
-            row[3] += idle - id_prev;
-            row[4] += 1;
-        }
-        // reward scaling, one channel per lane (pt:54-83,108-124; pe:255-260)
-        if (lane < 4) {
-            const double x = lane == 0 ? r_t : lane == 1 ? r_idle : lane == 2 ? r_pt : r_tt;
-            const double n = s_sc[S_N] + 1.0;
-            const double R = P.gamma * s_sc[S_R + lane] + x;
-            double mean, S = s_sc[S_S + lane], sd;
-            if (n == 1.0) { mean = R; sd = fabs(R); }
-            else {
-                const double old = s_sc[S_MEAN + lane];
-                mean = old + (R - old) / n;
-                S = S + (R - old) * (R - mean);
-                sd = sqrt(S / n);
-            }
-            const double scaled = x / (sd + 1e-8);
-            WSYNC();
-            s_sc[S_R + lane] = R; s_sc[S_MEAN + lane] = mean; s_sc[S_S + lane] = S; s_sc[S_STD + lane] = sd;
-            P.obs.info[(size_t)b * 6 + 2 + lane] = scaled;
-            if (P.rec_r4) P.rec_r4[(size_t)lane * P.B + b] = (float)scaled;
-        }
-        if (lane == 4) {
-            P.obs.info[(size_t)b * 6 + 0] = tot / P.divisor;
-            P.obs.info[(size_t)b * 6 + 1] = done ? 1.0 : 0.0;
-            if (P.rec_done) P.rec_done[b] = done ? 1.f : 0.f;
-        }
-        if (P.obs.raw && lane >= 8 && lane < 13) {
-            const int i = lane - 8;
-            P.obs.raw[(size_t)b * 5 + i] = i == 0 ? tot / P.divisor : i == 1 ? r_t : i == 2 ? r_idle : i == 3 ? r_pt : r_tt;
-        }
-    } else {
-        if (lane < 6) P.obs.info[(size_t)b * 6 + lane] = (lane == 1 && s_mstart[M] == T) ? 1.0 : 0.0;
-        if (P.obs.raw && lane < 5) P.obs.raw[(size_t)b * 5 + lane] = 0.0;
-    }
-    if (RESET && lane < 6) P.obs.info[(size_t)b * 6 + lane] = 0.0;
-    if (RESET && lane < 5 && P.obs.raw) P.obs.raw[(size_t)b * 5 + lane] = 0.0;
-    if (lane == 5) P.obs.status[b] = status;
-    WSYNC();
-    if (!RESET && valid && lane == 0) s_sc[S_N] += 1.0;
-    STAMP(3);
-    STAMP(4);
-
-    // =========================================================================================
-    // C. observation (env:2001-2515)
-    const double w30 = s_sc[S_W3], w31 = s_sc[S_W3 + 1], w32 = s_sc[S_W3 + 2];
-    {
-        for (int c0 = 0; c0 < T; c0 += WAVE) {
-            const int v = c0 + lane;
-            const int rows = (T - c0) < WAVE ? (T - c0) : WAVE;
-            if (v < T) {
-                const int mv = s_mach[v];
-                const bool s = mv >= 0;
-                const int jv = DIVM(v);
-                const int opv = v - jv * M;
-                const int pr = s_prev[v];
-                const bool merged = pr >= 0 && opv != 0 && pr == v - 1;          // route predecessor == job predecessor: ONE edge
-                // ---- in-edges -> ELL slots
-                int c_job = -1, c_mch = -1;
-                float a_job = 0.f, a_mch = 0.f;
-                if (opv != 0) {
-                    const int u = v - 1;
-                    const int mu = s_mach[u];
-                    double w, nd;
-                    if (mu < 0) { w = 1.0; nd = 1.0; }                           // never refreshed: initial weight 1 (env:617-644)
-                    else {
-                        nd = s_dur[u];
-                        if (merged && !RESET && v == a && valid) {
-                            // machine edge written AFTER this step's refresh wins (env:1607-1675,1703-1765)
-                            const double x = s_tt[mu * M + mv];
-                            w = s_dur[u] + x + (s_st[v] - s_ft[u]);
-                        } else {
-                            const double x = s ? s_tt[mu * M + mv] : 0.0;        // env:1384-1422 job-edge refresh
-                            w = s_dur[u] + x;
-                        }
-                    }
-                    long A = trunc_l(w);                                          // env:2019 astype(int)
-                    if (A != 0) {
-                        A = trunc_l((double)A - nd) + 1;                          // env:2060-2062 (int-array item assignment)
-                        c_job = u; a_job = (float)A;
-                    }
-                }
-                if (pr >= 0 && !merged) {
-                    const double x = (DIVM(pr) == jv) ? s_tt[s_mach[pr] * M + mv] : 0.0;
-                    const double w = s_dur[pr] + x + (s_st[v] - s_ft[pr]);
-                    long A = trunc_l(w);
-                    if (A != 0) {
-                        A = trunc_l((double)A - s_dur[pr]) + 1;
-                        c_mch = pr; a_mch = (float)A;
-                    }
-                }
-                reinterpret_cast<int2 *>(P.obs.ell_col)[bT + v] = make_int2(c_job, c_mch);
-                reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(a_job, a_mch);
-                // ---- 12 task features (env:2245-2277)
-                const double ste = s_ste[v], fte = s_fte[v];
-                OBS *f = s_stage + lane * 12;
-                f[0] = (OBS)ste; f[1] = (OBS)fte; f[2] = (OBS)s_pte[v];
-                f[3] = (OBS)(s ? 1.0 : 0.0);
-                f[4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));                // len(G.in_edges): src/job edge + machine edge
-                f[5] = (OBS)(s ? mv + 1 : 0);
-                f[6] = (OBS)(s ? s_dur[v] : 0.0);
-                f[7] = (OBS)(s ? s_psel[v] : 0.0);
-                f[8] = (OBS)(jv + 1);
-                f[9] = (OBS)w30; f[10] = (OBS)w31; f[11] = (OBS)w32;
-            }
-            WSYNC();
-            {   // coalesced 16-byte copy-out of rows [c0, c0+rows)
-                const int n16 = rows * 12 * (int)sizeof(OBS) / 16;
-                const uint4 *src = reinterpret_cast<const uint4 *>(s_stage);
-                uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + c0) * 12);
-                for (int i = lane; i < n16; i += WAVE) dst[i] = src[i];
-            }
-            WSYNC();
-        }
-    }
-    for (int i = lane; i < M * 8; i += WAVE)
-        reinterpret_cast<OBS *>(P.obs.m_fea2)[(size_t)b * M * 8 + i] = (OBS)s_mf[i];
-    STAMP(5);
-
-    // =========================================================================================
-    // D. candidate + job mask (ppo:202-316), from the per-job counters — lanes = jobs (J <= 64: one pass of shuffles)
-    {
-        int cmin = M;
-        double mn = INFINITY;
-        for (int j0 = 0; j0 < J; j0 += WAVE) {
-            const int j = j0 + lane;
-            int c = j < J ? s_cnt[j] : M;
-            for (int o = 32; o > 0; o >>= 1) { const int y = __shfl_xor(c, o); c = y < c ? y : c; }
-            cmin = c < cmin ? c : cmin;
-        }
-        if (cmin > 0 && cmin < M)
-            for (int j0 = 0; j0 < J; j0 += WAVE) {
-                const int j = j0 + lane;
-                double r = (j < J && s_cnt[j] != M) ? s_rowmax[j] : INFINITY;
-                for (int o = 32; o > 0; o >>= 1) r = fmin(r, __shfl_xor(r, o));
-                mn = fmin(mn, r);
-            }
-        for (int j = lane; j < J; j += WAVE) {
-            const int cnt = s_cnt[j];
-            unsigned char mk_;
-            if (cmin == 0) mk_ = cnt >= 1;                                   // column 0 not full: mask = scheduled[:,0]
-            else if (cmin == M) mk_ = 1;                                     // everything scheduled
-            else mk_ = !((cnt == M ? INFINITY : s_rowmax[j]) == mn);         // only the earliest-finishing jobs
-            P.obs.job_mask[(size_t)b * J + j] = mk_;
-            P.obs.candidate[(size_t)b * J + j] = j * M + (cnt < M ? cnt : M - 1);
-        }
-    }
-
-    // =========================================================================================
-    // write back the state that changed
-    if (RESET || valid) {
-        for (int v = lane; v < T; v += WAVE) {
-            Link l; l.mach = (short)s_mach[v]; l.prev = (short)s_prev[v]; l.pos = (short)s_pos[v]; l.pad = -1;   // pad = route successor (k_env_reg)
+    for (int c0 = 0; c0 < T; c0 += WAVE) {
+        const int v = c0 + lane;
+        const int rows = (T - c0) < WAVE ? (T - c0) : WAVE;
+        if (v < T) {
+            const int jv = (int)__umulhi((unsigned)v, invM), c = v - jv * M;
+            double acc = 0.0, prev = 0.0;                                   // env:1965-1993 on an empty schedule
+            for (int k = 0; k <= c; k++) { prev = acc; acc = acc + s_mind[jv * M + k]; }
+            s_fte[v] = acc;
+            mkmax = fmax(mkmax, acc);
+            OBS *f = s_stage + lane * 12;                                   // env:2245-2277
+            f[0] = (OBS)(c == 0 ? 0.0 : prev); f[1] = (OBS)acc; f[2] = (OBS)s_pte[v];
+            f[3] = (OBS)0; f[4] = (OBS)1; f[5] = (OBS)0; f[6] = (OBS)0; f[7] = (OBS)0;
+            f[8] = (OBS)(jv + 1); f[9] = (OBS)w30; f[10] = (OBS)w31; f[11] = (OBS)w32;
+            reinterpret_cast<int2 *>(P.obs.ell_col)[bT + v] = make_int2(c != 0 ? v - 1 : -1, -1);   // job edge weight 1 (env:617-644)
+            reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(c != 0 ? 1.f : 0.f, 0.f);
+            Link l; l.mach = -1; l.prev = -1; l.pos = 0; l.pad = -1;                               // pad = route successor
             P.link[bT + v] = l;
-            if (RESET) { P.st[bT + v] = 0.0; P.ft[bT + v] = 0.0; P.dur[bT + v] = 0.0; P.psel[bT + v] = 0.0; }
+            P.st[bT + v] = 0.0; P.ft[bT + v] = 0.0; P.dur[bT + v] = 0.0; P.psel[bT + v] = 0.0; P.pte[bT + v] = s_pte[v];
         }
-        if (!RESET && lane == 0) { P.st[bT + a] = s_st[a]; P.ft[bT + a] = s_ft[a]; P.dur[bT + a] = s_dur[a]; P.psel[bT + a] = s_psel[a]; }
-        for (int i = lane; i < M; i += WAVE) {
-            MRec r; r.head = (short)s_head[i]; r.tail = (short)s_tail[i]; r.len = (short)s_len[i]; r.pad = 0;
-            P.mrec[(size_t)b * M + i] = r;
-        }
-        for (int i = lane; i < J; i += WAVE) P.jcnt[(size_t)b * J + i] = (short)s_cnt[i];
-        if (RESET) {
-            for (int v = lane; v < T; v += WAVE) P.pte[bT + v] = s_pte[v];
-            for (int j = lane; j < J; j += WAVE) {
-                double fm = s_fte[j * M];
-                for (int c = 1; c < M; c++) fm = fmax(fm, s_fte[j * M + c]);
-                P.jmax[(size_t)b * J + j] = fm; P.jrow[(size_t)b * J + j] = 0.0;
-            }
-            if (lane == 0) P.lastm[b] = -1;
-        }
-        if (RESET) { for (int i = lane; i < M * 8; i += WAVE) P.mfea[(size_t)b * M * 8 + i] = s_mf[i]; }
-        else if (lane < 8) P.mfea[((size_t)b * M + m) * 8 + lane] = s_mf[m * 8 + lane];
-        if (lane < SCAL_N) P.scal[(size_t)b * SCAL_N + lane] = s_sc[lane];
+        WSYNC();
+        const int n16 = rows * 12 * (int)sizeof(OBS) / 16;
+        const uint4 *src = reinterpret_cast<const uint4 *>(s_stage);
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + c0) * 12);
+        for (int i = lane; i < n16; i += WAVE) dst[i] = src[i];
+        WSYNC();
     }
-#ifdef MTFJSP_STAMP
-    STAMP(6);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(7);
-    if (P.stamps && lane == 0) for (int i = 0; i < 8; i++) P.stamps[(size_t)b * 8 + i] = ph[i];
-#endif
-#undef DIVM
+    const double mk = wave_max(mkmax);                                      // env:683-705 initial "previous" values
+    const double e1 = np_sum(s_pte, T);
+    for (int j = lane; j < J; j += WAVE) {
+        double fm = s_fte[j * M];
+        for (int c = 1; c < M; c++) fm = fmax(fm, s_fte[j * M + c]);
+        P.jmax[(size_t)b * J + j] = fm; P.jrow[(size_t)b * J + j] = 0.0; P.jcnt[(size_t)b * J + j] = 0;
+        P.obs.candidate[(size_t)b * J + j] = j * M;                         // ppo:90-98 pool = first op of every job
+        P.obs.job_mask[(size_t)b * J + j] = 0;
+    }
+    for (int i = lane; i < M; i += WAVE) { MRec r; r.head = -1; r.tail = -1; r.len = 0; r.pad = 0; P.mrec[(size_t)b * M + i] = r; }
+    for (int i = lane; i < M * 8; i += WAVE) {
+        const int f = i & 7;
+        const double x = f == 5 ? w30 : f == 6 ? w31 : f == 7 ? w32 : 0.0;  // env:2343-2354
+        P.mfea[(size_t)b * M * 8 + i] = x;
+        reinterpret_cast<OBS *>(P.obs.m_fea2)[(size_t)b * M * 8 + i] = (OBS)x;
+    }
+    if (lane < SCAL_N) {
+        double x = 0.0;
+        if (lane >= S_R && lane <= S_N) x = P.scal[(size_t)b * SCAL_N + lane];   // the scaler survives resets (pe:70-85)
+        else if (lane == S_MK_PREV) x = mk;
+        else if (lane == S_E1_PREV) x = e1;
+        else if (lane == S_W3) x = w30;
+        else if (lane == S_W3 + 1) x = w31;
+        else if (lane == S_W3 + 2) x = w32;
+        P.scal[(size_t)b * SCAL_N + lane] = x;
+    }
+    if (lane < 6) P.obs.info[(size_t)b * 6 + lane] = 0.0;
+    if (lane < 5 && P.obs.raw) P.obs.raw[(size_t)b * 5 + lane] = 0.0;
+    if (lane == 6) { P.obs.status[b] = 0; P.lastm[b] = -1; }
 }
-
-static size_t env_lds_bytes(int J, int M, int T, bool f32)
-{
-    const int Tp = (T + 7) & ~7;
-    size_t off = (size_t)(10 * T + Tp + M * M + M * 8 + J + SCAL_N + 8) * sizeof(double);
-    off = (off + 15) & ~(size_t)15;
-    int rows = T < WAVE ? T : WAVE;
-    off += (size_t)rows * 12 * (f32 ? 4 : 8);
-    off = (off + 15) & ~(size_t)15;
-    off += (size_t)(3 * T + J + 4 * M + 1 + 4) * sizeof(int);
-    return off;
-}
+static size_t env_reset_lds_bytes(int T, bool f32) { return (size_t)3 * T * 8 + (size_t)(T < WAVE ? T : WAVE) * 12 * (f32 ? 4 : 8) + 16; }
 
 // =================================================================================================
 // k_env_step — incremental step kernel (one wavefront per instance, one launch per batched step).
@@ -1536,7 +1137,8 @@ extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
     h->cfg = *cfg;
     h->T = cfg->n_job * cfg->n_machine;
     const size_t B = cfg->batch, T = h->T, M = cfg->n_machine;
-    size_t lds = env_lds_bytes(cfg->n_job, cfg->n_machine, h->T, cfg->obs_dtype == MTFJSP_OBS_F32);
+    size_t lds = env_step_lds_bytes(cfg->n_job, cfg->n_machine, h->T, cfg->obs_dtype == MTFJSP_OBS_F32);
+    if (env_reset_lds_bytes(h->T, false) > lds) lds = env_reset_lds_bytes(h->T, false);
     if (lds > 160 * 1024) { g_create_err = "instance too large for one CU's LDS"; delete h; return MTFJSP_ERR_ARG; }
     int rc = 0;
     rc |= dalloc(h, &h->t, B * T * M); rc |= dalloc(h, &h->p, B * T * M); rc |= dalloc(h, &h->tt, B * M * M);
@@ -1550,9 +1152,7 @@ extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
     if (hipMemset(h->scal, 0, B * SCAL_N * sizeof(double)) != hipSuccess) { g_create_err = "memset failed"; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
     // opt in to large dynamic LDS
     (void)hipFuncSetAttribute((const void *)k_env_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void *)k_env<true, double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void *)k_env_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void *)k_env<true, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     *out = h;
     return MTFJSP_OK;
 }
@@ -1673,9 +1273,9 @@ extern "C" int mtfjsp_reset(mtfjsp_handle_t h, const double *w3)
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     EnvParams P = make_params(h);
     P.w3 = w3;
-    const size_t lds = env_lds_bytes(P.J, P.M, P.T, P.obs_f32);
-    if (P.obs_f32) hipLaunchKernelGGL((k_env<true, float>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
-    else hipLaunchKernelGGL((k_env<true, double>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
+    const size_t lds = env_reset_lds_bytes(P.T, P.obs_f32);
+    if (P.obs_f32) hipLaunchKernelGGL((k_env_reset<float>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
+    else hipLaunchKernelGGL((k_env_reset<double>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
     HIPCHK(h, hipGetLastError());
     h->was_reset = true;
     return MTFJSP_OK;
@@ -1706,7 +1306,6 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     EnvParams P = make_params(h);
     P.task_idx = task_idx; P.mach_idx = mach_idx; P.rec_r4 = r4; P.rec_done = dn;
-    const size_t lds = env_lds_bytes(P.J, P.M, P.T, P.obs_f32);
     std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
     if (h->timing) {
         if (h->ev_used == h->ev_pool.size()) {
