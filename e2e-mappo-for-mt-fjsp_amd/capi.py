@@ -70,6 +70,7 @@ PROTOTYPES = {
     "mtfjsp_encoder_weights_ready": (_I, [_VP]),
     "mtfjsp_job_actor_forward": (_I, [_VP] * 11),
     "mtfjsp_machine_actor_forward": (_I, [_VP] * 8),
+    "mtfjsp_global_critic_forward": (_I, [_VP] * 7),
     "mtfjsp_sample_categorical": (_I, [_VP, _VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
     "mtfjsp_encoder_timing_begin": (_I, [_VP]),
     "mtfjsp_encoder_timing_end": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -21,6 +21,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(int B, int T, int J, co
         if (h_nodes) *reinterpret_cast<float4 *>(h_nodes + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
     }
     for (int q = 0; q < 4; q++) s_part[rg][c4 + q] = acc[q];
-    for (int jj = rg; jj < J; jj += 8) {                                           // candidate gather (ac:197-207)
+    for (int jj = rg; jj < J; jj += 8) {                                           // candidate gather (ac:197-207); J = 0: skipped
         const int v = cand[b * J + jj];
         const float4 x = *reinterpret_cast<const float4 *>(z + ((size_t)b * T + v) * HD + c4);
         *reinterpret_cast<float4 *>(cand_feat + ((size_t)b * J + jj) * HD + c4) =
@@ -894,6 +895,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     const int lds = (int)gemm_lds_bytes();
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_GAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_MACHIN, EPI_GAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_BNRELU, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_AGG, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -927,10 +929,11 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
     HIPCHK(e, hipMemcpy(d, data, (size_t)numel * 4, hipMemcpyHostToDevice));
     // 128-wide Linear weights [out=128, in=128*k] and gat W [in,out]: keep GEMM-ready [in-block][k][n] copies
     const bool is_w = key.size() > 7 && key.compare(key.size() - 7, 7, ".weight") == 0 && key.find("linears") != std::string::npos;
-    if ((is_w && numel % (HD * HD) == 0) || key == "machine_actor.gat_layer.W") {
+    const bool is_gat_w = key.size() >= 11 && key.compare(key.size() - 11, 11, "gat_layer.W") == 0;
+    if ((is_w && numel % (HD * HD) == 0) || is_gat_w) {
         const int blocks = (int)(numel / (HD * HD));
         std::vector<float> t((size_t)numel);
-        if (key == "machine_actor.gat_layer.W") memcpy(t.data(), data, (size_t)numel * 4);     // already [in,out] (gat:82 h @ W)
+        if (is_gat_w) memcpy(t.data(), data, (size_t)numel * 4);     // already [in,out] (gat:82 h @ W)
         else {
             const int in = blocks * HD;
             for (int blk = 0; blk < blocks; blk++)
@@ -1006,16 +1009,13 @@ static GemmArgs gemm_args(const float *in, int N, const float *Wt, const float *
     return a;
 }
 
-extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
-                                        const int32_t *candidate, const uint8_t *job_mask, const float *h_m_prev,
-                                        float *prob, float *h_pooled, float *job_v, float *h_nodes)
+// GIN encoder (gcn:109-197) with the weights under `pre` ("job_actor." / "global_critic."), followed by the graph mean
+// pool and (optionally) the candidate gather.  Uses BatchNorm accumulator slots 0..5.
+static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
+                   const int32_t *candidate, int J, float *h_pooled, float *cand_feat, float *h_nodes)
 {
-    if (!e || !tasks_fea || !ell_col || !ell_val || !candidate || !job_mask || !prob || !h_pooled || !job_v) return MTFJSP_ERR_ARG;
-    int rc = mtfjsp_encoder_weights_ready(e);
-    if (rc) return rc;
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
-    const int B = e->cfg.batch, T = e->T, J = e->cfg.n_job, N = B * T;
-    const std::string P = "job_actor.encoder.feature_extract.";
+    const int B = e->cfg.batch, T = e->T, N = B * T;
+    const std::string P = pre + "encoder.feature_extract.";
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
     double *st = e->stats;
@@ -1050,9 +1050,54 @@ extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fe
     bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5);
     {
         Timed t(e, "job_pool_gather");
-        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(256), 0, e->stream, B, T, J, e->zB, st + 5 * STAT_REP * 256, invN,
-                           W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, e->cand_feat, h_nodes);
+        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(256), 0, e->stream, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
+                           W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, cand_feat, h_nodes);
     }
+    HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+// Machine path shared by the machine actor and the global critic (ac:383-444): input projections + 3x the same GATLayer
+// + node mean (in-place GEMM passes), then BatchNorm over all B*M rows and the mean over M.  Uses accumulator slot 6.
+static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, float *h_pooled)
+{
+    const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
+    auto W = [&](const std::string &k) { return e->w.at(k); };
+    auto WT = [&](const std::string &k) { return e->wt.at(k); };
+    double *st = e->stats + 6 * STAT_REP * 256;
+    HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
+    for (int pass = 0; pass < 3; pass++) {                                    // the SAME GATLayer three times (ac:409-414)
+        GemmArgs a = gemm_args(e->X, 2 * R, WT(pre + "gat_layer.W"), nullptr, e->X);      // in place: a wave only rewrites the tile it read
+        a.gat_a = W(pre + "gat_layer.a"); a.gat_last = pass == 2; a.gat_node = e->node; a.epi_stats = st;
+        if (pass == 0) {                                                        // input projections generated in the prologue
+            a.f1 = m_fea1; a.f2 = m_fea2; a.W1 = W(pre + "m_fea_1_fcl.weight"); a.W2 = W(pre + "m_fea_2_fcl.weight");
+            a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
+            launch_gemm<PRO_MACHIN, EPI_GAT>(e, a, "gat_pass");
+        } else
+            launch_gemm<PRO_PLAIN, EPI_GAT>(e, a, "gat_pass");
+    }
+    {
+        Timed t(e, "mach_bn_pool");
+        hipLaunchKernelGGL(k_mach_bn_pool, dim3(B), dim3(128), 0, e->stream, B, M, e->node, st, 1.0 / (double)R, W(pre + "bn.weight"),
+                           W(pre + "bn.bias"), h_pooled);
+    }
+    HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
+                                  const int32_t *candidate, const uint8_t *job_mask, const float *h_m_prev,
+                                  float *prob, float *h_pooled, float *job_v, float *h_nodes)
+{
+    if (!e || !tasks_fea || !ell_col || !ell_val || !candidate || !job_mask || !prob || !h_pooled || !job_v) return MTFJSP_ERR_ARG;
+    int rc = mtfjsp_encoder_weights_ready(e);
+    if (rc) return rc;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    const int B = e->cfg.batch, J = e->cfg.n_job;
+    auto W = [&](const std::string &k) { return e->w.at(k); };
+    auto WT = [&](const std::string &k) { return e->wt.at(k); };
+    rc = run_gin(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes);
+    if (rc) return rc;
     // ---- heads (ac:205-293): score = L2 tanh(L1 tanh(Wa cand + Wb pooled + Wc hm + b0))
     const float *hm = h_m_prev;
     if (!hm) {
@@ -1094,8 +1139,8 @@ extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fe
     return MTFJSP_OK;
 }
 
-extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fea1, const void *m_fea2, const float *h_pooled_o,
-                                            const uint8_t *mmask, float *prob, float *h_pooled, float *machine_v)
+static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, const void *m_fea2, const float *h_pooled_o,
+                                      const uint8_t *mmask, float *prob, float *h_pooled, float *machine_v)
 {
     if (!e || !m_fea1 || !m_fea2 || !h_pooled_o || !mmask || !prob || !h_pooled || !machine_v) return MTFJSP_ERR_ARG;
     int rc = mtfjsp_encoder_weights_ready(e);
@@ -1104,23 +1149,8 @@ extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fe
     const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
-    double *st = e->stats + 6 * STAT_REP * 256;
-    HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
-    for (int pass = 0; pass < 3; pass++) {                                    // the SAME GATLayer three times (ac:409-414)
-        GemmArgs a = gemm_args(e->X, 2 * R, WT("machine_actor.gat_layer.W"), nullptr, e->X);      // in place: a wave only rewrites the tile it read
-        a.gat_a = W("machine_actor.gat_layer.a"); a.gat_last = pass == 2; a.gat_node = e->node; a.epi_stats = st;
-        if (pass == 0) {                                                        // input projections generated in the prologue
-            a.f1 = m_fea1; a.f2 = m_fea2; a.W1 = W("machine_actor.m_fea_1_fcl.weight"); a.W2 = W("machine_actor.m_fea_2_fcl.weight");
-            a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
-            launch_gemm<PRO_MACHIN, EPI_GAT>(e, a, "gat_pass");
-        } else
-            launch_gemm<PRO_PLAIN, EPI_GAT>(e, a, "gat_pass");
-    }
-    {
-        Timed t(e, "mach_bn_pool");
-        hipLaunchKernelGGL(k_mach_bn_pool, dim3(B), dim3(128), 0, e->stream, B, M, e->node, st, 1.0 / (double)R, W("machine_actor.bn.weight"),
-                           W("machine_actor.bn.bias"), h_pooled);
-    }
+    rc = run_gat(e, "machine_actor.", m_fea1, m_fea2, h_pooled);
+    if (rc) return rc;
     {
         Timed t(e, "heads");
         HeadArgs ha{};
@@ -1136,6 +1166,73 @@ extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fe
     }
     HIPCHK(e, hipGetLastError());
     return MTFJSP_OK;
+}
+
+// out[b][o] = W[o,:] . x[b,:] + bias[o]   (the last 128 -> O linear of a critic head), thread = (b, o)
+__global__ void k_linear_small(int B, int O, const float *x, const float *W, const float *bias, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * O) return;
+    const int b = i / O, o = i % O;
+    float p = 0.f;
+    for (int k = 0; k < HD; k++) p = fmaf(x[(size_t)b * HD + k], W[o * HD + k], p);
+    out[i] = p + bias[o];
+}
+
+// = Global_Critic_JointAction_GAT.forward (ac:587-750): own GIN encoder -> graph pool, own GAT machine path
+// -> pool, MLPCritic(256 -> 128 -> 128 -> 4) on [pooled_m, pooled_o].  Weights under "global_critic.".
+static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
+                                      const void *m_fea1, const void *m_fea2, float *value4)
+{
+    if (!e || !tasks_fea || !ell_col || !ell_val || !m_fea1 || !m_fea2 || !value4) return MTFJSP_ERR_ARG;
+    static const char *need[] = {"global_critic.critic.linears.0.weight", "global_critic.critic.linears.2.bias", "global_critic.gat_layer.W",
+                                 "global_critic.encoder.feature_extract.mlps.1.linears.2.weight", "global_critic.bn.weight"};
+    for (const char *k : need)
+        if (!e->w.count(k)) { e->err = std::string("missing weight: ") + k; return MTFJSP_ERR_STATE; }
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    const int B = e->cfg.batch;
+    auto W = [&](const std::string &k) { return e->w.at(k); };
+    auto WT = [&](const std::string &k) { return e->wt.at(k); };
+    int rc = run_gin(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr);
+    if (rc) return rc;
+    rc = run_gat(e, "global_critic.", m_fea1, m_fea2, e->u);
+    if (rc) return rc;
+    const float *W0t = WT("global_critic.critic.linears.0.weight");             // [pooled_m | pooled_o] (ac: torch.cat((h_g_m_pooled, h_g_o_pooled)))
+    GemmArgs a = gemm_args(e->u, B, W0t, W("global_critic.critic.linears.0.bias"), e->c1);
+    launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, a, "head_gemm");
+    GemmArgs b = gemm_args(e->pooled_int, B, W0t + HD * HD, nullptr, e->c1);
+    b.accumulate = 1;
+    launch_gemm<PRO_PLAIN, EPI_TANH>(e, b, "head_gemm");
+    GemmArgs c = gemm_args(e->c1, B, WT("global_critic.critic.linears.1.weight"), W("global_critic.critic.linears.1.bias"), e->c2);
+    launch_gemm<PRO_PLAIN, EPI_TANH>(e, c, "head_gemm");
+    {
+        Timed t(e, "small");
+        hipLaunchKernelGGL(k_linear_small, dim3((B * 4 + 255) / 256), dim3(256), 0, e->stream, B, 4, e->c2, W("global_critic.critic.linears.2.weight"),
+                           W("global_critic.critic.linears.2.bias"), value4);
+    }
+    HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+// C ABI wrappers: no C++ exception may cross the boundary (a weight missing from the maps surfaces as MTFJSP_ERR_STATE)
+#define GUARDED(e, call)                                                                               \
+    try { return call; }                                                                               \
+    catch (const std::exception &ex) { if (e) (e)->err = std::string("missing weight or internal error: ") + ex.what(); return MTFJSP_ERR_STATE; }
+extern "C" int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
+                                        const int32_t *candidate, const uint8_t *job_mask, const float *h_m_prev,
+                                        float *prob, float *h_pooled, float *job_v, float *h_nodes)
+{
+    GUARDED(e, job_actor_forward_impl(e, tasks_fea, ell_col, ell_val, candidate, job_mask, h_m_prev, prob, h_pooled, job_v, h_nodes))
+}
+extern "C" int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fea1, const void *m_fea2, const float *h_pooled_o,
+                                            const uint8_t *mmask, float *prob, float *h_pooled, float *machine_v)
+{
+    GUARDED(e, machine_actor_forward_impl(e, m_fea1, m_fea2, h_pooled_o, mmask, prob, h_pooled, machine_v))
+}
+extern "C" int mtfjsp_global_critic_forward(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
+                                            const void *m_fea1, const void *m_fea2, float *value4)
+{
+    GUARDED(e, global_critic_forward_impl(e, tasks_fea, ell_col, ell_val, m_fea1, m_fea2, value4))
 }
 
 extern "C" int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *prob, int32_t n, int32_t greedy, uint64_t seed, uint64_t counter,

@@ -91,9 +91,9 @@ class Encoder:
         except Exception:
             pass
 
-    def load_weights(self, job_actor, machine_actor):
+    def load_weights(self, job_actor, machine_actor, global_critic=None):
         """dicts keyed by the reference's state_dict names (numpy arrays or torch tensors)."""
-        for prefix, d in (("job_actor.", job_actor), ("machine_actor.", machine_actor)):
+        for prefix, d in (("job_actor.", job_actor), ("machine_actor.", machine_actor), ("global_critic.", global_critic or {})):
             for k, v in d.items():
                 if "running_" in k or "num_batches_tracked" in k:
                     continue
@@ -115,6 +115,14 @@ class Encoder:
             self.h, m_fea1.data_ptr(), m_fea2.data_ptr(), h_pooled_o.data_ptr(), mmask.data_ptr(), self.mch_prob.data_ptr(),
             self.h_pooled_m.data_ptr(), (v_out if v_out is not None else self.mach_v).data_ptr()), self.h, enc=True)
         return self.mch_prob, self.h_pooled_m, (v_out if v_out is not None else self.mach_v)
+
+    def global_critic_forward(self, tasks_fea, ell_col, ell_val, m_fea1, m_fea2, out=None):
+        """-> value [B,4] f32 (mk, pt, tt, it) of the reference's Global_Critic_JointAction_GAT (needs its weights loaded)"""
+        if out is None:
+            out = torch.empty(self.B, 4, dtype=torch.float32, device=self.device)
+        capi.check(self.L.mtfjsp_global_critic_forward(self.h, tasks_fea.data_ptr(), ell_col.data_ptr(), ell_val.data_ptr(),
+                                                       m_fea1.data_ptr(), m_fea2.data_ptr(), out.data_ptr()), self.h, enc=True)
+        return out
 
     def sample(self, prob, greedy, seed, counter, idx_out, logp_out=None, gather_from=None, gathered_out=None):
         capi.check(self.L.mtfjsp_sample_categorical(

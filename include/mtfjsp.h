@@ -200,6 +200,11 @@ int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fea, const in
 int mtfjsp_machine_actor_forward(mtfjsp_encoder_t e, const void *m_fea1, const void *m_fea2,
                                  const float *h_pooled_o, const uint8_t *mmask, float *prob, float *h_pooled,
                                  float *machine_v);
+/* = Global_Critic_JointAction_GAT.forward (ac:587-750; SURVEY §8f N1, used under no_grad by ppo:628-703 to sample the
+ * global values for GAE): weights under the prefix "global_critic." (loaded with mtfjsp_encoder_load_weight_host);
+ * value4 [B,4] f32 = (mk, pt, tt, it). */
+int mtfjsp_global_critic_forward(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
+                                 const void *m_fea1, const void *m_fea2, float *value4);
 /* = select_operation_action / greedy_select_action / select_machine_action (agent:22-72):
  * categorical sample (Philox, (seed,counter)) or argmax from prob [B,N]; idx_out [B], logp_out [B];
  * gather_from (optional, [B,N] int32, e.g. candidate) -> gathered_out [B] (task index). */
@@ -209,7 +214,7 @@ int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *prob, int32_t n, 
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
 int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);
 /* per kernel family (between begin and the next begin): "gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg",
- * "job_pool_gather", "heads", "mach_in", "gat_pass", "mach_bn_pool", "sample", "small" */
+ * "job_pool_gather", "heads", "head_gemm", "gat_pass", "mach_bn_pool", "sample", "small" */
 int mtfjsp_encoder_timing_query(mtfjsp_encoder_t e, const char *family, double *ms_total, int64_t *launches);
 
 #ifdef __cplusplus

@@ -137,3 +137,39 @@ def split_weights(npz):
     ja = {k[len("w_ja."):]: npz[k] for k in npz.files if k.startswith("w_ja.")}
     ma = {k[len("w_ma."):]: npz[k] for k in npz.files if k.startswith("w_ma.")}
     return ja, ma
+
+
+def critic_weights(npz):
+    return {k[len("w_gc."):]: npz[k] for k in npz.files if k.startswith("w_gc.")}
+
+
+def _gat_machine_nodes(w, mfea1, mfea2, B, M):
+    """shared by the machine actor and the global critic: input projections, 3x the same GATLayer, node mean, BN"""
+    f1 = torch.as_tensor(np.asarray(mfea1), dtype=torch.float64).float().reshape(B * M, 6)
+    f2 = torch.as_tensor(np.asarray(mfea2), dtype=torch.float64).float().reshape(B * M, 8)
+    n0 = f1 @ w["m_fea_1_fcl.weight"].t()
+    n1 = f2 @ w["m_fea_2_fcl.weight"].t()
+    W = w["gat_layer.W"]
+    a = w["gat_layer.a"].reshape(-1)
+    Hd = W.shape[1]
+    a_src, a_dst = a[:Hd], a[Hd:]
+    for it in range(3):
+        z0, z1 = n0 @ W, n1 @ W
+        e00 = torch.nn.functional.leaky_relu(z0 @ a_src + z0 @ a_dst, 0.2)
+        e01 = torch.nn.functional.leaky_relu(z0 @ a_src + z1 @ a_dst, 0.2)
+        att = torch.softmax(torch.stack([e00, e01], 1), 1)
+        n0 = att[:, 0:1] * z0 + att[:, 1:2] * z1
+        n1 = z1
+        if it < 2:
+            n0 = torch.nn.functional.elu(n0)
+            n1 = torch.nn.functional.elu(n1)
+    return _bn((n0 + n1) / 2, w["bn.weight"], w["bn.bias"]).reshape(B, M, Hd)
+
+
+def global_critic_forward(w, tfea, ell_col, ell_val, mfea1, mfea2, B, T, M):
+    """Global_Critic_JointAction_GAT.forward (ac:587-750): its own GIN encoder -> graph pool, its own GAT
+    machine path -> pool, MLPCritic(256 -> 128 -> 128 -> 4) on [pooled_m, pooled_o]."""
+    w = {k: torch.as_tensor(v) for k, v in w.items()}
+    _, h_o = gin_encoder(w, tfea, ell_col, ell_val, B, T)
+    h_m = _gat_machine_nodes(w, mfea1, mfea2, B, M).mean(1)
+    return _mlp_tanh(torch.cat([h_m, h_o], -1), w, "critic").numpy()

@@ -256,15 +256,18 @@ def encoder_vectors(ins, weights, B=16, steps=(0, 17), seed=0):
         base = os.path.join(REF, "trained_model", "can_use", "No_lr_decay")
         ppo.job_actor.load_state_dict(torch.load(os.path.join(base, "PPO_job_actor_J6M6E2_top1.pth"), map_location="cpu"))
         ppo.machine_actor_gcn.load_state_dict(torch.load(os.path.join(base, "PPO_machine_actor_J6M6E2_top1.pth"), map_location="cpu"))
+        ppo.global_critic.load_state_dict(torch.load(os.path.join(base, "PPO_global_critic_J6M6E2_top1.pth"), map_location="cpu"))
     else:
         torch.manual_seed(seed)
         from model.actor_critic import Operation_Actor_JointAction_selfCritic as JA, \
             Machine_Actor_JointAction_selfGAT_selfCritic as MA
+        from model.actor_critic import Global_Critic_JointAction_GAT as GC
         ppo.job_actor = quiet(JA, cfg)
         ppo.machine_actor_gcn = quiet(MA, cfg)
+        ppo.global_critic = quiet(GC, cfg)
         # make BN affine parameters non-trivial so the test sees gamma/beta
         with torch.no_grad():
-            for mod in list(ppo.job_actor.modules()) + list(ppo.machine_actor_gcn.modules()):
+            for mod in list(ppo.job_actor.modules()) + list(ppo.machine_actor_gcn.modules()) + list(ppo.global_critic.modules()):
                 if isinstance(mod, torch.nn.BatchNorm1d):
                     mod.weight.uniform_(0.5, 1.5)
                     mod.bias.uniform_(-0.5, 0.5)
@@ -295,6 +298,7 @@ def encoder_vectors(ins, weights, B=16, steps=(0, 17), seed=0):
             mch_prob, h_m, mach_v = ppo.machine_actor_gcn(machine_fea_1=mfea1, machine_fea_2=mfea2,
                                                           h_pooled_o=h_o, machine_mask=mm)
             m_action = mch_prob.argmax(1)
+            gv = ppo.global_critic(x_fea=tfea, graph_pool_avg=gpool, adj=adj, candidate=cand, machine_fea1=mfea1, machine_fea2=mfea2)
         if step in steps:
             # node embeddings are not returned by the actor; recompute through the encoder
             with torch.no_grad():
@@ -312,11 +316,12 @@ def encoder_vectors(ins, weights, B=16, steps=(0, 17), seed=0):
                 p + "job_logp": log_a.numpy(), p + "job_prob": prob.numpy(), p + "h_o": h_o.numpy(),
                 p + "job_v": job_v.numpy(), p + "h_nodes": h_nodes.numpy(),
                 p + "mch_prob": mch_prob.numpy(), p + "h_m": h_m.numpy(), p + "mach_v": mach_v.numpy(),
+                p + "global_v": gv.numpy(),
             })
         joint = list(zip(task_index.tolist(), m_action.tolist()))
         adj, info, mfea2, tfea = quiet(penv.DGFJSPEnv_paral_step, joint)
         cand, mask = ppo.esa_update_chosenTaskID_CandidateTaskIDx_JobMask(paralenv=penv, action_batch=action_index, mask_value=1)
-    for name, net in (("ja", ppo.job_actor), ("ma", ppo.machine_actor_gcn)):
+    for name, net in (("ja", ppo.job_actor), ("ma", ppo.machine_actor_gcn), ("gc", ppo.global_critic)):
         for k, v in net.state_dict().items():
             if "num_batches_tracked" in k or "running_" in k:
                 continue

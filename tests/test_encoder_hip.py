@@ -32,7 +32,7 @@ def test_actor_forwards_match_reference_outputs(name, obs):
     T = J * M
     ja, ma = eo.split_weights(g)
     enc = enc_mod.Encoder(J, M, B, obs_dtype=obs)
-    enc.load_weights(ja, ma)
+    enc.load_weights(ja, ma, eo.critic_weights(g))
     odt = torch.float32 if obs == "f32" else torch.float64
     for s in g["steps"]:
         p = f"s{int(s)}_"
@@ -66,6 +66,11 @@ def test_actor_forwards_match_reference_outputs(name, obs):
         np.testing.assert_allclose(mprob.cpu().numpy(), g[p + "mch_prob"], rtol=0, atol=1e-4)
         np.testing.assert_allclose(h_m.cpu().numpy(), g[p + "h_m"], rtol=0, atol=1e-4)
         np.testing.assert_allclose(mach_v.cpu().numpy(), g[p + "mach_v"], rtol=1e-3, atol=1e-3)
+        # global critic
+        gv = enc.global_critic_forward(_t(g[p + "tfea"], odt), _t(col.reshape(B * T, 2).astype(np.int32)), _t(val.reshape(B * T, 2).astype(np.float32)),
+                                       _t(g[p + "mfea1"], odt), _t(g[p + "mfea2"], odt))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(gv.cpu().numpy(), g[p + "global_v"], rtol=1e-3, atol=1e-3)
 
 
 def test_sampling_follows_the_distribution():

@@ -33,3 +33,5 @@ def test_encoder_oracle_matches_reference_modules(name):
         np.testing.assert_allclose(mo["prob"], g[p + "mch_prob"], rtol=0, atol=2e-5)
         np.testing.assert_allclose(mo["h_pooled"], g[p + "h_m"], rtol=0, atol=2e-5)
         np.testing.assert_allclose(mo["mach_v"], g[p + "mach_v"], rtol=1e-4, atol=1e-4)
+        gv = eo.global_critic_forward(eo.critic_weights(g), g[p + "tfea"], col, val, g[p + "mfea1"], g[p + "mfea2"], B, T, M)
+        np.testing.assert_allclose(gv, g[p + "global_v"], rtol=1e-4, atol=1e-4)
