@@ -1,15 +1,15 @@
 // mtfjsp_env.hip — batched MT-FJSP disjunctive-graph environment for MI355X (gfx950 / CDNA4).
 //
-// One 64-lane wavefront (= one 64-thread workgroup, so __syncthreads() is a wave-local
-// fence) owns one instance for the duration of a launch: the instance's whole
-// scheduling state is staged in LDS, lanes are tasks, and the step is
-//   A. left-shift scheduling decision  — gap search evaluated for all route positions in parallel
-//                                        (one ds_min on a (position,task) key), no linked-list walk
-//   B. cost update                     — ordered idle sum, per-job estimated-finish scan (job per lane),
-//                                        makespan max-reduce, numpy-order energy sum, rewards, Welford scaler
-//   C. observation                     — 12 task features + ≤2 in-edges per node (ELL form of adj_wrk),
-//                                        staged through LDS and written with 16-byte coalesced stores
-//   D. candidate / job mask            — derived from the same per-job counters as B
+// One 64-lane wavefront (= one 64-thread workgroup) owns one instance for the duration of a launch; lanes are
+// tasks.  A batched step is
+//   A. left-shift scheduling decision  — gap search evaluated for all route positions in parallel, no list walk
+//   B. cost update                     — ordered idle sum, per-job estimated-finish scan, makespan max-reduce,
+//                                        numpy-order energy sum, rewards, Welford reward scaler
+//   C. observation                     — only the rows the decision changes (task features of the acting job's
+//                                        unscheduled tail, <= 4 ELL in-edge rows, one m_fea2 row); k_env_reset
+//                                        writes the full observation once per episode
+//   D. candidate / job mask            — derived from the per-job counters
+// Kernels: k_env_reset, k_env_reg (T <= 64: state in registers, readlane gathers, no LDS), k_env_step (LDS).
 // in ONE kernel launch (mtfjsp_step).  The graph is never materialised: with a simple digraph the
 // in-edges of node v are exactly {job predecessor, route predecessor}, and every edge weight the
 // reference stores is a closed form of (dur, st, ft, machine) of its two endpoints.
@@ -121,7 +121,7 @@ __device__ __forceinline__ long trunc_l(double x) { return (long)x; }   // numpy
 #else
 #define STAMP(slot) do { } while (0)
 #endif
-// Fused reset / step kernel.  grid = B workgroups of 64 threads.
+// grid = B workgroups of 64 threads for all three environment kernels.
 // wave-local LDS fence: a workgroup is ONE wavefront, the LDS pipeline executes a wave's DS instructions in issue
 // order, so cross-lane hand-offs through LDS only need the compiler not to reorder (and no vmcnt drain, unlike
 // __syncthreads()).

@@ -7,6 +7,8 @@ policy="actor" : the GIN job actor and the GAT machine actor run as HIP kernels 
 import ctypes as C
 import random as _random
 
+import os
+
 import numpy as np
 import torch
 
@@ -76,6 +78,11 @@ class Rollout:
                     "+ fused env step (transition, rewards, reward scaling, observation, job mask); batched reset every T steps")
         return ("env-only step: on-device random valid action + fused env step (transition, rewards, reward scaling, "
                 "observation, job mask); batched reset every T steps")
+
+    def env_kernel_name(self):
+        """which step kernel mtfjsp_step dispatches to for this shape (csrc/mtfjsp_env.hip launch selection)"""
+        small = self.T <= 64 and self.M * self.M <= 64 and self.J <= 64 and not os.environ.get("MTFJSP_ENV_LDS")
+        return "k_env_reg" if small else "k_env_step"
 
     def step(self):
         env = self.env

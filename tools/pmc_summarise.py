@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) into profiles/r01_pmc_traffic.json.
+
+    python tools/pmc_summarise.py gpurun_out/pmc_traffic_raw2.json profiles/r01_pmc_traffic.json
+
+Input: {kernel name prefix: {FETCH_SIZE_avg, WRITE_SIZE_avg (KiB per launch), launches_*}} as written by the inline
+post-processing of the gpurun command.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE under-reports wide
+(16 B/lane) coalesced reads by 2x.
+"""
+import json
+import sys
+
+FAMILY = {
+    "void k_gemm128<1, 1>": "gin_gemm_bn_relu", "void k_gemm128<2, 1>": "gin_gemm_agg", "void k_env_reg<float>": "env_step",
+    "k_heads": "heads", "void k_gemm128<3, 3>": "gat_pass_first", "void k_gemm128<0, 3>": "gat_pass",
+    "void k_gin0<float>": "gin0_agg_linear12", "k_job_pool_gather": "job_pool_gather", "k_mach_bn_pool": "mach_bn_pool",
+    "void k_mfea1<float>": "mfea1", "k_sample": "sample", "void k_env_reset<float>": "env_reset", "k_gae": "gae",
+}
+raw = json.load(open(sys.argv[1]))
+out = {"_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py "
+       "--no-cpu-baseline --steps 72 --warmup 36 ; B=4096 J6M6E2 obs f32; averages per launch. Counters are in KiB. gfx950: "
+       "FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md §HBM) -> "
+       "fetch_corrected = 2*FETCH_SIZE; WRITE_SIZE is exact. k_env_reg mixes 4/8/16-B accesses: its read side is "
+       "uncalibrated, traffic_bytes uses the 2x (upper) figure and the raw figure is kept beside it.", "kernels": {}}
+for name, v in raw.items():
+    fam = next((f for k, f in FAMILY.items() if name.startswith(k)), None)
+    if fam is None:
+        continue
+    fr, wr = v["FETCH_SIZE_avg"] * 1024, v["WRITE_SIZE_avg"] * 1024
+    out["kernels"][fam] = {"kernel": name.split("(")[0], "fetch_bytes_raw": fr, "fetch_bytes_corrected": 2 * fr, "write_bytes": wr,
+                           "traffic_bytes": 2 * fr + wr, "launches": v["launches_fetch"]}
+json.dump(out, open(sys.argv[2], "w"), indent=1)
+for k, v in out["kernels"].items():
+    print(f"{k:22s} {v['traffic_bytes'] / 1e6:9.2f} MB/launch")
