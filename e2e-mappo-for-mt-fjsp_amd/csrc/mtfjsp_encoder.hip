@@ -32,9 +32,12 @@
 #define BN_EPS 1e-5
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2, PRO_MACHIN = 3 };
-enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2, EPI_GAT = 3 };
+enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2 };
+enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2 };
 
+// All [rows,128] activation buffers the GEMM kernels read or write are INTERNAL workspaces allocated with the row count
+// rounded up to a whole 32-row tile (rows_padded()), so tiles are loaded, multiplied and stored without per-row bounds
+// checks; only the BatchNorm column sums mask the rows >= N of the last tile.
 struct GemmArgs {
     const float *in;        // [N,128] producer output (pre-activation for PRO_BNRELU / PRO_AGG)
     int N;
@@ -42,25 +45,14 @@ struct GemmArgs {
     const float *bias;      // [128] or NULL
     float *out;             // [N,128]
     // prologue: BatchNorm of `in` from the producer's column sums
-    const double *pro_stats;   // [256] sum | sumsq
+    const double *pro_stats;   // [STAT_REP][256] sum | sumsq
     const float *pro_gamma, *pro_beta;
     double pro_inv_rows;
-    const int *ell_col;     // PRO_AGG: [N,2]
+    const int *ell_col;     // PRO_AGG: [N,2] (caller buffer: exactly N rows)
     const float *ell_val;   // PRO_AGG: [N,2]
     int T;                  // PRO_AGG: rows per instance
-    // epilogue
-    double *epi_stats;      // EPI_STATS: [256] accumulated with atomics (zeroed by the host per forward)
-    const float *rowbias;   // optional [N/rowbias_div,128] added to row r: rowbias[(r / rowbias_div)]
-    int rowbias_div;
-    const void *f1, *f2;    // PRO_MACHIN: m_fea1 [R,6], m_fea2 [R,8] (obs dtype) — rows are generated, not read (ac:383-384)
-    const float *W1, *W2;   // PRO_MACHIN: m_fea_1_fcl.weight [128,6], m_fea_2_fcl.weight [128,8]
-    int feat_f64;
-    const float *gat_a;     // EPI_GAT: [256] a_src | a_dst of the shared GATLayer (gat:68-79)
-    int gat_last;           // EPI_GAT: 0 = ELU + write the next pass' node pair in place, 1 = mean of the 2 nodes -> gat_node + column stats
-    float *gat_node;        // EPI_GAT last pass: [N/2,128]
-    int accumulate;         // C initialised from `out` (K > 128 as a sum of 128-wide GEMMs)
+    double *epi_stats;      // EPI_STATS: [STAT_REP][256] accumulated with atomics (zeroed by the host per forward)
     unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
-    int dbg;                // timing-only ablation bits (MTFJSP_GEMM_DBG): 1 skip prologue loads, 2 skip MFMA, 4 skip epilogue stores
 };
 
 #ifdef MTFJSP_STAMP
@@ -97,42 +89,90 @@ __device__ __forceinline__ float bn_relu(float x, float mean, float rstd, float 
     float y = (x - mean) * rstd * g + b;
     return y > 0.f ? y : 0.f;
 }
+// the same BatchNorm + ReLU as one FMA: y = max(x * sc + sh, 0) with sc = rstd * gamma, sh = beta - mean * sc (the form
+// torch's CPU kernel uses as well: alpha = invstd * weight, beta' = bias - mean * alpha)
+__device__ __forceinline__ float bn_relu_ss(float x, float sc, float sh) { return fmaxf(fmaf(x, sc, sh), 0.f); }
 
 #define STAT_REP 8            // replicated BatchNorm accumulators: <=32 adders per address keeps f64 atomics at full rate
 
-template <int PRO, int EPI>
+// ---- shared pieces of the matrix-core kernels -----------------------------------------------------------------
+// W^T (64 KB) -> LDS with coalesced 16-byte loads; the chunk order is rotated per workgroup so that 256 CUs streaming the
+// same 64 KB do not hit the same L2 channel in lock-step.
+__device__ __forceinline__ void stage_w(float *s_w, const float *Wt, int tid)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(Wt);
+    float4 *dst = reinterpret_cast<float4 *>(s_w);
+#pragma unroll
+    for (int i = 0; i < 16; i++) { const int ii = tid + ((i + blockIdx.x) & 15) * 256; dst[ii] = src[ii]; }
+}
+// BatchNorm scale/shift of 128 columns from the producer's replicated f64 column sums -> s_bn[0..127] = sc, [128..255] = sh
+__device__ __forceinline__ void stage_bn(float *s_bn, const double *stats, double inv_rows, const float *gamma, const float *beta, int tid)
+{
+    if (tid < HD) {
+        double su = 0, sq = 0;
+        for (int r = 0; r < STAT_REP; r++) { su += stats[r * 256 + tid]; sq += stats[r * 256 + HD + tid]; }
+        const double mean = su * inv_rows;
+        double var = sq * inv_rows - mean * mean;                 // biased variance (training-mode BN)
+        if (var < 0) var = 0;
+        const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
+        const float sc = rstd * gamma[tid];
+        s_bn[tid] = sc;
+        s_bn[HD + tid] = beta[tid] - (float)mean * sc;
+    }
+}
+// one 32-row tile x W^T: 64 k-steps x 4 column blocks.  K is permuted (k = 64 h + s) so that each lane half streams its
+// own half row; tile row stride 129 words and W^T row stride 128 words make every ds_read_b32 conflict-free.
+__device__ __forceinline__ void mfma_tile(const float *my_a, const float *s_w, int j, int h, f32x16 (&acc)[4])
+{
+    const float *ap = my_a + j * LDA + 64 * h;                // A[row j][k = 64h + s]
+    const float *bp = s_w + (64 * h) * HD + j;                // B[k = 64h + s][col cb*32 + j]
+#pragma unroll 8
+    for (int s = 0; s < 64; s++) {
+        const float a = ap[s];
+        const float b0 = bp[s * HD], b1 = bp[s * HD + 32], b2 = bp[s * HD + 64], b3 = bp[s * HD + 96];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+    }
+}
+// accumulator register i of lane (j, h) holds C[row = CROW(i) + 4h][col = cb*32 + j]
+#define CROW(i) (((i) & 3) + 8 * ((i) >> 2))
+// per-wave f64 column sums -> one f64 atomic per column per workgroup (into one of STAT_REP replicas)
+__device__ __forceinline__ void flush_stats(double *s_red, double *epi_stats, const double (&st_sum)[4], const double (&st_sq)[4],
+                                            int tid, int wave, int j, int h)
+{
+    for (int cb = 0; cb < 4; cb++) {
+        double a = st_sum[cb], q = st_sq[cb];
+        a += __shfl_xor(a, 32);
+        q += __shfl_xor(q, 32);
+        if (h == 0) { s_red[wave * 256 + cb * 32 + j] = a; s_red[wave * 256 + HD + cb * 32 + j] = q; }
+    }
+    __syncthreads();
+    const double v = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
+    atomicAdd(&epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
+}
+
+template <int PRO, int EPI, bool ACC>
 __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *s_w = reinterpret_cast<float *>(smem);                 // 128*128
     float *s_a = s_w + HD * HD;                                   // 4 * 32 * LDA
-    float *s_bn = s_a + 4 * 32 * LDA;                             // mean | rstd | gamma | beta  (4*128)
+    float *s_bn = s_a + 4 * 32 * LDA;                             // scale | shift  (2*128)
     double *s_red = reinterpret_cast<double *>(s_bn + 4 * HD);    // 4 waves * 256
-    float *s_feat = reinterpret_cast<float *>(s_red + 4 * 256);   // PRO_MACHIN: 4 waves * 32 rows * 8
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 31, h = lane >> 5;
 #ifdef MTFJSP_STAMP
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
 #endif
-
-    {   // W^T -> LDS (coalesced float4)
-        const float4 *src = reinterpret_cast<const float4 *>(A.Wt);
-        float4 *dst = reinterpret_cast<float4 *>(s_w);
-#pragma unroll
-        for (int i = 0; i < 16; i++) { const int ii = tid + ((i + blockIdx.x) & 15) * 256; dst[ii] = src[ii]; }   // rotated: de-phase the CUs across L2 channels
-    }
-    if ((PRO == PRO_BNRELU || PRO == PRO_AGG) && tid < HD) {
-        double su = 0, sq = 0;
-        for (int r = 0; r < STAT_REP; r++) { su += A.pro_stats[r * 256 + tid]; sq += A.pro_stats[r * 256 + HD + tid]; }
-        const double mean = su * A.pro_inv_rows;
-        double var = sq * A.pro_inv_rows - mean * mean;           // biased variance (training-mode BN)
-        if (var < 0) var = 0;
-        s_bn[tid] = (float)mean;
-        s_bn[HD + tid] = 1.0f / sqrtf((float)(var + BN_EPS));
-        s_bn[2 * HD + tid] = A.pro_gamma[tid];
-        s_bn[3 * HD + tid] = A.pro_beta[tid];
-    }
+    stage_w(s_w, A.Wt, tid);
+#ifdef MTFJSP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(7);
+#endif
+    if (PRO != PRO_PLAIN) stage_bn(s_bn, A.pro_stats, A.pro_inv_rows, A.pro_gamma, A.pro_beta, tid);
     __syncthreads();
     STAMP(0);
     // From here on the four waves never synchronise again: each owns its LDS tile, LDS operations of one wave
@@ -143,65 +183,45 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
     const int stride = gridDim.x * 4;
     double st_sum[4] = {0, 0, 0, 0}, st_sq[4] = {0, 0, 0, 0};   // per column block (lane j, block cb), EPI_STATS
     const int c4 = j * 4;
-    float mean4[4], rstd4[4], g4[4], b4[4];
-    if (PRO == PRO_BNRELU || PRO == PRO_AGG)
-        for (int q = 0; q < 4; q++) { mean4[q] = s_bn[c4 + q]; rstd4[q] = s_bn[HD + c4 + q]; g4[q] = s_bn[2 * HD + c4 + q]; b4[q] = s_bn[3 * HD + c4 + q]; }
-
+    float sc0 = 1.f, sc1 = 1.f, sc2 = 1.f, sc3 = 1.f, sh0 = 0.f, sh1 = 0.f, sh2 = 0.f, sh3 = 0.f;
+    if (PRO != PRO_PLAIN) {
+        sc0 = s_bn[c4]; sc1 = s_bn[c4 + 1]; sc2 = s_bn[c4 + 2]; sc3 = s_bn[c4 + 3];
+        sh0 = s_bn[HD + c4]; sh1 = s_bn[HD + c4 + 1]; sh2 = s_bn[HD + c4 + 2]; sh3 = s_bn[HD + c4 + 3];
+    }
     float bias4[4];                                               // hoisted: a load inside the epilogue would force vmcnt(0)
-    for (int cb = 0; cb < 4; cb++) bias4[cb] = (A.bias && !A.accumulate) ? A.bias[cb * 32 + j] : 0.f;
-    float wf[PRO == PRO_MACHIN ? 4 : 1][8];                        // this lane's 4 output columns of W1 (h = 0) or W2 (h = 1)
-    if (PRO == PRO_MACHIN)
-        for (int q = 0; q < 4; q++)
-            for (int k = 0; k < 8; k++) wf[q][k] = h == 0 ? (k < 6 ? A.W1[(c4 + q) * 6 + k] : 0.f) : A.W2[(c4 + q) * 8 + k];
-    float asrc[4] = {0, 0, 0, 0}, adst[4] = {0, 0, 0, 0};
-    if (EPI == EPI_GAT) for (int cb = 0; cb < 4; cb++) { asrc[cb] = A.gat_a[cb * 32 + j]; adst[cb] = A.gat_a[HD + cb * 32 + j]; }
+    for (int cb = 0; cb < 4; cb++) bias4[cb] = (A.bias && !ACC) ? A.bias[cb * 32 + j] : 0.f;
+    const int lane_off = h * HD + c4;                             // this lane's 16 bytes of tile row h (then every second row)
     float4 pre[16];                                               // raw rows of the NEXT tile, in flight during the MFMA phase
     // PRO_AGG keeps the two neighbour rows of every row in flight as well, and the ELL entries one tile further ahead
-    // (the neighbour addresses of tile t+1 must be known when its rows are requested, i.e. before the MFMA phase of t)
+    // (the neighbour addresses of tile t+1 must be known when its rows are requested, i.e. before the MFMA phase of t).
     constexpr int NA = (PRO == PRO_AGG) ? 16 : 1;
     float4 nb0[NA], nb1[NA];
-    // ELL entries: lane l holds those of tile row (l & 31); row 2p+h is read with a cross-lane shuffle
-    int e_cx = -1, e_cy = -1, en_cx = -1, en_cy = -1;              // current tile / next tile
+    // ELL entries: lane l holds those of tile row (l & 31) as (offset of neighbour row relative to the tile's first row,
+    // weight; a missing neighbour = the row itself with weight 0) and 1/deg; row 2p+h is read with a cross-lane shuffle
+    int e_ox = 0, e_oy = 0, en_ox = 0, en_oy = 0;                  // current tile / next tile
     float e_vx = 0.f, e_vy = 0.f, en_vx = 0.f, en_vy = 0.f;
+    double e_inv = 1.0, en_inv = 1.0;
     auto fetch_ell = [&](int tile) __attribute__((always_inline)) {
         const int g = tile * 32 + j;
         int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
         if (g < A.N) { cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
-        en_cx = cc.x; en_cy = cc.y; en_vx = vv.x; en_vy = vv.y;
+        const int base = (g / A.T) * A.T - tile * 32;             // instance's first row relative to the tile
+        en_ox = cc.x >= 0 ? base + cc.x : j; en_vx = cc.x >= 0 ? vv.x : 0.f;
+        en_oy = cc.y >= 0 ? base + cc.y : j; en_vy = cc.y >= 0 ? vv.y : 0.f;
+        const int deg = 1 + (cc.x >= 0) + (cc.y >= 0);
+        en_inv = deg == 1 ? 1.0 : deg == 2 ? 0.5 : (1.0 / 3.0);
     };
     auto prefetch = [&](int tile) __attribute__((always_inline)) {
-        const int row0 = tile * 32;
-        if (PRO == PRO_MACHIN) {
-            // lane L fetches 4 of the 256 feature words of the tile: row L/2 = (machine, node), words 4*(L&1)..+3
-            const int r = row0 + (lane >> 1), k0 = (lane & 1) * 4;
-            float x[4] = {0.f, 0.f, 0.f, 0.f};
-            if (r < A.N) {
-                const int q = r >> 1, node = r & 1, width = node ? 8 : 6;
-                for (int k = 0; k < 4; k++)
-                    if (k0 + k < width) {
-                        const size_t idx = (size_t)q * width + k0 + k;
-                        x[k] = A.feat_f64 ? (float)reinterpret_cast<const double *>(node ? A.f2 : A.f1)[idx]
-                                          : reinterpret_cast<const float *>(node ? A.f2 : A.f1)[idx];
-                    }
-            }
-            pre[0] = make_float4(x[0], x[1], x[2], x[3]);
-            return;
-        }
-        if (PRO == PRO_AGG) { e_cx = en_cx; e_cy = en_cy; e_vx = en_vx; e_vy = en_vy; }   // ELL of THIS tile (fetched one iteration earlier)
+        const float *tb = A.in + (size_t)tile * 32 * HD;          // wave-uniform
+        if (PRO == PRO_AGG) { e_ox = en_ox; e_oy = en_oy; e_vx = en_vx; e_vy = en_vy; e_inv = en_inv; }   // ELL of THIS tile (fetched one iteration earlier)
 #pragma unroll
         for (int p = 0; p < 16; p++) {
-            const int g = row0 + 2 * p + h;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g < A.N && !(A.dbg & 1)) x = *reinterpret_cast<const float4 *>(A.in + (size_t)g * HD + c4);
-            pre[p] = x;
+            pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
             if (PRO == PRO_AGG) {
                 const int pp = p < NA ? p : 0;
-                const int2 cc = make_int2(__shfl(e_cx, 2 * p + h), __shfl(e_cy, 2 * p + h));
-                const int base = (g / A.T) * A.T;
-                float4 y0 = make_float4(0.f, 0.f, 0.f, 0.f), y1 = y0;
-                if (cc.x >= 0) y0 = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.x) * HD + c4);
-                if (cc.y >= 0) y1 = *reinterpret_cast<const float4 *>(A.in + (size_t)(base + cc.y) * HD + c4);
-                nb0[pp] = y0; nb1[pp] = y1;
+                const int ox = __shfl(e_ox, 2 * p + h), oy = __shfl(e_oy, 2 * p + h);
+                nb0[pp] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)ox * HD + c4);
+                nb1[pp] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)oy * HD + c4);
             }
         }
     };
@@ -215,52 +235,24 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
     for (; tile < ntiles; tile += stride) {
         const int row0 = tile * 32;
         // ------------------------------------------------------------------ transform the prefetched rows -> LDS tile
-        float *my_f = s_feat + wave * 256;
-        if (PRO == PRO_MACHIN) {
-            *reinterpret_cast<float4 *>(my_f + lane * 4) = pre[0];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
 #pragma unroll
         for (int p = 0; p < 16; p++) {
             const int r = 2 * p + h;
-            const int g = row0 + r;
-            float v[4] = {pre[p].x, pre[p].y, pre[p].z, pre[p].w};
-            if (PRO == PRO_MACHIN) {
-                // node 0 = m_fea_1_fcl(m_fea1) (6 -> 128), node 1 = m_fea_2_fcl(m_fea2) (8 -> 128), no bias (ac:383-384)
-                const float4 fa = *reinterpret_cast<const float4 *>(my_f + r * 8), fb = *reinterpret_cast<const float4 *>(my_f + r * 8 + 4);
-                const float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
-                for (int q = 0; q < 4; q++) {
-                    float a = 0.f;
-                    for (int k = 0; k < 8; k++) a = fmaf(ff[k], wf[PRO == PRO_MACHIN ? q : 0][k], a);
-                    v[q] = g < A.N ? a : 0.f;
-                }
-            } else
-            if (g < A.N) {
-                if (PRO == PRO_BNRELU) {
-                    for (int q = 0; q < 4; q++) v[q] = bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
-                } else if (PRO == PRO_AGG) {
-                    // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
-                    const int pp = p < NA ? p : 0;
-                    double acc[4];
-                    for (int q = 0; q < 4; q++) acc[q] = (double)bn_relu(v[q], mean4[q], rstd4[q], g4[q], b4[q]);
-                    const int2 cc = make_int2(__shfl(e_cx, r), __shfl(e_cy, r));
-                    const float2 vv = make_float2(__shfl(e_vx, r), __shfl(e_vy, r));
-                    int deg = 1;
-                    if (cc.x >= 0) {
-                        const float yy[4] = {nb0[pp].x, nb0[pp].y, nb0[pp].z, nb0[pp].w};
-                        for (int q = 0; q < 4; q++) acc[q] += (double)vv.x * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
-                        deg++;
-                    }
-                    if (cc.y >= 0) {
-                        const float yy[4] = {nb1[pp].x, nb1[pp].y, nb1[pp].z, nb1[pp].w};
-                        for (int q = 0; q < 4; q++) acc[q] += (double)vv.y * (double)bn_relu(yy[q], mean4[q], rstd4[q], g4[q], b4[q]);
-                        deg++;
-                    }
-                    for (int q = 0; q < 4; q++) v[q] = (float)(acc[q] / (double)deg);
-                }
+            float v0 = pre[p].x, v1 = pre[p].y, v2 = pre[p].z, v3 = pre[p].w;
+            if (PRO == PRO_BNRELU) {
+                v0 = bn_relu_ss(v0, sc0, sh0); v1 = bn_relu_ss(v1, sc1, sh1); v2 = bn_relu_ss(v2, sc2, sh2); v3 = bn_relu_ss(v3, sc3, sh3);
+            } else if (PRO == PRO_AGG) {
+                // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
+                const int pp = p < NA ? p : 0;
+                const double wx = (double)__shfl(e_vx, r), wy = (double)__shfl(e_vy, r), inv = __shfl(e_inv, r);
+                const double a0 = (double)bn_relu_ss(v0, sc0, sh0) + wx * (double)bn_relu_ss(nb0[pp].x, sc0, sh0) + wy * (double)bn_relu_ss(nb1[pp].x, sc0, sh0);
+                const double a1 = (double)bn_relu_ss(v1, sc1, sh1) + wx * (double)bn_relu_ss(nb0[pp].y, sc1, sh1) + wy * (double)bn_relu_ss(nb1[pp].y, sc1, sh1);
+                const double a2 = (double)bn_relu_ss(v2, sc2, sh2) + wx * (double)bn_relu_ss(nb0[pp].z, sc2, sh2) + wy * (double)bn_relu_ss(nb1[pp].z, sc2, sh2);
+                const double a3 = (double)bn_relu_ss(v3, sc3, sh3) + wx * (double)bn_relu_ss(nb0[pp].w, sc3, sh3) + wy * (double)bn_relu_ss(nb1[pp].w, sc3, sh3);
+                v0 = (float)(a0 * inv); v1 = (float)(a1 * inv); v2 = (float)(a2 * inv); v3 = (float)(a3 * inv);
             }
             float *d = my_a + r * LDA + c4;
-            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+            d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // tile complete before this wave reads it back (also a compiler fence)
         STAMP(2);
@@ -269,47 +261,406 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
             if (PRO == PRO_AGG && tile + 2 * stride < ntiles) fetch_ell(tile + 2 * stride);
         }
         STAMP(3);
-        // ------------------------------------------------------------------ main loop
+        // ------------------------------------------------------------------ main loop (accumulators start at the bias)
         f32x16 acc[4];
+        float *ob = A.out + (size_t)row0 * HD + (4 * h) * HD + j;   // C[row CROW(i) + 4h][col cb*32 + j] = ob[CROW(i)*HD + cb*32]
+#pragma unroll
         for (int cb = 0; cb < 4; cb++)
-            for (int i = 0; i < 16; i++) acc[cb][i] = 0.f;
-        if (A.accumulate) {
-            for (int cb = 0; cb < 4; cb++)
-                for (int i = 0; i < 16; i++) {
-                    const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                    if (r < A.N) acc[cb][i] = A.out[(size_t)r * HD + cb * 32 + j];
-                }
-        }
-        // per-instance row bias (scorer input thirds computed once per instance): fetched BEFORE the matrix phase so the
-        // epilogue issues stores only (vmcnt is in-order: any load there would wait for every store before it)
-        float rb[4][16];
-        if (A.rowbias) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                const float *rp = A.rowbias + (size_t)((r < A.N ? r : 0) / A.rowbias_div) * HD + j;
-#pragma unroll
-                for (int cb = 0; cb < 4; cb++) rb[cb][i] = rp[cb * 32];
-            }
-        }
-        const float *ap = my_a + j * LDA + 64 * h;                // A[row j][k = 64h + s]
-        const float *bp = s_w + (64 * h) * HD + j;                // B[k = 64h + s][col cb*32 + j]
-#pragma unroll 8
-        for (int s = 0; s < 64; s++) {
-            const float a = ap[s];
-            const float b0 = bp[s * HD], b1 = bp[s * HD + 32], b2 = bp[s * HD + 64], b3 = bp[s * HD + 96];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
-        }
+            for (int i = 0; i < 16; i++) acc[cb][i] = ACC ? ob[CROW(i) * HD + cb * 32] : bias4[cb];
+        mfma_tile(my_a, s_w, j, h, acc);
         asm volatile("" ::: "memory");                            // keep next iteration's LDS writes behind these reads
         STAMP(4);
-        // ------------------------------------------------------------------ epilogue
-        if (EPI == EPI_GAT) {
-            // One GAT pass on the fixed 2-node graph [[1,1],[0,1]] (gat:82-159, ac:402-414).  Tile rows are
-            // (machine, node) interleaved, so accumulator registers (i, i+1), i even, are z0, z1 of ONE machine:
-            //   e0j = LeakyReLU_0.2(a_src.z0 + a_dst.zj) ; (al0, al1) = softmax(e00, e01) ; n0' = al0 z0 + al1 z1 ; n1' = z1
+        // ------------------------------------------------------------------ epilogue: stores only (vmcnt is in-order)
+        const bool full = row0 + 32 <= A.N;
+#pragma unroll
+        for (int cb = 0; cb < 4; cb++) {
+            float ts = 0.f, tq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                float v = acc[cb][i];
+                if (EPI == EPI_TANH) v = fast_tanh(v);
+                ob[CROW(i) * HD + cb * 32] = v;
+                if (EPI == EPI_STATS) {
+                    if (!full && row0 + CROW(i) + 4 * h >= A.N) v = 0.f;
+                    ts += v; tq += v * v;
+                }
+            }
+            if (EPI == EPI_STATS) { st_sum[cb] += (double)ts; st_sq[cb] += (double)tq; }
+        }
+        STAMP(5);
+    }
+    if (EPI == EPI_STATS) flush_stats(s_red, A.epi_stats, st_sum, st_sq, tid, wave, j, h);
+#ifdef MTFJSP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(6);
+    if (A.stamps && lane == 0)
+        for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
+#endif
+}
+static size_t gemm_lds_bytes() { return (size_t)(HD * HD + 4 * 32 * LDA + 4 * HD) * 4 + 4 * 256 * 8 + 4 * 32 * 8 * 4; }
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm16 — the same product on 16-row tiles (v_mfma_f32_16x16x4_f32) with EIGHT waves per workgroup = two per SIMD:
+// while one wave of a SIMD is in its matrix phase its partner transforms / stores / waits for HBM, so the matrix pipe
+// stays fed.  Half-size tiles also halve the round-robin tail, and tiles are handed out dynamically inside a CU (LDS
+// counter), so each CU's waves finish together.  W^T is kept XOR-swizzled (column ^ 16*(k&1)) so that the B-operand
+// ds_read_b32 of lane quarters k = 4s+q, q = 0/1 fall on opposite halves of the bank row; tile row stride 130 words makes
+// the A-operand reads conflict-free.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LDA16 130
+template <int PRO, int EPI, bool ACC>
+__global__ __launch_bounds__(512) void k_gemm16(GemmArgs A, int stagger)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_w = reinterpret_cast<float *>(smem);                 // 128*128, swizzled
+    float *s_a = s_w + HD * HD;                                   // 8 * 16 * LDA16
+    float *s_bn = s_a + 8 * 16 * LDA16;                           // scale | shift
+    int *s_ctr = reinterpret_cast<int *>(s_bn + 2 * HD);          // [0] tile counter, [1..4] matrix-pipe token of each SIMD pair
+    double *s_red = reinterpret_cast<double *>(s_a);              // reused after the last tile (8 waves * 256 doubles = 16 KB)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5, c4 = j * 4;           // load / transform mapping: rows 2p+h, 4 columns
+    const int m = lane & 15, q = lane >> 4, qo = q & 1;           // matrix mapping: A[row m][k = 4s+q], B[k][col 16c+m], C[row 4q+i][col 16c+m]
+#ifdef MTFJSP_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(A.Wt);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int ii = tid + ((i + blockIdx.x) & 7) * 512;   // rotated chunk order (L2 channel de-phasing)
+            const int k = ii >> 5, n4 = (ii & 31) * 4;
+            *reinterpret_cast<float4 *>(s_w + k * HD + (n4 ^ (16 * (k & 1)))) = src[ii];
+        }
+    }
+    if (PRO != PRO_PLAIN) stage_bn(s_bn, A.pro_stats, A.pro_inv_rows, A.pro_gamma, A.pro_beta, tid);
+    if (tid == 0) *s_ctr = 8;
+    if (tid >= 1 && tid <= 4) s_ctr[tid] = 0;
+    __syncthreads();
+    STAMP(0);
+    // Waves w and w+4 of a workgroup sit on the same SIMD and share its matrix pipe.  Left alone they fall into
+    // lock-step (both in the matrix phase at half rate, then both outside it with the pipe idle), so the matrix phase
+    // is made exclusive per SIMD pair with a token in LDS: one wave multiplies at full rate while its partner
+    // transforms, stores and waits for HBM, then they swap.
+    int *tok = s_ctr + 1 + (wave & 3);
+    float *my_a = s_a + wave * 16 * LDA16;
+    const int ntiles = (A.N + 15) / 16;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int first = blockIdx.x * per;
+    const int last = first + per < ntiles ? first + per : ntiles;
+    auto grab = [&]() __attribute__((always_inline)) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(s_ctr, 1);
+        return first + __builtin_amdgcn_readfirstlane(t);
+    };
+    double st_sum[8], st_sq[8];
+    for (int c = 0; c < 8; c++) { st_sum[c] = 0; st_sq[c] = 0; }
+    float sc0 = 1.f, sc1 = 1.f, sc2 = 1.f, sc3 = 1.f, sh0 = 0.f, sh1 = 0.f, sh2 = 0.f, sh3 = 0.f;
+    if (PRO != PRO_PLAIN) {
+        sc0 = s_bn[c4]; sc1 = s_bn[c4 + 1]; sc2 = s_bn[c4 + 2]; sc3 = s_bn[c4 + 3];
+        sh0 = s_bn[HD + c4]; sh1 = s_bn[HD + c4 + 1]; sh2 = s_bn[HD + c4 + 2]; sh3 = s_bn[HD + c4 + 3];
+    }
+    float bias8[8];
+    for (int c = 0; c < 8; c++) bias8[c] = (A.bias && !ACC) ? A.bias[c * 16 + m] : 0.f;
+    const int lane_off = h * HD + c4;
+    float4 pre[8];
+    constexpr int NA = (PRO == PRO_AGG) ? 8 : 1;
+    float4 nb0[NA], nb1[NA];
+    // ELL entries of a tile: lane l < 16 (and its copies l+16, ...) holds those of tile row (l & 15)
+    int e_ox = 0, e_oy = 0, en_ox = 0, en_oy = 0;
+    float e_vx = 0.f, e_vy = 0.f, en_vx = 0.f, en_vy = 0.f, e_inv = 1.f, en_inv = 1.f;
+    auto fetch_ell = [&](int tile) __attribute__((always_inline)) {
+        const int g = tile * 16 + m;
+        int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
+        if (g < A.N) { cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
+        const int base = (g / A.T) * A.T - tile * 16;             // instance's first row relative to the tile
+        en_ox = cc.x >= 0 ? base + cc.x : m; en_vx = cc.x >= 0 ? vv.x : 0.f;
+        en_oy = cc.y >= 0 ? base + cc.y : m; en_vy = cc.y >= 0 ? vv.y : 0.f;
+        en_inv = (float)(1 + (cc.x >= 0) + (cc.y >= 0));          // degree; its reciprocal is taken in f64 at the use
+    };
+    auto prefetch = [&](int tile) __attribute__((always_inline)) {
+        const float *tb = A.in + (size_t)tile * 16 * HD;          // wave-uniform
+        if (PRO == PRO_AGG) { e_ox = en_ox; e_oy = en_oy; e_vx = en_vx; e_vy = en_vy; e_inv = en_inv; }
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
+            if (PRO == PRO_AGG) {
+                const int pp = p < NA ? p : 0;
+                const int ox = __shfl(e_ox, 2 * p + h), oy = __shfl(e_oy, 2 * p + h);
+                nb0[pp] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)ox * HD + c4);
+                nb1[pp] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)oy * HD + c4);
+            }
+        }
+    };
+    // Tile pipeline of one wave (vmcnt counts loads and stores together and the compiler must assume they complete out
+    // of order, so any wait for a load drains every store issued before it — the order below keeps a whole matrix phase
+    // between a tile's stores and the next wait):
+    //     matrix phase(t) -> transform(t+1) into the LDS tile -> request rows(t+2) -> store results(t)
+    auto transform = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int r = 2 * p + h;
+            float v0 = pre[p].x, v1 = pre[p].y, v2 = pre[p].z, v3 = pre[p].w;
+            if (PRO == PRO_BNRELU) {
+                v0 = bn_relu_ss(v0, sc0, sh0); v1 = bn_relu_ss(v1, sc1, sh1); v2 = bn_relu_ss(v2, sc2, sh2); v3 = bn_relu_ss(v3, sc3, sh3);
+            } else if (PRO == PRO_AGG) {
+                // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
+                const int pp = p < NA ? p : 0;
+                const double wx = (double)__shfl(e_vx, r), wy = (double)__shfl(e_vy, r);
+                const float dg = __shfl(e_inv, r);
+                const double inv = dg == 1.f ? 1.0 : dg == 2.f ? 0.5 : (1.0 / 3.0);
+                const double a0 = (double)bn_relu_ss(v0, sc0, sh0) + wx * (double)bn_relu_ss(nb0[pp].x, sc0, sh0) + wy * (double)bn_relu_ss(nb1[pp].x, sc0, sh0);
+                const double a1 = (double)bn_relu_ss(v1, sc1, sh1) + wx * (double)bn_relu_ss(nb0[pp].y, sc1, sh1) + wy * (double)bn_relu_ss(nb1[pp].y, sc1, sh1);
+                const double a2 = (double)bn_relu_ss(v2, sc2, sh2) + wx * (double)bn_relu_ss(nb0[pp].z, sc2, sh2) + wy * (double)bn_relu_ss(nb1[pp].z, sc2, sh2);
+                const double a3 = (double)bn_relu_ss(v3, sc3, sh3) + wx * (double)bn_relu_ss(nb0[pp].w, sc3, sh3) + wy * (double)bn_relu_ss(nb1[pp].w, sc3, sh3);
+                v0 = (float)(a0 * inv); v1 = (float)(a1 * inv); v2 = (float)(a2 * inv); v3 = (float)(a3 * inv);
+            }
+            float *d = my_a + r * LDA16 + c4;
+            *reinterpret_cast<float2 *>(d) = make_float2(v0, v1);
+            *reinterpret_cast<float2 *>(d + 2) = make_float2(v2, v3);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // tile queue: t_cur (in the LDS tile), t_n1 (rows in registers), t_n2 (ELL entries in registers, PRO_AGG only)
+    int t_cur = first + wave, t_n1 = grab(), t_n2 = (PRO == PRO_AGG) ? grab() : 0;
+    if (t_cur < last) {
+        if (PRO == PRO_AGG) fetch_ell(t_cur);
+        prefetch(t_cur);
+        if (PRO == PRO_AGG && t_n1 < last) fetch_ell(t_n1);
+        transform();
+        if (t_n1 < last) {
+            prefetch(t_n1);
+            if (PRO == PRO_AGG && t_n2 < last) fetch_ell(t_n2);
+        }
+    }
+    STAMP(1);
+    const float *ap = my_a + m * LDA16 + q;
+    const float *bp = s_w + q * HD + m;
+    int bo[8];
+    for (int c = 0; c < 8; c++) bo[c] = (c ^ qo) * 16;
+    while (t_cur < last) {
+        const int row0 = t_cur * 16;
+        // ------------------------------------------------------------------ matrix phase
+        f32x4 acc[8];
+        float *ob = A.out + (size_t)row0 * HD + (4 * q) * HD + m;   // C[row 4q+i][col 16c+m] = ob[i*HD + 16c]
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[c][i] = ACC ? ob[i * HD + c * 16] : bias8[c];
+        if (stagger) {
+            if (lane == 0) while (atomicCAS(tok, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+        }
+        STAMP(3);
+        // operands of k-step s+1 are requested before the 8 products of step s are issued (two register sets), so the
+        // ~100-cycle LDS latency hides behind 256 cycles of matrix work instead of stalling every other product
+        {
+            float a0 = ap[0], a1, b0[8], b1[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) b0[c] = bp[bo[c]];
+#pragma unroll 2
+            for (int s = 0; s < 32; s += 2) {
+                const float *bs1 = bp + (s + 1) * 4 * HD;
+                a1 = ap[4 * (s + 1)];
+#pragma unroll
+                for (int c = 0; c < 8; c++) b1[c] = bs1[bo[c]];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[c], acc[c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int s2 = s + 2 < 32 ? s + 2 : 0;             // (the last request is a harmless re-read of step 0)
+                const float *bs2 = bp + s2 * 4 * HD;
+                a0 = ap[4 * s2];
+#pragma unroll
+                for (int c = 0; c < 8; c++) b0[c] = bs2[bo[c]];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[c], acc[c], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (stagger) { if (lane == 0) atomicExch(tok, 0); }
+        STAMP(4);
+        // ------------------------------------------------------------------ results: column sums from the accumulators,
+        // then transposed through the (now free) LDS tile into row-major 16-byte pieces — dword stores (one column per
+        // lane) are issue-bound in the memory pipeline at 1/4 of the bytes per cycle of dwordx4 stores
+        const bool full = row0 + 16 <= A.N;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            float ts = 0.f, tq = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float v = acc[c][i];
+                if (EPI == EPI_TANH) v = fast_tanh(v);
+                my_a[(4 * q + i) * LDA16 + c * 16 + m] = v;
+                if (EPI == EPI_STATS) {
+                    if (!full && row0 + 4 * q + i >= A.N) v = 0.f;
+                    ts += v; tq += v * v;
+                }
+            }
+            if (EPI == EPI_STATS) { st_sum[c] += (double)ts; st_sq[c] += (double)tq; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        float4 res[8];
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const float *d = my_a + (2 * p + h) * LDA16 + c4;
+            const float2 lo = *reinterpret_cast<const float2 *>(d), hi = *reinterpret_cast<const float2 *>(d + 2);
+            res[p] = make_float4(lo.x, lo.y, hi.x, hi.y);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STAMP(5);
+#ifdef MTFJSP_STAMP
+        ph[7] += 1;
+#endif
+        // ------------------------------------------------------------------ next tile -> LDS, the one after -> in flight
+        const int t_n3 = grab();
+        if (t_n1 < last) {
+            transform();
+            const int t_pf = (PRO == PRO_AGG) ? t_n2 : t_n3;
+            if (t_pf < last) {
+                prefetch(t_pf);
+                if (PRO == PRO_AGG && t_n3 < last) fetch_ell(t_n3);
+            }
+            STAMP(2);
+        }
+        {
+            float *orow = A.out + (size_t)row0 * HD + lane_off;
+#pragma unroll
+            for (int p = 0; p < 8; p++) *reinterpret_cast<float4 *>(orow + p * 2 * HD) = res[p];
+        }
+        STAMP(5);
+        t_cur = t_n1;
+        if (PRO == PRO_AGG) { t_n1 = t_n2; t_n2 = t_n3; } else t_n1 = t_n3;
+    }
+    if (EPI == EPI_STATS) {
+        __syncthreads();                                          // every wave is done with its tile: s_red aliases them
+        for (int c = 0; c < 8; c++) {
+            double a = st_sum[c], b = st_sq[c];
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+            if (q == 0) { s_red[wave * 256 + c * 16 + m] = a; s_red[wave * 256 + HD + c * 16 + m] = b; }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            double v = 0;
+            for (int w = 0; w < 8; w++) v += s_red[w * 256 + tid];
+            atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
+        }
+    }
+#ifdef MTFJSP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP(6);
+    if (A.stamps && lane == 0)
+        for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
+#endif
+}
+static size_t gemm16_lds_bytes() { return (size_t)(HD * HD + 8 * 16 * LDA16 + 2 * HD) * 4 + 64; }
+
+// ---------------------------------------------------------------------------------------------
+// Machine path of the machine actor / global critic (ac:383-434, gat:82-159) in ONE launch.  The three applications of
+// the single shared GATLayer on the fixed 2-node graph [[1,1],[0,1]] couple only rows (2q, 2q+1) = (node 0, node 1) of
+// machine q, which lie in the same 32-row tile, so a wave keeps its tile in LDS across all three passes:
+//   rows   : node 0 = m_fea_1_fcl(m_fea1[q]) (6 -> 128), node 1 = m_fea_2_fcl(m_fea2[q]) (8 -> 128), no bias (ac:383-384)
+//   pass   : z = rows x W (MFMA);  e0j = LeakyReLU_0.2(a_src.z0 + a_dst.zj);  (al0, al1) = softmax(e00, e01);
+//            n0' = al0 z0 + al1 z1 ; n1' = z1 ;  ELU after passes 1 and 2, written back into the LDS tile (ac:409-413)
+//   end    : mean of the two nodes (ac:420) -> node[q] and the column sums of the BatchNorm that follows (ac:434)
+// W^T is staged once and no intermediate ever leaves the CU.
+struct GatArgs {
+    int R;                  // machines rows = B*M ; tile rows = 2R
+    const void *f1, *f2;    // m_fea1 [R,6], m_fea2 [R,8] (obs dtype)
+    int feat_f64;
+    const float *W1, *W2;   // m_fea_1_fcl.weight [128,6], m_fea_2_fcl.weight [128,8]
+    const float *Wt;        // gat_layer.W [in,out]
+    const float *gat_a;     // [256] a_src | a_dst (gat:68-79)
+    float *node;            // [R,128] (padded to 16-row multiples) pre-BatchNorm node mean
+    double *epi_stats;
+    unsigned long long *stamps;
+};
+__global__ __launch_bounds__(256, 1) void k_gat3(GatArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_w = reinterpret_cast<float *>(smem);                 // 128*128
+    float *s_a = s_w + HD * HD;                                   // 4 * 32 * LDA
+    float *s_bn = s_a + 4 * 32 * LDA;
+    double *s_red = reinterpret_cast<double *>(s_bn + 4 * HD);    // 4 waves * 256
+    float *s_feat = reinterpret_cast<float *>(s_red + 4 * 256);   // 4 waves * 32 rows * 8
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+#ifdef MTFJSP_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
+    stage_w(s_w, A.Wt, tid);
+    __syncthreads();
+    STAMP(0);
+    float *my_a = s_a + wave * 32 * LDA;
+    float *my_f = s_feat + wave * 256;
+    const int N = 2 * A.R;
+    const int ntiles = (N + 31) / 32;
+    const int stride = gridDim.x * 4;
+    double st_sum[4] = {0, 0, 0, 0}, st_sq[4] = {0, 0, 0, 0};
+    const int c4 = j * 4;
+    float wf[4][8];                                               // this lane's 4 output columns of W1 (h = 0) or W2 (h = 1)
+    for (int q = 0; q < 4; q++)
+        for (int k = 0; k < 8; k++) wf[q][k] = h == 0 ? (k < 6 ? A.W1[(c4 + q) * 6 + k] : 0.f) : A.W2[(c4 + q) * 8 + k];
+    float asrc[4], adst[4];
+    for (int cb = 0; cb < 4; cb++) { asrc[cb] = A.gat_a[cb * 32 + j]; adst[cb] = A.gat_a[HD + cb * 32 + j]; }
+    // lane L fetches 4 of the 256 feature words of a tile: row L/2 = (machine, node), words 4*(L&1)..+3
+    auto fetch_feat = [&](int tile) __attribute__((always_inline)) -> float4 {
+        const int r = tile * 32 + (lane >> 1), k0 = (lane & 1) * 4;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < N) {
+            const int q = r >> 1, node = r & 1, width = node ? 8 : 6;
+            for (int k = 0; k < 4; k++)
+                if (k0 + k < width) {
+                    const size_t idx = (size_t)q * width + k0 + k;
+                    x[k] = A.feat_f64 ? (float)reinterpret_cast<const double *>(node ? A.f2 : A.f1)[idx]
+                                      : reinterpret_cast<const float *>(node ? A.f2 : A.f1)[idx];
+                }
+        }
+        return make_float4(x[0], x[1], x[2], x[3]);
+    };
+    int tile = blockIdx.x * 4 + wave;
+    float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tile < ntiles) fpre = fetch_feat(tile);
+    STAMP(1);
+    for (; tile < ntiles; tile += stride) {
+        const int row0 = tile * 32;
+        // ---- input rows: row r of the tile is node (r & 1) of machine (row0 + r) / 2; tile rows 2p+h have node = h
+        *reinterpret_cast<float4 *>(my_f + lane * 4) = fpre;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 16; p++) {
+            const int r = 2 * p + h;
+            const float4 fa = *reinterpret_cast<const float4 *>(my_f + r * 8), fb = *reinterpret_cast<const float4 *>(my_f + r * 8 + 4);
+            const float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+            float *d = my_a + r * LDA + c4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) a = fmaf(ff[k], wf[q][k], a);
+                d[q] = a;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (tile + stride < ntiles) fpre = fetch_feat(tile + stride);
+        STAMP(2);
+        const bool full = row0 + 32 <= N;
+#pragma unroll 1
+        for (int pass = 0; pass < 3; pass++) {
+            f32x16 acc[4];
+#pragma unroll
+            for (int cb = 0; cb < 4; cb++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[cb][i] = 0.f;
+            mfma_tile(my_a, s_w, j, h, acc);
+            asm volatile("" ::: "memory");
+            STAMP(3);
+            // accumulator registers (i, i+1), i even, are z0, z1 of ONE machine (tile rows CROW(i)+4h, +1)
 #pragma unroll
             for (int ip = 0; ip < 8; ip++) {
                 const int i = 2 * ip;
@@ -324,57 +675,35 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
                 const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
                 const float inv = 1.0f / (x0 + x1);
                 const float al0 = x0 * inv, al1 = x1 * inv;
-                const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;          // even: node 0 of machine r/2
-                if (r < A.N) {
+                const int r = CROW(i) + 4 * h;                                // even tile row: node 0 of its machine
+                if (pass < 2) {
 #pragma unroll
                     for (int cb = 0; cb < 4; cb++) {
-                        const int col = cb * 32 + j;
                         const float z0 = acc[cb][i], z1 = acc[cb][i + 1];
                         float n0 = al0 * z0 + al1 * z1, n1 = z1;
-                        if (!A.gat_last) {
-                            n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;           // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
-                            n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
-                            A.out[(size_t)r * HD + col] = n0;
-                            A.out[(size_t)(r + 1) * HD + col] = n1;
-                        } else {
-                            const float mv = (n0 + n1) * 0.5f;                // mean over the 2 nodes (ac:420)
-                            A.gat_node[(size_t)(r >> 1) * HD + col] = mv;
-                            st_sum[cb] += (double)mv; st_sq[cb] += (double)mv * (double)mv;
-                        }
+                        n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;               // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
+                        n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
+                        my_a[r * LDA + cb * 32 + j] = n0;
+                        my_a[(r + 1) * LDA + cb * 32 + j] = n1;
+                    }
+                } else {
+                    const bool valid = full || row0 + r < N;
+                    float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + j;
+#pragma unroll
+                    for (int cb = 0; cb < 4; cb++) {
+                        const float z0 = acc[cb][i], z1 = acc[cb][i + 1];
+                        float mv = (al0 * z0 + al1 * z1 + z1) * 0.5f;        // mean over the 2 nodes (ac:420)
+                        nd[cb * 32] = mv;
+                        if (!valid) mv = 0.f;
+                        st_sum[cb] += (double)mv; st_sq[cb] += (double)mv * (double)mv;
                     }
                 }
             }
-        } else
-        for (int cb = 0; cb < 4; cb++) {
-            const int col = cb * 32 + j;
-            const float bias = bias4[cb];
-            float ts = 0.f, tq = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int r = row0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (r < A.N && !(A.dbg & 4)) {
-                    float v = acc[cb][i] + bias;
-                    if (A.rowbias) v += rb[cb][i];
-                    if (EPI == EPI_TANH) v = fast_tanh(v);
-                    A.out[(size_t)r * HD + col] = v;
-                    if (EPI == EPI_STATS) { ts += v; tq += v * v; }
-                }
-            }
-            if (EPI == EPI_STATS) { st_sum[cb] += (double)ts; st_sq[cb] += (double)tq; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tile is complete before the next pass reads it
+            STAMP(4);
         }
-        STAMP(5);
     }
-    if (EPI == EPI_STATS || (EPI == EPI_GAT && A.gat_last)) {
-        for (int cb = 0; cb < 4; cb++) {
-            double a = st_sum[cb], q = st_sq[cb];
-            a += __shfl_xor(a, 32);
-            q += __shfl_xor(q, 32);
-            if (h == 0) { s_red[wave * 256 + cb * 32 + j] = a; s_red[wave * 256 + HD + cb * 32 + j] = q; }
-        }
-        __syncthreads();
-        const double v = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
-        atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
-    }
+    flush_stats(s_red, A.epi_stats, st_sum, st_sq, tid, wave, j, h);
 #ifdef MTFJSP_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(6);
@@ -382,7 +711,6 @@ __global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
         for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
 #endif
 }
-static size_t gemm_lds_bytes() { return (size_t)(HD * HD + 4 * 32 * LDA + 4 * HD) * 4 + 4 * 256 * 8 + 4 * 32 * 8 * 4; }
 
 // ---------------------------------------------------------------------------------------------
 // Fused actor heads (ac:205-293 / ac:444-495): for a group of 16 instances one workgroup computes
@@ -807,9 +1135,8 @@ struct mtfjsp_encoder {
     int num_cu = 256;
     // workspaces
     float *zA = nullptr, *zB = nullptr;     // [B*T,128] ping-pong
-    float *cand_feat = nullptr, *s1 = nullptr, *s2 = nullptr;   // [B*max(J,M),128]
+    float *cand_feat = nullptr;             // [B*max(J,M),128]
     float *u = nullptr, *c1 = nullptr, *c2 = nullptr, *hm_b = nullptr, *pooled_int = nullptr;   // [B,128]
-    float *X = nullptr, *Z = nullptr;       // [2,B*M,128]
     float *node = nullptr;                  // [B*M,128]
     double *stats = nullptr;                // [8,256]
     // timing
@@ -885,20 +1212,34 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     if (hipGetDeviceProperties(&prop, cfg->device_id) == hipSuccess) e->num_cu = prop.multiProcessorCount;
     const size_t B = cfg->batch, T = e->T, M = cfg->n_machine, J = cfg->n_job, R = J > M ? J : M;
     int rc = 0;
-    rc |= dalloc(e, &e->zA, B * T * HD); rc |= dalloc(e, &e->zB, B * T * HD);
-    rc |= dalloc(e, &e->cand_feat, B * R * HD); rc |= dalloc(e, &e->s1, B * R * HD); rc |= dalloc(e, &e->s2, B * R * HD);
-    rc |= dalloc(e, &e->u, B * HD); rc |= dalloc(e, &e->c1, B * HD); rc |= dalloc(e, &e->c2, B * HD); rc |= dalloc(e, &e->hm_b, B * HD);
-    rc |= dalloc(e, &e->pooled_int, B * HD);
-    rc |= dalloc(e, &e->X, 2 * B * M * HD); rc |= dalloc(e, &e->Z, 2 * B * M * HD); rc |= dalloc(e, &e->node, B * M * HD);
+    // every [rows,128] workspace is padded to whole 32-row tiles (+1 tile) and zero-filled once: the matrix-core kernels
+    // load and store whole tiles without bounds checks
+    auto rows_padded = [](size_t rows) { return ((rows + 31) / 32 + 1) * 32; };
+    auto dalloc_rows = [&](float **ptr, size_t rows) {
+        const size_t n = rows_padded(rows) * HD;
+        if (dalloc(e, ptr, n)) return 1;
+        return hipMemset(*ptr, 0, n * sizeof(float)) == hipSuccess ? 0 : 1;
+    };
+    rc |= dalloc_rows(&e->zA, B * T); rc |= dalloc_rows(&e->zB, B * T);
+    rc |= dalloc_rows(&e->cand_feat, B * R);
+    rc |= dalloc_rows(&e->u, B); rc |= dalloc_rows(&e->c1, B); rc |= dalloc_rows(&e->c2, B); rc |= dalloc_rows(&e->hm_b, B);
+    rc |= dalloc_rows(&e->pooled_int, B);
+    rc |= dalloc_rows(&e->node, B * M);
     rc |= dalloc(e, &e->stats, 8 * STAT_REP * 256);
     if (rc) { g_enc_err = e->err; mtfjsp_encoder_destroy(e); return MTFJSP_ERR_HIP; }
     const int lds = (int)gemm_lds_bytes();
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_PLAIN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_GAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_TANH>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_MACHIN, EPI_GAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_BNRELU, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_AGG, EPI_STATS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_PLAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_TANH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_TANH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_BNRELU, EPI_STATS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_AGG, EPI_STATS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute((const void *)k_gat3, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int lds16 = (int)gemm16_lds_bytes();
+    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_PLAIN, EPI_PLAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_PLAIN, EPI_TANH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_PLAIN, EPI_TANH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_BNRELU, EPI_STATS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_AGG, EPI_STATS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
     *out = e;
     return MTFJSP_OK;
@@ -971,41 +1312,51 @@ struct Timed {
     ~Timed() { if (on) (void)hipEventRecord(ev.second, e->stream); }
 };
 
-template <int PRO, int EPI>
+template <int PRO, int EPI, bool ACC = false>
 static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
 {
     Timed t(e, name);
-    const int ntiles = (a.N + 31) / 32;
-    int grid = (ntiles + 3) / 4;
+    static const int use16 = getenv("MTFJSP_GEMM32") ? 0 : 1;
+    static const int stagger = getenv("MTFJSP_GEMM_TOKEN") ? atoi(getenv("MTFJSP_GEMM_TOKEN")) : 0;
+    const int waves = use16 ? 8 : 4;
+    const int ntiles = use16 ? (a.N + 15) / 16 : (a.N + 31) / 32;
+    int grid = (ntiles + waves - 1) / waves;
     if (grid > e->num_cu) grid = e->num_cu;
+    GemmArgs b = a;
 #ifdef MTFJSP_STAMP
     static unsigned long long *d_st = nullptr;
-    if (!d_st) (void)hipMalloc((void **)&d_st, 1024 * 8 * 8);
-    (void)hipMemsetAsync(d_st, 0, 1024 * 8 * 8, e->stream);
-    GemmArgs b = a; b.stamps = d_st;
-    hipLaunchKernelGGL((k_gemm128<PRO, EPI>), dim3(grid), dim3(256), gemm_lds_bytes(), e->stream, b);
+    if (!d_st) (void)hipMalloc((void **)&d_st, 2048 * 8 * 8);
+    (void)hipMemsetAsync(d_st, 0, 2048 * 8 * 8, e->stream);
+    b.stamps = d_st;
+#endif
+    if (use16) hipLaunchKernelGGL((k_gemm16<PRO, EPI, ACC>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b, stagger);
+    else hipLaunchKernelGGL((k_gemm128<PRO, EPI, ACC>), dim3(grid), dim3(256), gemm_lds_bytes(), e->stream, b);
+#ifdef MTFJSP_STAMP
     static int printed = 0;
     if (printed < 40 && getenv("MTFJSP_STAMP_PRINT")) {
         (void)hipStreamSynchronize(e->stream);
-        std::vector<unsigned long long> hst(1024 * 8);
-        (void)hipMemcpy(hst.data(), d_st, 1024 * 8 * 8, hipMemcpyDeviceToHost);
-        double m[8] = {0};
-        for (int w = 0; w < grid * 4; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i] / (grid * 4);
-        printf("STAMP %-18s N=%d grid=%d  Wload %.0f  prefetch0 %.0f  transform %.0f  prefetch %.0f  mfma %.0f  epilogue %.0f  tail %.0f (cycles/wave, summed over its tiles)\n",
-               name, a.N, grid, m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+        std::vector<unsigned long long> hst(2048 * 8);
+        (void)hipMemcpy(hst.data(), d_st, 2048 * 8 * 8, hipMemcpyDeviceToHost);
+        for (int half = 0; half < (use16 ? 2 : 1); half++) {
+            double m[8] = {0}; int n = 0;
+            for (int w = 0; w < grid * waves; w++) {
+                if (use16 && ((w % 8) >= 4) != (half == 1)) continue;
+                n++;
+                for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i];
+            }
+            for (int i = 0; i < 8; i++) m[i] /= n;
+            printf("STAMP %-18s N=%d grid=%d waves=%d half=%d  tiles %.2f  bn+sync %.0f  prefetch0 %.0f  transform+prefetch %.0f  token-wait %.0f  mfma %.0f  epilogue %.0f  tail %.0f (cycles/wave, summed over its tiles)\n",
+                   name, a.N, grid, waves, half, m[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+        }
         printed++;
     }
-#else
-    hipLaunchKernelGGL((k_gemm128<PRO, EPI>), dim3(grid), dim3(256), gemm_lds_bytes(), e->stream, a);
 #endif
 }
 
 static GemmArgs gemm_args(const float *in, int N, const float *Wt, const float *bias, float *out)
 {
     GemmArgs a{};
-    a.in = in; a.N = N; a.Wt = Wt; a.bias = bias; a.out = out; a.rowbias_div = 1;
-    static const int dbg = getenv("MTFJSP_GEMM_DBG") ? atoi(getenv("MTFJSP_GEMM_DBG")) : 0;
-    a.dbg = dbg;
+    a.in = in; a.N = N; a.Wt = Wt; a.bias = bias; a.out = out;
     return a;
 }
 
@@ -1066,15 +1417,34 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
     double *st = e->stats + 6 * STAT_REP * 256;
     HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
-    for (int pass = 0; pass < 3; pass++) {                                    // the SAME GATLayer three times (ac:409-414)
-        GemmArgs a = gemm_args(e->X, 2 * R, WT(pre + "gat_layer.W"), nullptr, e->X);      // in place: a wave only rewrites the tile it read
-        a.gat_a = W(pre + "gat_layer.a"); a.gat_last = pass == 2; a.gat_node = e->node; a.epi_stats = st;
-        if (pass == 0) {                                                        // input projections generated in the prologue
-            a.f1 = m_fea1; a.f2 = m_fea2; a.W1 = W(pre + "m_fea_1_fcl.weight"); a.W2 = W(pre + "m_fea_2_fcl.weight");
-            a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
-            launch_gemm<PRO_MACHIN, EPI_GAT>(e, a, "gat_pass");
-        } else
-            launch_gemm<PRO_PLAIN, EPI_GAT>(e, a, "gat_pass");
+    {                                                                          // the SAME GATLayer three times (ac:409-414), one launch
+        Timed t(e, "gat3");
+        GatArgs a{};
+        a.R = R; a.f1 = m_fea1; a.f2 = m_fea2; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
+        a.W1 = W(pre + "m_fea_1_fcl.weight"); a.W2 = W(pre + "m_fea_2_fcl.weight");
+        a.Wt = WT(pre + "gat_layer.W"); a.gat_a = W(pre + "gat_layer.a"); a.node = e->node; a.epi_stats = st;
+        const int ntiles = (2 * R + 31) / 32;
+        int grid = (ntiles + 3) / 4;
+        if (grid > e->num_cu) grid = e->num_cu;
+#ifdef MTFJSP_STAMP
+        static unsigned long long *d_st = nullptr;
+        if (!d_st) (void)hipMalloc((void **)&d_st, 1024 * 8 * 8);
+        (void)hipMemsetAsync(d_st, 0, 1024 * 8 * 8, e->stream);
+        a.stamps = d_st;
+#endif
+        hipLaunchKernelGGL(k_gat3, dim3(grid), dim3(256), gemm_lds_bytes(), e->stream, a);
+#ifdef MTFJSP_STAMP
+        static int printed = 0;
+        if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
+            (void)hipStreamSynchronize(e->stream);
+            std::vector<unsigned long long> hst(1024 * 8);
+            (void)hipMemcpy(hst.data(), d_st, 1024 * 8 * 8, hipMemcpyDeviceToHost);
+            double m[8] = {0};
+            for (int w = 0; w < grid * 4; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i] / (grid * 4);
+            printf("STAMP k_gat3 R=%d grid=%d  Wload %.0f  feat0 %.0f  rows %.0f  mfma %.0f  gat-epilogue %.0f  tail %.0f (cycles/wave, summed)\n",
+                   R, grid, m[0], m[1], m[2], m[3], m[4], m[6]);
+        }
+#endif
     }
     {
         Timed t(e, "mach_bn_pool");
@@ -1201,8 +1571,7 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
     GemmArgs a = gemm_args(e->u, B, W0t, W("global_critic.critic.linears.0.bias"), e->c1);
     launch_gemm<PRO_PLAIN, EPI_PLAIN>(e, a, "head_gemm");
     GemmArgs b = gemm_args(e->pooled_int, B, W0t + HD * HD, nullptr, e->c1);
-    b.accumulate = 1;
-    launch_gemm<PRO_PLAIN, EPI_TANH>(e, b, "head_gemm");
+    launch_gemm<PRO_PLAIN, EPI_TANH, true>(e, b, "head_gemm");
     GemmArgs c = gemm_args(e->c1, B, WT("global_critic.critic.linears.1.weight"), W("global_critic.critic.linears.1.bias"), e->c2);
     launch_gemm<PRO_PLAIN, EPI_TANH>(e, c, "head_gemm");
     {

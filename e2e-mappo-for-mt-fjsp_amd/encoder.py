@@ -13,8 +13,8 @@ import torch
 from . import capi
 
 H = 128
-FAMILIES = ["gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg", "job_pool_gather", "heads", "head_gemm", "score_softmax",
-            "mach_in", "gat_pass", "gat_gemm", "gat_combine", "mach_bn_pool", "sample", "small"]
+FAMILIES = ["gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg", "job_pool_gather", "heads", "head_gemm", "gat3", "mach_bn_pool",
+            "sample", "small"]
 
 
 def available():
@@ -182,11 +182,13 @@ class ActorPair:
         """f32 MFMA roofline for the GEMM families; HBM for the rest."""
         J, M, T = self.enc.J, self.enc.M, self.enc.T
         avg_s = kd["ms_total"] / max(kd["launches"], 1) * 1e-3
-        rows = {"gin_gemm_bn_relu": B * T, "gin_gemm_agg": B * T, "gat_gemm": 2 * B * M, "gat_pass": 2 * B * M}.get(name)
+        rows = {"gin_gemm_bn_relu": B * T, "gin_gemm_agg": B * T, "gat3": 2 * B * M}.get(name)
         if rows is not None:
-            flops = 2.0 * rows * H * H
+            flops = 2.0 * rows * H * H * (3 if name == "gat3" else 1)
             ach = flops / avg_s / 1e12
-            return {"kernel": f"k_gemm128<{name}> ([{rows},128]x[128,128] f32 MFMA 32x32x2, fused BN/aggregation prologue + stats epilogue)",
+            kern = ("k_gat3 (3 fused GAT passes, f32 MFMA 32x32x2)" if name == "gat3" else
+                    f"k_gemm16<{name}> ([{rows},128]x[128,128] f32 MFMA 16x16x4, fused BN/aggregation prologue + stats epilogue)")
+            return {"kernel": kern,
                     "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_flops_per_launch": flops,
                     "hbm_GBps_same_launch": rows * H * 4 * 2 / avg_s / 1e9}

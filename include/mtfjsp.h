@@ -214,7 +214,7 @@ int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *prob, int32_t n, 
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
 int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);
 /* per kernel family (between begin and the next begin): "gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg",
- * "job_pool_gather", "heads", "head_gemm", "gat_pass", "mach_bn_pool", "sample", "small" */
+ * "job_pool_gather", "heads", "head_gemm", "gat3", "mach_bn_pool", "sample", "small" */
 int mtfjsp_encoder_timing_query(mtfjsp_encoder_t e, const char *family, double *ms_total, int64_t *launches);
 
 #ifdef __cplusplus
