@@ -53,6 +53,7 @@ struct GemmArgs {
     int T;                  // PRO_AGG: rows per instance
     double *epi_stats;      // EPI_STATS: [STAT_REP][256] accumulated with atomics (zeroed by the host per forward)
     unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
+    int dbg;                // diagnostic build only: timing ablations of k_gemm16p (1 no stores/sums, 2 no row requests/transform)
 };
 
 #ifdef MTFJSP_STAMP
@@ -84,6 +85,17 @@ __device__ __forceinline__ float fast_tanh(float x)
     return 1.0f - __fdividef(2.0f, e + 1.0f);
 }
 
+// sum over the 16 lanes of a DPP row, result in every lane: xor 1, xor 2 (quad permutes), half-row mirror, row mirror —
+// four VALU instructions with DPP operands instead of four dependent ds_bpermute round trips
+__device__ __forceinline__ float row_sum16(float x)
+{
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
+    return x;
+}
+
 __device__ __forceinline__ float bn_relu(float x, float mean, float rstd, float g, float b)
 {
     float y = (x - mean) * rstd * g + b;
@@ -96,14 +108,22 @@ __device__ __forceinline__ float bn_relu_ss(float x, float sc, float sh) { retur
 #define STAT_REP 8            // replicated BatchNorm accumulators: <=32 adders per address keeps f64 atomics at full rate
 
 // ---- shared pieces of the matrix-core kernels -----------------------------------------------------------------
-// W^T (64 KB) -> LDS with coalesced 16-byte loads; the chunk order is rotated per workgroup so that 256 CUs streaming the
-// same 64 KB do not hit the same L2 channel in lock-step.
-__device__ __forceinline__ void stage_w(float *s_w, const float *Wt, int tid)
+// Layout of every matrix kernel below (v_mfma_f32_16x16x4_f32, 16-row tiles, 8 waves per workgroup = 2 per SIMD):
+//   lane = (m = lane & 15, q = lane >> 4):  A[row m][k = 4s+q],  B[k = 4s+q][col 16c+m],  C[row 4q+i][col 16c+m], i = 0..3
+//   W^T [k][n] in LDS, XOR-swizzled (n ^ 16*(k&1)) so the B reads of lane quarters q = 0/1 fall on opposite halves of the
+//   bank row; tile row stride LDA16 = 130 words makes the A reads conflict-free
+//   load/transform mapping: lane = (j = lane & 31, h = lane >> 5) owns rows 2p+h (p = 0..7), columns 4j..4j+3
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define LDA16 130
+__device__ __forceinline__ void stage_w16(float *s_w, const float *Wt, int tid)
 {
     const float4 *src = reinterpret_cast<const float4 *>(Wt);
-    float4 *dst = reinterpret_cast<float4 *>(s_w);
 #pragma unroll
-    for (int i = 0; i < 16; i++) { const int ii = tid + ((i + blockIdx.x) & 15) * 256; dst[ii] = src[ii]; }
+    for (int i = 0; i < 8; i++) {
+        const int ii = tid + ((i + blockIdx.x) & 7) * 512;       // rotated chunk order: 256 CUs streaming the same 64 KB
+        const int k = ii >> 5, n4 = (ii & 31) * 4;                // would otherwise hit one L2 channel in lock-step
+        *reinterpret_cast<float4 *>(s_w + k * HD + (n4 ^ (16 * (k & 1)))) = src[ii];
+    }
 }
 // BatchNorm scale/shift of 128 columns from the producer's replicated f64 column sums -> s_bn[0..127] = sc, [128..255] = sh
 __device__ __forceinline__ void stage_bn(float *s_bn, const double *stats, double inv_rows, const float *gamma, const float *beta, int tid)
@@ -120,256 +140,153 @@ __device__ __forceinline__ void stage_bn(float *s_bn, const double *stats, doubl
         s_bn[HD + tid] = beta[tid] - (float)mean * sc;
     }
 }
-// one 32-row tile x W^T: 64 k-steps x 4 column blocks.  K is permuted (k = 64 h + s) so that each lane half streams its
-// own half row; tile row stride 129 words and W^T row stride 128 words make every ds_read_b32 conflict-free.
-__device__ __forceinline__ void mfma_tile(const float *my_a, const float *s_w, int j, int h, f32x16 (&acc)[4])
+// 16-row tile x W^T: 32 k-steps x 8 column blocks.  The operands of step s+1 are requested before the 8 products of step
+// s are issued (two register sets), so the LDS latency hides behind 256 cycles of matrix work.
+__device__ __forceinline__ void mfma_tile16(const float *ap, const float *bp, const int (&bo)[8], f32x4 (&acc)[8])
 {
-    const float *ap = my_a + j * LDA + 64 * h;                // A[row j][k = 64h + s]
-    const float *bp = s_w + (64 * h) * HD + j;                // B[k = 64h + s][col cb*32 + j]
-#pragma unroll 8
-    for (int s = 0; s < 64; s++) {
-        const float a = ap[s];
-        const float b0 = bp[s * HD], b1 = bp[s * HD + 32], b2 = bp[s * HD + 64], b3 = bp[s * HD + 96];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b3, acc[3], 0, 0, 0);
+    float a0 = ap[0], a1, b0[8], b1[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) b0[c] = bp[bo[c]];
+#pragma unroll 2
+    for (int s = 0; s < 32; s += 2) {
+        const float *bs1 = bp + (s + 1) * 4 * HD;
+        a1 = ap[4 * (s + 1)];
+#pragma unroll
+        for (int c = 0; c < 8; c++) b1[c] = bs1[bo[c]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[c], acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int s2 = s + 2 < 32 ? s + 2 : 0;                   // (the last request is a harmless re-read of step 0)
+        const float *bs2 = bp + s2 * 4 * HD;
+        a0 = ap[4 * s2];
+#pragma unroll
+        for (int c = 0; c < 8; c++) b0[c] = bs2[bo[c]];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[c], acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
-// accumulator register i of lane (j, h) holds C[row = CROW(i) + 4h][col = cb*32 + j]
-#define CROW(i) (((i) & 3) + 8 * ((i) >> 2))
-// per-wave f64 column sums -> one f64 atomic per column per workgroup (into one of STAT_REP replicas)
-__device__ __forceinline__ void flush_stats(double *s_red, double *epi_stats, const double (&st_sum)[4], const double (&st_sq)[4],
-                                            int tid, int wave, int j, int h)
+// per-wave f64 column sums (lane (m,q), block c) -> one f64 atomic per column per workgroup (into one of STAT_REP replicas);
+// s_red may alias the LDS tiles: the first barrier makes sure every wave is done with them
+__device__ __forceinline__ void flush_stats16(double *s_red, double *epi_stats, const double (&st_sum)[8], const double (&st_sq)[8],
+                                              int tid, int wave, int m, int q)
 {
-    for (int cb = 0; cb < 4; cb++) {
-        double a = st_sum[cb], q = st_sq[cb];
-        a += __shfl_xor(a, 32);
-        q += __shfl_xor(q, 32);
-        if (h == 0) { s_red[wave * 256 + cb * 32 + j] = a; s_red[wave * 256 + HD + cb * 32 + j] = q; }
+    __syncthreads();
+    for (int c = 0; c < 8; c++) {
+        double a = st_sum[c], b = st_sq[c];
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+        if (q == 0) { s_red[wave * 256 + c * 16 + m] = a; s_red[wave * 256 + HD + c * 16 + m] = b; }
     }
     __syncthreads();
-    const double v = s_red[tid] + s_red[256 + tid] + s_red[512 + tid] + s_red[768 + tid];
-    atomicAdd(&epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
+    if (tid < 256) {
+        double v = 0;
+        for (int w = 0; w < 8; w++) v += s_red[w * 256 + tid];
+        atomicAdd(&epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
+    }
 }
-
-template <int PRO, int EPI, bool ACC>
-__global__ __launch_bounds__(256, 1) void k_gemm128(GemmArgs A)
-{
-    extern __shared__ __align__(16) unsigned char smem[];
-    float *s_w = reinterpret_cast<float *>(smem);                 // 128*128
-    float *s_a = s_w + HD * HD;                                   // 4 * 32 * LDA
-    float *s_bn = s_a + 4 * 32 * LDA;                             // scale | shift  (2*128)
-    double *s_red = reinterpret_cast<double *>(s_bn + 4 * HD);    // 4 waves * 256
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int j = lane & 31, h = lane >> 5;
-#ifdef MTFJSP_STAMP
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
-#endif
-    stage_w(s_w, A.Wt, tid);
-#ifdef MTFJSP_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(7);
-#endif
-    if (PRO != PRO_PLAIN) stage_bn(s_bn, A.pro_stats, A.pro_inv_rows, A.pro_gamma, A.pro_beta, tid);
-    __syncthreads();
-    STAMP(0);
-    // From here on the four waves never synchronise again: each owns its LDS tile, LDS operations of one wave
-    // execute in issue order, and the waves are free to drift apart so that one wave's loads/stores overlap
-    // another's MFMA phase (they would otherwise hit HBM in lock-step bursts).
-    float *my_a = s_a + wave * 32 * LDA;
-    const int ntiles = (A.N + 31) / 32;
-    const int stride = gridDim.x * 4;
-    double st_sum[4] = {0, 0, 0, 0}, st_sq[4] = {0, 0, 0, 0};   // per column block (lane j, block cb), EPI_STATS
-    const int c4 = j * 4;
-    float sc0 = 1.f, sc1 = 1.f, sc2 = 1.f, sc3 = 1.f, sh0 = 0.f, sh1 = 0.f, sh2 = 0.f, sh3 = 0.f;
-    if (PRO != PRO_PLAIN) {
-        sc0 = s_bn[c4]; sc1 = s_bn[c4 + 1]; sc2 = s_bn[c4 + 2]; sc3 = s_bn[c4 + 3];
-        sh0 = s_bn[HD + c4]; sh1 = s_bn[HD + c4 + 1]; sh2 = s_bn[HD + c4 + 2]; sh3 = s_bn[HD + c4 + 3];
-    }
-    float bias4[4];                                               // hoisted: a load inside the epilogue would force vmcnt(0)
-    for (int cb = 0; cb < 4; cb++) bias4[cb] = (A.bias && !ACC) ? A.bias[cb * 32 + j] : 0.f;
-    const int lane_off = h * HD + c4;                             // this lane's 16 bytes of tile row h (then every second row)
-    float4 pre[16];                                               // raw rows of the NEXT tile, in flight during the MFMA phase
-    // PRO_AGG keeps the two neighbour rows of every row in flight as well, and the ELL entries one tile further ahead
-    // (the neighbour addresses of tile t+1 must be known when its rows are requested, i.e. before the MFMA phase of t).
-    constexpr int NA = (PRO == PRO_AGG) ? 16 : 1;
-    float4 nb0[NA], nb1[NA];
-    // ELL entries: lane l holds those of tile row (l & 31) as (offset of neighbour row relative to the tile's first row,
-    // weight; a missing neighbour = the row itself with weight 0) and 1/deg; row 2p+h is read with a cross-lane shuffle
-    int e_ox = 0, e_oy = 0, en_ox = 0, en_oy = 0;                  // current tile / next tile
-    float e_vx = 0.f, e_vy = 0.f, en_vx = 0.f, en_vy = 0.f;
-    double e_inv = 1.0, en_inv = 1.0;
-    auto fetch_ell = [&](int tile) __attribute__((always_inline)) {
-        const int g = tile * 32 + j;
-        int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
-        if (g < A.N) { cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
-        const int base = (g / A.T) * A.T - tile * 32;             // instance's first row relative to the tile
-        en_ox = cc.x >= 0 ? base + cc.x : j; en_vx = cc.x >= 0 ? vv.x : 0.f;
-        en_oy = cc.y >= 0 ? base + cc.y : j; en_vy = cc.y >= 0 ? vv.y : 0.f;
-        const int deg = 1 + (cc.x >= 0) + (cc.y >= 0);
-        en_inv = deg == 1 ? 1.0 : deg == 2 ? 0.5 : (1.0 / 3.0);
-    };
-    auto prefetch = [&](int tile) __attribute__((always_inline)) {
-        const float *tb = A.in + (size_t)tile * 32 * HD;          // wave-uniform
-        if (PRO == PRO_AGG) { e_ox = en_ox; e_oy = en_oy; e_vx = en_vx; e_vy = en_vy; e_inv = en_inv; }   // ELL of THIS tile (fetched one iteration earlier)
-#pragma unroll
-        for (int p = 0; p < 16; p++) {
-            pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
-            if (PRO == PRO_AGG) {
-                const int pp = p < NA ? p : 0;
-                const int ox = __shfl(e_ox, 2 * p + h), oy = __shfl(e_oy, 2 * p + h);
-                nb0[pp] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)ox * HD + c4);
-                nb1[pp] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)oy * HD + c4);
-            }
-        }
-    };
-    int tile = blockIdx.x * 4 + wave;
-    if (tile < ntiles) {
-        if (PRO == PRO_AGG) fetch_ell(tile);
-        prefetch(tile);
-        if (PRO == PRO_AGG && tile + stride < ntiles) fetch_ell(tile + stride);
-    }
-    STAMP(1);
-    for (; tile < ntiles; tile += stride) {
-        const int row0 = tile * 32;
-        // ------------------------------------------------------------------ transform the prefetched rows -> LDS tile
-#pragma unroll
-        for (int p = 0; p < 16; p++) {
-            const int r = 2 * p + h;
-            float v0 = pre[p].x, v1 = pre[p].y, v2 = pre[p].z, v3 = pre[p].w;
-            if (PRO == PRO_BNRELU) {
-                v0 = bn_relu_ss(v0, sc0, sh0); v1 = bn_relu_ss(v1, sc1, sh1); v2 = bn_relu_ss(v2, sc2, sh2); v3 = bn_relu_ss(v3, sc3, sh3);
-            } else if (PRO == PRO_AGG) {
-                // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
-                const int pp = p < NA ? p : 0;
-                const double wx = (double)__shfl(e_vx, r), wy = (double)__shfl(e_vy, r), inv = __shfl(e_inv, r);
-                const double a0 = (double)bn_relu_ss(v0, sc0, sh0) + wx * (double)bn_relu_ss(nb0[pp].x, sc0, sh0) + wy * (double)bn_relu_ss(nb1[pp].x, sc0, sh0);
-                const double a1 = (double)bn_relu_ss(v1, sc1, sh1) + wx * (double)bn_relu_ss(nb0[pp].y, sc1, sh1) + wy * (double)bn_relu_ss(nb1[pp].y, sc1, sh1);
-                const double a2 = (double)bn_relu_ss(v2, sc2, sh2) + wx * (double)bn_relu_ss(nb0[pp].z, sc2, sh2) + wy * (double)bn_relu_ss(nb1[pp].z, sc2, sh2);
-                const double a3 = (double)bn_relu_ss(v3, sc3, sh3) + wx * (double)bn_relu_ss(nb0[pp].w, sc3, sh3) + wy * (double)bn_relu_ss(nb1[pp].w, sc3, sh3);
-                v0 = (float)(a0 * inv); v1 = (float)(a1 * inv); v2 = (float)(a2 * inv); v3 = (float)(a3 * inv);
-            }
-            float *d = my_a + r * LDA + c4;
-            d[0] = v0; d[1] = v1; d[2] = v2; d[3] = v3;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // tile complete before this wave reads it back (also a compiler fence)
-        STAMP(2);
-        if (tile + stride < ntiles) {                             // asynchronous: lands while the matrix cores run
-            prefetch(tile + stride);
-            if (PRO == PRO_AGG && tile + 2 * stride < ntiles) fetch_ell(tile + 2 * stride);
-        }
-        STAMP(3);
-        // ------------------------------------------------------------------ main loop (accumulators start at the bias)
-        f32x16 acc[4];
-        float *ob = A.out + (size_t)row0 * HD + (4 * h) * HD + j;   // C[row CROW(i) + 4h][col cb*32 + j] = ob[CROW(i)*HD + cb*32]
-#pragma unroll
-        for (int cb = 0; cb < 4; cb++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[cb][i] = ACC ? ob[CROW(i) * HD + cb * 32] : bias4[cb];
-        mfma_tile(my_a, s_w, j, h, acc);
-        asm volatile("" ::: "memory");                            // keep next iteration's LDS writes behind these reads
-        STAMP(4);
-        // ------------------------------------------------------------------ epilogue: stores only (vmcnt is in-order)
-        const bool full = row0 + 32 <= A.N;
-#pragma unroll
-        for (int cb = 0; cb < 4; cb++) {
-            float ts = 0.f, tq = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; i++) {
-                float v = acc[cb][i];
-                if (EPI == EPI_TANH) v = fast_tanh(v);
-                ob[CROW(i) * HD + cb * 32] = v;
-                if (EPI == EPI_STATS) {
-                    if (!full && row0 + CROW(i) + 4 * h >= A.N) v = 0.f;
-                    ts += v; tq += v * v;
-                }
-            }
-            if (EPI == EPI_STATS) { st_sum[cb] += (double)ts; st_sq[cb] += (double)tq; }
-        }
-        STAMP(5);
-    }
-    if (EPI == EPI_STATS) flush_stats(s_red, A.epi_stats, st_sum, st_sq, tid, wave, j, h);
-#ifdef MTFJSP_STAMP
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    STAMP(6);
-    if (A.stamps && lane == 0)
-        for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
-#endif
-}
-static size_t gemm_lds_bytes() { return (size_t)(HD * HD + 4 * 32 * LDA + 4 * HD) * 4 + 4 * 256 * 8 + 4 * 32 * 8 * 4; }
 
 // ---------------------------------------------------------------------------------------------
-// k_gemm16 — the same product on 16-row tiles (v_mfma_f32_16x16x4_f32) with EIGHT waves per workgroup = two per SIMD:
-// while one wave of a SIMD is in its matrix phase its partner transforms / stores / waits for HBM, so the matrix pipe
-// stays fed.  Half-size tiles also halve the round-robin tail, and tiles are handed out dynamically inside a CU (LDS
-// counter), so each CU's waves finish together.  W^T is kept XOR-swizzled (column ^ 16*(k&1)) so that the B-operand
-// ds_read_b32 of lane quarters k = 4s+q, q = 0/1 fall on opposite halves of the bank row; tile row stride 130 words makes
-// the A-operand reads conflict-free.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define LDA16 130
-template <int PRO, int EPI, bool ACC>
-__global__ __launch_bounds__(512) void k_gemm16(GemmArgs A, int stagger)
+// k_gemm16 — plain [N,128] x [128,128] (+bias, optional tanh, optional accumulate into `out`) for the small critic-head
+// products: load tile -> LDS -> 256 products -> store.  Not pipelined; the GIN encoder uses k_gemm16p below.
+template <int EPI, bool ACC>
+__global__ __launch_bounds__(512) void k_gemm16(GemmArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_w = reinterpret_cast<float *>(smem);                 // 128*128, swizzled
+    float *s_a = s_w + HD * HD;                                   // 8 * 16 * LDA16
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5, c4 = j * 4;
+    const int m = lane & 15, q = lane >> 4, qo = q & 1;
+    stage_w16(s_w, A.Wt, tid);
+    __syncthreads();
+    float *my_a = s_a + wave * 16 * LDA16;
+    const int ntiles = (A.N + 15) / 16;
+    float bias8[8];
+    for (int c = 0; c < 8; c++) bias8[c] = (A.bias && !ACC) ? A.bias[c * 16 + m] : 0.f;
+    const float *ap = my_a + m * LDA16 + q;
+    const float *bp = s_w + q * HD + m;
+    int bo[8];
+    for (int c = 0; c < 8; c++) bo[c] = (c ^ qo) * 16;
+    for (int tile = blockIdx.x * 8 + wave; tile < ntiles; tile += gridDim.x * 8) {
+        const float *tb = A.in + (size_t)tile * 16 * HD + h * HD + c4;
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const float4 x = *reinterpret_cast<const float4 *>(tb + p * 2 * HD);
+            float *d = my_a + (2 * p + h) * LDA16 + c4;
+            *reinterpret_cast<float2 *>(d) = make_float2(x.x, x.y);
+            *reinterpret_cast<float2 *>(d + 2) = make_float2(x.z, x.w);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        f32x4 acc[8];
+        float *ob = A.out + (size_t)tile * 16 * HD + (4 * q) * HD + m;
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc[c][i] = ACC ? ob[i * HD + c * 16] : bias8[c];
+        mfma_tile16(ap, bp, bo, acc);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) ob[i * HD + c * 16] = EPI == EPI_TANH ? fast_tanh(acc[c][i]) : acc[c][i];
+    }
+}
+static size_t gemm16_lds_bytes() { return (size_t)(HD * HD + 8 * 16 * LDA16 + 2 * HD) * 4 + 64 + 8 * 16 * 8 * 4; }
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm16p — the GIN-encoder product as ONE matrix-dense instruction stream per wave (16-row tiles, 8 waves per CU).
+// Measured on k_gemm16: a wave alone on its SIMD reaches ~70 % of the f32 matrix rate, two waves multiplying at the same
+// time saturate the pipe, and two free-running waves fall into lock-step — so whatever a wave does outside its matrix
+// phase is time the pipe idles.  Here nothing is outside: while the 256 products of tile t are issued, the same wave
+//     k-steps  0.. 7 : stores tile t-1 (previous accumulator set) and adds its BatchNorm column sums,
+//     k-step   8     : requests the rows of tile t+1 (and, PRO_AGG, its neighbour rows; ELL entries one tile ahead),
+//     k-step  16     : draws the next tile index from the CU's LDS counter,
+//     k-steps 24..31 : BatchNorm+ReLU / neighbour aggregation of tile t+1 in registers,
+// and only the 16 ds_write_b64 that put tile t+1 into the LDS tile (free once tile t's products are issued) are exposed.
+// vmcnt counts loads and stores together and any wait drains both, hence stores first, loads 8 k-steps later, first use
+// another 16 k-steps later.  Both waves of a SIMD run this stream, so the pipe always has two takers.
+template <int PRO>
+__global__ __launch_bounds__(512) void k_gemm16p(GemmArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float *s_w = reinterpret_cast<float *>(smem);                 // 128*128, swizzled
     float *s_a = s_w + HD * HD;                                   // 8 * 16 * LDA16
     float *s_bn = s_a + 8 * 16 * LDA16;                           // scale | shift
-    int *s_ctr = reinterpret_cast<int *>(s_bn + 2 * HD);          // [0] tile counter, [1..4] matrix-pipe token of each SIMD pair
-    double *s_red = reinterpret_cast<double *>(s_a);              // reused after the last tile (8 waves * 256 doubles = 16 KB)
+    int *s_ctr = reinterpret_cast<int *>(s_bn + 2 * HD);
+    double *s_red = reinterpret_cast<double *>(s_a);              // reused after the last tile
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 31, h = lane >> 5, c4 = j * 4;           // load / transform mapping: rows 2p+h, 4 columns
     const int m = lane & 15, q = lane >> 4, qo = q & 1;           // matrix mapping: A[row m][k = 4s+q], B[k][col 16c+m], C[row 4q+i][col 16c+m]
 #ifdef MTFJSP_STAMP
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last, rt0, rt1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+    const unsigned long long t_first = t_last;
 #endif
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(A.Wt);
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int ii = tid + ((i + blockIdx.x) & 7) * 512;   // rotated chunk order (L2 channel de-phasing)
-            const int k = ii >> 5, n4 = (ii & 31) * 4;
-            *reinterpret_cast<float4 *>(s_w + k * HD + (n4 ^ (16 * (k & 1)))) = src[ii];
-        }
-    }
-    if (PRO != PRO_PLAIN) stage_bn(s_bn, A.pro_stats, A.pro_inv_rows, A.pro_gamma, A.pro_beta, tid);
-    if (tid == 0) *s_ctr = 8;
-    if (tid >= 1 && tid <= 4) s_ctr[tid] = 0;
+    stage_w16(s_w, A.Wt, tid);
+    stage_bn(s_bn, A.pro_stats, A.pro_inv_rows, A.pro_gamma, A.pro_beta, tid);
     __syncthreads();
     STAMP(0);
-    // Waves w and w+4 of a workgroup sit on the same SIMD and share its matrix pipe.  Left alone they fall into
-    // lock-step (both in the matrix phase at half rate, then both outside it with the pipe idle), so the matrix phase
-    // is made exclusive per SIMD pair with a token in LDS: one wave multiplies at full rate while its partner
-    // transforms, stores and waits for HBM, then they swap.
-    int *tok = s_ctr + 1 + (wave & 3);
     float *my_a = s_a + wave * 16 * LDA16;
     const int ntiles = (A.N + 15) / 16;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
     const int first = blockIdx.x * per;
     const int last = first + per < ntiles ? first + per : ntiles;
-    auto grab = [&]() __attribute__((always_inline)) {
-        int t = 0;
-        if (lane == 0) t = atomicAdd(s_ctr, 1);
-        return first + __builtin_amdgcn_readfirstlane(t);
-    };
     double st_sum[8], st_sq[8];
     for (int c = 0; c < 8; c++) { st_sum[c] = 0; st_sq[c] = 0; }
-    float sc0 = 1.f, sc1 = 1.f, sc2 = 1.f, sc3 = 1.f, sh0 = 0.f, sh1 = 0.f, sh2 = 0.f, sh3 = 0.f;
-    if (PRO != PRO_PLAIN) {
-        sc0 = s_bn[c4]; sc1 = s_bn[c4 + 1]; sc2 = s_bn[c4 + 2]; sc3 = s_bn[c4 + 3];
-        sh0 = s_bn[HD + c4]; sh1 = s_bn[HD + c4 + 1]; sh2 = s_bn[HD + c4 + 2]; sh3 = s_bn[HD + c4 + 3];
-    }
+    const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
+    const float sh0 = s_bn[HD + c4], sh1 = s_bn[HD + c4 + 1], sh2 = s_bn[HD + c4 + 2], sh3 = s_bn[HD + c4 + 3];
     float bias8[8];
-    for (int c = 0; c < 8; c++) bias8[c] = (A.bias && !ACC) ? A.bias[c * 16 + m] : 0.f;
+    for (int c = 0; c < 8; c++) bias8[c] = A.bias ? A.bias[c * 16 + m] : 0.f;
     const int lane_off = h * HD + c4;
     float4 pre[8];
     constexpr int NA = (PRO == PRO_AGG) ? 8 : 1;
     float4 nb0[NA], nb1[NA];
-    // ELL entries of a tile: lane l < 16 (and its copies l+16, ...) holds those of tile row (l & 15)
     int e_ox = 0, e_oy = 0, en_ox = 0, en_oy = 0;
-    float e_vx = 0.f, e_vy = 0.f, en_vx = 0.f, en_vy = 0.f, e_inv = 1.f, en_inv = 1.f;
+    float e_vx = 0.f, e_vy = 0.f, en_vx = 0.f, en_vy = 0.f, e_dg = 1.f, en_dg = 1.f;
     auto fetch_ell = [&](int tile) __attribute__((always_inline)) {
         const int g = tile * 16 + m;
         int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
@@ -377,11 +294,11 @@ __global__ __launch_bounds__(512) void k_gemm16(GemmArgs A, int stagger)
         const int base = (g / A.T) * A.T - tile * 16;             // instance's first row relative to the tile
         en_ox = cc.x >= 0 ? base + cc.x : m; en_vx = cc.x >= 0 ? vv.x : 0.f;
         en_oy = cc.y >= 0 ? base + cc.y : m; en_vy = cc.y >= 0 ? vv.y : 0.f;
-        en_inv = (float)(1 + (cc.x >= 0) + (cc.y >= 0));          // degree; its reciprocal is taken in f64 at the use
+        en_dg = (float)(1 + (cc.x >= 0) + (cc.y >= 0));
     };
     auto prefetch = [&](int tile) __attribute__((always_inline)) {
         const float *tb = A.in + (size_t)tile * 16 * HD;          // wave-uniform
-        if (PRO == PRO_AGG) { e_ox = en_ox; e_oy = en_oy; e_vx = en_vx; e_vy = en_vy; e_inv = en_inv; }
+        if (PRO == PRO_AGG) { e_ox = en_ox; e_oy = en_oy; e_vx = en_vx; e_vy = en_vy; e_dg = en_dg; }
 #pragma unroll
         for (int p = 0; p < 8; p++) {
             pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
@@ -393,46 +310,62 @@ __global__ __launch_bounds__(512) void k_gemm16(GemmArgs A, int stagger)
             }
         }
     };
-    // Tile pipeline of one wave (vmcnt counts loads and stores together and the compiler must assume they complete out
-    // of order, so any wait for a load drains every store issued before it — the order below keeps a whole matrix phase
-    // between a tile's stores and the next wait):
-    //     matrix phase(t) -> transform(t+1) into the LDS tile -> request rows(t+2) -> store results(t)
-    auto transform = [&]() __attribute__((always_inline)) {
+    // rows 2p+h of the requested tile: raw -> BatchNorm+ReLU (-> neighbour aggregation), in place in pre[p]
+    auto transform_rows = [&](int p) __attribute__((always_inline)) {
+        float v0 = pre[p].x, v1 = pre[p].y, v2 = pre[p].z, v3 = pre[p].w;
+        if (PRO == PRO_BNRELU) {
+            v0 = bn_relu_ss(v0, sc0, sh0); v1 = bn_relu_ss(v1, sc1, sh1); v2 = bn_relu_ss(v2, sc2, sh2); v3 = bn_relu_ss(v3, sc3, sh3);
+        } else {
+            // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
+            const int pp = p < NA ? p : 0;
+            const int r = 2 * p + h;
+            const double wx = (double)__shfl(e_vx, r), wy = (double)__shfl(e_vy, r);
+            const float dg = __shfl(e_dg, r);
+            const double inv = dg == 1.f ? 1.0 : dg == 2.f ? 0.5 : (1.0 / 3.0);
+            const double a0 = (double)bn_relu_ss(v0, sc0, sh0) + wx * (double)bn_relu_ss(nb0[pp].x, sc0, sh0) + wy * (double)bn_relu_ss(nb1[pp].x, sc0, sh0);
+            const double a1 = (double)bn_relu_ss(v1, sc1, sh1) + wx * (double)bn_relu_ss(nb0[pp].y, sc1, sh1) + wy * (double)bn_relu_ss(nb1[pp].y, sc1, sh1);
+            const double a2 = (double)bn_relu_ss(v2, sc2, sh2) + wx * (double)bn_relu_ss(nb0[pp].z, sc2, sh2) + wy * (double)bn_relu_ss(nb1[pp].z, sc2, sh2);
+            const double a3 = (double)bn_relu_ss(v3, sc3, sh3) + wx * (double)bn_relu_ss(nb0[pp].w, sc3, sh3) + wy * (double)bn_relu_ss(nb1[pp].w, sc3, sh3);
+            v0 = (float)(a0 * inv); v1 = (float)(a1 * inv); v2 = (float)(a2 * inv); v3 = (float)(a3 * inv);
+        }
+        pre[p] = make_float4(v0, v1, v2, v3);
+    };
+    auto tile_to_lds = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int p = 0; p < 8; p++) {
-            const int r = 2 * p + h;
-            float v0 = pre[p].x, v1 = pre[p].y, v2 = pre[p].z, v3 = pre[p].w;
-            if (PRO == PRO_BNRELU) {
-                v0 = bn_relu_ss(v0, sc0, sh0); v1 = bn_relu_ss(v1, sc1, sh1); v2 = bn_relu_ss(v2, sc2, sh2); v3 = bn_relu_ss(v3, sc3, sh3);
-            } else if (PRO == PRO_AGG) {
-                // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
-                const int pp = p < NA ? p : 0;
-                const double wx = (double)__shfl(e_vx, r), wy = (double)__shfl(e_vy, r);
-                const float dg = __shfl(e_inv, r);
-                const double inv = dg == 1.f ? 1.0 : dg == 2.f ? 0.5 : (1.0 / 3.0);
-                const double a0 = (double)bn_relu_ss(v0, sc0, sh0) + wx * (double)bn_relu_ss(nb0[pp].x, sc0, sh0) + wy * (double)bn_relu_ss(nb1[pp].x, sc0, sh0);
-                const double a1 = (double)bn_relu_ss(v1, sc1, sh1) + wx * (double)bn_relu_ss(nb0[pp].y, sc1, sh1) + wy * (double)bn_relu_ss(nb1[pp].y, sc1, sh1);
-                const double a2 = (double)bn_relu_ss(v2, sc2, sh2) + wx * (double)bn_relu_ss(nb0[pp].z, sc2, sh2) + wy * (double)bn_relu_ss(nb1[pp].z, sc2, sh2);
-                const double a3 = (double)bn_relu_ss(v3, sc3, sh3) + wx * (double)bn_relu_ss(nb0[pp].w, sc3, sh3) + wy * (double)bn_relu_ss(nb1[pp].w, sc3, sh3);
-                v0 = (float)(a0 * inv); v1 = (float)(a1 * inv); v2 = (float)(a2 * inv); v3 = (float)(a3 * inv);
-            }
-            float *d = my_a + r * LDA16 + c4;
-            *reinterpret_cast<float2 *>(d) = make_float2(v0, v1);
-            *reinterpret_cast<float2 *>(d + 2) = make_float2(v2, v3);
+            float *d = my_a + (2 * p + h) * LDA16 + c4;
+            *reinterpret_cast<float2 *>(d) = make_float2(pre[p].x, pre[p].y);
+            *reinterpret_cast<float2 *>(d + 2) = make_float2(pre[p].z, pre[p].w);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
-    // tile queue: t_cur (in the LDS tile), t_n1 (rows in registers), t_n2 (ELL entries in registers, PRO_AGG only)
-    int t_cur = first + wave, t_n1 = grab(), t_n2 = (PRO == PRO_AGG) ? grab() : 0;
+    // previous tile: its accumulators, first output row, output pointer
+    f32x4 acc[8], accp[8];
+    float *obp = A.out;
+    int rowp = 0;
+    bool have_prev = false;
+    auto store_prev = [&](int c) __attribute__((always_inline)) {   // column block c of the previous tile: 4 rows per lane
+        float ts = 0.f, tq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float v = accp[c][i];
+            obp[i * HD + c * 16] = v;
+            v = (rowp + 4 * q + i < A.N) ? v : 0.f;
+            ts += v; tq += v * v;
+        }
+        st_sum[c] += (double)ts; st_sq[c] += (double)tq;
+    };
+    // tile queue: t_cur (in the LDS tile), t_n1 (next; its ELL entries in en_* for PRO_AGG), t_new (drawn mid-tile)
+    // static round-robin inside the CU's contiguous range (waves w and w+4 share a SIMD: a remainder of <= 4 tiles lands on
+    // four different SIMDs)
+    int t_cur = first + wave, t_n1 = t_cur + 8;
     if (t_cur < last) {
         if (PRO == PRO_AGG) fetch_ell(t_cur);
         prefetch(t_cur);
         if (PRO == PRO_AGG && t_n1 < last) fetch_ell(t_n1);
-        transform();
-        if (t_n1 < last) {
-            prefetch(t_n1);
-            if (PRO == PRO_AGG && t_n2 < last) fetch_ell(t_n2);
-        }
+#pragma unroll
+        for (int p = 0; p < 8; p++) transform_rows(p);
+        tile_to_lds();
     }
     STAMP(1);
     const float *ap = my_a + m * LDA16 + q;
@@ -441,233 +374,188 @@ __global__ __launch_bounds__(512) void k_gemm16(GemmArgs A, int stagger)
     for (int c = 0; c < 8; c++) bo[c] = (c ^ qo) * 16;
     while (t_cur < last) {
         const int row0 = t_cur * 16;
-        // ------------------------------------------------------------------ matrix phase
-        f32x4 acc[8];
         float *ob = A.out + (size_t)row0 * HD + (4 * q) * HD + m;   // C[row 4q+i][col 16c+m] = ob[i*HD + 16c]
+#ifdef MTFJSP_STAMP
+        const bool have_next = t_n1 < last && !(A.dbg & 2);
+        if (A.dbg & 1) have_prev = false;
+#else
+        const bool have_next = t_n1 < last;
+#endif
+        const int t_new = t_n1 + 8;
 #pragma unroll
         for (int c = 0; c < 8; c++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) acc[c][i] = ACC ? ob[i * HD + c * 16] : bias8[c];
-        if (stagger) {
-            if (lane == 0) while (atomicCAS(tok, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
-            asm volatile("" ::: "memory");
-        }
-        STAMP(3);
-        // operands of k-step s+1 are requested before the 8 products of step s are issued (two register sets), so the
-        // ~100-cycle LDS latency hides behind 256 cycles of matrix work instead of stalling every other product
-        {
-            float a0 = ap[0], a1, b0[8], b1[8];
+            for (int i = 0; i < 4; i++) acc[c][i] = bias8[c];
+        float av[2], bv[2][8];
+        av[0] = ap[0];
 #pragma unroll
-            for (int c = 0; c < 8; c++) b0[c] = bp[bo[c]];
-#pragma unroll 2
-            for (int s = 0; s < 32; s += 2) {
-                const float *bs1 = bp + (s + 1) * 4 * HD;
-                a1 = ap[4 * (s + 1)];
+        for (int c = 0; c < 8; c++) bv[0][c] = bp[bo[c]];
 #pragma unroll
-                for (int c = 0; c < 8; c++) b1[c] = bs1[bo[c]];
-                __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < 32; s++) {
+            // operands of k-step s+1 (the last request is a harmless re-read of step 0)
+            const int sn = s + 1 < 32 ? s + 1 : 0;
+            av[(s + 1) & 1] = ap[4 * sn];
 #pragma unroll
-                for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0[c], acc[c], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                const int s2 = s + 2 < 32 ? s + 2 : 0;             // (the last request is a harmless re-read of step 0)
-                const float *bs2 = bp + s2 * 4 * HD;
-                a0 = ap[4 * s2];
-#pragma unroll
-                for (int c = 0; c < 8; c++) b0[c] = bs2[bo[c]];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[c], acc[c], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int c = 0; c < 8; c++) bv[(s + 1) & 1][c] = bp[sn * 4 * HD + bo[c]];
+            // side work of this k-step
+            if (s < 8) { if (have_prev) store_prev(s); }
+            if (s == 8 && have_next) {
+                prefetch(t_n1);
+                if (PRO == PRO_AGG && t_new < last) fetch_ell(t_new);
             }
+            if (s >= 24 && have_next) transform_rows(s - 24);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1], bv[s & 1][c], acc[c], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("" ::: "memory");
-        if (stagger) { if (lane == 0) atomicExch(tok, 0); }
-        STAMP(4);
-        // ------------------------------------------------------------------ results: column sums from the accumulators,
-        // then transposed through the (now free) LDS tile into row-major 16-byte pieces — dword stores (one column per
-        // lane) are issue-bound in the memory pipeline at 1/4 of the bytes per cycle of dwordx4 stores
-        const bool full = row0 + 16 <= A.N;
+        if (have_next) tile_to_lds();
 #pragma unroll
-        for (int c = 0; c < 8; c++) {
-            float ts = 0.f, tq = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float v = acc[c][i];
-                if (EPI == EPI_TANH) v = fast_tanh(v);
-                my_a[(4 * q + i) * LDA16 + c * 16 + m] = v;
-                if (EPI == EPI_STATS) {
-                    if (!full && row0 + 4 * q + i >= A.N) v = 0.f;
-                    ts += v; tq += v * v;
-                }
-            }
-            if (EPI == EPI_STATS) { st_sum[c] += (double)ts; st_sq[c] += (double)tq; }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        float4 res[8];
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const float *d = my_a + (2 * p + h) * LDA16 + c4;
-            const float2 lo = *reinterpret_cast<const float2 *>(d), hi = *reinterpret_cast<const float2 *>(d + 2);
-            res[p] = make_float4(lo.x, lo.y, hi.x, hi.y);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        STAMP(5);
+        for (int c = 0; c < 8; c++) accp[c] = acc[c];
+        obp = ob; rowp = row0; have_prev = true;
 #ifdef MTFJSP_STAMP
         ph[7] += 1;
 #endif
-        // ------------------------------------------------------------------ next tile -> LDS, the one after -> in flight
-        const int t_n3 = grab();
-        if (t_n1 < last) {
-            transform();
-            const int t_pf = (PRO == PRO_AGG) ? t_n2 : t_n3;
-            if (t_pf < last) {
-                prefetch(t_pf);
-                if (PRO == PRO_AGG && t_n3 < last) fetch_ell(t_n3);
-            }
-            STAMP(2);
-        }
-        {
-            float *orow = A.out + (size_t)row0 * HD + lane_off;
+        t_cur = t_n1; t_n1 = t_new;
+    }
+    STAMP(4);
+    if (have_prev)
 #pragma unroll
-            for (int p = 0; p < 8; p++) *reinterpret_cast<float4 *>(orow + p * 2 * HD) = res[p];
-        }
-        STAMP(5);
-        t_cur = t_n1;
-        if (PRO == PRO_AGG) { t_n1 = t_n2; t_n2 = t_n3; } else t_n1 = t_n3;
-    }
-    if (EPI == EPI_STATS) {
-        __syncthreads();                                          // every wave is done with its tile: s_red aliases them
-        for (int c = 0; c < 8; c++) {
-            double a = st_sum[c], b = st_sq[c];
-            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-            b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-            if (q == 0) { s_red[wave * 256 + c * 16 + m] = a; s_red[wave * 256 + HD + c * 16 + m] = b; }
-        }
-        __syncthreads();
-        if (tid < 256) {
-            double v = 0;
-            for (int w = 0; w < 8; w++) v += s_red[w * 256 + tid];
-            atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
-        }
-    }
+        for (int c = 0; c < 8; c++) store_prev(c);
+    flush_stats16(s_red, A.epi_stats, st_sum, st_sq, tid, wave, m, q);
 #ifdef MTFJSP_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(6);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+    ph[2] = t_last - t_first; ph[3] = rt1 - rt0;                  // whole kernel: shader ticks | 100 MHz ticks
     if (A.stamps && lane == 0)
         for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
 #endif
 }
-static size_t gemm16_lds_bytes() { return (size_t)(HD * HD + 8 * 16 * LDA16 + 2 * HD) * 4 + 64; }
 
 // ---------------------------------------------------------------------------------------------
 // Machine path of the machine actor / global critic (ac:383-434, gat:82-159) in ONE launch.  The three applications of
-// the single shared GATLayer on the fixed 2-node graph [[1,1],[0,1]] couple only rows (2q, 2q+1) = (node 0, node 1) of
-// machine q, which lie in the same 32-row tile, so a wave keeps its tile in LDS across all three passes:
-//   rows   : node 0 = m_fea_1_fcl(m_fea1[q]) (6 -> 128), node 1 = m_fea_2_fcl(m_fea2[q]) (8 -> 128), no bias (ac:383-384)
-//   pass   : z = rows x W (MFMA);  e0j = LeakyReLU_0.2(a_src.z0 + a_dst.zj);  (al0, al1) = softmax(e00, e01);
+// the single shared GATLayer on the fixed 2-node graph [[1,1],[0,1]] couple only rows (2u, 2u+1) = (node 0, node 1) of
+// machine u, which lie in the same 16-row tile, so a wave keeps its tile in LDS across all three passes:
+//   rows   : node 0 = m_fea_1_fcl(m_fea1[u]) (6 -> 128), node 1 = m_fea_2_fcl(m_fea2[u]) (8 -> 128), no bias (ac:383-384)
+//   pass   : z = rows x W (matrix cores);  e0v = LeakyReLU_0.2(a_src.z0 + a_dst.zv);  (al0, al1) = softmax(e00, e01);
 //            n0' = al0 z0 + al1 z1 ; n1' = z1 ;  ELU after passes 1 and 2, written back into the LDS tile (ac:409-413)
-//   end    : mean of the two nodes (ac:420) -> node[q] and the column sums of the BatchNorm that follows (ac:434)
-// W^T is staged once and no intermediate ever leaves the CU.
+//   end    : mean of the two nodes (ac:420) -> node[u] and the column sums of the BatchNorm that follows (ac:434)
+// W^T is staged once and no intermediate ever leaves the CU.  In the C layout accumulator registers (0,1) and (2,3) of a
+// lane are (z0, z1) of machines 2q and 2q+1 of the tile, and the 128-column dot products reduce over the 16 lanes of a
+// DPP row.
 struct GatArgs {
-    int R;                  // machines rows = B*M ; tile rows = 2R
+    int R;                  // machine rows = B*M ; tile rows = 2R
     const void *f1, *f2;    // m_fea1 [R,6], m_fea2 [R,8] (obs dtype)
     int feat_f64;
     const float *W1, *W2;   // m_fea_1_fcl.weight [128,6], m_fea_2_fcl.weight [128,8]
     const float *Wt;        // gat_layer.W [in,out]
     const float *gat_a;     // [256] a_src | a_dst (gat:68-79)
-    float *node;            // [R,128] (padded to 16-row multiples) pre-BatchNorm node mean
+    float *node;            // [R,128] (padded) pre-BatchNorm node mean
     double *epi_stats;
     unsigned long long *stamps;
 };
-__global__ __launch_bounds__(256, 1) void k_gat3(GatArgs A)
+__global__ __launch_bounds__(512) void k_gat3(GatArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    float *s_w = reinterpret_cast<float *>(smem);                 // 128*128
-    float *s_a = s_w + HD * HD;                                   // 4 * 32 * LDA
-    float *s_bn = s_a + 4 * 32 * LDA;
-    double *s_red = reinterpret_cast<double *>(s_bn + 4 * HD);    // 4 waves * 256
-    float *s_feat = reinterpret_cast<float *>(s_red + 4 * 256);   // 4 waves * 32 rows * 8
+    float *s_w = reinterpret_cast<float *>(smem);                 // 128*128, swizzled
+    float *s_a = s_w + HD * HD;                                   // 8 * 16 * LDA16
+    float *s_bn = s_a + 8 * 16 * LDA16;
+    int *s_ctr = reinterpret_cast<int *>(s_bn + 2 * HD);
+    float *s_feat = reinterpret_cast<float *>(s_ctr + 16);        // 8 waves * 16 rows * 8
+    double *s_red = reinterpret_cast<double *>(s_a);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int j = lane & 31, h = lane >> 5;
+    const int j = lane & 31, h = lane >> 5, c4 = j * 4;
+    const int m = lane & 15, q = lane >> 4, qo = q & 1;
 #ifdef MTFJSP_STAMP
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
 #endif
-    stage_w(s_w, A.Wt, tid);
+    stage_w16(s_w, A.Wt, tid);
     __syncthreads();
     STAMP(0);
-    float *my_a = s_a + wave * 32 * LDA;
-    float *my_f = s_feat + wave * 256;
+    float *my_a = s_a + wave * 16 * LDA16;
+    float *my_f = s_feat + wave * 128;
     const int N = 2 * A.R;
-    const int ntiles = (N + 31) / 32;
-    const int stride = gridDim.x * 4;
-    double st_sum[4] = {0, 0, 0, 0}, st_sq[4] = {0, 0, 0, 0};
-    const int c4 = j * 4;
+    const int ntiles = (N + 15) / 16;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int first = blockIdx.x * per;
+    const int last = first + per < ntiles ? first + per : ntiles;
+    double st_sum[8], st_sq[8];
+    for (int c = 0; c < 8; c++) { st_sum[c] = 0; st_sq[c] = 0; }
     float wf[4][8];                                               // this lane's 4 output columns of W1 (h = 0) or W2 (h = 1)
-    for (int q = 0; q < 4; q++)
-        for (int k = 0; k < 8; k++) wf[q][k] = h == 0 ? (k < 6 ? A.W1[(c4 + q) * 6 + k] : 0.f) : A.W2[(c4 + q) * 8 + k];
-    float asrc[4], adst[4];
-    for (int cb = 0; cb < 4; cb++) { asrc[cb] = A.gat_a[cb * 32 + j]; adst[cb] = A.gat_a[HD + cb * 32 + j]; }
-    // lane L fetches 4 of the 256 feature words of a tile: row L/2 = (machine, node), words 4*(L&1)..+3
+    for (int x = 0; x < 4; x++)
+        for (int k = 0; k < 8; k++) wf[x][k] = h == 0 ? (k < 6 ? A.W1[(c4 + x) * 6 + k] : 0.f) : A.W2[(c4 + x) * 8 + k];
+    float asrc[8], adst[8];
+    for (int c = 0; c < 8; c++) { asrc[c] = A.gat_a[c * 16 + m]; adst[c] = A.gat_a[HD + c * 16 + m]; }
+    // lane L < 32 fetches 4 of the 128 feature words of a tile: row L/2 = (machine, node), words 4*(L&1)..+3
     auto fetch_feat = [&](int tile) __attribute__((always_inline)) -> float4 {
-        const int r = tile * 32 + (lane >> 1), k0 = (lane & 1) * 4;
+        const int r = tile * 16 + (lane >> 1), k0 = (lane & 1) * 4;
         float x[4] = {0.f, 0.f, 0.f, 0.f};
-        if (r < N) {
-            const int q = r >> 1, node = r & 1, width = node ? 8 : 6;
+        if (lane < 32 && r < N) {
+            const int u = r >> 1, node = r & 1, width = node ? 8 : 6;
             for (int k = 0; k < 4; k++)
                 if (k0 + k < width) {
-                    const size_t idx = (size_t)q * width + k0 + k;
+                    const size_t idx = (size_t)u * width + k0 + k;
                     x[k] = A.feat_f64 ? (float)reinterpret_cast<const double *>(node ? A.f2 : A.f1)[idx]
                                       : reinterpret_cast<const float *>(node ? A.f2 : A.f1)[idx];
                 }
         }
         return make_float4(x[0], x[1], x[2], x[3]);
     };
-    int tile = blockIdx.x * 4 + wave;
+    // static round-robin inside the CU's contiguous range: waves w and w+4 share a SIMD, so a remainder of <= 4 tiles
+    // lands on four different SIMDs
+    int t_cur = first + wave, t_n1 = t_cur + 8;
     float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (tile < ntiles) fpre = fetch_feat(tile);
+    if (t_cur < last) fpre = fetch_feat(t_cur);
+    const float *ap = my_a + m * LDA16 + q;
+    const float *bp = s_w + q * HD + m;
+    int bo[8];
+    for (int c = 0; c < 8; c++) bo[c] = (c ^ qo) * 16;
     STAMP(1);
-    for (; tile < ntiles; tile += stride) {
-        const int row0 = tile * 32;
-        // ---- input rows: row r of the tile is node (r & 1) of machine (row0 + r) / 2; tile rows 2p+h have node = h
-        *reinterpret_cast<float4 *>(my_f + lane * 4) = fpre;
+    while (t_cur < last) {
+        const int row0 = t_cur * 16;
+        // ---- input rows: tile rows 2p+h are node h of machine (row0/2 + p)
+        if (lane < 32) *reinterpret_cast<float4 *>(my_f + lane * 4) = fpre;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int p = 0; p < 16; p++) {
+        for (int p = 0; p < 8; p++) {
             const int r = 2 * p + h;
             const float4 fa = *reinterpret_cast<const float4 *>(my_f + r * 8), fb = *reinterpret_cast<const float4 *>(my_f + r * 8 + 4);
             const float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
-            float *d = my_a + r * LDA + c4;
+            float o[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int x = 0; x < 4; x++) {
                 float a = 0.f;
 #pragma unroll
-                for (int k = 0; k < 8; k++) a = fmaf(ff[k], wf[q][k], a);
-                d[q] = a;
+                for (int k = 0; k < 8; k++) a = fmaf(ff[k], wf[x][k], a);
+                o[x] = a;
             }
+            float *d = my_a + r * LDA16 + c4;
+            *reinterpret_cast<float2 *>(d) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2 *>(d + 2) = make_float2(o[2], o[3]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (tile + stride < ntiles) fpre = fetch_feat(tile + stride);
+        if (t_n1 < last) fpre = fetch_feat(t_n1);
         STAMP(2);
-        const bool full = row0 + 32 <= N;
 #pragma unroll 1
         for (int pass = 0; pass < 3; pass++) {
-            f32x16 acc[4];
+            f32x4 acc[8];
 #pragma unroll
-            for (int cb = 0; cb < 4; cb++)
+            for (int c = 0; c < 8; c++)
 #pragma unroll
-                for (int i = 0; i < 16; i++) acc[cb][i] = 0.f;
-            mfma_tile(my_a, s_w, j, h, acc);
+                for (int i = 0; i < 4; i++) acc[c][i] = 0.f;
+            mfma_tile16(ap, bp, bo, acc);
             asm volatile("" ::: "memory");
             STAMP(3);
-            // accumulator registers (i, i+1), i even, are z0, z1 of ONE machine (tile rows CROW(i)+4h, +1)
 #pragma unroll
-            for (int ip = 0; ip < 8; ip++) {
-                const int i = 2 * ip;
+            for (int u = 0; u < 2; u++) {                                     // the lane's two machines: tile rows 4q+2u (node 0), +1 (node 1)
+                const int i = 2 * u;
                 float s0 = 0.f, d0 = 0.f, d1 = 0.f;
 #pragma unroll
-                for (int cb = 0; cb < 4; cb++) { const float z0 = acc[cb][i], z1 = acc[cb][i + 1]; s0 += asrc[cb] * z0; d0 += adst[cb] * z0; d1 += adst[cb] * z1; }
-                for (int o = 16; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); d0 += __shfl_xor(d0, o); d1 += __shfl_xor(d1, o); }
+                for (int c = 0; c < 8; c++) { const float z0 = acc[c][i], z1 = acc[c][i + 1]; s0 += asrc[c] * z0; d0 += adst[c] * z0; d1 += adst[c] * z1; }
+                s0 = row_sum16(s0); d0 = row_sum16(d0); d1 = row_sum16(d1);
                 float e00 = s0 + d0, e01 = s0 + d1;
                 e00 = e00 > 0.f ? e00 : 0.2f * e00;
                 e01 = e01 > 0.f ? e01 : 0.2f * e01;
@@ -675,40 +563,41 @@ __global__ __launch_bounds__(256, 1) void k_gat3(GatArgs A)
                 const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
                 const float inv = 1.0f / (x0 + x1);
                 const float al0 = x0 * inv, al1 = x1 * inv;
-                const int r = CROW(i) + 4 * h;                                // even tile row: node 0 of its machine
+                const int r = 4 * q + i;
                 if (pass < 2) {
 #pragma unroll
-                    for (int cb = 0; cb < 4; cb++) {
-                        const float z0 = acc[cb][i], z1 = acc[cb][i + 1];
+                    for (int c = 0; c < 8; c++) {
+                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
                         float n0 = al0 * z0 + al1 * z1, n1 = z1;
                         n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;               // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
                         n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
-                        my_a[r * LDA + cb * 32 + j] = n0;
-                        my_a[(r + 1) * LDA + cb * 32 + j] = n1;
+                        my_a[r * LDA16 + c * 16 + m] = n0;
+                        my_a[(r + 1) * LDA16 + c * 16 + m] = n1;
                     }
                 } else {
-                    const bool valid = full || row0 + r < N;
-                    float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + j;
+                    const bool valid = row0 + r < N;
+                    float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + m;
 #pragma unroll
-                    for (int cb = 0; cb < 4; cb++) {
-                        const float z0 = acc[cb][i], z1 = acc[cb][i + 1];
+                    for (int c = 0; c < 8; c++) {
+                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
                         float mv = (al0 * z0 + al1 * z1 + z1) * 0.5f;        // mean over the 2 nodes (ac:420)
-                        nd[cb * 32] = mv;
+                        nd[c * 16] = mv;
                         if (!valid) mv = 0.f;
-                        st_sum[cb] += (double)mv; st_sq[cb] += (double)mv * (double)mv;
+                        st_sum[c] += (double)mv; st_sq[c] += (double)mv * (double)mv;
                     }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tile is complete before the next pass reads it
             STAMP(4);
         }
+        t_cur = t_n1; t_n1 += 8;
     }
-    flush_stats(s_red, A.epi_stats, st_sum, st_sq, tid, wave, j, h);
+    flush_stats16(s_red, A.epi_stats, st_sum, st_sq, tid, wave, m, q);
 #ifdef MTFJSP_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP(6);
     if (A.stamps && lane == 0)
-        for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
+        for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
 #endif
 }
 
@@ -1227,19 +1116,13 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     rc |= dalloc_rows(&e->node, B * M);
     rc |= dalloc(e, &e->stats, 8 * STAT_REP * 256);
     if (rc) { g_enc_err = e->err; mtfjsp_encoder_destroy(e); return MTFJSP_ERR_HIP; }
-    const int lds = (int)gemm_lds_bytes();
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_PLAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_TANH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_PLAIN, EPI_TANH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_BNRELU, EPI_STATS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gemm128<PRO_AGG, EPI_STATS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute((const void *)k_gat3, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int lds16 = (int)gemm16_lds_bytes();
-    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_PLAIN, EPI_PLAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
-    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_PLAIN, EPI_TANH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
-    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_PLAIN, EPI_TANH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
-    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_BNRELU, EPI_STATS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
-    (void)hipFuncSetAttribute((const void *)k_gemm16<PRO_AGG, EPI_STATS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm16<EPI_PLAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm16<EPI_TANH, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm16<EPI_TANH, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm16p<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm16p<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gat3, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
     *out = e;
     return MTFJSP_OK;
@@ -1316,37 +1199,35 @@ template <int PRO, int EPI, bool ACC = false>
 static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
 {
     Timed t(e, name);
-    static const int use16 = getenv("MTFJSP_GEMM32") ? 0 : 1;
-    static const int stagger = getenv("MTFJSP_GEMM_TOKEN") ? atoi(getenv("MTFJSP_GEMM_TOKEN")) : 0;
-    const int waves = use16 ? 8 : 4;
-    const int ntiles = use16 ? (a.N + 15) / 16 : (a.N + 31) / 32;
-    int grid = (ntiles + waves - 1) / waves;
+    const int ntiles = (a.N + 15) / 16;
+    int grid = (ntiles + 7) / 8;
     if (grid > e->num_cu) grid = e->num_cu;
     GemmArgs b = a;
 #ifdef MTFJSP_STAMP
+    b.dbg = getenv("MTFJSP_GEMM_DBG") ? atoi(getenv("MTFJSP_GEMM_DBG")) : 0;
     static unsigned long long *d_st = nullptr;
     if (!d_st) (void)hipMalloc((void **)&d_st, 2048 * 8 * 8);
     (void)hipMemsetAsync(d_st, 0, 2048 * 8 * 8, e->stream);
     b.stamps = d_st;
 #endif
-    if (use16) hipLaunchKernelGGL((k_gemm16<PRO, EPI, ACC>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b, stagger);
-    else hipLaunchKernelGGL((k_gemm128<PRO, EPI, ACC>), dim3(grid), dim3(256), gemm_lds_bytes(), e->stream, b);
+    if constexpr (PRO == PRO_PLAIN) hipLaunchKernelGGL((k_gemm16<EPI, ACC>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
+    else hipLaunchKernelGGL((k_gemm16p<PRO>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
 #ifdef MTFJSP_STAMP
     static int printed = 0;
-    if (printed < 40 && getenv("MTFJSP_STAMP_PRINT")) {
+    if (PRO != PRO_PLAIN && printed < 40 && getenv("MTFJSP_STAMP_PRINT")) {
         (void)hipStreamSynchronize(e->stream);
         std::vector<unsigned long long> hst(2048 * 8);
         (void)hipMemcpy(hst.data(), d_st, 2048 * 8 * 8, hipMemcpyDeviceToHost);
-        for (int half = 0; half < (use16 ? 2 : 1); half++) {
+        for (int half = 0; half < 2; half++) {
             double m[8] = {0}; int n = 0;
-            for (int w = 0; w < grid * waves; w++) {
-                if (use16 && ((w % 8) >= 4) != (half == 1)) continue;
+            for (int w = 0; w < grid * 8; w++) {
+                if (((w % 8) >= 4) != (half == 1)) continue;
                 n++;
                 for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i];
             }
             for (int i = 0; i < 8; i++) m[i] /= n;
-            printf("STAMP %-18s N=%d grid=%d waves=%d half=%d  tiles %.2f  bn+sync %.0f  prefetch0 %.0f  transform+prefetch %.0f  token-wait %.0f  mfma %.0f  epilogue %.0f  tail %.0f (cycles/wave, summed over its tiles)\n",
-                   name, a.N, grid, waves, half, m[7], m[0], m[1], m[2], m[3], m[4], m[5], m[6]);
+            printf("STAMP %-18s N=%d grid=%d half=%d  tiles %.2f  W+bn+sync %.0f  first-tile %.0f  tile-loop %.0f  tail %.0f | kernel %.0f shader ticks = %.2f us (s_memrealtime)\n",
+                   name, a.N, grid, half, m[7], m[0], m[1], m[4], m[6], m[2], m[3] / 100.0);
         }
         printed++;
     }
@@ -1423,24 +1304,24 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
         a.R = R; a.f1 = m_fea1; a.f2 = m_fea2; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
         a.W1 = W(pre + "m_fea_1_fcl.weight"); a.W2 = W(pre + "m_fea_2_fcl.weight");
         a.Wt = WT(pre + "gat_layer.W"); a.gat_a = W(pre + "gat_layer.a"); a.node = e->node; a.epi_stats = st;
-        const int ntiles = (2 * R + 31) / 32;
-        int grid = (ntiles + 3) / 4;
+        const int ntiles = (2 * R + 15) / 16;
+        int grid = (ntiles + 7) / 8;
         if (grid > e->num_cu) grid = e->num_cu;
 #ifdef MTFJSP_STAMP
         static unsigned long long *d_st = nullptr;
-        if (!d_st) (void)hipMalloc((void **)&d_st, 1024 * 8 * 8);
-        (void)hipMemsetAsync(d_st, 0, 1024 * 8 * 8, e->stream);
+        if (!d_st) (void)hipMalloc((void **)&d_st, 2048 * 8 * 8);
+        (void)hipMemsetAsync(d_st, 0, 2048 * 8 * 8, e->stream);
         a.stamps = d_st;
 #endif
-        hipLaunchKernelGGL(k_gat3, dim3(grid), dim3(256), gemm_lds_bytes(), e->stream, a);
+        hipLaunchKernelGGL(k_gat3, dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, a);
 #ifdef MTFJSP_STAMP
         static int printed = 0;
         if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
             (void)hipStreamSynchronize(e->stream);
-            std::vector<unsigned long long> hst(1024 * 8);
-            (void)hipMemcpy(hst.data(), d_st, 1024 * 8 * 8, hipMemcpyDeviceToHost);
+            std::vector<unsigned long long> hst(2048 * 8);
+            (void)hipMemcpy(hst.data(), d_st, 2048 * 8 * 8, hipMemcpyDeviceToHost);
             double m[8] = {0};
-            for (int w = 0; w < grid * 4; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i] / (grid * 4);
+            for (int w = 0; w < grid * 8; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i] / (grid * 8);
             printf("STAMP k_gat3 R=%d grid=%d  Wload %.0f  feat0 %.0f  rows %.0f  mfma %.0f  gat-epilogue %.0f  tail %.0f (cycles/wave, summed)\n",
                    R, grid, m[0], m[1], m[2], m[3], m[4], m[6]);
         }
