@@ -28,9 +28,7 @@
 #include "../../include/mtfjsp.h"
 
 #define HD 128
-#define LDA 129
 #define BN_EPS 1e-5
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2 };
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2 };
@@ -602,240 +600,213 @@ __global__ __launch_bounds__(512) void k_gat3(GatArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused actor heads (ac:205-293 / ac:444-495): for a group of 16 instances one workgroup computes
+// Fused actor heads (ac:205-293 / ac:444-495): for a group of 16 instances (= R 16-row tiles of scorer rows, since an
+// instance has R candidates / machines) one 8-wave workgroup computes
 //   u   = Wb pooled + Wc other + b0                      (the per-instance thirds of the 384-wide scorer input)
 //   s1  = tanh(Wa x_row + u[instance]) ; s2 = tanh(W1 s1 + b1) ; score = scale * (w2 . s2 + b2) ; masked softmax
 //   c1  = tanh(Wc0 pooled + bc0) ; c2 = tanh(Wc1 c1 + bc1) ; value = Wc2 c2 + bc2
-// All six [128,128] weight blocks stream once through one 64 KB LDS buffer (next block prefetched into registers
-// while the matrix cores run); a 32-row tile is split by COLUMN block over the four waves (64 MFMAs each), and
-// every intermediate stays in LDS as the next product's A tile.  One launch instead of six GEMMs + a softmax.
-struct W16 { float4 v[16]; };     // one 64 KB weight block spread over 256 threads, by value so it stays in registers
-struct R4 { float4 v[4]; };       // 32 staged rows: 4 x 16 bytes per thread
-__device__ __forceinline__ W16 w_fetch16(const float *Wt, int tid, int rot)
-{
-    W16 w;
-    const float4 *src = reinterpret_cast<const float4 *>(Wt);
-#pragma unroll
-    for (int i = 0; i < 16; i++) w.v[i] = src[tid + ((i + rot) & 15) * 256];   // rotated start: all CUs stream the same 64 KB,
-    return w;                                                                    // so de-phase them across the L2 channels
-}
-__device__ __forceinline__ void w_commit16(float *s_w, const W16 &w, int tid, int rot)
-{
-    float4 *dst = reinterpret_cast<float4 *>(s_w);
-#pragma unroll
-    for (int i = 0; i < 16; i++) dst[tid + ((i + rot) & 15) * 256] = w.v[i];
-}
-__device__ __forceinline__ R4 fetch_rows4(const float *src, int first_row, int nrows, int sr, int sc4)
-{
-    R4 r;
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        const int rr = p * 8 + sr;
-        r.v[p] = (rr < nrows) ? *reinterpret_cast<const float4 *>(src + (size_t)(first_row + rr) * HD + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    return r;
-}
-__device__ __forceinline__ void commit_rows4(float *tile, const R4 &r, int sr, int sc4)
-{
-#pragma unroll
-    for (int p = 0; p < 4; p++) {
-        float *d = tile + (p * 8 + sr) * LDA + sc4;
-        d[0] = r.v[p].x; d[1] = r.v[p].y; d[2] = r.v[p].z; d[3] = r.v[p].w;
-    }
-}
+// Work is split by OUTPUT COLUMN: wave w owns columns 16w..16w+15 of every product, so its B operand — one 128x16 column
+// block of a weight, 32 registers — is loaded from global memory straight into registers (no LDS staging, no commit
+// barrier, the next weight is requested while the current one is multiplied), is reused for every tile, and the eight
+// waves load the MFMA pipes evenly (512 products each).  Only activations live in LDS: every A tile is read by all waves
+// and every intermediate is written back as the next product's A tile (three barriers per chunk of 8 tiles).
 struct HeadArgs {
     int B, R;
     const float *X;                      // [B*R,128] candidate / machine node embeddings
     const float *pooled, *other;         // [B,128]
-    const float *W0t;                    // [3][128][128] transposed blocks of linears.0: X | pooled | other
-    const float *b0, *W1t, *b1, *w2, *b2;
-    const float *Wc0t, *bc0, *Wc1t, *bc1, *wc2, *bc2;
+    const float *W0i;                    // register images (mtfjsp_encoder::wimg) of the 3 blocks of linears.0: X | pooled | other
+    const float *b0, *W1i, *b1, *w2, *b2;
+    const float *Wc0i, *bc0, *Wc1i, *bc1, *wc2, *bc2;
     const uint8_t *mask;                 // [B,R]
     float scale;
     float *prob, *value;                 // [B,R], [B,2]
     unsigned long long *stamps;
 };
-#define HG 16                            // instances per workgroup
-#define HTILES 3                         // LDS tiles (the scorer loop below is written for exactly 3)
+#define HG 16                            // instances per group
+#define HCH 6                            // scorer tiles per chunk (even; X tiles and s1 tiles are separate LDS buffers)
 
-__global__ __launch_bounds__(256, 1) void k_heads(HeadArgs A)
+__global__ __launch_bounds__(512) void k_heads(HeadArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    float *s_w = reinterpret_cast<float *>(smem);                  // 128*128
-    float *s_t = s_w + HD * HD;                                    // HTILES * 32 * LDA
-    float *s_u = s_t + HTILES * 32 * LDA;                          // HG * 128
-    float *s_score = s_u + HG * HD;                                // HG * 64
-    float *s_part = s_score + HG * 64;                             // 4 waves * 32 rows
-    float *s_wc2 = s_part + 128;                                   // 2 * 128
+    float *s_x = reinterpret_cast<float *>(smem);                  // HCH tiles of 16 x LDA16: X rows
+    float *s_s = s_x + HCH * 16 * LDA16;                           // HCH tiles: s1
+    float *s_p = s_s + HCH * 16 * LDA16;                           // pooled tile
+    float *s_o = s_p + 16 * LDA16;                                 // other tile
+    float *s_c1 = s_o + 16 * LDA16;                                // c1 tile
+    float *s_c2 = s_c1 + 16 * LDA16;                               // c2 tile
+    float *s_u = s_c2 + 16 * LDA16;                                // [16][128]
+    float *s_part = s_u + HG * HD;                                 // 8 waves * (HCH*16) rows
+    float *s_score = s_part + 8 * HCH * 16;                        // HG * 64
+    float *s_wc2 = s_score + HG * 64;                              // 2 * 128
     unsigned char *s_mask = reinterpret_cast<unsigned char *>(s_wc2 + 2 * HD);   // HG * 64
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int j = lane & 31, h = lane >> 5;
+    const int m = lane & 15, q = lane >> 4;
+    const int col = 16 * wave + m;
 #ifdef MTFJSP_STAMP
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
 #endif
-    const int g0 = blockIdx.x * HG;
-    const int ng = (A.B - g0) < HG ? (A.B - g0) : HG;
     const int R = A.R;
     const unsigned invR = (unsigned)((0x100000000ull + (unsigned)R - 1) / (unsigned)R);
-    float4 w0, w1, w2_, w3, w4, w5, w6, w7, w8, w9, w10, w11, w12, w13, w14, w15;   // one 64 KB weight block in flight (named scalars:
-                                                                                     // an array here is not promoted out of scratch)
-    const int rot = blockIdx.x;
-    int cur = 2; (void)cur;
-#define W_SLOT(i) (tid + (((i) + rot) & 15) * 256)              /* rotated start: all CUs stream the same 64 KB, de-phase them across L2 channels */
-#define w_fetch(Wt)                                                                                                   \
-    do {                                                                                                              \
-        const float4 *src_ = reinterpret_cast<const float4 *>(Wt);                                                    \
-        w0 = src_[W_SLOT(0)]; w1 = src_[W_SLOT(1)]; w2_ = src_[W_SLOT(2)]; w3 = src_[W_SLOT(3)];                      \
-        w4 = src_[W_SLOT(4)]; w5 = src_[W_SLOT(5)]; w6 = src_[W_SLOT(6)]; w7 = src_[W_SLOT(7)];                       \
-        w8 = src_[W_SLOT(8)]; w9 = src_[W_SLOT(9)]; w10 = src_[W_SLOT(10)]; w11 = src_[W_SLOT(11)];                   \
-        w12 = src_[W_SLOT(12)]; w13 = src_[W_SLOT(13)]; w14 = src_[W_SLOT(14)]; w15 = src_[W_SLOT(15)];               \
+    // this wave's column block of a weight, b[s] = W^T[k = 4s+q][col], from its register image: 8 coalesced 16-byte loads
+#define WCOL(dst, Wi)                                                                              \
+    do {                                                                                           \
+        const float4 *w_ = reinterpret_cast<const float4 *>(Wi) + (size_t)wave * 8 * 64 + lane;    \
+        _Pragma("unroll") for (int g_ = 0; g_ < 8; g_++) {                                         \
+            const float4 v_ = w_[g_ * 64];                                                         \
+            dst[4 * g_] = v_.x; dst[4 * g_ + 1] = v_.y; dst[4 * g_ + 2] = v_.z; dst[4 * g_ + 3] = v_.w; \
+        }                                                                                          \
     } while (0)
-#define w_commit()                                                                                                    \
-    do {                                                                                                              \
-        STAMP(cur);                                                                                                   \
-        float4 *dst_ = reinterpret_cast<float4 *>(s_w);                                                               \
-        dst_[W_SLOT(0)] = w0; dst_[W_SLOT(1)] = w1; dst_[W_SLOT(2)] = w2_; dst_[W_SLOT(3)] = w3;                      \
-        dst_[W_SLOT(4)] = w4; dst_[W_SLOT(5)] = w5; dst_[W_SLOT(6)] = w6; dst_[W_SLOT(7)] = w7;                       \
-        dst_[W_SLOT(8)] = w8; dst_[W_SLOT(9)] = w9; dst_[W_SLOT(10)] = w10; dst_[W_SLOT(11)] = w11;                   \
-        dst_[W_SLOT(12)] = w12; dst_[W_SLOT(13)] = w13; dst_[W_SLOT(14)] = w14; dst_[W_SLOT(15)] = w15;               \
-        STAMP(0);                                                                                                     \
+    // two 16-row tiles x this wave's column block: two independent chains of 32 products (fully unrolled: b[] stays in registers)
+#define TILE2(acc0, acc1, t0p, t1p, bw)                                                                          \
+    do {                                                                                                         \
+        _Pragma("unroll") for (int s_ = 0; s_ < 32; s_++) {                                                      \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((t0p)[4 * s_], bw[s_], acc0, 0, 0, 0);                   \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((t1p)[4 * s_], bw[s_], acc1, 0, 0, 0);                   \
+        }                                                                                                        \
     } while (0)
-    const int sr = tid >> 5, sc4 = (tid & 31) * 4;                  // staging: thread -> (row sr + 8p, 4 columns)
-    auto tile_gemm = [&](const float *tile, f32x16 acc) __attribute__((always_inline)) -> f32x16 {  // this wave: output columns [32*wave, 32*wave+32)
-        const float *ap = tile + j * LDA + 64 * h;
-        const float *bp = s_w + (64 * h) * HD + 32 * wave + j;
-        STAMP(cur);
-#pragma unroll 8
-        for (int s = 0; s < 64; s++) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s], bp[s * HD], acc, 0, 0, 0);
-        STAMP(1);
-        return acc;
-    };
-    f32x16 zero;
-    for (int i = 0; i < 16; i++) zero[i] = 0.f;
-    const int col = 32 * wave + j;
-    float *t0 = s_t, *t1 = s_t + 32 * LDA, *t2 = s_t + 2 * 32 * LDA;
-    const int nrows = ng * R, ntiles = (nrows + 31) / 32;
-
-    // ---- everything that comes from global memory is requested up front (a load at its point of use would stall the
-    //      whole workgroup for a full memory round trip each time)
-    w_fetch(A.W0t + 1 * HD * HD);
-    R4 r_x0, r_x1, r_x2;
-    const R4 r_pool = fetch_rows4(A.pooled, g0, ng, sr, sc4);
-    const R4 r_oth = fetch_rows4(A.other, g0, ng, sr, sc4);
+    const int sr = tid >> 5, sc4 = (tid & 31) * 4;                  // staging: thread -> (row sr of 16, 4 columns)
+    const int aoff = m * LDA16 + q;                                 // A operand: tile[row m][k = 4s+q]
     const float b0c = A.b0[col], bc0c = A.bc0[col], bc1c = A.bc1[col], b1c = A.b1[col], w2c = A.w2[col], b2 = A.b2[0];
-    s_wc2[tid] = A.wc2[tid];
-    for (int i = tid; i < ng * R; i += 256) s_mask[i] = A.mask[(size_t)g0 * R + i];
-    r_x0 = fetch_rows4(A.X, g0 * R, nrows, sr, sc4);
-    r_x1 = fetch_rows4(A.X, g0 * R + 32, nrows - 32, sr, sc4);
-    r_x2 = fetch_rows4(A.X, g0 * R + 64, nrows - 64, sr, sc4);
-    commit_rows4(t0, r_pool, sr, sc4);
-    commit_rows4(t1, r_oth, sr, sc4);
-    w_commit();
-    LDS_BARRIER();
-    // ---- u = Wb pooled + Wc other + b0
-    STAMP(2); cur = 3;
-    w_fetch(A.W0t + 2 * HD * HD);
-    f32x16 acc = tile_gemm(t0, zero);
-    LDS_BARRIER();
-    w_commit();
-    LDS_BARRIER();
-    w_fetch(A.Wc0t);
-    acc = tile_gemm(t1, acc);
-    for (int i = 0; i < 16; i++) {
-        const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (r < HG) s_u[r * HD + col] = acc[i] + b0c;
-    }
-    LDS_BARRIER();
-    // ---- critic: c1 = tanh(Wc0 pooled + bc0) -> t1 ; c2 = tanh(Wc1 c1 + bc1) -> t2 ; value = Wc2 c2 + bc2
-    w_commit();
-    LDS_BARRIER();
-    w_fetch(A.Wc1t);
-    acc = tile_gemm(t0, zero);
-    for (int i = 0; i < 16; i++) { const int r = (i & 3) + 8 * (i >> 2) + 4 * h; t1[r * LDA + col] = fast_tanh(acc[i] + bc0c); }
-    LDS_BARRIER();
-    w_commit();
-    LDS_BARRIER();
-    w_fetch(A.W0t);                                                  // Wa for the first group of X tiles
-    acc = tile_gemm(t1, zero);
-    for (int i = 0; i < 16; i++) { const int r = (i & 3) + 8 * (i >> 2) + 4 * h; t2[r * LDA + col] = fast_tanh(acc[i] + bc1c); }
-    LDS_BARRIER();
-    STAMP(3); cur = 4;
-    {   // value head: 16 threads per instance row, 8 columns each, both outputs
-        const int r = tid >> 4, part = tid & 15;
-        float p0 = 0.f, p1 = 0.f;
-        for (int k = 0; k < 8; k++) { const float x = t2[r * LDA + part * 8 + k]; p0 = fmaf(x, s_wc2[part * 8 + k], p0); p1 = fmaf(x, s_wc2[HD + part * 8 + k], p1); }
-        for (int o = 8; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
-        if (part == 0 && r < ng) { A.value[(size_t)(g0 + r) * 2] = p0 + A.bc2[0]; A.value[(size_t)(g0 + r) * 2 + 1] = p1 + A.bc2[1]; }
-    }
-    LDS_BARRIER();
-    STAMP(4); cur = 5;
-    // ---- scorer over the ng*R rows of this group, HTILES tiles at a time
-    for (int tb = 0; tb < ntiles; tb += HTILES) {
-        const int nt = (ntiles - tb) < HTILES ? (ntiles - tb) : HTILES;
-        if (tb > 0) {
-            w_fetch(A.W0t);
-            r_x0 = fetch_rows4(A.X, g0 * R + tb * 32, nrows - tb * 32, sr, sc4);
-            r_x1 = fetch_rows4(A.X, g0 * R + (tb + 1) * 32, nrows - (tb + 1) * 32, sr, sc4);
-            r_x2 = fetch_rows4(A.X, g0 * R + (tb + 2) * 32, nrows - (tb + 2) * 32, sr, sc4);
+    if (tid < 2 * HD) s_wc2[tid] = A.wc2[tid];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
+        // 64-bit weight addresses into registers and spill them)
+        const int g0 = blockIdx.x * HG;
+        const int ng = (A.B - g0) < HG ? (A.B - g0) : HG;
+        const int nrows = ng * R;
+        // ---- requests first: weights of phase A, the instance tiles, the masks
+        float wA[32], wB[32], wC[32];
+        WCOL(wA, A.W0i + 1 * HD * HD);                              // Wb
+        WCOL(wB, A.W0i + 2 * HD * HD);                              // Wc
+        WCOL(wC, A.Wc0i);
+        {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 xp = sr < ng ? *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4) : z;
+            const float4 xo = sr < ng ? *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + sr) * HD + sc4) : z;
+            float *dp = s_p + sr * LDA16 + sc4, *dq = s_o + sr * LDA16 + sc4;
+            *reinterpret_cast<float2 *>(dp) = make_float2(xp.x, xp.y); *reinterpret_cast<float2 *>(dp + 2) = make_float2(xp.z, xp.w);
+            *reinterpret_cast<float2 *>(dq) = make_float2(xo.x, xo.y); *reinterpret_cast<float2 *>(dq + 2) = make_float2(xo.z, xo.w);
         }
-        commit_rows4(t0, r_x0, sr, sc4);
-        if (nt > 1) commit_rows4(t1, r_x1, sr, sc4);
-        if (nt > 2) commit_rows4(t2, r_x2, sr, sc4);
-        w_commit();                                                  // Wa
+        for (int i = tid; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
+        float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
+#pragma unroll
+        for (int t = 0; t < HCH; t++) {
+            const int grow = t * 16 + sr;
+            xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(A.X + ((size_t)g0 * R + grow) * HD + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         LDS_BARRIER();
-        w_fetch(A.W1t);
-        for (int k = 0; k < nt; k++) {
-            float *tile = s_t + k * 32 * LDA;
-            acc = tile_gemm(tile, zero);
-            LDS_BARRIER();                                         // every wave has read the X tile before it is overwritten
-            for (int i = 0; i < 16; i++) {
-                const int r = (i & 3) + 8 * (i >> 2) + 4 * h;
-                const int grow = (tb + k) * 32 + r;
-                const int inst = grow < nrows ? (int)__umulhi((unsigned)grow, invR) : 0;
-                tile[r * LDA + col] = fast_tanh(acc[i] + s_u[inst * HD + col]);
+        STAMP(0);
+        // ---- phase A: u = Wb pooled + Wc other + b0 ; c1 = tanh(Wc0 pooled + bc0)
+        {
+            f32x4 au = zero4, au2 = zero4, ac = zero4;
+            const float *pp = s_p + aoff, *po = s_o + aoff;
+#pragma unroll
+            for (int s = 0; s < 32; s++) {
+                const float a_p = pp[4 * s], a_o = po[4 * s];
+                au = __builtin_amdgcn_mfma_f32_16x16x4f32(a_p, wA[s], au, 0, 0, 0);
+                ac = __builtin_amdgcn_mfma_f32_16x16x4f32(a_p, wC[s], ac, 0, 0, 0);
+                au2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, wB[s], au2, 0, 0, 0);
+            }
+            WCOL(wA, A.Wc1i);                                       // requested now, used in phase B
+            WCOL(wB, A.W0i);                                        // Wa
+            WCOL(wC, A.W1i);                                        // phase C
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                s_u[(4 * q + i) * HD + col] = au[i] + au2[i] + b0c;
+                s_c1[(4 * q + i) * LDA16 + col] = fast_tanh(ac[i] + bc0c);
             }
         }
-        LDS_BARRIER();
-        STAMP(5); cur = 6;
-        w_commit();                                                  // W1
-        LDS_BARRIER();
-        for (int k = 0; k < nt; k++) {
-            acc = tile_gemm(s_t + k * 32 * LDA, zero);
-            for (int i = 0; i < 16; i++) {
-                float v = fast_tanh(acc[i] + b1c) * w2c;
-                for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);          // over the 32 columns of this wave
-                if (j == 0) s_part[wave * 32 + (i & 3) + 8 * (i >> 2) + 4 * h] = v;
+        STAMP(1);
+        for (int tb = 0; tb < R; tb += HCH) {
+            const int nt = (R - tb) < HCH ? (R - tb) : HCH;
+            // ---- X rows of this chunk -> LDS tiles (rows beyond the group's are zero)
+#pragma unroll
+            for (int t = 0; t < HCH; t++) {
+                if (tb > 0) {
+                    const int grow = (tb + t) * 16 + sr;
+                    xr[t] = (tb + t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(A.X + ((size_t)g0 * R + grow) * HD + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                float *d = s_x + (t * 16 + sr) * LDA16 + sc4;
+                *reinterpret_cast<float2 *>(d) = make_float2(xr[t].x, xr[t].y); *reinterpret_cast<float2 *>(d + 2) = make_float2(xr[t].z, xr[t].w);
+            }
+            LDS_BARRIER();                                          // X tiles, u and c1 are complete
+            STAMP(2);
+            // ---- phase B: s1 = tanh(Wa x + u[instance]) -> s_s ; first chunk: c2 = tanh(Wc1 c1 + bc1)
+#pragma unroll 1
+            for (int t = 0; t < nt; t += 2) {
+                f32x4 a0 = zero4, a1 = zero4;
+                const float *p0 = s_x + t * 16 * LDA16 + aoff, *p1 = p0 + 16 * LDA16;
+                TILE2(a0, a1, p0, p1, wB);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int grow = (tb + t) * 16 + 4 * q + i;
+                    const int i0 = grow < nrows ? (int)__umulhi((unsigned)grow, invR) : 0;
+                    const int i1 = grow + 16 < nrows ? (int)__umulhi((unsigned)(grow + 16), invR) : 0;
+                    s_s[(t * 16 + 4 * q + i) * LDA16 + col] = fast_tanh(a0[i] + s_u[i0 * HD + col]);
+                    s_s[((t + 1) * 16 + 4 * q + i) * LDA16 + col] = fast_tanh(a1[i] + s_u[i1 * HD + col]);
+                }
+            }
+            if (tb == 0) {
+                f32x4 a0 = zero4;
+                const float *pc = s_c1 + aoff;
+#pragma unroll
+                for (int s = 0; s < 32; s++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pc[4 * s], wA[s], a0, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) s_c2[(4 * q + i) * LDA16 + col] = fast_tanh(a0[i] + bc1c);
+            }
+            LDS_BARRIER();                                          // s1 tiles and c2 are complete
+            STAMP(3);
+            // ---- phase C: s2 = tanh(W1 s1 + b1) ; partial scores of this wave's 16 columns
+#pragma unroll 1
+            for (int t = 0; t < nt; t += 2) {
+                f32x4 a0 = zero4, a1 = zero4;
+                const float *p0 = s_s + t * 16 * LDA16 + aoff, *p1 = p0 + 16 * LDA16;
+                TILE2(a0, a1, p0, p1, wC);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float v0 = row_sum16(fast_tanh(a0[i] + b1c) * w2c), v1 = row_sum16(fast_tanh(a1[i] + b1c) * w2c);
+                    if (m == 0) { s_part[wave * (HCH * 16) + t * 16 + 4 * q + i] = v0; s_part[wave * (HCH * 16) + (t + 1) * 16 + 4 * q + i] = v1; }
+                }
+            }
+            if (tb == 0) {   // value head: 32 threads per instance row, 4 columns each, both outputs
+                const int r = tid >> 5, part = tid & 31;
+                float p0 = 0.f, p1 = 0.f;
+                for (int k = 0; k < 4; k++) { const float x = s_c2[r * LDA16 + part * 4 + k]; p0 = fmaf(x, s_wc2[part * 4 + k], p0); p1 = fmaf(x, s_wc2[HD + part * 4 + k], p1); }
+                for (int o = 16; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+                if (part == 0 && r < ng) { A.value[(size_t)(g0 + r) * 2] = p0 + A.bc2[0]; A.value[(size_t)(g0 + r) * 2 + 1] = p1 + A.bc2[1]; }
             }
             LDS_BARRIER();
-            if (tid < 32) {
-                const int grow = (tb + k) * 32 + tid;
-                if (grow < nrows) s_score[grow] = (s_part[tid] + s_part[32 + tid] + s_part[64 + tid] + s_part[96 + tid] + b2) * A.scale;
+            if (tid < nt * 16) {
+                const int grow = tb * 16 + tid;
+                float v = b2;
+                for (int w = 0; w < 8; w++) v += s_part[w * (HCH * 16) + tid];
+                if (grow < nrows) s_score[grow] = v * A.scale;
             }
-            LDS_BARRIER();
+            LDS_BARRIER();                                          // tiles / s_part are reused by the next chunk
+            STAMP(4);
         }
-    }
-    STAMP(6); cur = 7;
-    // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance
-    {
-        const int r0 = tid >> 4, l = tid & 15;
-        if (r0 < ng) {
-            float mx = -INFINITY;
-            for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) mx = fmaxf(mx, s_score[r0 * R + r]);
-            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-            float sum = 0.f;
-            for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) sum += __expf(s_score[r0 * R + r] - mx);
-            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            for (int r = l; r < R; r += 16)
-                A.prob[(size_t)(g0 + r0) * R + r] = s_mask[r0 * R + r] ? 0.f : __expf(s_score[r0 * R + r] - mx) / sum;
+        // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance
+        {
+            const int r0 = tid >> 4, l = tid & 15;
+            if (r0 < ng) {
+                float mx = -INFINITY;
+                for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) mx = fmaxf(mx, s_score[r0 * R + r]);
+                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                float sum = 0.f;
+                for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) sum += __expf(s_score[r0 * R + r] - mx);
+                for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                for (int r = l; r < R; r += 16)
+                    A.prob[(size_t)(g0 + r0) * R + r] = s_mask[r0 * R + r] ? 0.f : __expf(s_score[r0 * R + r] - mx) / sum;
+            }
         }
+        STAMP(5);
     }
 #ifdef MTFJSP_STAMP
-    STAMP(7);
-    if (A.stamps && lane == 0) for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 4 + wave) * 8 + i] = ph[i];
+    if (A.stamps && lane == 0) for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
 #endif
 }
-static size_t heads_lds_bytes() { return (size_t)(HD * HD + HTILES * 32 * LDA + HG * HD + HG * 64 + 128 + 2 * HD) * 4 + HG * 64; }
+static size_t heads_lds_bytes() { return (size_t)((2 * HCH + 4) * 16 * LDA16 + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD) * 4 + HG * 64; }
 
 // ---------------------------------------------------------------------------------------------
 // GIN layer 0, first Linear (12 -> 128) fused with the neighbour aggregation of the raw task features
@@ -1020,6 +991,7 @@ struct mtfjsp_encoder {
     std::string err;
     std::map<std::string, float *> w;       // device copies, torch layout
     std::map<std::string, float *> wt;      // transposed [in,out] copies of the 128-wide Linear weights (split per 128-block of `in`)
+    std::map<std::string, float *> wimg;    // the same blocks as per-wave register images for k_heads: [block][wave 8][g 8][lane 64][4]
     std::vector<void *> owned;
     int num_cu = 256;
     // workspaces
@@ -1169,6 +1141,24 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
         if (jt != e->wt.end()) dt = jt->second;
         else { if (dalloc(e, &dt, (size_t)numel)) return MTFJSP_ERR_HIP; e->wt[key] = dt; }
         HIPCHK(e, hipMemcpy(dt, t.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
+        if (!is_gat_w) {
+            // k_heads: wave w (output columns 16w..16w+15), lane (m = lane & 15, q = lane >> 4) holds b[s] = W^T[k = 4s+q][16w+m],
+            // s = 0..31, fetched as 8 coalesced 16-byte loads: img[blk][w][g][lane][x] = W^T[4(4g+x)+q][16w+m]
+            std::vector<float> im((size_t)numel);
+            for (int blk = 0; blk < blocks; blk++)
+                for (int w = 0; w < 8; w++)
+                    for (int g = 0; g < 8; g++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int x = 0; x < 4; x++) {
+                                const int m = lane & 15, q = lane >> 4, k = 4 * (4 * g + x) + q;
+                                im[((((size_t)blk * 8 + w) * 8 + g) * 64 + lane) * 4 + x] = t[((size_t)blk * HD + k) * HD + 16 * w + m];
+                            }
+            float *di = nullptr;
+            auto kt = e->wimg.find(key);
+            if (kt != e->wimg.end()) di = kt->second;
+            else { if (dalloc(e, &di, (size_t)numel)) return MTFJSP_ERR_HIP; e->wimg[key] = di; }
+            HIPCHK(e, hipMemcpy(di, im.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
+        }
     }
     return MTFJSP_OK;
 }
@@ -1346,7 +1336,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     const int B = e->cfg.batch, J = e->cfg.n_job;
     auto W = [&](const std::string &k) { return e->w.at(k); };
-    auto WT = [&](const std::string &k) { return e->wt.at(k); };
+    auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     rc = run_gin(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes);
     if (rc) return rc;
     // ---- heads (ac:205-293): score = L2 tanh(L1 tanh(Wa cand + Wb pooled + Wc hm + b0))
@@ -1360,11 +1350,11 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         Timed t(e, "heads");
         HeadArgs ha{};
         ha.B = B; ha.R = J; ha.X = e->cand_feat; ha.pooled = h_pooled; ha.other = hm;
-        ha.W0t = WT("job_actor.o_policy.linears.0.weight"); ha.b0 = W("job_actor.o_policy.linears.0.bias");
-        ha.W1t = WT("job_actor.o_policy.linears.1.weight"); ha.b1 = W("job_actor.o_policy.linears.1.bias");
+        ha.W0i = WI("job_actor.o_policy.linears.0.weight"); ha.b0 = W("job_actor.o_policy.linears.0.bias");
+        ha.W1i = WI("job_actor.o_policy.linears.1.weight"); ha.b1 = W("job_actor.o_policy.linears.1.bias");
         ha.w2 = W("job_actor.o_policy.linears.2.weight"); ha.b2 = W("job_actor.o_policy.linears.2.bias");
-        ha.Wc0t = WT("job_actor.job_critic.linears.0.weight"); ha.bc0 = W("job_actor.job_critic.linears.0.bias");
-        ha.Wc1t = WT("job_actor.job_critic.linears.1.weight"); ha.bc1 = W("job_actor.job_critic.linears.1.bias");
+        ha.Wc0i = WI("job_actor.job_critic.linears.0.weight"); ha.bc0 = W("job_actor.job_critic.linears.0.bias");
+        ha.Wc1i = WI("job_actor.job_critic.linears.1.weight"); ha.bc1 = W("job_actor.job_critic.linears.1.bias");
         ha.wc2 = W("job_actor.job_critic.linears.2.weight"); ha.bc2 = W("job_actor.job_critic.linears.2.bias");
         ha.mask = job_mask; ha.scale = 1.0f; ha.prob = prob; ha.value = job_v;
 #ifdef MTFJSP_STAMP
@@ -1372,17 +1362,17 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         if (!d_st) (void)hipMalloc((void **)&d_st, 4096 * 8 * 8);
         ha.stamps = d_st;
 #endif
-        hipLaunchKernelGGL(k_heads, dim3((B + HG - 1) / HG), dim3(256), heads_lds_bytes(), e->stream, ha);
+        hipLaunchKernelGGL(k_heads, dim3((B + HG - 1) / HG), dim3(512), heads_lds_bytes(), e->stream, ha);
 #ifdef MTFJSP_STAMP
         static int printed = 0;
         if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
             (void)hipStreamSynchronize(e->stream);
-            const int nw = ((B + HG - 1) / HG) * 4;
+            const int nw = ((B + HG - 1) / HG) * 8;
             std::vector<unsigned long long> hst((size_t)nw * 8);
             (void)hipMemcpy(hst.data(), d_st, (size_t)nw * 64, hipMemcpyDeviceToHost);
             double m[8] = {0};
             for (int w = 0; w < nw; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[(size_t)w * 8 + i] / nw;
-            printf("STAMP k_heads: w_commit %.0f  tile_gemm %.0f  init %.0f  u+critic-epilogues %.0f  value %.0f  scorer-s1 %.0f  scorer-score %.0f  softmax %.0f (cycles/wave)\n", m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+            printf("STAMP k_heads: requests+stage %.0f  phaseA %.0f  X-stage %.0f  phaseB %.0f  phaseC+score %.0f  softmax %.0f (cycles/wave)\n", m[0], m[1], m[2], m[3], m[4], m[5]);
         }
 #endif
     }
@@ -1399,21 +1389,21 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
     auto W = [&](const std::string &k) { return e->w.at(k); };
-    auto WT = [&](const std::string &k) { return e->wt.at(k); };
+    auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     rc = run_gat(e, "machine_actor.", m_fea1, m_fea2, h_pooled);
     if (rc) return rc;
     {
         Timed t(e, "heads");
         HeadArgs ha{};
         ha.B = B; ha.R = M; ha.X = e->node; ha.pooled = h_pooled; ha.other = h_pooled_o;
-        ha.W0t = WT("machine_actor.m_policy.linears.0.weight"); ha.b0 = W("machine_actor.m_policy.linears.0.bias");
-        ha.W1t = WT("machine_actor.m_policy.linears.1.weight"); ha.b1 = W("machine_actor.m_policy.linears.1.bias");
+        ha.W0i = WI("machine_actor.m_policy.linears.0.weight"); ha.b0 = W("machine_actor.m_policy.linears.0.bias");
+        ha.W1i = WI("machine_actor.m_policy.linears.1.weight"); ha.b1 = W("machine_actor.m_policy.linears.1.bias");
         ha.w2 = W("machine_actor.m_policy.linears.2.weight"); ha.b2 = W("machine_actor.m_policy.linears.2.bias");
-        ha.Wc0t = WT("machine_actor.machine_critic.linears.0.weight"); ha.bc0 = W("machine_actor.machine_critic.linears.0.bias");
-        ha.Wc1t = WT("machine_actor.machine_critic.linears.1.weight"); ha.bc1 = W("machine_actor.machine_critic.linears.1.bias");
+        ha.Wc0i = WI("machine_actor.machine_critic.linears.0.weight"); ha.bc0 = W("machine_actor.machine_critic.linears.0.bias");
+        ha.Wc1i = WI("machine_actor.machine_critic.linears.1.weight"); ha.bc1 = W("machine_actor.machine_critic.linears.1.bias");
         ha.wc2 = W("machine_actor.machine_critic.linears.2.weight"); ha.bc2 = W("machine_actor.machine_critic.linears.2.bias");
         ha.mask = mmask; ha.scale = 10.0f; ha.prob = prob; ha.value = machine_v;
-        hipLaunchKernelGGL(k_heads, dim3((B + HG - 1) / HG), dim3(256), heads_lds_bytes(), e->stream, ha);
+        hipLaunchKernelGGL(k_heads, dim3((B + HG - 1) / HG), dim3(512), heads_lds_bytes(), e->stream, ha);
     }
     HIPCHK(e, hipGetLastError());
     return MTFJSP_OK;
