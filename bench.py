@@ -85,8 +85,8 @@ def cpu_baseline(J, M, E, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=360)
-    ap.add_argument("--warmup", type=int, default=36)
+    ap.add_argument("--steps", type=int, default=720)
+    ap.add_argument("--warmup", type=int, default=360)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--size", default="6x6x2")
     ap.add_argument("--policy", default="auto", choices=["auto", "actor", "random"])

@@ -610,6 +610,46 @@ __global__ __launch_bounds__(512) void k_gat3(GatArgs A)
 // barrier, the next weight is requested while the current one is multiplied), is reused for every tile, and the eight
 // waves load the MFMA pipes evenly (512 products each).  Only activations live in LDS: every A tile is read by all waves
 // and every intermediate is written back as the next product's A tile (three barriers per chunk of 8 tiles).
+// Philox4x32-10 (counter-based; Salmon et al. 2011) and the categorical / greedy pick shared by k_sample and the fused
+// selection at the end of k_heads (agent:22-72): p[0..n) with stride 1.
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ int pick_action(const float *p, int n, int b, int greedy, uint64_t seed, uint64_t counter)
+{
+    int pick = 0;
+    if (greedy) {
+        float best = p[0];
+        for (int i = 1; i < n; i++) if (p[i] > best) { best = p[i]; pick = i; }
+    } else {
+        uint32_t c[4] = {(uint32_t)b, (uint32_t)counter, (uint32_t)(counter >> 32), 0x73616d70u};
+        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);      // [0,1)
+        float tot = 0.f;
+        for (int i = 0; i < n; i++) tot += p[i];
+        float acc = 0.f;
+        const float thr = u * tot;
+        pick = -1;
+        int last = 0;
+        for (int i = 0; i < n; i++) {
+            if (p[i] > 0.f) {
+                last = i;
+                acc += p[i];
+                if (pick < 0 && thr < acc) pick = i;
+            }
+        }
+        if (pick < 0) pick = last;
+    }
+    return pick;
+}
+
 struct HeadArgs {
     int B, R;
     const float *X;                      // [B*R,128] candidate / machine node embeddings
@@ -620,6 +660,12 @@ struct HeadArgs {
     const uint8_t *mask;                 // [B,R]
     float scale;
     float *prob, *value;                 // [B,R], [B,2]
+    // machine actor: X arrives pre-BatchNorm (k_gat3 output); normalise it while staging, pool it over the R rows of an
+    // instance here (ac:434-444) and publish the pooled embedding — no separate normalisation pass over `node`
+    const double *xbn_stats; const float *xbn_gamma, *xbn_beta; double xbn_inv_rows; float *pooled_out;
+    // optional fused action selection (agent:22-72), same Philox stream as k_sample: 0 = off, 1 = sample, 2 = greedy
+    int sample_mode; unsigned long long seed, counter; int *idx_out; float *logp_out; const int *gather_from; int *gathered_out;
+    double *zero_stats; int zero_count;  // BatchNorm accumulators no kernel reads any more: zeroed here for the next forward
     unsigned long long *stamps;
 };
 #define HG 16                            // instances per group
@@ -670,6 +716,15 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
     const float b0c = A.b0[col], bc0c = A.bc0[col], bc1c = A.bc1[col], b1c = A.b1[col], w2c = A.w2[col], b2 = A.b2[0];
     if (tid < 2 * HD) s_wc2[tid] = A.wc2[tid];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
+    float xs0 = 1.f, xs1 = 1.f, xs2 = 1.f, xs3 = 1.f, xh0 = 0.f, xh1 = 0.f, xh2 = 0.f, xh3 = 0.f;   // X scale / shift of this thread's 4 columns
+    if (A.xbn_stats) {
+        stage_bn(s_u, A.xbn_stats, A.xbn_inv_rows, A.xbn_gamma, A.xbn_beta, tid);      // s_u is free until phase A
+        LDS_BARRIER();
+        xs0 = s_u[sc4]; xs1 = s_u[sc4 + 1]; xs2 = s_u[sc4 + 2]; xs3 = s_u[sc4 + 3];
+        xh0 = s_u[HD + sc4]; xh1 = s_u[HD + sc4 + 1]; xh2 = s_u[HD + sc4 + 2]; xh3 = s_u[HD + sc4 + 3];
+        LDS_BARRIER();
+    }
     {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
         // 64-bit weight addresses into registers and spill them)
         const int g0 = blockIdx.x * HG;
@@ -682,7 +737,19 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
         WCOL(wC, A.Wc0i);
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 xp = sr < ng ? *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4) : z;
+            float4 xp = z;
+            if (A.xbn_stats) {                                      // pooled = mean over the instance's R normalised rows (ac:444)
+                if (sr < ng) {
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                    for (int r = 0; r < R; r++) {
+                        const float4 v = *reinterpret_cast<const float4 *>(A.X + ((size_t)(g0 + sr) * R + r) * HD + sc4);
+                        a0 += fmaf(v.x, xs0, xh0); a1 += fmaf(v.y, xs1, xh1); a2 += fmaf(v.z, xs2, xh2); a3 += fmaf(v.w, xs3, xh3);
+                    }
+                    const float ir = 1.0f / (float)R;
+                    xp = make_float4(a0 * ir, a1 * ir, a2 * ir, a3 * ir);
+                    *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
+                }
+            } else if (sr < ng) xp = *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4);
             const float4 xo = sr < ng ? *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + sr) * HD + sc4) : z;
             float *dp = s_p + sr * LDA16 + sc4, *dq = s_o + sr * LDA16 + sc4;
             *reinterpret_cast<float2 *>(dp) = make_float2(xp.x, xp.y); *reinterpret_cast<float2 *>(dp + 2) = make_float2(xp.z, xp.w);
@@ -697,6 +764,9 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
         }
         LDS_BARRIER();
         STAMP(0);
+        auto xnorm = [&](float4 v, bool valid) __attribute__((always_inline)) {
+            return valid ? make_float4(fmaf(v.x, xs0, xh0), fmaf(v.y, xs1, xh1), fmaf(v.z, xs2, xh2), fmaf(v.w, xs3, xh3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
         // ---- phase A: u = Wb pooled + Wc other + b0 ; c1 = tanh(Wc0 pooled + bc0)
         {
             f32x4 au = zero4, au2 = zero4, ac = zero4;
@@ -727,8 +797,9 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
                     const int grow = (tb + t) * 16 + sr;
                     xr[t] = (tb + t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(A.X + ((size_t)g0 * R + grow) * HD + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
+                const float4 xv = xnorm(xr[t], (tb + t) * 16 + sr < nrows);
                 float *d = s_x + (t * 16 + sr) * LDA16 + sc4;
-                *reinterpret_cast<float2 *>(d) = make_float2(xr[t].x, xr[t].y); *reinterpret_cast<float2 *>(d + 2) = make_float2(xr[t].z, xr[t].w);
+                *reinterpret_cast<float2 *>(d) = make_float2(xv.x, xv.y); *reinterpret_cast<float2 *>(d + 2) = make_float2(xv.z, xv.w);
             }
             LDS_BARRIER();                                          // X tiles, u and c1 are complete
             STAMP(2);
@@ -786,7 +857,7 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
             LDS_BARRIER();                                          // tiles / s_part are reused by the next chunk
             STAMP(4);
         }
-        // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance
+        // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance; optional action selection
         {
             const int r0 = tid >> 4, l = tid & 15;
             if (r0 < ng) {
@@ -796,8 +867,21 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
                 float sum = 0.f;
                 for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) sum += __expf(s_score[r0 * R + r] - mx);
                 for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                for (int r = l; r < R; r += 16)
-                    A.prob[(size_t)(g0 + r0) * R + r] = s_mask[r0 * R + r] ? 0.f : __expf(s_score[r0 * R + r] - mx) / sum;
+                for (int r = l; r < R; r += 16) {
+                    const float pr = s_mask[r0 * R + r] ? 0.f : __expf(s_score[r0 * R + r] - mx) / sum;
+                    A.prob[(size_t)(g0 + r0) * R + r] = pr;
+                    s_score[r0 * R + r] = pr;                           // lanes of one wave: visible to lane l == 0 below
+                }
+                if (A.sample_mode) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (l == 0) {
+                        const int b = g0 + r0;
+                        const int pick = pick_action(s_score + r0 * R, R, b, A.sample_mode == 2, A.seed, A.counter);
+                        A.idx_out[b] = pick;
+                        if (A.logp_out) A.logp_out[b] = logf(s_score[r0 * R + pick]);
+                        if (A.gather_from && A.gathered_out) A.gathered_out[b] = A.gather_from[(size_t)b * R + pick];
+                    }
+                }
             }
         }
         STAMP(5);
@@ -937,46 +1021,14 @@ __global__ __launch_bounds__(128) void k_mach_bn_pool(int B, int M, float *node 
 }
 
 // ---------------------------------------------------------------------------------------------
-// categorical sampling / argmax (agent:22-72). thread = instance. Philox4x32-10.
-__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1)
-{
-    for (int r = 0; r < 10; r++) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
+// categorical sampling / argmax (agent:22-72). thread = instance.
 __global__ void k_sample(int B, int n, const float *prob, int greedy, uint64_t seed, uint64_t counter, int *idx_out, float *logp_out,
                          const int *gather_from, int *gathered_out)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float *p = prob + (size_t)b * n;
-    int pick = 0;
-    if (greedy) {
-        float best = p[0];
-        for (int i = 1; i < n; i++) if (p[i] > best) { best = p[i]; pick = i; }
-    } else {
-        uint32_t c[4] = {(uint32_t)b, (uint32_t)counter, (uint32_t)(counter >> 32), 0x73616d70u};
-        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);      // [0,1)
-        float tot = 0.f;
-        for (int i = 0; i < n; i++) tot += p[i];
-        float acc = 0.f;
-        const float thr = u * tot;
-        pick = -1;
-        int last = 0;
-        for (int i = 0; i < n; i++) {
-            if (p[i] > 0.f) {
-                last = i;
-                acc += p[i];
-                if (pick < 0 && thr < acc) pick = i;
-            }
-        }
-        if (pick < 0) pick = last;
-    }
+    const int pick = pick_action(p, n, b, greedy, seed, counter);
     idx_out[b] = pick;
     if (logp_out) logp_out[b] = logf(p[pick]);
     if (gather_from && gathered_out) gathered_out[b] = gather_from[(size_t)b * n + pick];
@@ -999,7 +1051,12 @@ struct mtfjsp_encoder {
     float *cand_feat = nullptr;             // [B*max(J,M),128]
     float *u = nullptr, *c1 = nullptr, *c2 = nullptr, *hm_b = nullptr, *pooled_int = nullptr;   // [B,128]
     float *node = nullptr;                  // [B*M,128]
-    double *stats = nullptr;                // [8,256]
+    double *stats = nullptr;                // [8][STAT_REP][256]: slots 0..5 GIN layers, 6/7 machine path (alternating)
+    bool gin_stats_clean = false;           // slots 0..5 are zero (the job-actor heads kernel zeroes them after their last reader)
+    bool gat_stats_clean[2] = {false, false};
+    int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
+    struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
+                         const int32_t *gather_from = nullptr; int32_t *gathered = nullptr; } fs[2];   // [0] job actor, [1] machine actor
     // timing
     bool timing = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> ev;
@@ -1087,6 +1144,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     rc |= dalloc_rows(&e->pooled_int, B);
     rc |= dalloc_rows(&e->node, B * M);
     rc |= dalloc(e, &e->stats, 8 * STAT_REP * 256);
+    if (!rc && hipMemset(e->stats, 0, 8 * STAT_REP * 256 * sizeof(double)) == hipSuccess) { e->gin_stats_clean = true; e->gat_stats_clean[0] = e->gat_stats_clean[1] = true; }
     if (rc) { g_enc_err = e->err; mtfjsp_encoder_destroy(e); return MTFJSP_ERR_HIP; }
     const int lds16 = (int)gemm16_lds_bytes();
     (void)hipFuncSetAttribute((const void *)k_gemm16<EPI_PLAIN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
@@ -1241,7 +1299,8 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
     double *st = e->stats;
-    HIPCHK(e, hipMemsetAsync(st, 0, 6 * STAT_REP * 256 * sizeof(double), e->stream));
+    if (!e->gin_stats_clean) HIPCHK(e, hipMemsetAsync(st, 0, 6 * STAT_REP * 256 * sizeof(double), e->stream));
+    e->gin_stats_clean = false;
     const double invN = 1.0 / (double)N;
     const int pgrid = e->num_cu * 8;
     {   // layer 0 / linear 0 with aggregation of the raw features
@@ -1281,13 +1340,19 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
 
 // Machine path shared by the machine actor and the global critic (ac:383-444): input projections + 3x the same GATLayer
 // + node mean (in-place GEMM passes), then BatchNorm over all B*M rows and the mean over M.  Uses accumulator slot 6.
-static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, float *h_pooled)
+// h_pooled == nullptr: leave `node` pre-BatchNorm for a consumer that normalises and pools it itself (k_heads); *slot_out = the
+// accumulator slot holding the column sums.
+static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, float *h_pooled, int *slot_out = nullptr)
 {
     const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
-    double *st = e->stats + 6 * STAT_REP * 256;
-    HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
+    const int slot = e->gat_slot;
+    e->gat_slot ^= 1;
+    if (slot_out) *slot_out = slot;
+    double *st = e->stats + (6 + slot) * STAT_REP * 256;
+    if (!e->gat_stats_clean[slot]) HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
+    e->gat_stats_clean[slot] = false;
     {                                                                          // the SAME GATLayer three times (ac:409-414), one launch
         Timed t(e, "gat3");
         GatArgs a{};
@@ -1317,12 +1382,30 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
         }
 #endif
     }
-    {
+    if (h_pooled) {
         Timed t(e, "mach_bn_pool");
         hipLaunchKernelGGL(k_mach_bn_pool, dim3(B), dim3(128), 0, e->stream, B, M, e->node, st, 1.0 / (double)R, W(pre + "bn.weight"),
                            W(pre + "bn.bias"), h_pooled);
     }
     HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+static void arm_sampling(mtfjsp_encoder *e, int which, HeadArgs &ha)
+{
+    mtfjsp_encoder::FusedSample &f = e->fs[which];
+    if (!f.armed) return;
+    ha.sample_mode = f.greedy ? 2 : 1; ha.seed = f.seed; ha.counter = f.counter;
+    ha.idx_out = f.idx; ha.logp_out = f.logp; ha.gather_from = f.gather_from; ha.gathered_out = f.gathered;
+    f.armed = false;                                                // one forward only
+}
+extern "C" int mtfjsp_encoder_arm_selection(mtfjsp_encoder_t e, int32_t which, int32_t greedy, uint64_t seed, uint64_t counter,
+                                            int32_t *idx_out, float *logp_out, const int32_t *gather_from, int32_t *gathered_out)
+{
+    if (!e || which < 0 || which > 1 || !idx_out) return MTFJSP_ERR_ARG;
+    mtfjsp_encoder::FusedSample &f = e->fs[which];
+    f.armed = true; f.greedy = greedy; f.seed = seed; f.counter = counter; f.idx = idx_out; f.logp = logp_out;
+    f.gather_from = gather_from; f.gathered = gathered_out;
     return MTFJSP_OK;
 }
 
@@ -1357,6 +1440,9 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         ha.Wc1i = WI("job_actor.job_critic.linears.1.weight"); ha.bc1 = W("job_actor.job_critic.linears.1.bias");
         ha.wc2 = W("job_actor.job_critic.linears.2.weight"); ha.bc2 = W("job_actor.job_critic.linears.2.bias");
         ha.mask = job_mask; ha.scale = 1.0f; ha.prob = prob; ha.value = job_v;
+        ha.zero_stats = e->stats; ha.zero_count = 6 * STAT_REP * 256;    // every GIN accumulator has been consumed by now
+        e->gin_stats_clean = true;
+        arm_sampling(e, 0, ha);
 #ifdef MTFJSP_STAMP
         static unsigned long long *d_st = nullptr;
         if (!d_st) (void)hipMalloc((void **)&d_st, 4096 * 8 * 8);
@@ -1390,12 +1476,18 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
     const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
-    rc = run_gat(e, "machine_actor.", m_fea1, m_fea2, h_pooled);
+    int slot = 0;
+    rc = run_gat(e, "machine_actor.", m_fea1, m_fea2, nullptr, &slot);
     if (rc) return rc;
     {
         Timed t(e, "heads");
         HeadArgs ha{};
-        ha.B = B; ha.R = M; ha.X = e->node; ha.pooled = h_pooled; ha.other = h_pooled_o;
+        ha.B = B; ha.R = M; ha.X = e->node; ha.pooled = nullptr; ha.other = h_pooled_o;
+        ha.xbn_stats = e->stats + (6 + slot) * STAT_REP * 256; ha.xbn_gamma = W("machine_actor.bn.weight"); ha.xbn_beta = W("machine_actor.bn.bias");
+        ha.xbn_inv_rows = 1.0 / (double)R; ha.pooled_out = h_pooled;
+        ha.zero_stats = e->stats + (6 + (slot ^ 1)) * STAT_REP * 256; ha.zero_count = STAT_REP * 256;   // the slot of the next machine forward
+        e->gat_stats_clean[slot ^ 1] = true;
+        arm_sampling(e, 1, ha);
         ha.W0i = WI("machine_actor.m_policy.linears.0.weight"); ha.b0 = W("machine_actor.m_policy.linears.0.bias");
         ha.W1i = WI("machine_actor.m_policy.linears.1.weight"); ha.b1 = W("machine_actor.m_policy.linears.1.bias");
         ha.w2 = W("machine_actor.m_policy.linears.2.weight"); ha.b2 = W("machine_actor.m_policy.linears.2.bias");

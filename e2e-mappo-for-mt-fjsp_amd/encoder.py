@@ -7,6 +7,8 @@ Weights are addressed by the reference's state_dict key names, so the shipped ch
 import ctypes as C
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -130,6 +132,14 @@ class Encoder:
             logp_out.data_ptr() if logp_out is not None else 0, gather_from.data_ptr() if gather_from is not None else 0,
             gathered_out.data_ptr() if gathered_out is not None else 0), self.h, enc=True)
 
+    def arm_selection(self, which, greedy, seed, counter, idx_out, logp_out=None, gather_from=None, gathered_out=None):
+        """fuse the action selection of the next job (which=0) / machine (which=1) actor forward into its heads kernel; same
+        stream and outputs as sample() on that forward's prob"""
+        capi.check(self.L.mtfjsp_encoder_arm_selection(
+            self.h, which, int(greedy), seed, counter, idx_out.data_ptr(), logp_out.data_ptr() if logp_out is not None else 0,
+            gather_from.data_ptr() if gather_from is not None else 0, gathered_out.data_ptr() if gathered_out is not None else 0),
+            self.h, enc=True)
+
     def timing_begin(self):
         capi.check(self.L.mtfjsp_encoder_timing_begin(self.h), self.h, enc=True)
 
@@ -154,6 +164,7 @@ class ActorPair:
         ja, ma = weights if weights is not None else random_init_weights(seed)
         self.enc.load_weights(ja, ma)
         self.greedy, self.seed = greedy, seed
+        self.fused = not os.environ.get("MTFJSP_NO_FUSED_SELECT")   # action selection inside the heads kernels (same stream either way)
         dev = self.enc.device
         self.job_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
         self.mch_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
@@ -164,12 +175,20 @@ class ActorPair:
 
     def act(self, env, counter, task_idx, mach_idx, job_idx, jv_out=None, mv_out=None):
         e = self.enc
-        prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask,
-                                           e.h_pooled_m if self.have_hm else None, v_out=jv_out)
-        e.sample(prob, self.greedy, self.seed, 2 * counter, job_idx, self.job_logp, env.candidate, task_idx)
+        hm = e.h_pooled_m if self.have_hm else None
+        if self.fused:
+            e.arm_selection(0, self.greedy, self.seed, 2 * counter, job_idx, self.job_logp, env.candidate, task_idx)
+            prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
+        else:
+            prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
+            e.sample(prob, self.greedy, self.seed, 2 * counter, job_idx, self.job_logp, env.candidate, task_idx)
         env.observe_mfea1(task_idx)                             # -> env.m_fea1, env.mmask
-        mprob, _, _ = e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
-        e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, self.mch_logp)
+        if self.fused:
+            e.arm_selection(1, self.greedy, self.seed, 2 * counter + 1, mach_idx, self.mch_logp)
+            e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
+        else:
+            mprob, _, _ = e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
+            e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, self.mch_logp)
         self.have_hm = True
 
     def timing_begin(self):

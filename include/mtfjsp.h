@@ -211,6 +211,11 @@ int mtfjsp_global_critic_forward(mtfjsp_encoder_t e, const void *tasks_fea, cons
 int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *prob, int32_t n, int32_t greedy, uint64_t seed,
                               uint64_t counter, int32_t *idx_out, float *logp_out, const int32_t *gather_from,
                               int32_t *gathered_out);
+/* Fuse the action selection of the NEXT mtfjsp_job_actor_forward (which = 0) / mtfjsp_machine_actor_forward (which = 1) call into
+ * its heads kernel: same arguments and the same Philox stream as mtfjsp_sample_categorical on that forward's `prob`
+ * (agent:22-72), one launch less per decision.  One-shot: applies to one forward call. */
+int mtfjsp_encoder_arm_selection(mtfjsp_encoder_t e, int32_t which, int32_t greedy, uint64_t seed, uint64_t counter,
+                                 int32_t *idx_out, float *logp_out, const int32_t *gather_from, int32_t *gathered_out);
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
 int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);
 /* per kernel family (between begin and the next begin): "gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg",
