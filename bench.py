@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--size", default="6x6x2")
     ap.add_argument("--policy", default="auto", choices=["auto", "actor", "random"])
     ap.add_argument("--obs", default="f32", choices=["f32", "f64"])
+    ap.add_argument("--trajectory", default="advantage", choices=["advantage", "full"],
+                    help="what the rollout records per step: the advantage inputs (rewards, dones, critic values) or every "
+                         "field of the reference's ReplayBuffer (device-resident TrajectoryBuffer, SURVEY 8f N2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -118,7 +121,7 @@ def main():
     if policy == "auto":
         policy = "actor" if rollout_mod.actor_available() else "random"
     ro = rollout_mod.Rollout(J, M, E, B, device=local_rank, policy=policy, obs_dtype=args.obs,
-                             instance_seed=rank, rank=rank, world=world)
+                             instance_seed=rank, rank=rank, world=world, collect="full" if args.trajectory == "full" else True)
 
     def sync():
         torch.cuda.synchronize()
@@ -178,7 +181,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"J{J}M{M}E{E}, {B} parallel instances per GPU, {ro.describe()}",
-                       "instances_per_gpu": B, "obs_dtype": args.obs, "policy": policy,
+                       "instances_per_gpu": B, "obs_dtype": args.obs, "policy": policy, "trajectory": args.trajectory,
                        "parallelism": f"instances sharded over {world} GPU(s); env/encoder path has no collective; one all-gather of advantages per {ro.S}-step buffer (RCCL when world>1)"},
             "roofline": roof, "roofline_env_step": roof_env,
             "kernel_times_ms": {k: v for k, v in ktimes.items()}, "kernel_times_steps": prof_steps,

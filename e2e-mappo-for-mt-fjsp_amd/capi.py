@@ -43,6 +43,7 @@ PROTOTYPES = {
     "mtfjsp_synchronize": (_I, [_VP]),
     "mtfjsp_alloc_obs": (_I, [_VP, C.POINTER(Obs)]),
     "mtfjsp_bind_obs": (_I, [_VP, C.POINTER(Obs)]),
+    "mtfjsp_snapshot_obs": (_I, [_VP, C.POINTER(Obs)]),
     "mtfjsp_load_instances": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_load_instances_host": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_scaler_init": (_I, [_VP]),

@@ -1070,6 +1070,25 @@ __global__ void k_scaler(int B, int full, double *scal, const uint8_t *mask)
     if (full) { for (int i = 0; i < 4; i++) { s[S_MEAN + i] = 0.0; s[S_S + i] = 0.0; s[S_STD + i] = 0.0; } s[S_N] = 0.0; }
 }
 
+// observation snapshot into a trajectory slot (device-resident replacement of ReplayBuffer.store_operation's
+// per-step copies, replaybuffer.py:82-139): up to 8 (src, dst, bytes) segments in ONE launch; 16-byte lanes for the bulk,
+// bytes for a ragged tail.  Pointers are 16-byte aligned when bytes % 16 == 0 slots are used (checked on the host).
+struct SnapSeg { const unsigned char *src; unsigned char *dst; unsigned long long bytes; };
+struct SnapArgs { SnapSeg seg[8]; int n; };
+__global__ __launch_bounds__(256) void k_snapshot(SnapArgs A)
+{
+    const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (int i = 0; i < A.n; i++) {
+        const SnapSeg g = A.seg[i];
+        const bool al = (((size_t)g.src | (size_t)g.dst) & 15) == 0;
+        const size_t n16 = al ? g.bytes >> 4 : 0;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(g.src);
+        uint4 *d4 = reinterpret_cast<uint4 *>(g.dst);
+        for (size_t k = gt; k < n16; k += stride) d4[k] = s4[k];
+        for (size_t k = (n16 << 4) + gt; k < g.bytes; k += stride) g.dst[k] = g.src[k];
+    }
+}
+
 // =================================================================================================
 // host side
 struct mtfjsp_env {
@@ -1194,6 +1213,40 @@ extern "C" int mtfjsp_bind_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *o)
         h->err = "bind_obs: every field except raw must be non-NULL"; return MTFJSP_ERR_ARG;
     }
     h->obs = *o; h->obs_bound = true;
+    return MTFJSP_OK;
+}
+
+// = the observation part of ReplayBuffer.store_operation (replaybuffer.py:82-139): copy the CURRENT bound observation
+// (tasks_fea, ELL adjacency, m_fea2, candidate, job_mask; info/raw/status when dst has them) into caller buffers of the
+// same layout, one launch on the handle's stream.  dst fields left NULL are skipped.
+extern "C" int mtfjsp_snapshot_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *dst)
+{
+    if (!h || !dst) return MTFJSP_ERR_ARG;
+    if (!h->obs_bound) { h->err = "no observation buffers bound (mtfjsp_alloc_obs / mtfjsp_bind_obs)"; return MTFJSP_ERR_STATE; }
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const size_t B = h->cfg.batch, T = h->T, M = h->cfg.n_machine, J = h->cfg.n_job;
+    const size_t es = h->cfg.obs_dtype == MTFJSP_OBS_F32 ? 4 : 8;
+    SnapArgs a{};
+    size_t total = 0;
+    auto add = [&](const void *src, void *d, size_t bytes) {
+        if (!d || !src) return;
+        a.seg[a.n].src = (const unsigned char *)src; a.seg[a.n].dst = (unsigned char *)d; a.seg[a.n].bytes = bytes; a.n++;
+        total += bytes;
+    };
+    add(h->obs.tasks_fea, dst->tasks_fea, B * T * 12 * es);
+    add(h->obs.ell_col, dst->ell_col, B * T * 2 * 4);
+    add(h->obs.ell_val, dst->ell_val, B * T * 2 * 4);
+    add(h->obs.m_fea2, dst->m_fea2, B * M * 8 * es);
+    add(h->obs.candidate, dst->candidate, B * J * 4);
+    add(h->obs.job_mask, dst->job_mask, B * J);
+    add(h->obs.info, dst->info, B * 6 * 8);
+    add(h->obs.raw, dst->raw, B * 5 * 8);
+    if (a.n == 0) return MTFJSP_OK;
+    size_t blocks = (total / 16 + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_snapshot, dim3((unsigned)blocks), dim3(256), 0, h->stream, a);
+    HIPCHK(h, hipGetLastError());
     return MTFJSP_OK;
 }
 

@@ -173,22 +173,29 @@ class ActorPair:
     def begin_episode(self):
         self.have_hm = False                                    # run:280 h_mch_pooled = None
 
-    def act(self, env, counter, task_idx, mach_idx, job_idx, jv_out=None, mv_out=None):
+    def act(self, env, counter, task_idx, mach_idx, job_idx, jv_out=None, mv_out=None, job_logp=None, mach_logp=None,
+            after_mfea1=None):
+        """one joint decision for every instance; the optional outputs let a trajectory buffer receive action indices,
+        log-probabilities and critic values in place (no copies)"""
         e = self.enc
+        jl = job_logp if job_logp is not None else self.job_logp
+        ml = mach_logp if mach_logp is not None else self.mch_logp
         hm = e.h_pooled_m if self.have_hm else None
         if self.fused:
-            e.arm_selection(0, self.greedy, self.seed, 2 * counter, job_idx, self.job_logp, env.candidate, task_idx)
+            e.arm_selection(0, self.greedy, self.seed, 2 * counter, job_idx, jl, env.candidate, task_idx)
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
         else:
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
-            e.sample(prob, self.greedy, self.seed, 2 * counter, job_idx, self.job_logp, env.candidate, task_idx)
+            e.sample(prob, self.greedy, self.seed, 2 * counter, job_idx, jl, env.candidate, task_idx)
         env.observe_mfea1(task_idx)                             # -> env.m_fea1, env.mmask
+        if after_mfea1 is not None:
+            after_mfea1(env)
         if self.fused:
-            e.arm_selection(1, self.greedy, self.seed, 2 * counter + 1, mach_idx, self.mch_logp)
+            e.arm_selection(1, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
             e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
         else:
             mprob, _, _ = e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
-            e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, self.mch_logp)
+            e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
         self.have_hm = True
 
     def timing_begin(self):

@@ -55,12 +55,23 @@ class Rollout:
         self.nsteps = 0
         # trajectory record of the quantities the advantage computation needs (Appendix A of SURVEY.md, rows 17-20 and
         # 23-26): 4 scaled reward components, done, local critic values — [S,B] device tensors, S = buffer_episodes*T
-        self.collect = collect and policy == "actor"
+        # collect=True: what the advantage computation needs; collect="full": every field of the reference's ReplayBuffer
+        # in a device-resident TrajectoryBuffer
+        self.collect = bool(collect) and policy == "actor"
+        self.full = self.collect and collect == "full"
         self.S = buffer_episodes * self.T
         self.gamma, self.lam = gamma, lam
         self.buf_pos = 0
         self.last_adv = None
-        if self.collect:
+        self.traj = None
+        if self.full:
+            from .trajectory import TrajectoryBuffer
+            self.traj = TrajectoryBuffer({"n_job": n_job, "n_machine": n_machine, "buffer_size": buffer_episodes,
+                                          "env_batch": batch, "gcn_input_dim": 12}, device=dev,
+                                         obs_dtype=torch.float32 if obs_dtype == "f32" else torch.float64, alias_v_next=True)
+            tb = self.traj
+            self.buf_r, self.buf_done, self.buf_jv, self.buf_mv = tb.r4, tb.done_operation, tb._jv, tb._mv
+        elif self.collect:
             f = dict(dtype=torch.float32, device=dev)
             self.buf_r = torch.zeros(self.S, 4, batch, **f)          # mk, idle, pt, tt (scaled, pe:255-262 order)
             self.buf_done = torch.zeros(self.S, batch, **f)
@@ -91,7 +102,21 @@ class Rollout:
             env.reset(self.w3_pool[self.episode % self.w3_pool.shape[0]])  # pe:87 / run:229
             if self.actor is not None:
                 self.actor.begin_episode()
-        if self.collect:
+            if self.full:
+                self.traj.begin_episode(self.w3_pool[self.episode % self.w3_pool.shape[0]])
+        if self.full:
+            tb = self.traj
+            sl = tb.slot()
+            tb.snapshot(env, "pre")
+            self.actor.act(env, self.nsteps, self.task, sl["mach_idx"], sl["job_idx"], sl["job_v"], sl["mach_v"],
+                           job_logp=sl["job_logp"], mach_logp=sl["mach_logp"], after_mfea1=tb.after_decision)
+            env.step_record(self.task, sl["mach_idx"], sl["r4"], sl["done"])
+            tb.after_step(env)
+            self.buf_pos += 1
+            if self.buf_pos == self.S:
+                self.finish_buffer()
+                tb.reset()
+        elif self.collect:
             k = self.buf_pos                  # critic values and rewards land directly in the trajectory slots (no copies)
             self.actor.act(env, self.nsteps, self.task, self.mach, self.job, self.buf_jv[k], self.buf_mv[k])
             env.step_record(self.task, self.mach, self.buf_r[k], self.buf_done[k])

@@ -100,6 +100,11 @@ int mtfjsp_synchronize(mtfjsp_handle_t h);
 /* Library-owned observation buffers (freed by destroy) / caller-owned ones. */
 int mtfjsp_alloc_obs(mtfjsp_handle_t h, mtfjsp_obs_t *out);
 int mtfjsp_bind_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *obs);
+/* = the observation copies of ReplayBuffer.store_operation (trainer/replaybuffer.py:82-139): snapshot of the
+ * CURRENT bound observation into caller buffers of the same layout (a trajectory slot), one launch on the handle's stream.
+ * Fields of dst left NULL are skipped (status is never copied).  The adjacency stays ELL: the reference's dense
+ * [steps,B,T,T] f64 buffer is 7.6 GB per copy at B=4096 J6M6. */
+int mtfjsp_snapshot_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *dst);
 
 /* ------------------------------------------------------------------ instances */
 /* = Parallel_env.get_batch (pe:39-66): t,p [B,T,M] (negative = machine infeasible), tt [B,M,M],
