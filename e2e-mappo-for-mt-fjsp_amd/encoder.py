@@ -212,8 +212,8 @@ class ActorPair:
         if rows is not None:
             flops = 2.0 * rows * H * H * (3 if name == "gat3" else 1)
             ach = flops / avg_s / 1e12
-            kern = ("k_gat3 (3 fused GAT passes, f32 MFMA 32x32x2)" if name == "gat3" else
-                    f"k_gemm16<{name}> ([{rows},128]x[128,128] f32 MFMA 16x16x4, fused BN/aggregation prologue + stats epilogue)")
+            kern = ("k_gat3 (3 fused GAT passes, f32 MFMA 16x16x4)" if name == "gat3" else
+                    f"k_gemm16p<{name}> ([{rows},128]x[128,128] f32 MFMA 16x16x4, software-pipelined, fused BN/aggregation prologue + stats epilogue)")
             return {"kernel": kern,
                     "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_flops_per_launch": flops,

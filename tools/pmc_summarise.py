@@ -11,10 +11,9 @@ import json
 import sys
 
 FAMILY = {
-    "void k_gemm128<1, 1>": "gin_gemm_bn_relu", "void k_gemm128<2, 1>": "gin_gemm_agg", "void k_env_reg<float>": "env_step",
-    "k_heads": "heads", "void k_gemm128<3, 3>": "gat_pass_first", "void k_gemm128<0, 3>": "gat_pass",
-    "void k_gin0<float>": "gin0_agg_linear12", "k_job_pool_gather": "job_pool_gather", "k_mach_bn_pool": "mach_bn_pool",
-    "void k_mfea1<float>": "mfea1", "k_sample": "sample", "void k_env_reset<float>": "env_reset", "k_gae": "gae",
+    "void k_gemm16p<1>": "gin_gemm_bn_relu", "void k_gemm16p<2>": "gin_gemm_agg", "void k_env_reg<float>": "env_step",
+    "k_heads": "heads", "k_gat3": "gat3", "void k_gin0<float>": "gin0_agg_linear12", "k_job_pool_gather": "job_pool_gather",
+    "void k_mfea1<float>": "mfea1", "void k_env_reset<float>": "env_reset", "k_gae": "gae", "k_snapshot": "snapshot",
 }
 raw = json.load(open(sys.argv[1]))
 out = {"_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py "
