@@ -73,6 +73,7 @@ PROTOTYPES = {
     "mtfjsp_machine_actor_forward": (_I, [_VP] * 8),
     "mtfjsp_global_critic_forward": (_I, [_VP] * 7),
     "mtfjsp_sample_categorical": (_I, [_VP, _VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
+    "mtfjsp_encoder_set_bn_mode": (_I, [_VP, C.c_int32]),
     "mtfjsp_encoder_arm_selection": (_I, [_VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
     "mtfjsp_encoder_timing_begin": (_I, [_VP]),
     "mtfjsp_encoder_timing_end": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

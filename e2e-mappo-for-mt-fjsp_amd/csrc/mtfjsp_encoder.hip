@@ -138,6 +138,19 @@ __device__ __forceinline__ void stage_bn(float *s_bn, const double *stats, doubl
         s_bn[HD + tid] = beta[tid] - (float)mean * sc;
     }
 }
+// the same from workgroup-local sums (LDS, no replicas): per-instance BatchNorm
+__device__ __forceinline__ void stage_bn_local(float *s_bn, const double *st, double inv_rows, const float *gamma, const float *beta, int tid)
+{
+    if (tid < HD) {
+        const double mean = st[tid] * inv_rows;
+        double var = st[HD + tid] * inv_rows - mean * mean;
+        if (var < 0) var = 0;
+        const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
+        const float sc = rstd * gamma[tid];
+        s_bn[tid] = sc;
+        s_bn[HD + tid] = beta[tid] - (float)mean * sc;
+    }
+}
 // 16-row tile x W^T: 32 k-steps x 8 column blocks.  The operands of step s+1 are requested before the 8 products of step
 // s are issued (two register sets), so the LDS latency hides behind 256 cycles of matrix work.
 __device__ __forceinline__ void mfma_tile16(const float *ap, const float *bp, const int (&bo)[8], f32x4 (&acc)[8])
@@ -1035,6 +1048,322 @@ __global__ void k_sample(int B, int n, const float *prob, int greedy, uint64_t s
 }
 
 // =================================================================================================
+// Per-instance BatchNorm.  The reference evaluates greedily with env_batch = 1 (validate.py:60-297): every
+// BatchNorm then normalises over the rows of ONE instance (T task rows, M machine rows).  Batching those 100 serial
+// episodes means one statistic set per instance, and since all rows of an instance can be given to one workgroup, every
+// BatchNorm boundary is a workgroup-local reduction: no atomics, no grid-wide dependency, the whole GIN encoder (gin0 +
+// five products + six BatchNorms + graph pool + candidate gather) is ONE launch with one workgroup per instance, the
+// machine path (projections + 3 GAT passes + BatchNorm + pool) another.  Activations ping-pong through this instance's
+// rows of the global workspaces; the heads / selection kernels are the batched ones (they contain no BatchNorm).
+struct GinInstArgs {
+    int B, T, J;
+    const void *tfea; int feat_f64;          // [B*T,12] obs dtype
+    const int *ell_col; const float *ell_val;
+    const float *W0, *b0;                    // mlps.0.linears.0 [128,12], [128]
+    const float *Wt[5]; const float *bias[5];   // the five 128x128 products (transposed weights), in execution order
+    const float *gamma[6], *beta[6];         // BatchNorms in execution order: mlps.0.bn0, mlps.0.bn1, outer bn0, mlps.1.bn0, mlps.1.bn1, outer bn1
+    float *zA, *zB;                          // [B*T(+pad),128] workspaces
+    const int *cand;                         // [B,J] or NULL
+    float *h_pooled, *cand_feat, *h_nodes;   // [B,128], [B*J,128], optional [B*T,128]
+};
+template <typename OBS>
+__global__ __launch_bounds__(512) void k_gin_inst(GinInstArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_w = reinterpret_cast<float *>(smem);                 // 128*128, swizzled
+    float *s_a = s_w + HD * HD;                                   // 8 * 16 * LDA16
+    float *s_bn = s_a + 8 * 16 * LDA16;                           // scale | shift of the producer's BatchNorm
+    double *s_st = reinterpret_cast<double *>(s_bn + 2 * HD);     // [2][256] column sum | sum of squares (ping-pong per layer)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5, c4 = j * 4;
+    const int m = lane & 15, q = lane >> 4, qo = q & 1;
+    const int b = blockIdx.x, T = A.T;
+    const size_t r0 = (size_t)b * T;                              // first row of this instance
+    const int ntile = (T + 15) / 16;
+    const double invT = 1.0 / (double)T;
+    float *my_a = s_a + wave * 16 * LDA16;
+    const float *ap = my_a + m * LDA16 + q;
+    const float *bp = s_w + q * HD + m;
+    int bo[8];
+    for (int c = 0; c < 8; c++) bo[c] = (c ^ qo) * 16;
+    for (int i = tid; i < 512; i += 512) s_st[i] = 0.0;
+    __syncthreads();
+    // ---- layer 0: z0 = W0 agg(x) + b0 (gcn:125-153) -> zA, column sums -> s_st[0]
+    {
+        const int c = tid & 127, rg = tid >> 7;                  // column, row group (4)
+        float w[12];
+        for (int k = 0; k < 12; k++) w[k] = A.W0[c * 12 + k];
+        const float bc = A.b0[c];
+        double su = 0, sq = 0;
+        for (int v = rg; v < T; v += 4) {
+            const size_t g = r0 + v;
+            const int c0 = A.ell_col[g * 2], c1 = A.ell_col[g * 2 + 1];
+            const double v0 = (double)A.ell_val[g * 2], v1 = (double)A.ell_val[g * 2 + 1];
+            const int deg = 1 + (c0 >= 0) + (c1 >= 0);
+            float a = 0.f;
+            for (int k = 0; k < 12; k++) {
+                auto fe = [&](size_t row) { return A.feat_f64 ? (double)(float)reinterpret_cast<const double *>(A.tfea)[row * 12 + k]
+                                                              : (double)reinterpret_cast<const float *>(A.tfea)[row * 12 + k]; };
+                double acc = fe(g);
+                if (c0 >= 0) acc += v0 * fe(r0 + c0);
+                if (c1 >= 0) acc += v1 * fe(r0 + c1);
+                a = fmaf((float)(acc / (double)deg), w[k], a);
+            }
+            a += bc;
+            A.zA[g * HD + c] = a;
+            su += (double)a; sq += (double)a * (double)a;
+        }
+        atomicAdd(&s_st[c], su); atomicAdd(&s_st[HD + c], sq);
+    }
+    __syncthreads();
+    const float *in = A.zA;
+    float *out = A.zB;
+    for (int L = 0; L < 5; L++) {
+        double *st_in = s_st + (L & 1) * 256, *st_out = s_st + ((L + 1) & 1) * 256;
+        stage_w16(s_w, A.Wt[L], tid);
+        // BatchNorm feeding this product: L=0: mlps.0.bn0, 1: mlps.0.bn1, 2: outer bn0 (then aggregation), 3: mlps.1.bn0, 4: mlps.1.bn1
+        stage_bn_local(s_bn, st_in, invT, A.gamma[L], A.beta[L], tid);
+        if (tid < 256) st_out[tid] = 0.0;
+        __syncthreads();
+        const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
+        const float sh0 = s_bn[HD + c4], sh1 = s_bn[HD + c4 + 1], sh2 = s_bn[HD + c4 + 2], sh3 = s_bn[HD + c4 + 3];
+        float bias8[8];
+        for (int c = 0; c < 8; c++) bias8[c] = A.bias[L][c * 16 + m];
+        double su[8], sq[8];
+        for (int c = 0; c < 8; c++) { su[c] = 0; sq[c] = 0; }
+        for (int t = wave; t < ntile; t += 8) {
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int v = t * 16 + 2 * p + h;
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+                if (v < T) {
+                    const float4 x = *reinterpret_cast<const float4 *>(in + (r0 + v) * HD + c4);
+                    v0 = bn_relu_ss(x.x, sc0, sh0); v1 = bn_relu_ss(x.y, sc1, sh1); v2 = bn_relu_ss(x.z, sc2, sh2); v3 = bn_relu_ss(x.w, sc3, sh3);
+                    if (L == 2) {                                 // neighbour aggregation of h = relu(bn_outer0(z)) (gcn:125-149)
+                        const int c0 = A.ell_col[(r0 + v) * 2], c1 = A.ell_col[(r0 + v) * 2 + 1];
+                        double a0 = v0, a1 = v1, a2 = v2, a3 = v3;
+                        int deg = 1;
+                        if (c0 >= 0) {
+                            const double w = (double)A.ell_val[(r0 + v) * 2];
+                            const float4 y = *reinterpret_cast<const float4 *>(in + (r0 + c0) * HD + c4);
+                            a0 += w * (double)bn_relu_ss(y.x, sc0, sh0); a1 += w * (double)bn_relu_ss(y.y, sc1, sh1);
+                            a2 += w * (double)bn_relu_ss(y.z, sc2, sh2); a3 += w * (double)bn_relu_ss(y.w, sc3, sh3);
+                            deg++;
+                        }
+                        if (c1 >= 0) {
+                            const double w = (double)A.ell_val[(r0 + v) * 2 + 1];
+                            const float4 y = *reinterpret_cast<const float4 *>(in + (r0 + c1) * HD + c4);
+                            a0 += w * (double)bn_relu_ss(y.x, sc0, sh0); a1 += w * (double)bn_relu_ss(y.y, sc1, sh1);
+                            a2 += w * (double)bn_relu_ss(y.z, sc2, sh2); a3 += w * (double)bn_relu_ss(y.w, sc3, sh3);
+                            deg++;
+                        }
+                        const double inv = 1.0 / (double)deg;
+                        v0 = (float)(a0 * inv); v1 = (float)(a1 * inv); v2 = (float)(a2 * inv); v3 = (float)(a3 * inv);
+                    }
+                }
+                float *d = my_a + (2 * p + h) * LDA16 + c4;
+                *reinterpret_cast<float2 *>(d) = make_float2(v0, v1);
+                *reinterpret_cast<float2 *>(d + 2) = make_float2(v2, v3);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x4 acc[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[c][i] = bias8[c];
+            mfma_tile16(ap, bp, bo, acc);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int v = t * 16 + 4 * q + i;
+                    if (v < T) {                                  // rows >= T belong to the next instance
+                        const float x = acc[c][i];
+                        out[(r0 + v) * HD + c * 16 + m] = x;
+                        su[c] += (double)x; sq[c] += (double)x * (double)x;
+                    }
+                }
+        }
+        for (int c = 0; c < 8; c++) {
+            double a = su[c], bq = sq[c];
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            bq += __shfl_xor(bq, 16); bq += __shfl_xor(bq, 32);
+            if (q == 0) { atomicAdd(&st_out[c * 16 + m], a); atomicAdd(&st_out[HD + c * 16 + m], bq); }
+        }
+        __syncthreads();                                          // rows of `out` and st_out complete (vmcnt drained by the barrier)
+        const float *tmp = in; in = out; out = const_cast<float *>(tmp);
+    }
+    // ---- h = relu(bn_outer1(z5)); graph mean pool (gcn:192) and candidate gather (ac:197-207)
+    stage_bn_local(s_bn, s_st + 256, invT, A.gamma[5], A.beta[5], tid);     // five products: the last sums are in buffer 1
+    __syncthreads();
+    {
+        const int rg = tid >> 5, cc = (tid & 31) * 4;             // 16 row groups x 4 columns
+        const float sc0 = s_bn[cc], sc1 = s_bn[cc + 1], sc2 = s_bn[cc + 2], sc3 = s_bn[cc + 3];
+        const float sh0 = s_bn[HD + cc], sh1 = s_bn[HD + cc + 1], sh2 = s_bn[HD + cc + 2], sh3 = s_bn[HD + cc + 3];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int v = rg; v < T; v += 16) {
+            const float4 x = *reinterpret_cast<const float4 *>(in + (r0 + v) * HD + cc);
+            const float4 y = make_float4(bn_relu_ss(x.x, sc0, sh0), bn_relu_ss(x.y, sc1, sh1), bn_relu_ss(x.z, sc2, sh2), bn_relu_ss(x.w, sc3, sh3));
+            a0 += y.x; a1 += y.y; a2 += y.z; a3 += y.w;
+            if (A.h_nodes) *reinterpret_cast<float4 *>(A.h_nodes + (r0 + v) * HD + cc) = y;
+        }
+        float *part = s_a + rg * HD + cc;                         // [16][128] partial sums (tiles are free now)
+        part[0] = a0; part[1] = a1; part[2] = a2; part[3] = a3;
+        for (int jj = rg; jj < A.J; jj += 16) {
+            if (!A.cand) break;
+            const int v = A.cand[(size_t)b * A.J + jj];
+            const float4 x = *reinterpret_cast<const float4 *>(in + (r0 + v) * HD + cc);
+            *reinterpret_cast<float4 *>(A.cand_feat + ((size_t)b * A.J + jj) * HD + cc) =
+                make_float4(bn_relu_ss(x.x, sc0, sh0), bn_relu_ss(x.y, sc1, sh1), bn_relu_ss(x.z, sc2, sh2), bn_relu_ss(x.w, sc3, sh3));
+        }
+    }
+    __syncthreads();
+    if (tid < HD) {
+        float t = 0.f;
+        for (int r = 0; r < 16; r++) t += s_a[r * HD + tid];
+        A.h_pooled[(size_t)b * HD + tid] = t * (1.0f / (float)T);
+    }
+}
+
+struct GatInstArgs {
+    int B, M;
+    const void *f1, *f2; int feat_f64;       // m_fea1 [B*M,6], m_fea2 [B*M,8]
+    const float *W1, *W2, *Wt, *gat_a, *gamma, *beta;
+    float *node;                             // [B*M,128] normalised machine nodes (ac:434)
+    float *h_pooled;                         // [B,128] (ac:444)
+};
+__global__ __launch_bounds__(512) void k_gat_inst(GatInstArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_w = reinterpret_cast<float *>(smem);
+    float *s_a = s_w + HD * HD;                                   // 8 tiles
+    float *s_bn = s_a + 8 * 16 * LDA16;
+    double *s_st = reinterpret_cast<double *>(s_bn + 2 * HD);     // [256]
+    float *s_pool = reinterpret_cast<float *>(s_st + 512);        // [128]
+    float *s_feat = s_pool + HD;                                  // 8 waves * 16 rows * 8
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5, c4 = j * 4;
+    const int m = lane & 15, q = lane >> 4, qo = q & 1;
+    const int b = blockIdx.x, M = A.M, N = 2 * M;                 // tile rows of this instance: (machine, node) interleaved
+    stage_w16(s_w, A.Wt, tid);
+    if (tid < 256) s_st[tid] = 0.0;
+    if (tid < HD) s_pool[tid] = 0.f;
+    __syncthreads();
+    float *my_a = s_a + wave * 16 * LDA16;
+    float *my_f = s_feat + wave * 128;
+    const float *ap = my_a + m * LDA16 + q;
+    const float *bp = s_w + q * HD + m;
+    int bo[8];
+    for (int c = 0; c < 8; c++) bo[c] = (c ^ qo) * 16;
+    float asrc[8], adst[8];
+    for (int c = 0; c < 8; c++) { asrc[c] = A.gat_a[c * 16 + m]; adst[c] = A.gat_a[HD + c * 16 + m]; }
+    const int t = wave;                                           // 2M <= 128 rows: at most one tile per wave
+    const bool active = t * 16 < N;
+    float mv[8][2];                                               // node means of this lane's two machines, 8 column blocks
+    for (int c = 0; c < 8; c++) { mv[c][0] = 0.f; mv[c][1] = 0.f; }
+    if (active) {
+        {   // feature words of the tile: lane L < 32 -> row L/2, words 4*(L&1)..+3
+            const int r = t * 16 + (lane >> 1), k0 = (lane & 1) * 4;
+            float x[4] = {0.f, 0.f, 0.f, 0.f};
+            if (lane < 32 && r < N) {
+                const int u = r >> 1, node = r & 1, width = node ? 8 : 6;
+                for (int k = 0; k < 4; k++)
+                    if (k0 + k < width) {
+                        const size_t idx = ((size_t)b * M + u) * width + k0 + k;
+                        x[k] = A.feat_f64 ? (float)reinterpret_cast<const double *>(node ? A.f2 : A.f1)[idx]
+                                          : reinterpret_cast<const float *>(node ? A.f2 : A.f1)[idx];
+                    }
+            }
+            if (lane < 32) *reinterpret_cast<float4 *>(my_f + lane * 4) = make_float4(x[0], x[1], x[2], x[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int r = 2 * p + h;
+            const float4 fa = *reinterpret_cast<const float4 *>(my_f + r * 8), fb = *reinterpret_cast<const float4 *>(my_f + r * 8 + 4);
+            const float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+            float o[4];
+            for (int x = 0; x < 4; x++) {
+                float a = 0.f;
+                for (int k = 0; k < 8; k++) {
+                    const float w = h == 0 ? (k < 6 ? A.W1[(c4 + x) * 6 + k] : 0.f) : A.W2[(c4 + x) * 8 + k];
+                    a = fmaf(ff[k], w, a);
+                }
+                o[x] = a;
+            }
+            float *d = my_a + r * LDA16 + c4;
+            *reinterpret_cast<float2 *>(d) = make_float2(o[0], o[1]);
+            *reinterpret_cast<float2 *>(d + 2) = make_float2(o[2], o[3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll 1
+        for (int pass = 0; pass < 3; pass++) {
+            f32x4 acc[8];
+            for (int c = 0; c < 8; c++) for (int i = 0; i < 4; i++) acc[c][i] = 0.f;
+            mfma_tile16(ap, bp, bo, acc);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = 2 * u;
+                float s0 = 0.f, d0 = 0.f, d1 = 0.f;
+                for (int c = 0; c < 8; c++) { const float z0 = acc[c][i], z1 = acc[c][i + 1]; s0 += asrc[c] * z0; d0 += adst[c] * z0; d1 += adst[c] * z1; }
+                s0 = row_sum16(s0); d0 = row_sum16(d0); d1 = row_sum16(d1);
+                float e00 = s0 + d0, e01 = s0 + d1;
+                e00 = e00 > 0.f ? e00 : 0.2f * e00;
+                e01 = e01 > 0.f ? e01 : 0.2f * e01;
+                const float mx = fmaxf(e00, e01);
+                const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
+                const float inv = 1.0f / (x0 + x1);
+                const float al0 = x0 * inv, al1 = x1 * inv;
+                const int r = 4 * q + i;
+                for (int c = 0; c < 8; c++) {
+                    const float z0 = acc[c][i], z1 = acc[c][i + 1];
+                    float n0 = al0 * z0 + al1 * z1, n1 = z1;
+                    if (pass < 2) {
+                        n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;
+                        n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
+                        my_a[r * LDA16 + c * 16 + m] = n0;
+                        my_a[(r + 1) * LDA16 + c * 16 + m] = n1;
+                    } else mv[c][u] = (n0 + n1) * 0.5f;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        for (int c = 0; c < 8; c++) {                             // BatchNorm sums over the instance's M machines
+            double a = 0, bq = 0;
+            for (int u = 0; u < 2; u++)
+                if (t * 16 + 4 * q + 2 * u < N) { a += (double)mv[c][u]; bq += (double)mv[c][u] * (double)mv[c][u]; }
+            a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+            bq += __shfl_xor(bq, 16); bq += __shfl_xor(bq, 32);
+            if (q == 0) { atomicAdd(&s_st[c * 16 + m], a); atomicAdd(&s_st[HD + c * 16 + m], bq); }
+        }
+    }
+    __syncthreads();
+    stage_bn_local(s_bn, s_st, 1.0 / (double)M, A.gamma, A.beta, tid);
+    __syncthreads();
+    if (active) {
+        for (int c = 0; c < 8; c++) {
+            const int col = c * 16 + m;
+            float pl = 0.f;
+            for (int u = 0; u < 2; u++) {
+                const int r = t * 16 + 4 * q + 2 * u;
+                if (r < N) {
+                    const float y = fmaf(mv[c][u], s_bn[col], s_bn[HD + col]);            // ac:434 (no ReLU)
+                    A.node[((size_t)b * M + (r >> 1)) * HD + col] = y;
+                    pl += y;
+                }
+            }
+            pl += __shfl_xor(pl, 16); pl += __shfl_xor(pl, 32);
+            if (q == 0) atomicAdd(&s_pool[col], pl);
+        }
+    }
+    __syncthreads();
+    if (tid < HD) A.h_pooled[(size_t)b * HD + tid] = s_pool[tid] / (float)M;
+}
+static size_t inst_lds_bytes() { return (size_t)(HD * HD + 8 * 16 * LDA16 + 2 * HD) * 4 + 512 * 8 + (HD + 8 * 128) * 4 + 64; }
+
+// =================================================================================================
 // host side
 struct mtfjsp_encoder {
     mtfjsp_encoder_config_t cfg;
@@ -1054,6 +1383,7 @@ struct mtfjsp_encoder {
     double *stats = nullptr;                // [8][STAT_REP][256]: slots 0..5 GIN layers, 6/7 machine path (alternating)
     bool gin_stats_clean = false;           // slots 0..5 are zero (the job-actor heads kernel zeroes them after their last reader)
     bool gat_stats_clean[2] = {false, false};
+    int bn_mode = 0;                        // 0: BatchNorm statistics over the whole device batch; 1: per instance (validate.py semantics)
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
     struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
                          const int32_t *gather_from = nullptr; int32_t *gathered = nullptr; } fs[2];   // [0] job actor, [1] machine actor
@@ -1153,6 +1483,9 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gemm16p<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_gemm16p<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_gat3, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gin_inst<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_gin_inst<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
     *out = e;
     return MTFJSP_OK;
@@ -1391,6 +1724,50 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
     return MTFJSP_OK;
 }
 
+// per-instance BatchNorm variants (bn_mode 1): one workgroup per instance, one launch per path
+static int run_gin_inst(mtfjsp_encoder *e, const std::string &pre, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
+                        const int32_t *candidate, int J, float *h_pooled, float *cand_feat, float *h_nodes)
+{
+    const std::string P = pre + "encoder.feature_extract.";
+    auto W = [&](const std::string &k) { return e->w.at(k); };
+    auto WT = [&](const std::string &k) { return e->wt.at(k); };
+    GinInstArgs a{};
+    a.B = e->cfg.batch; a.T = e->T; a.J = candidate ? J : 0;
+    a.tfea = tasks_fea; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64; a.ell_col = ell_col; a.ell_val = ell_val;
+    a.W0 = W(P + "mlps.0.linears.0.weight"); a.b0 = W(P + "mlps.0.linears.0.bias");
+    const char *lin[5] = {"mlps.0.linears.1", "mlps.0.linears.2", "mlps.1.linears.0", "mlps.1.linears.1", "mlps.1.linears.2"};
+    const char *bn[6] = {"mlps.0.batch_norms.0", "mlps.0.batch_norms.1", "batch_norms.0", "mlps.1.batch_norms.0", "mlps.1.batch_norms.1", "batch_norms.1"};
+    for (int i = 0; i < 5; i++) { a.Wt[i] = WT(P + lin[i] + ".weight"); a.bias[i] = W(P + lin[i] + ".bias"); }
+    for (int i = 0; i < 6; i++) { a.gamma[i] = W(P + bn[i] + ".weight"); a.beta[i] = W(P + bn[i] + ".bias"); }
+    a.zA = e->zA; a.zB = e->zB; a.cand = candidate; a.h_pooled = h_pooled; a.cand_feat = cand_feat; a.h_nodes = h_nodes;
+    Timed t(e, "gin_inst");
+    if (a.feat_f64) hipLaunchKernelGGL((k_gin_inst<double>), dim3(a.B), dim3(512), inst_lds_bytes(), e->stream, a);
+    else hipLaunchKernelGGL((k_gin_inst<float>), dim3(a.B), dim3(512), inst_lds_bytes(), e->stream, a);
+    HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+static int run_gat_inst(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, float *h_pooled)
+{
+    auto W = [&](const std::string &k) { return e->w.at(k); };
+    GatInstArgs a{};
+    a.B = e->cfg.batch; a.M = e->cfg.n_machine; a.f1 = m_fea1; a.f2 = m_fea2; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
+    a.W1 = W(pre + "m_fea_1_fcl.weight"); a.W2 = W(pre + "m_fea_2_fcl.weight"); a.Wt = e->wt.at(pre + "gat_layer.W");
+    a.gat_a = W(pre + "gat_layer.a"); a.gamma = W(pre + "bn.weight"); a.beta = W(pre + "bn.bias");
+    a.node = e->node; a.h_pooled = h_pooled;
+    Timed t(e, "gat_inst");
+    hipLaunchKernelGGL(k_gat_inst, dim3(a.B), dim3(512), inst_lds_bytes(), e->stream, a);
+    HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+// = evaluating with env_batch 1 per instance (validate.py:60-297): mode 1 makes every BatchNorm of the two
+// actor forwards normalise over the rows of ONE instance; mode 0 (default) over the whole device batch (training rollout).
+extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance)
+{
+    if (!e || per_instance < 0 || per_instance > 1) return MTFJSP_ERR_ARG;
+    e->bn_mode = per_instance;
+    return MTFJSP_OK;
+}
+
 static void arm_sampling(mtfjsp_encoder *e, int which, HeadArgs &ha)
 {
     mtfjsp_encoder::FusedSample &f = e->fs[which];
@@ -1420,7 +1797,8 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     const int B = e->cfg.batch, J = e->cfg.n_job;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
-    rc = run_gin(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes);
+    rc = e->bn_mode ? run_gin_inst(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
+                    : run_gin(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes);
     if (rc) return rc;
     // ---- heads (ac:205-293): score = L2 tanh(L1 tanh(Wa cand + Wb pooled + Wc hm + b0))
     const float *hm = h_m_prev;
@@ -1440,8 +1818,10 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         ha.Wc1i = WI("job_actor.job_critic.linears.1.weight"); ha.bc1 = W("job_actor.job_critic.linears.1.bias");
         ha.wc2 = W("job_actor.job_critic.linears.2.weight"); ha.bc2 = W("job_actor.job_critic.linears.2.bias");
         ha.mask = job_mask; ha.scale = 1.0f; ha.prob = prob; ha.value = job_v;
-        ha.zero_stats = e->stats; ha.zero_count = 6 * STAT_REP * 256;    // every GIN accumulator has been consumed by now
-        e->gin_stats_clean = true;
+        if (!e->bn_mode) {
+            ha.zero_stats = e->stats; ha.zero_count = 6 * STAT_REP * 256;    // every GIN accumulator has been consumed by now
+            e->gin_stats_clean = true;
+        }
         arm_sampling(e, 0, ha);
 #ifdef MTFJSP_STAMP
         static unsigned long long *d_st = nullptr;
@@ -1477,16 +1857,20 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     int slot = 0;
-    rc = run_gat(e, "machine_actor.", m_fea1, m_fea2, nullptr, &slot);
+    rc = e->bn_mode ? run_gat_inst(e, "machine_actor.", m_fea1, m_fea2, h_pooled) : run_gat(e, "machine_actor.", m_fea1, m_fea2, nullptr, &slot);
     if (rc) return rc;
     {
         Timed t(e, "heads");
         HeadArgs ha{};
-        ha.B = B; ha.R = M; ha.X = e->node; ha.pooled = nullptr; ha.other = h_pooled_o;
-        ha.xbn_stats = e->stats + (6 + slot) * STAT_REP * 256; ha.xbn_gamma = W("machine_actor.bn.weight"); ha.xbn_beta = W("machine_actor.bn.bias");
-        ha.xbn_inv_rows = 1.0 / (double)R; ha.pooled_out = h_pooled;
-        ha.zero_stats = e->stats + (6 + (slot ^ 1)) * STAT_REP * 256; ha.zero_count = STAT_REP * 256;   // the slot of the next machine forward
-        e->gat_stats_clean[slot ^ 1] = true;
+        ha.B = B; ha.R = M; ha.X = e->node; ha.other = h_pooled_o;
+        if (e->bn_mode) ha.pooled = h_pooled;                     // k_gat_inst already normalised and pooled the nodes per instance
+        else {
+            ha.pooled = nullptr;
+            ha.xbn_stats = e->stats + (6 + slot) * STAT_REP * 256; ha.xbn_gamma = W("machine_actor.bn.weight"); ha.xbn_beta = W("machine_actor.bn.bias");
+            ha.xbn_inv_rows = 1.0 / (double)R; ha.pooled_out = h_pooled;
+            ha.zero_stats = e->stats + (6 + (slot ^ 1)) * STAT_REP * 256; ha.zero_count = STAT_REP * 256;   // the slot of the next machine forward
+            e->gat_stats_clean[slot ^ 1] = true;
+        }
         arm_sampling(e, 1, ha);
         ha.W0i = WI("machine_actor.m_policy.linears.0.weight"); ha.b0 = W("machine_actor.m_policy.linears.0.bias");
         ha.W1i = WI("machine_actor.m_policy.linears.1.weight"); ha.b1 = W("machine_actor.m_policy.linears.1.bias");

@@ -16,7 +16,7 @@ from . import capi
 
 H = 128
 FAMILIES = ["gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg", "job_pool_gather", "heads", "head_gemm", "gat3", "mach_bn_pool",
-            "sample", "small"]
+            "sample", "small", "gin_inst", "gat_inst"]
 
 
 def available():
@@ -132,6 +132,11 @@ class Encoder:
             logp_out.data_ptr() if logp_out is not None else 0, gather_from.data_ptr() if gather_from is not None else 0,
             gathered_out.data_ptr() if gathered_out is not None else 0), self.h, enc=True)
 
+    def set_bn_mode(self, per_instance):
+        """per_instance=True: every BatchNorm of the actor forwards normalises over the rows of one instance (= the reference's
+        greedy evaluation with env_batch 1, validate.py:60-297); False (default): over the whole device batch"""
+        capi.check(self.L.mtfjsp_encoder_set_bn_mode(self.h, 1 if per_instance else 0), self.h, enc=True)
+
     def arm_selection(self, which, greedy, seed, counter, idx_out, logp_out=None, gather_from=None, gathered_out=None):
         """fuse the action selection of the next job (which=0) / machine (which=1) actor forward into its heads kernel; same
         stream and outputs as sample() on that forward's prob"""
@@ -174,9 +179,10 @@ class ActorPair:
         self.have_hm = False                                    # run:280 h_mch_pooled = None
 
     def act(self, env, counter, task_idx, mach_idx, job_idx, jv_out=None, mv_out=None, job_logp=None, mach_logp=None,
-            after_mfea1=None):
+            after_mfea1=None, force=None):
         """one joint decision for every instance; the optional outputs let a trajectory buffer receive action indices,
-        log-probabilities and critic values in place (no copies)"""
+        log-probabilities and critic values in place (no copies).  force = (task [B], machine [B]) int32 tensors: replay
+        these decisions instead of the selected ones (teacher forcing; the forwards and their outputs are unchanged)."""
         e = self.enc
         jl = job_logp if job_logp is not None else self.job_logp
         ml = mach_logp if mach_logp is not None else self.mch_logp
@@ -187,6 +193,8 @@ class ActorPair:
         else:
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
             e.sample(prob, self.greedy, self.seed, 2 * counter, job_idx, jl, env.candidate, task_idx)
+        if force is not None:
+            task_idx.copy_(force[0])
         env.observe_mfea1(task_idx)                             # -> env.m_fea1, env.mmask
         if after_mfea1 is not None:
             after_mfea1(env)
@@ -196,6 +204,8 @@ class ActorPair:
         else:
             mprob, _, _ = e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
             e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
+        if force is not None:
+            mach_idx.copy_(force[1])
         self.have_hm = True
 
     def timing_begin(self):

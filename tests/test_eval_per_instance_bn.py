@@ -1,0 +1,166 @@
+"""SURVEY.md §8f N3 — batched greedy evaluation with per-instance BatchNorm statistics.
+
+The reference evaluates with env_batch = 1 (validate.py:60-297), so each training-mode BatchNorm sees the rows of one
+instance only.  tests/golden/eval_b1_*.npz hold the outputs of the REFERENCE actors fed one instance at a time
+(oracle/ref_harness/gen_golden_eval.py); inputs and weights are those of the encoder fixtures.
+ * CPU: the fp32 oracle restatement, called per instance, matches (pins the oracle for batch 1);
+ * GPU: ONE batched forward of the HIP encoder in bn_mode 1 over the same 8 instances matches every per-instance output.
+"""
+import os
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+NAMES = ["j6m6e2_rand", "j6m6e2_top1"]
+# BatchNorm over the M = 6 machine rows of ONE instance (ac:434, eps 1e-5) divides by a standard deviation that can be as
+# small as sqrt(eps): f32 round-off of the GAT output is amplified up to ~300x, so the normalised machine embedding of
+# any two f32 implementations (the reference on another BLAS included) agrees to ~5e-3 only; probabilities still to 1e-4.
+HM_ATOL = 5e-3
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_per_instance_matches_reference_batch1(name):
+    from oracle import encoder_oracle as eo
+    g = np.load(os.path.join(GOLDEN, "encoder_" + name + ".npz"))
+    f = np.load(os.path.join(GOLDEN, "eval_b1_" + name + ".npz"))
+    J, M, E, NB = [int(x) for x in f["meta"]]
+    T = J * M
+    ja, ma = eo.split_weights(g)
+    for s in f["steps"]:
+        p = f"s{int(s)}_"
+        col, val = eo.ell_from_dense(g[p + "adj"])
+        hm = g[p + "h_m_in"]
+        for b in range(NB):
+            o = eo.job_actor_forward(ja, g[p + "tfea"][b * T:(b + 1) * T], col[b:b + 1], val[b:b + 1], g[p + "cand"][b:b + 1],
+                                     g[p + "mask"][b:b + 1], hm if hm.size == 0 else hm[b:b + 1], 1, T)
+            np.testing.assert_allclose(o["prob"], f[p + "job_prob"][b:b + 1], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(o["h_pooled"], f[p + "h_o"][b:b + 1], rtol=0, atol=2e-4)
+            mo = eo.machine_actor_forward(ma, g[p + "mfea1"][b:b + 1], g[p + "mfea2"][b:b + 1], f[p + "h_o"][b:b + 1],
+                                          g[p + "mmask"][b:b + 1], 1, M)
+            np.testing.assert_allclose(mo["prob"], f[p + "mch_prob"][b:b + 1], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(mo["h_pooled"], f[p + "h_m"][b:b + 1], rtol=0, atol=HM_ATOL)
+    # and the per-instance statistics really differ from the batched ones (the fixture would otherwise prove nothing)
+    p = f"s{int(f['steps'][-1])}_"
+    assert np.abs(f[p + "h_o"] - g[p + "h_o"][:NB]).max() > 1e-3
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("obs", ["f32", "f64"])
+def test_hip_batched_per_instance_bn_matches_reference_batch1(name, obs):
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    from oracle import encoder_oracle as eo
+    g = np.load(os.path.join(GOLDEN, "encoder_" + name + ".npz"))
+    f = np.load(os.path.join(GOLDEN, "eval_b1_" + name + ".npz"))
+    J, M, E, NB = [int(x) for x in f["meta"]]
+    T = J * M
+    ja, ma = eo.split_weights(g)
+    enc = enc_mod.Encoder(J, M, NB, obs_dtype=obs)
+    enc.load_weights(ja, ma)
+    enc.set_bn_mode(True)
+    odt = torch.float32 if obs == "f32" else torch.float64
+    _t = lambda a, dt=None: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).cuda()
+    for s in f["steps"]:
+        p = f"s{int(s)}_"
+        col, val = eo.ell_from_dense(g[p + "adj"][:NB])
+        hm = g[p + "h_m_in"]
+        idx = torch.zeros(NB, dtype=torch.int32, device="cuda"); task = torch.zeros_like(idx); logp = torch.zeros(NB, device="cuda")
+        cand_t = _t(g[p + "cand"][:NB].astype(np.int32))            # must outlive the forward: arm_selection keeps the raw pointer
+        enc.arm_selection(0, True, 0, 0, idx, logp, cand_t, task)
+        prob, h_o, job_v = enc.job_actor_forward(
+            _t(g[p + "tfea"][:NB * T], odt), _t(col.reshape(NB * T, 2).astype(np.int32)), _t(val.reshape(NB * T, 2).astype(np.float32)),
+            _t(g[p + "cand"][:NB].astype(np.int32)), _t(g[p + "mask"][:NB].astype(np.uint8)),
+            None if hm.size == 0 else _t(hm[:NB].astype(np.float32)))
+        torch.cuda.synchronize()
+        scale = max(1.0, float(np.abs(f[p + "h_o"]).max()))
+        np.testing.assert_allclose(prob.cpu().numpy(), f[p + "job_prob"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(h_o.cpu().numpy(), f[p + "h_o"], rtol=0, atol=1e-4 * scale)
+        np.testing.assert_allclose(job_v.cpu().numpy(), f[p + "job_v"], rtol=1e-3, atol=1e-3)
+        assert np.array_equal(idx.cpu().numpy(), f[p + "job_index"].astype(np.int32))
+        assert np.array_equal(task.cpu().numpy(), f[p + "task_index"].astype(np.int32))
+        mprob, h_m, mach_v = enc.machine_actor_forward(_t(g[p + "mfea1"][:NB], odt), _t(g[p + "mfea2"][:NB], odt),
+                                                       _t(f[p + "h_o"].astype(np.float32)),
+                                                       _t(g[p + "mmask"][:NB].reshape(NB, M).astype(np.uint8)))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(mprob.cpu().numpy(), f[p + "mch_prob"], rtol=0, atol=1e-4)
+        dh = np.abs(h_m.cpu().numpy() - f[p + "h_m"])
+        assert dh.max() < 4 * HM_ATOL and np.median(dh) < 5e-4, (dh.max(), np.median(dh))   # ill-conditioned columns: see HM_ATOL
+        # the critic head amplifies those columns further: the torch oracle itself is 7e-3 off the reference on top1 (|v| ~ 7)
+        vtol = 1e-3 if name.endswith("rand") else 5e-2
+        np.testing.assert_allclose(mach_v.cpu().numpy(), f[p + "mach_v"], rtol=0, atol=vtol)
+    # switching back restores batch statistics
+    enc.set_bn_mode(False)
+    p = f"s{int(f['steps'][-1])}_"
+    col, val = eo.ell_from_dense(g[p + "adj"][:NB])
+    hm = g[p + "h_m_in"]
+    prob, _, _ = enc.job_actor_forward(
+        _t(g[p + "tfea"][:NB * T], odt), _t(col.reshape(NB * T, 2).astype(np.int32)), _t(val.reshape(NB * T, 2).astype(np.float32)),
+        _t(g[p + "cand"][:NB].astype(np.int32)), _t(g[p + "mask"][:NB].astype(np.uint8)),
+        None if hm.size == 0 else _t(hm[:NB].astype(np.float32)))
+    o = eo.job_actor_forward(ja, g[p + "tfea"][:NB * T], col, val, g[p + "cand"][:NB], g[p + "mask"][:NB],
+                             hm if hm.size == 0 else hm[:NB], NB, T)
+    np.testing.assert_allclose(prob.cpu().numpy(), o["prob"], rtol=0, atol=1e-4)
+
+
+def _eval_setup(tag):
+    from oracle import encoder_oracle as eo
+    v = np.load(os.path.join(GOLDEN, "validate_j6m6e2_eval12.npz"))
+    g = np.load(os.path.join(GOLDEN, "trace_j6m6e2_eval16_free.npz"))
+    w = np.load(os.path.join(GOLDEN, f"encoder_j6m6e2_{tag}.npz"))
+    J, M, E, NB = [int(x) for x in v["meta"]]
+    args = {"n_job": J, "n_machine": M, "n_edge": E, "weight_mk": float(v["cfg_w"][0]), "weight_ec": float(v["cfg_w"][1]),
+            "weight_tt": float(v["cfg_w"][2])}
+    return v, g, eo.split_weights(w), args, (J, M, E, NB)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["rand", "top1"])
+def test_batched_evaluation_replays_reference_validate(tag):
+    """The reference's validate_cost_gcn_jointActor_GAT (env_batch 1, greedy) was run on 12 instances and its 72 decisions,
+    the probabilities behind them and its results recorded (tests/golden/validate_j6m6e2_eval12.npz).  Its greedy choice
+    among machines whose scores tie is decided by f32 round-off (e.g. 0.1666666 x5 vs 0.1666668), so the schedules of a
+    second implementation may legitimately differ.  Teacher-forced on the recorded decisions, ONE batched rollout must
+    (a) produce the reference's probabilities in every visited state (2e-4 / 1e-4; per-instance BatchNorm), (b) always have its
+    own greedy choice among the reference's maximisers up to that noise, and (c) end with exactly the reference's final
+    costs, objective and summed raw rewards."""
+    import mtfjsp_amd  # noqa: F401
+    ev = import_module("e2e-mappo-for-mt-fjsp_amd.evaluate")
+    v, g, weights, args, (J, M, E, NB) = _eval_setup(tag)
+    ref_p = v[tag + "_probs"]                                       # [NB, T, 2, J]
+    worst = {"job": 0.0, "mch": 0.0, "regret": 0.0}
+
+    def on_step(s, job_prob, mch_prob):
+        jp, mp = job_prob.cpu().numpy(), mch_prob.cpu().numpy()
+        worst["job"] = max(worst["job"], np.abs(jp - ref_p[:, s, 0]).max())
+        worst["mch"] = max(worst["mch"], np.abs(mp - ref_p[:, s, 1]).max())
+        idx = np.arange(NB)
+        for mine, ref in ((jp, ref_p[:, s, 0]), (mp, ref_p[:, s, 1])):
+            worst["regret"] = max(worst["regret"], (ref.max(1) - ref[idx, mine.argmax(1)]).max())
+
+    cost, final4, obj = ev.validate_cost_batched(weights, g["t"][:NB], g["p"][:NB], g["tt"][:NB], g["edge"][:NB], args,
+                                                 forced_actions=v[tag + "_actions"], on_step=on_step)
+    # the job actor consumes the previous machine embedding (ill-conditioned per-instance BatchNorm, see HM_ATOL): 2e-4
+    assert worst["job"] < 2e-4 and worst["mch"] < 1e-4, worst
+    assert worst["regret"] < 1e-5, worst
+    np.testing.assert_allclose(final4, v[tag + "_final4"], rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(obj, v[tag + "_objective"], rtol=1e-12)
+    got = np.stack([cost[k] for k in ("opr_Gt", "opr_mk", "opr_idleT", "opr_pt", "opr_transT")], 1)
+    np.testing.assert_allclose(got, v[tag + "_cumsum"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_batched_evaluation_free_running():
+    """free-running greedy evaluation: finishes with valid schedules; instances without an early tie reproduce the reference
+    exactly, and the mean objective over the set is within 3 % of the reference's (tie-breaking noise, not a bias)."""
+    import mtfjsp_amd  # noqa: F401
+    ev = import_module("e2e-mappo-for-mt-fjsp_amd.evaluate")
+    v, g, weights, args, (J, M, E, NB) = _eval_setup("top1")
+    cost, final4, obj = ev.validate_cost_batched(weights, g["t"][:NB], g["p"][:NB], g["tt"][:NB], g["edge"][:NB], args)
+    same = np.all(np.abs(final4 - v["top1_final4"]) < 1e-9, axis=1)
+    assert same.sum() >= 3 and np.isfinite(final4).all() and (final4[:, 0] > 0).all()
+    np.testing.assert_allclose(obj[same], v["top1_objective"][same], rtol=1e-12)
+    assert abs(obj.mean() / v["top1_objective"].mean() - 1.0) < 0.03
