@@ -87,6 +87,25 @@ class DeviceBatchEnv:
         assert shop.dtype == torch.int32
         capi.check(self.L.mtfjsp_load_instances(self.h, t.data_ptr(), p.data_ptr(), tt.data_ptr(), shop.data_ptr()), self.h)
 
+    def generate_instances(self, seed, first_instance=0, scope=None):
+        """draw this batch's instances ON the device: the distribution of the reference's Instance_Dataset
+        (instances.DEFAULT_SCOPE = instance/config_ins.json), Philox keyed by (seed, first_instance + b); nothing is uploaded"""
+        from .instances import DEFAULT_SCOPE
+        sc = dict(DEFAULT_SCOPE)
+        if scope:
+            sc.update(scope)
+        s9 = np.array([sc["t_low"], sc["t_high"], sc["p_low"], sc["p_high"], sc["weight_low"], sc["weight_high"],
+                       sc["transT_in_low"], sc["transT_in_high"], sc["transT_out_high"]], np.float64)
+        capi.check(self.L.mtfjsp_generate_instances(self.h, int(seed), int(first_instance), s9.ctypes.data), self.h)
+
+    def read_instances(self):
+        """-> (t, p [B,T,M], tt [B,M,M], edge [B,E,M/E]) host arrays of the loaded / generated instances"""
+        B, T, M, E = self.B, self.T, self.M, self.E
+        t = np.zeros((B, T, M)); p = np.zeros((B, T, M)); tt = np.zeros((B, M, M)); shop = np.zeros((B, M), np.int32)
+        capi.check(self.L.mtfjsp_read_instances_host(self.h, t.ctypes.data, p.ctypes.data, tt.ctypes.data, shop.ctypes.data), self.h)
+        edge = np.stack([np.stack([np.flatnonzero(shop[b] == e) for e in range(E)]) for b in range(B)]).astype(np.int64)
+        return t, p, tt, edge
+
     def scaler_init(self):
         capi.check(self.L.mtfjsp_scaler_init(self.h), self.h)
 

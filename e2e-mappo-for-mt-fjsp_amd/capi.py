@@ -44,6 +44,8 @@ PROTOTYPES = {
     "mtfjsp_alloc_obs": (_I, [_VP, C.POINTER(Obs)]),
     "mtfjsp_bind_obs": (_I, [_VP, C.POINTER(Obs)]),
     "mtfjsp_snapshot_obs": (_I, [_VP, C.POINTER(Obs)]),
+    "mtfjsp_generate_instances": (_I, [_VP, _U64, _U64, _VP]),
+    "mtfjsp_read_instances_host": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_load_instances": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_load_instances_host": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_scaler_init": (_I, [_VP]),

@@ -1089,6 +1089,68 @@ __global__ __launch_bounds__(256) void k_snapshot(SnapArgs A)
     }
 }
 
+// On-device instance generator (distribution of instance/generate_allsize_mofjsp_dataset.py:133-296, values of
+// instance/config_ins.json): per task mean duration / power uniform, per (task, machine) a uniform weight, a uniform number
+// k in [0,M) of machines made infeasible (a uniformly random k-subset: partial Fisher-Yates), t and p negative there;
+// transport times uniform by shop distance, symmetric, zero diagonal.  Philox counters (seed; instance, task | pair), so a
+// shard generates exactly its own instances; the legacy MT19937 stream of the host generator is not reproduced (parity is
+// distributional, instances.py keeps the bit-exact host path).
+struct GenScope { double t_low, t_high, p_low, p_high, w_low, w_high, in_low, in_high, out_high; };
+__device__ __forceinline__ double u01(uint32_t a, uint32_t b) { return ((double)(((uint64_t)a << 21) ^ (uint64_t)(b >> 11)) + 0.5) * (1.0 / 9007199254740992.0); }
+__global__ void k_generate(int B, int T, int M, int E, uint64_t seed, uint64_t first_instance, GenScope S, double *t, double *p, double *tt, int *shop)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * T) {
+        const int b = i / T, v = i % T;
+        const uint64_t inst = first_instance + (uint64_t)b;
+        uint32_t c[4] = {(uint32_t)inst, (uint32_t)(inst >> 32), (uint32_t)v, 0x67656e31u};
+        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        const double avg_t = S.t_low + (S.t_high - S.t_low) * u01(c[0], c[1]);
+        const double avg_p = S.p_low + (S.p_high - S.p_low) * u01(c[2], c[3]);
+        uint64_t bad = 0;                                         // k-subset of infeasible machines (M <= 64)
+        {
+            uint32_t d[4] = {(uint32_t)inst, (uint32_t)(inst >> 32), (uint32_t)v, 0x67656e32u};
+            philox4x32(d, (uint32_t)seed, (uint32_t)(seed >> 32));
+            const int k = (int)(u01(d[0], d[1]) * M);             // [0, M)
+            int perm[64];
+            for (int m = 0; m < M; m++) perm[m] = m;
+            uint32_t ctr = 0;
+            for (int j = 0; j < k; j++) {
+                uint32_t e[4] = {(uint32_t)inst, (uint32_t)v, ctr++, 0x67656e33u};
+                philox4x32(e, (uint32_t)seed, (uint32_t)(seed >> 32));
+                const int r = j + (int)(u01(e[0], e[1]) * (M - j));
+                const int tmp = perm[j]; perm[j] = perm[r]; perm[r] = tmp;
+                bad |= 1ull << perm[j];
+            }
+        }
+        for (int m = 0; m < M; m++) {
+            uint32_t e[4] = {(uint32_t)inst, (uint32_t)v, (uint32_t)m, 0x67656e34u};
+            philox4x32(e, (uint32_t)seed, (uint32_t)(seed >> 32));
+            double tv = avg_t * (S.w_low + (S.w_high - S.w_low) * u01(e[0], e[1]));
+            double pv = avg_p * (S.w_low + (S.w_high - S.w_low) * u01(e[2], e[3]));
+            if ((bad >> m) & 1ull) { tv = -tv; pv = -pv; }
+            t[((size_t)b * T + v) * M + m] = tv;
+            p[((size_t)b * T + v) * M + m] = pv;
+        }
+    }
+    if (i < B * M * M) {
+        const int b = i / (M * M), r = (i / M) % M, cc = i % M;
+        const int per = M / E, sr = r / per < E ? r / per : E - 1, scc = cc / per < E ? cc / per : E - 1;
+        double val = 0.0;
+        if (r != cc) {
+            const int lo = r < cc ? r : cc, hi = r < cc ? cc : r;   // one draw per unordered pair: symmetric
+            const uint64_t inst = first_instance + (uint64_t)b;
+            uint32_t e[4] = {(uint32_t)inst, (uint32_t)(inst >> 32), (uint32_t)(lo * M + hi), 0x67656e35u};
+            philox4x32(e, (uint32_t)seed, (uint32_t)(seed >> 32));
+            const int d = sr > scc ? sr - scc : scc - sr;
+            const double u = u01(e[0], e[1]);
+            val = d == 0 ? S.in_low + (S.in_high - S.in_low) * u : S.in_high * d + (S.out_high * d - S.in_high * d) * u;
+        }
+        tt[i] = val;
+        if (r == 0) shop[b * M + cc] = scc;
+    }
+}
+
 // =================================================================================================
 // host side
 struct mtfjsp_env {
@@ -1274,6 +1336,37 @@ extern "C" int mtfjsp_load_instances_host(mtfjsp_handle_t h, const double *t, co
 {
     if (!h || !t || !p || !tt || !shop) return MTFJSP_ERR_ARG;
     return load_common(h, t, p, tt, shop, hipMemcpyHostToDevice);
+}
+
+// = Instance_Dataset generation (generate…py:133-296) directly into the handle's instance arrays: no host->device upload
+// (SURVEY §8f N4).  scope9 = {t_low, t_high, p_low, p_high, weight_low, weight_high, transT_in_low, transT_in_high,
+// transT_out_high}; first_instance offsets the Philox counter so that shards / successive batches draw distinct instances.
+extern "C" int mtfjsp_generate_instances(mtfjsp_handle_t h, uint64_t seed, uint64_t first_instance, const double *scope9)
+{
+    if (!h || !scope9) return MTFJSP_ERR_ARG;
+    const int B = h->cfg.batch, T = h->T, M = h->cfg.n_machine, E = h->cfg.n_edge;
+    if (E < 1 || M % E != 0) { h->err = "n_machine must be divisible by n_edge"; return MTFJSP_ERR_ARG; }
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    GenScope S{scope9[0], scope9[1], scope9[2], scope9[3], scope9[4], scope9[5], scope9[6], scope9[7], scope9[8]};
+    const int n = B * (T > M * M ? T : M * M);
+    hipLaunchKernelGGL(k_generate, dim3((n + 127) / 128), dim3(128), 0, h->stream, B, T, M, E, seed, first_instance, S, h->t, h->p, h->tt, h->shop);
+    hipLaunchKernelGGL(k_prepare, dim3((B * T + 127) / 128), dim3(128), 0, h->stream, B, T, M, h->t, h->p, h->cst, h->mean3);
+    HIPCHK(h, hipGetLastError());
+    h->loaded = true; h->was_reset = false;
+    return MTFJSP_OK;
+}
+// instance arrays back to the host (t, p [B,T,M] f64; tt [B,M,M] f64; shop [B,M] i32) — e.g. to export a generated set in
+// the reference's pickle layout
+extern "C" int mtfjsp_read_instances_host(mtfjsp_handle_t h, double *t, double *p, double *tt, int32_t *shop)
+{
+    if (!h || !t || !p || !tt || !shop) return MTFJSP_ERR_ARG;
+    if (!h->loaded) { h->err = "no instances loaded"; return MTFJSP_ERR_STATE; }
+    const size_t B = h->cfg.batch, T = h->T, M = h->cfg.n_machine;
+    int rc = mtfjsp_copy_to_host(h, t, h->t, B * T * M * 8);
+    if (!rc) rc = mtfjsp_copy_to_host(h, p, h->p, B * T * M * 8);
+    if (!rc) rc = mtfjsp_copy_to_host(h, tt, h->tt, B * M * M * 8);
+    if (!rc) rc = mtfjsp_copy_to_host(h, shop, h->shop, B * M * 4);
+    return rc;
 }
 
 static int scaler_launch(mtfjsp_env *h, int full, const uint8_t *mask = nullptr)

@@ -72,6 +72,14 @@ def generate_instances(samples, n_job=6, n_machine=6, n_edge=2, seed=None, scope
     return t, p, tt, edge
 
 
+def export_pickle(path, t, p, tt, edge):
+    """write a generated set in the reference's dataset layout (generate…py:272-275 / 277-290): a pickled list
+    [t, p, transT, edge] of numpy arrays, which `Instance_Dataset(dataset_pth=...)` loads unchanged"""
+    import pickle
+    with open(path, "wb") as f:
+        pickle.dump([np.asarray(t), np.asarray(p), np.asarray(tt), np.asarray(edge)], f)
+
+
 def random_weights(batch, rng=None, kind="01", config_weights=(0.4, 0.4, 0.2)):
     """Reward weights w3 [B,3] exactly as env.generate_random_weights (env:1253-1270): three python
     `random.uniform(0,1)` draws per instance in instance order, normalised by their numpy sum."""

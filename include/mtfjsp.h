@@ -114,6 +114,13 @@ int mtfjsp_load_instances(mtfjsp_handle_t h, const double *t, const double *p, c
                           const int32_t *shop_of_machine);
 int mtfjsp_load_instances_host(mtfjsp_handle_t h, const double *t_host, const double *p_host,
                                const double *tt_host, const int32_t *shop_host);
+/* = Instance_Dataset generation (instance/generate_allsize_mofjsp_dataset.py:133-296) ON the device, straight into the
+ * handle's instance arrays: same distributions (scope9 = t_low, t_high, p_low, p_high, weight_low,
+ * weight_high, transT_in_low, transT_in_high, transT_out_high of instance/config_ins.json), Philox stream keyed by
+ * (seed, first_instance + b) — distributional parity only, the legacy MT19937 stream stays in the host generator. */
+int mtfjsp_generate_instances(mtfjsp_handle_t h, uint64_t seed, uint64_t first_instance, const double *scope9);
+/* t, p [B,T,M] f64, tt [B,M,M] f64, shop [B,M] i32 of the loaded / generated instances, to host memory. */
+int mtfjsp_read_instances_host(mtfjsp_handle_t h, double *t, double *p, double *tt, int32_t *shop);
 
 /* = init_RewardScaling_sameBATCH (pe:70-85) and RewardScaling.reset() per episode (run:283-284). */
 int mtfjsp_scaler_init(mtfjsp_handle_t h);
