@@ -9,7 +9,7 @@ LIB = os.path.join(PKG, "libmtfjsp.so")
 SOURCES = ["mtfjsp_env.hip", "mtfjsp_encoder.hip"]
 # -ffp-contract=off: the scheduling state must follow the reference's binary64 operation order exactly
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-         "-Wall", "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+         "-Wall"]
 
 
 def hipcc():

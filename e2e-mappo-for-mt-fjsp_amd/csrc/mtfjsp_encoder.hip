@@ -266,7 +266,6 @@ __global__ __launch_bounds__(512) void k_gemm16p(GemmArgs A)
     float *s_w = reinterpret_cast<float *>(smem);                 // 128*128, swizzled
     float *s_a = s_w + HD * HD;                                   // 8 * 16 * LDA16
     float *s_bn = s_a + 8 * 16 * LDA16;                           // scale | shift
-    int *s_ctr = reinterpret_cast<int *>(s_bn + 2 * HD);
     double *s_red = reinterpret_cast<double *>(s_a);              // reused after the last tile
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 31, h = lane >> 5, c4 = j * 4;           // load / transform mapping: rows 2p+h, 4 columns
@@ -473,8 +472,7 @@ __global__ __launch_bounds__(512) void k_gat3(GatArgs A)
     float *s_w = reinterpret_cast<float *>(smem);                 // 128*128, swizzled
     float *s_a = s_w + HD * HD;                                   // 8 * 16 * LDA16
     float *s_bn = s_a + 8 * 16 * LDA16;
-    int *s_ctr = reinterpret_cast<int *>(s_bn + 2 * HD);
-    float *s_feat = reinterpret_cast<float *>(s_ctr + 16);        // 8 waves * 16 rows * 8
+    float *s_feat = s_bn + 2 * HD + 16;                           // 8 waves * 16 rows * 8
     double *s_red = reinterpret_cast<double *>(s_a);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 31, h = lane >> 5, c4 = j * 4;

@@ -221,7 +221,7 @@ static size_t env_reset_lds_bytes(int T, bool f32) { return (size_t)3 * T * 8 + 
 // so only those are rewritten; the per-task state needed for decisions (link, st, ft, dur) and for the two
 // order-sensitive sums (pt_est for numpy's pairwise sum, st/ft for the ordered idle sum) is staged in LDS.
 template <typename OBS>
-__global__ __launch_bounds__(WAVE, 8) void k_env_step(EnvParams P)
+__global__ __launch_bounds__(WAVE, 4) void k_env_step(EnvParams P)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int b = blockIdx.x;
