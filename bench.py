@@ -46,6 +46,36 @@ def pmc_traffic(family):
         return None
 
 
+def env_kernel_large_batch(J, M, E, device, B=262144, episodes=2):
+    """The step kernel alone at a batch that fills the chip (at 4096 instances all waves are resident at once and a launch
+    lasts as long as ONE wave's dependent chain): on-device random valid actions, HIP events around every step launch."""
+    from importlib import import_module
+    be = import_module("e2e-mappo-for-mt-fjsp_amd.batch_env")
+    T = J * M
+    env = be.DeviceBatchEnv(J, M, E, B, obs_dtype="f32", device=device)
+    env.generate_instances(seed=123)                            # on-device generator: nothing to upload
+    env.scaler_init()
+    w3 = torch.full((B, 3), 1.0 / 3, dtype=torch.float64, device=env.device)
+    a = torch.zeros(B, dtype=torch.int32, device=env.device); m = torch.zeros_like(a)
+    for ep in range(episodes + 1):
+        if ep == 1:
+            torch.cuda.synchronize(); env.timing_begin()
+        env.reset(w3)
+        for s in range(T):
+            env.random_actions(7, ep * T + s, a, m)
+            env.step(a, m)
+    torch.cuda.synchronize()
+    ms, n = env.timing_end()
+    assert bool(env.info[:, 1].all()) and int((env.status & 0x100).sum()) == 0
+    sec = ms / n * 1e-3
+    ach = B * env_bytes(J, M) / sec / 1e9
+    del env
+    torch.cuda.empty_cache()
+    return {"kernel": "k_env_reg" if (T <= 64 and M * M <= 64) else "k_env_step", "instances": B, "bound": "hbm", "achieved": ach,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBPS,
+            "avg_launch_us": sec * 1e6, "launches": n, "env_steps_per_s": B / sec}
+
+
 def cpu_baseline(J, M, E, seconds_target=12.0):
     """Time the CPU oracle port (oracle/mtfjsp_oracle.c, scalar C, 1 core) on a bounded sample of the same workload."""
     from oracle.env_oracle import OracleBatch
@@ -95,6 +125,7 @@ def main():
                     help="what the rollout records per step: the advantage inputs (rewards, dones, critic values) or every "
                          "field of the reference's ReplayBuffer (device-resident TrajectoryBuffer, SURVEY 8f N2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-env-sweep", action="store_true", help="skip the chip-filling step-kernel measurement (N=1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -186,6 +217,10 @@ def main():
             "roofline": roof, "roofline_env_step": roof_env,
             "kernel_times_ms": {k: v for k, v in ktimes.items()}, "kernel_times_steps": prof_steps,
         }
+        if world == 1 and not args.no_env_sweep:
+            del ro
+            torch.cuda.empty_cache()
+            out["roofline_env_step_large_batch"] = env_kernel_large_batch(J, M, E, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(J, M, E)
         print(json.dumps(out), flush=True)

@@ -1,0 +1,76 @@
+"""HIP encoder vs the fp32 oracle restatement at sizes beyond the J6M6 reference fixtures: exercises the chunked heads
+(R = J or M > 6 tiles per group), ragged tile counts (B*T not a multiple of 16), larger per-instance kernels, f64
+observations, and both BatchNorm modes.  The oracle is generic tensor code pinned against the reference modules at J6M6
+(tests/test_encoder_oracle_golden.py, tests/test_eval_per_instance_bn.py); inputs come from a real device rollout."""
+import os
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _perturb(ja, ma, seed):
+    """non-trivial BatchNorm affine parameters (the default initialiser has gamma 1 / beta 0)"""
+    rs = np.random.RandomState(seed)
+    for d in (ja, ma):
+        for k in d:
+            if "batch_norms" in k or k.startswith("bn."):
+                d[k] = (rs.uniform(0.5, 1.5, d[k].shape) if k.endswith("weight") else rs.uniform(-0.5, 0.5, d[k].shape)).astype(np.float32)
+
+
+@pytest.mark.parametrize("J,M,E,B,steps,obs", [(10, 6, 2, 37, 23, "f32"), (10, 10, 2, 24, 41, "f64"), (20, 20, 4, 5, 150, "f32"),
+                                             (3, 4, 2, 7, 5, "f32")])
+def test_encoder_matches_oracle_at_other_sizes(J, M, E, B, steps, obs):
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    from oracle import encoder_oracle as eo
+    T = J * M
+    ja, ma = enc_mod.random_init_weights(seed=J * 100 + M)
+    _perturb(ja, ma, 3)
+    ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype=obs, weights=(ja, ma), collect=False)
+    for _ in range(steps):
+        ro.step()
+    env, e = ro.env, ro.actor.enc
+    torch.cuda.synchronize()
+    tf = env.tasks_fea.cpu().numpy().astype(np.float64)
+    col = env.ell_col.cpu().numpy().reshape(B, T, 2); val = env.ell_val.cpu().numpy().reshape(B, T, 2).astype(np.float64)
+    cand = env.candidate.cpu().numpy(); mask = env.job_mask.cpu().numpy()
+    hm = e.h_pooled_m.cpu().numpy().copy()
+    for per_instance in (False, True):
+        e.set_bn_mode(per_instance)
+        prob, h_o, job_v = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, torch.as_tensor(hm).cuda())
+        torch.cuda.synchronize()
+        prob, h_o, job_v = prob.cpu().numpy(), h_o.cpu().numpy().copy(), job_v.cpu().numpy().copy()
+        if per_instance:
+            outs = [eo.job_actor_forward(ja, tf[b * T:(b + 1) * T], col[b:b + 1], val[b:b + 1], cand[b:b + 1], mask[b:b + 1], hm[b:b + 1], 1, T)
+                    for b in range(B)]
+            o = {k: np.concatenate([x[k] for x in outs], 0) for k in ("prob", "h_pooled", "job_v")}
+        else:
+            o = eo.job_actor_forward(ja, tf, col, val, cand, mask, hm, B, T)
+        scale = max(1.0, float(np.abs(o["h_pooled"]).max()))
+        np.testing.assert_allclose(h_o, o["h_pooled"], rtol=0, atol=2e-4 * scale)
+        np.testing.assert_allclose(prob, o["prob"], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(job_v, o["job_v"], rtol=2e-3, atol=2e-3)
+        # machine actor on the task each instance would pick greedily
+        task = torch.as_tensor(cand[np.arange(B), prob.argmax(1)].astype(np.int32)).cuda()
+        env.observe_mfea1(task)
+        mprob, h_m, mach_v = e.machine_actor_forward(env.m_fea1, env.m_fea2, torch.as_tensor(o["h_pooled"]).cuda(), env.mmask)
+        torch.cuda.synchronize()
+        f1 = env.m_fea1.cpu().numpy().astype(np.float64).reshape(B, M, 6); f2 = env.m_fea2.cpu().numpy().astype(np.float64).reshape(B, M, 8)
+        mm = env.mmask.cpu().numpy().reshape(B, M)
+        if per_instance:
+            outs = [eo.machine_actor_forward(ma, f1[b:b + 1], f2[b:b + 1], o["h_pooled"][b:b + 1], mm[b:b + 1], 1, M) for b in range(B)]
+            mo = {k: np.concatenate([x[k] for x in outs], 0) for k in ("prob", "h_pooled", "mach_v")}
+            htol = 5e-3                                               # BatchNorm over the M rows of one instance: see tests/test_eval_per_instance_bn.py
+        else:
+            mo = eo.machine_actor_forward(ma, f1, f2, o["h_pooled"], mm, B, M)
+            htol = 2e-4
+        np.testing.assert_allclose(mprob.cpu().numpy(), mo["prob"], rtol=0, atol=5e-4)
+        dh = np.abs(h_m.cpu().numpy() - mo["h_pooled"])
+        assert dh.max() < htol * 4 and np.median(dh) < htol / 4, (dh.max(), np.median(dh))
+        np.testing.assert_allclose(mach_v.cpu().numpy(), mo["mach_v"], rtol=5e-3, atol=5e-3)
+    e.set_bn_mode(False)
