@@ -734,22 +734,23 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
     // B. costs
     // estimated start/finish of the acting job's ops: the reference's left-to-right loop (env:1965-1995), run with
     // scalar indices; lane ja*M+c keeps its own (ste, fte)
-    double my_ste = 0.0, my_fte = 0.0, jmax_new = -INFINITY, jrow_new = 0.0, accp = 0.0;
-    for (int c = 0; c < M; c++) {
-        const int vv = ja * M + c;
-        const bool s = rl_i(mach, vv) >= 0;
-        const double f = rl_d(ft, vv);
-        double fte_c, ste_c;
-        if (s && f != 0.0) { fte_c = f; ste_c = rl_d(st, vv); }
-        else {
-            fte_c = (c ? accp : 0.0) + rl_d(md, c);
-            ste_c = s ? rl_d(st, vv) : (c ? accp : 0.0);
-        }
+    // Ops of a job are scheduled in order: ops < op are scheduled (their estimate IS their finish time, already folded into
+    // the job's running row maximum jrow_), op is being scheduled now, ops > op are unscheduled -> only the tail is walked.
+    double my_ste = 0.0, my_fte = 0.0, accp = ft_k;
+    const double row_prev = rl_d(jrow_, ja);                                    // max real finish time of ops < op (0 if none)
+    double jrow_new = op == 0 ? ft_k : fmax(row_prev, ft_k);                    // ppo:265-275 row maximum of real finish times
+    double jmax_new = jrow_new;                                                 // estimated finish times of ops <= op are the real ones
+    if (v == a) { my_ste = st_k; my_fte = ft_k; }
+    if (ft_k == 0.0) {                                                          // env:1977: a zero finish time is treated as "not set"
+        accp = (op ? rl_d(ft, a - 1) : 0.0) + rl_d(md, op);
+        if (v == a) my_fte = accp;
+        jmax_new = op == 0 ? accp : fmax(row_prev, accp);
+    }
+    for (int c = op + 1; c < M; c++) {
+        const double fte_c = accp + rl_d(md, c);
+        if (v == ja * M + c) { my_ste = accp; my_fte = fte_c; }
         accp = fte_c;
-        if (v == vv) { my_ste = ste_c; my_fte = fte_c; }
-        jmax_new = c == 0 ? fte_c : fmax(jmax_new, fte_c);
-        const double f0 = s ? f : 0.0;
-        jrow_new = c == 0 ? f0 : fmax(jrow_new, f0);                            // ppo:265-275 row maximum of real finish times
+        jmax_new = fmax(jmax_new, fte_c);
     }
     if (lane == ja) { jmax_ = jmax_new; jrow_ = jrow_new; }
     double mk = rl_d(jmax_, 0);                                                 // env:894 np.amax
@@ -757,15 +758,14 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
     double e1;                                                                  // env:896 np.sum, numpy's pairwise order
     if (T < 8) { e1 = 0.0; for (int i = 0; i < T; i++) e1 += rl_d(pte, i); }
     else {
-        double r0 = rl_d(pte, 0), r1 = rl_d(pte, 1), r2 = rl_d(pte, 2), r3 = rl_d(pte, 3);
-        double r4 = rl_d(pte, 4), r5 = rl_d(pte, 5), r6 = rl_d(pte, 6), r7 = rl_d(pte, 7);
-        int i = 8;
-        for (; i < T - (T & 7); i += 8) {
-            r0 += rl_d(pte, i); r1 += rl_d(pte, i + 1); r2 += rl_d(pte, i + 2); r3 += rl_d(pte, i + 3);
-            r4 += rl_d(pte, i + 4); r5 += rl_d(pte, i + 5); r6 += rl_d(pte, i + 6); r7 += rl_d(pte, i + 7);
-        }
-        e1 = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
-        for (; i < T; i++) e1 += rl_d(pte, i);
+        // lanes 0..7 are numpy's 8 accumulators r[k] = a[k] + a[k+8] + ... (in that order), then its fixed tree
+        // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) as an xor butterfly (fp addition commutes), then the ragged tail in order
+        const int nb = T - (T & 7);
+        double r = pte;
+        for (int i = 8; i < nb; i += 8) r += __shfl(pte, (lane & 7) + i);
+        r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
+        e1 = rl_d(r, 0);
+        for (int i = nb; i < T; i++) e1 += rl_d(pte, i);
     }
     e1 = 0.0 + e1;
     // idle time (dg:144-170): term per lane, summed in (machine, route) order by a scalar walk
