@@ -768,13 +768,29 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
         for (int i = nb; i < T; i++) e1 += rl_d(pte, i);
     }
     e1 = 0.0 + e1;
-    // idle time (dg:144-170): term per lane, summed in (machine, route) order by a scalar walk
+    // idle time (dg:144-170): one term per scheduled task, summed strictly left to right in (machine, route position)
+    // order.  Instead of chasing the route links (a dependent readlane per element) every scheduled lane computes its rank
+    // in that order = (tasks on lower machines) + (its route position), a forward permute puts the terms into rank order
+    // and a scalar-indexed loop adds lanes 0..nsched-1.
     const double ftPr = __shfl(ft, prev >= 0 ? prev : 0);
     const double term = prev < 0 ? st : st - ftPr;
     double idle = 0.0;
-    for (int mm = 0; mm < M; mm++) {
-        int cur = rl_i(head_, mm);
-        while (cur >= 0) { idle = idle + rl_d(term, cur); cur = rl_i(next, cur); }
+    {
+        int before = 0;                                                         // lanes < M: tasks on machines below this one
+        for (int mm = 0; mm + 1 < M; mm++) { const int L = rl_i(len_, mm); before += lane > mm ? L : 0; }
+        const bool sch = isT && mach >= 0;
+        const int below = __shfl(before, mach >= 0 ? mach : 0);                 // executed by ALL lanes: the source lanes must be active
+        const int rank = sch ? below + pos : 63;                                // lane 63 is free whenever anything is unscheduled
+        const double tv = sch ? term : 0.0;
+        const int lo = __builtin_amdgcn_ds_permute(rank << 2, __double2loint(tv));
+        const int hi = __builtin_amdgcn_ds_permute(rank << 2, __double2hiint(tv));
+        const double sorted = __hiloint2double(hi, lo);
+        int i = 0;
+        for (; i + 3 < nsched; i += 4) {
+            idle = idle + rl_d(sorted, i); idle = idle + rl_d(sorted, i + 1);
+            idle = idle + rl_d(sorted, i + 2); idle = idle + rl_d(sorted, i + 3);
+        }
+        for (; i < nsched; i++) idle = idle + rl_d(sorted, i);
     }
     const double new_tr = (op == 0) ? 0.0 : rl_d(ttv, mach_p * M + m);          // env:872-876
     const double trans_this = rl_d(sc, S_TR_THIS) + new_tr;
@@ -852,42 +868,48 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
         for (int i = 0; i < (int)(12 * sizeof(OBS) / 16); i++) dst[i] = src[i];
     }
     {   // in-edge (ELL) rows of a, its job successor, its new route successor, and the node whose merged edge reverts:
-        // all indices are wave-uniform -> computed with scalar-index register reads, written by one lane each
+        // lanes 0..3 take one row each and gather what they need with shuffles (every lane executes the shuffles: their
+        // source lanes must be active), so the edge arithmetic runs once instead of four times with scalar reads
         const int merged_now = merged_a ? a : -1;
-        const int rows[4] = {a, (op + 1 < M) ? a + 1 : -1, Nk, lastm};
-        for (int q = 0; q < 4; q++) {
-            const int vv = rows[q];
-            if (vv < 0) continue;
-            const int mv = rl_i(mach, vv), pr = rl_i(prev, vv);
-            const bool s = mv >= 0;
-            const int jvv = DIVM(vv), opvv = vv - jvv * M;
-            const bool merged = pr >= 0 && opvv != 0 && pr == vv - 1;
-            int c_job = -1, c_mch = -1;
-            float a_job = 0.f, a_mch = 0.f;
-            if (opvv != 0) {
-                const int u = vv - 1, mu = rl_i(mach, u);
-                double w, nd;
-                if (mu < 0) { w = 1.0; nd = 1.0; }
-                else {
-                    nd = rl_d(dur, u);
-                    if (merged && vv == merged_now) w = nd + rl_d(ttv, mu * M + mv) + (rl_d(st, vv) - rl_d(ft, u));   // env:1607-1675,1703-1765
-                    else w = nd + (s ? rl_d(ttv, mu * M + mv) : 0.0);                                                   // env:1384-1422
-                }
-                long A = trunc_l(w);
-                if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }                           // env:2019, 2060-2062
+        const int vv0 = lane == 0 ? a : lane == 1 ? ((op + 1 < M) ? a + 1 : -1) : lane == 2 ? Nk : lane == 3 ? lastm : -1;
+        const bool act = vv0 >= 0;
+        const int vv = act ? vv0 : 0;
+        const int mv = __shfl(mach, vv), pr = __shfl(prev, vv);
+        const double st_v = __shfl(st, vv);
+        const int jvv = DIVM(vv), opvv = vv - jvv * M;
+        const int u = vv > 0 ? vv - 1 : 0;
+        const int mu = __shfl(mach, u);
+        const double dur_u = __shfl(dur, u), ft_u = __shfl(ft, u);
+        const int pri = pr >= 0 ? pr : 0;
+        const int mpr = __shfl(mach, pri);
+        const double dur_p = __shfl(dur, pri), ft_p = __shfl(ft, pri);
+        const double tt_uv = __shfl(ttv, (mu >= 0 ? mu : 0) * M + (mv >= 0 ? mv : 0));
+        const double tt_pv = __shfl(ttv, (mpr >= 0 ? mpr : 0) * M + (mv >= 0 ? mv : 0));
+        const bool s = mv >= 0;
+        const bool merged = pr >= 0 && opvv != 0 && pr == vv - 1;
+        int c_job = -1, c_mch = -1;
+        float a_job = 0.f, a_mch = 0.f;
+        if (opvv != 0) {
+            double w, nd;
+            if (mu < 0) { w = 1.0; nd = 1.0; }
+            else {
+                nd = dur_u;
+                if (merged && vv == merged_now) w = nd + tt_uv + (st_v - ft_u);                                             // env:1607-1675,1703-1765
+                else w = nd + (s ? tt_uv : 0.0);                                                                           // env:1384-1422
             }
-            if (pr >= 0 && !merged) {
-                const double dp = rl_d(dur, pr);
-                const double x = (DIVM(pr) == jvv) ? rl_d(ttv, rl_i(mach, pr) * M + mv) : 0.0;
-                const double w = dp + x + (rl_d(st, vv) - rl_d(ft, pr));
-                long A = trunc_l(w);
-                if (A != 0) { A = trunc_l((double)A - dp) + 1; c_mch = pr; a_mch = (float)A; }
-            }
-            if (lane == q) {
-                reinterpret_cast<int2 *>(P.obs.ell_col)[bT + vv] = make_int2(c_job, c_mch);
-                reinterpret_cast<float2 *>(P.obs.ell_val)[bT + vv] = make_float2(a_job, a_mch);
-                if (q == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + vv) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
-            }
+            long A = trunc_l(w);
+            if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }                                   // env:2019, 2060-2062
+        }
+        if (pr >= 0 && !merged) {
+            const double x = (DIVM(pri) == jvv) ? tt_pv : 0.0;
+            const double w = dur_p + x + (st_v - ft_p);
+            long A = trunc_l(w);
+            if (A != 0) { A = trunc_l((double)A - dur_p) + 1; c_mch = pr; a_mch = (float)A; }
+        }
+        if (act) {
+            reinterpret_cast<int2 *>(P.obs.ell_col)[bT + vv] = make_int2(c_job, c_mch);
+            reinterpret_cast<float2 *>(P.obs.ell_val)[bT + vv] = make_float2(a_job, a_mch);
+            if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + vv) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
         }
         if (lane == 6) P.lastm[b] = merged_now;
     }
