@@ -436,7 +436,8 @@ __global__ __launch_bounds__(WAVE, 4) void k_env_step(EnvParams P)
     r_pt = r_pt / (double)T;                                                   // env:1073-1076
     const double r_tt = 1.0 * tr_prev - trans_this;                            // env:1083
     const double r_idle = 1.0 * id_prev - idle;                                // env:1088
-    const double tot = (P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1) / P.divisor;   // env:1164
+    const double tot_n = P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1;                  // env:1164
+    const double tot = P.divisor == 1.0 ? tot_n : tot_n / P.divisor;            // x / 1.0 == x exactly: skip the f64 divide for the default scaling_divisor
     const bool done = nsched == T;                                             // env:797-800
     const double scN = s_sc[S_N];
     double sR = 0, sMean = 0, sS = 0, sSd = 0, scaled = 0;
@@ -776,8 +777,13 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
     const double term = prev < 0 ? st : st - ftPr;
     double idle = 0.0;
     {
-        int before = 0;                                                         // lanes < M: tasks on machines below this one
-        for (int mm = 0; mm + 1 < M; mm++) { const int L = rl_i(len_, mm); before += lane > mm ? L : 0; }
+        // lanes < M: tasks on machines below this one = exclusive prefix sum of the route lengths (M <= 8 here: three DPP
+        // row shifts with zero fill)
+        int incl = lane < M ? len_ : 0;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+        const int before = incl - (lane < M ? len_ : 0);
         const bool sch = isT && mach >= 0;
         const int below = __shfl(before, mach >= 0 ? mach : 0);                 // executed by ALL lanes: the source lanes must be active
         const int rank = sch ? below + pos : 63;                                // lane 63 is free whenever anything is unscheduled
@@ -800,7 +806,8 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
     r_pt = r_pt / (double)T;                                                    // env:1073-1076
     const double r_tt = 1.0 * tr_prev - trans_this;                             // env:1083
     const double r_idle = 1.0 * id_prev - idle;                                 // env:1088
-    const double tot = (P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1) / P.divisor;   // env:1164
+    const double tot_n = P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1;                  // env:1164
+    const double tot = P.divisor == 1.0 ? tot_n : tot_n / P.divisor;            // x / 1.0 == x exactly: skip the f64 divide for the default scaling_divisor
     const bool done = nsched == T;                                              // env:797-800
     // reward scaling, one channel per lane (pt:54-124): lane c gathers its channel's state slots
     {
