@@ -459,7 +459,8 @@ struct GatArgs {
     int R;                  // machine rows = B*M ; tile rows = 2R
     const void *f1, *f2;    // m_fea1 [R,6], m_fea2 [R,8] (obs dtype)
     int feat_f64;
-    const float *W1, *W2;   // m_fea_1_fcl.weight [128,6], m_fea_2_fcl.weight [128,8]
+    const float *W1, *W2;   // (m_fea_1_fcl.weight^T . gat W)^T [128,6], (m_fea_2_fcl.weight^T . gat W)^T [128,8]: input projection and
+                            // the first pass' h W fused on the host (one 14 x 128 x 128 product per weight load)
     const float *Wt;        // gat_layer.W [in,out]
     const float *gat_a;     // [256] a_src | a_dst (gat:68-79)
     float *node;            // [R,128] (padded) pre-BatchNorm node mean
@@ -551,12 +552,22 @@ __global__ __launch_bounds__(512) void k_gat3(GatArgs A)
 #pragma unroll 1
         for (int pass = 0; pass < 3; pass++) {
             f32x4 acc[8];
+            if (pass == 0) {
+                // the rows just written ARE z of the first pass: W1/W2 arrive pre-multiplied with the GAT weight (GatArgs), so
+                // the 6/8 -> 128 projection and the first h W product are one K = 8 product — read it back in the C layout
 #pragma unroll
-            for (int c = 0; c < 8; c++)
+                for (int c = 0; c < 8; c++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc[c][i] = 0.f;
-            mfma_tile16(ap, bp, bo, acc);
-            asm volatile("" ::: "memory");
+                    for (int i = 0; i < 4; i++) acc[c][i] = my_a[(4 * q + i) * LDA16 + c * 16 + m];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[c][i] = 0.f;
+                mfma_tile16(ap, bp, bo, acc);
+                asm volatile("" ::: "memory");
+            }
             STAMP(3);
 #pragma unroll
             for (int u = 0; u < 2; u++) {                                     // the lane's two machines: tile rows 4q+2u (node 0), +1 (node 1)
@@ -1370,6 +1381,8 @@ struct mtfjsp_encoder {
     std::string err;
     std::map<std::string, float *> w;       // device copies, torch layout
     std::map<std::string, float *> wt;      // transposed [in,out] copies of the 128-wide Linear weights (split per 128-block of `in`)
+    std::map<std::string, std::vector<float>> hostw;   // host copies of gat_layer.W / m_fea_*_fcl.weight (inputs of the fused projections)
+    std::map<std::string, float *> wfused;  // per prefix + "1"/"2": (m_fea_k_fcl.weight^T . gat_layer.W)^T, [128,6] / [128,8]
     std::map<std::string, float *> wimg;    // the same blocks as per-wave register images for k_heads: [block][wave 8][g 8][lane 64][4]
     std::vector<void *> owned;
     int num_cu = 256;
@@ -1512,6 +1525,12 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
     if (it != e->w.end()) d = it->second;
     else { if (dalloc(e, &d, (size_t)numel)) return MTFJSP_ERR_HIP; e->w[key] = d; }
     HIPCHK(e, hipMemcpy(d, data, (size_t)numel * 4, hipMemcpyHostToDevice));
+    if ((key.size() >= 11 && key.compare(key.size() - 11, 11, "gat_layer.W") == 0) || key.find("m_fea_1_fcl.weight") != std::string::npos ||
+        key.find("m_fea_2_fcl.weight") != std::string::npos) {
+        e->hostw[key].assign(data, data + numel);
+        const std::string prefix = key.substr(0, key.find('.') + 1);
+        e->wfused.erase(prefix + "1"); e->wfused.erase(prefix + "2");   // rebuilt at the next forward (buffers stay owned)
+    }
     // 128-wide Linear weights [out=128, in=128*k] and gat W [in,out]: keep GEMM-ready [in-block][k][n] copies
     const bool is_w = key.size() > 7 && key.compare(key.size() - 7, 7, ".weight") == 0 && key.find("linears") != std::string::npos;
     const bool is_gat_w = key.size() >= 11 && key.compare(key.size() - 11, 11, "gat_layer.W") == 0;
@@ -1671,6 +1690,29 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
 
 // Machine path shared by the machine actor and the global critic (ac:383-444): input projections + 3x the same GATLayer
 // + node mean (in-place GEMM passes), then BatchNorm over all B*M rows and the mean over M.  Uses accumulator slot 6.
+// (m_fea_k_fcl.weight^T . gat_layer.W)^T on the host, cached per prefix until one of the three weights is loaded again
+static int fused_projection(mtfjsp_encoder *e, const std::string &pre, int which, const float **out)
+{
+    const std::string key = pre + (which == 1 ? "1" : "2");
+    auto it = e->wfused.find(key);
+    if (it != e->wfused.end()) { *out = it->second; return MTFJSP_OK; }
+    const int K = which == 1 ? 6 : 8;
+    const std::vector<float> &P = e->hostw.at(pre + (which == 1 ? "m_fea_1_fcl.weight" : "m_fea_2_fcl.weight"));   // [128,K]
+    const std::vector<float> &W = e->hostw.at(pre + "gat_layer.W");                                                  // [128(in),128(out)]
+    std::vector<float> f((size_t)HD * K);
+    for (int n = 0; n < HD; n++)
+        for (int k = 0; k < K; k++) {
+            double a = 0.0;
+            for (int i = 0; i < HD; i++) a += (double)P[(size_t)i * K + k] * (double)W[(size_t)i * HD + n];
+            f[(size_t)n * K + k] = (float)a;
+        }
+    float *d = nullptr;
+    if (dalloc(e, &d, f.size())) return MTFJSP_ERR_HIP;
+    HIPCHK(e, hipMemcpy(d, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+    e->wfused[key] = d;
+    *out = d;
+    return MTFJSP_OK;
+}
 // h_pooled == nullptr: leave `node` pre-BatchNorm for a consumer that normalises and pools it itself (k_heads); *slot_out = the
 // accumulator slot holding the column sums.
 static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, float *h_pooled, int *slot_out = nullptr)
@@ -1688,7 +1730,9 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
         Timed t(e, "gat3");
         GatArgs a{};
         a.R = R; a.f1 = m_fea1; a.f2 = m_fea2; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
-        a.W1 = W(pre + "m_fea_1_fcl.weight"); a.W2 = W(pre + "m_fea_2_fcl.weight");
+        int frc = fused_projection(e, pre, 1, &a.W1);
+        if (!frc) frc = fused_projection(e, pre, 2, &a.W2);
+        if (frc) return frc;
         a.Wt = WT(pre + "gat_layer.W"); a.gat_a = W(pre + "gat_layer.a"); a.node = e->node; a.epi_stats = st;
         const int ntiles = (2 * R + 15) / 16;
         int grid = (ntiles + 7) / 8;
