@@ -685,9 +685,14 @@ struct HeadArgs {
     // machine actor: X arrives pre-BatchNorm (k_gat3 output); normalise it while staging, pool it over the R rows of an
     // instance here (ac:434-444) and publish the pooled embedding — no separate normalisation pass over `node`
     const double *xbn_stats; const float *xbn_gamma, *xbn_beta; double xbn_inv_rows; float *pooled_out;
+    // job actor: X is the last GIN product z [B*xT,128] (pre-BatchNorm); row (instance, r) of the scorer input is
+    // relu(bn(z[instance*xT + xgather[instance*R + r]])) (candidate gather, ac:197-207) and the pooled embedding the mean of
+    // relu(bn(.)) over all xT rows of the instance (gcn:192) — k_job_pool_gather folded in.  xgather == NULL: rows instance*R + r.
+    const int *xgather; int xT, xrelu;
     // optional fused action selection (agent:22-72), same Philox stream as k_sample: 0 = off, 1 = sample, 2 = greedy
     int sample_mode; unsigned long long seed, counter; int *idx_out; float *logp_out; const int *gather_from; int *gathered_out;
     double *zero_stats; int zero_count;  // BatchNorm accumulators no kernel reads any more: zeroed here for the next forward
+    double *zero_stats2; int zero_count2;
     unsigned long long *stamps;
 };
 #define HG 16                            // instances per group
@@ -739,6 +744,7 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
     if (tid < 2 * HD) s_wc2[tid] = A.wc2[tid];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
+    if (A.zero_stats2 && blockIdx.x == 0) for (int i = tid; i < A.zero_count2; i += 512) A.zero_stats2[i] = 0.0;
     float xs0 = 1.f, xs1 = 1.f, xs2 = 1.f, xs3 = 1.f, xh0 = 0.f, xh1 = 0.f, xh2 = 0.f, xh3 = 0.f;   // X scale / shift of this thread's 4 columns
     if (A.xbn_stats) {
         stage_bn(s_u, A.xbn_stats, A.xbn_inv_rows, A.xbn_gamma, A.xbn_beta, tid);      // s_u is free until phase A
@@ -760,14 +766,19 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 xp = z;
-            if (A.xbn_stats) {                                      // pooled = mean over the instance's R normalised rows (ac:444)
+            if (A.xbn_stats) {                                      // pooled = mean over the instance's normalised rows (ac:444 / gcn:192)
                 if (sr < ng) {
+                    const int nr = A.xgather ? A.xT : R;
+                    const float *src = A.X + (size_t)(g0 + sr) * nr * HD + sc4;
                     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-                    for (int r = 0; r < R; r++) {
-                        const float4 v = *reinterpret_cast<const float4 *>(A.X + ((size_t)(g0 + sr) * R + r) * HD + sc4);
-                        a0 += fmaf(v.x, xs0, xh0); a1 += fmaf(v.y, xs1, xh1); a2 += fmaf(v.z, xs2, xh2); a3 += fmaf(v.w, xs3, xh3);
+#pragma unroll 12
+                    for (int r = 0; r < nr; r++) {                   // 12 rows in flight per thread
+                        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)r * HD);
+                        float y0 = fmaf(v.x, xs0, xh0), y1 = fmaf(v.y, xs1, xh1), y2 = fmaf(v.z, xs2, xh2), y3 = fmaf(v.w, xs3, xh3);
+                        if (A.xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+                        a0 += y0; a1 += y1; a2 += y2; a3 += y3;
                     }
-                    const float ir = 1.0f / (float)R;
+                    const float ir = 1.0f / (float)nr;
                     xp = make_float4(a0 * ir, a1 * ir, a2 * ir, a3 * ir);
                     *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
                 }
@@ -778,16 +789,25 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
             *reinterpret_cast<float2 *>(dq) = make_float2(xo.x, xo.y); *reinterpret_cast<float2 *>(dq + 2) = make_float2(xo.z, xo.w);
         }
         for (int i = tid; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
+        // scorer row `grow` of the group (instance grow / R, candidate / machine grow % R) -> its source row in X
+        auto xrow = [&](int grow) __attribute__((always_inline)) -> const float * {
+            if (!A.xgather) return A.X + ((size_t)g0 * R + grow) * HD + sc4;
+            const int il = (int)__umulhi((unsigned)grow, invR);
+            return A.X + ((size_t)(g0 + il) * A.xT + A.xgather[(size_t)g0 * R + grow]) * HD + sc4;
+        };
         float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
 #pragma unroll
         for (int t = 0; t < HCH; t++) {
             const int grow = t * 16 + sr;
-            xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(A.X + ((size_t)g0 * R + grow) * HD + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         LDS_BARRIER();
         STAMP(0);
         auto xnorm = [&](float4 v, bool valid) __attribute__((always_inline)) {
-            return valid ? make_float4(fmaf(v.x, xs0, xh0), fmaf(v.y, xs1, xh1), fmaf(v.z, xs2, xh2), fmaf(v.w, xs3, xh3)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!valid) return make_float4(0.f, 0.f, 0.f, 0.f);
+            float y0 = fmaf(v.x, xs0, xh0), y1 = fmaf(v.y, xs1, xh1), y2 = fmaf(v.z, xs2, xh2), y3 = fmaf(v.w, xs3, xh3);
+            if (A.xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+            return make_float4(y0, y1, y2, y3);
         };
         // ---- phase A: u = Wb pooled + Wc other + b0 ; c1 = tanh(Wc0 pooled + bc0)
         {
@@ -817,7 +837,7 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
             for (int t = 0; t < HCH; t++) {
                 if (tb > 0) {
                     const int grow = (tb + t) * 16 + sr;
-                    xr[t] = (tb + t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(A.X + ((size_t)g0 * R + grow) * HD + sc4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    xr[t] = (tb + t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 const float4 xv = xnorm(xr[t], (tb + t) * 16 + sr < nrows);
                 float *d = s_x + (t * 16 + sr) * LDA16 + sc4;
@@ -1392,6 +1412,7 @@ struct mtfjsp_encoder {
     float *u = nullptr, *c1 = nullptr, *c2 = nullptr, *hm_b = nullptr, *pooled_int = nullptr;   // [B,128]
     float *node = nullptr;                  // [B*M,128]
     double *stats = nullptr;                // [8][STAT_REP][256]: slots 0..5 GIN layers, 6/7 machine path (alternating)
+    bool gin_slot5_dirty = false;           // slots 0..4 zeroed by the job heads, slot 5 still holds sums (zeroed by the machine heads)
     bool gin_stats_clean = false;           // slots 0..5 are zero (the job-actor heads kernel zeroes them after their last reader)
     bool gat_stats_clean[2] = {false, false};
     int bn_mode = 0;                        // 0: BatchNorm statistics over the whole device batch; 1: per instance (validate.py semantics)
@@ -1650,7 +1671,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
     double *st = e->stats;
     if (!e->gin_stats_clean) HIPCHK(e, hipMemsetAsync(st, 0, 6 * STAT_REP * 256 * sizeof(double), e->stream));
-    e->gin_stats_clean = false;
+    e->gin_stats_clean = false; e->gin_slot5_dirty = false;
     const double invN = 1.0 / (double)N;
     const int pgrid = e->num_cu * 8;
     {   // layer 0 / linear 0 with aggregation of the raw features
@@ -1679,7 +1700,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     }
     bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4);
     bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5);
-    {
+    if (h_pooled) {                                               // h_pooled == NULL: the consumer (k_heads) normalises, pools and gathers itself
         Timed t(e, "job_pool_gather");
         hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(256), 0, e->stream, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
                            W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, cand_feat, h_nodes);
@@ -1839,8 +1860,9 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     const int B = e->cfg.batch, J = e->cfg.n_job;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
+    const bool fuse_pool = !e->bn_mode && !h_nodes;               // the heads kernel does BatchNorm+ReLU, graph pool and candidate gather
     rc = e->bn_mode ? run_gin_inst(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
-                    : run_gin(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes);
+                    : run_gin(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, fuse_pool ? nullptr : h_pooled, e->cand_feat, h_nodes);
     if (rc) return rc;
     // ---- heads (ac:205-293): score = L2 tanh(L1 tanh(Wa cand + Wb pooled + Wc hm + b0))
     const float *hm = h_m_prev;
@@ -1860,7 +1882,14 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         ha.Wc1i = WI("job_actor.job_critic.linears.1.weight"); ha.bc1 = W("job_actor.job_critic.linears.1.bias");
         ha.wc2 = W("job_actor.job_critic.linears.2.weight"); ha.bc2 = W("job_actor.job_critic.linears.2.bias");
         ha.mask = job_mask; ha.scale = 1.0f; ha.prob = prob; ha.value = job_v;
-        if (!e->bn_mode) {
+        if (fuse_pool) {
+            const std::string P = "job_actor.encoder.feature_extract.";
+            ha.X = e->zB; ha.pooled = nullptr; ha.pooled_out = h_pooled; ha.xgather = candidate; ha.xT = e->T; ha.xrelu = 1;
+            ha.xbn_stats = e->stats + 5 * STAT_REP * 256; ha.xbn_gamma = W(P + "batch_norms.1.weight"); ha.xbn_beta = W(P + "batch_norms.1.bias");
+            ha.xbn_inv_rows = 1.0 / ((double)B * (double)e->T);
+            ha.zero_stats = e->stats; ha.zero_count = 5 * STAT_REP * 256;    // slots 0..4 are consumed; slot 5 is being read by this very
+            e->gin_slot5_dirty = true;                                       // kernel and is zeroed by the machine heads (or a memset)
+        } else if (!e->bn_mode) {
             ha.zero_stats = e->stats; ha.zero_count = 6 * STAT_REP * 256;    // every GIN accumulator has been consumed by now
             e->gin_stats_clean = true;
         }
@@ -1912,6 +1941,10 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
             ha.xbn_inv_rows = 1.0 / (double)R; ha.pooled_out = h_pooled;
             ha.zero_stats = e->stats + (6 + (slot ^ 1)) * STAT_REP * 256; ha.zero_count = STAT_REP * 256;   // the slot of the next machine forward
             e->gat_stats_clean[slot ^ 1] = true;
+            if (e->gin_slot5_dirty) {                                 // left by a job forward that pooled inside its heads kernel
+                ha.zero_stats2 = e->stats + 5 * STAT_REP * 256; ha.zero_count2 = STAT_REP * 256;
+                e->gin_slot5_dirty = false; e->gin_stats_clean = true;
+            }
         }
         arm_sampling(e, 1, ha);
         ha.W0i = WI("machine_actor.m_policy.linears.0.weight"); ha.b0 = W("machine_actor.m_policy.linears.0.bias");
