@@ -1860,7 +1860,9 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     const int B = e->cfg.batch, J = e->cfg.n_job;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
-    const bool fuse_pool = !e->bn_mode && !h_nodes;               // the heads kernel does BatchNorm+ReLU, graph pool and candidate gather
+    // the heads kernel does BatchNorm+ReLU, graph pool and candidate gather itself — while T is small: a workgroup pools 16
+    // instances with 512 threads, which is too little parallelism for 400-row instances (J20M20: 199 vs 81+113 us measured)
+    const bool fuse_pool = !e->bn_mode && !h_nodes && e->T <= 128;
     rc = e->bn_mode ? run_gin_inst(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
                     : run_gin(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, fuse_pool ? nullptr : h_pooled, e->cand_feat, h_nodes);
     if (rc) return rc;
