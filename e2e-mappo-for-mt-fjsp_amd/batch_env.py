@@ -165,6 +165,13 @@ class DeviceBatchEnv:
         capi.check(self.L.mtfjsp_observe_mfea1(self.h, task_idx.data_ptr(), mm, self.m_fea1.data_ptr(), self.mmask.data_ptr()), self.h)
         return self.m_fea1
 
+    def mfea1_context(self):
+        """device-pointer recipe of observe_mfea1 (-> self.m_fea1, self.mmask) for the encoder's heads kernel to execute right
+        after it has selected the task (capi.Mfea1Ctx; valid while the instances stay loaded)"""
+        ctx = capi.Mfea1Ctx()
+        capi.check(self.L.mtfjsp_get_mfea1_context(self.h, self.m_fea1.data_ptr(), self.mmask.data_ptr(), C.byref(ctx)), self.h)
+        return ctx
+
     def random_actions(self, seed, counter, task_idx, mach_idx, job_idx=None):
         capi.check(self.L.mtfjsp_random_actions(self.h, seed, counter, task_idx.data_ptr(), mach_idx.data_ptr(),
                                                 job_idx.data_ptr() if job_idx is not None else 0), self.h)

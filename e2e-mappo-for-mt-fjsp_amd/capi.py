@@ -28,6 +28,12 @@ class Obs(C.Structure):
                 ("status", C.c_void_p)]
 
 
+class Mfea1Ctx(C.Structure):
+    _fields_ = [("t", C.c_void_p), ("p", C.c_void_p), ("tt", C.c_void_p), ("mean3", C.c_void_p), ("shop", C.c_void_p),
+                ("link", C.c_void_p), ("m_fea1_out", C.c_void_p), ("mmask_out", C.c_void_p),
+                ("T", C.c_int32), ("M", C.c_int32), ("obs_f32", C.c_int32)]
+
+
 class EncoderConfig(C.Structure):
     _fields_ = [("n_job", C.c_int32), ("n_machine", C.c_int32), ("batch", C.c_int32), ("hidden", C.c_int32),
                 ("obs_dtype", C.c_int32), ("device_id", C.c_int32)]
@@ -76,6 +82,8 @@ PROTOTYPES = {
     "mtfjsp_global_critic_forward": (_I, [_VP] * 7),
     "mtfjsp_sample_categorical": (_I, [_VP, _VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
     "mtfjsp_encoder_set_bn_mode": (_I, [_VP, C.c_int32]),
+    "mtfjsp_get_mfea1_context": (_I, [_VP, _VP, _VP, C.POINTER(Mfea1Ctx)]),
+    "mtfjsp_encoder_arm_mfea1": (_I, [_VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_selection": (_I, [_VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
     "mtfjsp_encoder_timing_begin": (_I, [_VP]),
     "mtfjsp_encoder_timing_end": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -691,6 +691,7 @@ struct HeadArgs {
     const int *xgather; int xT, xrelu;
     // optional fused action selection (agent:22-72), same Philox stream as k_sample: 0 = off, 1 = sample, 2 = greedy
     int sample_mode; unsigned long long seed, counter; int *idx_out; float *logp_out; const int *gather_from; int *gathered_out;
+    mtfjsp_mfea1_ctx_t mf; int mf_on;    // optional: m_fea1 / machine mask of the selected task (pe:152-214), see include/mtfjsp.h
     double *zero_stats; int zero_count;  // BatchNorm accumulators no kernel reads any more: zeroed here for the next forward
     double *zero_stats2; int zero_count2;
     unsigned long long *stamps;
@@ -921,7 +922,40 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
                         const int pick = pick_action(s_score + r0 * R, R, b, A.sample_mode == 2, A.seed, A.counter);
                         A.idx_out[b] = pick;
                         if (A.logp_out) A.logp_out[b] = logf(s_score[r0 * R + pick]);
-                        if (A.gather_from && A.gathered_out) A.gathered_out[b] = A.gather_from[(size_t)b * R + pick];
+                        const int gsel = A.gather_from ? A.gather_from[(size_t)b * R + pick] : pick;
+                        if (A.gather_from && A.gathered_out) A.gathered_out[b] = gsel;
+                        s_part[r0] = __int_as_float(gsel);                     // hand the selected task to the instance's 16 lanes (s_part is free now)
+                    }
+                    if (A.mf_on) {
+                        // = k_mfea1 (pe:152-214) for the task just selected: the 16 lanes of the instance take the machines
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const int b = g0 + r0, T_ = A.mf.T, M_ = A.mf.M;
+                        int a = __float_as_int(s_part[r0]);
+                        if (a < 0 || a >= T_) a = 0;
+                        const size_t row = (size_t)b * T_ + a;
+                        int pm = 0;
+                        if (a % M_ != 0) {
+                            pm = reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
+                            if (pm < 0) pm += M_;                                             // python negative index (pe:206)
+                        }
+                        for (int mm = l; mm < M_; mm += 16) {
+                            const double tv = A.mf.t[row * M_ + mm], pv = A.mf.p[row * M_ + mm];
+                            const double ptv = tv * fabs(pv);
+                            const unsigned char mk = (unsigned char)!(tv >= 0);              // run:258-259 ~(t >= 0)
+                            const double x = (a % M_ != 0) ? A.mf.tt[((size_t)b * M_ + pm) * M_ + mm] : 0.0;
+                            const double f0 = tv > 0 ? tv : A.mf.mean3[row * 3 + 0], f1 = ptv > 0 ? ptv : A.mf.mean3[row * 3 + 1];
+                            const double f4 = pv > 0 ? pv : A.mf.mean3[row * 3 + 2];
+                            const size_t o = ((size_t)b * M_ + mm) * 6;
+                            const double f3 = (double)(1 - (int)mk), f5 = (double)(A.mf.shop[(size_t)b * M_ + mm] + 1);
+                            if (A.mf.obs_f32) {
+                                float *of = reinterpret_cast<float *>(A.mf.m_fea1_out) + o;
+                                of[0] = (float)f0; of[1] = (float)f1; of[2] = (float)x; of[3] = (float)f3; of[4] = (float)f4; of[5] = (float)f5;
+                            } else {
+                                double *od = reinterpret_cast<double *>(A.mf.m_fea1_out) + o;
+                                od[0] = f0; od[1] = f1; od[2] = x; od[3] = f3; od[4] = f4; od[5] = f5;
+                            }
+                            A.mf.mmask_out[(size_t)b * M_ + mm] = mk;
+                        }
                     }
                 }
             }
@@ -1417,6 +1451,7 @@ struct mtfjsp_encoder {
     bool gat_stats_clean[2] = {false, false};
     int bn_mode = 0;                        // 0: BatchNorm statistics over the whole device batch; 1: per instance (validate.py semantics)
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
+    mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
     struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
                          const int32_t *gather_from = nullptr; int32_t *gathered = nullptr; } fs[2];   // [0] job actor, [1] machine actor
     // timing
@@ -1849,6 +1884,14 @@ extern "C" int mtfjsp_encoder_arm_selection(mtfjsp_encoder_t e, int32_t which, i
     return MTFJSP_OK;
 }
 
+extern "C" int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_ctx_t *ctx)
+{
+    if (!e || !ctx || !ctx->t || !ctx->p || !ctx->tt || !ctx->mean3 || !ctx->shop || !ctx->link || !ctx->m_fea1_out || !ctx->mmask_out) return MTFJSP_ERR_ARG;
+    if (ctx->M != e->cfg.n_machine || ctx->T != e->T) { e->err = "mfea1 context of a different problem size"; return MTFJSP_ERR_ARG; }
+    e->mf_ctx = *ctx; e->mf_armed = true;
+    return MTFJSP_OK;
+}
+
 static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
                                   const int32_t *candidate, const uint8_t *job_mask, const float *h_m_prev,
                                   float *prob, float *h_pooled, float *job_v, float *h_nodes)
@@ -1896,6 +1939,11 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
             e->gin_stats_clean = true;
         }
         arm_sampling(e, 0, ha);
+        if (e->mf_armed) {
+            e->mf_armed = false;
+            if (!ha.sample_mode || !ha.gather_from) { e->err = "mtfjsp_encoder_arm_mfea1 needs mtfjsp_encoder_arm_selection(which = 0) with gather_from"; return MTFJSP_ERR_STATE; }
+            ha.mf = e->mf_ctx; ha.mf_on = 1;
+        }
 #ifdef MTFJSP_STAMP
         static unsigned long long *d_st = nullptr;
         if (!d_st) (void)hipMalloc((void **)&d_st, 4096 * 8 * 8);

@@ -1558,6 +1558,17 @@ extern "C" int mtfjsp_observe_mfea1(mtfjsp_handle_t h, const int32_t *task_idx, 
     return MTFJSP_OK;
 }
 
+extern "C" int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask_out, mtfjsp_mfea1_ctx_t *ctx)
+{
+    if (!h || !m_fea1_out || !mmask_out || !ctx) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    ctx->t = h->t; ctx->p = h->p; ctx->tt = h->tt; ctx->mean3 = h->mean3; ctx->shop = h->shop; ctx->link = h->link;
+    ctx->m_fea1_out = m_fea1_out; ctx->mmask_out = mmask_out;
+    ctx->T = h->T; ctx->M = h->cfg.n_machine; ctx->obs_f32 = h->cfg.obs_dtype == MTFJSP_OBS_F32;
+    return MTFJSP_OK;
+}
+
 extern "C" int mtfjsp_random_actions(mtfjsp_handle_t h, uint64_t seed, uint64_t counter, int32_t *task_idx, int32_t *mach_idx, int32_t *job_idx)
 {
     if (!h || !task_idx || !mach_idx) return MTFJSP_ERR_ARG;

@@ -145,6 +145,10 @@ class Encoder:
             gather_from.data_ptr() if gather_from is not None else 0, gathered_out.data_ptr() if gathered_out is not None else 0),
             self.h, enc=True)
 
+    def arm_mfea1(self, ctx):
+        """the next job actor forward (with an armed selection) also writes m_fea1 / the machine mask of the selected tasks"""
+        capi.check(self.L.mtfjsp_encoder_arm_mfea1(self.h, C.byref(ctx)), self.h, enc=True)
+
     def timing_begin(self):
         capi.check(self.L.mtfjsp_encoder_timing_begin(self.h), self.h, enc=True)
 
@@ -169,6 +173,7 @@ class ActorPair:
         ja, ma = weights if weights is not None else random_init_weights(seed)
         self.enc.load_weights(ja, ma)
         self.greedy, self.seed = greedy, seed
+        self._mf_ctx, self._mf_env = None, None
         self.fused = not os.environ.get("MTFJSP_NO_FUSED_SELECT")   # action selection inside the heads kernels (same stream either way)
         dev = self.enc.device
         self.job_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
@@ -187,15 +192,21 @@ class ActorPair:
         jl = job_logp if job_logp is not None else self.job_logp
         ml = mach_logp if mach_logp is not None else self.mch_logp
         hm = e.h_pooled_m if self.have_hm else None
+        fuse_mfea1 = self.fused and force is None
         if self.fused:
             e.arm_selection(0, self.greedy, self.seed, 2 * counter, job_idx, jl, env.candidate, task_idx)
+            if fuse_mfea1:
+                if self._mf_env is not env:
+                    self._mf_ctx, self._mf_env = env.mfea1_context(), env
+                e.arm_mfea1(self._mf_ctx)
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
         else:
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
             e.sample(prob, self.greedy, self.seed, 2 * counter, job_idx, jl, env.candidate, task_idx)
         if force is not None:
             task_idx.copy_(force[0])
-        env.observe_mfea1(task_idx)                             # -> env.m_fea1, env.mmask
+        if not fuse_mfea1:
+            env.observe_mfea1(task_idx)                         # -> env.m_fea1, env.mmask (else: written by the heads kernel)
         if after_mfea1 is not None:
             after_mfea1(env)
         if self.fused:

@@ -223,6 +223,19 @@ int mtfjsp_global_critic_forward(mtfjsp_encoder_t e, const void *tasks_fea, cons
 int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *prob, int32_t n, int32_t greedy, uint64_t seed,
                               uint64_t counter, int32_t *idx_out, float *logp_out, const int32_t *gather_from,
                               int32_t *gathered_out);
+/* Device-side recipe of Parallel_env.cal_cur_task_machine_feature (pe:152-214) for ONE decision: everything
+ * mtfjsp_observe_mfea1 reads and writes, as plain device pointers, so that the job actor's heads kernel can produce
+ * m_fea1 / the machine mask for the task it has just selected (one launch less between the two actor forwards).
+ * Filled by mtfjsp_get_mfea1_context (environment side), consumed by mtfjsp_encoder_arm_mfea1 (encoder side). */
+typedef struct {
+    const double *t, *p, *tt, *mean3;   /* [B,T,M], [B,T,M], [B,M,M], [B,T,3] */
+    const int32_t *shop;                /* [B,M] */
+    const void *link;                   /* [B,T] 8-byte task records {i16 machine, prev, pos, next} */
+    void *m_fea1_out;                   /* [B,M,6] obs dtype */
+    uint8_t *mmask_out;                 /* [B,M] */
+    int32_t T, M, obs_f32;
+} mtfjsp_mfea1_ctx_t;
+int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask_out, mtfjsp_mfea1_ctx_t *ctx);
 /* BatchNorm statistics of the two actor forwards (every BatchNorm in the reference is in training mode):
  * per_instance = 0 (default): over all rows of the device batch = one reference run with env_batch = B (training rollout);
  * per_instance = 1: over the rows of ONE instance = B independent reference runs with env_batch = 1, i.e. the greedy
@@ -233,6 +246,9 @@ int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance);
  * (agent:22-72), one launch less per decision.  One-shot: applies to one forward call. */
 int mtfjsp_encoder_arm_selection(mtfjsp_encoder_t e, int32_t which, int32_t greedy, uint64_t seed, uint64_t counter,
                                  int32_t *idx_out, float *logp_out, const int32_t *gather_from, int32_t *gathered_out);
+/* One-shot like mtfjsp_encoder_arm_selection (and only together with it, which = 0): the next job actor forward also
+ * writes m_fea1 / the machine mask of every instance's selected task (== mtfjsp_observe_mfea1 on gathered_out). */
+int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_ctx_t *ctx);
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
 int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);
 /* per kernel family (between begin and the next begin): "gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg",

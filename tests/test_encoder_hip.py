@@ -107,12 +107,17 @@ def test_fused_selection_equals_standalone_sampler():
         idx_f, task_f, idx_s, task_s = mk(), mk(), mk(), mk()
         lp_f, lp_s = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
         e.arm_selection(0, greedy, 1234, 77, idx_f, lp_f, env.candidate, task_f)
+        env.m_fea1.fill_(-5); env.mmask.fill_(9)
+        e.arm_mfea1(env.mfea1_context())                           # m_fea1 / machine mask of the selected task from the same kernel
         prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, e.h_pooled_m)
         e.sample(prob, greedy, 1234, 77, idx_s, lp_s, env.candidate, task_s)
         torch.cuda.synchronize()
         assert torch.equal(idx_f, idx_s) and torch.equal(task_f, task_s) and torch.equal(lp_f, lp_s)
         assert int(idx_f.min()) >= 0
+        mf_fused, mm_fused = env.m_fea1.clone(), env.mmask.clone()
         env.observe_mfea1(task_f)
+        torch.cuda.synchronize()
+        assert torch.equal(mf_fused, env.m_fea1) and torch.equal(mm_fused, env.mmask)
         midx_f, midx_s = mk(), mk()
         mlp_f, mlp_s = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
         e.arm_selection(1, greedy, 1234, 78, midx_f, mlp_f)
