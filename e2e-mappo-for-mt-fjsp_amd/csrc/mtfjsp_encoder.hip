@@ -276,23 +276,29 @@ __global__ __launch_bounds__(512) void k_gemm16p(GemmArgs A)
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
     const unsigned long long t_first = t_last;
 #endif
+    // the first tile's rows are requested before anything else: their HBM latency hides behind the W^T / BatchNorm staging
+    const int ntiles = (A.N + 15) / 16;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int first = blockIdx.x * per;
+    const int last = first + per < ntiles ? first + per : ntiles;
+    const int lane_off = h * HD + c4;
+    float4 pre[8];
+    if (first + wave < last) {
+        const float *tb0 = A.in + (size_t)(first + wave) * 16 * HD;
+#pragma unroll
+        for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(tb0 + p * 2 * HD + lane_off);
+    }
     stage_w16(s_w, A.Wt, tid);
     stage_bn(s_bn, A.pro_stats, A.pro_inv_rows, A.pro_gamma, A.pro_beta, tid);
     __syncthreads();
     STAMP(0);
     float *my_a = s_a + wave * 16 * LDA16;
-    const int ntiles = (A.N + 15) / 16;
-    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int first = blockIdx.x * per;
-    const int last = first + per < ntiles ? first + per : ntiles;
     double st_sum[8], st_sq[8];
     for (int c = 0; c < 8; c++) { st_sum[c] = 0; st_sq[c] = 0; }
     const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
     const float sh0 = s_bn[HD + c4], sh1 = s_bn[HD + c4 + 1], sh2 = s_bn[HD + c4 + 2], sh3 = s_bn[HD + c4 + 3];
     float bias8[8];
     for (int c = 0; c < 8; c++) bias8[c] = A.bias ? A.bias[c * 16 + m] : 0.f;
-    const int lane_off = h * HD + c4;
-    float4 pre[8];
     constexpr int NA = (PRO == PRO_AGG) ? 8 : 1;
     float4 nb0[NA], nb1[NA];
     int e_ox = 0, e_oy = 0, en_ox = 0, en_oy = 0;
@@ -370,8 +376,17 @@ __global__ __launch_bounds__(512) void k_gemm16p(GemmArgs A)
     // four different SIMDs)
     int t_cur = first + wave, t_n1 = t_cur + 8;
     if (t_cur < last) {
-        if (PRO == PRO_AGG) fetch_ell(t_cur);
-        prefetch(t_cur);
+        if (PRO == PRO_AGG) {                                     // own rows are already in flight; ELL entries, then the neighbour rows
+            fetch_ell(t_cur);
+            e_ox = en_ox; e_oy = en_oy; e_vx = en_vx; e_vy = en_vy; e_dg = en_dg;
+            const float *tb = A.in + (size_t)t_cur * 16 * HD;
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const int ox = __shfl(e_ox, 2 * p + h), oy = __shfl(e_oy, 2 * p + h);
+                nb0[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)ox * HD + c4);
+                nb1[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)oy * HD + c4);
+            }
+        }
         if (PRO == PRO_AGG && t_n1 < last) fetch_ell(t_n1);
 #pragma unroll
         for (int p = 0; p < 8; p++) transform_rows(p);
