@@ -47,3 +47,16 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("no oracle", ""), f"{f} mentions the oracle"
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/mtfjsp.h is the drop-in boundary: it must be consumable from C (no C++-only constructs, no torch types)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "mtfjsp.h"\nint main(void) { mtfjsp_config_t c; mtfjsp_obs_t o; mtfjsp_mfea1_ctx_t m; (void)c; (void)o; (void)m; return 0; }\n')
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)])
