@@ -3,6 +3,8 @@ import os
 import re
 from importlib import import_module
 
+import pytest
+
 import mtfjsp_amd  # noqa: F401
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
