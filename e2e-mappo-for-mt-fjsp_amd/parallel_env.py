@@ -12,7 +12,6 @@ Differences that are deliberate (documented in DESIGN.md §6):
     silently corrupting node attributes (env:1496-1528); never reached under the reference's masks;
   * per-env `.step()` / `.render()` of the proxies are not available (the batch steps together).
 """
-import random
 
 import numpy as np
 import torch

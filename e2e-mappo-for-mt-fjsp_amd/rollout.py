@@ -4,10 +4,8 @@ sample -> env step + job mask] x T -> done) with every tensor staying in HBM.
 policy="random": uniform random valid actions drawn on device (Philox) — env-only workload.
 policy="actor" : the GIN job actor and the GAT machine actor run as HIP kernels (encoder.py) and sample the joint action.
 """
-import ctypes as C
-import random as _random
-
 import os
+import random as _random
 
 import numpy as np
 import torch
