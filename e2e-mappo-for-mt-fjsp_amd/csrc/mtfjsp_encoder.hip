@@ -40,6 +40,7 @@ struct GemmArgs {
     const float *in;        // [N,128] producer output (pre-activation for PRO_BNRELU / PRO_AGG)
     int N;
     const float *Wt;        // [128(k),128(n)] = W^T of a torch Linear weight [out,in]
+    const void *Wx6;        // the same weight as bf16 x 3-plane register images (mtfjsp_encoder::wx6), k_gemm_x6
     const float *bias;      // [128] or NULL
     float *out;             // [N,128]
     // prologue: BatchNorm of `in` from the producer's column sums
@@ -458,6 +459,174 @@ __global__ __launch_bounds__(512) void k_gemm16p(GemmArgs A)
         for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
 #endif
 }
+
+// ---------------------------------------------------------------------------------------------
+// k_gemm_x6 — the GIN product on the bf16 matrix cores at f32 accuracy.
+//
+// Measured on gfx950 (tools/ubench/mfma_valu.hip): v_mfma_f32_16x16x4_f32 runs at the packed-f32 VALU rate (one per 32
+// cycles per SIMD, 155 TFLOP/s chip-wide) and does NOT overlap with VALU work — every VALU instruction of either wave
+// adds its 4 cycles to the SIMD's time — so an f32-input product kernel is bounded by matrix time + all side work.
+// v_mfma_f32_16x16x32_bf16 does 8x the flops in half the cycles.  Each f32 operand is therefore split exactly into three
+// bf16 pieces (round-to-nearest: x = x0 + x1 + x2, |x1| <= 2^-9 |x|, |x2| <= 2^-18 |x|) and the product is formed from
+// the six piece products of weight >= 2^-18 (x0w0, x0w1, x1w0, x1w1, x0w2, x2w0), accumulated in f32 by the matrix core,
+// smallest terms first.  The dropped terms are <= 2^-26 relative — below the 2^-24 rounding of an f32 FMA — and
+// tools/ubench/bf16x6.hip measures the result against f64: mean |error| 6.8e-8 vs 8.3e-8 for the f32 instruction.
+// 6 products x 4 k-steps x 16 cycles = 384 cycles per 16x16 output tile instead of 1024.
+//
+// Layout: 8 waves; wave w owns output columns 32(w&3)..+31 (two 16-column blocks: 2 x 3 planes x 4 k-steps of weight
+// fragments = 96 registers, loaded once from the weight's bf16 register image) and the tiles 2i + (w>>2) of every batch
+// of eight 16-row tiles.  Per batch: (T) each wave BatchNorm+ReLU-transforms one tile from registers, splits it and
+// writes three bf16 planes to LDS (row pitch 272 B: conflict-free 16-byte operand reads), then requests its tile of
+// the next batch; barrier; (M) 4 tiles x 2 column blocks x 24 products per wave with the operand fragments of the next
+// k-step in flight, 16-byte stores of the transposed accumulators (lane = row m, 4 consecutive columns) and the column
+// sums; barrier.  The kernel is HBM-bound (1 KiB per row).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#define X6_ROWB 272
+#define X6_PLANE (16 * X6_ROWB)
+#define X6_TILE (3 * X6_PLANE)
+__device__ __forceinline__ void split3x4(const float (&v)[4], bf16x4 &p0, bf16x4 &p1, bf16x4 &p2)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const __bf16 h = (__bf16)v[i];
+        const float r1 = v[i] - (float)h;
+        const __bf16 md = (__bf16)r1;
+        const float r2 = r1 - (float)md;
+        p0[i] = h; p1[i] = md; p2[i] = (__bf16)r2;
+    }
+}
+template <int PRO>
+__global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *s_tiles = smem;                                // [8 tiles][3 planes][16 rows x 272 B]
+    double *s_stat = reinterpret_cast<double *>(smem + 8 * X6_TILE);   // column sums | sums of squares of this workgroup
+    float *s_bn = reinterpret_cast<float *>(s_stat + 2 * HD);     // scale | shift
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5, c4 = j * 4;           // load / transform mapping: rows 2p+h, 4 columns
+    const int m = lane & 15, q = lane >> 4;                       // matrix mapping (operands swapped): A[col c0+m][k = 8q..], B[k = 8q..][row m], C[col c0+4q+i][row m]
+    const int cg = wave & 3, th = wave >> 2;
+    const int ntiles = (A.N + 15) / 16;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int first = blockIdx.x * per;
+    const int last = first + per < ntiles ? first + per : ntiles;
+    const int lane_off = h * HD + c4;
+    float4 pre[8];
+    auto request_rows = [&](int tile) __attribute__((always_inline)) {
+        const float *tb = A.in + (size_t)tile * 16 * HD;
+#pragma unroll
+        for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
+    };
+    if (first + wave < last) request_rows(first + wave);
+    bf16x8 wf[2][3][4];                                           // [column block][plane][k-step]: W[32cg + 16c + m][32ks + 8q .. +7]
+    {
+        const float4 *wi = reinterpret_cast<const float4 *>(A.Wx6) + (size_t)cg * (2 * 3 * 4 * 64) + lane;
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int p = 0; p < 3; p++)
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const float4 v = wi[((c * 3 + p) * 4 + ks) * 64];
+                    wf[c][p][ks] = __builtin_bit_cast(bf16x8, v);
+                }
+    }
+    stage_bn(s_bn, A.pro_stats, A.pro_inv_rows, A.pro_gamma, A.pro_beta, tid);
+    if (tid < 2 * HD) s_stat[tid] = 0.0;
+    __syncthreads();
+    const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
+    const float sh0 = s_bn[HD + c4], sh1 = s_bn[HD + c4 + 1], sh2 = s_bn[HD + c4 + 2], sh3 = s_bn[HD + c4 + 3];
+    f32x4 biasv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (A.bias) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const float4 b = *reinterpret_cast<const float4 *>(A.bias + 32 * cg + 16 * c + 4 * q);
+            biasv[c] = f32x4{b.x, b.y, b.z, b.w};
+        }
+    }
+    const unsigned char *xa = s_tiles + m * X6_ROWB + 16 * q;     // operand fragment (tile t, plane p, k-step ks): xa + t*X6_TILE + p*X6_PLANE + 64*ks
+    for (int tb = first; tb < last; tb += 8) {
+        const int nt = last - tb < 8 ? last - tb : 8;
+        // ---- (T) this wave's tile: BatchNorm + ReLU, split, three bf16 planes to LDS
+        if (wave < nt) {
+            unsigned char *dst = s_tiles + wave * X6_TILE + h * X6_ROWB + j * 8;
+#pragma unroll
+            for (int p = 0; p < 8; p++) {
+                const float v[4] = {bn_relu_ss(pre[p].x, sc0, sh0), bn_relu_ss(pre[p].y, sc1, sh1), bn_relu_ss(pre[p].z, sc2, sh2), bn_relu_ss(pre[p].w, sc3, sh3)};
+                bf16x4 p0, p1, p2;
+                split3x4(v, p0, p1, p2);
+                *reinterpret_cast<bf16x4 *>(dst + p * 2 * X6_ROWB) = p0;
+                *reinterpret_cast<bf16x4 *>(dst + p * 2 * X6_ROWB + X6_PLANE) = p1;
+                *reinterpret_cast<bf16x4 *>(dst + p * 2 * X6_ROWB + 2 * X6_PLANE) = p2;
+            }
+        }
+        if (tb + 8 + wave < last) request_rows(tb + 8 + wave);    // in flight during (M), used in the next (T)
+        LDS_BARRIER();
+        // ---- (M) tiles 2i + th x two column blocks
+        float ts[2][4], tq[2][4];
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { ts[c][i] = 0.f; tq[c][i] = 0.f; }
+        bf16x8 xf[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + th * X6_TILE + p * X6_PLANE);
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) {
+            const int t = 2 * tt + th;
+            const bool on = t < nt;
+            f32x4 acc[2] = {biasv[0], biasv[1]};
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                const int u = tt * 4 + ks;
+                if (u + 1 < 16) {                                 // fragments of the next (tile, k-step); a stale tile beyond nt is read but never used
+                    const int tn = 2 * ((u + 1) >> 2) + th, kn = (u + 1) & 3;
+#pragma unroll
+                    for (int p = 0; p < 3; p++) xf[(u + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(xa + tn * X6_TILE + p * X6_PLANE + 64 * kn);
+                }
+                if (on) {
+                    const bf16x8 *x = xf[u & 1];
+#pragma unroll
+                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[2], acc[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][2][ks], x[0], acc[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][1][ks], x[1], acc[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[1], acc[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][1][ks], x[0], acc[c], 0, 0, 0);
+#pragma unroll
+                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[0], acc[c], 0, 0, 0);
+                }
+            }
+            if (on) {
+                const int row = (tb + t) * 16 + m;
+                const bool ok = row < A.N;
+                float *ob = A.out + (size_t)row * HD + 32 * cg + 4 * q;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const f32x4 v = acc[c];
+                    *reinterpret_cast<float4 *>(ob + 16 * c) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { const float x = ok ? v[i] : 0.f; ts[c][i] += x; tq[c][i] += x * x; }
+                }
+            }
+        }
+        // column sums of this batch: 16 rows (lanes m) -> one value per column, f64 from there on
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const float a = row_sum16(ts[c][i]), b = row_sum16(tq[c][i]);
+                if (m == 0) { atomicAdd(&s_stat[32 * cg + 16 * c + 4 * q + i], (double)a); atomicAdd(&s_stat[HD + 32 * cg + 16 * c + 4 * q + i], (double)b); }
+            }
+        LDS_BARRIER();                                            // every operand read of this batch is done: the planes may be overwritten
+    }
+    if (tid < 2 * HD) atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], s_stat[tid]);
+}
+static size_t gemm_x6_lds_bytes() { return (size_t)8 * X6_TILE + 2 * HD * 8 + 2 * HD * 4 + 64; }
 
 // ---------------------------------------------------------------------------------------------
 // Machine path of the machine actor / global critic (ac:383-434, gat:82-159) in ONE launch.  The three applications of
@@ -1452,6 +1621,7 @@ struct mtfjsp_encoder {
     std::map<std::string, float *> wt;      // transposed [in,out] copies of the 128-wide Linear weights (split per 128-block of `in`)
     std::map<std::string, std::vector<float>> hostw;   // host copies of gat_layer.W / m_fea_*_fcl.weight (inputs of the fused projections)
     std::map<std::string, float *> wfused;  // per prefix + "1"/"2": (m_fea_k_fcl.weight^T . gat_layer.W)^T, [128,6] / [128,8]
+    std::map<std::string, void *> wx6;      // 128x128 Linear weights as 3 bf16 planes in k_gemm_x6's register-image order
     std::map<std::string, float *> wimg;    // the same blocks as per-wave register images for k_heads: [block][wave 8][g 8][lane 64][4]
     std::vector<void *> owned;
     int num_cu = 256;
@@ -1565,6 +1735,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gemm16p<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_gemm16p<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_gat3, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gin_inst<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gin_inst<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
@@ -1638,6 +1809,30 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
             else { if (dalloc(e, &di, (size_t)numel)) return MTFJSP_ERR_HIP; e->wimg[key] = di; }
             HIPCHK(e, hipMemcpy(di, im.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
         }
+        if (!is_gat_w && blocks == 1) {
+            // k_gemm_x6: exact 3-way bf16 split (round-to-nearest-even each), img[cg 4][c 2][plane 3][ks 4][lane 64][i 8] =
+            // plane(W[n = 32cg + 16c + (lane & 15)][k = 32ks + 8(lane >> 4) + i]);  W is the torch layout [out n][in k]
+            auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+            auto from_bf16 = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
+            std::vector<uint16_t> im((size_t)3 * HD * HD);
+            for (int cgi = 0; cgi < 4; cgi++)
+                for (int c = 0; c < 2; c++)
+                    for (int ks = 0; ks < 4; ks++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int i = 0; i < 8; i++) {
+                                const int n = 32 * cgi + 16 * c + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + i;
+                                const float w = data[(size_t)n * HD + k];
+                                const uint16_t p0 = to_bf16(w); const float r1 = w - from_bf16(p0);
+                                const uint16_t p1 = to_bf16(r1); const float r2 = r1 - from_bf16(p1);
+                                const uint16_t pl[3] = {p0, p1, to_bf16(r2)};
+                                for (int p = 0; p < 3; p++) im[((((((size_t)cgi * 2 + c) * 3 + p) * 4 + ks) * 64 + lane) * 8) + i] = pl[p];
+                            }
+            void *dx = nullptr;
+            auto kt = e->wx6.find(key);
+            if (kt != e->wx6.end()) dx = kt->second;
+            else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx6[key] = dx; }
+            HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
+        }
     }
     return MTFJSP_OK;
 }
@@ -1680,7 +1875,11 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
     b.stamps = d_st;
 #endif
     if constexpr (PRO == PRO_PLAIN) hipLaunchKernelGGL((k_gemm16<EPI, ACC>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
-    else hipLaunchKernelGGL((k_gemm16p<PRO>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
+    else {
+        static const int f32mfma = getenv("MTFJSP_GEMM_F32MFMA") ? 1 : 0;      // A/B switch: the f32-instruction kernel
+        if (PRO == PRO_BNRELU && b.Wx6 && !f32mfma) hipLaunchKernelGGL((k_gemm_x6<PRO_BNRELU>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
+        else hipLaunchKernelGGL((k_gemm16p<PRO>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
+    }
 #ifdef MTFJSP_STAMP
     static int printed = 0;
     if (PRO != PRO_PLAIN && printed < 40 && getenv("MTFJSP_STAMP_PRINT")) {
@@ -1695,8 +1894,8 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
                 for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i];
             }
             for (int i = 0; i < 8; i++) m[i] /= n;
-            printf("STAMP %-18s N=%d grid=%d half=%d  tiles %.2f  W+bn+sync %.0f  first-tile %.0f  tile-loop %.0f  tail %.0f | kernel %.0f shader ticks = %.2f us (s_memrealtime)\n",
-                   name, a.N, grid, half, m[7], m[0], m[1], m[4], m[6], m[2], m[3] / 100.0);
+            printf("STAMP %-18s N=%d grid=%d half=%d  tiles|chunk-epilogue %.2f  W+bn+sync %.0f  first-tile|matrix %.0f  tile-loop|barrier %.0f  take+transform %.0f  to-barrier %.0f | kernel %.0f shader ticks = %.2f us (s_memrealtime)\n",
+                   name, a.N, grid, half, m[7], m[0], m[1], m[4], m[5], m[6], m[2], m[3] / 100.0);
         }
         printed++;
     }
@@ -1737,6 +1936,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         GemmArgs a = gemm_args(in, N, WT(P + lin + ".weight"), W(P + lin + ".bias"), out);
         a.pro_stats = st + sin * STAT_REP * 256; a.pro_gamma = W(P + bn + ".weight"); a.pro_beta = W(P + bn + ".bias"); a.pro_inv_rows = invN;
         a.epi_stats = st + sout * STAT_REP * 256;
+        a.Wx6 = e->wx6.at(P + lin + ".weight");
         launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_bn_relu");
     };
     bn_gemm(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1);
