@@ -485,16 +485,26 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define X6_ROWB 272
 #define X6_PLANE (16 * X6_ROWB)
 #define X6_TILE (3 * X6_PLANE)
-__device__ __forceinline__ void split3x4(const float (&v)[4], bf16x4 &p0, bf16x4 &p1, bf16x4 &p2)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// exact 3-way split of four f32 values into bf16 pieces (round-to-nearest-even), two packed dwords per plane
+__device__ __forceinline__ void split3x4(const float (&v)[4], uint2 &p0, uint2 &p1, uint2 &p2)
 {
+    unsigned o[3][2];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const __bf16 h = (__bf16)v[i];
-        const float r1 = v[i] - (float)h;
-        const __bf16 md = (__bf16)r1;
-        const float r2 = r1 - (float)md;
-        p0[i] = h; p1[i] = md; p2[i] = (__bf16)r2;
+    for (int hlf = 0; hlf < 2; hlf++) {
+        float a = v[2 * hlf], b = v[2 * hlf + 1];
+#pragma unroll
+        for (int lvl = 0; lvl < 3; lvl++) {
+            const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));   // v_cvt_pk_bf16_f32
+            o[lvl][hlf] = pk;
+            if (lvl < 2) {                                        // remainders are exact: a - bf16(a) has <= 16 significant bits
+                a -= __builtin_bit_cast(float, pk << 16);
+                b -= __builtin_bit_cast(float, pk & 0xffff0000u);
+            }
+        }
     }
+    p0 = make_uint2(o[0][0], o[0][1]); p1 = make_uint2(o[1][0], o[1][1]); p2 = make_uint2(o[2][0], o[2][1]);
 }
 template <int PRO>
 __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
@@ -507,6 +517,12 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     const int j = lane & 31, h = lane >> 5, c4 = j * 4;           // load / transform mapping: rows 2p+h, 4 columns
     const int m = lane & 15, q = lane >> 4;                       // matrix mapping (operands swapped): A[col c0+m][k = 8q..], B[k = 8q..][row m], C[col c0+4q+i][row m]
     const int cg = wave & 3, th = wave >> 2;
+#ifdef MTFJSP_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last, rt0, rt1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
+    const unsigned long long t_first = t_last;
+#endif
     const int ntiles = (A.N + 15) / 16;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
     const int first = blockIdx.x * per;
@@ -518,6 +534,14 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 #pragma unroll
         for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
     };
+    // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of the input, first tile, weights
+    double bsu[STAT_REP], bsq[STAT_REP];
+    float bga = 0.f, bbe = 0.f;
+    if (tid < HD) {
+#pragma unroll
+        for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.pro_stats[r * 256 + tid]; bsq[r] = A.pro_stats[r * 256 + HD + tid]; }
+        bga = A.pro_gamma[tid]; bbe = A.pro_beta[tid];
+    }
     if (first + wave < last) request_rows(first + wave);
     bf16x8 wf[2][3][4];                                           // [column block][plane][k-step]: W[32cg + 16c + m][32ks + 8q .. +7]
     {
@@ -532,9 +556,20 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                     wf[c][p][ks] = __builtin_bit_cast(bf16x8, v);
                 }
     }
-    stage_bn(s_bn, A.pro_stats, A.pro_inv_rows, A.pro_gamma, A.pro_beta, tid);
+    if (tid < HD) {                                               // stage_bn() from the registers requested above
+        double su = 0, sq = 0;
+#pragma unroll
+        for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
+        const double mean = su * A.pro_inv_rows;
+        double var = sq * A.pro_inv_rows - mean * mean;           // biased variance (training-mode BN)
+        if (var < 0) var = 0;
+        const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
+        const float sc = rstd * bga;
+        s_bn[tid] = sc;
+        s_bn[HD + tid] = bbe - (float)mean * sc;
+    }
     if (tid < 2 * HD) s_stat[tid] = 0.0;
-    __syncthreads();
+    LDS_BARRIER();                                                // (not __syncthreads: the weight fragments stay in flight behind the first transform)
     const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
     const float sh0 = s_bn[HD + c4], sh1 = s_bn[HD + c4 + 1], sh2 = s_bn[HD + c4 + 2], sh3 = s_bn[HD + c4 + 3];
     f32x4 biasv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -545,7 +580,13 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             biasv[c] = f32x4{b.x, b.y, b.z, b.w};
         }
     }
+    STAMP(0);
     const unsigned char *xa = s_tiles + m * X6_ROWB + 16 * q;     // operand fragment (tile t, plane p, k-step ks): xa + t*X6_TILE + p*X6_PLANE + 64*ks
+    float ts[2][4], tq[2][4];                                     // per-lane column sums (row m of the tiles this wave multiplied)
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) { ts[c][i] = 0.f; tq[c][i] = 0.f; }
     for (int tb = first; tb < last; tb += 8) {
         const int nt = last - tb < 8 ? last - tb : 8;
         // ---- (T) this wave's tile: BatchNorm + ReLU, split, three bf16 planes to LDS
@@ -554,38 +595,36 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 #pragma unroll
             for (int p = 0; p < 8; p++) {
                 const float v[4] = {bn_relu_ss(pre[p].x, sc0, sh0), bn_relu_ss(pre[p].y, sc1, sh1), bn_relu_ss(pre[p].z, sc2, sh2), bn_relu_ss(pre[p].w, sc3, sh3)};
-                bf16x4 p0, p1, p2;
+                uint2 p0, p1, p2;
                 split3x4(v, p0, p1, p2);
-                *reinterpret_cast<bf16x4 *>(dst + p * 2 * X6_ROWB) = p0;
-                *reinterpret_cast<bf16x4 *>(dst + p * 2 * X6_ROWB + X6_PLANE) = p1;
-                *reinterpret_cast<bf16x4 *>(dst + p * 2 * X6_ROWB + 2 * X6_PLANE) = p2;
+                *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB) = p0;
+                *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + X6_PLANE) = p1;
+                *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + 2 * X6_PLANE) = p2;
             }
         }
         if (tb + 8 + wave < last) request_rows(tb + 8 + wave);    // in flight during (M), used in the next (T)
+        STAMP(1);
         LDS_BARRIER();
+        STAMP(4);
         // ---- (M) tiles 2i + th x two column blocks
-        float ts[2][4], tq[2][4];
+        auto tiles4 = [&](auto FULLc) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(FULLc)::value;        // FULL: all eight tiles exist and none holds rows >= N
+            bf16x8 xf[2][3];
 #pragma unroll
-        for (int c = 0; c < 2; c++)
+            for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + th * X6_TILE + p * X6_PLANE);
 #pragma unroll
-            for (int i = 0; i < 4; i++) { ts[c][i] = 0.f; tq[c][i] = 0.f; }
-        bf16x8 xf[2][3];
+            for (int tt = 0; tt < 4; tt++) {
+                const int t = 2 * tt + th;
+                if (!FULL && t >= nt) break;
+                f32x4 acc[2] = {biasv[0], biasv[1]};
 #pragma unroll
-        for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + th * X6_TILE + p * X6_PLANE);
+                for (int ks = 0; ks < 4; ks++) {
+                    const int u = tt * 4 + ks;
+                    if (u + 1 < 16) {                             // fragments of the next (tile, k-step); a stale tile beyond nt is read but never used
+                        const int tn = 2 * ((u + 1) >> 2) + th, kn = (u + 1) & 3;
 #pragma unroll
-        for (int tt = 0; tt < 4; tt++) {
-            const int t = 2 * tt + th;
-            const bool on = t < nt;
-            f32x4 acc[2] = {biasv[0], biasv[1]};
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                const int u = tt * 4 + ks;
-                if (u + 1 < 16) {                                 // fragments of the next (tile, k-step); a stale tile beyond nt is read but never used
-                    const int tn = 2 * ((u + 1) >> 2) + th, kn = (u + 1) & 3;
-#pragma unroll
-                    for (int p = 0; p < 3; p++) xf[(u + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(xa + tn * X6_TILE + p * X6_PLANE + 64 * kn);
-                }
-                if (on) {
+                        for (int p = 0; p < 3; p++) xf[(u + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(xa + tn * X6_TILE + p * X6_PLANE + 64 * kn);
+                    }
                     const bf16x8 *x = xf[u & 1];
 #pragma unroll
                     for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[2], acc[c], 0, 0, 0);
@@ -600,31 +639,46 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 #pragma unroll
                     for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[0], acc[c], 0, 0, 0);
                 }
-            }
-            if (on) {
                 const int row = (tb + t) * 16 + m;
-                const bool ok = row < A.N;
+                const bool ok = FULL || row < A.N;
                 float *ob = A.out + (size_t)row * HD + 32 * cg + 4 * q;
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
                     const f32x4 v = acc[c];
                     *reinterpret_cast<float4 *>(ob + 16 * c) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) { const float x = ok ? v[i] : 0.f; ts[c][i] += x; tq[c][i] += x * x; }
+                    for (int i = 0; i < 4; i++) { const float x = ok ? v[i] : 0.f; ts[c][i] += x; tq[c][i] = __builtin_fmaf(x, x, tq[c][i]); }
                 }
             }
+        };
+        if (nt == 8 && (tb + 8) * 16 <= A.N) tiles4(std::true_type{});
+        else tiles4(std::false_type{});
+        STAMP(5);
+        // column sums: 16 rows (lanes m) -> one value per column, f64 from there on; every 4th batch (f32 partial sums of
+        // <= 16 values per lane) and after the last one
+        if (((tb - first) & 31) == 24 || tb + 8 >= last) {
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float a = row_sum16(ts[c][i]), b = row_sum16(tq[c][i]);
+                    if (m == 0) { atomicAdd(&s_stat[32 * cg + 16 * c + 4 * q + i], (double)a); atomicAdd(&s_stat[HD + 32 * cg + 16 * c + 4 * q + i], (double)b); }
+                    ts[c][i] = 0.f; tq[c][i] = 0.f;
+                }
         }
-        // column sums of this batch: 16 rows (lanes m) -> one value per column, f64 from there on
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const float a = row_sum16(ts[c][i]), b = row_sum16(tq[c][i]);
-                if (m == 0) { atomicAdd(&s_stat[32 * cg + 16 * c + 4 * q + i], (double)a); atomicAdd(&s_stat[HD + 32 * cg + 16 * c + 4 * q + i], (double)b); }
-            }
+        STAMP(6);
         LDS_BARRIER();                                            // every operand read of this batch is done: the planes may be overwritten
+        STAMP(7);
     }
     if (tid < 2 * HD) atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], s_stat[tid]);
+#ifdef MTFJSP_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt1)::"memory");
+    ph[2] = t_last - t_first; ph[3] = rt1 - rt0;
+    if (A.stamps && lane == 0)
+        for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
+#endif
 }
 static size_t gemm_x6_lds_bytes() { return (size_t)8 * X6_TILE + 2 * HD * 8 + 2 * HD * 4 + 64; }
 
@@ -1894,7 +1948,7 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
                 for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i];
             }
             for (int i = 0; i < 8; i++) m[i] /= n;
-            printf("STAMP %-18s N=%d grid=%d half=%d  tiles|chunk-epilogue %.2f  W+bn+sync %.0f  first-tile|matrix %.0f  tile-loop|barrier %.0f  take+transform %.0f  to-barrier %.0f | kernel %.0f shader ticks = %.2f us (s_memrealtime)\n",
+            printf("STAMP %-18s N=%d grid=%d half=%d  tiles|x6:barrier2 %.2f  W+bn+sync %.0f  first-tile|x6:T %.0f  tile-loop|x6:barrier1 %.0f  x6:M %.0f  x6:fold %.0f | kernel %.0f shader ticks = %.2f us (s_memrealtime)\n",
                    name, a.N, grid, half, m[7], m[0], m[1], m[4], m[5], m[6], m[2], m[3] / 100.0);
         }
         printed++;
