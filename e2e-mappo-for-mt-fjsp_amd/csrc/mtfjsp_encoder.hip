@@ -473,13 +473,17 @@ __global__ __launch_bounds__(512) void k_gemm16p(GemmArgs A)
 // tools/ubench/bf16x6.hip measures the result against f64: mean |error| 6.8e-8 vs 8.3e-8 for the f32 instruction.
 // 6 products x 4 k-steps x 16 cycles = 384 cycles per 16x16 output tile instead of 1024.
 //
-// Layout: 8 waves; wave w owns output columns 32(w&3)..+31 (two 16-column blocks: 2 x 3 planes x 4 k-steps of weight
-// fragments = 96 registers, loaded once from the weight's bf16 register image) and the tiles 2i + (w>>2) of every batch
-// of eight 16-row tiles.  Per batch: (T) each wave BatchNorm+ReLU-transforms one tile from registers, splits it and
-// writes three bf16 planes to LDS (row pitch 272 B: conflict-free 16-byte operand reads), then requests its tile of
-// the next batch; barrier; (M) 4 tiles x 2 column blocks x 24 products per wave with the operand fragments of the next
-// k-step in flight, 16-byte stores of the transposed accumulators (lane = row m, 4 consecutive columns) and the column
-// sums; barrier.  The kernel is HBM-bound (1 KiB per row).
+// Layout: 4 consumer waves + 4 producer waves, one of each per SIMD, stepping through groups of four 16-row tiles with two
+// LDS plane buffers and ONE barrier per step:
+//   * producer wave w (4..7): BatchNorm+ReLU (PRO_AGG: + neighbour aggregation over the ELL adjacency, f64 accumulate) of
+//     tile 4s + (w-4) from registers, exact split, three bf16 planes to buffer s&1 (row pitch 272 B: conflict-free
+//     16-byte operand reads); its rows are requested two steps ahead, the aggregation's neighbour rows one step ahead.
+//   * consumer wave w (0..3) owns output columns 32w..32w+31 (2 x 3 planes x 4 k-steps of weight fragments = 96
+//     registers, loaded once from the weight's bf16 register image): in step s it multiplies the four tiles of buffer
+//     (s-1)&1 — 4 x 2 x 24 products, operand fragments of the next k-step in flight — stores the transposed accumulators
+//     (lane = row m, 4 consecutive columns: 16-byte stores) and keeps the BatchNorm column sums of the output.
+//   The two roles never hold each other's registers (weights vs. rows in flight), a transform's memory latency is covered
+//   by the consumer on the same SIMD, and the consumers are the older waves, which the issue arbiter favours.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define X6_ROWB 272
@@ -510,31 +514,22 @@ template <int PRO>
 __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *s_tiles = smem;                                // [8 tiles][3 planes][16 rows x 272 B]
+    unsigned char *s_tiles = smem;                                // [2 buffers][4 tiles][3 planes][16 rows x 272 B]
     double *s_stat = reinterpret_cast<double *>(smem + 8 * X6_TILE);   // column sums | sums of squares of this workgroup
     float *s_bn = reinterpret_cast<float *>(s_stat + 2 * HD);     // scale | shift
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int j = lane & 31, h = lane >> 5, c4 = j * 4;           // load / transform mapping: rows 2p+h, 4 columns
-    const int m = lane & 15, q = lane >> 4;                       // matrix mapping (operands swapped): A[col c0+m][k = 8q..], B[k = 8q..][row m], C[col c0+4q+i][row m]
-    const int cg = wave & 3, th = wave >> 2;
+    const int ntiles = (A.N + 15) / 16;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int first = blockIdx.x * per;
+    const int last = first + per < ntiles ? first + per : ntiles;
+    const int nsteps = last > first ? (last - first + 3) >> 2 : 0;
 #ifdef MTFJSP_STAMP
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last, rt0, rt1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rt0)::"memory");
     const unsigned long long t_first = t_last;
 #endif
-    const int ntiles = (A.N + 15) / 16;
-    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int first = blockIdx.x * per;
-    const int last = first + per < ntiles ? first + per : ntiles;
-    const int lane_off = h * HD + c4;
-    float4 pre[8];
-    auto request_rows = [&](int tile) __attribute__((always_inline)) {
-        const float *tb = A.in + (size_t)tile * 16 * HD;
-#pragma unroll
-        for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
-    };
-    // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of the input, first tile, weights
+    // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of the input first
     double bsu[STAT_REP], bsq[STAT_REP];
     float bga = 0.f, bbe = 0.f;
     if (tid < HD) {
@@ -542,133 +537,208 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.pro_stats[r * 256 + tid]; bsq[r] = A.pro_stats[r * 256 + HD + tid]; }
         bga = A.pro_gamma[tid]; bbe = A.pro_beta[tid];
     }
-    if (first + wave < last) request_rows(first + wave);
-    bf16x8 wf[2][3][4];                                           // [column block][plane][k-step]: W[32cg + 16c + m][32ks + 8q .. +7]
-    {
-        const float4 *wi = reinterpret_cast<const float4 *>(A.Wx6) + (size_t)cg * (2 * 3 * 4 * 64) + lane;
+    auto stage_scale_shift = [&]() __attribute__((always_inline)) {   // stage_bn() from the registers requested above
+        if (tid < HD) {
+            double su = 0, sq = 0;
 #pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int p = 0; p < 3; p++)
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    const float4 v = wi[((c * 3 + p) * 4 + ks) * 64];
-                    wf[c][p][ks] = __builtin_bit_cast(bf16x8, v);
-                }
-    }
-    if (tid < HD) {                                               // stage_bn() from the registers requested above
-        double su = 0, sq = 0;
-#pragma unroll
-        for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
-        const double mean = su * A.pro_inv_rows;
-        double var = sq * A.pro_inv_rows - mean * mean;           // biased variance (training-mode BN)
-        if (var < 0) var = 0;
-        const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
-        const float sc = rstd * bga;
-        s_bn[tid] = sc;
-        s_bn[HD + tid] = bbe - (float)mean * sc;
-    }
-    if (tid < 2 * HD) s_stat[tid] = 0.0;
-    LDS_BARRIER();                                                // (not __syncthreads: the weight fragments stay in flight behind the first transform)
-    const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
-    const float sh0 = s_bn[HD + c4], sh1 = s_bn[HD + c4 + 1], sh2 = s_bn[HD + c4 + 2], sh3 = s_bn[HD + c4 + 3];
-    f32x4 biasv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    if (A.bias) {
-#pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const float4 b = *reinterpret_cast<const float4 *>(A.bias + 32 * cg + 16 * c + 4 * q);
-            biasv[c] = f32x4{b.x, b.y, b.z, b.w};
+            for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
+            const double mean = su * A.pro_inv_rows;
+            double var = sq * A.pro_inv_rows - mean * mean;       // biased variance (training-mode BN)
+            if (var < 0) var = 0;
+            const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
+            const float sc = rstd * bga;
+            s_bn[tid] = sc;
+            s_bn[HD + tid] = bbe - (float)mean * sc;
         }
-    }
-    STAMP(0);
-    const unsigned char *xa = s_tiles + m * X6_ROWB + 16 * q;     // operand fragment (tile t, plane p, k-step ks): xa + t*X6_TILE + p*X6_PLANE + 64*ks
-    float ts[2][4], tq[2][4];                                     // per-lane column sums (row m of the tiles this wave multiplied)
+        if (tid < 2 * HD) s_stat[tid] = 0.0;
+    };
+    if (wave >= 4) {
+        // ================================ producer ================================
+        const int pw = wave - 4;
+        const int j = lane & 31, h = lane >> 5, c4 = j * 4;       // rows 2p+h of the tile, 4 columns
+        const int m = lane & 15;
+        const int lane_off = h * HD + c4;
+        float4 preA[8], preB[8];
+        constexpr int NA = (PRO == PRO_AGG) ? 8 : 1;
+        float4 nb0[NA], nb1[NA];
+        int e_ox = 0, e_oy = 0, en_ox = 0, en_oy = 0;
+        float e_vx = 0.f, e_vy = 0.f, en_vx = 0.f, en_vy = 0.f, e_dg = 1.f, en_dg = 1.f;
+        auto request_rows = [&](float4 (&pre)[8], int tile) __attribute__((always_inline)) {
+            const float *tb = A.in + (size_t)tile * 16 * HD;
 #pragma unroll
-    for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int i = 0; i < 4; i++) { ts[c][i] = 0.f; tq[c][i] = 0.f; }
-    for (int tb = first; tb < last; tb += 8) {
-        const int nt = last - tb < 8 ? last - tb : 8;
-        // ---- (T) this wave's tile: BatchNorm + ReLU, split, three bf16 planes to LDS
-        if (wave < nt) {
-            unsigned char *dst = s_tiles + wave * X6_TILE + h * X6_ROWB + j * 8;
+            for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
+        };
+        auto fetch_ell = [&](int tile) __attribute__((always_inline)) {
+            const int g = tile * 16 + m;
+            int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
+            if (g < A.N) { cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
+            const int base = (g / A.T) * A.T - tile * 16;         // instance's first row relative to the tile
+            en_ox = cc.x >= 0 ? base + cc.x : m; en_vx = cc.x >= 0 ? vv.x : 0.f;
+            en_oy = cc.y >= 0 ? base + cc.y : m; en_vy = cc.y >= 0 ? vv.y : 0.f;
+            en_dg = (float)(1 + (cc.x >= 0) + (cc.y >= 0));
+        };
+        auto request_nb = [&](int tile) __attribute__((always_inline)) {   // neighbour rows of `tile`, whose ELL entries are in en_*
+            e_ox = en_ox; e_oy = en_oy; e_vx = en_vx; e_vy = en_vy; e_dg = en_dg;
+            const float *tb = A.in + (size_t)tile * 16 * HD;
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                const float v[4] = {bn_relu_ss(pre[p].x, sc0, sh0), bn_relu_ss(pre[p].y, sc1, sh1), bn_relu_ss(pre[p].z, sc2, sh2), bn_relu_ss(pre[p].w, sc3, sh3)};
-                uint2 p0, p1, p2;
-                split3x4(v, p0, p1, p2);
-                *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB) = p0;
-                *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + X6_PLANE) = p1;
-                *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + 2 * X6_PLANE) = p2;
-            }
-        }
-        if (tb + 8 + wave < last) request_rows(tb + 8 + wave);    // in flight during (M), used in the next (T)
-        STAMP(1);
-        LDS_BARRIER();
-        STAMP(4);
-        // ---- (M) tiles 2i + th x two column blocks
-        auto tiles4 = [&](auto FULLc) __attribute__((always_inline)) {
-            constexpr bool FULL = decltype(FULLc)::value;        // FULL: all eight tiles exist and none holds rows >= N
-            bf16x8 xf[2][3];
-#pragma unroll
-            for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + th * X6_TILE + p * X6_PLANE);
-#pragma unroll
-            for (int tt = 0; tt < 4; tt++) {
-                const int t = 2 * tt + th;
-                if (!FULL && t >= nt) break;
-                f32x4 acc[2] = {biasv[0], biasv[1]};
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    const int u = tt * 4 + ks;
-                    if (u + 1 < 16) {                             // fragments of the next (tile, k-step); a stale tile beyond nt is read but never used
-                        const int tn = 2 * ((u + 1) >> 2) + th, kn = (u + 1) & 3;
-#pragma unroll
-                        for (int p = 0; p < 3; p++) xf[(u + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(xa + tn * X6_TILE + p * X6_PLANE + 64 * kn);
-                    }
-                    const bf16x8 *x = xf[u & 1];
-#pragma unroll
-                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[2], acc[c], 0, 0, 0);
-#pragma unroll
-                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][2][ks], x[0], acc[c], 0, 0, 0);
-#pragma unroll
-                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][1][ks], x[1], acc[c], 0, 0, 0);
-#pragma unroll
-                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[1], acc[c], 0, 0, 0);
-#pragma unroll
-                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][1][ks], x[0], acc[c], 0, 0, 0);
-#pragma unroll
-                    for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[0], acc[c], 0, 0, 0);
-                }
-                const int row = (tb + t) * 16 + m;
-                const bool ok = FULL || row < A.N;
-                float *ob = A.out + (size_t)row * HD + 32 * cg + 4 * q;
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    const f32x4 v = acc[c];
-                    *reinterpret_cast<float4 *>(ob + 16 * c) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { const float x = ok ? v[i] : 0.f; ts[c][i] += x; tq[c][i] = __builtin_fmaf(x, x, tq[c][i]); }
-                }
+                const int ox = __shfl(e_ox, 2 * p + h), oy = __shfl(e_oy, 2 * p + h);
+                nb0[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)ox * HD + c4);
+                nb1[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)oy * HD + c4);
             }
         };
-        if (nt == 8 && (tb + 8) * 16 <= A.N) tiles4(std::true_type{});
-        else tiles4(std::false_type{});
-        STAMP(5);
-        // column sums: 16 rows (lanes m) -> one value per column, f64 from there on; every 4th batch (f32 partial sums of
-        // <= 16 values per lane) and after the last one
-        if (((tb - first) & 31) == 24 || tb + 8 >= last) {
+        const int t0 = first + pw;
+        if (t0 < last) request_rows(preA, t0);
+        if (PRO == PRO_AGG && t0 < last) { fetch_ell(t0); request_nb(t0); }
+        if (t0 + 4 < last) request_rows(preB, t0 + 4);
+        if (PRO == PRO_AGG && t0 + 4 < last) fetch_ell(t0 + 4);
+        stage_scale_shift();
+        LDS_BARRIER();
+        STAMP(0);
+        const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
+        const float sh0 = s_bn[HD + c4], sh1 = s_bn[HD + c4 + 1], sh2 = s_bn[HD + c4 + 2], sh3 = s_bn[HD + c4 + 3];
+        auto produce = [&](float4 (&pre)[8], int s) __attribute__((always_inline)) {
+            const int tile = t0 + 4 * s;
+            if (tile < last) {
+                unsigned char *dst = s_tiles + ((s & 1) * 4 + pw) * X6_TILE + h * X6_ROWB + j * 8;
+#pragma unroll
+                for (int p = 0; p < 8; p++) {
+                    float v[4] = {bn_relu_ss(pre[p].x, sc0, sh0), bn_relu_ss(pre[p].y, sc1, sh1), bn_relu_ss(pre[p].z, sc2, sh2), bn_relu_ss(pre[p].w, sc3, sh3)};
+                    if (PRO == PRO_AGG) {
+                        // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
+                        const int pp = p < NA ? p : 0;
+                        const int r = 2 * p + h;
+                        const double wx = (double)__shfl(e_vx, r), wy = (double)__shfl(e_vy, r);
+                        const float dg = __shfl(e_dg, r);
+                        const double inv = dg == 1.f ? 1.0 : dg == 2.f ? 0.5 : (1.0 / 3.0);
+                        const double a0 = (double)v[0] + wx * (double)bn_relu_ss(nb0[pp].x, sc0, sh0) + wy * (double)bn_relu_ss(nb1[pp].x, sc0, sh0);
+                        const double a1 = (double)v[1] + wx * (double)bn_relu_ss(nb0[pp].y, sc1, sh1) + wy * (double)bn_relu_ss(nb1[pp].y, sc1, sh1);
+                        const double a2 = (double)v[2] + wx * (double)bn_relu_ss(nb0[pp].z, sc2, sh2) + wy * (double)bn_relu_ss(nb1[pp].z, sc2, sh2);
+                        const double a3 = (double)v[3] + wx * (double)bn_relu_ss(nb0[pp].w, sc3, sh3) + wy * (double)bn_relu_ss(nb1[pp].w, sc3, sh3);
+                        v[0] = (float)(a0 * inv); v[1] = (float)(a1 * inv); v[2] = (float)(a2 * inv); v[3] = (float)(a3 * inv);
+                    }
+                    uint2 p0, p1, p2;
+                    split3x4(v, p0, p1, p2);
+                    *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB) = p0;
+                    *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + X6_PLANE) = p1;
+                    *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + 2 * X6_PLANE) = p2;
+                }
+            }
+            // requests, oldest-needed first (vmcnt retires in order): neighbour rows of step s+1, ELL entries of step s+2, then
+            // the rows of step s+2 into the registers this tile just left
+            if (PRO == PRO_AGG && tile + 4 < last) request_nb(tile + 4);
+            if (PRO == PRO_AGG && tile + 8 < last) fetch_ell(tile + 8);
+            if (tile + 8 < last) request_rows(pre, tile + 8);
+            STAMP(1);
+            LDS_BARRIER();
+            STAMP(4);
+        };
+        for (int s = 0; s < nsteps; s += 2) {
+            produce(preA, s);
+            if (s + 1 < nsteps) produce(preB, s + 1);
+        }
+        LDS_BARRIER();                                            // the consumers' last step
+    } else {
+        // ================================ consumer ================================
+        const int m = lane & 15, q = lane >> 4;                   // operands swapped: A[col c0+m][k = 8q..], B[k = 8q..][row m], C[col c0+4q+i][row m]
+        const int cg = wave;
+        bf16x8 wf[2][3][4];                                       // [column block][plane][k-step]: W[32cg + 16c + m][32ks + 8q .. +7]
+        {
+            const float4 *wi = reinterpret_cast<const float4 *>(A.Wx6) + (size_t)cg * (2 * 3 * 4 * 64) + lane;
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const float a = row_sum16(ts[c][i]), b = row_sum16(tq[c][i]);
-                    if (m == 0) { atomicAdd(&s_stat[32 * cg + 16 * c + 4 * q + i], (double)a); atomicAdd(&s_stat[HD + 32 * cg + 16 * c + 4 * q + i], (double)b); }
-                    ts[c][i] = 0.f; tq[c][i] = 0.f;
-                }
+                for (int p = 0; p < 3; p++)
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        const float4 v = wi[((c * 3 + p) * 4 + ks) * 64];
+                        wf[c][p][ks] = __builtin_bit_cast(bf16x8, v);
+                    }
         }
-        STAMP(6);
-        LDS_BARRIER();                                            // every operand read of this batch is done: the planes may be overwritten
-        STAMP(7);
+        f32x4 biasv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        if (A.bias) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float4 b = *reinterpret_cast<const float4 *>(A.bias + 32 * cg + 16 * c + 4 * q);
+                biasv[c] = f32x4{b.x, b.y, b.z, b.w};
+            }
+        }
+        stage_scale_shift();
+        LDS_BARRIER();
+        STAMP(0);
+        float ts[2][4], tq[2][4];                                 // per-lane column sums (row m of the tiles multiplied so far)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { ts[c][i] = 0.f; tq[c][i] = 0.f; }
+        const unsigned char *xa0 = s_tiles + m * X6_ROWB + 16 * q; // operand fragment (slot t, plane p, k-step ks): + t*X6_TILE + p*X6_PLANE + 64*ks
+        LDS_BARRIER();                                            // step 0: the producers fill buffer 0
+        STAMP(4);
+        for (int s = 1; s <= nsteps; s++) {
+            const int tb = first + 4 * (s - 1);
+            const unsigned char *xa = xa0 + ((s - 1) & 1) * 4 * X6_TILE;
+            auto tiles4 = [&](auto FULLc) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(FULLc)::value;    // FULL: all four tiles exist and none holds rows >= N
+                bf16x8 xf[2][3];
+#pragma unroll
+                for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + p * X6_PLANE);
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    if (!FULL && tb + t >= last) break;
+                    f32x4 acc[2] = {biasv[0], biasv[1]};
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++) {
+                        const int u = t * 4 + ks;
+                        if (u + 1 < 16) {                         // fragments of the next (tile, k-step); a stale slot is read but never used
+                            const int tn = (u + 1) >> 2, kn = (u + 1) & 3;
+#pragma unroll
+                            for (int p = 0; p < 3; p++) xf[(u + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(xa + tn * X6_TILE + p * X6_PLANE + 64 * kn);
+                        }
+                        const bf16x8 *x = xf[u & 1];
+#pragma unroll
+                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[2], acc[c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][2][ks], x[0], acc[c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][1][ks], x[1], acc[c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[1], acc[c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][1][ks], x[0], acc[c], 0, 0, 0);
+#pragma unroll
+                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[0], acc[c], 0, 0, 0);
+                    }
+                    const int row = (tb + t) * 16 + m;
+                    const bool ok = FULL || row < A.N;
+                    float *ob = A.out + (size_t)row * HD + 32 * cg + 4 * q;
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const f32x4 v = acc[c];
+                        *reinterpret_cast<float4 *>(ob + 16 * c) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) { const float x = ok ? v[i] : 0.f; ts[c][i] += x; tq[c][i] = __builtin_fmaf(x, x, tq[c][i]); }
+                    }
+                }
+            };
+            if (tb + 4 <= last && (tb + 4) * 16 <= A.N) tiles4(std::true_type{});
+            else tiles4(std::false_type{});
+            STAMP(5);
+            // column sums: 16 rows (lanes m) -> one value per column, f64 from there on; every 4th step (f32 partial sums of
+            // <= 16 values per lane) and after the last one
+            if ((s & 3) == 0 || s == nsteps) {
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float a = row_sum16(ts[c][i]), b = row_sum16(tq[c][i]);
+                        if (m == 0) { atomicAdd(&s_stat[32 * cg + 16 * c + 4 * q + i], (double)a); atomicAdd(&s_stat[HD + 32 * cg + 16 * c + 4 * q + i], (double)b); }
+                        ts[c][i] = 0.f; tq[c][i] = 0.f;
+                    }
+            }
+            STAMP(6);
+            LDS_BARRIER();                                        // buffer (s-1)&1 may be overwritten; buffer s&1 is complete
+            STAMP(7);
+        }
     }
     if (tid < 2 * HD) atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], s_stat[tid]);
 #ifdef MTFJSP_STAMP
@@ -1790,6 +1860,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gemm16p<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_gat3, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gin_inst<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gin_inst<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
@@ -1931,7 +2002,7 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
     if constexpr (PRO == PRO_PLAIN) hipLaunchKernelGGL((k_gemm16<EPI, ACC>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
     else {
         static const int f32mfma = getenv("MTFJSP_GEMM_F32MFMA") ? 1 : 0;      // A/B switch: the f32-instruction kernel
-        if (PRO == PRO_BNRELU && b.Wx6 && !f32mfma) hipLaunchKernelGGL((k_gemm_x6<PRO_BNRELU>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
+        if (b.Wx6 && !f32mfma) hipLaunchKernelGGL((k_gemm_x6<PRO>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
         else hipLaunchKernelGGL((k_gemm16p<PRO>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
     }
 #ifdef MTFJSP_STAMP
@@ -2000,6 +2071,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         a.pro_stats = st + 2 * STAT_REP * 256; a.pro_gamma = W(P + "batch_norms.0.weight"); a.pro_beta = W(P + "batch_norms.0.bias"); a.pro_inv_rows = invN;
         a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
         a.epi_stats = st + 3 * STAT_REP * 256;
+        a.Wx6 = e->wx6.at(P + "mlps.1.linears.0.weight");
         launch_gemm<PRO_AGG, EPI_STATS>(e, a, "gin_gemm_agg");
     }
     bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4);
