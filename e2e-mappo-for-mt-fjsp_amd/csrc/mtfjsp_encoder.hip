@@ -555,6 +555,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     if (wave >= 4) {
         // ================================ producer ================================
         const int pw = wave - 4;
+        if (A.dbg & 16) __builtin_amdgcn_s_setprio(2);
         const int j = lane & 31, h = lane >> 5, c4 = j * 4;       // rows 2p+h of the tile, 4 columns
         const int m = lane & 15;
         const int lane_off = h * HD + c4;
@@ -679,9 +680,11 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             const unsigned char *xa = xa0 + ((s - 1) & 1) * 4 * X6_TILE;
             auto tiles4 = [&](auto FULLc) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(FULLc)::value;    // FULL: all four tiles exist and none holds rows >= N
-                bf16x8 xf[2][3];
+                bf16x8 xf[3][3];                                  // fragments of (tile, k-step) units u, u+1, u+2: two units (24 products) of LDS latency cover
 #pragma unroll
                 for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + p * X6_PLANE);
+#pragma unroll
+                for (int p = 0; p < 3; p++) xf[1][p] = *reinterpret_cast<const bf16x8 *>(xa + p * X6_PLANE + 64);
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     if (!FULL && tb + t >= last) break;
@@ -689,12 +692,12 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 #pragma unroll
                     for (int ks = 0; ks < 4; ks++) {
                         const int u = t * 4 + ks;
-                        if (u + 1 < 16) {                         // fragments of the next (tile, k-step); a stale slot is read but never used
-                            const int tn = (u + 1) >> 2, kn = (u + 1) & 3;
+                        if (u + 2 < 16) {                         // a stale slot beyond the last tile is read but never used
+                            const int tn = (u + 2) >> 2, kn = (u + 2) & 3;
 #pragma unroll
-                            for (int p = 0; p < 3; p++) xf[(u + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(xa + tn * X6_TILE + p * X6_PLANE + 64 * kn);
+                            for (int p = 0; p < 3; p++) xf[(u + 2) % 3][p] = *reinterpret_cast<const bf16x8 *>(xa + tn * X6_TILE + p * X6_PLANE + 64 * kn);
                         }
-                        const bf16x8 *x = xf[u & 1];
+                        const bf16x8 *x = xf[u % 3];
 #pragma unroll
                         for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[2], acc[c], 0, 0, 0);
 #pragma unroll
@@ -1992,8 +1995,9 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
     int grid = (ntiles + 7) / 8;
     if (grid > e->num_cu) grid = e->num_cu;
     GemmArgs b = a;
+    static const int dbg_env = getenv("MTFJSP_GEMM_DBG") ? atoi(getenv("MTFJSP_GEMM_DBG")) : 0;
+    b.dbg = dbg_env;
 #ifdef MTFJSP_STAMP
-    b.dbg = getenv("MTFJSP_GEMM_DBG") ? atoi(getenv("MTFJSP_GEMM_DBG")) : 0;
     static unsigned long long *d_st = nullptr;
     if (!d_st) (void)hipMalloc((void **)&d_st, 2048 * 8 * 8);
     (void)hipMemsetAsync(d_st, 0, 2048 * 8 * 8, e->stream);
