@@ -773,6 +773,7 @@ struct GatArgs {
     const float *W1, *W2;   // (m_fea_1_fcl.weight^T . gat W)^T [128,6], (m_fea_2_fcl.weight^T . gat W)^T [128,8]: input projection and
                             // the first pass' h W fused on the host (one 14 x 128 x 128 product per weight load)
     const float *Wt;        // gat_layer.W [in,out]
+    const void *Wx6;        // the same as bf16 x 3-plane operand fragments [c 8][plane 3][ks 4][lane 64][8] (k_gat3x)
     const float *gat_a;     // [256] a_src | a_dst (gat:68-79)
     float *node;            // [R,128] (padded) pre-BatchNorm node mean
     double *epi_stats;
@@ -933,6 +934,208 @@ __global__ __launch_bounds__(512) void k_gat3(GatArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_gat3x — k_gat3 with passes 2 and 3 on the bf16 matrix cores at f32 accuracy (exact 3-way split, 6 piece products, see
+// k_gemm_x6).  Four waves per workgroup (one per SIMD), each keeping its own 16-row tile through all three passes:
+//   * the GAT weight lives in LDS as bf16 fragments in operand order [column block 8][plane 3][k-step 4][lane 64][16 B]
+//     (96 KiB, conflict-free 16-byte reads), streamed two column blocks at a time with the next pair in flight;
+//   * the tile's activations are the A operand, held in registers: after each pass's epilogue wrote the new rows to the
+//     wave's f32 LDS tile (the C layout -> operand layout transpose, pitch 132 words), they are read back as 8 x 16 bytes
+//     per lane and split into 3 planes x 4 k-steps of fragments (48 registers);
+//   * the accumulators stay in the ordinary C layout (rows 4q+i in the lane, columns across the 16 lanes of a DPP row), so
+//     the attention epilogue is k_gat3's.
+// 2 passes x 8 column blocks x 24 products x 16 cycles = 6.1 k cycles per tile instead of 16.4 k with the f32 instruction.
+#define GX_LDA 132
+__global__ __launch_bounds__(256) void k_gat3x(GatArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *s_wf = smem;                                   // 8*3*4*64*16 B
+    float *s_a = reinterpret_cast<float *>(smem + 8 * 3 * 4 * 64 * 16);   // 4 waves * 16 * GX_LDA
+    float *s_feat = s_a + 4 * 16 * GX_LDA;                        // 4 waves * 16 rows * 8
+    double *s_red = reinterpret_cast<double *>(s_feat + 4 * 128); // 4 waves * 256
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5, c4 = j * 4;
+    const int m = lane & 15, q = lane >> 4;
+    {   // stage the weight fragments: 98304 B = 24 x 16 B per thread, coalesced
+        const float4 *src = reinterpret_cast<const float4 *>(A.Wx6);
+        float4 *dst = reinterpret_cast<float4 *>(s_wf);
+        float4 v[24];
+#pragma unroll
+        for (int i = 0; i < 24; i++) v[i] = src[i * 256 + tid];
+#pragma unroll
+        for (int i = 0; i < 24; i++) dst[i * 256 + tid] = v[i];
+    }
+    float *my_a = s_a + wave * 16 * GX_LDA;
+    float *my_f = s_feat + wave * 128;
+    const int N = 2 * A.R;
+    const int ntiles = (N + 15) / 16;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int first = blockIdx.x * per;
+    const int last = first + per < ntiles ? first + per : ntiles;
+    double st_sum[8], st_sq[8];
+    for (int c = 0; c < 8; c++) { st_sum[c] = 0; st_sq[c] = 0; }
+    float wp[4][8];                                               // this lane's 4 output columns of W1 (h = 0) or W2 (h = 1)
+    for (int x = 0; x < 4; x++)
+        for (int k = 0; k < 8; k++) wp[x][k] = h == 0 ? (k < 6 ? A.W1[(c4 + x) * 6 + k] : 0.f) : A.W2[(c4 + x) * 8 + k];
+    float asrc[8], adst[8];
+    for (int c = 0; c < 8; c++) { asrc[c] = A.gat_a[c * 16 + m]; adst[c] = A.gat_a[HD + c * 16 + m]; }
+    auto fetch_feat = [&](int tile) __attribute__((always_inline)) -> float4 {   // lane L < 32: 4 of the 128 feature words of a tile
+        const int r = tile * 16 + (lane >> 1), k0 = (lane & 1) * 4;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane < 32 && r < N) {
+            const int u = r >> 1, node = r & 1, width = node ? 8 : 6;
+            for (int k = 0; k < 4; k++)
+                if (k0 + k < width) {
+                    const size_t idx = (size_t)u * width + k0 + k;
+                    x[k] = A.feat_f64 ? (float)reinterpret_cast<const double *>(node ? A.f2 : A.f1)[idx]
+                                      : reinterpret_cast<const float *>(node ? A.f2 : A.f1)[idx];
+                }
+        }
+        return make_float4(x[0], x[1], x[2], x[3]);
+    };
+    int t_cur = first + wave, t_n1 = t_cur + 4;
+    float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t_cur < last) fpre = fetch_feat(t_cur);
+    __syncthreads();                                              // weight fragments are staged
+    const unsigned char *wl = s_wf + lane * 16;                   // fragment (c, p, ks): wl + ((c*3 + p)*4 + ks) * 1024
+    while (t_cur < last) {
+        const int row0 = t_cur * 16;
+        // ---- input rows: tile rows 2p+h are node h of machine (row0/2 + p); W1/W2 arrive pre-multiplied with the GAT
+        // weight, so these rows ARE z of the first pass
+        if (lane < 32) *reinterpret_cast<float4 *>(my_f + lane * 4) = fpre;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int r = 2 * p + h;
+            const float4 fa = *reinterpret_cast<const float4 *>(my_f + r * 8), fb = *reinterpret_cast<const float4 *>(my_f + r * 8 + 4);
+            const float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+            float o[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) a = fmaf(ff[k], wp[x][k], a);
+                o[x] = a;
+            }
+            *reinterpret_cast<float4 *>(my_a + r * GX_LDA + c4) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t_n1 < last) fpre = fetch_feat(t_n1);
+#pragma unroll 1
+        for (int pass = 0; pass < 3; pass++) {
+            f32x4 acc[8];
+            if (pass == 0) {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[c][i] = my_a[(4 * q + i) * GX_LDA + c * 16 + m];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                // the tile in operand layout: row m, k = 32ks + 8q .. +7, split into three bf16 planes
+                bf16x8 xf[3][4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const float4 lo = *reinterpret_cast<const float4 *>(my_a + m * GX_LDA + 32 * ks + 8 * q);
+                    const float4 hi = *reinterpret_cast<const float4 *>(my_a + m * GX_LDA + 32 * ks + 8 * q + 4);
+                    const float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
+                    uint2 a0, a1, a2, b0, b1, b2;
+                    split3x4(v0, a0, a1, a2); split3x4(v1, b0, b1, b2);
+                    xf[0][ks] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+                    xf[1][ks] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+                    xf[2][ks] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+                }
+                // column blocks in pairs (two accumulator chains); units u = (pair, k-step): 6 weight fragments each, the next
+                // unit's in flight
+                bf16x8 wr[2][2][3];
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) wr[0][cc][p] = *reinterpret_cast<const bf16x8 *>(wl + ((cc * 3 + p) * 4) * 1024);
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int cp = u >> 2, ks = u & 3;
+                    if (u + 1 < 16) {
+                        const int cn = (u + 1) >> 2, kn = (u + 1) & 3;
+#pragma unroll
+                        for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                            for (int p = 0; p < 3; p++) wr[(u + 1) & 1][cc][p] = *reinterpret_cast<const bf16x8 *>(wl + (((2 * cn + cc) * 3 + p) * 4 + kn) * 1024);
+                    }
+                    const bf16x8 (*w)[3] = wr[u & 1];
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[0][ks], w[cc][2], acc[2 * cp + cc], 0, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[2][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[1][ks], w[cc][1], acc[2 * cp + cc], 0, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[0][ks], w[cc][1], acc[2 * cp + cc], 0, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[1][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[0][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {                                     // the lane's two machines: tile rows 4q+2u (node 0), +1 (node 1)
+                const int i = 2 * u;
+                float s0 = 0.f, d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; c++) { const float z0 = acc[c][i], z1 = acc[c][i + 1]; s0 += asrc[c] * z0; d0 += adst[c] * z0; d1 += adst[c] * z1; }
+                s0 = row_sum16(s0); d0 = row_sum16(d0); d1 = row_sum16(d1);
+                float e00 = s0 + d0, e01 = s0 + d1;
+                e00 = e00 > 0.f ? e00 : 0.2f * e00;
+                e01 = e01 > 0.f ? e01 : 0.2f * e01;
+                const float mx = fmaxf(e00, e01);
+                const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
+                const float inv = 1.0f / (x0 + x1);
+                const float al0 = x0 * inv, al1 = x1 * inv;
+                const int r = 4 * q + i;
+                if (pass < 2) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
+                        float n0 = al0 * z0 + al1 * z1, n1 = z1;
+                        n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;               // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
+                        n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
+                        my_a[r * GX_LDA + c * 16 + m] = n0;
+                        my_a[(r + 1) * GX_LDA + c * 16 + m] = n1;
+                    }
+                } else {
+                    const bool valid = row0 + r < N;
+                    float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + m;
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
+                        float mv = (al0 * z0 + al1 * z1 + z1) * 0.5f;        // mean over the 2 nodes (ac:420)
+                        nd[c * 16] = mv;
+                        if (!valid) mv = 0.f;
+                        st_sum[c] += (double)mv; st_sq[c] += (double)mv * (double)mv;
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tile is complete before the next pass reads it
+        }
+        t_cur = t_n1; t_n1 += 4;
+    }
+    // column sums: fold the 4 row quarters, then the 4 waves through LDS
+    for (int c = 0; c < 8; c++) {
+        double a = st_sum[c], b = st_sq[c];
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+        if (q == 0) { s_red[wave * 256 + c * 16 + m] = a; s_red[wave * 256 + HD + c * 16 + m] = b; }
+    }
+    __syncthreads();
+    {
+        double v = 0;
+        for (int w = 0; w < 4; w++) v += s_red[w * 256 + tid];
+        atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
+    }
+}
+static size_t gat3x_lds_bytes() { return (size_t)8 * 3 * 4 * 64 * 16 + (size_t)(4 * 16 * GX_LDA + 4 * 128) * 4 + 4 * 256 * 8 + 64; }
+
+// ---------------------------------------------------------------------------------------------
 // Fused actor heads (ac:205-293 / ac:444-495): for a group of 16 instances (= R 16-row tiles of scorer rows, since an
 // instance has R candidates / machines) one 8-wave workgroup computes
 //   u   = Wb pooled + Wc other + b0                      (the per-instance thirds of the 384-wide scorer input)
@@ -1065,6 +1268,7 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
         xh0 = s_u[HD + sc4]; xh1 = s_u[HD + sc4 + 1]; xh2 = s_u[HD + sc4 + 2]; xh3 = s_u[HD + sc4 + 3];
         LDS_BARRIER();
     }
+    STAMP(6);
     {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
         // 64-bit weight addresses into registers and spill them)
         const int g0 = blockIdx.x * HG;
@@ -1095,6 +1299,7 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
                     *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
                 }
             } else if (sr < ng) xp = *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4);
+            STAMP(7);
             const float4 xo = sr < ng ? *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + sr) * HD + sc4) : z;
             float *dp = s_p + sr * LDA16 + sc4, *dq = s_o + sr * LDA16 + sc4;
             *reinterpret_cast<float2 *>(dp) = make_float2(xp.x, xp.y); *reinterpret_cast<float2 *>(dp + 2) = make_float2(xp.z, xp.w);
@@ -1862,6 +2067,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gemm16p<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_gemm16p<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
     (void)hipFuncSetAttribute((const void *)k_gat3, hipFuncAttributeMaxDynamicSharedMemorySize, lds16);
+    (void)hipFuncSetAttribute((const void *)k_gat3x, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gat3x_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gin_inst<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
@@ -1936,6 +2142,28 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
             if (kt != e->wimg.end()) di = kt->second;
             else { if (dalloc(e, &di, (size_t)numel)) return MTFJSP_ERR_HIP; e->wimg[key] = di; }
             HIPCHK(e, hipMemcpy(di, im.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
+        }
+        if (is_gat_w) {
+            // k_gat3x: B-operand fragments of W [in k][out n]: img[c 8][plane 3][ks 4][lane 64][i 8] = plane(W[32ks + 8(lane >> 4) + i][16c + (lane & 15)])
+            auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+            auto from_bf16 = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
+            std::vector<uint16_t> im((size_t)3 * HD * HD);
+            for (int c = 0; c < 8; c++)
+                for (int ks = 0; ks < 4; ks++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int i = 0; i < 8; i++) {
+                            const int k = 32 * ks + 8 * (lane >> 4) + i, n = 16 * c + (lane & 15);
+                            const float w = data[(size_t)k * HD + n];
+                            const uint16_t p0 = to_bf16(w); const float r1 = w - from_bf16(p0);
+                            const uint16_t p1 = to_bf16(r1); const float r2 = r1 - from_bf16(p1);
+                            const uint16_t pl[3] = {p0, p1, to_bf16(r2)};
+                            for (int p = 0; p < 3; p++) im[(((((size_t)c * 3 + p) * 4 + ks) * 64 + lane) * 8) + i] = pl[p];
+                        }
+            void *dx = nullptr;
+            auto kt = e->wx6.find(key);
+            if (kt != e->wx6.end()) dx = kt->second;
+            else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx6[key] = dx; }
+            HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
         }
         if (!is_gat_w && blocks == 1) {
             // k_gemm_x6: exact 3-way bf16 split (round-to-nearest-even each), img[cg 4][c 2][plane 3][ks 4][lane 64][i 8] =
@@ -2144,7 +2372,14 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
         (void)hipMemsetAsync(d_st, 0, 2048 * 8 * 8, e->stream);
         a.stamps = d_st;
 #endif
-        hipLaunchKernelGGL(k_gat3, dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, a);
+        static const int gat_f32 = getenv("MTFJSP_GAT_F32MFMA") ? 1 : 0;      // A/B switch: the f32-instruction kernel
+        if (gat_f32) hipLaunchKernelGGL(k_gat3, dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, a);
+        else {
+            a.Wx6 = e->wx6.at(pre + "gat_layer.W");
+            int gx = (ntiles + 3) / 4;
+            if (gx > e->num_cu) gx = e->num_cu;
+            hipLaunchKernelGGL(k_gat3x, dim3(gx), dim3(256), gat3x_lds_bytes(), e->stream, a);
+        }
 #ifdef MTFJSP_STAMP
         static int printed = 0;
         if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
@@ -2304,7 +2539,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
             (void)hipMemcpy(hst.data(), d_st, (size_t)nw * 64, hipMemcpyDeviceToHost);
             double m[8] = {0};
             for (int w = 0; w < nw; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[(size_t)w * 8 + i] / nw;
-            printf("STAMP k_heads: requests+stage %.0f  phaseA %.0f  X-stage %.0f  phaseB %.0f  phaseC+score %.0f  softmax %.0f (cycles/wave)\n", m[0], m[1], m[2], m[3], m[4], m[5]);
+            printf("STAMP k_heads: bn-stage %.0f  weights+pool %.0f  rest-of-stage %.0f  phaseA %.0f  X-stage %.0f  phaseB %.0f  phaseC+score %.0f  softmax %.0f (cycles/wave)\n", m[6], m[7], m[0], m[1], m[2], m[3], m[4], m[5]);
         }
 #endif
     }

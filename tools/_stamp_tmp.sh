@@ -1,2 +1,2 @@
-export MTFJSP_LIB=$PWD/e2e-mappo-for-mt-fjsp_amd/libmtfjsp_stamp.so
-MTFJSP_STAMP_PRINT=1 python tools/bench_encoder.py --steps 36 --tag stamp 2>&1 | grep -E "STAMP k_heads|STAMP k_gat3|stamp" | head -12
+timeout 600 python -m pytest tests/test_encoder_hip.py tests/test_encoder_sizes_gpu.py tests/test_eval_per_instance_bn.py -m gpu -x -q 2>&1 | tail -4
+for i in 1 2; do python tools/bench_encoder.py --steps 360 --tag gat3x; MTFJSP_GAT_F32MFMA=1 python tools/bench_encoder.py --steps 360 --tag gat3-f32; done
