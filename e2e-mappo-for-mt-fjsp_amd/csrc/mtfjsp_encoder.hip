@@ -935,44 +935,45 @@ __global__ __launch_bounds__(512) void k_gat3(GatArgs A)
 
 // ---------------------------------------------------------------------------------------------
 // k_gat3x — k_gat3 with passes 2 and 3 on the bf16 matrix cores at f32 accuracy (exact 3-way split, 6 piece products, see
-// k_gemm_x6).  Four waves per workgroup (one per SIMD), each keeping its own 16-row tile through all three passes:
+// k_gemm_x6).  Eight waves per workgroup, each keeping its own 16-row tile through all three passes:
 //   * the GAT weight lives in LDS as bf16 fragments in operand order [column block 8][plane 3][k-step 4][lane 64][16 B]
 //     (96 KiB, conflict-free 16-byte reads), streamed two column blocks at a time with the next pair in flight;
 //   * the tile's activations are the A operand, held in registers: after each pass's epilogue wrote the new rows to the
-//     wave's f32 LDS tile (the C layout -> operand layout transpose, pitch 132 words), they are read back as 8 x 16 bytes
+//     wave's f32 LDS tile (the C layout -> operand layout transpose, XOR-swizzled), they are read back as 8 x 16 bytes
 //     per lane and split into 3 planes x 4 k-steps of fragments (48 registers);
 //   * the accumulators stay in the ordinary C layout (rows 4q+i in the lane, columns across the 16 lanes of a DPP row), so
 //     the attention epilogue is k_gat3's.
 // 2 passes x 8 column blocks x 24 products x 16 cycles = 6.1 k cycles per tile instead of 16.4 k with the f32 instruction.
-#define GX_LDA 132
-__global__ __launch_bounds__(256) void k_gat3x(GatArgs A)
+// f32 transpose tile without padding (weights 96 KiB + 8 tiles x 8 KiB = the whole 160 KiB of LDS): 16-byte chunk index
+// XOR (row & 7) makes the row-wise 16-byte operand reads, the C-layout word accesses and the row writes conflict-free
+__device__ __forceinline__ int gx_off(int row, int col) { return row * HD + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); }
+__global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned char *s_wf = smem;                                   // 8*3*4*64*16 B
-    float *s_a = reinterpret_cast<float *>(smem + 8 * 3 * 4 * 64 * 16);   // 4 waves * 16 * GX_LDA
-    float *s_feat = s_a + 4 * 16 * GX_LDA;                        // 4 waves * 16 rows * 8
-    double *s_red = reinterpret_cast<double *>(s_feat + 4 * 128); // 4 waves * 256
+    float *s_a = reinterpret_cast<float *>(smem + 8 * 3 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
+    double *s_red = reinterpret_cast<double *>(s_a);              // (after the last tile)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 31, h = lane >> 5, c4 = j * 4;
     const int m = lane & 15, q = lane >> 4;
-    {   // stage the weight fragments: 98304 B = 24 x 16 B per thread, coalesced
+    {   // stage the weight fragments: 98304 B = 12 x 16 B per thread, coalesced
         const float4 *src = reinterpret_cast<const float4 *>(A.Wx6);
         float4 *dst = reinterpret_cast<float4 *>(s_wf);
-        float4 v[24];
+        float4 v[12];
 #pragma unroll
-        for (int i = 0; i < 24; i++) v[i] = src[i * 256 + tid];
+        for (int i = 0; i < 12; i++) v[i] = src[i * 512 + tid];
 #pragma unroll
-        for (int i = 0; i < 24; i++) dst[i * 256 + tid] = v[i];
+        for (int i = 0; i < 12; i++) dst[i * 512 + tid] = v[i];
     }
-    float *my_a = s_a + wave * 16 * GX_LDA;
-    float *my_f = s_feat + wave * 128;
+    float *my_a = s_a + wave * 16 * HD;
+    float *my_f = my_a + 15 * HD;                                 // the tile's feature words live in its last row until that row is written (p = 7)
     const int N = 2 * A.R;
     const int ntiles = (N + 15) / 16;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
     const int first = blockIdx.x * per;
     const int last = first + per < ntiles ? first + per : ntiles;
-    double st_sum[8], st_sq[8];
-    for (int c = 0; c < 8; c++) { st_sum[c] = 0; st_sq[c] = 0; }
+    float st_sum[8], st_sq[8];                                    // per lane: <= 2 machines x (tiles per wave) values — f32 partial sums, f64 from the fold on
+    for (int c = 0; c < 8; c++) { st_sum[c] = 0.f; st_sq[c] = 0.f; }
     float wp[4][8];                                               // this lane's 4 output columns of W1 (h = 0) or W2 (h = 1)
     for (int x = 0; x < 4; x++)
         for (int k = 0; k < 8; k++) wp[x][k] = h == 0 ? (k < 6 ? A.W1[(c4 + x) * 6 + k] : 0.f) : A.W2[(c4 + x) * 8 + k];
@@ -992,7 +993,7 @@ __global__ __launch_bounds__(256) void k_gat3x(GatArgs A)
         }
         return make_float4(x[0], x[1], x[2], x[3]);
     };
-    int t_cur = first + wave, t_n1 = t_cur + 4;
+    int t_cur = first + wave, t_n1 = t_cur + 8;
     float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t_cur < last) fpre = fetch_feat(t_cur);
     __syncthreads();                                              // weight fragments are staged
@@ -1016,7 +1017,7 @@ __global__ __launch_bounds__(256) void k_gat3x(GatArgs A)
                 for (int k = 0; k < 8; k++) a = fmaf(ff[k], wp[x][k], a);
                 o[x] = a;
             }
-            *reinterpret_cast<float4 *>(my_a + r * GX_LDA + c4) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4 *>(my_a + gx_off(r, c4)) = make_float4(o[0], o[1], o[2], o[3]);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (t_n1 < last) fpre = fetch_feat(t_n1);
@@ -1027,15 +1028,15 @@ __global__ __launch_bounds__(256) void k_gat3x(GatArgs A)
 #pragma unroll
                 for (int c = 0; c < 8; c++)
 #pragma unroll
-                    for (int i = 0; i < 4; i++) acc[c][i] = my_a[(4 * q + i) * GX_LDA + c * 16 + m];
+                    for (int i = 0; i < 4; i++) acc[c][i] = my_a[gx_off(4 * q + i, c * 16 + m)];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else {
                 // the tile in operand layout: row m, k = 32ks + 8q .. +7, split into three bf16 planes
                 bf16x8 xf[3][4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ks++) {
-                    const float4 lo = *reinterpret_cast<const float4 *>(my_a + m * GX_LDA + 32 * ks + 8 * q);
-                    const float4 hi = *reinterpret_cast<const float4 *>(my_a + m * GX_LDA + 32 * ks + 8 * q + 4);
+                    const float4 lo = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q));
+                    const float4 hi = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q + 4));
                     const float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
                     uint2 a0, a1, a2, b0, b1, b2;
                     split3x4(v0, a0, a1, a2); split3x4(v1, b0, b1, b2);
@@ -1099,8 +1100,8 @@ __global__ __launch_bounds__(256) void k_gat3x(GatArgs A)
                         float n0 = al0 * z0 + al1 * z1, n1 = z1;
                         n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;               // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
                         n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
-                        my_a[r * GX_LDA + c * 16 + m] = n0;
-                        my_a[(r + 1) * GX_LDA + c * 16 + m] = n1;
+                        my_a[gx_off(r, c * 16 + m)] = n0;
+                        my_a[gx_off(r + 1, c * 16 + m)] = n1;
                     }
                 } else {
                     const bool valid = row0 + r < N;
@@ -1111,29 +1112,30 @@ __global__ __launch_bounds__(256) void k_gat3x(GatArgs A)
                         float mv = (al0 * z0 + al1 * z1 + z1) * 0.5f;        // mean over the 2 nodes (ac:420)
                         nd[c * 16] = mv;
                         if (!valid) mv = 0.f;
-                        st_sum[c] += (double)mv; st_sq[c] += (double)mv * (double)mv;
+                        st_sum[c] += mv; st_sq[c] = __builtin_fmaf(mv, mv, st_sq[c]);
                     }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tile is complete before the next pass reads it
         }
-        t_cur = t_n1; t_n1 += 4;
+        t_cur = t_n1; t_n1 += 8;
     }
-    // column sums: fold the 4 row quarters, then the 4 waves through LDS
+    // column sums: fold the 4 row quarters, then the 8 waves through LDS
+    __syncthreads();                                              // every tile is done: s_red aliases them
     for (int c = 0; c < 8; c++) {
-        double a = st_sum[c], b = st_sq[c];
+        double a = (double)st_sum[c], b = (double)st_sq[c];
         a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
         b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
         if (q == 0) { s_red[wave * 256 + c * 16 + m] = a; s_red[wave * 256 + HD + c * 16 + m] = b; }
     }
     __syncthreads();
-    {
+    if (tid < 256) {
         double v = 0;
-        for (int w = 0; w < 4; w++) v += s_red[w * 256 + tid];
+        for (int w = 0; w < 8; w++) v += s_red[w * 256 + tid];
         atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
     }
 }
-static size_t gat3x_lds_bytes() { return (size_t)8 * 3 * 4 * 64 * 16 + (size_t)(4 * 16 * GX_LDA + 4 * 128) * 4 + 4 * 256 * 8 + 64; }
+static size_t gat3x_lds_bytes() { return (size_t)8 * 3 * 4 * 64 * 16 + (size_t)8 * 16 * HD * 4; }
 
 // ---------------------------------------------------------------------------------------------
 // Fused actor heads (ac:205-293 / ac:444-495): for a group of 16 instances (= R 16-row tiles of scorer rows, since an
@@ -2376,9 +2378,7 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
         if (gat_f32) hipLaunchKernelGGL(k_gat3, dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, a);
         else {
             a.Wx6 = e->wx6.at(pre + "gat_layer.W");
-            int gx = (ntiles + 3) / 4;
-            if (gx > e->num_cu) gx = e->num_cu;
-            hipLaunchKernelGGL(k_gat3x, dim3(gx), dim3(256), gat3x_lds_bytes(), e->stream, a);
+            hipLaunchKernelGGL(k_gat3x, dim3(grid), dim3(512), gat3x_lds_bytes(), e->stream, a);
         }
 #ifdef MTFJSP_STAMP
         static int printed = 0;
