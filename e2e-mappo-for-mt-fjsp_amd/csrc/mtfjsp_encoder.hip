@@ -1195,6 +1195,7 @@ struct HeadArgs {
     const float *W0i;                    // register images (mtfjsp_encoder::wimg) of the 3 blocks of linears.0: X | pooled | other
     const float *b0, *W1i, *b1, *w2, *b2;
     const float *Wc0i, *bc0, *Wc1i, *bc1, *wc2, *bc2;
+    const void *W0x, *W1x, *Wc0x, *Wc1x; // the same weights as bf16 x 3-plane register images (mtfjsp_encoder::wx6), k_headsx
     const uint8_t *mask;                 // [B,R]
     float scale;
     float *prob, *value;                 // [B,R], [B,2]
@@ -1485,6 +1486,316 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
 #endif
 }
 static size_t heads_lds_bytes() { return (size_t)((2 * HCH + 4) * 16 * LDA16 + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD) * 4 + HG * 64; }
+
+// ---------------------------------------------------------------------------------------------
+// k_headsx — k_heads with every 128x128 product on the bf16 matrix cores at f32 accuracy (exact 3-way split, 6 piece
+// products, see k_gemm_x6).  Same work split (wave w owns output columns 16w..16w+15 of every product; its weight
+// fragments — 3 planes x 4 k-steps = 48 registers per weight — come from the bf16 register images), but
+//   * the operands are swapped (A := weight, B := activation rows), so a lane ends up with 4 consecutive columns of row m:
+//     the next product's operand planes are written with 8-byte stores, u is read as float4, and a scorer row's partial
+//     score is 4 FMAs + two cross-quarter shuffles instead of four 16-lane DPP reductions;
+//   * activations live in LDS as three bf16 planes per 16-row tile (pitch 272 B); each value is split once by its
+//     producer: X rows by the staging threads, c1 / s1 in the epilogue of the product that makes them;
+//   * the s1 planes overwrite the X planes (all six accumulators of a chunk are held across one barrier).
+// 384 matrix instructions x 16 cycles per wave instead of 512 x 32.
+#define WCOLX(dst, Wx, blk)                                                                                     \
+    do {                                                                                                         \
+        const float4 *w_ = reinterpret_cast<const float4 *>(Wx) + ((size_t)(blk) * 8 + wave) * (3 * 4 * 64) + lane; \
+        _Pragma("unroll") for (int p_ = 0; p_ < 3; p_++)                                                         \
+            _Pragma("unroll") for (int k_ = 0; k_ < 4; k_++) dst[p_][k_] = __builtin_bit_cast(bf16x8, w_[(p_ * 4 + k_) * 64]); \
+    } while (0)
+// the six piece products of one k-step on two accumulator chains (large terms | small terms)
+#define X6_STEP(accA, accB, wv, xv, ks)                                                          \
+    do {                                                                                          \
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0][ks], xv[2], accB, 0, 0, 0);          \
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0][ks], xv[1], accA, 0, 0, 0);          \
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[2][ks], xv[0], accB, 0, 0, 0);          \
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1][ks], xv[0], accA, 0, 0, 0);          \
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1][ks], xv[1], accB, 0, 0, 0);          \
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0][ks], xv[0], accA, 0, 0, 0);          \
+    } while (0)
+#define HX_CLDA 132
+__global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *s_xs = smem;                                    // HCH tiles of 3 planes: X rows, then s1
+    unsigned char *s_pp = s_xs + HCH * X6_TILE;                    // pooled planes
+    unsigned char *s_op = s_pp + X6_TILE;                          // other planes
+    unsigned char *s_c1p = s_op + X6_TILE;                         // c1 planes
+    float *s_c2 = reinterpret_cast<float *>(s_c1p + X6_TILE);      // [16][HX_CLDA] f32
+    float *s_u = s_c2 + 16 * HX_CLDA;                              // [16][128]
+    float *s_part = s_u + HG * HD;                                 // 8 waves * (HCH*16) rows
+    float *s_score = s_part + 8 * HCH * 16;                        // HG * 64
+    float *s_wc2 = s_score + HG * 64;                              // 2 * 128
+    float *s_vec = s_wc2 + 2 * HD;                                 // b0 | bc0 | bc1 | b1 | w2
+    unsigned char *s_mask = reinterpret_cast<unsigned char *>(s_vec + 5 * HD);   // HG * 64
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int m = lane & 15, q = lane >> 4;
+    const int col4 = 16 * wave + 4 * q;                            // this lane's 4 output columns
+#ifdef MTFJSP_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
+    const int R = A.R;
+    const unsigned invR = (unsigned)((0x100000000ull + (unsigned)R - 1) / (unsigned)R);
+    const int sr = tid >> 5, sc4 = (tid & 31) * 4;                  // staging: thread -> (row sr of 16, 4 columns)
+    const int xoff = m * X6_ROWB + 16 * q;                          // operand fragment of (plane p, k-step ks): + p*X6_PLANE + 64*ks
+    const float b2 = A.b2[0];
+    if (tid < 2 * HD) s_wc2[tid] = A.wc2[tid];
+    if (tid < HD) { s_vec[tid] = A.b0[tid]; s_vec[HD + tid] = A.bc0[tid]; s_vec[2 * HD + tid] = A.bc1[tid]; s_vec[3 * HD + tid] = A.b1[tid]; s_vec[4 * HD + tid] = A.w2[tid]; }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
+    if (A.zero_stats2 && blockIdx.x == 0) for (int i = tid; i < A.zero_count2; i += 512) A.zero_stats2[i] = 0.0;
+    float xs0 = 1.f, xs1 = 1.f, xs2 = 1.f, xs3 = 1.f, xh0 = 0.f, xh1 = 0.f, xh2 = 0.f, xh3 = 0.f;   // X scale / shift of this thread's 4 columns
+    if (A.xbn_stats) {
+        stage_bn(s_u, A.xbn_stats, A.xbn_inv_rows, A.xbn_gamma, A.xbn_beta, tid);      // s_u is free until phase A
+        LDS_BARRIER();
+        xs0 = s_u[sc4]; xs1 = s_u[sc4 + 1]; xs2 = s_u[sc4 + 2]; xs3 = s_u[sc4 + 3];
+        xh0 = s_u[HD + sc4]; xh1 = s_u[HD + sc4 + 1]; xh2 = s_u[HD + sc4 + 2]; xh3 = s_u[HD + sc4 + 3];
+        LDS_BARRIER();
+    }
+    STAMP(6);
+    {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
+        // 64-bit weight addresses into registers and spill them)
+        const int g0 = blockIdx.x * HG;
+        const int ng = (A.B - g0) < HG ? (A.B - g0) : HG;
+        const int nrows = ng * R;
+        // ---- requests first: weights of phase A, the instance tiles, the masks
+        bf16x8 wA[3][4], wB[3][4], wC[3][4];
+        WCOLX(wA, A.W0x, 1);                                        // Wb
+        WCOLX(wB, A.W0x, 2);                                        // Wc
+        WCOLX(wC, A.Wc0x, 0);
+        {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 xp = z;
+            if (A.xbn_stats) {                                      // pooled = mean over the instance's normalised rows (ac:444 / gcn:192)
+                if (sr < ng) {
+                    const int nr = A.xgather ? A.xT : R;
+                    const float *src = A.X + (size_t)(g0 + sr) * nr * HD + sc4;
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 12
+                    for (int r = 0; r < nr; r++) {                   // 12 rows in flight per thread
+                        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)r * HD);
+                        float y0 = fmaf(v.x, xs0, xh0), y1 = fmaf(v.y, xs1, xh1), y2 = fmaf(v.z, xs2, xh2), y3 = fmaf(v.w, xs3, xh3);
+                        if (A.xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+                        a0 += y0; a1 += y1; a2 += y2; a3 += y3;
+                    }
+                    const float ir = 1.0f / (float)nr;
+                    xp = make_float4(a0 * ir, a1 * ir, a2 * ir, a3 * ir);
+                    *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
+                }
+            } else if (sr < ng) xp = *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4);
+            STAMP(7);
+            const float4 xo = sr < ng ? *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + sr) * HD + sc4) : z;
+            {
+                const float vp[4] = {xp.x, xp.y, xp.z, xp.w}, vo[4] = {xo.x, xo.y, xo.z, xo.w};
+                uint2 a0, a1, a2, b0, b1, b2;
+                split3x4(vp, a0, a1, a2); split3x4(vo, b0, b1, b2);
+                unsigned char *dp = s_pp + sr * X6_ROWB + (tid & 31) * 8, *dq = s_op + sr * X6_ROWB + (tid & 31) * 8;
+                *reinterpret_cast<uint2 *>(dp) = a0; *reinterpret_cast<uint2 *>(dp + X6_PLANE) = a1; *reinterpret_cast<uint2 *>(dp + 2 * X6_PLANE) = a2;
+                *reinterpret_cast<uint2 *>(dq) = b0; *reinterpret_cast<uint2 *>(dq + X6_PLANE) = b1; *reinterpret_cast<uint2 *>(dq + 2 * X6_PLANE) = b2;
+            }
+        }
+        for (int i = tid; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
+        // scorer row `grow` of the group (instance grow / R, candidate / machine grow % R) -> its source row in X
+        auto xrow = [&](int grow) __attribute__((always_inline)) -> const float * {
+            if (!A.xgather) return A.X + ((size_t)g0 * R + grow) * HD + sc4;
+            const int il = (int)__umulhi((unsigned)grow, invR);
+            return A.X + ((size_t)(g0 + il) * A.xT + A.xgather[(size_t)g0 * R + grow]) * HD + sc4;
+        };
+        float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
+#pragma unroll
+        for (int t = 0; t < HCH; t++) {
+            const int grow = t * 16 + sr;
+            xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        LDS_BARRIER();
+        STAMP(0);
+        auto xnorm = [&](float4 v, bool valid) __attribute__((always_inline)) {
+            if (!valid) return make_float4(0.f, 0.f, 0.f, 0.f);
+            float y0 = fmaf(v.x, xs0, xh0), y1 = fmaf(v.y, xs1, xh1), y2 = fmaf(v.z, xs2, xh2), y3 = fmaf(v.w, xs3, xh3);
+            if (A.xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+            return make_float4(y0, y1, y2, y3);
+        };
+        // one 16-row tile (planes at `tp`) x this wave's column block: 24 products on two chains, fragments of the next k-step in flight
+        auto tile_x6 = [&](const unsigned char *tp, const bf16x8 (&wv)[3][4]) __attribute__((always_inline)) -> f32x4 {
+            f32x4 aA = zero4, aB = zero4;
+            bf16x8 xv[2][3];
+#pragma unroll
+            for (int p = 0; p < 3; p++) xv[0][p] = *reinterpret_cast<const bf16x8 *>(tp + xoff + p * X6_PLANE);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) {
+                if (ks < 3) {
+#pragma unroll
+                    for (int p = 0; p < 3; p++) xv[(ks + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(tp + xoff + p * X6_PLANE + 64 * (ks + 1));
+                }
+                X6_STEP(aA, aB, wv, xv[ks & 1], ks);
+            }
+            return aA + aB;
+        };
+        // a lane's 4 values of row m -> the three planes of a tile
+        auto put_planes = [&](unsigned char *tp, const float (&v)[4]) __attribute__((always_inline)) {
+            uint2 p0, p1, p2;
+            split3x4(v, p0, p1, p2);
+            unsigned char *d = tp + m * X6_ROWB + col4 * 2;
+            *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1; *reinterpret_cast<uint2 *>(d + 2 * X6_PLANE) = p2;
+        };
+        // ---- phase A: u = Wb pooled + Wc other + b0 ; c1 = tanh(Wc0 pooled + bc0)   (rows = the group's 16 instances)
+        {
+            const f32x4 au = tile_x6(s_pp, wA) + tile_x6(s_op, wB);
+            const f32x4 ac = tile_x6(s_pp, wC);
+            WCOLX(wA, A.Wc1x, 0);                                   // requested now, used in phase B
+            WCOLX(wB, A.W0x, 0);                                    // Wa
+            WCOLX(wC, A.W1x, 0);                                    // phase C
+            const float4 b0v = *reinterpret_cast<const float4 *>(s_vec + col4), bc0v = *reinterpret_cast<const float4 *>(s_vec + HD + col4);
+            *reinterpret_cast<float4 *>(s_u + m * HD + col4) = make_float4(au[0] + b0v.x, au[1] + b0v.y, au[2] + b0v.z, au[3] + b0v.w);
+            const float c1v[4] = {fast_tanh(ac[0] + bc0v.x), fast_tanh(ac[1] + bc0v.y), fast_tanh(ac[2] + bc0v.z), fast_tanh(ac[3] + bc0v.w)};
+            put_planes(s_c1p, c1v);
+        }
+        STAMP(1);
+        for (int tb = 0; tb < R; tb += HCH) {
+            const int nt = (R - tb) < HCH ? (R - tb) : HCH;
+            // ---- X rows of this chunk -> planes (rows beyond the group's are zero)
+#pragma unroll
+            for (int t = 0; t < HCH; t++) {
+                if (tb > 0) {
+                    const int grow = (tb + t) * 16 + sr;
+                    xr[t] = (tb + t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                const float4 xv4 = xnorm(xr[t], (tb + t) * 16 + sr < nrows);
+                const float v[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+                uint2 p0, p1, p2;
+                split3x4(v, p0, p1, p2);
+                unsigned char *d = s_xs + t * X6_TILE + sr * X6_ROWB + (tid & 31) * 8;
+                *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1; *reinterpret_cast<uint2 *>(d + 2 * X6_PLANE) = p2;
+            }
+            LDS_BARRIER();                                          // X planes, u and c1 are complete
+            STAMP(2);
+            // ---- phase B: Wa x for every tile of the chunk (accumulators held); first chunk: c2 = tanh(Wc1 c1 + bc1)
+            f32x4 accb[HCH];
+#pragma unroll
+            for (int t = 0; t < HCH; t++) accb[t] = t < nt ? tile_x6(s_xs + t * X6_TILE, wB) : zero4;
+            if (tb == 0) {
+                const f32x4 a0 = tile_x6(s_c1p, wA);
+                const float4 bc1v = *reinterpret_cast<const float4 *>(s_vec + 2 * HD + col4);
+                *reinterpret_cast<float4 *>(s_c2 + m * HX_CLDA + col4) =
+                    make_float4(fast_tanh(a0[0] + bc1v.x), fast_tanh(a0[1] + bc1v.y), fast_tanh(a0[2] + bc1v.z), fast_tanh(a0[3] + bc1v.w));
+            }
+            LDS_BARRIER();                                          // every wave is done with the X planes: s1 overwrites them
+            // s1 = tanh(Wa x + u[instance]) -> planes
+#pragma unroll
+            for (int t = 0; t < HCH; t++) {
+                if (t < nt) {
+                    const int grow = (tb + t) * 16 + m;
+                    const int i0 = grow < nrows ? (int)__umulhi((unsigned)grow, invR) : 0;
+                    const float4 uv = *reinterpret_cast<const float4 *>(s_u + i0 * HD + col4);
+                    const float sv[4] = {fast_tanh(accb[t][0] + uv.x), fast_tanh(accb[t][1] + uv.y), fast_tanh(accb[t][2] + uv.z), fast_tanh(accb[t][3] + uv.w)};
+                    put_planes(s_xs + t * X6_TILE, sv);
+                }
+            }
+            LDS_BARRIER();                                          // s1 planes and c2 are complete
+            STAMP(3);
+            // ---- phase C: s2 = tanh(W1 s1 + b1) ; partial scores of this wave's 16 columns
+            {
+                const float4 b1v = *reinterpret_cast<const float4 *>(s_vec + 3 * HD + col4), w2v = *reinterpret_cast<const float4 *>(s_vec + 4 * HD + col4);
+#pragma unroll
+                for (int t = 0; t < HCH; t++) {
+                    if (t < nt) {
+                        const f32x4 a0 = tile_x6(s_xs + t * X6_TILE, wC);
+                        float v = fast_tanh(a0[0] + b1v.x) * w2v.x;
+                        v = fmaf(fast_tanh(a0[1] + b1v.y), w2v.y, v);
+                        v = fmaf(fast_tanh(a0[2] + b1v.z), w2v.z, v);
+                        v = fmaf(fast_tanh(a0[3] + b1v.w), w2v.w, v);
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        if (q == 0) s_part[wave * (HCH * 16) + t * 16 + m] = v;
+                    }
+                }
+            }
+            if (tb == 0) {   // value head: 32 threads per instance row, 4 columns each, both outputs
+                const int r = tid >> 5, part = tid & 31;
+                float p0 = 0.f, p1 = 0.f;
+                for (int k = 0; k < 4; k++) { const float x = s_c2[r * HX_CLDA + part * 4 + k]; p0 = fmaf(x, s_wc2[part * 4 + k], p0); p1 = fmaf(x, s_wc2[HD + part * 4 + k], p1); }
+                for (int o = 16; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+                if (part == 0 && r < ng) { A.value[(size_t)(g0 + r) * 2] = p0 + A.bc2[0]; A.value[(size_t)(g0 + r) * 2 + 1] = p1 + A.bc2[1]; }
+            }
+            LDS_BARRIER();
+            if (tid < nt * 16) {
+                const int grow = tb * 16 + tid;
+                float v = b2;
+                for (int w = 0; w < 8; w++) v += s_part[w * (HCH * 16) + tid];
+                if (grow < nrows) s_score[grow] = v * A.scale;
+            }
+            LDS_BARRIER();                                          // planes / s_part are reused by the next chunk
+            STAMP(4);
+        }
+        // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance; optional action selection
+        {
+            const int r0 = tid >> 4, l = tid & 15;
+            if (r0 < ng) {
+                float mx = -INFINITY;
+                for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) mx = fmaxf(mx, s_score[r0 * R + r]);
+                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                float sum = 0.f;
+                for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) sum += __expf(s_score[r0 * R + r] - mx);
+                for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                for (int r = l; r < R; r += 16) {
+                    const float pr = s_mask[r0 * R + r] ? 0.f : __expf(s_score[r0 * R + r] - mx) / sum;
+                    A.prob[(size_t)(g0 + r0) * R + r] = pr;
+                    s_score[r0 * R + r] = pr;                           // lanes of one wave: visible to lane l == 0 below
+                }
+                if (A.sample_mode) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (l == 0) {
+                        const int b = g0 + r0;
+                        const int pick = pick_action(s_score + r0 * R, R, b, A.sample_mode == 2, A.seed, A.counter);
+                        A.idx_out[b] = pick;
+                        if (A.logp_out) A.logp_out[b] = logf(s_score[r0 * R + pick]);
+                        const int gsel = A.gather_from ? A.gather_from[(size_t)b * R + pick] : pick;
+                        if (A.gather_from && A.gathered_out) A.gathered_out[b] = gsel;
+                        s_part[r0] = __int_as_float(gsel);                     // hand the selected task to the instance's 16 lanes (s_part is free now)
+                    }
+                    if (A.mf_on) {
+                        // = k_mfea1 (pe:152-214) for the task just selected: the 16 lanes of the instance take the machines
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const int b = g0 + r0, T_ = A.mf.T, M_ = A.mf.M;
+                        int a = __float_as_int(s_part[r0]);
+                        if (a < 0 || a >= T_) a = 0;
+                        const size_t row = (size_t)b * T_ + a;
+                        int pm = 0;
+                        if (a % M_ != 0) {
+                            pm = reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
+                            if (pm < 0) pm += M_;                                             // python negative index (pe:206)
+                        }
+                        for (int mm = l; mm < M_; mm += 16) {
+                            const double tv = A.mf.t[row * M_ + mm], pv = A.mf.p[row * M_ + mm];
+                            const double ptv = tv * fabs(pv);
+                            const unsigned char mk = (unsigned char)!(tv >= 0);              // run:258-259 ~(t >= 0)
+                            const double x = (a % M_ != 0) ? A.mf.tt[((size_t)b * M_ + pm) * M_ + mm] : 0.0;
+                            const double f0 = tv > 0 ? tv : A.mf.mean3[row * 3 + 0], f1 = ptv > 0 ? ptv : A.mf.mean3[row * 3 + 1];
+                            const double f4 = pv > 0 ? pv : A.mf.mean3[row * 3 + 2];
+                            const size_t o = ((size_t)b * M_ + mm) * 6;
+                            const double f3 = (double)(1 - (int)mk), f5 = (double)(A.mf.shop[(size_t)b * M_ + mm] + 1);
+                            if (A.mf.obs_f32) {
+                                float *of = reinterpret_cast<float *>(A.mf.m_fea1_out) + o;
+                                of[0] = (float)f0; of[1] = (float)f1; of[2] = (float)x; of[3] = (float)f3; of[4] = (float)f4; of[5] = (float)f5;
+                            } else {
+                                double *od = reinterpret_cast<double *>(A.mf.m_fea1_out) + o;
+                                od[0] = f0; od[1] = f1; od[2] = x; od[3] = f3; od[4] = f4; od[5] = f5;
+                            }
+                            A.mf.mmask_out[(size_t)b * M_ + mm] = mk;
+                        }
+                    }
+                }
+            }
+        }
+        STAMP(5);
+    }
+#ifdef MTFJSP_STAMP
+    if (A.stamps && lane == 0) for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
+#endif
+}
+static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X6_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
 
 // ---------------------------------------------------------------------------------------------
 // GIN layer 0, first Linear (12 -> 128) fused with the neighbour aggregation of the raw task features
@@ -2076,6 +2387,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gin_inst<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_headsx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)headsx_lds_bytes());
     *out = e;
     return MTFJSP_OK;
 }
@@ -2167,24 +2479,27 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
             else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx6[key] = dx; }
             HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
         }
-        if (!is_gat_w && blocks == 1) {
-            // k_gemm_x6: exact 3-way bf16 split (round-to-nearest-even each), img[cg 4][c 2][plane 3][ks 4][lane 64][i 8] =
-            // plane(W[n = 32cg + 16c + (lane & 15)][k = 32ks + 8(lane >> 4) + i]);  W is the torch layout [out n][in k]
+        if (!is_gat_w) {
+            // k_gemm_x6 / k_headsx: exact 3-way bf16 split (round-to-nearest-even each), per 128-wide input block
+            // img[blk][cg 4][c 2][plane 3][ks 4][lane 64][i 8] = plane(W[n = 32cg + 16c + (lane & 15)][blk*128 + 32ks + 8(lane >> 4) + i]);
+            // W is the torch layout [out n][in].  (cg, c) = column block w = 2cg + c of k_headsx's wave w.
             auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
             auto from_bf16 = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
-            std::vector<uint16_t> im((size_t)3 * HD * HD);
-            for (int cgi = 0; cgi < 4; cgi++)
-                for (int c = 0; c < 2; c++)
-                    for (int ks = 0; ks < 4; ks++)
-                        for (int lane = 0; lane < 64; lane++)
-                            for (int i = 0; i < 8; i++) {
-                                const int n = 32 * cgi + 16 * c + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + i;
-                                const float w = data[(size_t)n * HD + k];
-                                const uint16_t p0 = to_bf16(w); const float r1 = w - from_bf16(p0);
-                                const uint16_t p1 = to_bf16(r1); const float r2 = r1 - from_bf16(p1);
-                                const uint16_t pl[3] = {p0, p1, to_bf16(r2)};
-                                for (int p = 0; p < 3; p++) im[((((((size_t)cgi * 2 + c) * 3 + p) * 4 + ks) * 64 + lane) * 8) + i] = pl[p];
-                            }
+            std::vector<uint16_t> im((size_t)3 * numel);
+            const int in = blocks * HD;
+            for (int blk = 0; blk < blocks; blk++)
+                for (int cgi = 0; cgi < 4; cgi++)
+                    for (int c = 0; c < 2; c++)
+                        for (int ks = 0; ks < 4; ks++)
+                            for (int lane = 0; lane < 64; lane++)
+                                for (int i = 0; i < 8; i++) {
+                                    const int n = 32 * cgi + 16 * c + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + i;
+                                    const float w = data[(size_t)n * in + blk * HD + k];
+                                    const uint16_t p0 = to_bf16(w); const float r1 = w - from_bf16(p0);
+                                    const uint16_t p1 = to_bf16(r1); const float r2 = r1 - from_bf16(p1);
+                                    const uint16_t pl[3] = {p0, p1, to_bf16(r2)};
+                                    for (int p = 0; p < 3; p++) im[(((((((size_t)blk * 4 + cgi) * 2 + c) * 3 + p) * 4 + ks) * 64 + lane) * 8) + i] = pl[p];
+                                }
             void *dx = nullptr;
             auto kt = e->wx6.find(key);
             if (kt != e->wx6.end()) dx = kt->second;
@@ -2446,6 +2761,15 @@ extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instan
     return MTFJSP_OK;
 }
 
+static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic)
+{
+    static const int f32mfma = getenv("MTFJSP_HEADS_F32MFMA") ? 1 : 0;      // A/B switch: the f32-instruction kernel
+    const int grid = (ha.B + HG - 1) / HG;
+    if (f32mfma) { hipLaunchKernelGGL(k_heads, dim3(grid), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
+    ha.W0x = e->wx6.at(policy + ".linears.0.weight"); ha.W1x = e->wx6.at(policy + ".linears.1.weight");
+    ha.Wc0x = e->wx6.at(critic + ".linears.0.weight"); ha.Wc1x = e->wx6.at(critic + ".linears.1.weight");
+    hipLaunchKernelGGL(k_headsx, dim3(grid), dim3(512), headsx_lds_bytes(), e->stream, ha);
+}
 static void arm_sampling(mtfjsp_encoder *e, int which, HeadArgs &ha)
 {
     mtfjsp_encoder::FusedSample &f = e->fs[which];
@@ -2529,7 +2853,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         if (!d_st) (void)hipMalloc((void **)&d_st, 4096 * 8 * 8);
         ha.stamps = d_st;
 #endif
-        hipLaunchKernelGGL(k_heads, dim3((B + HG - 1) / HG), dim3(512), heads_lds_bytes(), e->stream, ha);
+        launch_heads(e, ha, "job_actor.o_policy", "job_actor.job_critic");
 #ifdef MTFJSP_STAMP
         static int printed = 0;
         if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
@@ -2584,7 +2908,7 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
         ha.Wc1i = WI("machine_actor.machine_critic.linears.1.weight"); ha.bc1 = W("machine_actor.machine_critic.linears.1.bias");
         ha.wc2 = W("machine_actor.machine_critic.linears.2.weight"); ha.bc2 = W("machine_actor.machine_critic.linears.2.bias");
         ha.mask = mmask; ha.scale = 10.0f; ha.prob = prob; ha.value = machine_v;
-        hipLaunchKernelGGL(k_heads, dim3((B + HG - 1) / HG), dim3(512), heads_lds_bytes(), e->stream, ha);
+        launch_heads(e, ha, "machine_actor.m_policy", "machine_actor.machine_critic");
     }
     HIPCHK(e, hipGetLastError());
     return MTFJSP_OK;
