@@ -1547,24 +1547,55 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
     if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
     if (A.zero_stats2 && blockIdx.x == 0) for (int i = tid; i < A.zero_count2; i += 512) A.zero_stats2[i] = 0.0;
     float xs0 = 1.f, xs1 = 1.f, xs2 = 1.f, xs3 = 1.f, xh0 = 0.f, xh1 = 0.f, xh2 = 0.f, xh3 = 0.f;   // X scale / shift of this thread's 4 columns
-    if (A.xbn_stats) {
-        stage_bn(s_u, A.xbn_stats, A.xbn_inv_rows, A.xbn_gamma, A.xbn_beta, tid);      // s_u is free until phase A
-        LDS_BARRIER();
-        xs0 = s_u[sc4]; xs1 = s_u[sc4 + 1]; xs2 = s_u[sc4 + 2]; xs3 = s_u[sc4 + 3];
-        xh0 = s_u[HD + sc4]; xh1 = s_u[HD + sc4 + 1]; xh2 = s_u[HD + sc4 + 2]; xh3 = s_u[HD + sc4 + 3];
-        LDS_BARRIER();
+    // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of X, the gathered X rows of the
+    // first chunk (index -> row: two dependent round trips), the weights of phase A; only then the pooling stream
+    double bsu[STAT_REP], bsq[STAT_REP];
+    float bga = 0.f, bbe = 0.f;
+    if (A.xbn_stats && tid < HD) {
+#pragma unroll
+        for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.xbn_stats[r * 256 + tid]; bsq[r] = A.xbn_stats[r * 256 + HD + tid]; }
+        bga = A.xbn_gamma[tid]; bbe = A.xbn_beta[tid];
     }
-    STAMP(6);
     {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
         // 64-bit weight addresses into registers and spill them)
         const int g0 = blockIdx.x * HG;
         const int ng = (A.B - g0) < HG ? (A.B - g0) : HG;
         const int nrows = ng * R;
-        // ---- requests first: weights of phase A, the instance tiles, the masks
+        // scorer row `grow` of the group (instance grow / R, candidate / machine grow % R) -> its source row in X
+        auto xrow = [&](int grow) __attribute__((always_inline)) -> const float * {
+            if (!A.xgather) return A.X + ((size_t)g0 * R + grow) * HD + sc4;
+            const int il = (int)__umulhi((unsigned)grow, invR);
+            return A.X + ((size_t)(g0 + il) * A.xT + A.xgather[(size_t)g0 * R + grow]) * HD + sc4;
+        };
+        float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
+#pragma unroll
+        for (int t = 0; t < HCH; t++) {
+            const int grow = t * 16 + sr;
+            xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         bf16x8 wA[3][4], wB[3][4], wC[3][4];
         WCOLX(wA, A.W0x, 1);                                        // Wb
         WCOLX(wB, A.W0x, 2);                                        // Wc
         WCOLX(wC, A.Wc0x, 0);
+        if (A.xbn_stats) {
+            if (tid < HD) {                                         // stage_bn() from the registers requested above; s_u is free until phase A
+                double su = 0, sq = 0;
+#pragma unroll
+                for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
+                const double mean = su * A.xbn_inv_rows;
+                double var = sq * A.xbn_inv_rows - mean * mean;
+                if (var < 0) var = 0;
+                const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
+                const float sc = rstd * bga;
+                s_u[tid] = sc;
+                s_u[HD + tid] = bbe - (float)mean * sc;
+            }
+            LDS_BARRIER();
+            xs0 = s_u[sc4]; xs1 = s_u[sc4 + 1]; xs2 = s_u[sc4 + 2]; xs3 = s_u[sc4 + 3];
+            xh0 = s_u[HD + sc4]; xh1 = s_u[HD + sc4 + 1]; xh2 = s_u[HD + sc4 + 2]; xh3 = s_u[HD + sc4 + 3];
+            LDS_BARRIER();
+        }
+        STAMP(6);
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 xp = z;
@@ -1597,18 +1628,6 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
             }
         }
         for (int i = tid; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
-        // scorer row `grow` of the group (instance grow / R, candidate / machine grow % R) -> its source row in X
-        auto xrow = [&](int grow) __attribute__((always_inline)) -> const float * {
-            if (!A.xgather) return A.X + ((size_t)g0 * R + grow) * HD + sc4;
-            const int il = (int)__umulhi((unsigned)grow, invR);
-            return A.X + ((size_t)(g0 + il) * A.xT + A.xgather[(size_t)g0 * R + grow]) * HD + sc4;
-        };
-        float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
-#pragma unroll
-        for (int t = 0; t < HCH; t++) {
-            const int grow = t * 16 + sr;
-            xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
         LDS_BARRIER();
         STAMP(0);
         auto xnorm = [&](float4 v, bool valid) __attribute__((always_inline)) {
