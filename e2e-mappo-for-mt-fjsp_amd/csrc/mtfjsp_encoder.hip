@@ -30,7 +30,7 @@
 #define HD 128
 #define BN_EPS 1e-5
 
-enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2 };
+enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2, PRO_GIN0 = 3 };
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2 };
 
 // All [rows,128] activation buffers the GEMM kernels read or write are INTERNAL workspaces allocated with the row count
@@ -50,6 +50,8 @@ struct GemmArgs {
     const int *ell_col;     // PRO_AGG: [N,2] (caller buffer: exactly N rows)
     const float *ell_val;   // PRO_AGG: [N,2]
     int T;                  // PRO_AGG: rows per instance
+    const void *tfea;       // PRO_GIN0: raw task features [N,12] (f32 or f64), aggregated over the ELL adjacency and multiplied by the 12 -> 128 Linear
+    int feat_f64;
     double *epi_stats;      // EPI_STATS: [STAT_REP][256] accumulated with atomics (zeroed by the host per forward)
     unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
     int dbg;                // diagnostic build only: timing ablations of k_gemm16p (1 no stores/sums, 2 no row requests/transform)
@@ -523,6 +525,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     const int first = blockIdx.x * per;
     const int last = first + per < ntiles ? first + per : ntiles;
     const int nsteps = last > first ? (last - first + 3) >> 2 : 0;
+    constexpr int KS = (PRO == PRO_GIN0) ? 1 : 4;                 // k-steps of 32: the 12 -> 128 first Linear is one (k >= 12 are zero)
 #ifdef MTFJSP_STAMP
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last, rt0, rt1;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
@@ -532,13 +535,15 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of the input first
     double bsu[STAT_REP], bsq[STAT_REP];
     float bga = 0.f, bbe = 0.f;
-    if (tid < HD) {
+    if (PRO != PRO_GIN0 && tid < HD) {
 #pragma unroll
         for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.pro_stats[r * 256 + tid]; bsq[r] = A.pro_stats[r * 256 + HD + tid]; }
         bga = A.pro_gamma[tid]; bbe = A.pro_beta[tid];
     }
     auto stage_scale_shift = [&]() __attribute__((always_inline)) {   // stage_bn() from the registers requested above
-        if (tid < HD) {
+        if (PRO == PRO_GIN0) {                                    // the planes' k = 12..31 stay zero for the whole kernel
+            for (int i = tid; i < 8 * X6_TILE / 16; i += 512) reinterpret_cast<float4 *>(s_tiles)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else if (tid < HD) {
             double su = 0, sq = 0;
 #pragma unroll
             for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
@@ -589,6 +594,76 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             }
         };
         const int t0 = first + pw;
+        if constexpr (PRO == PRO_GIN0) {
+            // The consumers' step is short here (one k-step), shorter than an HBM round trip, so the producers take turns:
+            // wave pw builds ALL four tiles of the steps s = pw (mod 4) — lane = one of the step's 64 rows, all 12 features of
+            // the row and of its <= 2 neighbours (gcn:125-153: f64 accumulate, divide by the row's entry count) — and its
+            // requests are a whole turn (4 steps) ahead, the ELL entries two turns.
+            const int tl = lane >> 4, r = lane & 15;
+            float fo[12], fx[12], fy[12];
+            int2 cc = make_int2(-1, -1), cc_n = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f), vv_n = make_float2(0.f, 0.f);
+            auto feat12 = [&](size_t row, float (&o)[12]) __attribute__((always_inline)) {
+                if (A.feat_f64) {
+                    const double2 *p = reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(A.tfea) + row * 12);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { const double2 v = p[i]; o[2 * i] = (float)v.x; o[2 * i + 1] = (float)v.y; }
+                } else {
+                    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(A.tfea) + row * 12);
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { const float4 v = p[i]; o[4 * i] = v.x; o[4 * i + 1] = v.y; o[4 * i + 2] = v.z; o[4 * i + 3] = v.w; }
+                }
+            };
+            auto req_ell = [&](int s) __attribute__((always_inline)) {
+                const int tile = first + 4 * s + tl, g = tile * 16 + r;
+                cc_n = make_int2(-1, -1); vv_n = make_float2(0.f, 0.f);
+                if (tile < last && g < A.N) { cc_n = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv_n = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
+            };
+            auto req_feat = [&](int s) __attribute__((always_inline)) {          // ELL entries of step s are in cc_n / vv_n
+                const int tile = first + 4 * s + tl, g = tile * 16 + r;
+                cc = cc_n; vv = vv_n;
+#pragma unroll
+                for (int i = 0; i < 12; i++) { fo[i] = 0.f; fx[i] = 0.f; fy[i] = 0.f; }
+                if (tile < last && g < A.N) {
+                    const size_t base = (size_t)(g / A.T) * A.T;
+                    feat12((size_t)g, fo);
+                    if (cc.x >= 0) feat12(base + cc.x, fx);
+                    if (cc.y >= 0) feat12(base + cc.y, fy);
+                }
+            };
+            if (pw < nsteps) { req_ell(pw); req_feat(pw); }
+            if (pw + 4 < nsteps) req_ell(pw + 4);
+            stage_scale_shift();
+            LDS_BARRIER();
+            STAMP(0);
+            for (int s = 0; s < nsteps; s++) {
+                if ((s & 3) == pw) {
+                    const int deg = 1 + (cc.x >= 0) + (cc.y >= 0);
+                    unsigned char *d = s_tiles + ((s & 1) * 4 + tl) * X6_TILE + r * X6_ROWB;
+#pragma unroll
+                    for (int k4 = 0; k4 < 3; k4++) {
+                        float v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; i++) {
+                            double acc = (double)fo[4 * k4 + i];
+                            if (cc.x >= 0) acc += (double)vv.x * (double)fx[4 * k4 + i];
+                            if (cc.y >= 0) acc += (double)vv.y * (double)fy[4 * k4 + i];
+                            v[i] = (float)(acc / (double)deg);
+                        }
+                        uint2 p0, p1, p2;
+                        split3x4(v, p0, p1, p2);
+                        *reinterpret_cast<uint2 *>(d + k4 * 8) = p0;
+                        *reinterpret_cast<uint2 *>(d + k4 * 8 + X6_PLANE) = p1;
+                        *reinterpret_cast<uint2 *>(d + k4 * 8 + 2 * X6_PLANE) = p2;
+                    }
+                    if (s + 4 < nsteps) req_feat(s + 4);
+                    if (s + 8 < nsteps) req_ell(s + 8);
+                }
+                STAMP(1);
+                LDS_BARRIER();
+                STAMP(4);
+            }
+            LDS_BARRIER();                                        // the consumers' last step
+        } else {
         if (t0 < last) request_rows(preA, t0);
         if (PRO == PRO_AGG && t0 < last) { fetch_ell(t0); request_nb(t0); }
         if (t0 + 4 < last) request_rows(preB, t0 + 4);
@@ -639,20 +714,21 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             if (s + 1 < nsteps) produce(preB, s + 1);
         }
         LDS_BARRIER();                                            // the consumers' last step
+        }
     } else {
         // ================================ consumer ================================
         const int m = lane & 15, q = lane >> 4;                   // operands swapped: A[col c0+m][k = 8q..], B[k = 8q..][row m], C[col c0+4q+i][row m]
         const int cg = wave;
-        bf16x8 wf[2][3][4];                                       // [column block][plane][k-step]: W[32cg + 16c + m][32ks + 8q .. +7]
+        bf16x8 wf[2][3][KS];                                      // [column block][plane][k-step]: W[32cg + 16c + m][32ks + 8q .. +7]
         {
-            const float4 *wi = reinterpret_cast<const float4 *>(A.Wx6) + (size_t)cg * (2 * 3 * 4 * 64) + lane;
+            const float4 *wi = reinterpret_cast<const float4 *>(A.Wx6) + (size_t)cg * (2 * 3 * KS * 64) + lane;
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
                 for (int p = 0; p < 3; p++)
 #pragma unroll
-                    for (int ks = 0; ks < 4; ks++) {
-                        const float4 v = wi[((c * 3 + p) * 4 + ks) * 64];
+                    for (int ks = 0; ks < KS; ks++) {
+                        const float4 v = wi[((c * 3 + p) * KS + ks) * 64];
                         wf[c][p][ks] = __builtin_bit_cast(bf16x8, v);
                     }
         }
@@ -680,20 +756,21 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             const unsigned char *xa = xa0 + ((s - 1) & 1) * 4 * X6_TILE;
             auto tiles4 = [&](auto FULLc) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(FULLc)::value;    // FULL: all four tiles exist and none holds rows >= N
-                bf16x8 xf[3][3];                                  // fragments of (tile, k-step) units u, u+1, u+2: two units (24 products) of LDS latency cover
+                bf16x8 xf[3][3];                                  // fragments of (tile, k-step) units u, u+1, u+2: two units of LDS latency cover
+                constexpr int NU = 4 * KS;
 #pragma unroll
                 for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + p * X6_PLANE);
 #pragma unroll
-                for (int p = 0; p < 3; p++) xf[1][p] = *reinterpret_cast<const bf16x8 *>(xa + p * X6_PLANE + 64);
+                for (int p = 0; p < 3; p++) xf[1][p] = *reinterpret_cast<const bf16x8 *>(xa + (1 / KS) * X6_TILE + p * X6_PLANE + 64 * (1 % KS));
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     if (!FULL && tb + t >= last) break;
                     f32x4 acc[2] = {biasv[0], biasv[1]};
 #pragma unroll
-                    for (int ks = 0; ks < 4; ks++) {
-                        const int u = t * 4 + ks;
-                        if (u + 2 < 16) {                         // a stale slot beyond the last tile is read but never used
-                            const int tn = (u + 2) >> 2, kn = (u + 2) & 3;
+                    for (int ks = 0; ks < KS; ks++) {
+                        const int u = t * KS + ks;
+                        if (u + 2 < NU) {                         // a stale slot beyond the last tile is read but never used
+                            const int tn = (u + 2) / KS, kn = (u + 2) % KS;
 #pragma unroll
                             for (int p = 0; p < 3; p++) xf[(u + 2) % 3][p] = *reinterpret_cast<const bf16x8 *>(xa + tn * X6_TILE + p * X6_PLANE + 64 * kn);
                         }
@@ -2402,6 +2479,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gat3x, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gat3x_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_GIN0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gin_inst<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gin_inst<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
@@ -2439,6 +2517,30 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
         e->hostw[key].assign(data, data + numel);
         const std::string prefix = key.substr(0, key.find('.') + 1);
         e->wfused.erase(prefix + "1"); e->wfused.erase(prefix + "2");   // rebuilt at the next forward (buffers stay owned)
+    }
+    if (numel == (int64_t)HD * 12 && key.find("mlps.0.linears.0.weight") != std::string::npos) {
+        // k_gemm_x6<PRO_GIN0>: the 12 -> 128 first Linear as ONE k-step of 32 (k >= 12 zero), exact 3-way bf16 split:
+        // img[cg 4][c 2][plane 3][lane 64][i 8] = plane(W[n = 32cg + 16c + (lane & 15)][k = 8(lane >> 4) + i])
+        auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+        auto from_bf16 = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
+        std::vector<uint16_t> im((size_t)4 * 2 * 3 * 64 * 8, 0);
+        for (int cgi = 0; cgi < 4; cgi++)
+            for (int c = 0; c < 2; c++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int i = 0; i < 8; i++) {
+                        const int n = 32 * cgi + 16 * c + (lane & 15), k = 8 * (lane >> 4) + i;
+                        if (k >= 12) continue;
+                        const float w = data[(size_t)n * 12 + k];
+                        const uint16_t p0 = to_bf16(w); const float r1 = w - from_bf16(p0);
+                        const uint16_t p1 = to_bf16(r1); const float r2 = r1 - from_bf16(p1);
+                        const uint16_t pl[3] = {p0, p1, to_bf16(r2)};
+                        for (int p = 0; p < 3; p++) im[(((((size_t)cgi * 2 + c) * 3 + p) * 64 + lane) * 8) + i] = pl[p];
+                    }
+        void *dx = nullptr;
+        auto kt = e->wx6.find(key);
+        if (kt != e->wx6.end()) dx = kt->second;
+        else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx6[key] = dx; }
+        HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
     }
     // 128-wide Linear weights [out=128, in=128*k] and gat W [in,out]: keep GEMM-ready [in-block][k][n] copies
     const bool is_w = key.size() > 7 && key.compare(key.size() - 7, 7, ".weight") == 0 && key.find("linears") != std::string::npos;
@@ -2616,7 +2718,18 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     e->gin_stats_clean = false; e->gin_slot5_dirty = false;
     const double invN = 1.0 / (double)N;
     const int pgrid = e->num_cu * 8;
-    {   // layer 0 / linear 0 with aggregation of the raw features
+    static const int gin0_valu = getenv("MTFJSP_GIN0_VALU") ? 1 : 0;          // A/B switch: the VALU kernel
+    if (!gin0_valu) {   // layer 0 / linear 0 with aggregation of the raw features, on the producer/consumer product kernel
+        Timed t(e, "gin0_agg_linear12");
+        GemmArgs a = gemm_args(nullptr, N, nullptr, W(P + "mlps.0.linears.0.bias"), e->zA);
+        a.tfea = tasks_fea; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64; a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
+        a.epi_stats = st + 0 * STAT_REP * 256;
+        a.Wx6 = e->wx6.at(P + "mlps.0.linears.0.weight");
+        const int ntiles = (N + 15) / 16;
+        int grid = (ntiles + 7) / 8;
+        if (grid > e->num_cu) grid = e->num_cu;
+        hipLaunchKernelGGL((k_gemm_x6<PRO_GIN0>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, a);
+    } else {
         Timed t(e, "gin0_agg_linear12");
         if (e->cfg.obs_dtype == MTFJSP_OBS_F32)
             hipLaunchKernelGGL((k_gin0<float>), dim3(pgrid), dim3(256), 0, e->stream, N, T, (const float *)tasks_fea, ell_col, ell_val,
