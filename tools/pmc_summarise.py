@@ -11,13 +11,14 @@ import json
 import sys
 
 FAMILY = {
+    "void k_gemm_x6<1>": "gin_gemm_bn_relu", "void k_gemm_x6<2>": "gin_gemm_agg", "void k_gemm_x6<3>": "gin0_agg_linear12",
     "void k_gemm16p<1>": "gin_gemm_bn_relu", "void k_gemm16p<2>": "gin_gemm_agg", "void k_env_reg<float>": "env_step",
     "k_heads": "heads", "k_gat3": "gat3", "void k_gin0<float>": "gin0_agg_linear12", "k_job_pool_gather": "job_pool_gather",
     "void k_mfea1<float>": "mfea1", "void k_env_reset<float>": "env_reset", "k_gae": "gae", "k_snapshot": "snapshot",
 }
 raw = json.load(open(sys.argv[1]))
 out = {"_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py "
-       "--no-cpu-baseline --steps 72 --warmup 36 ; B=4096 J6M6E2 obs f32; averages per launch. Counters are in KiB. gfx950: "
+       "--no-cpu-baseline --no-env-sweep --steps 72 --warmup 36 (tools/profile_rollout.sh) ; B=4096 J6M6E2 obs f32; averages per launch. Counters are in KiB. gfx950: "
        "FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md §HBM) -> "
        "fetch_corrected = 2*FETCH_SIZE; WRITE_SIZE is exact. k_env_reg mixes 4/8/16-B accesses: its read side is "
        "uncalibrated, traffic_bytes uses the 2x (upper) figure and the raw figure is kept beside it.", "kernels": {}}
