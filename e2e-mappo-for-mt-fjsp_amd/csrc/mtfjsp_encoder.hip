@@ -2376,6 +2376,10 @@ struct mtfjsp_encoder {
     bool gin_stats_clean = false;           // slots 0..5 are zero (the job-actor heads kernel zeroes them after their last reader)
     bool gat_stats_clean[2] = {false, false};
     int bn_mode = 0;                        // 0: BatchNorm statistics over the whole device batch; 1: per instance (validate.py semantics)
+    // which products run with the f32 matrix instruction instead of the exact bf16 split (A/B reference; bits: 1 GIN products,
+    // 2 GAT passes, 4 heads, 8 first GIN Linear on the VALU); default from MTFJSP_GEMM_F32MFMA / _GAT_ / _HEADS_ / MTFJSP_GIN0_VALU
+    int f32_products = (getenv("MTFJSP_GEMM_F32MFMA") ? 1 : 0) | (getenv("MTFJSP_GAT_F32MFMA") ? 2 : 0) |
+                       (getenv("MTFJSP_HEADS_F32MFMA") ? 4 : 0) | (getenv("MTFJSP_GIN0_VALU") ? 8 : 0);
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
     mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
     struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
@@ -2671,8 +2675,7 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
 #endif
     if constexpr (PRO == PRO_PLAIN) hipLaunchKernelGGL((k_gemm16<EPI, ACC>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
     else {
-        static const int f32mfma = getenv("MTFJSP_GEMM_F32MFMA") ? 1 : 0;      // A/B switch: the f32-instruction kernel
-        if (b.Wx6 && !f32mfma) hipLaunchKernelGGL((k_gemm_x6<PRO>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
+        if (b.Wx6 && !(e->f32_products & 1)) hipLaunchKernelGGL((k_gemm_x6<PRO>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
         else hipLaunchKernelGGL((k_gemm16p<PRO>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
     }
 #ifdef MTFJSP_STAMP
@@ -2718,8 +2721,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     e->gin_stats_clean = false; e->gin_slot5_dirty = false;
     const double invN = 1.0 / (double)N;
     const int pgrid = e->num_cu * 8;
-    static const int gin0_valu = getenv("MTFJSP_GIN0_VALU") ? 1 : 0;          // A/B switch: the VALU kernel
-    if (!gin0_valu) {   // layer 0 / linear 0 with aggregation of the raw features, on the producer/consumer product kernel
+    if (!(e->f32_products & 8)) {   // layer 0 / linear 0 with aggregation of the raw features, on the producer/consumer product kernel
         Timed t(e, "gin0_agg_linear12");
         GemmArgs a = gemm_args(nullptr, N, nullptr, W(P + "mlps.0.linears.0.bias"), e->zA);
         a.tfea = tasks_fea; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64; a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
@@ -2821,8 +2823,7 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
         (void)hipMemsetAsync(d_st, 0, 2048 * 8 * 8, e->stream);
         a.stamps = d_st;
 #endif
-        static const int gat_f32 = getenv("MTFJSP_GAT_F32MFMA") ? 1 : 0;      // A/B switch: the f32-instruction kernel
-        if (gat_f32) hipLaunchKernelGGL(k_gat3, dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, a);
+        if (e->f32_products & 2) hipLaunchKernelGGL(k_gat3, dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, a);
         else {
             a.Wx6 = e->wx6.at(pre + "gat_layer.W");
             hipLaunchKernelGGL(k_gat3x, dim3(grid), dim3(512), gat3x_lds_bytes(), e->stream, a);
@@ -2886,6 +2887,12 @@ static int run_gat_inst(mtfjsp_encoder *e, const std::string &pre, const void *m
 }
 // = evaluating with env_batch 1 per instance (validate.py:60-297): mode 1 makes every BatchNorm of the two
 // actor forwards normalise over the rows of ONE instance; mode 0 (default) over the whole device batch (training rollout).
+extern "C" int mtfjsp_encoder_set_product_mode(mtfjsp_encoder_t e, int32_t f32_instruction_mask)
+{
+    if (!e || f32_instruction_mask < 0 || f32_instruction_mask > 15) return MTFJSP_ERR_ARG;
+    e->f32_products = f32_instruction_mask;
+    return MTFJSP_OK;
+}
 extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance)
 {
     if (!e || per_instance < 0 || per_instance > 1) return MTFJSP_ERR_ARG;
@@ -2895,9 +2902,8 @@ extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instan
 
 static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic)
 {
-    static const int f32mfma = getenv("MTFJSP_HEADS_F32MFMA") ? 1 : 0;      // A/B switch: the f32-instruction kernel
     const int grid = (ha.B + HG - 1) / HG;
-    if (f32mfma) { hipLaunchKernelGGL(k_heads, dim3(grid), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
+    if (e->f32_products & 4) { hipLaunchKernelGGL(k_heads, dim3(grid), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
     ha.W0x = e->wx6.at(policy + ".linears.0.weight"); ha.W1x = e->wx6.at(policy + ".linears.1.weight");
     ha.Wc0x = e->wx6.at(critic + ".linears.0.weight"); ha.Wc1x = e->wx6.at(critic + ".linears.1.weight");
     hipLaunchKernelGGL(k_headsx, dim3(grid), dim3(512), headsx_lds_bytes(), e->stream, ha);

@@ -137,6 +137,11 @@ class Encoder:
         greedy evaluation with env_batch 1, validate.py:60-297); False (default): over the whole device batch"""
         capi.check(self.L.mtfjsp_encoder_set_bn_mode(self.h, 1 if per_instance else 0), self.h, enc=True)
 
+    def set_product_mode(self, f32_instruction_mask=0):
+        """0 (default): 128x128 products as exact 3-way bf16 splits on the matrix cores (f32-accurate); bits select the f32
+        matrix instruction instead (1 GIN products, 2 GAT passes, 4 heads, 8 first GIN Linear on the VALU) — the A/B reference"""
+        capi.check(self.L.mtfjsp_encoder_set_product_mode(self.h, int(f32_instruction_mask)), self.h, enc=True)
+
     def arm_selection(self, which, greedy, seed, counter, idx_out, logp_out=None, gather_from=None, gathered_out=None):
         """fuse the action selection of the next job (which=0) / machine (which=1) actor forward into its heads kernel; same
         stream and outputs as sample() on that forward's prob"""
@@ -234,7 +239,7 @@ class ActorPair:
         if name in ("gin_gemm_bn_relu", "gin_gemm_agg"):
             rows = B * T
             flops = 2.0 * rows * H * H
-            if os.environ.get("MTFJSP_GEMM_F32MFMA"):
+            if os.environ.get("MTFJSP_GEMM_F32MFMA"):    # (set_product_mode() is not reflected here: bench.py never calls it)
                 ach = flops / avg_s / 1e12
                 return {"kernel": f"k_gemm16p<{name}> ([{rows},128]x[128,128] f32 MFMA 16x16x4, software-pipelined, fused BN/aggregation prologue + stats epilogue)",
                         "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,

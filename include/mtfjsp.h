@@ -241,6 +241,12 @@ int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask
  * per_instance = 1: over the rows of ONE instance = B independent reference runs with env_batch = 1, i.e. the greedy
  * evaluation of validate.py:60-297 batched over the evaluation set.  Not applied to the global critic. */
 int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance);
+/* How the [rows,128]x[128,128] products of the actor forwards (Linear layers of gcn:95-153 / ac:205-293, the GAT weight of
+ * gat:82) are formed.  0 (default): every f32 operand is split exactly into three bf16 pieces and the six significant piece
+ * products are accumulated in f32 on the bf16 matrix cores — as accurate as an f32 FMA chain.  Bits select
+ * the f32 matrix instruction instead, as the A/B reference: 1 = GIN products, 2 = GAT passes, 4 = actor/critic heads,
+ * 8 = first GIN Linear (12 -> 128) on the vector ALU. */
+int mtfjsp_encoder_set_product_mode(mtfjsp_encoder_t e, int32_t f32_instruction_mask);
 /* Fuse the action selection of the NEXT mtfjsp_job_actor_forward (which = 0) / mtfjsp_machine_actor_forward (which = 1) call into
  * its heads kernel: same arguments and the same Philox stream as mtfjsp_sample_categorical on that forward's `prob`
  * (agent:22-72), one launch less per decision.  One-shot: applies to one forward call. */

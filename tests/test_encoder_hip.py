@@ -156,3 +156,50 @@ def test_gae_kernel_matches_reference_recursion():
         ref = D.gae(r, v, vn, done, 0.99, 0.98)
         torch.cuda.synchronize()
         assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_split_products_match_the_f32_matrix_instruction():
+    """The default products (exact 3-way bf16 split, 6 piece products, f32 accumulate: DESIGN.md §4) against the same
+    forwards with every product on v_mfma_f32_16x16x4_f32 / the VALU (mtfjsp_encoder_set_product_mode(15)): two f32-accurate
+    evaluations of the same network differ by accumulation-order round-off only (a few 1e-6 of the tensor's scale after six
+    stacked GIN layers / three GAT passes + BatchNorm; bounds below) and the split path is no further from the reference's
+    own outputs than the f32-instruction path is."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    from oracle import encoder_oracle as eo
+    g = np.load(os.path.join(GOLDEN, "encoder_j6m6e2_rand.npz"))
+    J, M, E, B = [int(x) for x in g["meta"]]
+    T = J * M
+    ja, ma = eo.split_weights(g)
+    enc = enc_mod.Encoder(J, M, B, obs_dtype="f32")
+    enc.load_weights(ja, ma, eo.critic_weights(g))
+    worst = {}
+    for s in g["steps"]:
+        p = f"s{int(s)}_"
+        col, val = eo.ell_from_dense(g[p + "adj"])
+        hm_in = g[p + "h_m_in"]
+        outs = []
+        for mode in (0, 15):
+            enc.set_product_mode(mode)
+            h_nodes = torch.zeros(B * T, 128, dtype=torch.float32, device="cuda")
+            prob, h_o, job_v = enc.job_actor_forward(
+                _t(g[p + "tfea"], torch.float32), _t(col.reshape(B * T, 2).astype(np.int32)), _t(val.reshape(B * T, 2).astype(np.float32)),
+                _t(g[p + "cand"].astype(np.int32)), _t(g[p + "mask"].astype(np.uint8)),
+                None if hm_in.size == 0 else _t(hm_in.astype(np.float32)), h_nodes=h_nodes)
+            mprob, h_m, mach_v = enc.machine_actor_forward(_t(g[p + "mfea1"], torch.float32), _t(g[p + "mfea2"], torch.float32),
+                                                           _t(g[p + "h_o"].astype(np.float32)), _t(g[p + "mmask"].reshape(B, M).astype(np.uint8)))
+            torch.cuda.synchronize()
+            outs.append({k: v.cpu().numpy().copy() for k, v in dict(h_nodes=h_nodes, h_o=h_o, job_prob=prob, job_v=job_v, mch_prob=mprob,
+                                                                    h_m=h_m, mach_v=mach_v).items()})
+        enc.set_product_mode(0)
+        for k in outs[0]:
+            scale = max(1.0, float(np.abs(g[p + k]).max()))
+            d_ab = float(np.abs(outs[0][k] - outs[1][k]).max()) / scale
+            d_split = float(np.abs(outs[0][k] - g[p + k]).max()) / scale
+            d_f32 = float(np.abs(outs[1][k] - g[p + k]).max()) / scale
+            worst[k] = max(worst.get(k, 0.0), d_ab)
+            tol = 1e-5 if k.endswith("prob") or k in ("h_nodes", "h_o", "h_m") else 5e-5
+            assert d_ab <= tol, (k, d_ab)
+            assert d_split <= 1.5 * d_f32 + 2e-6, (k, d_split, d_f32)
+    print("max |split - f32 instruction| / scale:", {k: f"{v:.2e}" for k, v in worst.items()})
