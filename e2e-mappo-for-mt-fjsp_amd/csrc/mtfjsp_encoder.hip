@@ -595,72 +595,75 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         };
         const int t0 = first + pw;
         if constexpr (PRO == PRO_GIN0) {
-            // The consumers' step is short here (one k-step), shorter than an HBM round trip, so the producers take turns:
-            // wave pw builds ALL four tiles of the steps s = pw (mod 4) — lane = one of the step's 64 rows, all 12 features of
-            // the row and of its <= 2 neighbours (gcn:125-153: f64 accumulate, divide by the row's entry count) — and its
-            // requests are a whole turn (4 steps) ahead, the ELL entries two turns.
-            const int tl = lane >> 4, r = lane & 15;
-            float fo[12], fx[12], fy[12];
-            int2 cc = make_int2(-1, -1), cc_n = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f), vv_n = make_float2(0.f, 0.f);
-            auto feat12 = [&](size_t row, float (&o)[12]) __attribute__((always_inline)) {
-                if (A.feat_f64) {
-                    const double2 *p = reinterpret_cast<const double2 *>(reinterpret_cast<const double *>(A.tfea) + row * 12);
-#pragma unroll
-                    for (int i = 0; i < 6; i++) { const double2 v = p[i]; o[2 * i] = (float)v.x; o[2 * i + 1] = (float)v.y; }
-                } else {
-                    const float4 *p = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(A.tfea) + row * 12);
-#pragma unroll
-                    for (int i = 0; i < 3; i++) { const float4 v = p[i]; o[4 * i] = v.x; o[4 * i + 1] = v.y; o[4 * i + 2] = v.z; o[4 * i + 3] = v.w; }
-                }
+            // lane = (row r = lane >> 2 of this wave's tile, features 3*(lane & 3)..+2): raw features of the row and of its <= 2
+            // neighbours (gcn:125-153: f64 accumulate, divided by the row's entry count — 1, 2 or 3, as a multiplication).
+            // The consumers' step is short here (one k-step), shorter than an HBM round trip, so the requests run FOUR steps
+            // ahead (ring of 4 register stages) and the ELL entries they depend on eight.
+            const int r = lane >> 2, k0 = 3 * (lane & 3);
+            struct Stage { float fo[3], fx[3], fy[3]; int2 cc; float2 vv; } st[4];
+            struct Ell { int2 cc; float2 vv; } el[4];
+            auto feat3 = [&](size_t row, float (&o)[3]) __attribute__((always_inline)) {
+                if (A.feat_f64) { const double *p = reinterpret_cast<const double *>(A.tfea) + row * 12 + k0; o[0] = (float)p[0]; o[1] = (float)p[1]; o[2] = (float)p[2]; }
+                else { const float *p = reinterpret_cast<const float *>(A.tfea) + row * 12 + k0; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
             };
-            auto req_ell = [&](int s) __attribute__((always_inline)) {
-                const int tile = first + 4 * s + tl, g = tile * 16 + r;
-                cc_n = make_int2(-1, -1); vv_n = make_float2(0.f, 0.f);
-                if (tile < last && g < A.N) { cc_n = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv_n = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
+            auto req_ell = [&](Ell &e, int tile) __attribute__((always_inline)) {
+                const int g = tile * 16 + r;
+                e.cc = make_int2(-1, -1); e.vv = make_float2(0.f, 0.f);
+                if (tile < last && g < A.N) { e.cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); e.vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
             };
-            auto req_feat = [&](int s) __attribute__((always_inline)) {          // ELL entries of step s are in cc_n / vv_n
-                const int tile = first + 4 * s + tl, g = tile * 16 + r;
-                cc = cc_n; vv = vv_n;
+            auto req_feat = [&](Stage &x, const Ell &e, int tile) __attribute__((always_inline)) {
+                const int g = tile * 16 + r;
+                x.cc = e.cc; x.vv = e.vv;
 #pragma unroll
-                for (int i = 0; i < 12; i++) { fo[i] = 0.f; fx[i] = 0.f; fy[i] = 0.f; }
+                for (int i = 0; i < 3; i++) { x.fo[i] = 0.f; x.fx[i] = 0.f; x.fy[i] = 0.f; }
                 if (tile < last && g < A.N) {
                     const size_t base = (size_t)(g / A.T) * A.T;
-                    feat12((size_t)g, fo);
-                    if (cc.x >= 0) feat12(base + cc.x, fx);
-                    if (cc.y >= 0) feat12(base + cc.y, fy);
+                    feat3((size_t)g, x.fo);
+                    if (x.cc.x >= 0) feat3(base + x.cc.x, x.fx);
+                    if (x.cc.y >= 0) feat3(base + x.cc.y, x.fy);
                 }
             };
-            if (pw < nsteps) { req_ell(pw); req_feat(pw); }
-            if (pw + 4 < nsteps) req_ell(pw + 4);
+#pragma unroll
+            for (int i = 0; i < 4; i++) req_ell(el[i], t0 + 4 * i);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { req_feat(st[i], el[i], t0 + 4 * i); req_ell(el[i], t0 + 4 * (i + 4)); }
             stage_scale_shift();
             LDS_BARRIER();
             STAMP(0);
-            for (int s = 0; s < nsteps; s++) {
-                if ((s & 3) == pw) {
-                    const int deg = 1 + (cc.x >= 0) + (cc.y >= 0);
-                    unsigned char *d = s_tiles + ((s & 1) * 4 + tl) * X6_TILE + r * X6_ROWB;
+            for (int s0 = 0; s0 < nsteps; s0 += 4) {
 #pragma unroll
-                    for (int k4 = 0; k4 < 3; k4++) {
-                        float v[4];
+                for (int i = 0; i < 4; i++) {
+                    const int s = s0 + i;
+                    if (s < nsteps) {
+                        const int tile = t0 + 4 * s;
+                        if (tile < last) {
+                            const Stage &x = st[i];
+                            const int deg = 1 + (x.cc.x >= 0) + (x.cc.y >= 0);
+                            const double inv = deg == 1 ? 1.0 : deg == 2 ? 0.5 : (1.0 / 3.0);
+                            float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int i = 0; i < 4; i++) {
-                            double acc = (double)fo[4 * k4 + i];
-                            if (cc.x >= 0) acc += (double)vv.x * (double)fx[4 * k4 + i];
-                            if (cc.y >= 0) acc += (double)vv.y * (double)fy[4 * k4 + i];
-                            v[i] = (float)(acc / (double)deg);
+                            for (int f = 0; f < 3; f++) {
+                                double acc = (double)x.fo[f];
+                                if (x.cc.x >= 0) acc += (double)x.vv.x * (double)x.fx[f];
+                                if (x.cc.y >= 0) acc += (double)x.vv.y * (double)x.fy[f];
+                                v[f] = (float)(acc * inv);
+                            }
+                            uint2 p0, p1, p2;
+                            split3x4(v, p0, p1, p2);                  // element 3 is padding
+                            unsigned char *d = s_tiles + ((s & 1) * 4 + pw) * X6_TILE + r * X6_ROWB + k0 * 2;
+                            unsigned short *d0 = reinterpret_cast<unsigned short *>(d), *d1 = reinterpret_cast<unsigned short *>(d + X6_PLANE),
+                                           *d2 = reinterpret_cast<unsigned short *>(d + 2 * X6_PLANE);
+                            d0[0] = (unsigned short)p0.x; d0[1] = (unsigned short)(p0.x >> 16); d0[2] = (unsigned short)p0.y;
+                            d1[0] = (unsigned short)p1.x; d1[1] = (unsigned short)(p1.x >> 16); d1[2] = (unsigned short)p1.y;
+                            d2[0] = (unsigned short)p2.x; d2[1] = (unsigned short)(p2.x >> 16); d2[2] = (unsigned short)p2.y;
                         }
-                        uint2 p0, p1, p2;
-                        split3x4(v, p0, p1, p2);
-                        *reinterpret_cast<uint2 *>(d + k4 * 8) = p0;
-                        *reinterpret_cast<uint2 *>(d + k4 * 8 + X6_PLANE) = p1;
-                        *reinterpret_cast<uint2 *>(d + k4 * 8 + 2 * X6_PLANE) = p2;
+                        req_feat(st[i], el[i], tile + 16);            // step s + 4 (its ELL entries arrived 4 steps ago)
+                        req_ell(el[i], tile + 32);                    // step s + 8
+                        STAMP(1);
+                        LDS_BARRIER();
+                        STAMP(4);
                     }
-                    if (s + 4 < nsteps) req_feat(s + 4);
-                    if (s + 8 < nsteps) req_ell(s + 8);
                 }
-                STAMP(1);
-                LDS_BARRIER();
-                STAMP(4);
             }
             LDS_BARRIER();                                        // the consumers' last step
         } else {
