@@ -1797,8 +1797,8 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
             // ---- phase C: s2 = tanh(W1 s1 + b1) ; partial scores of this wave's 16 columns
             {
                 const float4 b1v = *reinterpret_cast<const float4 *>(s_vec + 3 * HD + col4), w2v = *reinterpret_cast<const float4 *>(s_vec + 4 * HD + col4);
-#pragma unroll
-                for (int t = 0; t < HCH; t++) {
+#pragma unroll 1
+                for (int t = 0; t < HCH; t++) {                     // (rolled: this kernel runs once per workgroup from a cold instruction cache)
                     if (t < nt) {
                         const f32x4 a0 = tile_x6(s_xs + t * X6_TILE, wC);
                         float v = fast_tanh(a0[0] + b1v.x) * w2v.x;
