@@ -21,7 +21,7 @@ def _perturb(ja, ma, seed):
 
 
 @pytest.mark.parametrize("J,M,E,B,steps,obs", [(10, 6, 2, 37, 23, "f32"), (10, 10, 2, 24, 41, "f64"), (20, 20, 4, 5, 150, "f32"),
-                                             (3, 4, 2, 7, 5, "f32")])
+                                             (3, 4, 2, 7, 5, "f32"), (5, 7, 1, 19, 17, "f32"), (7, 5, 5, 33, 9, "f64")])
 def test_encoder_matches_oracle_at_other_sizes(J, M, E, B, steps, obs):
     import torch
     import mtfjsp_amd  # noqa: F401
