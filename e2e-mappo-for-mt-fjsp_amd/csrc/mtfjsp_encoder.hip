@@ -1,17 +1,20 @@
 // mtfjsp_encoder.hip — rollout forward passes of the job actor (GIN encoder + candidate scorer + local critic)
 // and the machine actor (3x shared 2-node GAT + BatchNorm + scorer + local critic) for MI355X (gfx950 / CDNA4).
 //
-// Everything [rows,128] x [128,128] runs on the f32-input matrix cores (v_mfma_f32_32x32x2_f32: exact f32 FMA
-// chains, so parity with the reference's f32 modules is round-off only).  One persistent 256-thread workgroup per
-// CU keeps W^T (64 KB) in LDS; each wave owns 32-row tiles:
-//     prologue : coalesced 16-B loads of the producer's pre-activation rows, transformed on the fly
-//                (training-mode BatchNorm + ReLU from the producer's column sums, or the GIN neighbour
-//                aggregation over the ELL adjacency in f64) -> wave-private LDS tile (row stride 129: conflict-free)
-//     main     : 64 k-steps x 4 column blocks of MFMA (K is permuted so each lane half streams its own half row)
-//     epilogue : + bias [+ per-instance row bias] [tanh], store, and per-column sum / sum-of-squares for the
-//                consumer's BatchNorm (f32 per tile -> f64 per wave -> one f64 atomic per column per workgroup)
-// so every BatchNorm boundary costs exactly one write + one read of the [rows,128] f32 activations
-// (SURVEY.md §8d ENC_BYTES) and no separate normalisation pass exists.
+// Storage and accumulation are f32.  Every [rows,128] x [128,128] product runs on the bf16 matrix cores at f32 accuracy:
+// both operands are split exactly into three bf16 pieces (round-to-nearest) and the six significant piece products are
+// accumulated in f32 by v_mfma_f32_16x16x32_bf16 (k_gemm_x6 explains and cites the measurements).
+//   k_gemm_x6<PRO>  the GIN products (gcn:95-153): 4 producer waves (BatchNorm+ReLU / neighbour aggregation / first-layer
+//                   feature aggregation, split, bf16 planes to LDS) + 4 consumer waves (weights in registers, products,
+//                   16-byte stores, BatchNorm column sums of the output); one barrier per 4-tile step; HBM-bound
+//   k_gat3x         the three applications of the shared 2-node GAT layer of the machine actor (gat:82-159) in one launch
+//   k_headsx        scorer + local critic of an actor for 16 instances per workgroup, incl. BatchNorm/pool/gather of the
+//                   encoder output, masked softmax, action selection and m_fea1 of the selected task
+// Training-mode BatchNorm (batch statistics over all rows) couples all rows at every layer: each boundary
+// costs exactly one write + one read of the [rows,128] f32 activations (SURVEY.md §8d ENC_BYTES); the column sums are
+// accumulated by the producing kernel and applied by the consuming one — no separate normalisation pass exists.
+// The f32-instruction kernels of the earlier design (k_gemm16p, k_gat3, k_heads: v_mfma_f32_16x16x4_f32) are kept as the A/B
+// reference behind mtfjsp_encoder_set_product_mode(); k_gin_inst / k_gat_inst are the per-instance-BatchNorm (evaluation) path.
 //
 // "gcn:" = model/gcn_mlp.py, "gat:" = model/gat.py, "ac:" = model/actor_critic.py, "agent:" = algorithm/agent_func.py
 #include <hip/hip_runtime.h>
