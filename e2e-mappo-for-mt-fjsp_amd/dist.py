@@ -41,20 +41,35 @@ def all_gather_columns(x, group=None):
     return torch.cat(list(out.unbind(0)), dim=1)
 
 
-def all_gather_advantages(tensors, group=None):
+def all_gather_advantages(tensors, group=None, timed=False):
     """One collective for a list of [S,B_local] tensors (4 global + 4 local advantages and their 8 value targets in
-    the reference's update): packed into a single [K,S,B_local] buffer so that xGMI sees one large all-gather."""
+    the reference's update): packed into a single [K,S,B_local] buffer so that xGMI sees one large all-gather.
+    timed=True: also returns {"world", "bytes_per_rank", "ms"} of the collective (device events around it; ms is None
+    when no process group is active)."""
+    info = {"world": 1, "bytes_per_rank": 0, "ms": None}
     if not tensors:
-        return []
+        return ([], info) if timed else []
     packed = torch.stack([t.contiguous() for t in tensors], 0)
+    info["bytes_per_rank"] = packed.numel() * packed.element_size()
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return list(packed.unbind(0))
+        out = list(packed.unbind(0))
+        return (out, info) if timed else out
     world = dist.get_world_size(group)
+    info["world"] = world
     out = torch.empty((world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype, device=packed.device)
+    ev = None
+    if timed and packed.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     dist.all_gather_into_tensor(out, packed, group=group)
+    if ev is not None:
+        ev[1].record()
+        ev[1].synchronize()
+        info["ms"] = ev[0].elapsed_time(ev[1])
     out = out.view((world,) + tuple(packed.shape))
     full = torch.cat(list(out.unbind(0)), dim=2)          # [K,S,B_total]
-    return list(full.unbind(0))
+    res = list(full.unbind(0))
+    return (res, info) if timed else res
 
 
 def normalize_advantages_global(adv_local, group=None, eps=1e-5):

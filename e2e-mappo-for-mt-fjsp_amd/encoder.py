@@ -191,8 +191,9 @@ class ActorPair:
     def act(self, env, counter, task_idx, mach_idx, job_idx, jv_out=None, mv_out=None, job_logp=None, mach_logp=None,
             after_mfea1=None, force=None):
         """one joint decision for every instance; the optional outputs let a trajectory buffer receive action indices,
-        log-probabilities and critic values in place (no copies).  force = (task [B], machine [B]) int32 tensors: replay
-        these decisions instead of the selected ones (teacher forcing; the forwards and their outputs are unchanged)."""
+        log-probabilities and critic values in place (no copies).  force = (task [B], machine [B][, job [B]]) int32 tensors:
+        replay these decisions instead of the selected ones (teacher forcing; the forwards and their outputs are unchanged,
+        the recorded log-probabilities stay those of the actors' own selections)."""
         e = self.enc
         jl = job_logp if job_logp is not None else self.job_logp
         ml = mach_logp if mach_logp is not None else self.mch_logp
@@ -210,6 +211,8 @@ class ActorPair:
             e.sample(prob, self.greedy, self.seed, 2 * counter, job_idx, jl, env.candidate, task_idx)
         if force is not None:
             task_idx.copy_(force[0])
+            if len(force) > 2:
+                job_idx.copy_(force[2])
         if not fuse_mfea1:
             env.observe_mfea1(task_idx)                         # -> env.m_fea1, env.mmask (else: written by the heads kernel)
         if after_mfea1 is not None:
@@ -223,6 +226,17 @@ class ActorPair:
         if force is not None:
             mach_idx.copy_(force[1])
         self.have_hm = True
+
+    def terminal_values(self, env, prev_job_mask, jv_out, mv_out):
+        """The post-terminal forward pair of Run.py:455-475, to be called right after the env step that finished the
+        episode: job actor on the post-step observation and candidates with the PREVIOUS job mask (the new one masks every
+        job) and the last machine-graph embedding; machine actor on the last m_fea1 / machine mask, the post-step m_fea2
+        and that job forward's graph embedding.  Only the local critic values are kept: they are v_ of the terminal step
+        (replaybuffer.py:131-139), which every advantage of the episode depends on (ppo:473,523 have no (1-done) factor)."""
+        e = self.enc
+        hm = e.h_pooled_m if self.have_hm else None
+        _, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, prev_job_mask, hm, v_out=jv_out)
+        e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
 
     def timing_begin(self):
         self.enc.timing_begin()

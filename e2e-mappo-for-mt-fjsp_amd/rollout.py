@@ -26,24 +26,38 @@ def actor_available():
 class Rollout:
     def __init__(self, n_job, n_machine, n_edge, batch, device=0, policy="random", obs_dtype="f32",
                  instance_seed=0, rank=0, world=1, weights=None, w3_pool_episodes=32, greedy=False, seed=1234,
-                 buffer_episodes=5, gamma=0.99, lam=0.98, collect=True):
+                 buffer_episodes=5, gamma=0.99, lam=0.98, collect=True, instances=None, w3_episodes=None):
+        """instances: (t, p, tt, edge) host arrays for THIS shard; default = rows [rank*batch, (rank+1)*batch) of the
+        reference generator's `Instance_Dataset(samples=world*batch, seed=instance_seed)` (every
+        instance distinct).  w3_episodes: [n,B,3] reward weights to use episode by episode (tests); default = the
+        host `random` stream of env:1253-1259, drawn in pools of `w3_pool_episodes` episodes and refilled when used up."""
         self.J, self.M, self.E, self.B = n_job, n_machine, n_edge, batch
         self.T = n_job * n_machine
         self.policy = policy
         self.rank, self.world = rank, world
         self.env = DeviceBatchEnv(n_job, n_machine, n_edge, batch, obs_dtype=obs_dtype, device=device)
         dev = self.env.device
-        # synthetic instances (generator semantics of the reference); 256 distinct ones tiled over the shard
-        base = min(batch, 256)
-        t, p, tt, edge = generate_instances(base, n_job, n_machine, n_edge, seed=instance_seed)
-        rep = (batch + base - 1) // base
-        t, p, tt, edge = [np.concatenate([x] * rep)[:batch] for x in (t, p, tt, edge)]
+        if instances is None:
+            t, p, tt, edge = generate_instances(world * batch, n_job, n_machine, n_edge, seed=instance_seed)
+            lo, hi = rank * batch, (rank + 1) * batch
+            instances = (t[lo:hi], p[lo:hi], tt[lo:hi], edge[lo:hi])
+            self.instances_desc = (f"Instance_Dataset(samples={world * batch}, n_job={n_job}, n_machine={n_machine}, n_edge={n_edge}, "
+                                   f"seed={instance_seed}) rows [{lo},{hi}) — all distinct")
+        else:
+            self.instances_desc = "caller-provided instances"
+        t, p, tt, edge = instances
         self.env.load_instances(t, p, tt, edge=edge)
         self.env.scaler_init()
-        # reward weights: host `random` stream (env:1253-1259), pre-drawn for a pool of episodes and kept in HBM
-        rng = _random.Random(1000 + rank)
-        self.w3_pool = torch.as_tensor(np.stack([random_weights(batch, rng=rng) for _ in range(w3_pool_episodes)]),
-                                       dtype=torch.float64, device=dev)
+        # reward weights: host `random` stream (env:1253-1259; 3 draws per instance and episode in instance order),
+        # pre-drawn for a pool of episodes, kept in HBM, refilled from the same stream when the pool is used up
+        self._w3_rng = _random.Random(1000 + rank)
+        self._w3_pool_n = w3_pool_episodes
+        self._w3_fixed = w3_episodes is not None
+        if self._w3_fixed:
+            self.w3_pool = torch.as_tensor(np.asarray(w3_episodes), dtype=torch.float64, device=dev).contiguous()
+        else:
+            self.w3_pool = torch.empty(w3_pool_episodes, batch, 3, dtype=torch.float64, device=dev)
+            self._refill_w3()
         self.task = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.mach = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.job = torch.zeros(batch, dtype=torch.int32, device=dev)
@@ -58,10 +72,15 @@ class Rollout:
         self.collect = bool(collect) and policy == "actor"
         self.full = self.collect and collect == "full"
         self.S = buffer_episodes * self.T
+        self.buffer_episodes = buffer_episodes
         self.gamma, self.lam = gamma, lam
         self.buf_pos = 0
         self.last_adv = None
+        self.last_gather = None
+        self.n_handoffs = 0
         self.traj = None
+        # local critic values: T+1 slots per episode — slot t<T is the value at act time of step t, slot T the value of
+        # the terminal state from the post-terminal forward pair (run:455-475); v_ of step t is slot t+1 (run:451-454)
         if self.full:
             from .trajectory import TrajectoryBuffer
             self.traj = TrajectoryBuffer({"n_job": n_job, "n_machine": n_machine, "buffer_size": buffer_episodes,
@@ -73,8 +92,10 @@ class Rollout:
             f = dict(dtype=torch.float32, device=dev)
             self.buf_r = torch.zeros(self.S, 4, batch, **f)          # mk, idle, pt, tt (scaled, pe:255-262 order)
             self.buf_done = torch.zeros(self.S, batch, **f)
-            self.buf_jv = torch.zeros(self.S + 1, batch, 2, **f)     # job critic: mk, idle   (ac:293)
-            self.buf_mv = torch.zeros(self.S + 1, batch, 2, **f)     # machine critic: pt, tt (ac:495)
+            self.buf_jv = torch.zeros(buffer_episodes, self.T + 1, batch, 2, **f)     # job critic: mk, idle   (ac:293)
+            self.buf_mv = torch.zeros(buffer_episodes, self.T + 1, batch, 2, **f)     # machine critic: pt, tt (ac:495)
+        if self.collect:
+            self.prev_job_mask = torch.zeros(batch, n_job, dtype=torch.uint8, device=dev)
         self.actor = None
         if policy == "actor":
             from . import encoder
@@ -93,37 +114,57 @@ class Rollout:
         small = self.T <= 64 and self.M * self.M <= 64 and self.J <= 64 and not os.environ.get("MTFJSP_ENV_LDS")
         return "k_env_reg" if small else "k_env_step"
 
-    def step(self):
+    def _refill_w3(self):
+        self.w3_pool.copy_(torch.as_tensor(np.stack([random_weights(self.B, rng=self._w3_rng) for _ in range(self._w3_pool_n)])))
+
+    def _episode_w3(self):
+        n = self.w3_pool.shape[0]
+        if not self._w3_fixed and self.episode > 0 and self.episode % n == 0:
+            self._refill_w3()                                              # fresh draws for every episode (env:1253-1259)
+        return self.w3_pool[self.episode % n]
+
+    def step(self, force=None):
+        """one batched decision step.  force = (task [B], machine [B]) int32 device tensors: apply these decisions instead of
+        the sampled ones (teacher forcing for the parity tests; the forwards and everything recorded are unchanged)."""
         env = self.env
         if self.t_in_ep == 0:
+            w3 = self._episode_w3()
             env.scaler_reset_returns()                                     # run:283-284
-            env.reset(self.w3_pool[self.episode % self.w3_pool.shape[0]])  # pe:87 / run:229
+            env.reset(w3)                                                  # pe:87 / run:229
             if self.actor is not None:
                 self.actor.begin_episode()
             if self.full:
-                self.traj.begin_episode(self.w3_pool[self.episode % self.w3_pool.shape[0]])
+                self.traj.begin_episode(w3)
+        last = self.t_in_ep == self.T - 1
         if self.full:
             tb = self.traj
             sl = tb.slot()
             tb.snapshot(env, "pre")
             self.actor.act(env, self.nsteps, self.task, sl["mach_idx"], sl["job_idx"], sl["job_v"], sl["mach_v"],
-                           job_logp=sl["job_logp"], mach_logp=sl["mach_logp"], after_mfea1=tb.after_decision)
+                           job_logp=sl["job_logp"], mach_logp=sl["mach_logp"], after_mfea1=tb.after_decision, force=force)
             env.step_record(self.task, sl["mach_idx"], sl["r4"], sl["done"])
+            if last:           # value of the terminal state (run:455-475) with the mask the last decision was taken under
+                jv_t, mv_t = tb.terminal_slot()
+                self.actor.terminal_values(env, tb.mask_operation[tb.count_operation], jv_t, mv_t)
             tb.after_step(env)
             self.buf_pos += 1
             if self.buf_pos == self.S:
                 self.finish_buffer()
                 tb.reset()
         elif self.collect:
-            k = self.buf_pos                  # critic values and rewards land directly in the trajectory slots (no copies)
-            self.actor.act(env, self.nsteps, self.task, self.mach, self.job, self.buf_jv[k], self.buf_mv[k])
-            env.step_record(self.task, self.mach, self.buf_r[k], self.buf_done[k])
+            e, t = divmod(self.buf_pos, self.T)   # critic values and rewards land directly in the trajectory slots (no copies)
+            if last:
+                self.prev_job_mask.copy_(env.job_mask)
+            self.actor.act(env, self.nsteps, self.task, self.mach, self.job, self.buf_jv[e, t], self.buf_mv[e, t], force=force)
+            env.step_record(self.task, self.mach, self.buf_r[self.buf_pos], self.buf_done[self.buf_pos])
+            if last:
+                self.actor.terminal_values(env, self.prev_job_mask, self.buf_jv[e, self.T], self.buf_mv[e, self.T])
             self.buf_pos += 1
             if self.buf_pos == self.S:
                 self.finish_buffer()
         else:
             if self.actor is not None:
-                self.actor.act(env, self.nsteps, self.task, self.mach, self.job)
+                self.actor.act(env, self.nsteps, self.task, self.mach, self.job, force=force)
             else:
                 env.random_actions(self.seed, self.nsteps, self.task, self.mach, self.job)
             env.step(self.task, self.mach)
@@ -137,24 +178,18 @@ class Rollout:
         """Rollout -> update hand-off (ppo:438-489): local-critic GAE per reward channel on this shard, then the one
         collective of the data path — all-gather of the per-shard advantages (RCCL over xGMI when world > 1) for the
         GLOBAL normalisation (adv - mean) / (std + 1e-5) — leaving normalised advantages + value targets on device."""
-        from . import dist as D
-        S = self.S
-        # next-state values: v_ of step s is v of step s+1 (run:451-454); within an episode's last step the reference
-        # runs one extra forward (run:455-475) — its (1-done) factor zeroes that term in the GAE recursion anyway
-        jv, mv = self.buf_jv[:S], self.buf_mv[:S]
-        jv_, mv_ = self.buf_jv[1:S + 1], self.buf_mv[1:S + 1]
-        r = self.buf_r
-        pairs = [(r[:, 0], jv[..., 0], jv_[..., 0]), (r[:, 2], mv[..., 0], mv_[..., 0]),
-                 (r[:, 3], mv[..., 1], mv_[..., 1]), (r[:, 1], jv[..., 1], jv_[..., 1])]        # mk, pt, tt, it (ppo:441-443)
-        advs = [self.env.gae(rr, v, v_, self.buf_done, self.gamma, self.lam) for rr, v, v_ in pairs]     # HIP reverse scan
-        targets = [a + p[1] for a, p in zip(advs, pairs)]
-        full = D.all_gather_advantages(advs)                      # [S,B_total] each
-        norm = []
-        lo = self.rank * self.B
-        for a_full, a_loc in zip(full, advs):
-            mean, std = a_full.mean(), a_full.std()
-            norm.append((a_loc - mean) / (std + 1e-5))
+        from . import advantages as A
+        S, T, B = self.S, self.T, self.B
+        # v of step t = slot t, v_ of step t = slot t+1 of its episode; the terminal step's v_ is the post-terminal forward
+        # (run:451-475).  The deltas carry NO (1-done) factor (ppo:473,523): the terminal v_ enters every advantage of the
+        # episode; (1-done) only stops the carried gae at episode boundaries.
+        jv, mv = self.buf_jv[:, :T].reshape(S, B, 2), self.buf_mv[:, :T].reshape(S, B, 2)
+        jv_, mv_ = self.buf_jv[:, 1:].reshape(S, B, 2), self.buf_mv[:, 1:].reshape(S, B, 2)
+        norm, targets, raw, self.last_gather = A.local_advantages(self.env, self.buf_r, jv, jv_, mv, mv_, self.buf_done,
+                                                                  self.gamma, self.lam, timed=True)
         self.last_adv = (norm, targets)
+        self.last_raw_adv = raw
+        self.n_handoffs += 1
         self.buf_pos = 0
 
     def timing_begin(self):

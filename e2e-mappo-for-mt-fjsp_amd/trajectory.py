@@ -89,10 +89,12 @@ class TrajectoryBuffer:
     """`ReplayBuffer(args)` of the reference (replaybuffer.py:18-80) on the device.  `args` needs n_job, n_machine,
     buffer_size, env_batch, gcn_input_dim (12)."""
 
-    def __init__(self, args, device="cuda", obs_dtype=torch.float32, alias_v_next=False):
-        """alias_v_next: job_v_/machine_v_ are the one-step-shifted views of job_v/machine_v (v_ of step s = v of step
-        s+1, run:451-454) instead of separate arrays filled by store_v_next(); the only entries that differ from the
-        reference's are those of terminal steps, which every consumer multiplies by (1 - done) (ppo:444-457)."""
+    def __init__(self, args, device="cuda", obs_dtype=torch.float64, alias_v_next=False):
+        """alias_v_next (the device rollout's layout): the local critic values live in T+1 slots per episode — slot t < T is
+        the value at act time of step t, slot T the value of the terminal state written by the post-terminal forward pair
+        (run:455-475, `terminal_slot()`); job_v / machine_v are slots 0..T-1 and job_v_ / machine_v_ slots 1..T of every
+        episode (v_ of step t = v of step t+1, run:451-454), exactly what the reference's store_v_next sequence produces.
+        False: separate arrays filled through the reference's store_operation()/store_v_next() calls."""
         self.J, self.M = int(args["n_job"]), int(args["n_machine"])
         self.total_task = self.J * self.M
         self.total_step = int(args["buffer_size"]) * self.total_task
@@ -126,9 +128,8 @@ class TrajectoryBuffer:
         self.random_weight = z(S, B, 3)
         self.alias_v_next = alias_v_next
         if alias_v_next:
-            self._jv, self._mv = z(S + 1, B, 2), z(S + 1, B, 2)
-            self.job_v, self.machine_v = self._jv[:S], self._mv[:S]
-            self.job_v_, self.machine_v_ = self._jv[1:], self._mv[1:]
+            E = int(args["buffer_size"])
+            self._jv, self._mv = z(E, T + 1, B, 2), z(E, T + 1, B, 2)
         else:
             self.job_v, self.machine_v = z(S, B, 2), z(S, B, 2)
             self.job_v_, self.machine_v_ = z(S, B, 2), z(S, B, 2)
@@ -202,8 +203,15 @@ class TrajectoryBuffer:
                 adj_, self.tasks_fea_.to(f), self.candidate_.to(f), self.mask_operation_, self.r_operation,
                 self.done_operation,
                 self.machine_fea2.to(f), self.a.long(), self.a_logprob, self.machine_fea2_.to(f), self.mask_machine_,
-                self.mk, self.pt, self.tt, self.it, self.machine_fea1.to(f), self.random_weight, self.job_v,
-                self.machine_v, self.job_v_, self.machine_v_)
+                self.mk, self.pt, self.tt, self.it, self.machine_fea1.to(f), self.random_weight) + self.local_values()
+
+    def local_values(self):
+        """-> (job_v, machine_v, job_v_, machine_v_), each [S,B,2] (entries 23-26 of the tuple)"""
+        if not self.alias_v_next:
+            return (self.job_v, self.machine_v, self.job_v_, self.machine_v_)
+        S, B, T = self.total_step, self.B, self.total_task
+        return (self._jv[:, :T].reshape(S, B, 2), self._mv[:, :T].reshape(S, B, 2),
+                self._jv[:, 1:].reshape(S, B, 2), self._mv[:, 1:].reshape(S, B, 2))
 
     def reset(self):
         """Run.py resets the counters after every update (the arrays are overwritten, never cleared)."""
@@ -218,10 +226,21 @@ class TrajectoryBuffer:
         return sum(v.numel() * v.element_size() for v in vars(self).values() if torch.is_tensor(v) and v._base is None)
 
     # ------------------------------------------------------------------ zero-copy path of the device rollout
+    def _check_env(self, env):
+        """the snapshot kernel copies byte counts derived from the ENVIRONMENT's shape and observation dtype: a mismatching
+        buffer would be overrun"""
+        if (env.B, env.J, env.M) != (self.B, self.J, self.M):
+            raise ValueError(f"trajectory buffer is for B={self.B} J={self.J} M={self.M}, the environment has B={env.B} J={env.J} M={env.M}")
+        if env.obs_f32 != (self.obs_dtype == torch.float32):
+            raise ValueError("trajectory buffer and environment disagree on the observation dtype (f32 vs f64)")
+        if self.count_operation >= self.total_step:
+            raise IndexError("trajectory buffer is full: call reset() after the update")
+
     def snapshot(self, env, which):
         """copy the environment's CURRENT observation into slot `count_operation`: which='pre' (state the decision is
         taken in: adj, fea, candidate, mask, mch_fea2) or 'post' (adj_, fea_, candidate_, mask_, mch_fea2_).
         One kernel launch (mtfjsp_snapshot_obs)."""
+        self._check_env(env)
         k = self.count_operation
         if which == "pre":
             dst = (self.tasks_fea[k], self.ell_col[k], self.ell_val[k], self.machine_fea2[k], self.candidate[k],
@@ -237,9 +256,20 @@ class TrajectoryBuffer:
         """views of the current slot the rollout kernels write straight into (no copies): job index / log-prob, machine
         index / log-prob (int32 / f32 [B]), critic values [B,2] x 2, scaled reward components [4,B], done [B]"""
         k = self.count_operation
+        if self.alias_v_next:
+            e, t = divmod(k, self.total_task)
+            jv, mv = self._jv[e, t], self._mv[e, t]
+        else:
+            jv, mv = self.job_v[k], self.machine_v[k]
         return dict(job_idx=self.a_operation[k], job_logp=self.a_logprob_operation[k], mach_idx=self.a[k],
-                    mach_logp=self.a_logprob[k], job_v=self.job_v[k], mach_v=self.machine_v[k], r4=self.r4[k],
-                    done=self.done_operation[k])
+                    mach_logp=self.a_logprob[k], job_v=jv, mach_v=mv, r4=self.r4[k], done=self.done_operation[k])
+
+    def terminal_slot(self):
+        """(job_v_, machine_v_) [B,2] views of the CURRENT slot's episode that receive the value of the terminal state from
+        the post-terminal forward pair (run:455-475); alias_v_next layout only"""
+        assert self.alias_v_next
+        e = self.count_operation // self.total_task
+        return self._jv[e, self.total_task], self._mv[e, self.total_task]
 
     def begin_episode(self, w3):
         """the episode's reward weights are the same for all of its T slots (Run.py:477-478)"""
@@ -248,12 +278,14 @@ class TrajectoryBuffer:
 
     def after_decision(self, env):
         """m_fea1 and the machine mask of the chosen task (pe:152-214), produced between the two actor forwards"""
+        self._check_env(env)
         k = self.count_operation
         self.machine_fea1[k].copy_(env.m_fea1.reshape(self.B, self.M, 6))
         self.mask_machine_[k].copy_(env.mmask.reshape(self.B, 1, self.M))
 
     def after_step(self, env):
         """scalar reward (info[:,0], pe:255-262) and the post-decision observation; advances the slot"""
+        self._check_env(env)
         k = self.count_operation
         self.r_operation[k].copy_(env.info[:, 0])
         self.snapshot(env, "post")
