@@ -100,12 +100,14 @@ def job_actor_forward(w, tfea, ell_col, ell_val, cand, mask, h_m_prev, B, T):
                 greedy_logp=torch.log(prob[torch.arange(B), idx]).numpy())
 
 
-def machine_actor_forward(w, mfea1, mfea2, h_pooled_o, mmask, B, M):
+def machine_actor_forward(w, mfea1, mfea2, h_pooled_o, mmask, B, M, dtype=torch.float32):
     """E4: Machine_Actor_JointAction_selfGAT_selfCritic.forward (ac:359-498) with the single shared
-    GATLayer (gat:82-159) applied three times on the fixed 2-node graph [[1,1],[0,1]]."""
-    w = {k: torch.as_tensor(v) for k, v in w.items()}
-    f1 = torch.as_tensor(np.asarray(mfea1), dtype=torch.float64).float().reshape(B * M, 6)
-    f2 = torch.as_tensor(np.asarray(mfea2), dtype=torch.float64).float().reshape(B * M, 8)
+    GATLayer (gat:82-159) applied three times on the fixed 2-node graph [[1,1],[0,1]].
+    dtype=torch.float64: the same network evaluated in binary64 on the f32-rounded inputs and weights — the yardstick that
+    tells the round-off of the reference's own f32 evaluation from a kernel's (tests at full batch sizes)."""
+    w = {k: torch.as_tensor(v).to(dtype) for k, v in w.items()}
+    f1 = torch.as_tensor(np.asarray(mfea1), dtype=torch.float64).float().reshape(B * M, 6).to(dtype)
+    f2 = torch.as_tensor(np.asarray(mfea2), dtype=torch.float64).float().reshape(B * M, 8).to(dtype)
     n0 = f1 @ w["m_fea_1_fcl.weight"].t()
     n1 = f2 @ w["m_fea_2_fcl.weight"].t()
     W = w["gat_layer.W"]
@@ -124,7 +126,7 @@ def machine_actor_forward(w, mfea1, mfea2, h_pooled_o, mmask, B, M):
             n1 = torch.nn.functional.elu(n1)
     node = _bn((n0 + n1) / 2, w["bn.weight"], w["bn.bias"]).reshape(B, M, Hd)    # ac:420-434
     h_pooled = node.mean(1)
-    ho = torch.as_tensor(np.asarray(h_pooled_o), dtype=torch.float32)
+    ho = torch.as_tensor(np.asarray(h_pooled_o), dtype=torch.float32).to(dtype)
     cat = torch.cat([node, h_pooled.unsqueeze(1).expand(B, M, Hd), ho.unsqueeze(1).expand(B, M, Hd)], -1)
     score = _mlp_tanh(cat, w, "m_policy").squeeze(-1) * 10
     score = score.masked_fill(torch.as_tensor(np.asarray(mmask)).reshape(B, M).bool(), float("-inf"))

@@ -245,10 +245,11 @@ def run_trace(ins, n_job, n_machine, n_edge, B, episodes, policy, left_shift=Tru
 
 
 # ------------------------------------------------------------------ encoder vectors
-def encoder_vectors(ins, weights, B=16, steps=(0, 17), seed=0):
+def encoder_vectors(ins, weights, B=16, steps=(0, 17), seed=0, size=(6, 6, 2), keep_h_nodes=True):
     """Job-actor / machine-actor forwards of the reference modules on observations
-    produced by the reference env (greedy decoding so no sampling RNG is involved)."""
-    J, M, E = 6, 6, 2
+    produced by the reference env (greedy decoding so no sampling RNG is involved).
+    The modules are size-generic (gcn_mlp.py:109-197, actor_critic.py:104-296,359-498): `size` = (J, M, E)."""
+    J, M, E = size
     T = J * M
     cfg = default_config(J, M, E, B)
     ppo = quiet(PPOAlgorithm, cfg, False)
@@ -403,6 +404,10 @@ def main():
     if want("enc"):
         save("encoder_j6m6e2_top1", encoder_vectors(ev, "top1"))
         save("encoder_j6m6e2_rand", encoder_vectors([x[50:] for x in ev], "rand", B=8, steps=(0, 9), seed=123))
+    if want("enc_big"):
+        # BASELINE configs 2 and 4 sizes: seeded random weights with perturbed BatchNorm affine, steps 0 and T/2
+        save("encoder_j10m10e2_rand", encoder_vectors(ref_generate(4, 10, 10, 2, 14), "rand", B=4, steps=(0, 50), seed=124, size=(10, 10, 2)))
+        save("encoder_j20m20e4_rand", encoder_vectors(ref_generate(2, 20, 20, 4, 15), "rand", B=2, steps=(0, 200), seed=125, size=(20, 20, 4)))
     if speed:
         import platform
         with open(os.path.join(out_dir, "reference_cpu_speed.txt"), "a") as f:

@@ -20,7 +20,7 @@ def _t(x, dt=None):
     return t.to(dt) if dt is not None else t
 
 
-@pytest.mark.parametrize("name", ["encoder_j6m6e2_top1", "encoder_j6m6e2_rand"])
+@pytest.mark.parametrize("name", ["encoder_j6m6e2_top1", "encoder_j6m6e2_rand", "encoder_j10m10e2_rand", "encoder_j20m20e4_rand"])
 @pytest.mark.parametrize("obs", ["f64", "f32"])
 def test_actor_forwards_match_reference_outputs(name, obs):
     import torch

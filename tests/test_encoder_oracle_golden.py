@@ -11,7 +11,7 @@ from oracle import encoder_oracle as eo
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name", ["encoder_j6m6e2_top1", "encoder_j6m6e2_rand"])
+@pytest.mark.parametrize("name", ["encoder_j6m6e2_top1", "encoder_j6m6e2_rand", "encoder_j10m10e2_rand", "encoder_j20m20e4_rand"])
 def test_encoder_oracle_matches_reference_modules(name):
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
     J, M, E, B = [int(x) for x in g["meta"]]
