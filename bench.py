@@ -76,40 +76,57 @@ def env_kernel_large_batch(J, M, E, device, B=262144, episodes=2):
             "avg_launch_us": sec * 1e6, "launches": n, "env_steps_per_s": B / sec}
 
 
-def cpu_baseline(J, M, E, seconds_target=12.0):
-    """Time the CPU oracle port (oracle/mtfjsp_oracle.c, scalar C, 1 core) on a bounded sample of the same workload."""
-    from oracle.env_oracle import OracleBatch
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def cpu_baseline(J, M, E, seconds_per_leg=6.0):
+    """The CPU oracle port (oracle/mtfjsp_oracle.c) timed on the host cores, SURVEY §8d leg (ii): per env and step what the
+    reference's batched step does per env (env.step + RewardScaling + candidate/job-mask update + observation), random valid
+    actions chosen in C.  Three legs on bounded samples of the same generator stream as the GPU workload: one thread and
+    all cores (OpenMP over instances) at B = 1024, and BASELINE config 0's batch (B = 16) on one thread.  Environment only:
+    the GPU `value` additionally contains both actor forwards, sampling and m_fea1 — compare it with `roofline_env_step`'s
+    env-steps/s for like with like."""
+    from oracle.env_oracle import OracleBatch, max_threads
     from importlib import import_module
     inst = import_module("e2e-mappo-for-mt-fjsp_amd.instances")
-    B, T = 256, J * M
+    T = J * M
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    nthreads = max(1, min(ncores, max_threads()))
+    B = 1024
     t, p, tt, edge = inst.generate_instances(B, J, M, E, seed=0)
-    orc = OracleBatch(t, p, tt, edge)
-    orc.scaler_init()
-    rs = np.random.RandomState(0)
-    feas = t >= 0
     w3 = np.full((B, 3), 1.0 / 3)
-    n = 0
-    t_step = 0.0
-    t_start = time.perf_counter()
-    episodes = 0
-    while time.perf_counter() - t_start < seconds_target:
-        orc.reset(w3)
-        cand, mask = orc.job_mask_state()
-        for s in range(T):
-            # uniform random valid action (host side, not timed)
-            job = np.array([rs.choice(np.flatnonzero(mask[b] == 0)) for b in range(B)], np.int32)
-            task = cand[np.arange(B), job].astype(np.int32)
-            mach = np.array([rs.choice(np.flatnonzero(feas[b, task[b]])) for b in range(B)], np.int32)
-            t0 = time.perf_counter()
-            orc.step(task, mach)
-            cand, mask = orc.job_mask_update(job)
-            orc.observe(dense=False)
-            t_step += time.perf_counter() - t0
-            n += B
-        episodes += 1
-    return {"value": n / t_step, "unit": "env-steps/s", "cores": 1, "kind": "port",
-            "sample": f"J{J}M{M}E{E}, B=256, {episodes} episodes ({n} env-steps), step+reward scaling+job mask+observe (ELL adj), "
-                      f"random valid actions; oracle/mtfjsp_oracle.c -O2 scalar"}
+
+    def leg(batch, threads):
+        orc = OracleBatch(t[:batch], p[:batch], tt[:batch], edge[:batch])
+        orc.scaler_init()
+        n, sec, _ = orc.bench(1, threads, w3[:batch])                                  # calibrate (and warm the caches)
+        episodes = max(1, int(seconds_per_leg / max(sec, 1e-6)))
+        n, sec, sec_reset = orc.bench(episodes, threads, w3[:batch])
+        return {"env_steps_per_s": n / sec, "env_steps_per_s_incl_resets": n / sec_reset, "threads": threads, "batch": batch,
+                "episodes": episodes, "env_steps": n}
+
+    one = leg(B, 1)
+    allc = leg(B, nthreads) if nthreads > 1 else dict(one)
+    c1 = leg(16, 1)
+    best = max(one, allc, key=lambda d: d["env_steps_per_s"])
+    return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
+            "cpu_model": cpu_model(), "nproc": ncores,
+            "single_thread": one, "all_cores": allc, "config0_B16_single_thread": c1,
+            "sample": f"J{J}M{M}E{E}: first {B} instances of Instance_Dataset(seed=0), {best['episodes']} episodes ({best['env_steps']} env-steps) per leg, "
+                      "ENVIRONMENT ONLY (step + reward scaling + job mask + ELL observation per env and step, random valid actions; "
+                      "no actor forwards) — oracle/mtfjsp_oracle.c -O2, OpenMP over instances; the reference's own Python path "
+                      "measured in the build container: tests/golden/reference_cpu_speed.txt (about 330 env-steps/s, 1 core)"}
 
 
 def main():
@@ -124,8 +141,10 @@ def main():
     ap.add_argument("--trajectory", default="advantage", choices=["advantage", "full"],
                     help="what the rollout records per step: the advantage inputs (rewards, dones, critic values) or every "
                          "field of the reference's ReplayBuffer (device-resident TrajectoryBuffer, SURVEY 8f N2)")
+    ap.add_argument("--min-seconds", type=float, default=0.5,
+                    help="the timed region repeats blocks of exactly --steps steps until it has lasted at least this long")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-env-sweep", action="store_true", help="skip the chip-filling step-kernel measurement (N=1 only)")
+    ap.add_argument("--no-env-sweep", action="store_true", help="skip the step-kernel batch sweep (N=1 only)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -151,8 +170,9 @@ def main():
     policy = args.policy
     if policy == "auto":
         policy = "actor" if rollout_mod.actor_available() else "random"
+    # Instance_Dataset(samples = world*B, seed = 0), shard `rank` owns rows [rank*B, (rank+1)*B) — all distinct
     ro = rollout_mod.Rollout(J, M, E, B, device=local_rank, policy=policy, obs_dtype=args.obs,
-                             instance_seed=rank, rank=rank, world=world, collect="full" if args.trajectory == "full" else True)
+                             instance_seed=0, rank=rank, world=world, collect="full" if args.trajectory == "full" else True)
 
     def sync():
         torch.cuda.synchronize()
@@ -160,67 +180,108 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def agree_max(x):
+        if dist is None:
+            return x
+        tmax = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
     for _ in range(args.warmup):
         ro.step()
+    sync()
+    # timed region: a whole number of blocks of --steps steps, bracketed by barrier + synchronize on both sides, long enough to
+    # last --min-seconds (the driver's --steps 20 is 7 ms of work: too short to time).  The block count comes from one untimed
+    # calibration block and is agreed across ranks, so every rank times the same number of steps.
+    handoffs0 = ro.n_handoffs
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ro.step()
     sync()
-    elapsed = time.perf_counter() - t0
-    # second pass of the same steps with HIP events recorded on the launch stream around every kernel launch
+    t_block = agree_max(time.perf_counter() - t0)
+    blocks = max(1, min(100000, int(np.ceil(args.min_seconds / max(t_block, 1e-6)))))
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(blocks * args.steps):
+        ro.step()
+    sync()
+    elapsed = agree_max(time.perf_counter() - t0)
+    steps_timed = blocks * args.steps
+    handoffs = ro.n_handoffs - handoffs0
+    # the advantage all-gather of the rollout -> update hand-off (the only collective of the data path) fires once per
+    # S = buffer_episodes*T steps; when the timed region was shorter than that (N > 1), run the steps up to the next hand-off
+    # now so that the RCCL exchange is exercised and measured (reported separately, not part of `value`)
+    gather = ro.last_gather
+    if world > 1 and handoffs == 0 and ro.collect:
+        while ro.n_handoffs == handoffs0:
+            ro.step()
+        sync()
+        gather = ro.last_gather
+    # second pass with HIP events recorded on the launch stream around every kernel launch
     # (kept out of the timed region above: two event records per launch would perturb `value`)
-    prof_steps = min(args.steps, 4 * T)
+    prof_steps = min(max(args.steps, T), 4 * T)
     ro.timing_begin()
     for _ in range(prof_steps):
         ro.step()
     ktimes = ro.timing_end()
     sync()
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
     ro.check_finished_cleanly()
 
     if rank == 0:
-        value = world * B * args.steps / elapsed
+        value = world * B * steps_timed / elapsed
         # dominant kernel by measured device time
         dom = max(ktimes, key=lambda k: ktimes[k]["ms_total"])
         kd = ktimes[dom]
         avg_s = kd["ms_total"] / max(kd["launches"], 1) * 1e-3
+        headline = (B, J, M) == (4096, 6, 6)
+        traffic_note = ("profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at B=4096 J6M6E2, "
+                        "FETCH_SIZE x2 gfx950 correction; not re-measured inside this run)")
+
+        def env_roof(sec, name):
+            alg = B * env_bytes(J, M)
+            tr = pmc_traffic("env_step") if headline else None
+            d = {"kernel": name, "bound": "hbm", "achieved": alg / sec / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                 "frac": alg / sec / 1e9 / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": alg / sec / 1e9 / HBM_MEASURED_GBPS,
+                 "traffic": tr, "traffic_source": traffic_note if tr is not None else None,
+                 "avg_launch_us": sec * 1e6, "algorithmic_bytes_per_launch": alg,
+                 "algorithmic_bytes_per_env_step": env_bytes(J, M), "env_steps_per_s": B / sec}
+            if tr is not None:      # the same launch priced on the bytes the incremental kernel really moves (PMC)
+                d["achieved_on_pmc_traffic_GBps"] = tr / sec / 1e9
+                d["frac_of_measured_copy_bw_on_pmc_traffic"] = tr / sec / 1e9 / HBM_MEASURED_GBPS
+            return d
+
         if dom == "env_step":
-            achieved = B * env_bytes(J, M) / avg_s / 1e9
-            roof = {"kernel": ro.env_kernel_name() + " (fused state transition + rewards + scaler + incremental observation + job mask)",
-                    "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": achieved / HBM_MEASURED_GBPS,
-                    "traffic": pmc_traffic("env_step") if (B, J, M) == (4096, 6, 6) else None,
-                    "avg_launch_us": avg_s * 1e6, "launches": kd["launches"],
-                    "algorithmic_bytes_per_launch": B * env_bytes(J, M)}
+            roof = env_roof(avg_s, ro.env_kernel_name() + " (fused state transition + rewards + scaler + incremental observation + job mask)")
+            roof["launches"] = kd["launches"]
         else:
             roof = ro.roofline(dom, kd)
-            if (B, J, M) == (4096, 6, 6):
+            if headline:
                 roof["traffic"] = pmc_traffic(dom)
+                roof["traffic_source"] = traffic_note if roof["traffic"] is not None else None
         # the north-star kernel is always reported as well (extra key)
         ke = ktimes["env_step"]
-        es = ke["ms_total"] / max(ke["launches"], 1) * 1e-3
-        roof_env = {"kernel": ro.env_kernel_name(), "bound": "hbm", "achieved": B * env_bytes(J, M) / es / 1e9, "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": B * env_bytes(J, M) / es / 1e9 / HBM_PEAK_GBPS,
-                    "frac_of_measured_copy_bw": B * env_bytes(J, M) / es / 1e9 / HBM_MEASURED_GBPS,
-                    "traffic": pmc_traffic("env_step") if (B, J, M) == (4096, 6, 6) else None, "avg_launch_us": es * 1e6}
+        roof_env = env_roof(ke["ms_total"] / max(ke["launches"], 1) * 1e-3, ro.env_kernel_name())
         out = {
             "metric": "env-steps/sec (batched J%dM%dE%d)" % (J, M, E), "value": value, "unit": "env-steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / steps_timed * 1e3,
+            "steps_timed": steps_timed, "timed_blocks": blocks, "timed_seconds": elapsed,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (environment) / f32 (encoder: f32 storage and accumulation; GIN products as exact 3-way bf16 splits on the matrix cores, f32-accurate)", "data": "synthetic",
-            "config": {"workload": f"J{J}M{M}E{E}, {B} parallel instances per GPU, {ro.describe()}",
+            "config": {"workload": f"J{J}M{M}E{E}, {B} parallel instances per GPU ({ro.instances_desc}), {ro.describe()}",
                        "instances_per_gpu": B, "obs_dtype": args.obs, "policy": policy, "trajectory": args.trajectory,
                        "parallelism": f"instances sharded over {world} GPU(s); env/encoder path has no collective; one all-gather of advantages per {ro.S}-step buffer (RCCL when world>1)"},
             "roofline": roof, "roofline_env_step": roof_env,
+            "handoff": {"buffer_steps": ro.S, "handoffs_in_timed_region": handoffs, "world": (gather or {}).get("world"),
+                        "allgather_bytes_per_rank": (gather or {}).get("bytes_per_rank"), "allgather_ms": (gather or {}).get("ms"),
+                        "what": "local-critic GAE (4 reverse scans) + ONE packed all-gather of the 4 advantage tensors [4,S,B] f32 + global normalisation"},
             "kernel_times_ms": {k: v for k, v in ktimes.items()}, "kernel_times_steps": prof_steps,
         }
         if world == 1 and not args.no_env_sweep:
             del ro
             torch.cuda.empty_cache()
-            out["roofline_env_step_large_batch"] = env_kernel_large_batch(J, M, E, local_rank)
+            sweep = [env_kernel_large_batch(J, M, E, local_rank, B=b, episodes=1 if b >= 65536 else 2) for b in (4096, 16384, 65536, 262144)]
+            out["roofline_env_step_batch_sweep"] = sweep
+            out["roofline_env_step_large_batch"] = sweep[-1]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(J, M, E)
         print(json.dumps(out), flush=True)

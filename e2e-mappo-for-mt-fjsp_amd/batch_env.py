@@ -128,6 +128,14 @@ class DeviceBatchEnv:
             assert w3.shape == (self.B, 3)
             capi.check(self.L.mtfjsp_reset_host(self.h, w3.ctypes.data), self.h)
 
+    def draw_reward_weights(self, seed, episode, out=None):
+        """reward weights of one episode drawn on the device (env:1253-1259 type "01", Philox keyed by (seed, episode, b)) -> [B,3] f64"""
+        if out is None:
+            out = torch.empty(self.B, 3, dtype=torch.float64, device=self.device)
+        assert out.is_cuda and out.dtype == torch.float64 and out.is_contiguous()
+        capi.check(self.L.mtfjsp_draw_reward_weights(self.h, int(seed), int(episode), out.data_ptr()), self.h)
+        return out
+
     def step(self, task_idx, mach_idx):
         """device tensors (int32) -> asynchronous launch; numpy/list -> host variant (raises on invalid actions)."""
         if torch.is_tensor(task_idx):

@@ -58,6 +58,7 @@ PROTOTYPES = {
     "mtfjsp_scaler_reset_returns": (_I, [_VP]),
     "mtfjsp_scaler_reset_returns_masked_host": (_I, [_VP, _VP]),
     "mtfjsp_reset": (_I, [_VP, _VP]),
+    "mtfjsp_draw_reward_weights": (_I, [_VP, _U64, _U64, _VP]),
     "mtfjsp_reset_host": (_I, [_VP, _VP]),
     "mtfjsp_step": (_I, [_VP, _VP, _VP]),
     "mtfjsp_step_host": (_I, [_VP, _VP, _VP]),
@@ -66,6 +67,7 @@ PROTOTYPES = {
     "mtfjsp_observe_mfea1": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_random_actions": (_I, [_VP, _U64, _U64, _VP, _VP, _VP]),
     "mtfjsp_export_dense_adj": (_I, [_VP, _VP]),
+    "mtfjsp_export_dense_adj_host": (_I, [_VP, _VP]),
     "mtfjsp_valid_action_mask": (_I, [_VP, _VP]),
     "mtfjsp_read_state_host": (_I, [_VP, _I, _VP]),
     "mtfjsp_copy_to_host": (_I, [_VP, _VP, _VP, _SZ]),

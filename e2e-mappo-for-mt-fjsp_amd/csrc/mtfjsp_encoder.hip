@@ -2512,11 +2512,57 @@ extern "C" int mtfjsp_encoder_destroy(mtfjsp_encoder_t e)
 }
 extern "C" int mtfjsp_encoder_set_stream(mtfjsp_encoder_t e, void *s) { if (!e) return MTFJSP_ERR_ARG; e->stream = (hipStream_t)s; return MTFJSP_OK; }
 
+// element count of every tensor the forwards read, by the reference's state_dict key (after the "job_actor." / "machine_actor."
+// / "global_critic." prefix): gcn:60-107 (GraphCNN / MLP), gcn:322-433 (MLPActor / MLPCritic), ac:60-100, 330-357, 540-585
+static int64_t expected_numel(const std::string &key)
+{
+    const size_t dot = key.find('.');
+    if (dot == std::string::npos) return -1;
+    const std::string pre = key.substr(0, dot), k = key.substr(dot + 1);
+    if (pre != "job_actor" && pre != "machine_actor" && pre != "global_critic") return -1;
+    auto ends = [&](const char *suf) { const size_t n = strlen(suf); return k.size() >= n && k.compare(k.size() - n, n, suf) == 0; };
+    auto has = [&](const char *sub) { return k.find(sub) != std::string::npos; };
+    if (k == "_input") return HD;
+    if (has("batch_norms") || k == "bn.weight" || k == "bn.bias" || k == "encoder.feature_extract.bn.weight" || k == "encoder.feature_extract.bn.bias")
+        return has("feature_extract.bn.") ? 12 : HD;                           // GraphCNN.bn(input_dim) is defined but unused (gcn:66)
+    if (has("feature_extract.mlps.")) {
+        if (ends(".bias")) return HD;
+        return has("mlps.0.linears.0.weight") ? (int64_t)HD * 12 : (int64_t)HD * HD;
+    }
+    if (has("feature_extract.eps")) return 2;
+    if (k == "m_fea_1_fcl.weight") return (int64_t)HD * 6;
+    if (k == "m_fea_2_fcl.weight") return (int64_t)HD * 8;
+    if (k == "gat_layer.W") return (int64_t)HD * HD;
+    if (k == "gat_layer.a") return 2 * HD;
+    if (has("fcl_pooling")) return ends(".bias") ? HD : (int64_t)HD * HD;      // defined, unused (ac:357)
+    for (const char *head : {"o_policy", "m_policy", "job_critic", "machine_critic", "critic"}) {
+        const std::string h = std::string(head) + ".linears.";
+        if (k.compare(0, h.size(), h) != 0) continue;
+        const int layer = k[h.size()] - '0';
+        const bool policy = strstr(head, "policy") != nullptr;
+        const int first_in = policy ? 3 * HD : (strcmp(head, "critic") == 0 ? 2 * HD : HD);
+        const int out_last = policy ? 1 : (strcmp(head, "critic") == 0 ? 4 : 2);
+        const int in = layer == 0 ? first_in : HD, out = layer == 2 ? out_last : HD;
+        if (layer < 0 || layer > 2) return -1;
+        return ends(".bias") ? out : (int64_t)out * in;
+    }
+    return -1;
+}
+
 extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *name, const float *data, int64_t numel)
 {
     if (!e || !name || !data || numel <= 0) return MTFJSP_ERR_ARG;
-    HIPCHK(e, hipSetDevice(e->cfg.device_id));
     std::string key(name);
+    {   // the kernels assume 128-wide layers of the reference's architecture: reject a tensor of any other size (a checkpoint
+        // with another hidden size or layer count would otherwise be read out of bounds)
+        const int64_t want = expected_numel(key);
+        if (want < 0) { e->err = "unknown weight name: " + key; return MTFJSP_ERR_ARG; }
+        if (want != numel) {
+            e->err = "weight " + key + ": expected " + std::to_string(want) + " elements, got " + std::to_string(numel);
+            return MTFJSP_ERR_ARG;
+        }
+    }
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
     float *d = nullptr;
     auto it = e->w.find(key);
     if (it != e->w.end()) d = it->second;

@@ -1074,6 +1074,23 @@ __global__ void k_random_actions(int B, int J, int M, int T, const double *t, co
     if (job_idx) job_idx[b] = jj;
 }
 
+// env.generate_random_weights("01") (env:1253-1259) on the device: three uniforms in [0,1) per instance, normalised by their sum
+// (numpy's sum of three = left-to-right adds).  53-bit uniforms like python's random.random(): (a >> 5, b >> 6) -> (a*2^26 + b) / 2^53.
+__global__ void k_draw_w3(int B, uint64_t seed, uint64_t episode, double *w3)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double u[3];
+    for (int i = 0; i < 3; i += 2) {
+        uint32_t c[4] = {(uint32_t)b, (uint32_t)episode, (uint32_t)(episode >> 32), 0x77337733u + (uint32_t)i};
+        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        u[i] = ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) * (1.0 / 9007199254740992.0);
+        if (i + 1 < 3) u[i + 1] = ((double)(c[2] >> 5) * 67108864.0 + (double)(c[3] >> 6)) * (1.0 / 9007199254740992.0);
+    }
+    const double sum = (u[0] + u[1]) + u[2];
+    w3[(size_t)b * 3 + 0] = u[0] / sum; w3[(size_t)b * 3 + 1] = u[1] / sum; w3[(size_t)b * 3 + 2] = u[2] / sum;
+}
+
 // GAE reverse scan (ppo:444-457 / 500-510): thread = instance, coalesced over b at every step
 __global__ void k_gae(int B, int S, const float *r, long r_ss, long r_sb, const float *v, long v_ss, long v_sb, const float *vn, long n_ss, long n_sb,
                       const float *done, float gamma, float lam, float *adv)
@@ -1200,6 +1217,7 @@ struct mtfjsp_env {
     int *lastm = nullptr;
     int *d_task = nullptr, *d_mach = nullptr;
     double *d_w3 = nullptr;
+    double *dense_scratch = nullptr;   // [B,T,T] f64, allocated on the first mtfjsp_export_dense_adj_host
     mtfjsp_obs_t obs{};
     bool obs_bound = false;
     std::vector<void *> owned;
@@ -1260,9 +1278,15 @@ extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
     rc |= dalloc(h, &h->d_task, B); rc |= dalloc(h, &h->d_mach, B); rc |= dalloc(h, &h->d_w3, B * 3);
     if (rc) { g_create_err = h->err; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
     if (hipMemset(h->scal, 0, B * SCAL_N * sizeof(double)) != hipSuccess) { g_create_err = "memset failed"; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
-    // opt in to large dynamic LDS
-    (void)hipFuncSetAttribute((const void *)k_env_step<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void *)k_env_step<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // opt in to large dynamic LDS (every kernel that is launched with a dynamic allocation sized from T)
+    const void *dyn_kernels[] = {(const void *)k_env_step<double>, (const void *)k_env_step<float>,
+                                 (const void *)k_env_reset<double>, (const void *)k_env_reset<float>};
+    for (const void *k : dyn_kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            g_create_err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+            mtfjsp_destroy(h);
+            return MTFJSP_ERR_HIP;
+        }
     *out = h;
     return MTFJSP_OK;
 }
@@ -1582,6 +1606,16 @@ extern "C" int mtfjsp_random_actions(mtfjsp_handle_t h, uint64_t seed, uint64_t 
     return MTFJSP_OK;
 }
 
+extern "C" int mtfjsp_draw_reward_weights(mtfjsp_handle_t h, uint64_t seed, uint64_t episode, double *w3_out)
+{
+    if (!h || !w3_out) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const int B = h->cfg.batch;
+    hipLaunchKernelGGL(k_draw_w3, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, seed, episode, w3_out);
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+
 extern "C" int mtfjsp_export_dense_adj(mtfjsp_handle_t h, double *out)
 {
     if (!h || !out) return MTFJSP_ERR_ARG;
@@ -1594,6 +1628,19 @@ extern "C" int mtfjsp_export_dense_adj(mtfjsp_handle_t h, double *out)
     hipLaunchKernelGGL(k_dense_adj, dim3((n + 255) / 256), dim3(256), 0, h->stream, (int)B, (int)T, h->obs.ell_col, h->obs.ell_val, out);
     HIPCHK(h, hipGetLastError());
     return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_export_dense_adj_host(mtfjsp_handle_t h, double *out_host)
+{
+    if (!h || !out_host) return MTFJSP_ERR_ARG;
+    const size_t n = (size_t)h->cfg.batch * h->T * h->T;
+    if (!h->dense_scratch) {
+        int rc = dalloc(h, &h->dense_scratch, n);
+        if (rc) return MTFJSP_ERR_HIP;
+    }
+    int rc = mtfjsp_export_dense_adj(h, h->dense_scratch);
+    if (rc) return rc;
+    return mtfjsp_copy_to_host(h, out_host, h->dense_scratch, n * sizeof(double));
 }
 
 extern "C" int mtfjsp_valid_action_mask(mtfjsp_handle_t h, uint8_t *out)

@@ -86,11 +86,11 @@ def random_weights(batch, rng=None, kind="01", config_weights=(0.4, 0.4, 0.2)):
     import random as _random
     r = rng if rng is not None else _random
     out = np.zeros((batch, 3))
+    if kind == "01":          # all instances at once: same draws in the same order, same left-to-right sum of three per row
+        w = np.array([r.uniform(0, 1) for _ in range(3 * batch)]).reshape(batch, 3)
+        return w / np.sum(w, axis=-1, keepdims=True)
     for b in range(batch):
-        if kind == "01":
-            w = np.array([r.uniform(0, 1) for _ in range(3)])
-            out[b] = w / np.sum(w, axis=-1)
-        elif kind == "0.1":
+        if kind == "0.1":
             nums = [round(r.uniform(0, 1), 1) for _ in range(3)]
             tot = sum(nums)
             out[b] = np.array([round(x / tot, 1) for x in nums])

@@ -10,7 +10,13 @@ like the reference returns them).
 Differences that are deliberate (documented in DESIGN.md §6):
   * an action that is already scheduled / whose job predecessor is unscheduled raises ValueError instead of
     silently corrupting node attributes (env:1496-1528); never reached under the reference's masks;
-  * per-env `.step()` / `.render()` of the proxies are not available (the batch steps together).
+  * `paral_env_DG[i].render()` prints a console Gantt chart (the reference's default "gantt_console" visualisation,
+    Run.py:651-653, validate.py:286); window / rgb-array rendering is outside the accelerated hot path;
+  * `paral_env_DG[i].step([task, machine])` (gym-style, env:716-974) steps instance i alone through the same kernel (the other
+    instances of the batch receive a rejected no-op); entries of the reference's 14-tuple that no caller of the hot path
+    reads (flat gym observation, ft_s / it_s lists, the 3-column tasks_fea) are None.
+`DisjunctiveGraphJspEnv_singleStep` below is the same surface as a stand-alone one-instance environment for callers that
+build their own env (trainer/validate.py:108-127).
 """
 
 import numpy as np
@@ -86,11 +92,32 @@ class _EnvProxy:
         self._parent._w3[self._i] = w
         return None
 
-    def step(self, *a, **k):
-        raise NotImplementedError("instances of a device batch step together: use Parallel_env.DGFJSPEnv_paral_step")
+    def step(self, joint_action):
+        """env.step([task_idx, m_idx]) (env:716-974) for THIS instance only -> the reference's 14-tuple
+        (state, reward, done, info, r_mk, r_idle, r_pt, r_tt, ft_s, it_s, adj_wrk, tasks_fea, machine_fea, tasks_fea_1101);
+        rewards are the unscaled ones, as env.step returns them (reward scaling is Parallel_env's, pe:255-260)."""
+        return self._parent._step_one(self._i, int(joint_action[0]), int(joint_action[1]))
 
-    def render(self, *a, **k):
-        raise NotImplementedError("rendering is outside the accelerated hot path")
+    def render(self, mode="human", show=None, **render_kwargs):
+        """console Gantt chart of the current (partial) schedule — what the reference prints for its default
+        "gantt_console" visualisation (env:1274-1354 -> visualizer); returns None like mode="human"."""
+        par, i = self._parent, self._i
+        routes = par._mirror(capi.STATE_ROUTES)[i]
+        st, ft = par._mirror(capi.STATE_START)[i], par._mirror(capi.STATE_FINISH)[i]
+        M = self._env.M
+        horizon = float(np.nanmax(ft)) if np.isfinite(ft).any() else 0.0
+        width = 60
+        print(f"Gantt (instance {i}, makespan so far {horizon:.1f})")
+        for m in range(M):
+            line = [" "] * width
+            for a in routes[m][routes[m] >= 0]:
+                lo = int(st[a] / horizon * (width - 1)) if horizon > 0 else 0
+                hi = max(lo, int(ft[a] / horizon * (width - 1)) if horizon > 0 else 0)
+                ch = "0123456789abcdefghijklmnopqrstuvwxyz"[(int(a) // M) % 36]          # one symbol per job
+                for x in range(lo, hi + 1):
+                    line[x] = ch
+            print(f"  machine {m:2d} |" + "".join(line) + "|")
+        return None
 
 
 class _ScalerProxy:
@@ -174,9 +201,7 @@ class Parallel_env(object):
 
     def init_DGFJSPEnv_state0(self):
         """pe:87-149 -> (adj [B,T,T], m_fea2 [B,M,8], tasks_fea [B*T,12]) float64"""
-        kind = self.args.get('random_weight_type', "01") if isinstance(self.args, dict) else "01"
-        self._w3 = random_weights(self.batch_size, kind="01" if kind not in ("01", "0.1", "eval") else "01",
-                                  config_weights=self._w_cfg)           # env.reset() default type is "01" (env:1183)
+        self._w3 = random_weights(self.batch_size, kind="01", config_weights=self._w_cfg)   # pe:130 calls env.reset() with its default type "01" (env:1183)
         self._dev.reset(self._w3)
         self._cache = {}
         self.paral_env_DG = [_EnvProxy(self, i) for i in range(self.batch_size)]
@@ -213,7 +238,81 @@ class Parallel_env(object):
         adj, mfea2, tfea = self._host_obs()
         return adj, self.oenv_info, mfea2, tfea
 
+    def _step_one(self, i, a, m):
+        """per-env gym step of instance i (proxy.step): every other instance gets task index -1, which the kernel rejects
+        leaving it untouched (MTFJSP_ST_INVALID)"""
+        B, T, M = self.batch_size, self.ntasks, self.nmachines
+        ta = torch.full((B,), -1, dtype=torch.int32); ma = torch.zeros(B, dtype=torch.int32)
+        ta[i], ma[i] = a, m
+        self._flush_scaler_resets()
+        self._dev.step(ta.to(self._dev.device), ma.to(self._dev.device))
+        self._cache = {}
+        status = int(self._dev.status[i].item())
+        if status & capi.ST_INVALID:
+            raise ValueError(f"invalid action for instance {i}: task {a} is scheduled already, its job predecessor is not, or an index is out of range")
+        raw = self._dev.raw[i].cpu().numpy()
+        done = bool(self._dev.info[i, 1].item())
+        adj = self._dev.dense_adj()[i].cpu().numpy()
+        tfea = self._dev.tasks_fea.view(B, T, 12)[i].cpu().numpy().copy()
+        mfea = self._dev.m_fea2[i].cpu().numpy().copy()
+        return (None, float(raw[0]), done, {}, float(raw[1]), float(raw[2]), float(raw[3]), float(raw[4]), None, None,
+                adj, None, mfea, tfea)
+
     def reset_data(self):
         """pe:271-282"""
         self.paral_env_DG = []
         self.oenv_info = []
+
+
+class DisjunctiveGraphJspEnv_singleStep:
+    """One MT-FJSP instance with the gym-style surface of the reference's env class (env:34-368: constructor keywords of
+    pe:108-118 / validate.py:108-127; reset env:1183-1245; step env:716-974; valid_action_mask env:2535-2575; render) on top
+    of a one-instance device batch.  For the B = 1 callers that construct their own env (trainer/validate.py); a training
+    rollout should use Parallel_env / DeviceBatchEnv, which step thousands of instances per launch."""
+
+    def __init__(self, jps_instance=None, ability_tr_mm=None, reward_function='wrk', reward_function_parameters=None,
+                 perform_left_shift_if_possible=True, default_visualisations=None, configs=None, edge=None, **_ignored):
+        t, p = np.asarray(jps_instance[0], np.float64), np.asarray(jps_instance[1], np.float64)
+        cfg = dict(configs) if configs is not None else {}
+        M = t.shape[1]
+        J = t.shape[0] // M
+        E = int(cfg.get('n_edge', 1))
+        if reward_function != 'wrk':
+            raise ValueError("only the 'wrk' reward function of the training / evaluation path is provided (env:1051-1171)")
+        args = {'n_job': J, 'n_machine': M, 'n_edge': E, 'env_batch': 1, 'm_scaling': cfg.get('m_scaling', 1),
+                'reward_scaling': reward_function_parameters or {'scaling_divisor': 1}, 'GAMMA': cfg.get('GAMMA', 0.99),
+                'weight_mk': cfg.get('weight_mk', 0.4), 'weight_ec': cfg.get('weight_ec', 0.4), 'weight_tt': cfg.get('weight_tt', 0.2),
+                'perform_left_shift_if_possible': perform_left_shift_if_possible, 'hip_device': cfg.get('hip_device', 0)}
+        self._pe = Parallel_env(args)
+        if edge is None:                                              # machines split evenly into shops in index order (generate…py:219-233)
+            edge = np.arange(M).reshape(E, M // E)
+        self._pe.get_batch({"t": t[None], "p": p[None], "transT": np.asarray(ability_tr_mm, np.float64)[None], "edge": np.asarray(edge)[None]})
+        self._pe.init_RewardScaling_sameBATCH(4)
+        self.n_jobs, self.n_machines, self.total_tasks_without_dummies = J, M, J * M
+        self._proxy = None
+
+    def reset(self, Random_weight_type="01"):
+        """-> the 9-tuple of env._state_array (env:2515): (state, ft_s, it_s, adj_wrk, tasks_fea, machines_fea, tasks_fea_1101,
+        ft_estimated [T], pt_estimated [T]); entries no hot-path caller reads are None"""
+        pe = self._pe
+        pe._w3 = random_weights(1, kind=Random_weight_type, config_weights=pe._w_cfg)
+        pe._dev.reset(pe._w3)
+        pe._cache = {}
+        pe.paral_env_DG = [_EnvProxy(pe, 0)]
+        self._proxy = pe.paral_env_DG[0]
+        adj, mfea2, tfea = pe._host_obs()
+        return (None, None, None, adj[0], None, mfea2[0], tfea, tfea[:, 1].copy(), tfea[:, 2].copy())
+
+    def step(self, joint_action):
+        return self._proxy.step(joint_action)
+
+    def valid_action_mask(self, action_mode=None):
+        return self._proxy.valid_action_mask(action_mode)
+
+    def render(self, *a, **k):
+        return self._proxy.render(*a, **k)
+
+    def __getattr__(self, name):      # G, machine_routes, reward_random_weight, *_previous_step: the proxy's read-only views
+        if name.startswith("_") or self.__dict__.get("_proxy") is None:
+            raise AttributeError(name)
+        return getattr(self._proxy, name)

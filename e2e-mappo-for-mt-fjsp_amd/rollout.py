@@ -26,11 +26,11 @@ def actor_available():
 class Rollout:
     def __init__(self, n_job, n_machine, n_edge, batch, device=0, policy="random", obs_dtype="f32",
                  instance_seed=0, rank=0, world=1, weights=None, w3_pool_episodes=32, greedy=False, seed=1234,
-                 buffer_episodes=5, gamma=0.99, lam=0.98, collect=True, instances=None, w3_episodes=None):
+                 buffer_episodes=5, gamma=0.99, lam=0.98, collect=True, instances=None, w3_episodes=None, w3="device"):
         """instances: (t, p, tt, edge) host arrays for THIS shard; default = rows [rank*batch, (rank+1)*batch) of the
         reference generator's `Instance_Dataset(samples=world*batch, seed=instance_seed)` (every
-        instance distinct).  w3_episodes: [n,B,3] reward weights to use episode by episode (tests); default = the
-        host `random` stream of env:1253-1259, drawn in pools of `w3_pool_episodes` episodes and refilled when used up."""
+        instance distinct).  w3_episodes: [n,B,3] reward weights to use episode by episode (tests); otherwise w3 = "device"
+        (default) or "host", see below."""
         self.J, self.M, self.E, self.B = n_job, n_machine, n_edge, batch
         self.T = n_job * n_machine
         self.policy = policy
@@ -48,16 +48,22 @@ class Rollout:
         t, p, tt, edge = instances
         self.env.load_instances(t, p, tt, edge=edge)
         self.env.scaler_init()
-        # reward weights: host `random` stream (env:1253-1259; 3 draws per instance and episode in instance order),
-        # pre-drawn for a pool of episodes, kept in HBM, refilled from the same stream when the pool is used up
+        # reward weights, fresh for every episode and instance (env:1253-1259): w3="device" draws them on the device (Philox
+        # keyed by (seed, episode, instance); nothing crosses PCIe and the host never stalls the launch queue); w3="host" keeps
+        # the reference's python `random` stream (3 draws per instance in instance order), drawn in pools of
+        # `w3_pool_episodes` episodes and uploaded — about 10 us per instance and episode of host time
+        self.w3_mode = "fixed" if w3_episodes is not None else w3
         self._w3_rng = _random.Random(1000 + rank)
         self._w3_pool_n = w3_pool_episodes
-        self._w3_fixed = w3_episodes is not None
-        if self._w3_fixed:
+        if self.w3_mode == "fixed":
             self.w3_pool = torch.as_tensor(np.asarray(w3_episodes), dtype=torch.float64, device=dev).contiguous()
-        else:
+        elif self.w3_mode == "host":
             self.w3_pool = torch.empty(w3_pool_episodes, batch, 3, dtype=torch.float64, device=dev)
             self._refill_w3()
+        elif self.w3_mode == "device":
+            self.w3_pool = torch.empty(2, batch, 3, dtype=torch.float64, device=dev)     # this episode's / (full trajectory) kept alive
+        else:
+            raise ValueError("w3 must be 'device' or 'host'")
         self.task = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.mach = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.job = torch.zeros(batch, dtype=torch.int32, device=dev)
@@ -119,7 +125,9 @@ class Rollout:
 
     def _episode_w3(self):
         n = self.w3_pool.shape[0]
-        if not self._w3_fixed and self.episode > 0 and self.episode % n == 0:
+        if self.w3_mode == "device":
+            return self.env.draw_reward_weights(self.seed, self.episode, out=self.w3_pool[self.episode % n])
+        if self.w3_mode == "host" and self.episode > 0 and self.episode % n == 0:
             self._refill_w3()                                              # fresh draws for every episode (env:1253-1259)
         return self.w3_pool[self.episode % n]
 

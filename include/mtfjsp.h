@@ -132,6 +132,10 @@ int mtfjsp_scaler_reset_returns_masked_host(mtfjsp_handle_t h, const uint8_t *ma
 /* = init_DGFJSPEnv_state0 (pe:87-149) = env.reset() on every instance (env:1183-1245).
  * w3 [B,3]: normalised reward weights; the host draws them (env:1253-1259 uses python `random`). */
 int mtfjsp_reset(mtfjsp_handle_t h, const double *w3);
+/* = env.generate_random_weights("01") (env:1253-1259) for every instance ON the device: w3_out [B,3] f64 (device), three
+ * uniforms normalised by their sum, Philox stream keyed by (seed, episode, instance) — distributional parity, for rollouts
+ * that must not wait for the host; parity runs draw the weights with python `random` and pass them to mtfjsp_reset. */
+int mtfjsp_draw_reward_weights(mtfjsp_handle_t h, uint64_t seed, uint64_t episode, double *w3_out);
 int mtfjsp_reset_host(mtfjsp_handle_t h, const double *w3_host);
 
 /* = DGFJSPEnv_paral_step (pe:217-268): env.step (env:716-974) + RewardScaling (pe:255-260), fused with
@@ -156,6 +160,9 @@ int mtfjsp_random_actions(mtfjsp_handle_t h, uint64_t seed, uint64_t counter, in
 /* ------------------------------------------------------------------ exports (compat / tests) */
 /* dense adj_wrk [B,T,T] f64, row = destination, diagonal 1 (env:2066-2073) — what pe:136 returns. */
 int mtfjsp_export_dense_adj(mtfjsp_handle_t h, double *out);
+/* same, into HOST memory (the reference returns adj as a host numpy array, pe:136,263); the [B,T,T] device scratch is
+ * allocated inside the handle on first use — compatibility path for small batches */
+int mtfjsp_export_dense_adj_host(mtfjsp_handle_t h, double *out_host);
 /* gym-style valid_action_mask (env:2535-2575): [B,T] 1 = selectable */
 int mtfjsp_valid_action_mask(mtfjsp_handle_t h, uint8_t *out);
 enum {

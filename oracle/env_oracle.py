@@ -45,10 +45,17 @@ def lib():
         L.or_batch_job_mask_state.argtypes = [C.c_void_p, _ip, _bp]
         L.or_batch_state.argtypes = [C.c_void_p, _ip, _bp, _dp, _dp, _ip, _dp, _dp]
         L.or_batch_valid_action_mask.argtypes = [C.c_void_p, _bp]
+        L.or_batch_bench.restype = C.c_long
+        L.or_batch_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.or_max_threads.restype = C.c_int
         L.or_np_sum.restype = C.c_double
         L.or_np_sum.argtypes = [_dp, C.c_long]
         _lib = L
     return _lib
+
+
+def max_threads():
+    return lib().or_max_threads()
 
 
 def shop_of_machine(edge):
@@ -132,6 +139,15 @@ class OracleBatch:
         prev = np.zeros((B, 4)); sc = np.zeros((B, 17))
         self.L.or_batch_state(self.h, mach, sched, st, ft, routes, prev, sc)
         return dict(mach=mach, sched=sched, st=st, ft=ft, routes=routes, prev=prev, scaler=sc)
+
+    def bench(self, episodes, nthreads, w3):
+        """CPU baseline loop in C (random valid actions; step + reward scaling + job mask + ELL observation per env and step,
+        OpenMP over envs): -> (env_steps, seconds of the step loops, seconds incl. the per-episode resets)"""
+        s1, s2 = C.c_double(), C.c_double()
+        n = self.L.or_batch_bench(self.h, int(episodes), int(nthreads), np.ascontiguousarray(w3, np.float64), C.byref(s1), C.byref(s2))
+        if n < 0:
+            raise ValueError("or_batch_bench: n_job > 64")
+        return n, s1.value, s2.value
 
     def valid_action_mask(self):
         m = np.zeros((self.B, self.T), np.uint8)

@@ -702,3 +702,90 @@ void or_batch_valid_action_mask(Batch *b, unsigned char *mask)
 {
     for (int i = 0; i < b->B; i++) { int T = b->env[i]->h.T; or_valid_action_mask(b->env[i], mask + (long)i * T); }
 }
+
+/* ================================================================ CPU baseline loop (bench.py `cpu_baseline`, SURVEY §8d leg ii)
+ * `episodes` episodes of T batched steps over all B envs with uniform random valid actions chosen here (xorshift per env):
+ * per env and step, exactly what the reference's batched step does per env — env.step + RewardScaling (pe:229-262), the
+ * candidate / job-mask update (ppo:202-316) and the observation (ELL adjacency + tasks_fea + m_fea2, env:2001-2515) —
+ * as a loop over envs inside each step (pe:229 is that loop), parallelised over envs with OpenMP when nthreads > 1.
+ * Returns the env-steps done; *seconds = wall time of the step loops (resets excluded, like the GPU bench's per-step rate
+ * includes them: both are reported). */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include <time.h>
+static double now_s(void) { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+int or_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+long or_batch_bench(Batch *b, int episodes, int nthreads, const double *w3, double *seconds, double *seconds_with_reset)
+{
+    const int B = b->B, T = b->env[0]->h.T, M = b->env[0]->h.M, J = b->env[0]->h.J;
+    if (J > 64) return -1;
+    uint64_t *rng = (uint64_t *)malloc(sizeof(uint64_t) * B);
+    for (int i = 0; i < B; i++) rng[i] = 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+    if (nthreads < 1) nthreads = 1;
+    /* per-thread observation scratch (the observation is produced, as the reference returns it every step) */
+    int *ec = (int *)malloc(sizeof(int) * (size_t)nthreads * T * 2);
+    double *ev = (double *)malloc(sizeof(double) * (size_t)nthreads * T * 2);
+    double *tf = (double *)malloc(sizeof(double) * (size_t)nthreads * T * 12);
+    double *mf = (double *)malloc(sizeof(double) * (size_t)nthreads * M * 8);
+    double t_steps = 0.0, t_all = 0.0;
+    long n = 0;
+    for (int ep = 0; ep < episodes; ep++) {
+        const double t0 = now_s();
+        or_batch_scaler_reset_returns(b);
+        or_batch_reset(b, w3);
+        const double t1 = now_s();
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+        {
+#ifdef _OPENMP
+            const int th = omp_get_thread_num();
+#else
+            const int th = 0;
+#endif
+            int cand[64]; unsigned char mask[64];
+            for (int s = 0; s < T; s++) {
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+                for (int i = 0; i < B; i++) {
+                    Env *e = b->env[i];
+                    uint64_t x = rng[i];
+                    or_job_mask_state(e, cand, mask);
+                    int nj = 0, jsel = -1, msel = -1;
+                    for (int j = 0; j < J; j++) nj += !mask[j];
+                    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                    int pick = (int)(x % (uint64_t)nj);
+                    for (int j = 0; j < J; j++) if (!mask[j] && pick-- == 0) { jsel = j; break; }
+                    const int a = cand[jsel];
+                    int nm = 0;
+                    for (int m = 0; m < M; m++) nm += e->h.t[a * M + m] >= 0;
+                    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                    pick = (int)(x % (uint64_t)nm);
+                    for (int m = 0; m < M; m++) if (e->h.t[a * M + m] >= 0 && pick-- == 0) { msel = m; break; }
+                    rng[i] = x;
+                    double r5[5], s4[4]; int path;
+                    or_env_step(e, a, msel, r5, &path);
+                    or_scaler_apply(e, r5 + 1, s4);
+                    or_job_mask_update(e, jsel, cand, mask);
+                    or_env_observe_ell(e, ec + (size_t)th * T * 2, ev + (size_t)th * T * 2, tf + (size_t)th * T * 12, mf + (size_t)th * M * 8);
+                }
+            }
+        }
+        const double t2 = now_s();
+        t_steps += t2 - t1; t_all += t2 - t0;
+        n += (long)B * T;
+    }
+    free(rng); free(ec); free(ev); free(tf); free(mf);
+    if (seconds) *seconds = t_steps;
+    if (seconds_with_reset) *seconds_with_reset = t_all;
+    return n;
+}

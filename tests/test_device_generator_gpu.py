@@ -86,3 +86,27 @@ def test_rollout_on_generated_instances_matches_the_oracle():
         assert np.array_equal(env.info.cpu().numpy(), info) and np.array_equal(env.raw.cpu().numpy(), raw)
     o = orc.observe(dense=False)
     assert np.array_equal(env.tasks_fea.cpu().numpy(), o["tfea"]) and np.array_equal(env.m_fea2.cpu().numpy().reshape(B, M, 8), o["mfea2"])
+
+
+def test_device_reward_weights_follow_the_reference_distribution():
+    """mtfjsp_draw_reward_weights = env.generate_random_weights("01") (env:1253-1259) on the device: three uniforms normalised
+    by their sum, fresh per (episode, instance)."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    batch_env = import_module("e2e-mappo-for-mt-fjsp_amd.batch_env")
+    inst = import_module("e2e-mappo-for-mt-fjsp_amd.instances")
+    B = 20000
+    env = batch_env.DeviceBatchEnv(6, 6, 2, B, obs_dtype="f32")
+    w0 = env.draw_reward_weights(11, 0).cpu().numpy()
+    w1 = env.draw_reward_weights(11, 1).cpu().numpy()
+    w0b = env.draw_reward_weights(11, 0).cpu().numpy()
+    assert np.array_equal(w0, w0b) and not np.array_equal(w0, w1)            # a pure function of (seed, episode, instance)
+    assert len({r.tobytes() for r in w0}) == B
+    np.testing.assert_allclose(w0.sum(1), 1.0, rtol=0, atol=1e-15)
+    assert (w0 > 0).all() and (w0 < 1).all()
+    import random
+    ref = inst.random_weights(B, rng=random.Random(3))                       # the host stream of the reference
+    for d in (w0, w1):
+        np.testing.assert_allclose(d.mean(0), ref.mean(0), atol=0.01)
+        np.testing.assert_allclose(d.std(0), ref.std(0), atol=0.01)
+        np.testing.assert_allclose(np.quantile(d, [0.1, 0.5, 0.9], axis=0), np.quantile(ref, [0.1, 0.5, 0.9], axis=0), atol=0.015)

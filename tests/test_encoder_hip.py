@@ -203,3 +203,22 @@ def test_split_products_match_the_f32_matrix_instruction():
             assert d_ab <= tol, (k, d_ab)
             assert d_split <= 1.5 * d_f32 + 2e-6, (k, d_split, d_f32)
     print("max |split - f32 instruction| / scale:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
+def test_weight_loading_rejects_wrong_shapes_and_unknown_names():
+    """a checkpoint with another hidden size / layer count must not be accepted (the kernels assume 128-wide layers)"""
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    capi = import_module("e2e-mappo-for-mt-fjsp_amd.capi")
+    enc = enc_mod.Encoder(6, 6, 8)
+    ja, ma = enc_mod.random_init_weights(0)
+    enc.load_weights(ja, ma)                                              # the reference's shapes load
+    for key, bad in (("encoder.feature_extract.mlps.1.linears.0.weight", np.zeros((64, 64), np.float32)),
+                     ("o_policy.linears.0.weight", np.zeros((128, 256), np.float32)),
+                     ("encoder.feature_extract.mlps.0.linears.0.weight", np.zeros((128, 16), np.float32))):
+        with pytest.raises(capi.MtfjspError) as ei:
+            enc.load_weights({key: bad}, {})
+        assert ei.value.code == capi.ERR_ARG and "expected" in str(ei.value)
+    with pytest.raises(capi.MtfjspError):
+        enc.load_weights({"no_such_layer.weight": np.zeros(128, np.float32)}, {})
+    enc.load_weights(ja, ma)                                              # reloading the right shapes reuses the buffers
