@@ -838,6 +838,8 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 }
 static size_t gemm_x6_lds_bytes() { return (size_t)8 * X6_TILE + 2 * HD * 8 + 2 * HD * 4 + 64; }
 
+#include "mtfjsp_gin_resident.h"
+
 // ---------------------------------------------------------------------------------------------
 // Machine path of the machine actor / global critic (ac:383-434, gat:82-159) in ONE launch.  The three applications of
 // the single shared GATLayer on the fixed 2-node graph [[1,1],[0,1]] couple only rows (2u, 2u+1) = (node 0, node 1) of
@@ -2369,6 +2371,7 @@ struct mtfjsp_encoder {
     std::map<std::string, std::vector<float>> hostw;   // host copies of gat_layer.W / m_fea_*_fcl.weight (inputs of the fused projections)
     std::map<std::string, float *> wfused;  // per prefix + "1"/"2": (m_fea_k_fcl.weight^T . gat_layer.W)^T, [128,6] / [128,8]
     std::map<std::string, void *> wx6;      // 128x128 Linear weights as 3 bf16 planes in k_gemm_x6's register-image order
+    std::map<std::string, void *> wx32;     // GIN Linear weights as 3 bf16 planes in k_gin_res's (32x32x16) register-image order
     std::map<std::string, float *> wimg;    // the same blocks as per-wave register images for k_heads: [block][wave 8][g 8][lane 64][4]
     std::vector<void *> owned;
     int num_cu = 256;
@@ -2386,6 +2389,12 @@ struct mtfjsp_encoder {
     // 2 GAT passes, 4 heads, 8 first GIN Linear on the VALU); default from MTFJSP_GEMM_F32MFMA / _GAT_ / _HEADS_ / MTFJSP_GIN0_VALU
     int f32_products = (getenv("MTFJSP_GEMM_F32MFMA") ? 1 : 0) | (getenv("MTFJSP_GAT_F32MFMA") ? 2 : 0) |
                        (getenv("MTFJSP_HEADS_F32MFMA") ? 4 : 0) | (getenv("MTFJSP_GIN0_VALU") ? 8 : 0);
+    // resident GIN kernel (mtfjsp_gin_resident.h): eligibility decided at create time, then verified by a census launch
+    bool res_ok = false; int res_ipc = 0, res_grid = 0;
+    double *res_stats = nullptr;            // [2 sets][GR_STATS_SET]; forward n uses set n & 1 and zeroes the other one
+    unsigned long long *res_bar = nullptr;  // [17 * 16] barrier words
+    unsigned *res_fail = nullptr;
+    unsigned long long res_epoch = 0;
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
     mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
     struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
@@ -2495,6 +2504,30 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_headsx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)headsx_lds_bytes());
+    {   // resident GIN kernel: whole instances per workgroup, at most 576 rows, one workgroup per CU
+        const int T = e->T, B = cfg->batch;
+        if (!getenv("MTFJSP_NO_RESIDENT_GIN") && T >= GR_MINT && T <= GR_MAXT) {
+            const int ipc = (B + e->num_cu - 1) / e->num_cu;
+            const int grid = (B + ipc - 1) / ipc;
+            if (ipc * T <= GR_ROWS && ipc <= GR_MAXIPC && grid <= e->num_cu && ipc * cfg->n_job <= GR_MAXCAND &&
+                hipFuncSetAttribute((const void *)k_gin_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gin_res_lds_bytes()) == hipSuccess) {
+                int rc = dalloc(e, &e->res_stats, (size_t)2 * GR_STATS_SET) | dalloc(e, &e->res_bar, (size_t)17 * 16) | dalloc(e, &e->res_fail, (size_t)4);
+                if (!rc && hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8) == hipSuccess &&
+                    hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8) == hipSuccess && hipMemset(e->res_fail, 0, 16) == hipSuccess) {
+                    // census: every workgroup must be resident at once for the grid barriers to complete (bounded spins report it)
+                    GinResArgs a{};
+                    a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail; a.barrier_only = 1;
+                    hipLaunchKernelGGL(k_gin_res, dim3(grid), dim3(256), gin_res_lds_bytes(), nullptr, a);
+                    unsigned failed = 1;
+                    if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&failed, e->res_fail, 4, hipMemcpyDeviceToHost) == hipSuccess && !failed) {
+                        e->res_ok = true; e->res_ipc = ipc; e->res_grid = grid;
+                    } else {       // leave the streaming kernels in charge; fresh barrier words in case the census is retried elsewhere
+                        (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); (void)hipMemset(e->res_fail, 0, 16);
+                    }
+                }
+            }
+        }
+    }
     *out = e;
     return MTFJSP_OK;
 }
@@ -2596,6 +2629,32 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
         auto kt = e->wx6.find(key);
         if (kt != e->wx6.end()) dx = kt->second;
         else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx6[key] = dx; }
+        HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
+    }
+    if (key.find("feature_extract.mlps.") != std::string::npos && key.size() > 7 && key.compare(key.size() - 7, 7, ".weight") == 0 &&
+        key.find("linears") != std::string::npos) {
+        // k_gin_res (v_mfma_f32_32x32x16_bf16, A := weight): img[w 4][plane 3][ks KS][lane 64][j 8] =
+        // plane(W[n = 32w + (lane & 31)][k = 16ks + 8(lane >> 5) + j]), KS = in/16 (the 12 -> 128 Linear: one k-step, k >= 12 zero)
+        const int in = (int)(numel / HD), KS = in == 12 ? 1 : in / 16;
+        auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
+        auto from_bf16 = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
+        std::vector<uint16_t> im((size_t)4 * 3 * KS * 64 * 8, 0);
+        for (int w = 0; w < 4; w++)
+            for (int ks = 0; ks < KS; ks++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int n = 32 * w + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
+                        if (k >= in) continue;
+                        const float x = data[(size_t)n * in + k];
+                        const uint16_t p0 = to_bf16(x); const float r1 = x - from_bf16(p0);
+                        const uint16_t p1 = to_bf16(r1); const float r2 = r1 - from_bf16(p1);
+                        const uint16_t pl[3] = {p0, p1, to_bf16(r2)};
+                        for (int p = 0; p < 3; p++) im[(((((size_t)w * 3 + p) * KS + ks) * 64 + lane) * 8) + j] = pl[p];
+                    }
+        void *dx = nullptr;
+        auto kt = e->wx32.find(key);
+        if (kt != e->wx32.end()) dx = kt->second;
+        else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx32[key] = dx; }
         HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
     }
     // 128-wide Linear weights [out=128, in=128*k] and gat W [in,out]: keep GEMM-ready [in-block][k][n] copies
@@ -2820,6 +2879,60 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     return MTFJSP_OK;
 }
 
+// The same encoder as ONE launch with register-resident activations (mtfjsp_gin_resident.h); h_pooled and cand_feat (when
+// `candidate` is given) are written normalised, as run_gin's k_job_pool_gather would.
+static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
+                            const int32_t *candidate, int J, float *h_pooled, float *cand_feat, float *h_nodes)
+{
+    const int B = e->cfg.batch, T = e->T;
+    const std::string P = pre + "encoder.feature_extract.";
+    auto W = [&](const std::string &k) { return e->w.at(k); };
+    GinResArgs a{};
+    a.B = B; a.T = T; a.J = candidate ? J : 0; a.ipc = e->res_ipc;
+    a.tfea = tasks_fea; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64; a.ell_col = ell_col; a.ell_val = ell_val;
+    const char *lin[6] = {"mlps.0.linears.0", "mlps.0.linears.1", "mlps.0.linears.2", "mlps.1.linears.0", "mlps.1.linears.1", "mlps.1.linears.2"};
+    const char *bn[6] = {"mlps.0.batch_norms.0", "mlps.0.batch_norms.1", "batch_norms.0", "mlps.1.batch_norms.0", "mlps.1.batch_norms.1", "batch_norms.1"};
+    for (int i = 0; i < 6; i++) {
+        a.Wx32[i] = e->wx32.at(P + lin[i] + ".weight");           // (the Linear biases cancel in the BatchNorms that follow them)
+        a.gamma[i] = W(P + bn[i] + ".weight"); a.beta[i] = W(P + bn[i] + ".bias");
+    }
+    const int set = (int)(e->res_epoch & 1);
+    a.stats = e->res_stats + (size_t)set * GR_STATS_SET;
+    a.stats_next = e->res_stats + (size_t)(set ^ 1) * GR_STATS_SET;
+    a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail;
+    a.candidate = candidate; a.pooled = h_pooled; a.cand_feat = cand_feat; a.h_nodes = h_nodes;
+    a.inv_rows = 1.0 / ((double)B * (double)T);
+#ifdef GR_STAMP
+    static unsigned long long *d_st = nullptr;
+    if (!d_st) (void)hipMalloc((void **)&d_st, 256 * 64 * 8);
+    a.stamps = d_st;
+#endif
+    {
+        Timed t(e, "gin_resident");
+        hipLaunchKernelGGL(k_gin_res, dim3(e->res_grid), dim3(256), gin_res_lds_bytes(), e->stream, a);
+    }
+#ifdef GR_STAMP
+    static int printed = 0;
+    if (printed++ % 50 == 20 && getenv("MTFJSP_STAMP_PRINT")) {
+        (void)hipStreamSynchronize(e->stream);
+        std::vector<unsigned long long> h((size_t)e->res_grid * 64);
+        (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
+        // per stamp index: mean over blocks of (stamp - min over blocks of stamp 0), in us (s_memrealtime = 100 MHz)
+        unsigned long long t0 = ~0ull;
+        for (int b = 0; b < e->res_grid; b++) t0 = h[(size_t)b * 64] < t0 ? h[(size_t)b * 64] : t0;
+        printf("GR_STAMP (us since first block start; mean / max over %d blocks):", e->res_grid);
+        for (int i = 0; i < 32; i++) {
+            double m = 0, mx = 0;
+            for (int b = 0; b < e->res_grid; b++) { const double v = (double)(h[(size_t)b * 64 + i] - t0) / 100.0; m += v; mx = v > mx ? v : mx; }
+            printf(" [%d] %.1f/%.1f", i, m / e->res_grid, mx);
+        }
+        printf("\n");
+    }
+#endif
+    HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+
 // Machine path shared by the machine actor and the global critic (ac:383-444): input projections + 3x the same GATLayer
 // + node mean (in-place GEMM passes), then BatchNorm over all B*M rows and the mean over M.  Uses accumulator slot 6.
 // (m_fea_k_fcl.weight^T . gat_layer.W)^T on the host, cached per prefix until one of the three weights is loaded again
@@ -2941,7 +3054,7 @@ static int run_gat_inst(mtfjsp_encoder *e, const std::string &pre, const void *m
 // actor forwards normalise over the rows of ONE instance; mode 0 (default) over the whole device batch (training rollout).
 extern "C" int mtfjsp_encoder_set_product_mode(mtfjsp_encoder_t e, int32_t f32_instruction_mask)
 {
-    if (!e || f32_instruction_mask < 0 || f32_instruction_mask > 15) return MTFJSP_ERR_ARG;
+    if (!e || f32_instruction_mask < 0 || f32_instruction_mask > 31) return MTFJSP_ERR_ARG;
     e->f32_products = f32_instruction_mask;
     return MTFJSP_OK;
 }
@@ -2999,8 +3112,10 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     // the heads kernel does BatchNorm+ReLU, graph pool and candidate gather itself — while T is small: a workgroup pools 16
     // instances with 512 threads, which is too little parallelism for 400-row instances (J20M20: 199 vs 81+113 us measured)
-    const bool fuse_pool = !e->bn_mode && !h_nodes && e->T <= 128;
+    const bool resident = !e->bn_mode && e->res_ok && !(e->f32_products & (1 | 8 | 16));
+    const bool fuse_pool = !e->bn_mode && !resident && !h_nodes && e->T <= 128;
     rc = e->bn_mode ? run_gin_inst(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
+         : resident ? run_gin_resident(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
                     : run_gin(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, fuse_pool ? nullptr : h_pooled, e->cand_feat, h_nodes);
     if (rc) return rc;
     // ---- heads (ac:205-293): score = L2 tanh(L1 tanh(Wa cand + Wb pooled + Wc hm + b0))
@@ -3028,7 +3143,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
             ha.xbn_inv_rows = 1.0 / ((double)B * (double)e->T);
             ha.zero_stats = e->stats; ha.zero_count = 5 * STAT_REP * 256;    // slots 0..4 are consumed; slot 5 is being read by this very
             e->gin_slot5_dirty = true;                                       // kernel and is zeroed by the machine heads (or a memset)
-        } else if (!e->bn_mode) {
+        } else if (!e->bn_mode && !resident) {
             ha.zero_stats = e->stats; ha.zero_count = 6 * STAT_REP * 256;    // every GIN accumulator has been consumed by now
             e->gin_stats_clean = true;
         }
@@ -3129,7 +3244,9 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
     const int B = e->cfg.batch;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
-    int rc = run_gin(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr);
+    const bool resident = e->res_ok && !(e->f32_products & (1 | 8 | 16));
+    int rc = resident ? run_gin_resident(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr)
+                      : run_gin(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr);
     if (rc) return rc;
     rc = run_gat(e, "global_critic.", m_fea1, m_fea2, e->u);
     if (rc) return rc;
@@ -3179,6 +3296,20 @@ extern "C" int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *prob, 
     const int B = e->cfg.batch;
     hipLaunchKernelGGL(k_sample, dim3((B + 127) / 128), dim3(128), 0, e->stream, B, n, prob, greedy, seed, counter, idx_out, logp_out, gather_from, gathered_out);
     HIPCHK(e, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_out)
+{
+    if (!e) return MTFJSP_ERR_ARG;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (gin_resident_out) *gin_resident_out = e->res_ok ? 1 : 0;
+    if (e->res_ok) {
+        unsigned failed = 0;
+        HIPCHK(e, hipMemcpy(&failed, e->res_fail, 4, hipMemcpyDeviceToHost));
+        if (failed) { e->err = "resident GIN kernel: a grid barrier timed out (workgroups not co-resident); outputs since then are invalid"; return MTFJSP_ERR_STATE; }
+    }
     return MTFJSP_OK;
 }
 

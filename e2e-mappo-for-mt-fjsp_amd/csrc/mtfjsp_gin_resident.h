@@ -1,0 +1,619 @@
+// mtfjsp_gin_resident.h — the whole GIN encoder (gcn:109-197) of one forward as ONE launch whose activations never leave
+// the chip.  Included by mtfjsp_encoder.hip (uses split3x4, row_sum16, bn_relu_ss, LDS_BARRIER, STAT_REP, BN_EPS).
+//
+// Why: with training-mode BatchNorm every one of the six Linear products needs the batch statistics of its output before the
+// next layer can start, so the streaming design (k_gemm_x6) writes and re-reads the [rows,128] f32 activations at every
+// boundary: 6 launches, 983 MB per forward at 147 456 rows, each launch HBM-bound.  At the headline batch (4096 J6M6
+// instances = 576 rows per CU) the activations fit in the register file instead: 256 workgroups (one per CU, 4 waves, one per
+// SIMD with 512 registers each) keep z[576 rows][128] as 288 accumulator registers per lane; a layer is
+//     registers --BatchNorm+ReLU(+aggregation), exact 3-way bf16 split--> LDS planes --ds_read_b128--> matrix cores --> registers
+// and the only global traffic between layers is the BatchNorm column sums (2 KB per workgroup) and a grid-wide barrier.
+// The products are the 6-piece split products of k_gemm_x6 (f32-accurate), so the kernel is bound by the bf16 matrix cores
+// (29 GFLOP of piece products per layer = 12.8 us at the measured 2.27 PFLOP/s) plus six barriers.
+//
+// Layout.  v_mfma_f32_32x32x16_bf16 with the operands swapped (A := weight fragments, resident in registers; B := activation
+// rows from LDS): wave w owns output columns 32w..32w+31 of ALL rows of the workgroup.  Lane l = (n = l & 31, h = l >> 5) holds,
+// for row tile rt (32 rows), row 32rt+n, columns 32w + 8g + 4h + r (g, r = 0..3) in acc[rt][4g+r] — 16 registers per tile, 18
+// tiles.  The 32x32 shape is chosen over 16x16x32 because one wave per SIMD cannot overlap its own vector and matrix
+// instructions beyond the issue slots a matrix instruction leaves free: 24 of 32 cycles here against 8 of 16 (measured: the
+// 16x16x32 form of this kernel took 28 us per layer, of which 11 us were vector work that did not overlap).
+// A tile's planes (3 x 32 rows x 272 B) are written by all four waves (each its 32 columns) into one of two LDS buffers while
+// the previous tile is being multiplied: one LDS barrier per tile.
+// The second GIN layer's neighbour aggregation (gcn:125-149) reads rows of the same instance: h = relu(bn(z)) is staged as
+// f32 in a ring of 6 row tiles (192 rows, XOR-swizzled); with T <= 65 rows per instance the neighbours of tile rt lie in tiles
+// rt-2..rt+2.  Eligibility (host): 16 <= T <= 65 and ceil(B / 256) instances * T <= 576 rows per workgroup.
+// The bias of a Linear that feeds a BatchNorm cancels exactly (BN(z + b) = BN(z)), so no bias is added anywhere here.
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#ifndef GR_ABL                            // diagnostic timing ablations (wrong results): 1 no plane production, 2 no matrix products, 4 no statistics
+#define GR_ABL 0
+#endif
+#define GR_NT 18                          // row tiles per workgroup (576 rows)
+#define GR_ROWS (32 * GR_NT)
+#define GR_RING 6                         // row tiles in the f32 ring of the aggregation layer
+#define GR_NBAR 6                         // grid barriers per launch
+#define GR_ROWB 272                       // plane row pitch in bytes (256 + 16: conflict-free 16-byte operand reads)
+#define GR_PLANE (32 * GR_ROWB)
+#define GR_TILE (3 * GR_PLANE)
+#define GR_MAXCAND 384
+#define GR_MAXT 65                        // rows per instance: the in-edge sources of a tile lie within two tiles of it
+#define GR_MINT 16                        // ... and a 16-row run spans at most two instances (pooling)
+#define GR_MAXIPC 64                      // instances per workgroup (u8 instance ids; pool accumulators in the ring area)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GinResArgs {
+    int B, T, J, ipc;                     // instances, rows per instance, candidates per instance, instances per workgroup
+    const void *tfea; int feat_f64;       // [B*T,12] raw task features
+    const int *ell_col; const float *ell_val;   // [B*T,2]
+    const void *Wx32[6];                  // register images of the six Linear weights for the 32x32x16 form (first: the 12 -> 128 one-k-step image)
+    const float *gamma[6], *beta[6];      // BatchNorm after each Linear (mlps.0.bn0, mlps.0.bn1, outer 0, mlps.1.bn0, mlps.1.bn1, outer 1)
+    double *stats;                        // this forward's accumulators (zero on entry): [6][8 groups][128][2] partial | [6][128][2] total
+    double *stats_next;                   // the set of the next forward: zeroed here
+    unsigned long long *bar;              // barrier words (monotonic counters, never reset)
+    unsigned long long epoch;             // launches on `bar` so far
+    unsigned *fail;                       // set when a barrier timed out (the outputs are then garbage)
+    const int *candidate;                 // [B,J] or NULL
+    float *pooled;                        // [B,128] graph mean pool of h (gcn:192)
+    float *cand_feat;                     // [B*J,128] h rows of the candidates (ac:197-207)
+    float *h_nodes;                       // optional [B*T,128]
+    double inv_rows;                      // 1 / (B*T)
+    int barrier_only;                     // census launch: barriers only
+    unsigned long long *stamps;           // diagnostic build only (-DGR_STAMP): [blocks][64] s_memrealtime at the phase boundaries
+};
+#define GR_STATS_PART (6 * 8 * HD * 2)                            // doubles: per layer, per dispatch group: (sum, sumsq) per column
+#define GR_STATS_SET (GR_STATS_PART + 6 * HD * 2)                 // + per layer totals
+#ifdef GR_STAMP
+#define GR_STAMP_AT(i) do { if (tid == 0 && A.stamps) A.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define GR_STAMP_AT(i) do { } while (0)
+#endif
+
+// LDS map (bytes)
+#define GR_OFF_PLANES 0                                           // [2][3 planes][32 rows][272]
+#define GR_OFF_RING (2 * GR_TILE)                                 // f32 [6 tiles * 32 rows][128], swizzled (first phase: features [576][12])
+#define GR_OFF_ELLC (GR_OFF_RING + GR_RING * 32 * HD * 4)         // u32 [576]: workgroup-relative rows of the <= 2 in-edges, 0xffff = none
+#define GR_OFF_ELLV0 (GR_OFF_ELLC + GR_ROWS * 4)
+#define GR_OFF_ELLV1 (GR_OFF_ELLV0 + GR_ROWS * 4)
+#define GR_OFF_STAT (GR_OFF_ELLV1 + GR_ROWS * 4)                  // f64 [128][2]
+#define GR_OFF_BN (GR_OFF_STAT + 2 * HD * 8)                      // f32 [256] scale | shift
+#define GR_OFF_CAND (GR_OFF_BN + 2 * HD * 4)                      // i32 [GR_MAXCAND] workgroup-relative candidate rows
+#define GR_OFF_ZERO (GR_OFF_CAND + GR_MAXCAND * 4)               // f32 [256] zeros: the "scale | shift" of rows >= nrows
+#define GR_OFF_FLAG (GR_OFF_ZERO + 2 * HD * 4)
+#define GR_LDS_BYTES (GR_OFF_FLAG + 64)
+static size_t gin_res_lds_bytes() { return (size_t)GR_LDS_BYTES; }
+static_assert(GR_LDS_BYTES <= 160 * 1024, "resident GIN kernel: LDS budget");
+
+template <typename F, int... I>
+__device__ __forceinline__ void gr_static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, typename F>
+__device__ __forceinline__ void gr_static_for(F &&f) { gr_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+// sum over the 32 lanes of a half wave, result in every lane (row_sum16 + the other 16-lane row)
+__device__ __forceinline__ float gr_sum32(float x)
+{
+    x = row_sum16(x);
+    return x + __shfl_xor(x, 16);
+}
+
+// Grid-wide barrier over `nblk` co-resident workgroups that also completes a reduction: hierarchical over the 8 dispatch
+// groups blockIdx % 8 (observed to share an XCD; a different placement changes speed only).  Monotonic counters: generation
+// `gen` (1, 2, ...) is complete for a group when its counter reaches gen * group size.  Before the call every thread has
+// added its (sum | sumsq) word to part_group[tid] with a device-scope atomic and waited for it (s_waitcnt vmcnt(0)).
+// The last workgroup of a group to arrive folds the group's partial sums into `total` (again atomics, 8 adders per address);
+// the last group releases everybody.  On return (workgroup-wide) total[] may be read with sc1 loads: it is written by
+// memory-side atomics only and no line of it has been touched by this launch before.
+__device__ __forceinline__ void gr_grid_barrier(unsigned long long *bar, unsigned long long gen, unsigned nblk, unsigned *fail,
+                                                const double *part_group, double *total, unsigned *s_flag)
+{
+    const int tid = threadIdx.x;
+    const unsigned g = blockIdx.x & 7u;
+    const unsigned ngroups = nblk < 8u ? nblk : 8u;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long gsize = (nblk >> 3) + (g < (nblk & 7u) ? 1u : 0u);
+        const unsigned long long old = __hip_atomic_fetch_add(&bar[16 * g], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = (old + 1 == gen * gsize) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (*s_flag) {                                                // this workgroup completes its group (workgroup-uniform)
+        if (part_group) {
+            // the group's sums: every adder has drained its atomics before it arrived
+            const double v = __hip_atomic_load(&part_group[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&total[tid], v);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long old2 = __hip_atomic_fetch_add(&bar[16 * 8], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old2 + 1 == gen * ngroups)
+                for (unsigned j = 0; j < ngroups; j++) __hip_atomic_store(&bar[16 * (9 + j)], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (tid == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&bar[16 * (9 + g)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
+            __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) { *fail = 1u; break; }     // 4 ms at 100 MHz: not all workgroups are resident
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned char *s_planes = smem + GR_OFF_PLANES;
+    float *s_ring = reinterpret_cast<float *>(smem + GR_OFF_RING);
+    unsigned *s_ellc = reinterpret_cast<unsigned *>(smem + GR_OFF_ELLC);
+    float *s_ellv0 = reinterpret_cast<float *>(smem + GR_OFF_ELLV0);
+    float *s_ellv1 = reinterpret_cast<float *>(smem + GR_OFF_ELLV1);
+    double *s_stat = reinterpret_cast<double *>(smem + GR_OFF_STAT);
+    float *s_bn = reinterpret_cast<float *>(smem + GR_OFF_BN);
+    int *s_cand = reinterpret_cast<int *>(smem + GR_OFF_CAND);
+    float *s_zero = reinterpret_cast<float *>(smem + GR_OFF_ZERO);
+    unsigned *s_flag = reinterpret_cast<unsigned *>(smem + GR_OFF_FLAG);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int n = lane & 31, h = lane >> 5;
+    const unsigned nblk = gridDim.x;
+    const unsigned long long gen0 = A.epoch * GR_NBAR;
+    if (A.barrier_only) {
+        for (int k = 0; k < GR_NBAR; k++) gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, nullptr, nullptr, s_flag);
+        return;
+    }
+    const int T = A.T;
+    const int inst0 = blockIdx.x * A.ipc;
+    const int ninst = A.B - inst0 < A.ipc ? A.B - inst0 : A.ipc;
+    const int nrows = ninst * T;
+    const size_t grow0 = (size_t)inst0 * T;                       // first global row of this workgroup
+    // (every workgroup computes all GR_NT tiles: rows >= nrows are zero inputs, masked out of the BatchNorm sums and never
+    // written — no tile-count branches, which would split the fully unrolled body into blocks the register allocator has to
+    // reconcile through scratch memory)
+
+    // ---------------------------------------------------------------- prologue: features + adjacency to LDS, zero the planes
+    for (int i = blockIdx.x * 256 + tid; i < GR_STATS_SET; i += (int)nblk * 256) A.stats_next[i] = 0.0;
+    {
+        float *s_feat = s_ring;                                   // [nrows][12]
+        if (A.feat_f64) {
+            const double *src = reinterpret_cast<const double *>(A.tfea) + grow0 * 12;
+            for (int i = tid; i < nrows * 12; i += 256) s_feat[i] = (float)src[i];
+        } else {
+            const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(A.tfea) + grow0 * 12);
+            for (int i = tid; i < nrows * 3; i += 256) reinterpret_cast<float4 *>(s_feat)[i] = src[i];
+        }
+        for (int r = tid; r < GR_ROWS; r += 256) {
+            unsigned cp = 0xffffffffu; float v0 = 0.f, v1 = 0.f;
+            if (r < nrows) {
+                const int2 cc = *reinterpret_cast<const int2 *>(A.ell_col + (grow0 + r) * 2);
+                const float2 vv = *reinterpret_cast<const float2 *>(A.ell_val + (grow0 + r) * 2);
+                const int base = (r / T) * T;
+                const unsigned r0 = cc.x >= 0 ? (unsigned)(base + cc.x) : 0xffffu, r1 = cc.y >= 0 ? (unsigned)(base + cc.y) : 0xffffu;
+                cp = r0 | (r1 << 16); v0 = cc.x >= 0 ? vv.x : 0.f; v1 = cc.y >= 0 ? vv.y : 0.f;
+            }
+            s_ellc[r] = cp; s_ellv0[r] = v0; s_ellv1[r] = v1;
+        }
+        for (int i = tid; i < 2 * GR_TILE / 16; i += 256) reinterpret_cast<float4 *>(s_planes)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (A.candidate)
+            for (int i = tid; i < ninst * A.J; i += 256) s_cand[i] = (i / A.J) * T + A.candidate[(size_t)inst0 * A.J + i];
+        s_stat[tid] = 0.0;
+        s_zero[tid] = 0.f;
+    }
+    f32x16 acc[GR_NT];
+    bf16x8 wf[3][8];
+    float ts[16], tq[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) { ts[i] = 0.f; tq[i] = 0.f; }
+
+    auto load_weights = [&](int layer, auto KSc) __attribute__((always_inline)) {
+        constexpr int KS = decltype(KSc)::value;
+        const float4 *wi = reinterpret_cast<const float4 *>(A.Wx32[layer]) + (size_t)wave * (3 * KS * 64) + lane;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) wf[p][ks] = __builtin_bit_cast(bf16x8, wi[(p * KS + ks) * 64]);
+    };
+    // BatchNorm statistics.  stats_tile: this lane's row of tile RT into the per-lane column sums (one value per tile and lane:
+    // f32 is ample) — called one tile late, so that it never waits for the matrix pipe.  Rows >= nrows need no mask: their
+    // operand planes are written as zeros (scale = shift = 0 below), and without a bias a zero row stays exactly zero.
+    auto stats_tile = [&](auto Tc) __attribute__((always_inline)) {
+        constexpr int RT = decltype(Tc)::value;
+        if (GR_ABL & 4) return;
+        const f32x16 &a = acc[RT];
+#pragma unroll
+        for (int e = 0; e < 16; e++) { ts[e] += a[e]; tq[e] = __builtin_fmaf(a[e], a[e], tq[e]); asm volatile("" : "+v"(ts[e]), "+v"(tq[e])); }   // (pinned here: hipcc would sink the whole layer's sums to their use)
+    };
+    // sums over the 32 rows of the lanes -> the owner lanes (n == 0) store the workgroup's (sum, sumsq) per column as f64.  Once per layer.
+    auto fold_stats = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const float a = gr_sum32(ts[e]), b = gr_sum32(tq[e]);
+            const int col = 32 * wave + 8 * (e >> 2) + 4 * h + (e & 3);
+            if (n == 0) *reinterpret_cast<double2 *>(s_stat + 2 * col) = make_double2((double)a, (double)b);
+            ts[e] = 0.f; tq[e] = 0.f;
+        }
+    };
+    // BatchNorm + ReLU of columns 8g+4h..+3 of tile rt's resident values -> exact split -> planes of buffer buf
+    auto produce_quarter = [&](auto Tc, auto Gc, int buf) __attribute__((always_inline)) {
+        constexpr int rt = decltype(Tc)::value, g = decltype(Gc)::value;
+        unsigned char *dst = s_planes + buf * GR_TILE + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
+        const float *bn = rt * 32 + n < nrows ? s_bn : s_zero;    // rows >= nrows: scale = shift = 0 -> zero planes
+        const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);        // scale | shift of these 4 columns
+        const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
+        const f32x16 &a = acc[rt];
+        const float v[4] = {bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y), bn_relu_ss(a[4 * g + 2], s4.z, h4.z),
+                            bn_relu_ss(a[4 * g + 3], s4.w, h4.w)};
+        uint2 p0, p1, p2;
+        split3x4(v, p0, p1, p2);
+        *reinterpret_cast<uint2 *>(dst) = p0;
+        *reinterpret_cast<uint2 *>(dst + GR_PLANE) = p1;
+        *reinterpret_cast<uint2 *>(dst + 2 * GR_PLANE) = p2;
+    };
+    auto produce_tile = [&](auto Tc, int buf) __attribute__((always_inline)) {
+        gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) { produce_quarter(Tc, Gc, buf); });
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // multiply tile RT (planes in buffer `buf`) by the resident weight fragments -> acc[RT].  One wave per SIMD is in-order: a
+    // vector instruction placed behind a run of matrix instructions waits for all of them to issue, and the matrix pipe then idles
+    // behind a run of vector instructions.  hipcc emits each kind as one clump (and sched_group_barrier did not change that
+    // here), so the stream is hand-placed: 48 slices of ONE matrix instruction + 3..5 vector / LDS instructions, each closed by
+    // a scheduling barrier.  The vector work riding along is a quarter (per 12 slices) of the NEXT tile's plane production
+    // (BatchNorm + ReLU + exact split of its resident values) and of the PREVIOUS tile's BatchNorm sums, plus the operand reads
+    // of the following k-steps.
+    const unsigned char *xa0 = s_planes + n * GR_ROWB + 16 * h;
+#define GR_FENCE() __builtin_amdgcn_sched_barrier(0)
+    auto consume_tile = [&](auto Tc, auto NEXTc, int buf) __attribute__((always_inline)) {
+        constexpr int RT = decltype(Tc)::value;
+        constexpr bool NEXT = decltype(NEXTc)::value && (RT + 1 < GR_NT) && !(GR_ABL & 1);
+        constexpr bool STATS = RT > 0 && !(GR_ABL & 4);
+        const unsigned char *xa = xa0 + buf * GR_TILE;
+        const int nb = (RT + 1) & 1;
+        const float *bn = (RT + 1) * 32 + n < nrows ? s_bn : s_zero;      // rows >= nrows: scale = shift = 0 -> zero planes
+        bf16x8 xf[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + p * GR_PLANE);
+        float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = s4;
+        if constexpr (NEXT) {
+            s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 4 * h);
+            h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 4 * h);
+        }
+        f32x16 &a = acc[RT];                                          // (its previous-layer values went into the planes one tile ago)
+        a = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
+            constexpr int g = decltype(Pc)::value;                       // region = k-steps 2g, 2g+1 = column quarter g of the next tile
+            const bf16x8 *x0 = xf[0], *x1 = xf[1];
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            float4 s4n = s4, h4n = h4;
+            unsigned pa = 0, pb = 0, qa = 0, qb = 0, ra = 0, rb = 0;
+            unsigned char *dst = s_planes + nb * GR_TILE + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
+            const f32x16 &nx = acc[RT + 1 < GR_NT ? RT + 1 : RT];
+            const f32x16 &pv = acc[RT > 0 ? RT - 1 : RT];
+            auto M = [&](int ks, int wp, int xp) __attribute__((always_inline)) {
+                if (!(GR_ABL & 2)) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
+            };
+            auto cvt2 = [&](float lo, float hi) __attribute__((always_inline)) {
+                return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));          // v_cvt_pk_bf16_f32
+            };
+            // slice 0
+            M(2 * g, 0, 2);                                              // smallest terms first: w0 x2, w2 x0, w1 x1, w0 x1, w1 x0, w0 x0
+            xf[1][0] = *reinterpret_cast<const bf16x8 *>(xa + 0 * GR_PLANE + 32 * (2 * g + 1));
+            if constexpr (NEXT) { v0 = bn_relu_ss(nx[4 * g], s4.x, h4.x); v1 = bn_relu_ss(nx[4 * g + 1], s4.y, h4.y); }
+            GR_FENCE();
+            // slice 1
+            M(2 * g, 2, 0);
+            xf[1][1] = *reinterpret_cast<const bf16x8 *>(xa + 1 * GR_PLANE + 32 * (2 * g + 1));
+            if constexpr (NEXT) { v2 = bn_relu_ss(nx[4 * g + 2], s4.z, h4.z); v3 = bn_relu_ss(nx[4 * g + 3], s4.w, h4.w); }
+            GR_FENCE();
+            // slice 2
+            M(2 * g, 1, 1);
+            xf[1][2] = *reinterpret_cast<const bf16x8 *>(xa + 2 * GR_PLANE + 32 * (2 * g + 1));
+            if constexpr (NEXT) { pa = cvt2(v0, v1); pb = cvt2(v2, v3); v0 -= __builtin_bit_cast(float, pa << 16); }
+            if constexpr (NEXT && g < 3) s4n = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * (g + 1) + 4 * h);   // scale | shift of the next quarter:
+            GR_FENCE();
+            // slice 3
+            M(2 * g, 0, 1);
+            if constexpr (NEXT) { v1 -= __builtin_bit_cast(float, pa & 0xffff0000u); v2 -= __builtin_bit_cast(float, pb << 16); }
+            if constexpr (NEXT && g < 3) h4n = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * (g + 1) + 4 * h);   // ... nine slices ahead of its use
+            GR_FENCE();
+            // slice 4
+            M(2 * g, 1, 0);
+            if constexpr (NEXT) { v3 -= __builtin_bit_cast(float, pb & 0xffff0000u); qa = cvt2(v0, v1); *reinterpret_cast<uint2 *>(dst) = make_uint2(pa, pb); }
+            GR_FENCE();
+            // slice 5
+            M(2 * g, 0, 0);
+            if constexpr (NEXT) { qb = cvt2(v2, v3); v0 -= __builtin_bit_cast(float, qa << 16); }
+            GR_FENCE();
+            // slice 6: the k-step 2g operands are dead once its six instructions have issued
+            M(2 * g + 1, 0, 2);
+            if constexpr (g < 3) xf[0][0] = *reinterpret_cast<const bf16x8 *>(xa + 0 * GR_PLANE + 32 * (2 * g + 2));
+            if constexpr (NEXT) { v1 -= __builtin_bit_cast(float, qa & 0xffff0000u); v2 -= __builtin_bit_cast(float, qb << 16); }
+            GR_FENCE();
+            // slice 7
+            M(2 * g + 1, 2, 0);
+            if constexpr (g < 3) xf[0][1] = *reinterpret_cast<const bf16x8 *>(xa + 1 * GR_PLANE + 32 * (2 * g + 2));
+            if constexpr (NEXT) { v3 -= __builtin_bit_cast(float, qb & 0xffff0000u); ra = cvt2(v0, v1); *reinterpret_cast<uint2 *>(dst + GR_PLANE) = make_uint2(qa, qb); }
+            GR_FENCE();
+            // slice 8
+            M(2 * g + 1, 1, 1);
+            if constexpr (g < 3) xf[0][2] = *reinterpret_cast<const bf16x8 *>(xa + 2 * GR_PLANE + 32 * (2 * g + 2));
+            if constexpr (NEXT) { rb = cvt2(v2, v3); }
+            if constexpr (STATS) { ts[4 * g] += pv[4 * g]; tq[4 * g] = __builtin_fmaf(pv[4 * g], pv[4 * g], tq[4 * g]); asm volatile("" : "+v"(ts[4 * g]), "+v"(tq[4 * g])); }
+            GR_FENCE();
+            // slice 9
+            M(2 * g + 1, 0, 1);
+            if constexpr (NEXT) { *reinterpret_cast<uint2 *>(dst + 2 * GR_PLANE) = make_uint2(ra, rb); }
+            if constexpr (STATS) { ts[4 * g + 1] += pv[4 * g + 1]; tq[4 * g + 1] = __builtin_fmaf(pv[4 * g + 1], pv[4 * g + 1], tq[4 * g + 1]); asm volatile("" : "+v"(ts[4 * g + 1]), "+v"(tq[4 * g + 1])); }
+            GR_FENCE();
+            // slice 10
+            M(2 * g + 1, 1, 0);
+            if constexpr (STATS) { ts[4 * g + 2] += pv[4 * g + 2]; tq[4 * g + 2] = __builtin_fmaf(pv[4 * g + 2], pv[4 * g + 2], tq[4 * g + 2]); asm volatile("" : "+v"(ts[4 * g + 2]), "+v"(tq[4 * g + 2])); }
+            GR_FENCE();
+            // slice 11
+            M(2 * g + 1, 0, 0);
+            s4 = s4n; h4 = h4n;
+            if constexpr (STATS) { ts[4 * g + 3] += pv[4 * g + 3]; tq[4 * g + 3] = __builtin_fmaf(pv[4 * g + 3], pv[4 * g + 3], tq[4 * g + 3]); asm volatile("" : "+v"(ts[4 * g + 3]), "+v"(tq[4 * g + 3])); }
+            GR_FENCE();
+        });
+    };
+    // first Linear: tile RT's 16-wide operand sits at byte offset 32*(RT & 7) of buffer 0's rows
+    auto consume_tile0 = [&](auto Tc) __attribute__((always_inline)) {
+        constexpr int RT = decltype(Tc)::value;
+        const unsigned char *xa = xa0 + 32 * (RT & 7);
+        bf16x8 x[3];
+#pragma unroll
+        for (int p = 0; p < 3; p++) x[p] = *reinterpret_cast<const bf16x8 *>(xa + p * GR_PLANE);
+        f32x16 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][0], x[2], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2][0], x[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][0], x[1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][0], x[1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][0], x[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][0], x[0], a, 0, 0, 0);
+        acc[RT] = a;
+        if constexpr (RT > 0) stats_tile(std::integral_constant<int, RT - 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // this workgroup's column sums -> its dispatch group's accumulators, grid barrier `k` (which folds the groups into the totals),
+    // then the BatchNorm scale / shift of the NEXT layer's input from the complete sums
+    auto layer_boundary = [&](auto Kc) __attribute__((always_inline)) {
+        constexpr int k = decltype(Kc)::value;
+        GR_STAMP_AT(4 + 4 * k);
+        stats_tile(std::integral_constant<int, GR_NT - 1>{});
+        fold_stats();
+        if (k == 1) GR_STAMP_AT(2);
+        LDS_BARRIER();
+        double *part = A.stats + ((size_t)k * 8 + (blockIdx.x & 7)) * (2 * HD);
+        double *total = A.stats + GR_STATS_PART + (size_t)k * (2 * HD);
+        {
+            atomicAdd(&part[tid], s_stat[tid]);                   // [col][2] interleaved: thread tid -> (column tid >> 1, sum | sumsq)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (k == 1) GR_STAMP_AT(3);
+        // requests that do not depend on the other workgroups go out before the wait: the next Linear's weight fragments
+        // and this BatchNorm's affine parameters
+        if constexpr (k < 5) load_weights(k + 1, std::integral_constant<int, 8>{});
+        const float ga = A.gamma[k][tid & (HD - 1)], be = A.beta[k][tid & (HD - 1)];
+        GR_STAMP_AT(5 + 4 * k);
+        gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, part, total, s_flag);
+        GR_STAMP_AT(6 + 4 * k);
+        if (tid < HD) {
+            const double su = __hip_atomic_load(&total[2 * tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double sq = __hip_atomic_load(&total[2 * tid + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double mean = su * A.inv_rows;
+            double var = sq * A.inv_rows - mean * mean;           // biased variance (training-mode BN)
+            if (var < 0) var = 0;
+            const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
+            const float s = rstd * ga;
+            s_bn[tid] = s;
+            s_bn[HD + tid] = be - (float)mean * s;
+        }
+        LDS_BARRIER();
+        GR_STAMP_AT(7 + 4 * k);
+    };
+
+    // ---------------------------------------------------------------- layer 0 / Linear 0: aggregated raw features (12 -> 128)
+    GR_STAMP_AT(0);
+    load_weights(0, std::integral_constant<int, 1>{});
+    LDS_BARRIER();
+    GR_STAMP_AT(1);
+    {
+        const float *s_feat = s_ring;
+        // The operand of this Linear is 16 wide (12 features + 4 zeros) = 32 bytes of a plane row, so one plane buffer takes the
+        // operands of 8 tiles side by side (tile t at byte offset 32*(t & 7)): 3 barriers for the whole layer.
+        // wave w fills rows 8w..8w+7 of a tile: lane = (row r = lane >> 3, feature pair fk = lane & 7 < 6)
+        auto produce0 = [&](int rt) __attribute__((always_inline)) {
+            const int r = 8 * wave + (lane >> 3), fk = lane & 7, row = rt * 32 + r;
+            const int fo = fk < 6 ? 2 * fk : 0;
+            const unsigned cp = s_ellc[row];
+            const unsigned r0 = cp & 0xffffu, r1 = cp >> 16;
+            const int deg = 1 + (r0 != 0xffffu) + (r1 != 0xffffu);
+            const float inv = deg == 1 ? 1.0f : deg == 2 ? 0.5f : (1.0f / 3.0f);
+            const float w0 = s_ellv0[row], w1 = s_ellv1[row];            // 0 where there is no edge (and for rows >= nrows)
+            const int n0 = r0 != 0xffffu ? (int)r0 : row, n1 = r1 != 0xffffu ? (int)r1 : row;
+            const float2 o = *reinterpret_cast<const float2 *>(s_feat + row * 12 + fo);
+            const float2 x = *reinterpret_cast<const float2 *>(s_feat + n0 * 12 + fo);
+            const float2 y = *reinterpret_cast<const float2 *>(s_feat + n1 * 12 + fo);
+            // gcn:125-153 (A_w @ h) / nnz_row on the raw features; small-integer weights, <= 3 terms: f32 FMA chain
+            float v[4] = {__builtin_fmaf(w1, y.x, __builtin_fmaf(w0, x.x, o.x)) * inv, __builtin_fmaf(w1, y.y, __builtin_fmaf(w0, x.y, o.y)) * inv, 0.f, 0.f};
+            if (row >= nrows) { v[0] = 0.f; v[1] = 0.f; }
+            uint2 p0, p1, p2;
+            split3x4(v, p0, p1, p2);                              // elements 2, 3 are padding
+            unsigned char *d = s_planes + r * GR_ROWB + 32 * (rt & 7) + 4 * fk;
+            if (fk < 6) {
+                *reinterpret_cast<unsigned *>(d) = p0.x;
+                *reinterpret_cast<unsigned *>(d + GR_PLANE) = p1.x;
+                *reinterpret_cast<unsigned *>(d + 2 * GR_PLANE) = p2.x;
+            }
+        };
+        gr_static_for<(GR_NT + 7) / 8>([&](auto Cc) __attribute__((always_inline)) {
+            constexpr int C = decltype(Cc)::value;
+            constexpr int NTC = GR_NT - 8 * C < 8 ? GR_NT - 8 * C : 8;
+#pragma unroll
+            for (int i = 0; i < NTC; i++) produce0(8 * C + i);
+            LDS_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+            gr_static_for<NTC>([&](auto Ic) __attribute__((always_inline)) {
+                constexpr int RT = 8 * C + decltype(Ic)::value;
+                consume_tile0(std::integral_constant<int, RT>{});
+            });
+            LDS_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    layer_boundary(std::integral_constant<int, 0>{});
+
+    // ---------------------------------------------------------------- Linears 1..5 (the fourth, layer 3, aggregates over the graph first)
+    // (straight-line over the layers: a run-time loop would carry all 288 accumulators through its back edge, which the register
+    // allocator resolves through scratch memory)
+    gr_static_for<5>([&](auto Lc) __attribute__((always_inline)) {
+        constexpr int layer = decltype(Lc)::value + 1;
+        if constexpr (layer != 3) {
+            produce_tile(std::integral_constant<int, 0>{}, 0);
+            LDS_BARRIER();
+            gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
+                constexpr int RT = decltype(Tc)::value;
+                consume_tile(Tc, std::true_type{}, RT & 1);       // produces tile RT+1 between its matrix instructions
+                LDS_BARRIER();
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        } else {
+            // gcn:125-149: (A_w @ h) / nnz_row with h = relu(bn_outer0(z)), A_w incl. the self loop.  h tiles go through a ring of
+            // GR_RING tiles in LDS; tile rt's rows and their in-edge sources (same instance, T <= 65 rows) lie in tiles rt-2..rt+2
+            auto write_h = [&](auto Tc) __attribute__((always_inline)) {
+                constexpr int rt = decltype(Tc)::value;
+                float *base = s_ring + ((rt % GR_RING) * 32 + n) * HD;
+                gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) {
+                    constexpr int g = decltype(Gc)::value;
+                    const float *bn = rt * 32 + n < nrows ? s_bn : s_zero;
+                    const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);
+                    const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
+                    const f32x16 &a = acc[rt];
+                    const int ch = (8 * wave + 2 * g + h) ^ (n & 7);
+                    *reinterpret_cast<float4 *>(base + 4 * ch) = make_float4(bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y),
+                                                                             bn_relu_ss(a[4 * g + 2], s4.z, h4.z), bn_relu_ss(a[4 * g + 3], s4.w, h4.w));
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            auto ring_row = [&](int R) __attribute__((always_inline)) {      // workgroup-relative row -> float offset of its ring row
+                const int t = R >> 5;
+                return ((t - GR_RING * ((t * 43) >> 8)) * 32 + (R & 31)) * HD;   // t % 6 for t < 128
+            };
+            write_h(std::integral_constant<int, 0>{}); write_h(std::integral_constant<int, 1>{}); write_h(std::integral_constant<int, 2>{});
+            LDS_BARRIER();
+            gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
+                constexpr int RT = decltype(Tc)::value;
+                {
+                    const int row = RT * 32 + n;
+                    const unsigned cp = s_ellc[row];
+                    const unsigned r0 = cp & 0xffffu, r1 = cp >> 16;
+                    const float w0 = s_ellv0[row], w1 = s_ellv1[row];
+                    const int deg = 1 + (r0 != 0xffffu) + (r1 != 0xffffu);
+                    const float inv = deg == 1 ? 1.0f : deg == 2 ? 0.5f : (1.0f / 3.0f);
+                    const int n0 = r0 != 0xffffu ? (int)r0 : row, n1 = r1 != 0xffffu ? (int)r1 : row;
+                    const float *po = s_ring + ((RT % GR_RING) * 32 + n) * HD, *px = s_ring + ring_row(n0), *py = s_ring + ring_row(n1);
+                    unsigned char *dst = s_planes + (RT & 1) * GR_TILE + n * GR_ROWB + (32 * wave + 4 * h) * 2;
+                    gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) {
+                        constexpr int g = decltype(Gc)::value;
+                        const int chl = 8 * wave + 2 * g + h;
+                        const float4 o = *reinterpret_cast<const float4 *>(po + 4 * (chl ^ (n & 7)));
+                        const float4 x = *reinterpret_cast<const float4 *>(px + 4 * (chl ^ (n0 & 7)));
+                        const float4 y = *reinterpret_cast<const float4 *>(py + 4 * (chl ^ (n1 & 7)));
+                        // small-integer edge weights, <= 3 terms: an f32 FMA chain is within 2 ulp of the reference's f64-then-cast
+                        const float v[4] = {__builtin_fmaf(w1, y.x, __builtin_fmaf(w0, x.x, o.x)) * inv, __builtin_fmaf(w1, y.y, __builtin_fmaf(w0, x.y, o.y)) * inv,
+                                            __builtin_fmaf(w1, y.z, __builtin_fmaf(w0, x.z, o.z)) * inv, __builtin_fmaf(w1, y.w, __builtin_fmaf(w0, x.w, o.w)) * inv};
+                        uint2 p0, p1, p2;
+                        split3x4(v, p0, p1, p2);
+                        *reinterpret_cast<uint2 *>(dst + 16 * g) = p0;
+                        *reinterpret_cast<uint2 *>(dst + 16 * g + GR_PLANE) = p1;
+                        *reinterpret_cast<uint2 *>(dst + 16 * g + 2 * GR_PLANE) = p2;
+                    });
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (RT + 3 < GR_NT) write_h(std::integral_constant<int, RT + 3>{});     // into the slot of tile RT-3 (no longer needed)
+                LDS_BARRIER();
+                __builtin_amdgcn_sched_barrier(0);
+                consume_tile(Tc, std::false_type{}, RT & 1);
+            });
+            LDS_BARRIER();
+        }
+        layer_boundary(std::integral_constant<int, layer>{});
+    });
+
+    GR_STAMP_AT(30);
+    // ---------------------------------------------------------------- h = relu(bn_outer1(z)): graph mean pool, candidate gather, node embeddings
+    {
+        auto write_h2 = [&](auto Tc) __attribute__((always_inline)) {       // tile rt -> slot rt & 1 of the ring area
+            constexpr int rt = decltype(Tc)::value;
+            float *base = s_ring + ((rt & 1) * 32 + n) * HD;
+            gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) {
+                constexpr int g = decltype(Gc)::value;
+                const float4 s4 = *reinterpret_cast<const float4 *>(s_bn + 32 * wave + 8 * g + 4 * h);
+                const float4 h4 = *reinterpret_cast<const float4 *>(s_bn + HD + 32 * wave + 8 * g + 4 * h);
+                const f32x16 &a = acc[rt];
+                const int ch = (8 * wave + 2 * g + h) ^ (n & 7);
+                *reinterpret_cast<float4 *>(base + 4 * ch) = make_float4(bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y),
+                                                                         bn_relu_ss(a[4 * g + 2], s4.z, h4.z), bn_relu_ss(a[4 * g + 3], s4.w, h4.w));
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // graph mean pool (gcn:192): per-instance column sums accumulate in LDS (behind the two h slots of the ring area); thread =
+        // (column, half of the tile's rows) adds runs of rows of one instance with one LDS atomic per run
+        float *s_pool = s_ring + 2 * 32 * HD;                     // [ipc][128]
+        unsigned char *s_inst = reinterpret_cast<unsigned char *>(s_pool + GR_MAXIPC * HD);   // [576] instance of every row, 255 = none
+        for (int i = tid; i < A.ipc * HD; i += 256) s_pool[i] = 0.f;
+        for (int r = tid; r < GR_ROWS; r += 256) s_inst[r] = (unsigned char)(r < nrows ? r / T : 255);
+        const int ncand = A.candidate ? ninst * A.J : 0;
+        // candidates of this wave: lane i holds the row of candidate wave + 4i (GR_MAXCAND / 4 <= 96 > 64: two registers)
+        int crow0 = -1, crow1 = -1;
+        if (wave + 4 * lane < ncand) crow0 = s_cand[wave + 4 * lane];
+        if (wave + 4 * (lane + 64) < ncand) crow1 = s_cand[wave + 4 * (lane + 64)];
+        write_h2(std::integral_constant<int, 0>{});
+        LDS_BARRIER();
+        gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
+            constexpr int RT = decltype(Tc)::value;
+            if constexpr (RT + 1 < GR_NT) write_h2(std::integral_constant<int, RT + 1>{});
+            const float *slot = s_ring + (RT & 1) * 32 * HD;
+            {   // 16 rows of one column: at most two instances (T >= 16); the run boundary comes from the rows' instance ids
+                const int col = tid & (HD - 1), r0 = 16 * (tid >> 7);
+                const int i0 = s_inst[RT * 32 + r0], i1 = s_inst[RT * 32 + r0 + 15];
+                float run0 = 0.f, run1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int r = r0 + i;
+                    const float x = slot[r * HD + 4 * ((col >> 2) ^ (r & 7)) + (col & 3)];
+                    const bool first = s_inst[RT * 32 + r] == i0;
+                    run0 += first ? x : 0.f; run1 += first ? 0.f : x;
+                }
+                if (i0 != 255) atomicAdd(&s_pool[i0 * HD + col], run0);
+                if (i1 != i0 && i1 != 255) atomicAdd(&s_pool[i1 * HD + col], run1);
+            }
+            // ac:197-207: the candidates whose row lies in this tile (about one per wave and tile), one wave per row, 8 bytes per lane
+            for (int part = 0; part < 2; part++) {
+                const int cr = part ? crow1 : crow0;
+                unsigned long long mask = __ballot(cr >= 0 && (cr >> 5) == RT);
+                while (mask) {
+                    const int i = __builtin_ctzll(mask);
+                    mask &= mask - 1;
+                    const int R = __builtin_amdgcn_readlane(cr, i), idx = wave + 4 * (i + 64 * part);
+                    const int r = R & 31, col = 2 * lane;
+                    const float2 x = *reinterpret_cast<const float2 *>(slot + r * HD + 4 * ((col >> 2) ^ (r & 7)) + (col & 3));
+                    *reinterpret_cast<float2 *>(A.cand_feat + ((size_t)inst0 * A.J + idx) * HD + col) = x;
+                }
+            }
+            if (A.h_nodes) {
+                for (int r = wave; r < 32; r += 4) {
+                    if (RT * 32 + r < nrows) {
+                        const int col = 2 * lane;
+                        const float2 x = *reinterpret_cast<const float2 *>(slot + r * HD + 4 * ((col >> 2) ^ (r & 7)) + (col & 3));
+                        *reinterpret_cast<float2 *>(A.h_nodes + (grow0 + RT * 32 + r) * HD + col) = x;
+                    }
+                }
+            }
+            LDS_BARRIER();
+        });
+        const float invT = 1.0f / (float)T;
+        for (int i = tid; i < ninst * HD; i += 256) A.pooled[(size_t)inst0 * HD + i] = s_pool[i] * invT;
+    }
+    GR_STAMP_AT(31);
+}

@@ -16,7 +16,7 @@ from . import capi
 
 H = 128
 FAMILIES = ["gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg", "job_pool_gather", "heads", "head_gemm", "gat3", "mach_bn_pool",
-            "sample", "small", "gin_inst", "gat_inst"]
+            "sample", "small", "gin_inst", "gat_inst", "gin_resident"]
 
 
 def available():
@@ -139,8 +139,16 @@ class Encoder:
 
     def set_product_mode(self, f32_instruction_mask=0):
         """0 (default): 128x128 products as exact 3-way bf16 splits on the matrix cores (f32-accurate); bits select the f32
-        matrix instruction instead (1 GIN products, 2 GAT passes, 4 heads, 8 first GIN Linear on the VALU) — the A/B reference"""
+        matrix instruction instead (1 GIN products, 2 GAT passes, 4 heads, 8 first GIN Linear on the VALU) — the A/B reference;
+        16: the GIN encoder as six streaming launches even where the register-resident single-launch kernel is eligible"""
         capi.check(self.L.mtfjsp_encoder_set_product_mode(self.h, int(f32_instruction_mask)), self.h, enc=True)
+
+    def check(self):
+        """synchronise and raise if a forward failed asynchronously (bounded grid-barrier spins of the single-launch GIN kernel);
+        -> True when that kernel is in use for this shape, False when the six streaming launches are"""
+        r = C.c_int32(0)
+        capi.check(self.L.mtfjsp_encoder_check(self.h, C.byref(r)), self.h, enc=True)
+        return bool(r.value)
 
     def arm_selection(self, which, greedy, seed, counter, idx_out, logp_out=None, gather_from=None, gathered_out=None):
         """fuse the action selection of the next job (which=0) / machine (which=1) actor forward into its heads kernel; same

@@ -217,6 +217,8 @@ class Rollout:
 
     def check_finished_cleanly(self):
         st = self.env.status
+        if self.actor is not None:
+            self.actor.enc.check()
         assert int((st & capi.ST_INVALID).sum().item()) == 0, "rollout produced invalid actions"
         if self.t_in_ep == 0 and self.nsteps > 0:
             assert bool(self.env.info[:, 1].all().item()), "episode boundary without done"
