@@ -2390,10 +2390,11 @@ struct mtfjsp_encoder {
     int f32_products = (getenv("MTFJSP_GEMM_F32MFMA") ? 1 : 0) | (getenv("MTFJSP_GAT_F32MFMA") ? 2 : 0) |
                        (getenv("MTFJSP_HEADS_F32MFMA") ? 4 : 0) | (getenv("MTFJSP_GIN0_VALU") ? 8 : 0);
     // resident GIN kernel (mtfjsp_gin_resident.h): eligibility decided at create time, then verified by a census launch
-    bool res_ok = false; int res_ipc = 0, res_grid = 0;
+    bool res_ok = false, res_default = false; int res_ipc = 0, res_grid = 0;
     double *res_stats = nullptr;            // [2 sets][GR_STATS_SET]; forward n uses set n & 1 and zeroes the other one
     unsigned long long *res_bar = nullptr;  // [17 * 16] barrier words
     unsigned *res_fail = nullptr;
+    float *res_zspill = nullptr;            // [grid][4][2][1024] f32: the two row tiles per workgroup that do not fit the registers
     unsigned long long res_epoch = 0;
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
     mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
@@ -2511,7 +2512,8 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
             const int grid = (B + ipc - 1) / ipc;
             if (ipc * T <= GR_ROWS && ipc <= GR_MAXIPC && grid <= e->num_cu && ipc * cfg->n_job <= GR_MAXCAND &&
                 hipFuncSetAttribute((const void *)k_gin_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gin_res_lds_bytes()) == hipSuccess) {
-                int rc = dalloc(e, &e->res_stats, (size_t)2 * GR_STATS_SET) | dalloc(e, &e->res_bar, (size_t)17 * 16) | dalloc(e, &e->res_fail, (size_t)4);
+                int rc = dalloc(e, &e->res_stats, (size_t)2 * GR_STATS_SET) | dalloc(e, &e->res_bar, (size_t)17 * 16) | dalloc(e, &e->res_fail, (size_t)4) |
+                         dalloc(e, &e->res_zspill, (size_t)grid * 4 * (GR_NT - GR_NRES) * 1024);
                 if (!rc && hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8) == hipSuccess &&
                     hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8) == hipSuccess && hipMemset(e->res_fail, 0, 16) == hipSuccess) {
                     // census: every workgroup must be resident at once for the grid barriers to complete (bounded spins report it)
@@ -2521,6 +2523,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
                     unsigned failed = 1;
                     if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&failed, e->res_fail, 4, hipMemcpyDeviceToHost) == hipSuccess && !failed) {
                         e->res_ok = true; e->res_ipc = ipc; e->res_grid = grid;
+                        e->res_default = getenv("MTFJSP_RESIDENT_GIN") != nullptr;
                     } else {       // leave the streaming kernels in charge; fresh barrier words in case the census is retried elsewhere
                         (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); (void)hipMemset(e->res_fail, 0, 16);
                     }
@@ -2900,7 +2903,7 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
     a.stats = e->res_stats + (size_t)set * GR_STATS_SET;
     a.stats_next = e->res_stats + (size_t)(set ^ 1) * GR_STATS_SET;
     a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail;
-    a.candidate = candidate; a.pooled = h_pooled; a.cand_feat = cand_feat; a.h_nodes = h_nodes;
+    a.candidate = candidate; a.pooled = h_pooled; a.cand_feat = cand_feat; a.h_nodes = h_nodes; a.zspill = e->res_zspill;
     a.inv_rows = 1.0 / ((double)B * (double)T);
 #ifdef GR_STAMP
     static unsigned long long *d_st = nullptr;
@@ -2919,9 +2922,9 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
         (void)hipMemcpy(h.data(), d_st, h.size() * 8, hipMemcpyDeviceToHost);
         // per stamp index: mean over blocks of (stamp - min over blocks of stamp 0), in us (s_memrealtime = 100 MHz)
         unsigned long long t0 = ~0ull;
-        for (int b = 0; b < e->res_grid; b++) t0 = h[(size_t)b * 64] < t0 ? h[(size_t)b * 64] : t0;
+        for (int b = 0; b < e->res_grid; b++) t0 = h[(size_t)b * 64 + 32] < t0 ? h[(size_t)b * 64 + 32] : t0;
         printf("GR_STAMP (us since first block start; mean / max over %d blocks):", e->res_grid);
-        for (int i = 0; i < 32; i++) {
+        for (int i = 0; i < 33; i++) {
             double m = 0, mx = 0;
             for (int b = 0; b < e->res_grid; b++) { const double v = (double)(h[(size_t)b * 64 + i] - t0) / 100.0; m += v; mx = v > mx ? v : mx; }
             printf(" [%d] %.1f/%.1f", i, m / e->res_grid, mx);
@@ -3112,7 +3115,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     // the heads kernel does BatchNorm+ReLU, graph pool and candidate gather itself — while T is small: a workgroup pools 16
     // instances with 512 threads, which is too little parallelism for 400-row instances (J20M20: 199 vs 81+113 us measured)
-    const bool resident = !e->bn_mode && e->res_ok && !(e->f32_products & (1 | 8 | 16));
+    const bool resident = !e->bn_mode && e->res_ok && (e->res_default || (e->f32_products & 16)) && !(e->f32_products & (1 | 8));
     const bool fuse_pool = !e->bn_mode && !resident && !h_nodes && e->T <= 128;
     rc = e->bn_mode ? run_gin_inst(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
          : resident ? run_gin_resident(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
@@ -3244,7 +3247,7 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
     const int B = e->cfg.batch;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
-    const bool resident = e->res_ok && !(e->f32_products & (1 | 8 | 16));
+    const bool resident = e->res_ok && (e->res_default || (e->f32_products & 16)) && !(e->f32_products & (1 | 8));
     int rc = resident ? run_gin_resident(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr)
                       : run_gin(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr);
     if (rc) return rc;
@@ -3304,7 +3307,7 @@ extern "C" int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_ou
     if (!e) return MTFJSP_ERR_ARG;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (gin_resident_out) *gin_resident_out = e->res_ok ? 1 : 0;
+    if (gin_resident_out) *gin_resident_out = (e->res_ok && (e->res_default || (e->f32_products & 16)) && !(e->f32_products & (1 | 8))) ? 1 : 0;
     if (e->res_ok) {
         unsigned failed = 0;
         HIPCHK(e, hipMemcpy(&failed, e->res_fail, 4, hipMemcpyDeviceToHost));

@@ -31,6 +31,9 @@
 #define GR_ABL 0
 #endif
 #define GR_NT 18                          // row tiles per workgroup (576 rows)
+#ifndef GR_NRES
+#define GR_NRES 16                        // ... of which this many stay in registers; the others go through zspill (see below)
+#endif
 #define GR_ROWS (32 * GR_NT)
 #define GR_RING 6                         // row tiles in the f32 ring of the aggregation layer
 #define GR_NBAR 6                         // grid barriers per launch
@@ -59,6 +62,7 @@ struct GinResArgs {
     float *pooled;                        // [B,128] graph mean pool of h (gcn:192)
     float *cand_feat;                     // [B*J,128] h rows of the candidates (ac:197-207)
     float *h_nodes;                       // optional [B*T,128]
+    float *zspill;                        // [blocks][4 waves][2 tiles][4][64 lanes][4] f32: the pre-BatchNorm values of row tiles 16, 17
     double inv_rows;                      // 1 / (B*T)
     int barrier_only;                     // census launch: barriers only
     unsigned long long *stamps;           // diagnostic build only (-DGR_STAMP): [blocks][64] s_memrealtime at the phase boundaries
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     // reconcile through scratch memory)
 
     // ---------------------------------------------------------------- prologue: features + adjacency to LDS, zero the planes
+    GR_STAMP_AT(32);
     for (int i = blockIdx.x * 256 + tid; i < GR_STATS_SET; i += (int)nblk * 256) A.stats_next[i] = 0.0;
     {
         float *s_feat = s_ring;                                   // [nrows][12]
@@ -200,19 +205,49 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         s_stat[tid] = 0.0;
         s_zero[tid] = 0.f;
     }
-    f32x16 acc[GR_NT];
+    // 18 tiles x 16 accumulators = 288 values per lane, but only 256 accumulation registers exist and the matrix instructions
+    // need one 16-register tuple of them to work in: left to itself hipcc keeps two values per tile in scratch memory and the
+    // reloads stall the wave.  So tiles 0..15 are resident and tiles 16, 17 make an explicit round trip per layer through 32 KB
+    // of global memory per workgroup (L2-resident, each wave its own 8 KB, 16-byte coalesced, requested a tile ahead of use).
+    f32x16 acc[GR_NRES];
+    f32x16 zs[2];                                                 // ring: spilled tile j uses zs[j & 1]
+    float *zsp = A.zspill + ((size_t)(blockIdx.x * 4 + wave) * (GR_NT - GR_NRES)) * 1024 + lane * 4;
+    auto zload = [&](auto Jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 v = *reinterpret_cast<const float4 *>(zsp + j * 1024 + g * 256);
+            zs[j & 1][4 * g] = v.x; zs[j & 1][4 * g + 1] = v.y; zs[j & 1][4 * g + 2] = v.z; zs[j & 1][4 * g + 3] = v.w;
+        }
+    };
+    auto zstore = [&](auto Jc, const f32x16 &a) __attribute__((always_inline)) {
+        constexpr int j = decltype(Jc)::value;
+#pragma unroll
+        for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(zsp + j * 1024 + g * 256) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+    };
+#define GR_TILEVAL(rt) ((rt) < GR_NRES ? acc[(rt) < GR_NRES ? (rt) : 0] : zs[(rt) >= GR_NRES ? ((rt) - GR_NRES) & 1 : 0])
     bf16x8 wf[3][8];
     float ts[16], tq[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) { ts[i] = 0.f; tq[i] = 0.f; }
 
-    auto load_weights = [&](int layer, auto KSc) __attribute__((always_inline)) {
+    // Weight fragments of a Linear from their register image.  W2LDS (the four Linears without aggregation): the plane-2 fragments
+    // (used by one of the six piece products) are parked in this wave's 8 KB of the ring area — free in those layers — and read back
+    // one k-step at a time, because 288 accumulators + 96 fragment registers + the operands in flight do not fit 512 registers
+    // (hipcc then keeps two accumulators per tile in scratch memory, whose reloads stall the whole wave).
+    unsigned char *s_w2 = reinterpret_cast<unsigned char *>(s_ring) + wave * 8192 + lane * 16;
+    auto load_weights = [&](int layer, auto KSc, auto W2c) __attribute__((always_inline)) {
         constexpr int KS = decltype(KSc)::value;
+        constexpr bool W2LDS = decltype(W2c)::value;
         const float4 *wi = reinterpret_cast<const float4 *>(A.Wx32[layer]) + (size_t)wave * (3 * KS * 64) + lane;
 #pragma unroll
-        for (int p = 0; p < 3; p++)
+        for (int p = 0; p < (W2LDS ? 2 : 3); p++)
 #pragma unroll
             for (int ks = 0; ks < KS; ks++) wf[p][ks] = __builtin_bit_cast(bf16x8, wi[(p * KS + ks) * 64]);
+        if constexpr (W2LDS) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) *reinterpret_cast<float4 *>(s_w2 + ks * 1024) = wi[(2 * KS + ks) * 64];
+        }
     };
     // BatchNorm statistics.  stats_tile: this lane's row of tile RT into the per-lane column sums (one value per tile and lane:
     // f32 is ample) — called one tile late, so that it never waits for the matrix pipe.  Rows >= nrows need no mask: their
@@ -220,7 +255,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     auto stats_tile = [&](auto Tc) __attribute__((always_inline)) {
         constexpr int RT = decltype(Tc)::value;
         if (GR_ABL & 4) return;
-        const f32x16 &a = acc[RT];
+        const f32x16 &a = GR_TILEVAL(RT);
 #pragma unroll
         for (int e = 0; e < 16; e++) { ts[e] += a[e]; tq[e] = __builtin_fmaf(a[e], a[e], tq[e]); asm volatile("" : "+v"(ts[e]), "+v"(tq[e])); }   // (pinned here: hipcc would sink the whole layer's sums to their use)
     };
@@ -241,7 +276,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         const float *bn = rt * 32 + n < nrows ? s_bn : s_zero;    // rows >= nrows: scale = shift = 0 -> zero planes
         const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);        // scale | shift of these 4 columns
         const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
-        const f32x16 &a = acc[rt];
+        const f32x16 &a = GR_TILEVAL(rt);
         const float v[4] = {bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y), bn_relu_ss(a[4 * g + 2], s4.z, h4.z),
                             bn_relu_ss(a[4 * g + 3], s4.w, h4.w)};
         uint2 p0, p1, p2;
@@ -263,10 +298,12 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     // of the following k-steps.
     const unsigned char *xa0 = s_planes + n * GR_ROWB + 16 * h;
 #define GR_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define GR_PIN_V() do { } while (0)
     auto consume_tile = [&](auto Tc, auto NEXTc, int buf) __attribute__((always_inline)) {
         constexpr int RT = decltype(Tc)::value;
         constexpr bool NEXT = decltype(NEXTc)::value && (RT + 1 < GR_NT) && !(GR_ABL & 1);
-        constexpr bool STATS = RT > 0 && !(GR_ABL & 4);
+        constexpr bool STATS = RT > 0 && RT - 1 < GR_NRES && !(GR_ABL & 4);     // (a spilled tile's sums are taken when it is stored)
+        constexpr bool W2LDS = decltype(NEXTc)::value;                // the layers that produce planes from registers (no aggregation)
         const unsigned char *xa = xa0 + buf * GR_TILE;
         const int nb = (RT + 1) & 1;
         const float *bn = (RT + 1) * 32 + n < nrows ? s_bn : s_zero;      // rows >= nrows: scale = shift = 0 -> zero planes
@@ -278,71 +315,83 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 4 * h);
             h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 4 * h);
         }
-        f32x16 &a = acc[RT];                                          // (its previous-layer values went into the planes one tile ago)
+        bf16x8 wA = wf[2][0], wB = wf[2][0];                          // plane-2 weight fragments of the even / odd k-step in flight
+        if constexpr (W2LDS) wA = *reinterpret_cast<const bf16x8 *>(s_w2);
+        f32x16 atmp;
+        f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : atmp;     // (its previous-layer values went into the planes one tile ago)
         a = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // the spilled tiles' old values: requested two tiles before the slices that turn them into planes
+        if constexpr (decltype(NEXTc)::value && RT + 2 >= GR_NRES && RT + 2 < GR_NT) zload(std::integral_constant<int, RT + 2 - GR_NRES>{});
         gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
             constexpr int g = decltype(Pc)::value;                       // region = k-steps 2g, 2g+1 = column quarter g of the next tile
             const bf16x8 *x0 = xf[0], *x1 = xf[1];
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-            float4 s4n = s4, h4n = h4;
-            unsigned pa = 0, pb = 0, qa = 0, qb = 0, ra = 0, rb = 0;
+            unsigned pa = 0, pb = 0, qa = 0, qb = 0, ra = 0, rb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
             unsigned char *dst = s_planes + nb * GR_TILE + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
-            const f32x16 &nx = acc[RT + 1 < GR_NT ? RT + 1 : RT];
-            const f32x16 &pv = acc[RT > 0 ? RT - 1 : RT];
+            const f32x16 &nx = GR_TILEVAL(RT + 1 < GR_NT ? RT + 1 : RT);
+            const f32x16 &pv = acc[RT > 0 && RT - 1 < GR_NRES ? RT - 1 : 0];
             auto M = [&](int ks, int wp, int xp) __attribute__((always_inline)) {
-                if (!(GR_ABL & 2)) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
+                const bf16x8 w = (wp == 2 && W2LDS) ? ((ks & 1) ? wB : wA) : wf[wp][ks];
+                if (!(GR_ABL & 2)) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
             };
             auto cvt2 = [&](float lo, float hi) __attribute__((always_inline)) {
                 return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));          // v_cvt_pk_bf16_f32
             };
+            // The production chain of a quarter (4 values: scale/shift+ReLU, three round-to-nearest bf16 levels with exact remainders)
+            // is laid out level by level, so that neighbouring vector instructions are independent of each other.
             // slice 0
             M(2 * g, 0, 2);                                              // smallest terms first: w0 x2, w2 x0, w1 x1, w0 x1, w1 x0, w0 x0
             xf[1][0] = *reinterpret_cast<const bf16x8 *>(xa + 0 * GR_PLANE + 32 * (2 * g + 1));
-            if constexpr (NEXT) { v0 = bn_relu_ss(nx[4 * g], s4.x, h4.x); v1 = bn_relu_ss(nx[4 * g + 1], s4.y, h4.y); }
+            if constexpr (NEXT) { v0 = __builtin_fmaf(nx[4 * g], s4.x, h4.x); v1 = __builtin_fmaf(nx[4 * g + 1], s4.y, h4.y);
+                                  v2 = __builtin_fmaf(nx[4 * g + 2], s4.z, h4.z); v3 = __builtin_fmaf(nx[4 * g + 3], s4.w, h4.w); }
             GR_FENCE();
             // slice 1
             M(2 * g, 2, 0);
             xf[1][1] = *reinterpret_cast<const bf16x8 *>(xa + 1 * GR_PLANE + 32 * (2 * g + 1));
-            if constexpr (NEXT) { v2 = bn_relu_ss(nx[4 * g + 2], s4.z, h4.z); v3 = bn_relu_ss(nx[4 * g + 3], s4.w, h4.w); }
+            if constexpr (NEXT) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
             GR_FENCE();
             // slice 2
             M(2 * g, 1, 1);
             xf[1][2] = *reinterpret_cast<const bf16x8 *>(xa + 2 * GR_PLANE + 32 * (2 * g + 1));
-            if constexpr (NEXT) { pa = cvt2(v0, v1); pb = cvt2(v2, v3); v0 -= __builtin_bit_cast(float, pa << 16); }
-            if constexpr (NEXT && g < 3) s4n = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * (g + 1) + 4 * h);   // scale | shift of the next quarter:
+            if constexpr (NEXT) { pa = cvt2(v0, v1); pb = cvt2(v2, v3); }
+            if constexpr (NEXT && g < 3) s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * (g + 1) + 4 * h);   // scale | shift of the next quarter (this one's are used up):
             GR_FENCE();
             // slice 3
             M(2 * g, 0, 1);
-            if constexpr (NEXT) { v1 -= __builtin_bit_cast(float, pa & 0xffff0000u); v2 -= __builtin_bit_cast(float, pb << 16); }
-            if constexpr (NEXT && g < 3) h4n = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * (g + 1) + 4 * h);   // ... nine slices ahead of its use
+            if constexpr (NEXT) { t0 = pa << 16; t1 = pa & 0xffff0000u; t2 = pb << 16; t3 = pb & 0xffff0000u; }
+            if constexpr (NEXT && g < 3) h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * (g + 1) + 4 * h);   // ... nine slices ahead of its use
+            if constexpr (W2LDS) wB = *reinterpret_cast<const bf16x8 *>(s_w2 + (2 * g + 1) * 1024);
             GR_FENCE();
             // slice 4
             M(2 * g, 1, 0);
-            if constexpr (NEXT) { v3 -= __builtin_bit_cast(float, pb & 0xffff0000u); qa = cvt2(v0, v1); *reinterpret_cast<uint2 *>(dst) = make_uint2(pa, pb); }
+            if constexpr (NEXT) { v0 -= __builtin_bit_cast(float, t0); v1 -= __builtin_bit_cast(float, t1); v2 -= __builtin_bit_cast(float, t2); v3 -= __builtin_bit_cast(float, t3);
+                                  if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst) = make_uint2(pa, pb); }
             GR_FENCE();
             // slice 5
             M(2 * g, 0, 0);
-            if constexpr (NEXT) { qb = cvt2(v2, v3); v0 -= __builtin_bit_cast(float, qa << 16); }
+            if constexpr (NEXT) { qa = cvt2(v0, v1); qb = cvt2(v2, v3); }
             GR_FENCE();
             // slice 6: the k-step 2g operands are dead once its six instructions have issued
             M(2 * g + 1, 0, 2);
             if constexpr (g < 3) xf[0][0] = *reinterpret_cast<const bf16x8 *>(xa + 0 * GR_PLANE + 32 * (2 * g + 2));
-            if constexpr (NEXT) { v1 -= __builtin_bit_cast(float, qa & 0xffff0000u); v2 -= __builtin_bit_cast(float, qb << 16); }
+            if constexpr (NEXT) { t0 = qa << 16; t1 = qa & 0xffff0000u; t2 = qb << 16; t3 = qb & 0xffff0000u; }
             GR_FENCE();
             // slice 7
             M(2 * g + 1, 2, 0);
             if constexpr (g < 3) xf[0][1] = *reinterpret_cast<const bf16x8 *>(xa + 1 * GR_PLANE + 32 * (2 * g + 2));
-            if constexpr (NEXT) { v3 -= __builtin_bit_cast(float, qb & 0xffff0000u); ra = cvt2(v0, v1); *reinterpret_cast<uint2 *>(dst + GR_PLANE) = make_uint2(qa, qb); }
+            if constexpr (NEXT) { v0 -= __builtin_bit_cast(float, t0); v1 -= __builtin_bit_cast(float, t1); v2 -= __builtin_bit_cast(float, t2); v3 -= __builtin_bit_cast(float, t3);
+                                  if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst + GR_PLANE) = make_uint2(qa, qb); }
             GR_FENCE();
             // slice 8
             M(2 * g + 1, 1, 1);
             if constexpr (g < 3) xf[0][2] = *reinterpret_cast<const bf16x8 *>(xa + 2 * GR_PLANE + 32 * (2 * g + 2));
-            if constexpr (NEXT) { rb = cvt2(v2, v3); }
+            if constexpr (NEXT) { ra = cvt2(v0, v1); rb = cvt2(v2, v3); }
             if constexpr (STATS) { ts[4 * g] += pv[4 * g]; tq[4 * g] = __builtin_fmaf(pv[4 * g], pv[4 * g], tq[4 * g]); asm volatile("" : "+v"(ts[4 * g]), "+v"(tq[4 * g])); }
             GR_FENCE();
             // slice 9
             M(2 * g + 1, 0, 1);
-            if constexpr (NEXT) { *reinterpret_cast<uint2 *>(dst + 2 * GR_PLANE) = make_uint2(ra, rb); }
+            if constexpr (W2LDS && g < 3) wA = *reinterpret_cast<const bf16x8 *>(s_w2 + (2 * g + 2) * 1024);
+            if constexpr (NEXT) { if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst + 2 * GR_PLANE) = make_uint2(ra, rb); else asm volatile("" :: "v"(pa), "v"(pb), "v"(qa), "v"(qb), "v"(ra), "v"(rb)); }
             if constexpr (STATS) { ts[4 * g + 1] += pv[4 * g + 1]; tq[4 * g + 1] = __builtin_fmaf(pv[4 * g + 1], pv[4 * g + 1], tq[4 * g + 1]); asm volatile("" : "+v"(ts[4 * g + 1]), "+v"(tq[4 * g + 1])); }
             GR_FENCE();
             // slice 10
@@ -351,10 +400,16 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             GR_FENCE();
             // slice 11
             M(2 * g + 1, 0, 0);
-            s4 = s4n; h4 = h4n;
             if constexpr (STATS) { ts[4 * g + 3] += pv[4 * g + 3]; tq[4 * g + 3] = __builtin_fmaf(pv[4 * g + 3], pv[4 * g + 3], tq[4 * g + 3]); asm volatile("" : "+v"(ts[4 * g + 3]), "+v"(tq[4 * g + 3])); }
             GR_FENCE();
         });
+        if constexpr (RT >= GR_NRES) {                                // not resident: BatchNorm sums now, then out to its spill slot
+            if (!(GR_ABL & 4))
+#pragma unroll
+                for (int e = 0; e < 16; e++) { ts[e] += a[e]; tq[e] = __builtin_fmaf(a[e], a[e], tq[e]); }
+            zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
+            GR_FENCE();
+        }
     };
     // first Linear: tile RT's 16-wide operand sits at byte offset 32*(RT & 7) of buffer 0's rows
     auto consume_tile0 = [&](auto Tc) __attribute__((always_inline)) {
@@ -370,8 +425,13 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][0], x[1], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][0], x[0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][0], x[0], a, 0, 0, 0);
-        acc[RT] = a;
-        if constexpr (RT > 0) stats_tile(std::integral_constant<int, RT - 1>{});
+        if constexpr (RT < GR_NRES) acc[RT] = a;
+        else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) { ts[e] += a[e]; tq[e] = __builtin_fmaf(a[e], a[e], tq[e]); }
+            zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
+        }
+        if constexpr (RT > 0 && RT - 1 < GR_NRES) stats_tile(std::integral_constant<int, RT - 1>{});
         __builtin_amdgcn_sched_barrier(0);
     };
     // this workgroup's column sums -> its dispatch group's accumulators, grid barrier `k` (which folds the groups into the totals),
@@ -379,8 +439,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     auto layer_boundary = [&](auto Kc) __attribute__((always_inline)) {
         constexpr int k = decltype(Kc)::value;
         GR_STAMP_AT(4 + 4 * k);
-        stats_tile(std::integral_constant<int, GR_NT - 1>{});
-        fold_stats();
+        fold_stats();                                             // (tile 17's sums were taken when it was stored)
         if (k == 1) GR_STAMP_AT(2);
         LDS_BARRIER();
         double *part = A.stats + ((size_t)k * 8 + (blockIdx.x & 7)) * (2 * HD);
@@ -392,7 +451,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if (k == 1) GR_STAMP_AT(3);
         // requests that do not depend on the other workgroups go out before the wait: the next Linear's weight fragments
         // and this BatchNorm's affine parameters
-        if constexpr (k < 5) load_weights(k + 1, std::integral_constant<int, 8>{});
+        if constexpr (k < 5) load_weights(k + 1, std::integral_constant<int, 8>{}, std::integral_constant<bool, k + 1 != 3>{});
         const float ga = A.gamma[k][tid & (HD - 1)], be = A.beta[k][tid & (HD - 1)];
         GR_STAMP_AT(5 + 4 * k);
         gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, part, total, s_flag);
@@ -414,7 +473,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 
     // ---------------------------------------------------------------- layer 0 / Linear 0: aggregated raw features (12 -> 128)
     GR_STAMP_AT(0);
-    load_weights(0, std::integral_constant<int, 1>{});
+    load_weights(0, std::integral_constant<int, 1>{}, std::false_type{});
     LDS_BARRIER();
     GR_STAMP_AT(1);
     {
@@ -474,6 +533,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
                 constexpr int RT = decltype(Tc)::value;
                 consume_tile(Tc, std::true_type{}, RT & 1);       // produces tile RT+1 between its matrix instructions
+                GR_PIN_V();
                 LDS_BARRIER();
                 __builtin_amdgcn_sched_barrier(0);
             });
@@ -488,7 +548,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                     const float *bn = rt * 32 + n < nrows ? s_bn : s_zero;
                     const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);
                     const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
-                    const f32x16 &a = acc[rt];
+                    const f32x16 &a = GR_TILEVAL(rt);
                     const int ch = (8 * wave + 2 * g + h) ^ (n & 7);
                     *reinterpret_cast<float4 *>(base + 4 * ch) = make_float4(bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y),
                                                                              bn_relu_ss(a[4 * g + 2], s4.z, h4.z), bn_relu_ss(a[4 * g + 3], s4.w, h4.w));
@@ -530,6 +590,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                     });
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (RT + 5 >= GR_NRES && RT + 5 < GR_NT) zload(std::integral_constant<int, RT + 5 - GR_NRES>{});   // the spilled tiles, two iterations ahead
                 if constexpr (RT + 3 < GR_NT) write_h(std::integral_constant<int, RT + 3>{});     // into the slot of tile RT-3 (no longer needed)
                 LDS_BARRIER();
                 __builtin_amdgcn_sched_barrier(0);
@@ -542,77 +603,83 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 
     GR_STAMP_AT(30);
     // ---------------------------------------------------------------- h = relu(bn_outer1(z)): graph mean pool, candidate gather, node embeddings
+    // Three steps of six tiles through the ring area (192 rows of f32 per step): all waves write their columns of h, then
+    // thread (column, half) sums its 96 rows in runs of one instance (boundaries are wave-uniform scalars) into the workgroup's
+    // pool accumulators (in the plane area, free now), and the candidate rows of the window go out, one wave per row.
     {
-        auto write_h2 = [&](auto Tc) __attribute__((always_inline)) {       // tile rt -> slot rt & 1 of the ring area
-            constexpr int rt = decltype(Tc)::value;
-            float *base = s_ring + ((rt & 1) * 32 + n) * HD;
-            gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) {
-                constexpr int g = decltype(Gc)::value;
-                const float4 s4 = *reinterpret_cast<const float4 *>(s_bn + 32 * wave + 8 * g + 4 * h);
-                const float4 h4 = *reinterpret_cast<const float4 *>(s_bn + HD + 32 * wave + 8 * g + 4 * h);
-                const f32x16 &a = acc[rt];
-                const int ch = (8 * wave + 2 * g + h) ^ (n & 7);
-                *reinterpret_cast<float4 *>(base + 4 * ch) = make_float4(bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y),
-                                                                         bn_relu_ss(a[4 * g + 2], s4.z, h4.z), bn_relu_ss(a[4 * g + 3], s4.w, h4.w));
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        // graph mean pool (gcn:192): per-instance column sums accumulate in LDS (behind the two h slots of the ring area); thread =
-        // (column, half of the tile's rows) adds runs of rows of one instance with one LDS atomic per run
-        float *s_pool = s_ring + 2 * 32 * HD;                     // [ipc][128]
-        unsigned char *s_inst = reinterpret_cast<unsigned char *>(s_pool + GR_MAXIPC * HD);   // [576] instance of every row, 255 = none
+        float *s_pool = reinterpret_cast<float *>(s_planes);     // [ipc][128]
         for (int i = tid; i < A.ipc * HD; i += 256) s_pool[i] = 0.f;
-        for (int r = tid; r < GR_ROWS; r += 256) s_inst[r] = (unsigned char)(r < nrows ? r / T : 255);
         const int ncand = A.candidate ? ninst * A.J : 0;
-        // candidates of this wave: lane i holds the row of candidate wave + 4i (GR_MAXCAND / 4 <= 96 > 64: two registers)
+        // candidates of this wave: lane i holds the row of candidate wave + 4i (and wave + 4(i + 64))
         int crow0 = -1, crow1 = -1;
         if (wave + 4 * lane < ncand) crow0 = s_cand[wave + 4 * lane];
         if (wave + 4 * (lane + 64) < ncand) crow1 = s_cand[wave + 4 * (lane + 64)];
-        write_h2(std::integral_constant<int, 0>{});
+        const int col = tid & (HD - 1), half = wave >> 1;         // (wave is a scalar: the run boundaries below are scalar too)
+        const float invT = 1.0f / (float)T;
         LDS_BARRIER();
-        gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
-            constexpr int RT = decltype(Tc)::value;
-            if constexpr (RT + 1 < GR_NT) write_h2(std::integral_constant<int, RT + 1>{});
-            const float *slot = s_ring + (RT & 1) * 32 * HD;
-            {   // 16 rows of one column: at most two instances (T >= 16); the run boundary comes from the rows' instance ids
-                const int col = tid & (HD - 1), r0 = 16 * (tid >> 7);
-                const int i0 = s_inst[RT * 32 + r0], i1 = s_inst[RT * 32 + r0 + 15];
-                float run0 = 0.f, run1 = 0.f;
+        gr_static_for<GR_NT / GR_RING>([&](auto Sc) __attribute__((always_inline)) {
+            constexpr int S = decltype(Sc)::value;
+            gr_static_for<GR_RING>([&](auto Jc) __attribute__((always_inline)) {
+                constexpr int j = decltype(Jc)::value, rt = S * GR_RING + j;
+                if constexpr (rt >= GR_NRES) zload(std::integral_constant<int, rt - GR_NRES>{});      // (a spilled tile: straight from its slot)
+                float *base = s_ring + (j * 32 + n) * HD;
+                const float *bn = rt * 32 + n < nrows ? s_bn : s_zero;
+                gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) {
+                    constexpr int g = decltype(Gc)::value;
+                    const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);
+                    const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
+                    const f32x16 &a = GR_TILEVAL(rt);
+                    const int ch = (8 * wave + 2 * g + h) ^ (n & 7);
+                    *reinterpret_cast<float4 *>(base + 4 * ch) = make_float4(bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y),
+                                                                             bn_relu_ss(a[4 * g + 2], s4.z, h4.z), bn_relu_ss(a[4 * g + 3], s4.w, h4.w));
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            LDS_BARRIER();
+            {   // gcn:192: sum over the rows of an instance
+                const int R0 = S * GR_RING * 32 + 96 * half;      // first row of this thread's run (scalar)
+                int inst = R0 / T, left = (inst + 1) * T - R0;    // current instance, rows of it still ahead
+                float run = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const int r = r0 + i;
-                    const float x = slot[r * HD + 4 * ((col >> 2) ^ (r & 7)) + (col & 3)];
-                    const bool first = s_inst[RT * 32 + r] == i0;
-                    run0 += first ? x : 0.f; run1 += first ? 0.f : x;
+                for (int c = 0; c < 6; c++) {                     // 16 rows at a time: the loads go out together, ahead of the (scalar) run bookkeeping
+                    float x[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const int r = 96 * half + 16 * c + i;     // row within the window
+                        x[i] = s_ring[r * HD + 4 * ((col >> 2) ^ (i & 7)) + (col & 3)];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        if (left == 0) { if (inst < ninst) atomicAdd(&s_pool[inst * HD + col], run); run = 0.f; inst++; left = T; }
+                        run += x[i];
+                        left--;
+                    }
                 }
-                if (i0 != 255) atomicAdd(&s_pool[i0 * HD + col], run0);
-                if (i1 != i0 && i1 != 255) atomicAdd(&s_pool[i1 * HD + col], run1);
+                if (inst < ninst) atomicAdd(&s_pool[inst * HD + col], run);
             }
-            // ac:197-207: the candidates whose row lies in this tile (about one per wave and tile), one wave per row, 8 bytes per lane
+            // ac:197-207: the candidates whose row lies in this window, one wave per row, 8 bytes per lane
             for (int part = 0; part < 2; part++) {
                 const int cr = part ? crow1 : crow0;
-                unsigned long long mask = __ballot(cr >= 0 && (cr >> 5) == RT);
+                unsigned long long mask = __ballot(cr >= S * GR_RING * 32 && cr < (S + 1) * GR_RING * 32);
                 while (mask) {
                     const int i = __builtin_ctzll(mask);
                     mask &= mask - 1;
-                    const int R = __builtin_amdgcn_readlane(cr, i), idx = wave + 4 * (i + 64 * part);
-                    const int r = R & 31, col = 2 * lane;
-                    const float2 x = *reinterpret_cast<const float2 *>(slot + r * HD + 4 * ((col >> 2) ^ (r & 7)) + (col & 3));
-                    *reinterpret_cast<float2 *>(A.cand_feat + ((size_t)inst0 * A.J + idx) * HD + col) = x;
+                    const int r = __builtin_amdgcn_readlane(cr, i) - S * GR_RING * 32, idx = wave + 4 * (i + 64 * part);
+                    const float2 x = *reinterpret_cast<const float2 *>(s_ring + r * HD + 4 * ((lane >> 1) ^ (r & 7)) + 2 * (lane & 1));
+                    *reinterpret_cast<float2 *>(A.cand_feat + ((size_t)inst0 * A.J + idx) * HD + 2 * lane) = x;
                 }
             }
             if (A.h_nodes) {
-                for (int r = wave; r < 32; r += 4) {
-                    if (RT * 32 + r < nrows) {
-                        const int col = 2 * lane;
-                        const float2 x = *reinterpret_cast<const float2 *>(slot + r * HD + 4 * ((col >> 2) ^ (r & 7)) + (col & 3));
-                        *reinterpret_cast<float2 *>(A.h_nodes + (grow0 + RT * 32 + r) * HD + col) = x;
+                for (int r = wave; r < GR_RING * 32; r += 4) {
+                    if (S * GR_RING * 32 + r < nrows) {
+                        const float2 x = *reinterpret_cast<const float2 *>(s_ring + r * HD + 4 * ((lane >> 1) ^ (r & 7)) + 2 * (lane & 1));
+                        *reinterpret_cast<float2 *>(A.h_nodes + (grow0 + S * GR_RING * 32 + r) * HD + 2 * lane) = x;
                     }
                 }
             }
             LDS_BARRIER();
         });
-        const float invT = 1.0f / (float)T;
         for (int i = tid; i < ninst * HD; i += 256) A.pooled[(size_t)inst0 * HD + i] = s_pool[i] * invT;
     }
     GR_STAMP_AT(31);

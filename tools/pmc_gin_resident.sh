@@ -1,10 +1,12 @@
 #!/bin/bash
 # SQ counters of the resident GIN kernel (rocprofv3 --pmc only with --kernel-trace; no other trace domains)
+#   bash tools/pmc_gin_resident.sh "SQ_WAVE_CYCLES SQ_BUSY_CYCLES ..." ["second set" ...]
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p gpurun_out
-for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SALU SQ_ACTIVE_INST_MISC"; do
-  tag=$(echo $set | cut -d' ' -f1)
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_gr_$tag -- python3 bench.py --steps 36 --warmup 36 --min-seconds 0.01 --no-cpu-baseline --no-env-sweep > /dev/null 2>&1
+i=0
+for set in "$@"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_gr_$i -- python3 bench.py --steps 36 --warmup 36 --min-seconds 0.01 --no-cpu-baseline --no-env-sweep > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections
