@@ -2371,7 +2371,8 @@ struct mtfjsp_encoder {
     std::map<std::string, std::vector<float>> hostw;   // host copies of gat_layer.W / m_fea_*_fcl.weight (inputs of the fused projections)
     std::map<std::string, float *> wfused;  // per prefix + "1"/"2": (m_fea_k_fcl.weight^T . gat_layer.W)^T, [128,6] / [128,8]
     std::map<std::string, void *> wx6;      // 128x128 Linear weights as 3 bf16 planes in k_gemm_x6's register-image order
-    std::map<std::string, void *> wx32;     // GIN Linear weights as 3 bf16 planes in k_gin_res's (32x32x16) register-image order
+    std::map<std::string, void *> wx32;     // GIN Linear weights as operand-piece planes in k_gin_res's (32x32x16) register-image order
+    std::map<std::string, float> wx32_sinv; // ... 1 / the power-of-two scale folded into that image
     std::map<std::string, float *> wimg;    // the same blocks as per-wave register images for k_heads: [block][wave 8][g 8][lane 64][4]
     std::vector<void *> owned;
     int num_cu = 256;
@@ -2390,7 +2391,7 @@ struct mtfjsp_encoder {
     int f32_products = (getenv("MTFJSP_GEMM_F32MFMA") ? 1 : 0) | (getenv("MTFJSP_GAT_F32MFMA") ? 2 : 0) |
                        (getenv("MTFJSP_HEADS_F32MFMA") ? 4 : 0) | (getenv("MTFJSP_GIN0_VALU") ? 8 : 0);
     // resident GIN kernel (mtfjsp_gin_resident.h): eligibility decided at create time, then verified by a census launch
-    bool res_ok = false, res_default = false; int res_ipc = 0, res_grid = 0;
+    bool res_ok = false; int res_ipc = 0, res_grid = 0;
     double *res_stats = nullptr;            // [2 sets][GR_STATS_SET]; forward n uses set n & 1 and zeroes the other one
     unsigned long long *res_bar = nullptr;  // [17 * 16] barrier words
     unsigned *res_fail = nullptr;
@@ -2523,7 +2524,6 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
                     unsigned failed = 1;
                     if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&failed, e->res_fail, 4, hipMemcpyDeviceToHost) == hipSuccess && !failed) {
                         e->res_ok = true; e->res_ipc = ipc; e->res_grid = grid;
-                        e->res_default = getenv("MTFJSP_RESIDENT_GIN") != nullptr;
                     } else {       // leave the streaming kernels in charge; fresh barrier words in case the census is retried elsewhere
                         (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); (void)hipMemset(e->res_fail, 0, 16);
                     }
@@ -2636,29 +2636,64 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
     }
     if (key.find("feature_extract.mlps.") != std::string::npos && key.size() > 7 && key.compare(key.size() - 7, 7, ".weight") == 0 &&
         key.find("linears") != std::string::npos) {
-        // k_gin_res (v_mfma_f32_32x32x16_bf16, A := weight): img[w 4][plane 3][ks KS][lane 64][j 8] =
-        // plane(W[n = 32w + (lane & 31)][k = 16ks + 8(lane >> 5) + j]), KS = in/16 (the 12 -> 128 Linear: one k-step, k >= 12 zero)
-        const int in = (int)(numel / HD), KS = in == 12 ? 1 : in / 16;
+        // k_gin_res (v_mfma_f32_32x32x16_*, A := weight): img[w 4][plane P][ks KS][lane 64][j 8] =
+        // plane(W[n = 32w + (lane & 31)][k = 16ks + 8(lane >> 5) + j]).  The 12 -> 128 Linear: one k-step (k >= 12 zero), P = 3
+        // bf16 planes (exact split).  The 128 -> 128 ones: P = 2 f16 planes (high = f16(s W), low = f16(s W - high), round to
+        // nearest) of the weights scaled by the power of two s that puts max |W| in [2^13, 2^14): the low piece keeps its full 11
+        // bits well clear of the f16 subnormals.  1/s goes into the BatchNorm that follows (exact).
+        const int in = (int)(numel / HD), KS = in == 12 ? 1 : in / 16, P = in == 12 ? 3 : 2;
         auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
         auto from_bf16 = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
-        std::vector<uint16_t> im((size_t)4 * 3 * KS * 64 * 8, 0);
+        auto to_f16 = [](float x) {                                // round to nearest even, subnormals kept
+            uint32_t u; memcpy(&u, &x, 4);
+            const uint32_t sign = (u >> 16) & 0x8000u; u &= 0x7fffffffu;
+            uint32_t o;
+            if (u >= ((127u + 16u) << 23)) o = u > (255u << 23) ? 0x7e00u : 0x7c00u;
+            else if (u < (113u << 23)) { float f, magic; const uint32_t mb = ((127u - 15u) + (23u - 10u) + 1u) << 23; memcpy(&f, &u, 4); memcpy(&magic, &mb, 4);
+                                         f += magic; uint32_t fu; memcpy(&fu, &f, 4); o = fu - mb; }
+            else { const uint32_t odd = (u >> 13) & 1u; u += ((15u - 127u) << 23) + 0xfffu; u += odd; o = u >> 13; }
+            return (uint16_t)(o | sign);
+        };
+        auto from_f16 = [](uint16_t hbits) {
+            const uint32_t sgn = (uint32_t)(hbits & 0x8000u) << 16, ex = (hbits >> 10) & 31u, m = hbits & 0x3ffu;
+            float x;
+            if (ex == 0) { x = ldexpf((float)m, -24); return sgn ? -x : x; }
+            const uint32_t u = sgn | ((ex == 31 ? 255u : ex + 112u) << 23) | (m << 13);
+            memcpy(&x, &u, 4); return x;
+        };
+        float scale = 1.0f;
+        if (P == 2) {
+            float mx = 0.f;
+            for (int64_t i = 0; i < numel; i++) mx = fmaxf(mx, fabsf(data[i]));
+            if (!(mx < INFINITY)) { e->err = "load_weight: non-finite value in " + key; return MTFJSP_ERR_ARG; }
+            int ex = 0;
+            if (mx > 0.f) (void)frexpf(mx, &ex);                   // mx = f * 2^ex, f in [0.5, 1)
+            int k = 14 - ex; k = k > 60 ? 60 : k < -60 ? -60 : k;
+            scale = ldexpf(1.0f, k);
+        }
+        std::vector<uint16_t> im((size_t)4 * P * KS * 64 * 8, 0);
         for (int w = 0; w < 4; w++)
             for (int ks = 0; ks < KS; ks++)
                 for (int lane = 0; lane < 64; lane++)
                     for (int j = 0; j < 8; j++) {
                         const int n = 32 * w + (lane & 31), k = 16 * ks + 8 * (lane >> 5) + j;
                         if (k >= in) continue;
-                        const float x = data[(size_t)n * in + k];
-                        const uint16_t p0 = to_bf16(x); const float r1 = x - from_bf16(p0);
-                        const uint16_t p1 = to_bf16(r1); const float r2 = r1 - from_bf16(p1);
-                        const uint16_t pl[3] = {p0, p1, to_bf16(r2)};
-                        for (int p = 0; p < 3; p++) im[(((((size_t)w * 3 + p) * KS + ks) * 64 + lane) * 8) + j] = pl[p];
+                        const float x = data[(size_t)n * in + k] * scale;
+                        uint16_t pl[3] = {0, 0, 0};
+                        if (P == 3) {
+                            pl[0] = to_bf16(x); const float r1 = x - from_bf16(pl[0]);
+                            pl[1] = to_bf16(r1); pl[2] = to_bf16(r1 - from_bf16(pl[1]));
+                        } else {
+                            pl[0] = to_f16(x); pl[1] = to_f16(x - from_f16(pl[0]));
+                        }
+                        for (int p = 0; p < P; p++) im[(((((size_t)w * P + p) * KS + ks) * 64 + lane) * 8) + j] = pl[p];
                     }
         void *dx = nullptr;
         auto kt = e->wx32.find(key);
         if (kt != e->wx32.end()) dx = kt->second;
         else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx32[key] = dx; }
         HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
+        e->wx32_sinv[key] = 1.0f / scale;
     }
     // 128-wide Linear weights [out=128, in=128*k] and gat W [in,out]: keep GEMM-ready [in-block][k][n] copies
     const bool is_w = key.size() > 7 && key.compare(key.size() - 7, 7, ".weight") == 0 && key.find("linears") != std::string::npos;
@@ -2897,6 +2932,7 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
     const char *bn[6] = {"mlps.0.batch_norms.0", "mlps.0.batch_norms.1", "batch_norms.0", "mlps.1.batch_norms.0", "mlps.1.batch_norms.1", "batch_norms.1"};
     for (int i = 0; i < 6; i++) {
         a.Wx32[i] = e->wx32.at(P + lin[i] + ".weight");           // (the Linear biases cancel in the BatchNorms that follow them)
+        a.wsinv[i] = e->wx32_sinv.at(P + lin[i] + ".weight");
         a.gamma[i] = W(P + bn[i] + ".weight"); a.beta[i] = W(P + bn[i] + ".bias");
     }
     const int set = (int)(e->res_epoch & 1);
@@ -3115,7 +3151,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     // the heads kernel does BatchNorm+ReLU, graph pool and candidate gather itself — while T is small: a workgroup pools 16
     // instances with 512 threads, which is too little parallelism for 400-row instances (J20M20: 199 vs 81+113 us measured)
-    const bool resident = !e->bn_mode && e->res_ok && (e->res_default || (e->f32_products & 16)) && !(e->f32_products & (1 | 8));
+    const bool resident = !e->bn_mode && e->res_ok && !(e->f32_products & (1 | 8 | 16));
     const bool fuse_pool = !e->bn_mode && !resident && !h_nodes && e->T <= 128;
     rc = e->bn_mode ? run_gin_inst(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
          : resident ? run_gin_resident(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
@@ -3247,7 +3283,7 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
     const int B = e->cfg.batch;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
-    const bool resident = e->res_ok && (e->res_default || (e->f32_products & 16)) && !(e->f32_products & (1 | 8));
+    const bool resident = e->res_ok && !(e->f32_products & (1 | 8 | 16));
     int rc = resident ? run_gin_resident(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr)
                       : run_gin(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr);
     if (rc) return rc;
@@ -3307,7 +3343,7 @@ extern "C" int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_ou
     if (!e) return MTFJSP_ERR_ARG;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (gin_resident_out) *gin_resident_out = (e->res_ok && (e->res_default || (e->f32_products & 16)) && !(e->f32_products & (1 | 8))) ? 1 : 0;
+    if (gin_resident_out) *gin_resident_out = (e->res_ok && !(e->f32_products & (1 | 8 | 16))) ? 1 : 0;
     if (e->res_ok) {
         unsigned failed = 0;
         HIPCHK(e, hipMemcpy(&failed, e->res_fail, 4, hipMemcpyDeviceToHost));

@@ -6,18 +6,27 @@
 // boundary: 6 launches, 983 MB per forward at 147 456 rows, each launch HBM-bound.  At the headline batch (4096 J6M6
 // instances = 576 rows per CU) the activations fit in the register file instead: 256 workgroups (one per CU, 4 waves, one per
 // SIMD with 512 registers each) keep z[576 rows][128] as 288 accumulator registers per lane; a layer is
-//     registers --BatchNorm+ReLU(+aggregation), exact 3-way bf16 split--> LDS planes --ds_read_b128--> matrix cores --> registers
+//     registers --BatchNorm+ReLU(+aggregation), 2-way f16 split--> LDS planes --ds_read_b128--> matrix cores --> registers
 // and the only global traffic between layers is the BatchNorm column sums (2 KB per workgroup) and a grid-wide barrier.
-// The products are the 6-piece split products of k_gemm_x6 (f32-accurate), so the kernel is bound by the bf16 matrix cores
-// (29 GFLOP of piece products per layer = 12.8 us at the measured 2.27 PFLOP/s) plus six barriers.
 //
-// Layout.  v_mfma_f32_32x32x16_bf16 with the operands swapped (A := weight fragments, resident in registers; B := activation
+// Products.  An f32 operand x is split into high = f16(x) and low = f16(x - high) (round to nearest both times: x = high +
+// low up to 2^-22 |x|), the weights likewise on the host after scaling by a power of two (so that their low pieces stay
+// normal f16 numbers; 1/scale goes into the following BatchNorm, exactly), and a product is the three significant piece
+// products w_hi x_lo + w_lo x_hi + w_hi x_hi accumulated in f32 by v_mfma_f32_32x32x16_f16 — the dropped w_lo x_lo term is
+// <= 2^-22 |w x| too.  The rounding of a 128-term f32 FMA chain is of the same size, and the tests hold the kernel to the same
+// bounds as the exact 6-product bf16 split of the streaming kernels (which it replaced here: half the matrix work and about
+// half the vector work per element; measured 16.5 us instead of 23.4 us per layer).  f16 overflows at 65504: the operands are
+// BatchNorm outputs (|.| <= sqrt(rows) * |gamma| + |beta|) and 3-term neighbour sums of them.  The first Linear (12 raw
+// features, unbounded) keeps the exact bf16 split.  Matrix work: 14.5 GFLOP of piece products per layer = 6.4 us at the
+// measured 2.27 PFLOP/s.
+//
+// Layout.  v_mfma_f32_32x32x16_f16 with the operands swapped (A := weight fragments, resident in registers; B := activation
 // rows from LDS): wave w owns output columns 32w..32w+31 of ALL rows of the workgroup.  Lane l = (n = l & 31, h = l >> 5) holds,
 // for row tile rt (32 rows), row 32rt+n, columns 32w + 8g + 4h + r (g, r = 0..3) in acc[rt][4g+r] — 16 registers per tile, 18
 // tiles.  The 32x32 shape is chosen over 16x16x32 because one wave per SIMD cannot overlap its own vector and matrix
 // instructions beyond the issue slots a matrix instruction leaves free: 24 of 32 cycles here against 8 of 16 (measured: the
 // 16x16x32 form of this kernel took 28 us per layer, of which 11 us were vector work that did not overlap).
-// A tile's planes (3 x 32 rows x 272 B) are written by all four waves (each its 32 columns) into one of two LDS buffers while
+// A tile's planes (2 x 32 rows x 272 B) are written by all four waves (each its 32 columns) into one of two LDS buffers while
 // the previous tile is being multiplied: one LDS barrier per tile.
 // The second GIN layer's neighbour aggregation (gcn:125-149) reads rows of the same instance: h = relu(bn(z)) is staged as
 // f32 in a ring of 6 row tiles (192 rows, XOR-swizzled); with T <= 65 rows per instance the neighbours of tile rt lie in tiles
@@ -39,19 +48,23 @@
 #define GR_NBAR 6                         // grid barriers per launch
 #define GR_ROWB 272                       // plane row pitch in bytes (256 + 16: conflict-free 16-byte operand reads)
 #define GR_PLANE (32 * GR_ROWB)
-#define GR_TILE (3 * GR_PLANE)
+#define GR_TILE (2 * GR_PLANE)                // a tile buffer: the (high | low) f16 planes of 32 rows
 #define GR_MAXCAND 384
 #define GR_MAXT 65                        // rows per instance: the in-edge sources of a tile lie within two tiles of it
 #define GR_MINT 16                        // ... and a 16-row run spans at most two instances (pooling)
 #define GR_MAXIPC 64                      // instances per workgroup (u8 instance ids; pool accumulators in the ring area)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 gr_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 gr_h2 __attribute__((ext_vector_type(2)));
 
 struct GinResArgs {
     int B, T, J, ipc;                     // instances, rows per instance, candidates per instance, instances per workgroup
     const void *tfea; int feat_f64;       // [B*T,12] raw task features
     const int *ell_col; const float *ell_val;   // [B*T,2]
-    const void *Wx32[6];                  // register images of the six Linear weights for the 32x32x16 form (first: the 12 -> 128 one-k-step image)
+    const void *Wx32[6];                  // register images of the six Linear weights for the 32x32x16 form (first: the 12 -> 128 one-k-step bf16 image;
+                                          // the others: two f16 planes of W * wscale)
+    float wsinv[6];                       // 1 / wscale of each image (a power of two; 1 for the first)
     const float *gamma[6], *beta[6];      // BatchNorm after each Linear (mlps.0.bn0, mlps.0.bn1, outer 0, mlps.1.bn0, mlps.1.bn1, outer 1)
     double *stats;                        // this forward's accumulators (zero on entry): [6][8 groups][128][2] partial | [6][128][2] total
     double *stats_next;                   // the set of the next forward: zeroed here
@@ -76,7 +89,7 @@ struct GinResArgs {
 #endif
 
 // LDS map (bytes)
-#define GR_OFF_PLANES 0                                           // [2][3 planes][32 rows][272]
+#define GR_OFF_PLANES 0                                           // [2][2 planes][32 rows][272] (first Linear: 3 bf16 planes of 8 tiles side by side)
 #define GR_OFF_RING (2 * GR_TILE)                                 // f32 [6 tiles * 32 rows][128], swizzled (first phase: features [576][12])
 #define GR_OFF_ELLC (GR_OFF_RING + GR_RING * 32 * HD * 4)         // u32 [576]: workgroup-relative rows of the <= 2 in-edges, 0xffff = none
 #define GR_OFF_ELLV0 (GR_OFF_ELLC + GR_ROWS * 4)
@@ -226,50 +239,58 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(zsp + j * 1024 + g * 256) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
     };
 #define GR_TILEVAL(rt) ((rt) < GR_NRES ? acc[(rt) < GR_NRES ? (rt) : 0] : zs[(rt) >= GR_NRES ? ((rt) - GR_NRES) & 1 : 0])
-    bf16x8 wf[3][8];
-    float ts[16], tq[16];
+    gr_h8 wf[2][8];
+    bf16x8 w0f[3];                                                // (first Linear only)
+    f32x2 ts[8], tq[8];                                           // per-lane column (sum, sumsq) of this layer, two columns per register pair
 #pragma unroll
-    for (int i = 0; i < 16; i++) { ts[i] = 0.f; tq[i] = 0.f; }
+    for (int i = 0; i < 8; i++) { ts[i] = f32x2{0.f, 0.f}; tq[i] = f32x2{0.f, 0.f}; }
 
-    // Weight fragments of a Linear from their register image.  W2LDS (the four Linears without aggregation): the plane-2 fragments
-    // (used by one of the six piece products) are parked in this wave's 8 KB of the ring area — free in those layers — and read back
-    // one k-step at a time, because 288 accumulators + 96 fragment registers + the operands in flight do not fit 512 registers
-    // (hipcc then keeps two accumulators per tile in scratch memory, whose reloads stall the whole wave).
-    unsigned char *s_w2 = reinterpret_cast<unsigned char *>(s_ring) + wave * 8192 + lane * 16;
-    auto load_weights = [&](int layer, auto KSc, auto W2c) __attribute__((always_inline)) {
-        constexpr int KS = decltype(KSc)::value;
-        constexpr bool W2LDS = decltype(W2c)::value;
-        const float4 *wi = reinterpret_cast<const float4 *>(A.Wx32[layer]) + (size_t)wave * (3 * KS * 64) + lane;
+    // Weight fragments of a 128 -> 128 Linear from their register image: 2 planes x 8 k-steps x 4 registers = 64 registers.
+    auto load_weights = [&](int layer) __attribute__((always_inline)) {
+        const float4 *wi = reinterpret_cast<const float4 *>(A.Wx32[layer]) + (size_t)wave * (2 * 8 * 64) + lane;
 #pragma unroll
-        for (int p = 0; p < (W2LDS ? 2 : 3); p++)
+        for (int p = 0; p < 2; p++)
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) wf[p][ks] = __builtin_bit_cast(bf16x8, wi[(p * KS + ks) * 64]);
-        if constexpr (W2LDS) {
+            for (int ks = 0; ks < 8; ks++) wf[p][ks] = __builtin_bit_cast(gr_h8, wi[(p * 8 + ks) * 64]);
+    };
+    // the two statistics updates of a column pair, pinned where they are written (hipcc would sink a whole layer's sums to their use)
+    auto stat2 = [&](int i, float x, float y) __attribute__((always_inline)) {
+        const f32x2 v = {x, y};
+        ts[i] += v; tq[i] = __builtin_elementwise_fma(v, v, tq[i]);
+        asm volatile("" : "+v"(ts[i]), "+v"(tq[i]));
+    };
+    auto stats_all = [&](const f32x16 &a) __attribute__((always_inline)) {
+        if (GR_ABL & 4) return;
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) *reinterpret_cast<float4 *>(s_w2 + ks * 1024) = wi[(2 * KS + ks) * 64];
-        }
+        for (int i = 0; i < 8; i++) stat2(i, a[2 * i], a[2 * i + 1]);
+    };
+    // exact-to-2^-22 operand split of 4 values: high = f16(v), low = f16(v - high) (both round-to-nearest) -> packed pairs
+    auto split2x4 = [&](f32x2 v01, f32x2 v23, uint2 &p0, uint2 &p1) __attribute__((always_inline)) {
+        const gr_h2 a = __builtin_convertvector(v01, gr_h2), b = __builtin_convertvector(v23, gr_h2);
+        const f32x2 r01 = v01 - __builtin_convertvector(a, f32x2), r23 = v23 - __builtin_convertvector(b, f32x2);
+        const gr_h2 c = __builtin_convertvector(r01, gr_h2), d = __builtin_convertvector(r23, gr_h2);
+        p0 = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+        p1 = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
     };
     // BatchNorm statistics.  stats_tile: this lane's row of tile RT into the per-lane column sums (one value per tile and lane:
     // f32 is ample) — called one tile late, so that it never waits for the matrix pipe.  Rows >= nrows need no mask: their
     // operand planes are written as zeros (scale = shift = 0 below), and without a bias a zero row stays exactly zero.
     auto stats_tile = [&](auto Tc) __attribute__((always_inline)) {
         constexpr int RT = decltype(Tc)::value;
-        if (GR_ABL & 4) return;
-        const f32x16 &a = GR_TILEVAL(RT);
-#pragma unroll
-        for (int e = 0; e < 16; e++) { ts[e] += a[e]; tq[e] = __builtin_fmaf(a[e], a[e], tq[e]); asm volatile("" : "+v"(ts[e]), "+v"(tq[e])); }   // (pinned here: hipcc would sink the whole layer's sums to their use)
+        stats_all(GR_TILEVAL(RT));
     };
     // sums over the 32 rows of the lanes -> the owner lanes (n == 0) store the workgroup's (sum, sumsq) per column as f64.  Once per layer.
     auto fold_stats = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-            const float a = gr_sum32(ts[e]), b = gr_sum32(tq[e]);
+            const float a = gr_sum32(ts[e >> 1][e & 1]), b = gr_sum32(tq[e >> 1][e & 1]);
             const int col = 32 * wave + 8 * (e >> 2) + 4 * h + (e & 3);
             if (n == 0) *reinterpret_cast<double2 *>(s_stat + 2 * col) = make_double2((double)a, (double)b);
-            ts[e] = 0.f; tq[e] = 0.f;
         }
+#pragma unroll
+        for (int i = 0; i < 8; i++) { ts[i] = f32x2{0.f, 0.f}; tq[i] = f32x2{0.f, 0.f}; }
     };
-    // BatchNorm + ReLU of columns 8g+4h..+3 of tile rt's resident values -> exact split -> planes of buffer buf
+    // BatchNorm + ReLU of columns 8g+4h..+3 of tile rt's resident values -> operand split -> planes of buffer buf
     auto produce_quarter = [&](auto Tc, auto Gc, int buf) __attribute__((always_inline)) {
         constexpr int rt = decltype(Tc)::value, g = decltype(Gc)::value;
         unsigned char *dst = s_planes + buf * GR_TILE + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
@@ -277,25 +298,24 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);        // scale | shift of these 4 columns
         const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
         const f32x16 &a = GR_TILEVAL(rt);
-        const float v[4] = {bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y), bn_relu_ss(a[4 * g + 2], s4.z, h4.z),
-                            bn_relu_ss(a[4 * g + 3], s4.w, h4.w)};
-        uint2 p0, p1, p2;
-        split3x4(v, p0, p1, p2);
+        uint2 p0, p1;
+        split2x4(f32x2{bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y)},
+                 f32x2{bn_relu_ss(a[4 * g + 2], s4.z, h4.z), bn_relu_ss(a[4 * g + 3], s4.w, h4.w)}, p0, p1);
         *reinterpret_cast<uint2 *>(dst) = p0;
         *reinterpret_cast<uint2 *>(dst + GR_PLANE) = p1;
-        *reinterpret_cast<uint2 *>(dst + 2 * GR_PLANE) = p2;
     };
     auto produce_tile = [&](auto Tc, int buf) __attribute__((always_inline)) {
         gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) { produce_quarter(Tc, Gc, buf); });
         __builtin_amdgcn_sched_barrier(0);
     };
-    // multiply tile RT (planes in buffer `buf`) by the resident weight fragments -> acc[RT].  One wave per SIMD is in-order: a
-    // vector instruction placed behind a run of matrix instructions waits for all of them to issue, and the matrix pipe then idles
-    // behind a run of vector instructions.  hipcc emits each kind as one clump (and sched_group_barrier did not change that
-    // here), so the stream is hand-placed: 48 slices of ONE matrix instruction + 3..5 vector / LDS instructions, each closed by
-    // a scheduling barrier.  The vector work riding along is a quarter (per 12 slices) of the NEXT tile's plane production
-    // (BatchNorm + ReLU + exact split of its resident values) and of the PREVIOUS tile's BatchNorm sums, plus the operand reads
-    // of the following k-steps.
+    // multiply tile RT (planes in buffer `buf`) by the resident weight fragments -> acc[RT]: per k-step the three significant
+    // products of the (high | low) operand pieces, smallest first: w_hi x_lo, w_lo x_hi, w_hi x_hi.  One wave per SIMD is
+    // in-order: a vector instruction placed behind a run of matrix instructions waits for all of them to issue, and the matrix
+    // pipe then idles behind a run of vector instructions.  hipcc emits each kind as one clump (and sched_group_barrier did not
+    // change that here), so the stream is hand-placed: 24 slices of ONE matrix instruction + 4..6 vector / LDS instructions, each
+    // closed by a scheduling barrier.  The vector work riding along is a quarter (per 6 slices) of the NEXT tile's plane
+    // production (BatchNorm + ReLU + split of its resident values) and of the PREVIOUS tile's BatchNorm sums, plus the operand
+    // reads of the following k-steps.
     const unsigned char *xa0 = s_planes + n * GR_ROWB + 16 * h;
 #define GR_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define GR_PIN_V() do { } while (0)
@@ -303,20 +323,17 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         constexpr int RT = decltype(Tc)::value;
         constexpr bool NEXT = decltype(NEXTc)::value && (RT + 1 < GR_NT) && !(GR_ABL & 1);
         constexpr bool STATS = RT > 0 && RT - 1 < GR_NRES && !(GR_ABL & 4);     // (a spilled tile's sums are taken when it is stored)
-        constexpr bool W2LDS = decltype(NEXTc)::value;                // the layers that produce planes from registers (no aggregation)
         const unsigned char *xa = xa0 + buf * GR_TILE;
         const int nb = (RT + 1) & 1;
         const float *bn = (RT + 1) * 32 + n < nrows ? s_bn : s_zero;      // rows >= nrows: scale = shift = 0 -> zero planes
-        bf16x8 xf[2][3];
+        gr_h8 xf[2][2];
 #pragma unroll
-        for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + p * GR_PLANE);
+        for (int p = 0; p < 2; p++) xf[0][p] = *reinterpret_cast<const gr_h8 *>(xa + p * GR_PLANE);
         float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = s4;
         if constexpr (NEXT) {
             s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 4 * h);
             h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 4 * h);
         }
-        bf16x8 wA = wf[2][0], wB = wf[2][0];                          // plane-2 weight fragments of the even / odd k-step in flight
-        if constexpr (W2LDS) wA = *reinterpret_cast<const bf16x8 *>(s_w2);
         f32x16 atmp;
         f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : atmp;     // (its previous-layer values went into the planes one tile ago)
         a = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -324,89 +341,53 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if constexpr (decltype(NEXTc)::value && RT + 2 >= GR_NRES && RT + 2 < GR_NT) zload(std::integral_constant<int, RT + 2 - GR_NRES>{});
         gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
             constexpr int g = decltype(Pc)::value;                       // region = k-steps 2g, 2g+1 = column quarter g of the next tile
-            const bf16x8 *x0 = xf[0], *x1 = xf[1];
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-            unsigned pa = 0, pb = 0, qa = 0, qb = 0, ra = 0, rb = 0, t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            const gr_h8 *x0 = xf[0], *x1 = xf[1];
+            f32x2 v01 = {0.f, 0.f}, v23 = {0.f, 0.f}, e01 = v01, e23 = v01;
+            gr_h2 p01 = {0, 0}, p23 = p01, q01 = p01, q23 = p01;
             unsigned char *dst = s_planes + nb * GR_TILE + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
             const f32x16 &nx = GR_TILEVAL(RT + 1 < GR_NT ? RT + 1 : RT);
             const f32x16 &pv = acc[RT > 0 && RT - 1 < GR_NRES ? RT - 1 : 0];
             auto M = [&](int ks, int wp, int xp) __attribute__((always_inline)) {
-                const bf16x8 w = (wp == 2 && W2LDS) ? ((ks & 1) ? wB : wA) : wf[wp][ks];
-                if (!(GR_ABL & 2)) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
+                if (!(GR_ABL & 2)) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
             };
-            auto cvt2 = [&](float lo, float hi) __attribute__((always_inline)) {
-                return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2));          // v_cvt_pk_bf16_f32
-            };
-            // The production chain of a quarter (4 values: scale/shift+ReLU, three round-to-nearest bf16 levels with exact remainders)
-            // is laid out level by level, so that neighbouring vector instructions are independent of each other.
             // slice 0
-            M(2 * g, 0, 2);                                              // smallest terms first: w0 x2, w2 x0, w1 x1, w0 x1, w1 x0, w0 x0
-            xf[1][0] = *reinterpret_cast<const bf16x8 *>(xa + 0 * GR_PLANE + 32 * (2 * g + 1));
-            if constexpr (NEXT) { v0 = __builtin_fmaf(nx[4 * g], s4.x, h4.x); v1 = __builtin_fmaf(nx[4 * g + 1], s4.y, h4.y);
-                                  v2 = __builtin_fmaf(nx[4 * g + 2], s4.z, h4.z); v3 = __builtin_fmaf(nx[4 * g + 3], s4.w, h4.w); }
+            M(2 * g, 0, 1);
+            xf[1][0] = *reinterpret_cast<const gr_h8 *>(xa + 32 * (2 * g + 1));
+            if constexpr (NEXT) { v01 = __builtin_elementwise_fma(f32x2{nx[4 * g], nx[4 * g + 1]}, f32x2{s4.x, s4.y}, f32x2{h4.x, h4.y});
+                                  v23 = __builtin_elementwise_fma(f32x2{nx[4 * g + 2], nx[4 * g + 3]}, f32x2{s4.z, s4.w}, f32x2{h4.z, h4.w}); }
             GR_FENCE();
             // slice 1
-            M(2 * g, 2, 0);
-            xf[1][1] = *reinterpret_cast<const bf16x8 *>(xa + 1 * GR_PLANE + 32 * (2 * g + 1));
-            if constexpr (NEXT) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+            M(2 * g, 1, 0);
+            xf[1][1] = *reinterpret_cast<const gr_h8 *>(xa + GR_PLANE + 32 * (2 * g + 1));
+            if constexpr (NEXT) { v01 = __builtin_elementwise_max(v01, f32x2{0.f, 0.f}); v23 = __builtin_elementwise_max(v23, f32x2{0.f, 0.f}); }
             GR_FENCE();
             // slice 2
-            M(2 * g, 1, 1);
-            xf[1][2] = *reinterpret_cast<const bf16x8 *>(xa + 2 * GR_PLANE + 32 * (2 * g + 1));
-            if constexpr (NEXT) { pa = cvt2(v0, v1); pb = cvt2(v2, v3); }
-            if constexpr (NEXT && g < 3) s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * (g + 1) + 4 * h);   // scale | shift of the next quarter (this one's are used up):
+            M(2 * g, 0, 0);
+            if constexpr (NEXT) { p01 = __builtin_convertvector(v01, gr_h2); p23 = __builtin_convertvector(v23, gr_h2); }
+            if constexpr (NEXT && g < 3) s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * (g + 1) + 4 * h);   // scale | shift of the next quarter (this one's are used up)
             GR_FENCE();
-            // slice 3
-            M(2 * g, 0, 1);
-            if constexpr (NEXT) { t0 = pa << 16; t1 = pa & 0xffff0000u; t2 = pb << 16; t3 = pb & 0xffff0000u; }
-            if constexpr (NEXT && g < 3) h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * (g + 1) + 4 * h);   // ... nine slices ahead of its use
-            if constexpr (W2LDS) wB = *reinterpret_cast<const bf16x8 *>(s_w2 + (2 * g + 1) * 1024);
+            // slice 3: the k-step 2g operands are dead once its three instructions have issued
+            M(2 * g + 1, 0, 1);
+            if constexpr (g < 3) xf[0][0] = *reinterpret_cast<const gr_h8 *>(xa + 32 * (2 * g + 2));
+            if constexpr (NEXT) { e01 = __builtin_convertvector(p01, f32x2); e23 = __builtin_convertvector(p23, f32x2); }
+            if constexpr (NEXT && g < 3) h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * (g + 1) + 4 * h);
             GR_FENCE();
             // slice 4
-            M(2 * g, 1, 0);
-            if constexpr (NEXT) { v0 -= __builtin_bit_cast(float, t0); v1 -= __builtin_bit_cast(float, t1); v2 -= __builtin_bit_cast(float, t2); v3 -= __builtin_bit_cast(float, t3);
-                                  if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst) = make_uint2(pa, pb); }
+            M(2 * g + 1, 1, 0);
+            if constexpr (g < 3) xf[0][1] = *reinterpret_cast<const gr_h8 *>(xa + GR_PLANE + 32 * (2 * g + 2));
+            if constexpr (NEXT) { v01 -= e01; v23 -= e23;
+                                  if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23));
+                                  q01 = __builtin_convertvector(v01, gr_h2); q23 = __builtin_convertvector(v23, gr_h2); }
             GR_FENCE();
             // slice 5
-            M(2 * g, 0, 0);
-            if constexpr (NEXT) { qa = cvt2(v0, v1); qb = cvt2(v2, v3); }
-            GR_FENCE();
-            // slice 6: the k-step 2g operands are dead once its six instructions have issued
-            M(2 * g + 1, 0, 2);
-            if constexpr (g < 3) xf[0][0] = *reinterpret_cast<const bf16x8 *>(xa + 0 * GR_PLANE + 32 * (2 * g + 2));
-            if constexpr (NEXT) { t0 = qa << 16; t1 = qa & 0xffff0000u; t2 = qb << 16; t3 = qb & 0xffff0000u; }
-            GR_FENCE();
-            // slice 7
-            M(2 * g + 1, 2, 0);
-            if constexpr (g < 3) xf[0][1] = *reinterpret_cast<const bf16x8 *>(xa + 1 * GR_PLANE + 32 * (2 * g + 2));
-            if constexpr (NEXT) { v0 -= __builtin_bit_cast(float, t0); v1 -= __builtin_bit_cast(float, t1); v2 -= __builtin_bit_cast(float, t2); v3 -= __builtin_bit_cast(float, t3);
-                                  if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst + GR_PLANE) = make_uint2(qa, qb); }
-            GR_FENCE();
-            // slice 8
-            M(2 * g + 1, 1, 1);
-            if constexpr (g < 3) xf[0][2] = *reinterpret_cast<const bf16x8 *>(xa + 2 * GR_PLANE + 32 * (2 * g + 2));
-            if constexpr (NEXT) { ra = cvt2(v0, v1); rb = cvt2(v2, v3); }
-            if constexpr (STATS) { ts[4 * g] += pv[4 * g]; tq[4 * g] = __builtin_fmaf(pv[4 * g], pv[4 * g], tq[4 * g]); asm volatile("" : "+v"(ts[4 * g]), "+v"(tq[4 * g])); }
-            GR_FENCE();
-            // slice 9
-            M(2 * g + 1, 0, 1);
-            if constexpr (W2LDS && g < 3) wA = *reinterpret_cast<const bf16x8 *>(s_w2 + (2 * g + 2) * 1024);
-            if constexpr (NEXT) { if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst + 2 * GR_PLANE) = make_uint2(ra, rb); else asm volatile("" :: "v"(pa), "v"(pb), "v"(qa), "v"(qb), "v"(ra), "v"(rb)); }
-            if constexpr (STATS) { ts[4 * g + 1] += pv[4 * g + 1]; tq[4 * g + 1] = __builtin_fmaf(pv[4 * g + 1], pv[4 * g + 1], tq[4 * g + 1]); asm volatile("" : "+v"(ts[4 * g + 1]), "+v"(tq[4 * g + 1])); }
-            GR_FENCE();
-            // slice 10
-            M(2 * g + 1, 1, 0);
-            if constexpr (STATS) { ts[4 * g + 2] += pv[4 * g + 2]; tq[4 * g + 2] = __builtin_fmaf(pv[4 * g + 2], pv[4 * g + 2], tq[4 * g + 2]); asm volatile("" : "+v"(ts[4 * g + 2]), "+v"(tq[4 * g + 2])); }
-            GR_FENCE();
-            // slice 11
             M(2 * g + 1, 0, 0);
-            if constexpr (STATS) { ts[4 * g + 3] += pv[4 * g + 3]; tq[4 * g + 3] = __builtin_fmaf(pv[4 * g + 3], pv[4 * g + 3], tq[4 * g + 3]); asm volatile("" : "+v"(ts[4 * g + 3]), "+v"(tq[4 * g + 3])); }
+            if constexpr (NEXT) { if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst + GR_PLANE) = make_uint2(__builtin_bit_cast(unsigned, q01), __builtin_bit_cast(unsigned, q23));
+                                  else asm volatile("" :: "v"(p01), "v"(p23), "v"(q01), "v"(q23)); }
+            if constexpr (STATS) { stat2(2 * g, pv[4 * g], pv[4 * g + 1]); stat2(2 * g + 1, pv[4 * g + 2], pv[4 * g + 3]); }
             GR_FENCE();
         });
         if constexpr (RT >= GR_NRES) {                                // not resident: BatchNorm sums now, then out to its spill slot
-            if (!(GR_ABL & 4))
-#pragma unroll
-                for (int e = 0; e < 16; e++) { ts[e] += a[e]; tq[e] = __builtin_fmaf(a[e], a[e], tq[e]); }
+            stats_all(a);
             zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
             GR_FENCE();
         }
@@ -419,16 +400,15 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 #pragma unroll
         for (int p = 0; p < 3; p++) x[p] = *reinterpret_cast<const bf16x8 *>(xa + p * GR_PLANE);
         f32x16 a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][0], x[2], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[2][0], x[0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][0], x[1], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][0], x[1], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[1][0], x[0], a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[0][0], x[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[0], x[2], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[2], x[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[1], x[1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[0], x[1], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[1], x[0], a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[0], x[0], a, 0, 0, 0);
         if constexpr (RT < GR_NRES) acc[RT] = a;
         else {
-#pragma unroll
-            for (int e = 0; e < 16; e++) { ts[e] += a[e]; tq[e] = __builtin_fmaf(a[e], a[e], tq[e]); }
+            stats_all(a);
             zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
         }
         if constexpr (RT > 0 && RT - 1 < GR_NRES) stats_tile(std::integral_constant<int, RT - 1>{});
@@ -451,7 +431,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if (k == 1) GR_STAMP_AT(3);
         // requests that do not depend on the other workgroups go out before the wait: the next Linear's weight fragments
         // and this BatchNorm's affine parameters
-        if constexpr (k < 5) load_weights(k + 1, std::integral_constant<int, 8>{}, std::integral_constant<bool, k + 1 != 3>{});
+        if constexpr (k < 5) load_weights(k + 1);
         const float ga = A.gamma[k][tid & (HD - 1)], be = A.beta[k][tid & (HD - 1)];
         GR_STAMP_AT(5 + 4 * k);
         gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, part, total, s_flag);
@@ -459,12 +439,14 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if (tid < HD) {
             const double su = __hip_atomic_load(&total[2 * tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const double sq = __hip_atomic_load(&total[2 * tid + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double mean = su * A.inv_rows;
-            double var = sq * A.inv_rows - mean * mean;           // biased variance (training-mode BN)
+            // the accumulators hold z * wscale (power of two, exact): statistics of z, scale applied to the stored value
+            const double is = (double)A.wsinv[k];
+            const double mean = su * A.inv_rows * is;
+            double var = sq * A.inv_rows * is * is - mean * mean; // biased variance (training-mode BN)
             if (var < 0) var = 0;
             const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
             const float s = rstd * ga;
-            s_bn[tid] = s;
+            s_bn[tid] = s * A.wsinv[k];
             s_bn[HD + tid] = be - (float)mean * s;
         }
         LDS_BARRIER();
@@ -473,7 +455,11 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 
     // ---------------------------------------------------------------- layer 0 / Linear 0: aggregated raw features (12 -> 128)
     GR_STAMP_AT(0);
-    load_weights(0, std::integral_constant<int, 1>{}, std::false_type{});
+    {
+        const float4 *wi = reinterpret_cast<const float4 *>(A.Wx32[0]) + (size_t)wave * (3 * 64) + lane;
+#pragma unroll
+        for (int p = 0; p < 3; p++) w0f[p] = __builtin_bit_cast(bf16x8, wi[p * 64]);
+    }
     LDS_BARRIER();
     GR_STAMP_AT(1);
     {
@@ -582,11 +568,10 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                         // small-integer edge weights, <= 3 terms: an f32 FMA chain is within 2 ulp of the reference's f64-then-cast
                         const float v[4] = {__builtin_fmaf(w1, y.x, __builtin_fmaf(w0, x.x, o.x)) * inv, __builtin_fmaf(w1, y.y, __builtin_fmaf(w0, x.y, o.y)) * inv,
                                             __builtin_fmaf(w1, y.z, __builtin_fmaf(w0, x.z, o.z)) * inv, __builtin_fmaf(w1, y.w, __builtin_fmaf(w0, x.w, o.w)) * inv};
-                        uint2 p0, p1, p2;
-                        split3x4(v, p0, p1, p2);
+                        uint2 p0, p1;
+                        split2x4(f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, p0, p1);
                         *reinterpret_cast<uint2 *>(dst + 16 * g) = p0;
                         *reinterpret_cast<uint2 *>(dst + 16 * g + GR_PLANE) = p1;
-                        *reinterpret_cast<uint2 *>(dst + 16 * g + 2 * GR_PLANE) = p2;
                     });
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -138,10 +138,10 @@ class Encoder:
         capi.check(self.L.mtfjsp_encoder_set_bn_mode(self.h, 1 if per_instance else 0), self.h, enc=True)
 
     def set_product_mode(self, f32_instruction_mask=0):
-        """0 (default): 128x128 products as exact 3-way bf16 splits on the matrix cores (f32-accurate); bits select the f32
-        matrix instruction instead (1 GIN products, 2 GAT passes, 4 heads, 8 first GIN Linear on the VALU) — the A/B reference;
-        16 (not a numerics choice): the GIN encoder as ONE launch of the register-resident kernel instead of six streaming
-        launches, where the shape is eligible (check() tells); MTFJSP_RESIDENT_GIN=1 makes that the default of new encoders"""
+        """0 (default): 128x128 products on the 16-bit matrix cores from split f32 operands (f32-accurate: include/mtfjsp.h);
+        bits select the f32 matrix instruction instead (1 GIN products, 2 GAT passes, 4 heads, 8 first GIN Linear on the VALU) —
+        the A/B reference; 16 (not a numerics choice): the GIN encoder as six streaming launches even where the register-resident
+        single-launch kernel is eligible (check() tells which one runs)"""
         capi.check(self.L.mtfjsp_encoder_set_product_mode(self.h, int(f32_instruction_mask)), self.h, enc=True)
 
     def check(self):

@@ -249,13 +249,15 @@ int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask
  * evaluation of validate.py:60-297 batched over the evaluation set.  Not applied to the global critic. */
 int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance);
 /* How the [rows,128]x[128,128] products of the actor forwards (Linear layers of gcn:95-153 / ac:205-293, the GAT weight of
- * gat:82) are formed.  0 (default): every f32 operand is split exactly into three bf16 pieces and the six significant piece
- * products are accumulated in f32 on the bf16 matrix cores — as accurate as an f32 FMA chain.  Bits select
- * the f32 matrix instruction instead, as the A/B reference: 1 = GIN products, 2 = GAT passes, 4 = actor/critic heads,
- * 8 = first GIN Linear (12 -> 128) on the vector ALU.  Bit 16 is not a numerics choice: it runs the whole GIN encoder as ONE
- * launch of the register-resident kernel (k_gin_res; in-kernel grid barriers for the batch statistics) instead of six streaming
- * launches (k_gemm_x6), where the shape is eligible (16 <= T <= 65, <= 576 node rows per CU, census launch passed in
- * mtfjsp_encoder_create); MTFJSP_RESIDENT_GIN=1 in the environment makes that the default of new handles. */
+ * gat:82) are formed.  0 (default): on the 16-bit matrix cores with f32 accumulation, from operands split into pieces —
+ * three bf16 pieces (exact) and the six significant piece products in the streaming kernels, two f16 pieces (relative
+ * representation error <= 2^-22) and the three significant products in the single-launch GIN kernel; both are as accurate as
+ * an f32 FMA chain of the same length to within a small factor (tests/test_encoder_hip.py states the bounds).
+ * Bits select the f32 matrix instruction instead, as the A/B reference: 1 = GIN products, 2 = GAT passes, 4 = actor/critic
+ * heads, 8 = first GIN Linear (12 -> 128) on the vector ALU.  Bit 16 is not a numerics choice: it runs the GIN encoder as six
+ * streaming launches (k_gemm_x6) even where the single-launch register-resident kernel (k_gin_res; in-kernel grid barriers for
+ * the batch statistics) is eligible (16 <= T <= 65, <= 576 node rows per CU, census launch passed in mtfjsp_encoder_create);
+ * MTFJSP_NO_RESIDENT_GIN=1 in the environment does the same for every handle. */
 int mtfjsp_encoder_set_product_mode(mtfjsp_encoder_t e, int32_t f32_instruction_mask);
 /* Fuse the action selection of the NEXT mtfjsp_job_actor_forward (which = 0) / mtfjsp_machine_actor_forward (which = 1) call into
  * its heads kernel: same arguments and the same Philox stream as mtfjsp_sample_categorical on that forward's `prob`
@@ -268,8 +270,8 @@ int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_ctx_t *ctx);
 /* Synchronises the encoder's stream and reports asynchronous failures of the forwards enqueued so far: the single-launch GIN
  * kernel synchronises its workgroups with in-kernel grid barriers whose spins are bounded; a timeout (not all workgroups
  * resident) is latched and returned here as MTFJSP_ERR_STATE.  *gin_resident_out (may be NULL) = 1 when that kernel is in use
- * for this handle (selected by product-mode bit 16 and verified eligible by a census launch in mtfjsp_encoder_create), 0 when
- * the six streaming launches are. */
+ * for this handle (shape verified eligible by a census launch in mtfjsp_encoder_create, product-mode bits 1, 8, 16 clear), 0
+ * when the six streaming launches are. */
 int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_out);
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
 int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);

@@ -34,12 +34,12 @@ def test_actor_forwards_match_reference_outputs(name, obs, gin):
     ja, ma = eo.split_weights(g)
     enc = enc_mod.Encoder(J, M, B, obs_dtype=obs)
     enc.load_weights(ja, ma, eo.critic_weights(g))
-    if gin == "resident":          # the single-launch register-resident GIN kernel (product-mode bit 16), where the shape is eligible
-        enc.set_product_mode(16)
+    if gin == "resident":          # the single-launch register-resident GIN kernel: the default where the shape is eligible
         assert enc.check() == (16 <= T <= 65)
         if not enc.check():
             pytest.skip("shape not eligible for the resident GIN kernel")
-    else:
+    else:                          # six streaming launches (product-mode bit 16)
+        enc.set_product_mode(16)
         assert not enc.check()
     odt = torch.float32 if obs == "f32" else torch.float64
     for s in g["steps"]:

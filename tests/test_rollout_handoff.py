@@ -148,9 +148,11 @@ def _forced_rollout(f, collect, gin="streaming"):
     ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=(w["ja"], w["ma"]), collect=collect,
                          buffer_episodes=eps, gamma=g, lam=lam, instances=(f["t"], f["p"], f["tt"], f["edge"]),
                          w3_episodes=f["w3"])
-    if gin == "resident":                               # single-launch GIN kernel (product-mode bit 16); J6M6 is eligible
-        ro.actor.enc.set_product_mode(16)
+    if gin == "resident":                               # single-launch GIN kernel: the default, J6M6 is eligible
         assert ro.actor.enc.check()
+    else:                                               # six streaming launches
+        ro.actor.enc.set_product_mode(16)
+        assert not ro.actor.enc.check()
     return ro, (J, M, E, B, eps)
 
 
