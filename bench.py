@@ -35,12 +35,15 @@ def env_bytes(J, M):
     return 136 * T + 156 * M + 483
 
 
+PMC_FILE = "r02_pmc_traffic.json"
+
+
 def pmc_traffic(family):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  PMC
     collection cannot run inside the timed process, so bench.py reports the last committed measurement (B=4096 J6M6E2)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"][family]
+        d = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"][family]
         return d["traffic_bytes"]
     except Exception:
         return None
@@ -235,7 +238,7 @@ def main():
         kd = ktimes[dom]
         avg_s = kd["ms_total"] / max(kd["launches"], 1) * 1e-3
         headline = (B, J, M) == (4096, 6, 6)
-        traffic_note = ("profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at B=4096 J6M6E2, "
+        traffic_note = (f"profiles/{PMC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at B=4096 J6M6E2, "
                         "FETCH_SIZE x2 gfx950 correction; not re-measured inside this run)")
 
         def env_roof(sec, name):
@@ -266,7 +269,7 @@ def main():
             "metric": "env-steps/sec (batched J%dM%dE%d)" % (J, M, E), "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / steps_timed * 1e3,
             "steps_timed": steps_timed, "timed_blocks": blocks, "timed_seconds": elapsed,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (environment) / f32 (encoder: f32 storage and accumulation; GIN products as exact 3-way bf16 splits on the matrix cores, f32-accurate)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (environment) / f32 (encoder: f32 storage and accumulation; 128x128 products on the 16-bit matrix cores from split f32 operands, f32-accurate: DESIGN.md §4)", "data": "synthetic",
             "config": {"workload": f"J{J}M{M}E{E}, {B} parallel instances per GPU ({ro.instances_desc}), {ro.describe()}",
                        "instances_per_gpu": B, "obs_dtype": args.obs, "policy": policy, "trajectory": args.trajectory,
                        "parallelism": f"instances sharded over {world} GPU(s); env/encoder path has no collective; one all-gather of advantages per {ro.S}-step buffer (RCCL when world>1)"},

@@ -545,43 +545,137 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                 const int t = R >> 5;
                 return ((t - GR_RING * ((t * 43) >> 8)) * 32 + (R & 31)) * HD;   // t % 6 for t < 128
             };
-            write_h(std::integral_constant<int, 0>{}); write_h(std::integral_constant<int, 1>{}); write_h(std::integral_constant<int, 2>{});
-            LDS_BARRIER();
-            gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
+            // per-row constants of tile RT's aggregation: ring pointers of the row and of its (<= 2) in-edge sources, edge weights, 1 / nnz
+            struct AggRow { const float *po, *px, *py; float w0, w1, inv; int s0, s1, s2; };
+            auto agg_row = [&](int RT) __attribute__((always_inline)) {
+                AggRow r;
+                const int row = RT * 32 + n;
+                const unsigned cp = s_ellc[row];
+                const unsigned r0 = cp & 0xffffu, r1 = cp >> 16;
+                r.w0 = s_ellv0[row]; r.w1 = s_ellv1[row];
+                const int deg = 1 + (r0 != 0xffffu) + (r1 != 0xffffu);
+                r.inv = deg == 1 ? 1.0f : deg == 2 ? 0.5f : (1.0f / 3.0f);
+                const int n0 = r0 != 0xffffu ? (int)r0 : row, n1 = r1 != 0xffffu ? (int)r1 : row;
+                r.po = s_ring + ((RT % GR_RING) * 32 + n) * HD; r.px = s_ring + ring_row(n0); r.py = s_ring + ring_row(n1);
+                r.s0 = n & 7; r.s1 = n0 & 7; r.s2 = n1 & 7;
+                return r;
+            };
+            // small-integer edge weights, <= 3 terms: an f32 FMA chain is within 2 ulp of the reference's f64-then-cast
+            auto agg_quarter_standalone = [&](const AggRow &r, int g, unsigned char *dst) __attribute__((always_inline)) {
+                const int chl = 8 * wave + 2 * g + h;
+                const float4 o = *reinterpret_cast<const float4 *>(r.po + 4 * (chl ^ r.s0));
+                const float4 x = *reinterpret_cast<const float4 *>(r.px + 4 * (chl ^ r.s1));
+                const float4 y = *reinterpret_cast<const float4 *>(r.py + 4 * (chl ^ r.s2));
+                const f32x2 W0 = {r.w0, r.w0}, W1 = {r.w1, r.w1}, IV = {r.inv, r.inv};
+                const f32x2 v01 = __builtin_elementwise_fma(W1, f32x2{y.x, y.y}, __builtin_elementwise_fma(W0, f32x2{x.x, x.y}, f32x2{o.x, o.y})) * IV;
+                const f32x2 v23 = __builtin_elementwise_fma(W1, f32x2{y.z, y.w}, __builtin_elementwise_fma(W0, f32x2{x.z, x.w}, f32x2{o.z, o.w})) * IV;
+                uint2 p0, p1;
+                split2x4(v01, v23, p0, p1);
+                *reinterpret_cast<uint2 *>(dst + 16 * g) = p0;
+                *reinterpret_cast<uint2 *>(dst + 16 * g + GR_PLANE) = p1;
+            };
+            // tile RT: matrix products of its planes, with the aggregation + split of tile RT+1 (h of tiles RT-1..RT+3 from the ring)
+            // and the h = relu(bn(z)) of tile RT+4 (into the ring slot of tile RT-2) riding between the matrix instructions
+            auto consume_agg = [&](auto Tc) __attribute__((always_inline)) {
                 constexpr int RT = decltype(Tc)::value;
-                {
-                    const int row = RT * 32 + n;
-                    const unsigned cp = s_ellc[row];
-                    const unsigned r0 = cp & 0xffffu, r1 = cp >> 16;
-                    const float w0 = s_ellv0[row], w1 = s_ellv1[row];
-                    const int deg = 1 + (r0 != 0xffffu) + (r1 != 0xffffu);
-                    const float inv = deg == 1 ? 1.0f : deg == 2 ? 0.5f : (1.0f / 3.0f);
-                    const int n0 = r0 != 0xffffu ? (int)r0 : row, n1 = r1 != 0xffffu ? (int)r1 : row;
-                    const float *po = s_ring + ((RT % GR_RING) * 32 + n) * HD, *px = s_ring + ring_row(n0), *py = s_ring + ring_row(n1);
-                    unsigned char *dst = s_planes + (RT & 1) * GR_TILE + n * GR_ROWB + (32 * wave + 4 * h) * 2;
-                    gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) {
-                        constexpr int g = decltype(Gc)::value;
-                        const int chl = 8 * wave + 2 * g + h;
-                        const float4 o = *reinterpret_cast<const float4 *>(po + 4 * (chl ^ (n & 7)));
-                        const float4 x = *reinterpret_cast<const float4 *>(px + 4 * (chl ^ (n0 & 7)));
-                        const float4 y = *reinterpret_cast<const float4 *>(py + 4 * (chl ^ (n1 & 7)));
-                        // small-integer edge weights, <= 3 terms: an f32 FMA chain is within 2 ulp of the reference's f64-then-cast
-                        const float v[4] = {__builtin_fmaf(w1, y.x, __builtin_fmaf(w0, x.x, o.x)) * inv, __builtin_fmaf(w1, y.y, __builtin_fmaf(w0, x.y, o.y)) * inv,
-                                            __builtin_fmaf(w1, y.z, __builtin_fmaf(w0, x.z, o.z)) * inv, __builtin_fmaf(w1, y.w, __builtin_fmaf(w0, x.w, o.w)) * inv};
-                        uint2 p0, p1;
-                        split2x4(f32x2{v[0], v[1]}, f32x2{v[2], v[3]}, p0, p1);
-                        *reinterpret_cast<uint2 *>(dst + 16 * g) = p0;
-                        *reinterpret_cast<uint2 *>(dst + 16 * g + GR_PLANE) = p1;
-                    });
+                constexpr bool NEXT = RT + 1 < GR_NT && !(GR_ABL & 1);
+                constexpr bool WH = RT + 4 < GR_NT && !(GR_ABL & 1);
+                constexpr int WT = WH ? RT + 4 : RT;
+                constexpr bool STATS = RT > 0 && RT - 1 < GR_NRES && !(GR_ABL & 4);
+                const unsigned char *xa = xa0 + (RT & 1) * GR_TILE;
+                gr_h8 xf[2][2];
+#pragma unroll
+                for (int p = 0; p < 2; p++) xf[0][p] = *reinterpret_cast<const gr_h8 *>(xa + p * GR_PLANE);
+                AggRow r = agg_row(NEXT ? RT + 1 : RT);
+                unsigned char *dst = s_planes + ((RT + 1) & 1) * GR_TILE + n * GR_ROWB + (32 * wave + 4 * h) * 2;
+                const float *bnw = WT * 32 + n < nrows ? s_bn : s_zero;
+                float *hbase = s_ring + ((WT % GR_RING) * 32 + n) * HD;
+                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = s4;
+                if constexpr (WH) {
+                    s4 = *reinterpret_cast<const float4 *>(bnw + 32 * wave + 4 * h);
+                    h4 = *reinterpret_cast<const float4 *>(bnw + HD + 32 * wave + 4 * h);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if constexpr (RT + 5 >= GR_NRES && RT + 5 < GR_NT) zload(std::integral_constant<int, RT + 5 - GR_NRES>{});   // the spilled tiles, two iterations ahead
-                if constexpr (RT + 3 < GR_NT) write_h(std::integral_constant<int, RT + 3>{});     // into the slot of tile RT-3 (no longer needed)
+                f32x16 atmp;
+                f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : atmp;
+                // the spilled tiles' old values: requested two tiles before they are turned into h
+                if constexpr (RT + 6 >= GR_NRES && RT + 6 < GR_NT) zload(std::integral_constant<int, RT + 6 - GR_NRES>{});
+                gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
+                    constexpr int g = decltype(Pc)::value;
+                    const gr_h8 *x0 = xf[0], *x1 = xf[1];
+                    const f32x16 &wv = GR_TILEVAL(WT);
+                    const f32x16 &pv = acc[RT > 0 && RT - 1 < GR_NRES ? RT - 1 : 0];
+                    const int chl = 8 * wave + 2 * g + h;
+                    float4 o = make_float4(0.f, 0.f, 0.f, 0.f), x = o, y = o;
+                    f32x2 v01 = {0.f, 0.f}, v23 = v01, e01 = v01, e23 = v01, u01 = v01, u23 = v01;
+                    gr_h2 p01 = {0, 0}, p23 = p01, q01 = p01, q23 = p01;
+                    const f32x2 W0 = {r.w0, r.w0}, W1 = {r.w1, r.w1}, IV = {r.inv, r.inv};
+                    auto M = [&](int ks, int wp, int xp) __attribute__((always_inline)) {
+                        if (!(GR_ABL & 2)) {
+                            if (g == 0 && ks == 0 && wp == 0 && xp == 1)
+                                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], x0[xp], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            else a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
+                        }
+                    };
+                    // slice 0
+                    M(2 * g, 0, 1);
+                    xf[1][0] = *reinterpret_cast<const gr_h8 *>(xa + 32 * (2 * g + 1));
+                    if constexpr (NEXT) { o = *reinterpret_cast<const float4 *>(r.po + 4 * (chl ^ r.s0)); x = *reinterpret_cast<const float4 *>(r.px + 4 * (chl ^ r.s1));
+                                          y = *reinterpret_cast<const float4 *>(r.py + 4 * (chl ^ r.s2)); }
+                    if constexpr (STATS) { stat2(2 * g, pv[4 * g], pv[4 * g + 1]); stat2(2 * g + 1, pv[4 * g + 2], pv[4 * g + 3]); }
+                    GR_FENCE();
+                    // slice 1
+                    M(2 * g, 1, 0);
+                    xf[1][1] = *reinterpret_cast<const gr_h8 *>(xa + GR_PLANE + 32 * (2 * g + 1));
+                    if constexpr (WH) { u01 = __builtin_elementwise_max(__builtin_elementwise_fma(f32x2{wv[4 * g], wv[4 * g + 1]}, f32x2{s4.x, s4.y}, f32x2{h4.x, h4.y}), f32x2{0.f, 0.f});
+                                        u23 = __builtin_elementwise_max(__builtin_elementwise_fma(f32x2{wv[4 * g + 2], wv[4 * g + 3]}, f32x2{s4.z, s4.w}, f32x2{h4.z, h4.w}), f32x2{0.f, 0.f}); }
+                    GR_FENCE();
+                    // slice 2
+                    M(2 * g, 0, 0);
+                    if constexpr (WH) *reinterpret_cast<float4 *>(hbase + 4 * (chl ^ (n & 7))) = make_float4(u01[0], u01[1], u23[0], u23[1]);
+                    if constexpr (NEXT) { v01 = __builtin_elementwise_fma(W0, f32x2{x.x, x.y}, f32x2{o.x, o.y}); v23 = __builtin_elementwise_fma(W0, f32x2{x.z, x.w}, f32x2{o.z, o.w}); }
+                    if constexpr (WH && g < 3) s4 = *reinterpret_cast<const float4 *>(bnw + 32 * wave + 8 * (g + 1) + 4 * h);
+                    GR_FENCE();
+                    // slice 3
+                    M(2 * g + 1, 0, 1);
+                    if constexpr (g < 3) xf[0][0] = *reinterpret_cast<const gr_h8 *>(xa + 32 * (2 * g + 2));
+                    if constexpr (NEXT) { v01 = __builtin_elementwise_fma(W1, f32x2{y.x, y.y}, v01); v23 = __builtin_elementwise_fma(W1, f32x2{y.z, y.w}, v23); }
+                    if constexpr (WH && g < 3) h4 = *reinterpret_cast<const float4 *>(bnw + HD + 32 * wave + 8 * (g + 1) + 4 * h);
+                    GR_FENCE();
+                    // slice 4
+                    M(2 * g + 1, 1, 0);
+                    if constexpr (g < 3) xf[0][1] = *reinterpret_cast<const gr_h8 *>(xa + GR_PLANE + 32 * (2 * g + 2));
+                    if constexpr (NEXT) { v01 *= IV; v23 *= IV; p01 = __builtin_convertvector(v01, gr_h2); p23 = __builtin_convertvector(v23, gr_h2);
+                                          e01 = __builtin_convertvector(p01, f32x2); e23 = __builtin_convertvector(p23, f32x2); }
+                    GR_FENCE();
+                    // slice 5
+                    M(2 * g + 1, 0, 0);
+                    if constexpr (NEXT) { v01 -= e01; v23 -= e23; q01 = __builtin_convertvector(v01, gr_h2); q23 = __builtin_convertvector(v23, gr_h2);
+                                          *reinterpret_cast<uint2 *>(dst + 16 * g) = make_uint2(__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23));
+                                          *reinterpret_cast<uint2 *>(dst + 16 * g + GR_PLANE) = make_uint2(__builtin_bit_cast(unsigned, q01), __builtin_bit_cast(unsigned, q23)); }
+                    GR_FENCE();
+                });
+                if constexpr (RT >= GR_NRES) {
+                    stats_all(a);
+                    zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
+                    GR_FENCE();
+                }
+            };
+            write_h(std::integral_constant<int, 0>{}); write_h(std::integral_constant<int, 1>{}); write_h(std::integral_constant<int, 2>{});
+            write_h(std::integral_constant<int, 3>{});
+            LDS_BARRIER();
+            {
+                const AggRow r = agg_row(0);
+                unsigned char *dst = s_planes + n * GR_ROWB + (32 * wave + 4 * h) * 2;
+#pragma unroll
+                for (int g = 0; g < 4; g++) agg_quarter_standalone(r, g, dst);
+            }
+            LDS_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+            gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
+                consume_agg(Tc);
                 LDS_BARRIER();
                 __builtin_amdgcn_sched_barrier(0);
-                consume_tile(Tc, std::false_type{}, RT & 1);
             });
-            LDS_BARRIER();
         }
         layer_boundary(std::integral_constant<int, layer>{});
     });

@@ -254,8 +254,9 @@ class ActorPair:
         return self.enc.timing_end()
 
     def roofline(self, name, kd, B):
-        """HBM roofline for the GIN products (k_gemm_x6 streams 1 KiB per row: 512 B in, 512 B out; its matrix work runs on
-        the bf16 cores and is far from their peak), f32 MFMA roofline for the fused GAT kernel."""
+        """matrix-core roofline for the single-launch GIN kernel; HBM roofline for the streaming GIN products (k_gemm_x6 streams
+        1 KiB per row: 512 B in, 512 B out; its matrix work is far from the peak); f32 MFMA roofline for the fused GAT kernel
+        (DESIGN.md §4)."""
         import os
         J, M, T = self.enc.J, self.enc.M, self.enc.T
         avg_s = kd["ms_total"] / max(kd["launches"], 1) * 1e-3
@@ -277,6 +278,23 @@ class ActorPair:
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_bytes_per_launch": nbytes,
                     "algorithmic_flops_per_launch": flops, "f32_equivalent_TFLOPs": flops / avg_s / 1e12,
                     "bf16_matrix_TFLOPs": 6 * flops / avg_s / 1e12}
+        if name == "gin_resident":
+            # k_gin_res: the six Linear products of one forward in one launch.  Algorithmic work = the f32 products of the
+            # reference (2 * rows * (12*128 + 5*128*128)); executed on the f16 matrix cores as 3 piece products each (the first
+            # Linear: 6 bf16 piece products of a 16-wide k-step).  Bound: the dense 16-bit matrix peak (2.5 PFLOP/s).
+            rows = B * T
+            flops = 2.0 * rows * (12 * H + 5 * H * H)
+            executed = 2.0 * rows * (6 * 16 * H + 3 * 5 * H * H)
+            ach = executed / avg_s / 1e12
+            return {"kernel": f"k_gin_res (whole GIN encoder of one forward, [{rows},12]->128 + 5 x [{rows},128]x[128,128] + 6 batch-wide BatchNorms, "
+                              "activations resident in registers, 2-way f16 operand split = 3 piece products per product, f32 accumulate, "
+                              "6 in-kernel grid barriers; graph pool + candidate gather fused)",
+                    "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
+                    "what_is_counted": "executed piece-product flops (3 per algorithmic f32 product; 6 in the 12->128 Linear)",
+                    "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "executed_matrix_flops_per_launch": executed,
+                    "algorithmic_flops_per_launch": flops, "f32_equivalent_TFLOPs": flops / avg_s / 1e12,
+                    "f32_equivalent_frac_of_f32_matrix_peak_157.3": flops / avg_s / 1e12 / 157.3,
+                    "hbm_bytes_algorithmic_per_launch": rows * (12 * 4 + 16) + B * (H + J * H) * 4}
         if name == "gat3":
             rows = 2 * B * M
             flops = 2.0 * rows * H * H * 3

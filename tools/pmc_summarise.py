@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) into profiles/r01_pmc_traffic.json.
+"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) into profiles/<round>_pmc_traffic.json.
 
-    python tools/pmc_summarise.py gpurun_out/pmc_traffic_raw2.json profiles/r01_pmc_traffic.json
+    python tools/pmc_summarise.py gpurun_out/r02g_pmc_raw.json profiles/r02_pmc_traffic.json
 
 Input: {kernel name prefix: {FETCH_SIZE_avg, WRITE_SIZE_avg (KiB per launch), launches_*}} as written by the inline
 post-processing of the gpurun command.  gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE under-reports wide
@@ -14,7 +14,7 @@ FAMILY = {
     "void k_gemm_x6<1>": "gin_gemm_bn_relu", "void k_gemm_x6<2>": "gin_gemm_agg", "void k_gemm_x6<3>": "gin0_agg_linear12",
     "void k_gemm16p<1>": "gin_gemm_bn_relu", "void k_gemm16p<2>": "gin_gemm_agg", "void k_env_reg<float>": "env_step",
     "k_heads": "heads", "k_gat3": "gat3", "void k_gin0<float>": "gin0_agg_linear12", "k_job_pool_gather": "job_pool_gather",
-    "void k_mfea1<float>": "mfea1", "void k_env_reset<float>": "env_reset", "k_gae": "gae", "k_snapshot": "snapshot",
+    "void k_mfea1<float>": "mfea1", "k_gin_res": "gin_resident", "void k_env_reset<float>": "env_reset", "k_gae": "gae", "k_snapshot": "snapshot",
 }
 raw = json.load(open(sys.argv[1]))
 out = {"_provenance": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes) -- python3 bench.py "
