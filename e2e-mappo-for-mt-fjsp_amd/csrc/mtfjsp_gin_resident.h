@@ -36,7 +36,8 @@
 #include <type_traits>
 #include <utility>
 
-#ifndef GR_ABL                            // diagnostic timing ablations (wrong results): 1 no plane production, 2 no matrix products, 4 no statistics
+#ifndef GR_ABL                            // diagnostic timing ablations (wrong results): 1 no plane production, 2 no matrix products, 4 no statistics,
+                                          // 8 no plane writes, 16 no pooling, 32 no candidate gather
 #define GR_ABL 0
 #endif
 #define GR_NT 18                          // row tiles per workgroup (576 rows)
@@ -167,7 +168,6 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     unsigned *s_ellc = reinterpret_cast<unsigned *>(smem + GR_OFF_ELLC);
     float *s_ellv0 = reinterpret_cast<float *>(smem + GR_OFF_ELLV0);
     float *s_ellv1 = reinterpret_cast<float *>(smem + GR_OFF_ELLV1);
-    double *s_stat = reinterpret_cast<double *>(smem + GR_OFF_STAT);
     float *s_bn = reinterpret_cast<float *>(smem + GR_OFF_BN);
     int *s_cand = reinterpret_cast<int *>(smem + GR_OFF_CAND);
     float *s_zero = reinterpret_cast<float *>(smem + GR_OFF_ZERO);
@@ -215,7 +215,6 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         for (int i = tid; i < 2 * GR_TILE / 16; i += 256) reinterpret_cast<float4 *>(s_planes)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (A.candidate)
             for (int i = tid; i < ninst * A.J; i += 256) s_cand[i] = (i / A.J) * T + A.candidate[(size_t)inst0 * A.J + i];
-        s_stat[tid] = 0.0;
         s_zero[tid] = 0.f;
     }
     // 18 tiles x 16 accumulators = 288 values per lane, but only 256 accumulation registers exist and the matrix instructions
@@ -279,16 +278,27 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         constexpr int RT = decltype(Tc)::value;
         stats_all(GR_TILEVAL(RT));
     };
-    // sums over the 32 rows of the lanes -> the owner lanes (n == 0) store the workgroup's (sum, sumsq) per column as f64.  Once per layer.
+    // Once per layer: the per-lane sums -> this workgroup's (sum | sumsq) of column tid >> 1, one value per thread.  Every lane
+    // parks its 32 values in LDS (ring area, free at the boundaries; 144-byte lane pitch: conflict-free 16-byte writes) and
+    // thread (column, kind) adds up the 32 row-lanes of its column — 8 writes + 32 reads + 31 adds per thread instead of 32
+    // cross-lane reductions.
     auto fold_stats = [&]() __attribute__((always_inline)) {
+        float *red = s_ring;
+        float *mine = red + (wave * 64 + lane) * 36;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const float a = gr_sum32(ts[e >> 1][e & 1]), b = gr_sum32(tq[e >> 1][e & 1]);
-            const int col = 32 * wave + 8 * (e >> 2) + 4 * h + (e & 3);
-            if (n == 0) *reinterpret_cast<double2 *>(s_stat + 2 * col) = make_double2((double)a, (double)b);
+        for (int j = 0; j < 4; j++) {
+            *reinterpret_cast<float4 *>(mine + 4 * j) = make_float4(ts[2 * j][0], ts[2 * j][1], ts[2 * j + 1][0], ts[2 * j + 1][1]);
+            *reinterpret_cast<float4 *>(mine + 16 + 4 * j) = make_float4(tq[2 * j][0], tq[2 * j][1], tq[2 * j + 1][0], tq[2 * j + 1][1]);
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) { ts[i] = f32x2{0.f, 0.f}; tq[i] = f32x2{0.f, 0.f}; }
+        LDS_BARRIER();
+        const int col = tid >> 1, kind = tid & 1, cw = col & 31;
+        const float *src = red + ((col >> 5) * 64 + 32 * ((cw >> 2) & 1)) * 36 + 4 * (cw >> 3) + (cw & 3) + 16 * kind;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; i += 4) { s0 += src[i * 36]; s1 += src[(i + 1) * 36]; s2 += src[(i + 2) * 36]; s3 += src[(i + 3) * 36]; }
+        return (s0 + s1) + (s2 + s3);
     };
     // BatchNorm + ReLU of columns 8g+4h..+3 of tile rt's resident values -> operand split -> planes of buffer buf
     auto produce_quarter = [&](auto Tc, auto Gc, int buf) __attribute__((always_inline)) {
@@ -419,13 +429,12 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     auto layer_boundary = [&](auto Kc) __attribute__((always_inline)) {
         constexpr int k = decltype(Kc)::value;
         GR_STAMP_AT(4 + 4 * k);
-        fold_stats();                                             // (tile 17's sums were taken when it was stored)
+        const float colsum = fold_stats();                        // (tile 17's sums were taken when it was stored)
         if (k == 1) GR_STAMP_AT(2);
-        LDS_BARRIER();
         double *part = A.stats + ((size_t)k * 8 + (blockIdx.x & 7)) * (2 * HD);
         double *total = A.stats + GR_STATS_PART + (size_t)k * (2 * HD);
         {
-            atomicAdd(&part[tid], s_stat[tid]);                   // [col][2] interleaved: thread tid -> (column tid >> 1, sum | sumsq)
+            atomicAdd(&part[tid], (double)colsum);                // [col][2] interleaved: thread tid -> (column tid >> 1, sum | sumsq)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (k == 1) GR_STAMP_AT(3);
@@ -715,7 +724,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                 __builtin_amdgcn_sched_barrier(0);
             });
             LDS_BARRIER();
-            {   // gcn:192: sum over the rows of an instance
+            if (!(GR_ABL & 16)) {   // gcn:192: sum over the rows of an instance
                 const int R0 = S * GR_RING * 32 + 96 * half;      // first row of this thread's run (scalar)
                 int inst = R0 / T, left = (inst + 1) * T - R0;    // current instance, rows of it still ahead
                 float run = 0.f;
@@ -738,7 +747,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                 if (inst < ninst) atomicAdd(&s_pool[inst * HD + col], run);
             }
             // ac:197-207: the candidates whose row lies in this window, one wave per row, 8 bytes per lane
-            for (int part = 0; part < 2; part++) {
+            for (int part = 0; part < ((GR_ABL & 32) ? 0 : 2); part++) {
                 const int cr = part ? crow1 : crow0;
                 unsigned long long mask = __ballot(cr >= S * GR_RING * 32 && cr < (S + 1) * GR_RING * 32);
                 while (mask) {
