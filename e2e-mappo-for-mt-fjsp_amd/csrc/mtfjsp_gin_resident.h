@@ -95,10 +95,9 @@ struct GinResArgs {
 #define GR_OFF_ELLC (GR_OFF_RING + GR_RING * 32 * HD * 4)         // u32 [576]: workgroup-relative rows of the <= 2 in-edges, 0xffff = none
 #define GR_OFF_ELLV0 (GR_OFF_ELLC + GR_ROWS * 4)
 #define GR_OFF_ELLV1 (GR_OFF_ELLV0 + GR_ROWS * 4)
-#define GR_OFF_STAT (GR_OFF_ELLV1 + GR_ROWS * 4)                  // f64 [128][2]
-#define GR_OFF_BN (GR_OFF_STAT + 2 * HD * 8)                      // f32 [256] scale | shift
-#define GR_OFF_CAND (GR_OFF_BN + 2 * HD * 4)                      // i32 [GR_MAXCAND] workgroup-relative candidate rows
-#define GR_OFF_ZERO (GR_OFF_CAND + GR_MAXCAND * 4)               // f32 [256] zeros: the "scale | shift" of rows >= nrows
+#define GR_OFF_BN (GR_OFF_ELLV1 + GR_ROWS * 4)                    // f32 [256] scale | shift
+#define GR_OFF_CAND (GR_OFF_BN + 2 * HD * 4)                      // i32 [576]: candidate slot of a row (instance-local slot + J * local instance), -1 = none
+#define GR_OFF_ZERO (GR_OFF_CAND + GR_ROWS * 4)                   // f32 [256] zeros: the "scale | shift" of rows >= nrows
 #define GR_OFF_FLAG (GR_OFF_ZERO + 2 * HD * 4)
 #define GR_LDS_BYTES (GR_OFF_FLAG + 64)
 static size_t gin_res_lds_bytes() { return (size_t)GR_LDS_BYTES; }
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     float *s_ellv0 = reinterpret_cast<float *>(smem + GR_OFF_ELLV0);
     float *s_ellv1 = reinterpret_cast<float *>(smem + GR_OFF_ELLV1);
     float *s_bn = reinterpret_cast<float *>(smem + GR_OFF_BN);
-    int *s_cand = reinterpret_cast<int *>(smem + GR_OFF_CAND);
+    int *s_rowcand = reinterpret_cast<int *>(smem + GR_OFF_CAND);
     float *s_zero = reinterpret_cast<float *>(smem + GR_OFF_ZERO);
     unsigned *s_flag = reinterpret_cast<unsigned *>(smem + GR_OFF_FLAG);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -210,11 +209,17 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                 const unsigned r0 = cc.x >= 0 ? (unsigned)(base + cc.x) : 0xffffu, r1 = cc.y >= 0 ? (unsigned)(base + cc.y) : 0xffffu;
                 cp = r0 | (r1 << 16); v0 = cc.x >= 0 ? vv.x : 0.f; v1 = cc.y >= 0 ? vv.y : 0.f;
             }
-            s_ellc[r] = cp; s_ellv0[r] = v0; s_ellv1[r] = v1;
+            s_ellc[r] = cp; s_ellv0[r] = v0; s_ellv1[r] = v1; s_rowcand[r] = -1;
         }
+        if (tid == 0) s_flag[1] = 0u;
         for (int i = tid; i < 2 * GR_TILE / 16; i += 256) reinterpret_cast<float4 *>(s_planes)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (A.candidate)
-            for (int i = tid; i < ninst * A.J; i += 256) s_cand[i] = (i / A.J) * T + A.candidate[(size_t)inst0 * A.J + i];
+        if (A.candidate) {                                        // row -> candidate slot (ac:197-207 gathers h of one row per job)
+            __syncthreads();
+            for (int i = tid; i < ninst * A.J; i += 256) {
+                const int c = A.candidate[(size_t)inst0 * A.J + i];
+                if (c >= 0 && c < T && atomicExch(&s_rowcand[(i / A.J) * T + c], i) != -1) s_flag[1] = 1u;   // two slots on one row: fixed up at the end
+            }
+        }
         s_zero[tid] = 0.f;
     }
     // 18 tiles x 16 accumulators = 288 values per lane, but only 256 accumulation registers exist and the matrix instructions
@@ -691,84 +696,90 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 
     GR_STAMP_AT(30);
     // ---------------------------------------------------------------- h = relu(bn_outer1(z)): graph mean pool, candidate gather, node embeddings
-    // Three steps of six tiles through the ring area (192 rows of f32 per step): all waves write their columns of h, then
-    // thread (column, half) sums its 96 rows in runs of one instance (boundaries are wave-uniform scalars) into the workgroup's
-    // pool accumulators (in the plane area, free now), and the candidate rows of the window go out, one wave per row.
+    // Pooling is per column, so every wave works alone on its 32 columns (no workgroup barriers): it transposes a tile of h
+    // through a private 32 x 36 f32 buffer (ring area) — lane (column c, half) then sums rows 16 half .. +15, split at the one
+    // instance boundary a 16-row chunk can contain (T >= 16) — and parks the two partial sums per chunk; the chunks of an
+    // instance are added in a fixed order at the end (deterministic, no atomics).  Candidate rows and the optional node
+    // embeddings go out straight from the registers (16 bytes per lane and column group).
     {
-        float *s_pool = reinterpret_cast<float *>(s_planes);     // [ipc][128]
-        for (int i = tid; i < A.ipc * HD; i += 256) s_pool[i] = 0.f;
-        const int ncand = A.candidate ? ninst * A.J : 0;
-        // candidates of this wave: lane i holds the row of candidate wave + 4i (and wave + 4(i + 64))
-        int crow0 = -1, crow1 = -1;
-        if (wave + 4 * lane < ncand) crow0 = s_cand[wave + 4 * lane];
-        if (wave + 4 * (lane + 64) < ncand) crow1 = s_cand[wave + 4 * (lane + 64)];
-        const int col = tid & (HD - 1), half = wave >> 1;         // (wave is a scalar: the run boundaries below are scalar too)
-        const float invT = 1.0f / (float)T;
-        LDS_BARRIER();
-        gr_static_for<GR_NT / GR_RING>([&](auto Sc) __attribute__((always_inline)) {
-            constexpr int S = decltype(Sc)::value;
-            gr_static_for<GR_RING>([&](auto Jc) __attribute__((always_inline)) {
-                constexpr int j = decltype(Jc)::value, rt = S * GR_RING + j;
-                if constexpr (rt >= GR_NRES) zload(std::integral_constant<int, rt - GR_NRES>{});      // (a spilled tile: straight from its slot)
-                float *base = s_ring + (j * 32 + n) * HD;
-                const float *bn = rt * 32 + n < nrows ? s_bn : s_zero;
-                gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) {
-                    constexpr int g = decltype(Gc)::value;
-                    const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);
-                    const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
-                    const f32x16 &a = GR_TILEVAL(rt);
-                    const int ch = (8 * wave + 2 * g + h) ^ (n & 7);
-                    *reinterpret_cast<float4 *>(base + 4 * ch) = make_float4(bn_relu_ss(a[4 * g], s4.x, h4.x), bn_relu_ss(a[4 * g + 1], s4.y, h4.y),
-                                                                             bn_relu_ss(a[4 * g + 2], s4.z, h4.z), bn_relu_ss(a[4 * g + 3], s4.w, h4.w));
-                });
-                __builtin_amdgcn_sched_barrier(0);
-            });
-            LDS_BARRIER();
-            if (!(GR_ABL & 16)) {   // gcn:192: sum over the rows of an instance
-                const int R0 = S * GR_RING * 32 + 96 * half;      // first row of this thread's run (scalar)
-                int inst = R0 / T, left = (inst + 1) * T - R0;    // current instance, rows of it still ahead
-                float run = 0.f;
+        float *s_part = reinterpret_cast<float *>(s_planes);      // [2 * GR_NT chunks][2 segments][128] = 36 KB: the plane buffers and the first 2 KB of the ring area
+        static_assert(2 * GR_NT * 2 * HD * 4 <= 2 * GR_TILE + 4096, "partial pool sums: plane buffers + 4 KB");
+        float *tb = s_ring + 1024 + wave * (2 * 32 * 36);         // transposition buffers: ring area past those 4 KB
+        float4 S[4], Hs[4];
 #pragma unroll
-                for (int c = 0; c < 6; c++) {                     // 16 rows at a time: the loads go out together, ahead of the (scalar) run bookkeeping
-                    float x[16];
+        for (int g = 0; g < 4; g++) {
+            S[g] = *reinterpret_cast<const float4 *>(s_bn + 32 * wave + 8 * g + 4 * h);
+            Hs[g] = *reinterpret_cast<const float4 *>(s_bn + HD + 32 * wave + 8 * g + 4 * h);
+        }
+        if constexpr (GR_NT - GR_NRES >= 1) zload(std::integral_constant<int, 0>{});
+        if constexpr (GR_NT - GR_NRES >= 2) zload(std::integral_constant<int, 1>{});
+        const int c = lane & 31;
+        int left = ((16 * h) / T + 1) * T - 16 * h;                   // rows of the instance of this lane's first row (16h of tile 0) still ahead
+        LDS_BARRIER();                                                // the plane buffers are no longer read
+        gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
+            constexpr int rt = decltype(Tc)::value;
+            const f32x16 &a = GR_TILEVAL(rt);
+            float4 v[4];
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const int r = 96 * half + 16 * c + i;     // row within the window
-                        x[i] = s_ring[r * HD + 4 * ((col >> 2) ^ (i & 7)) + (col & 3)];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < 4; g++)
+                v[g] = make_float4(bn_relu_ss(a[4 * g], S[g].x, Hs[g].x), bn_relu_ss(a[4 * g + 1], S[g].y, Hs[g].y),
+                                   bn_relu_ss(a[4 * g + 2], S[g].z, Hs[g].z), bn_relu_ss(a[4 * g + 3], S[g].w, Hs[g].w));
+            float *wb = tb + (rt & 1) * (32 * 36);
 #pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        if (left == 0) { if (inst < ninst) atomicAdd(&s_pool[inst * HD + col], run); run = 0.f; inst++; left = T; }
-                        run += x[i];
-                        left--;
-                    }
-                }
-                if (inst < ninst) atomicAdd(&s_pool[inst * HD + col], run);
-            }
-            // ac:197-207: the candidates whose row lies in this window, one wave per row, 8 bytes per lane
-            for (int part = 0; part < ((GR_ABL & 32) ? 0 : 2); part++) {
-                const int cr = part ? crow1 : crow0;
-                unsigned long long mask = __ballot(cr >= S * GR_RING * 32 && cr < (S + 1) * GR_RING * 32);
-                while (mask) {
-                    const int i = __builtin_ctzll(mask);
-                    mask &= mask - 1;
-                    const int r = __builtin_amdgcn_readlane(cr, i) - S * GR_RING * 32, idx = wave + 4 * (i + 64 * part);
-                    const float2 x = *reinterpret_cast<const float2 *>(s_ring + r * HD + 4 * ((lane >> 1) ^ (r & 7)) + 2 * (lane & 1));
-                    *reinterpret_cast<float2 *>(A.cand_feat + ((size_t)inst0 * A.J + idx) * HD + 2 * lane) = x;
+            for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(wb + n * 36 + 8 * g + 4 * h) = v[g];
+            const int row = rt * 32 + n;
+            if (!(GR_ABL & 32)) {
+                const int slot = s_rowcand[row];
+                if (slot >= 0) {
+                    float *d = A.cand_feat + ((size_t)inst0 * A.J + slot) * HD + 32 * wave + 4 * h;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(d + 8 * g) = v[g];
                 }
             }
-            if (A.h_nodes) {
-                for (int r = wave; r < GR_RING * 32; r += 4) {
-                    if (S * GR_RING * 32 + r < nrows) {
-                        const float2 x = *reinterpret_cast<const float2 *>(s_ring + r * HD + 4 * ((lane >> 1) ^ (r & 7)) + 2 * (lane & 1));
-                        *reinterpret_cast<float2 *>(A.h_nodes + (grow0 + S * GR_RING * 32 + r) * HD + 2 * lane) = x;
-                    }
-                }
+            if (A.h_nodes && row < nrows) {
+                float *d = A.h_nodes + (grow0 + row) * HD + 32 * wave + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(d + 8 * g) = v[g];
             }
-            LDS_BARRIER();
+            if (!(GR_ABL & 16)) {                                     // gcn:192: rows 16h .. 16h+15 of column c, split at the instance boundary
+                const float fb = (float)left;
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const float x = wb[(16 * h + i) * 36 + c];
+                    const float wa = __builtin_amdgcn_fmed3f(fb - (float)i, 0.f, 1.f);       // 1 while i < left
+                    sa = __builtin_fmaf(x, wa, sa); sb = __builtin_fmaf(x, 1.0f - wa, sb);
+                }
+                float *pp = s_part + ((2 * rt + h) * 2) * HD + 32 * wave + c;
+                pp[0] = sa; pp[HD] = sb;
+            }
+            left -= 32;                                               // on to this lane's rows of the next tile (T >= 16: at most two instances further)
+            if (left <= 0) left += T;
+            if (left <= 0) left += T;
+            __builtin_amdgcn_sched_barrier(0);
         });
-        for (int i = tid; i < ninst * HD; i += 256) A.pooled[(size_t)inst0 * HD + i] = s_pool[i] * invT;
+        LDS_BARRIER();
+        const float invT = 1.0f / (float)T;
+        for (int item = tid; item < ninst * HD; item += 256) {
+            const int inst = item >> 7, col = item & (HD - 1);
+            const int r0 = inst * T, k0 = r0 >> 4, k1 = (r0 + T - 1) >> 4;
+            float sum = 0.f;
+            for (int k = k0; k <= k1; k++) sum += s_part[(2 * k + (16 * k < r0 ? 1 : 0)) * HD + col];     // a chunk that began in the previous instance: second segment
+            A.pooled[(size_t)inst0 * HD + item] = sum * invT;
+        }
+        if (A.candidate && s_flag[1]) {                               // (malformed input) slots that share a row: copy from the slot that was written
+            __threadfence();
+            __syncthreads();
+            for (int i = wave; i < ninst * A.J; i += 4) {
+                const int cnd = A.candidate[(size_t)inst0 * A.J + i];
+                if (cnd < 0 || cnd >= T) continue;
+                const int win = s_rowcand[(i / A.J) * T + cnd];
+                if (win != i) {
+                    const float2 x = *reinterpret_cast<const float2 *>(A.cand_feat + ((size_t)inst0 * A.J + win) * HD + 2 * lane);
+                    *reinterpret_cast<float2 *>(A.cand_feat + ((size_t)inst0 * A.J + i) * HD + 2 * lane) = x;
+                }
+            }
+        }
     }
     GR_STAMP_AT(31);
 }
