@@ -715,7 +715,30 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if constexpr (GR_NT - GR_NRES >= 2) zload(std::integral_constant<int, 1>{});
         const int c = lane & 31;
         int left = ((16 * h) / T + 1) * T - 16 * h;                   // rows of the instance of this lane's first row (16h of tile 0) still ahead
+        int slot[GR_NT];                                              // candidate slot of this lane's row in every tile (-1: none)
+#pragma unroll
+        for (int rt = 0; rt < GR_NT; rt++) slot[rt] = (GR_ABL & 32) ? -1 : s_rowcand[rt * 32 + n];
         LDS_BARRIER();                                                // the plane buffers are no longer read
+        // gcn:192 for one tile: rows 16h .. 16h+15 of column c from the transposition buffer, split at the instance boundary
+        auto pool_tile = [&](int rt) __attribute__((always_inline)) {
+            const float *rb = tb + (rt & 1) * (32 * 36) + (16 * h) * 36 + c;
+            float x[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) x[i] = rb[i * 36];
+            const float fb = (float)left;
+            float sa0 = 0.f, sa1 = 0.f, sb0 = 0.f, sb1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                const float wa = __builtin_amdgcn_fmed3f(fb - (float)i, 0.f, 1.f), wb_ = __builtin_amdgcn_fmed3f(fb - (float)(i + 1), 0.f, 1.f);   // 1 while i < left
+                sa0 = __builtin_fmaf(x[i], wa, sa0); sb0 = __builtin_fmaf(x[i], 1.0f - wa, sb0);
+                sa1 = __builtin_fmaf(x[i + 1], wb_, sa1); sb1 = __builtin_fmaf(x[i + 1], 1.0f - wb_, sb1);
+            }
+            float *pp = s_part + ((2 * rt + h) * 2) * HD + 32 * wave + c;
+            pp[0] = sa0 + sa1; pp[HD] = sb0 + sb1;
+            left -= 32;                                               // on to this lane's rows of the next tile (T >= 16: at most two instances further)
+            if (left <= 0) left += T;
+            if (left <= 0) left += T;
+        };
         gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
             constexpr int rt = decltype(Tc)::value;
             const f32x16 &a = GR_TILEVAL(rt);
@@ -727,37 +750,20 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             float *wb = tb + (rt & 1) * (32 * 36);
 #pragma unroll
             for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(wb + n * 36 + 8 * g + 4 * h) = v[g];
-            const int row = rt * 32 + n;
-            if (!(GR_ABL & 32)) {
-                const int slot = s_rowcand[row];
-                if (slot >= 0) {
-                    float *d = A.cand_feat + ((size_t)inst0 * A.J + slot) * HD + 32 * wave + 4 * h;
-#pragma unroll
-                    for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(d + 8 * g) = v[g];
-                }
-            }
-            if (A.h_nodes && row < nrows) {
-                float *d = A.h_nodes + (grow0 + row) * HD + 32 * wave + 4 * h;
+            if (slot[rt] >= 0) {
+                float *d = A.cand_feat + ((size_t)inst0 * A.J + slot[rt]) * HD + 32 * wave + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(d + 8 * g) = v[g];
             }
-            if (!(GR_ABL & 16)) {                                     // gcn:192: rows 16h .. 16h+15 of column c, split at the instance boundary
-                const float fb = (float)left;
-                float sa = 0.f, sb = 0.f;
+            if (A.h_nodes && rt * 32 + n < nrows) {
+                float *d = A.h_nodes + (grow0 + rt * 32 + n) * HD + 32 * wave + 4 * h;
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const float x = wb[(16 * h + i) * 36 + c];
-                    const float wa = __builtin_amdgcn_fmed3f(fb - (float)i, 0.f, 1.f);       // 1 while i < left
-                    sa = __builtin_fmaf(x, wa, sa); sb = __builtin_fmaf(x, 1.0f - wa, sb);
-                }
-                float *pp = s_part + ((2 * rt + h) * 2) * HD + 32 * wave + c;
-                pp[0] = sa; pp[HD] = sb;
+                for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(d + 8 * g) = v[g];
             }
-            left -= 32;                                               // on to this lane's rows of the next tile (T >= 16: at most two instances further)
-            if (left <= 0) left += T;
-            if (left <= 0) left += T;
+            if constexpr (rt > 0) { if (!(GR_ABL & 16)) pool_tile(rt - 1); }     // one tile behind: its writes have landed
             __builtin_amdgcn_sched_barrier(0);
         });
+        if (!(GR_ABL & 16)) pool_tile(GR_NT - 1);
         LDS_BARRIER();
         const float invT = 1.0f / (float)T;
         for (int item = tid; item < ninst * HD; item += 256) {
