@@ -43,7 +43,8 @@ struct GemmArgs {
     const float *in;        // [N,128] producer output (pre-activation for PRO_BNRELU / PRO_AGG)
     int N;
     const float *Wt;        // [128(k),128(n)] = W^T of a torch Linear weight [out,in]
-    const void *Wx6;        // the same weight as bf16 x 3-plane register images (mtfjsp_encoder::wx6), k_gemm_x6
+    const void *Wx6;        // the same weight as 16-bit operand-piece register images (mtfjsp_encoder::wx6), k_gemm_x6
+    float w_sinv;           // 1 / the power-of-two scale folded into that image (f16 images; 1 for the bf16 image of the first Linear)
     const float *bias;      // [128] or NULL
     float *out;             // [N,128]
     // prologue: BatchNorm of `in` from the producer's column sums
@@ -515,11 +516,29 @@ __device__ __forceinline__ void split3x4(const float (&v)[4], uint2 &p0, uint2 &
     }
     p0 = make_uint2(o[0][0], o[0][1]); p1 = make_uint2(o[1][0], o[1][1]); p2 = make_uint2(o[2][0], o[2][1]);
 }
+// 2-way split into f16 pieces (round to nearest both times): v = hi + lo up to 2^-22 |v|; with the three significant piece
+// products as accurate as the exact bf16 split with six (tools/ubench/bf16x6.hip).  |v| < 65 504.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+#define X2_TILE (2 * X6_PLANE)
+__device__ __forceinline__ void split2x4(const float (&v)[4], uint2 &p0, uint2 &p1)
+{
+    const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+    const h16x2 a = __builtin_convertvector(v01, h16x2), b = __builtin_convertvector(v23, h16x2);
+    const f32x2 r01 = v01 - __builtin_convertvector(a, f32x2), r23 = v23 - __builtin_convertvector(b, f32x2);
+    const h16x2 c = __builtin_convertvector(r01, h16x2), d = __builtin_convertvector(r23, h16x2);
+    p0 = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
+    p1 = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+}
 template <int PRO>
 __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 {
+    // operand pieces: the first Linear (raw, unbounded features) keeps the exact 3-way bf16 split (6 products); the 128 -> 128
+    // products, whose operands are BatchNorm outputs, use the 2-way f16 split (3 products, weights pre-scaled: A.w_sinv)
+    constexpr int NP = (PRO == PRO_GIN0) ? 3 : 2;
+    constexpr int XT = NP * X6_PLANE;                             // bytes of a tile's planes
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *s_tiles = smem;                                // [2 buffers][4 tiles][3 planes][16 rows x 272 B]
+    unsigned char *s_tiles = smem;                                // [2 buffers][4 tiles][NP planes][16 rows x 272 B]
     double *s_stat = reinterpret_cast<double *>(smem + 8 * X6_TILE);   // column sums | sums of squares of this workgroup
     float *s_bn = reinterpret_cast<float *>(s_stat + 2 * HD);     // scale | shift
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -545,7 +564,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     }
     auto stage_scale_shift = [&]() __attribute__((always_inline)) {   // stage_bn() from the registers requested above
         if (PRO == PRO_GIN0) {                                    // the planes' k = 12..31 stay zero for the whole kernel
-            for (int i = tid; i < 8 * X6_TILE / 16; i += 512) reinterpret_cast<float4 *>(s_tiles)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int i = tid; i < 8 * XT / 16; i += 512) reinterpret_cast<float4 *>(s_tiles)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         } else if (tid < HD) {
             double su = 0, sq = 0;
 #pragma unroll
@@ -653,7 +672,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                             }
                             uint2 p0, p1, p2;
                             split3x4(v, p0, p1, p2);                  // element 3 is padding
-                            unsigned char *d = s_tiles + ((s & 1) * 4 + pw) * X6_TILE + r * X6_ROWB + k0 * 2;
+                            unsigned char *d = s_tiles + ((s & 1) * 4 + pw) * XT + r * X6_ROWB + k0 * 2;
                             unsigned short *d0 = reinterpret_cast<unsigned short *>(d), *d1 = reinterpret_cast<unsigned short *>(d + X6_PLANE),
                                            *d2 = reinterpret_cast<unsigned short *>(d + 2 * X6_PLANE);
                             d0[0] = (unsigned short)p0.x; d0[1] = (unsigned short)(p0.x >> 16); d0[2] = (unsigned short)p0.y;
@@ -682,7 +701,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         auto produce = [&](float4 (&pre)[8], int s) __attribute__((always_inline)) {
             const int tile = t0 + 4 * s;
             if (tile < last) {
-                unsigned char *dst = s_tiles + ((s & 1) * 4 + pw) * X6_TILE + h * X6_ROWB + j * 8;
+                unsigned char *dst = s_tiles + ((s & 1) * 4 + pw) * XT + h * X6_ROWB + j * 8;
 #pragma unroll
                 for (int p = 0; p < 8; p++) {
                     float v[4] = {bn_relu_ss(pre[p].x, sc0, sh0), bn_relu_ss(pre[p].y, sc1, sh1), bn_relu_ss(pre[p].z, sc2, sh2), bn_relu_ss(pre[p].w, sc3, sh3)};
@@ -699,11 +718,10 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                         const double a3 = (double)v[3] + wx * (double)bn_relu_ss(nb0[pp].w, sc3, sh3) + wy * (double)bn_relu_ss(nb1[pp].w, sc3, sh3);
                         v[0] = (float)(a0 * inv); v[1] = (float)(a1 * inv); v[2] = (float)(a2 * inv); v[3] = (float)(a3 * inv);
                     }
-                    uint2 p0, p1, p2;
-                    split3x4(v, p0, p1, p2);
+                    uint2 p0, p1;
+                    split2x4(v, p0, p1);
                     *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB) = p0;
                     *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + X6_PLANE) = p1;
-                    *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + 2 * X6_PLANE) = p2;
                 }
             }
             // requests, oldest-needed first (vmcnt retires in order): neighbour rows of step s+1, ELL entries of step s+2, then
@@ -725,19 +743,17 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         // ================================ consumer ================================
         const int m = lane & 15, q = lane >> 4;                   // operands swapped: A[col c0+m][k = 8q..], B[k = 8q..][row m], C[col c0+4q+i][row m]
         const int cg = wave;
-        bf16x8 wf[2][3][KS];                                      // [column block][plane][k-step]: W[32cg + 16c + m][32ks + 8q .. +7]
+        float4 wf[2][NP][KS];                                     // [column block][plane][k-step]: pieces of W[32cg + 16c + m][32ks + 8q .. +7] (8 x 16 bit)
         {
-            const float4 *wi = reinterpret_cast<const float4 *>(A.Wx6) + (size_t)cg * (2 * 3 * KS * 64) + lane;
+            const float4 *wi = reinterpret_cast<const float4 *>(A.Wx6) + (size_t)cg * (2 * NP * KS * 64) + lane;
 #pragma unroll
             for (int c = 0; c < 2; c++)
 #pragma unroll
-                for (int p = 0; p < 3; p++)
+                for (int p = 0; p < NP; p++)
 #pragma unroll
-                    for (int ks = 0; ks < KS; ks++) {
-                        const float4 v = wi[((c * 3 + p) * KS + ks) * 64];
-                        wf[c][p][ks] = __builtin_bit_cast(bf16x8, v);
-                    }
+                    for (int ks = 0; ks < KS; ks++) wf[c][p][ks] = wi[((c * NP + p) * KS + ks) * 64];
         }
+        const float wsinv = PRO == PRO_GIN0 ? 1.0f : A.w_sinv;
         f32x4 biasv[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
         if (A.bias) {
 #pragma unroll
@@ -754,46 +770,51 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         for (int c = 0; c < 2; c++)
 #pragma unroll
             for (int i = 0; i < 4; i++) { ts[c][i] = 0.f; tq[c][i] = 0.f; }
-        const unsigned char *xa0 = s_tiles + m * X6_ROWB + 16 * q; // operand fragment (slot t, plane p, k-step ks): + t*X6_TILE + p*X6_PLANE + 64*ks
+        const unsigned char *xa0 = s_tiles + m * X6_ROWB + 16 * q; // operand fragment (slot t, plane p, k-step ks): + t*XT + p*X6_PLANE + 64*ks
         LDS_BARRIER();                                            // step 0: the producers fill buffer 0
         STAMP(4);
         for (int s = 1; s <= nsteps; s++) {
             const int tb = first + 4 * (s - 1);
-            const unsigned char *xa = xa0 + ((s - 1) & 1) * 4 * X6_TILE;
+            const unsigned char *xa = xa0 + ((s - 1) & 1) * 4 * XT;
             auto tiles4 = [&](auto FULLc) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(FULLc)::value;    // FULL: all four tiles exist and none holds rows >= N
-                bf16x8 xf[3][3];                                  // fragments of (tile, k-step) units u, u+1, u+2: two units of LDS latency cover
+                float4 xf[3][NP];                                 // fragments of (tile, k-step) units u, u+1, u+2: two units of LDS latency cover
                 constexpr int NU = 4 * KS;
 #pragma unroll
-                for (int p = 0; p < 3; p++) xf[0][p] = *reinterpret_cast<const bf16x8 *>(xa + p * X6_PLANE);
+                for (int p = 0; p < NP; p++) xf[0][p] = *reinterpret_cast<const float4 *>(xa + p * X6_PLANE);
 #pragma unroll
-                for (int p = 0; p < 3; p++) xf[1][p] = *reinterpret_cast<const bf16x8 *>(xa + (1 / KS) * X6_TILE + p * X6_PLANE + 64 * (1 % KS));
+                for (int p = 0; p < NP; p++) xf[1][p] = *reinterpret_cast<const float4 *>(xa + (1 / KS) * XT + p * X6_PLANE + 64 * (1 % KS));
 #pragma unroll
                 for (int t = 0; t < 4; t++) {
                     if (!FULL && tb + t >= last) break;
-                    f32x4 acc[2] = {biasv[0], biasv[1]};
+                    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
                     for (int ks = 0; ks < KS; ks++) {
                         const int u = t * KS + ks;
                         if (u + 2 < NU) {                         // a stale slot beyond the last tile is read but never used
                             const int tn = (u + 2) / KS, kn = (u + 2) % KS;
 #pragma unroll
-                            for (int p = 0; p < 3; p++) xf[(u + 2) % 3][p] = *reinterpret_cast<const bf16x8 *>(xa + tn * X6_TILE + p * X6_PLANE + 64 * kn);
+                            for (int p = 0; p < NP; p++) xf[(u + 2) % 3][p] = *reinterpret_cast<const float4 *>(xa + tn * XT + p * X6_PLANE + 64 * kn);
                         }
-                        const bf16x8 *x = xf[u % 3];
+                        const float4 *x = xf[u % 3];
+                        if constexpr (NP == 3) {
+                            auto MB = [&](int wp, int xp) __attribute__((always_inline)) {
 #pragma unroll
-                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[2], acc[c], 0, 0, 0);
+                                for (int c = 0; c < 2; c++)
+                                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[c][wp][ks]), __builtin_bit_cast(bf16x8, x[xp]), acc[c], 0, 0, 0);
+                            };
+                            MB(0, 2); MB(2, 0); MB(1, 1); MB(0, 1); MB(1, 0); MB(0, 0);     // smallest terms first
+                        } else {
+                            auto MH = [&](int wp, int xp) __attribute__((always_inline)) {
 #pragma unroll
-                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][2][ks], x[0], acc[c], 0, 0, 0);
-#pragma unroll
-                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][1][ks], x[1], acc[c], 0, 0, 0);
-#pragma unroll
-                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[1], acc[c], 0, 0, 0);
-#pragma unroll
-                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][1][ks], x[0], acc[c], 0, 0, 0);
-#pragma unroll
-                        for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[c][0][ks], x[0], acc[c], 0, 0, 0);
+                                for (int c = 0; c < 2; c++)
+                                    acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, wf[c][wp][ks]), __builtin_bit_cast(h16x8, x[xp]), acc[c], 0, 0, 0);
+                            };
+                            MH(0, 1); MH(1, 0); MH(0, 0);
+                        }
                     }
+#pragma unroll
+                    for (int c = 0; c < 2; c++) acc[c] = acc[c] * wsinv + biasv[c];
                     const int row = (tb + t) * 16 + m;
                     const bool ok = FULL || row < A.N;
                     float *ob = A.out + (size_t)row * HD + 32 * cg + 4 * q;
@@ -1280,7 +1301,8 @@ struct HeadArgs {
     const float *W0i;                    // register images (mtfjsp_encoder::wimg) of the 3 blocks of linears.0: X | pooled | other
     const float *b0, *W1i, *b1, *w2, *b2;
     const float *Wc0i, *bc0, *Wc1i, *bc1, *wc2, *bc2;
-    const void *W0x, *W1x, *Wc0x, *Wc1x; // the same weights as bf16 x 3-plane register images (mtfjsp_encoder::wx6), k_headsx
+    const void *W0x, *W1x, *Wc0x, *Wc1x; // the same weights as f16 x 2-plane register images (mtfjsp_encoder::wx6), k_headsx
+    float sW0, sW1, sWc0, sWc1;          // 1 / the power-of-two scale folded into each of those images
     const uint8_t *mask;                 // [B,R]
     float scale;
     float *prob, *value;                 // [B,R], [B,2]
@@ -1573,41 +1595,40 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
 static size_t heads_lds_bytes() { return (size_t)((2 * HCH + 4) * 16 * LDA16 + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD) * 4 + HG * 64; }
 
 // ---------------------------------------------------------------------------------------------
-// k_headsx — k_heads with every 128x128 product on the bf16 matrix cores at f32 accuracy (exact 3-way split, 6 piece
-// products, see k_gemm_x6).  Same work split (wave w owns output columns 16w..16w+15 of every product; its weight
-// fragments — 3 planes x 4 k-steps = 48 registers per weight — come from the bf16 register images), but
+// k_headsx — k_heads with every 128x128 product on the 16-bit matrix cores at f32 accuracy (2-way f16 split, 3 piece
+// products, weights pre-scaled by a power of two: see k_gemm_x6 / DESIGN.md §4).  Same work split (wave w owns output columns
+// 16w..16w+15 of every product; its weight fragments — 2 planes x 4 k-steps = 32 registers per weight — come from the f16
+// register images), but
 //   * the operands are swapped (A := weight, B := activation rows), so a lane ends up with 4 consecutive columns of row m:
 //     the next product's operand planes are written with 8-byte stores, u is read as float4, and a scorer row's partial
 //     score is 4 FMAs + two cross-quarter shuffles instead of four 16-lane DPP reductions;
-//   * activations live in LDS as three bf16 planes per 16-row tile (pitch 272 B); each value is split once by its
-//     producer: X rows by the staging threads, c1 / s1 in the epilogue of the product that makes them;
+//   * activations live in LDS as two f16 planes per 16-row tile (pitch 272 B); each value is split once by its
+//     producer: X rows by the staging threads, c1 / s1 in the epilogue of the product that makes them (all of them are
+//     BatchNorm outputs, means of them or tanh values: far inside the f16 range);
 //   * the s1 planes overwrite the X planes (all six accumulators of a chunk are held across one barrier).
-// 384 matrix instructions x 16 cycles per wave instead of 512 x 32.
+// 192 matrix instructions x 16 cycles per wave instead of 512 x 32.
 #define WCOLX(dst, Wx, blk)                                                                                     \
     do {                                                                                                         \
-        const float4 *w_ = reinterpret_cast<const float4 *>(Wx) + ((size_t)(blk) * 8 + wave) * (3 * 4 * 64) + lane; \
-        _Pragma("unroll") for (int p_ = 0; p_ < 3; p_++)                                                         \
-            _Pragma("unroll") for (int k_ = 0; k_ < 4; k_++) dst[p_][k_] = __builtin_bit_cast(bf16x8, w_[(p_ * 4 + k_) * 64]); \
+        const float4 *w_ = reinterpret_cast<const float4 *>(Wx) + ((size_t)(blk) * 8 + wave) * (2 * 4 * 64) + lane; \
+        _Pragma("unroll") for (int p_ = 0; p_ < 2; p_++)                                                         \
+            _Pragma("unroll") for (int k_ = 0; k_ < 4; k_++) dst[p_][k_] = __builtin_bit_cast(h16x8, w_[(p_ * 4 + k_) * 64]); \
     } while (0)
-// the six piece products of one k-step on two accumulator chains (large terms | small terms)
+// the three piece products of one k-step on two accumulator chains (large term | small terms)
 #define X6_STEP(accA, accB, wv, xv, ks)                                                          \
     do {                                                                                          \
-        accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0][ks], xv[2], accB, 0, 0, 0);          \
-        accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0][ks], xv[1], accA, 0, 0, 0);          \
-        accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[2][ks], xv[0], accB, 0, 0, 0);          \
-        accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1][ks], xv[0], accA, 0, 0, 0);          \
-        accB = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[1][ks], xv[1], accB, 0, 0, 0);          \
-        accA = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv[0][ks], xv[0], accA, 0, 0, 0);          \
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[0][ks], xv[1], accB, 0, 0, 0);           \
+        accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[0][ks], xv[0], accA, 0, 0, 0);           \
+        accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[1][ks], xv[0], accB, 0, 0, 0);           \
     } while (0)
 #define HX_CLDA 132
 __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *s_xs = smem;                                    // HCH tiles of 3 planes: X rows, then s1
-    unsigned char *s_pp = s_xs + HCH * X6_TILE;                    // pooled planes
-    unsigned char *s_op = s_pp + X6_TILE;                          // other planes
-    unsigned char *s_c1p = s_op + X6_TILE;                         // c1 planes
-    float *s_c2 = reinterpret_cast<float *>(s_c1p + X6_TILE);      // [16][HX_CLDA] f32
+    unsigned char *s_xs = smem;                                    // HCH tiles of 2 planes: X rows, then s1
+    unsigned char *s_pp = s_xs + HCH * X2_TILE;                    // pooled planes
+    unsigned char *s_op = s_pp + X2_TILE;                          // other planes
+    unsigned char *s_c1p = s_op + X2_TILE;                         // c1 planes
+    float *s_c2 = reinterpret_cast<float *>(s_c1p + X2_TILE);      // [16][HX_CLDA] f32
     float *s_u = s_c2 + 16 * HX_CLDA;                              // [16][128]
     float *s_part = s_u + HG * HD;                                 // 8 waves * (HCH*16) rows
     float *s_score = s_part + 8 * HCH * 16;                        // HG * 64
@@ -1658,7 +1679,8 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
             const int grow = t * 16 + sr;
             xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        bf16x8 wA[3][4], wB[3][4], wC[3][4];
+        h16x8 wA[2][4], wB[2][4], wC[2][4];
+        const float sW0 = A.sW0, sW1 = A.sW1, sWc0 = A.sWc0, sWc1 = A.sWc1;   // 1 / scale of the weight images
         WCOLX(wA, A.W0x, 1);                                        // Wb
         WCOLX(wB, A.W0x, 2);                                        // Wc
         WCOLX(wC, A.Wc0x, 0);
@@ -1705,11 +1727,11 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
             const float4 xo = sr < ng ? *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + sr) * HD + sc4) : z;
             {
                 const float vp[4] = {xp.x, xp.y, xp.z, xp.w}, vo[4] = {xo.x, xo.y, xo.z, xo.w};
-                uint2 a0, a1, a2, b0, b1, b2;
-                split3x4(vp, a0, a1, a2); split3x4(vo, b0, b1, b2);
+                uint2 a0, a1, b0, b1;
+                split2x4(vp, a0, a1); split2x4(vo, b0, b1);
                 unsigned char *dp = s_pp + sr * X6_ROWB + (tid & 31) * 8, *dq = s_op + sr * X6_ROWB + (tid & 31) * 8;
-                *reinterpret_cast<uint2 *>(dp) = a0; *reinterpret_cast<uint2 *>(dp + X6_PLANE) = a1; *reinterpret_cast<uint2 *>(dp + 2 * X6_PLANE) = a2;
-                *reinterpret_cast<uint2 *>(dq) = b0; *reinterpret_cast<uint2 *>(dq + X6_PLANE) = b1; *reinterpret_cast<uint2 *>(dq + 2 * X6_PLANE) = b2;
+                *reinterpret_cast<uint2 *>(dp) = a0; *reinterpret_cast<uint2 *>(dp + X6_PLANE) = a1;
+                *reinterpret_cast<uint2 *>(dq) = b0; *reinterpret_cast<uint2 *>(dq + X6_PLANE) = b1;
             }
         }
         for (int i = tid; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
@@ -1721,28 +1743,28 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
             if (A.xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
             return make_float4(y0, y1, y2, y3);
         };
-        // one 16-row tile (planes at `tp`) x this wave's column block: 24 products on two chains, fragments of the next k-step in flight
-        auto tile_x6 = [&](const unsigned char *tp, const bf16x8 (&wv)[3][4]) __attribute__((always_inline)) -> f32x4 {
+        // one 16-row tile (planes at `tp`) x this wave's column block: 12 products on two chains, fragments of the next k-step in flight
+        auto tile_x6 = [&](const unsigned char *tp, const h16x8 (&wv)[2][4]) __attribute__((always_inline)) -> f32x4 {
             f32x4 aA = zero4, aB = zero4;
-            bf16x8 xv[2][3];
+            h16x8 xv[2][2];
 #pragma unroll
-            for (int p = 0; p < 3; p++) xv[0][p] = *reinterpret_cast<const bf16x8 *>(tp + xoff + p * X6_PLANE);
+            for (int p = 0; p < 2; p++) xv[0][p] = *reinterpret_cast<const h16x8 *>(tp + xoff + p * X6_PLANE);
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) {
                 if (ks < 3) {
 #pragma unroll
-                    for (int p = 0; p < 3; p++) xv[(ks + 1) & 1][p] = *reinterpret_cast<const bf16x8 *>(tp + xoff + p * X6_PLANE + 64 * (ks + 1));
+                    for (int p = 0; p < 2; p++) xv[(ks + 1) & 1][p] = *reinterpret_cast<const h16x8 *>(tp + xoff + p * X6_PLANE + 64 * (ks + 1));
                 }
                 X6_STEP(aA, aB, wv, xv[ks & 1], ks);
             }
             return aA + aB;
         };
-        // a lane's 4 values of row m -> the three planes of a tile
+        // a lane's 4 values of row m -> the two planes of a tile
         auto put_planes = [&](unsigned char *tp, const float (&v)[4]) __attribute__((always_inline)) {
-            uint2 p0, p1, p2;
-            split3x4(v, p0, p1, p2);
+            uint2 p0, p1;
+            split2x4(v, p0, p1);
             unsigned char *d = tp + m * X6_ROWB + col4 * 2;
-            *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1; *reinterpret_cast<uint2 *>(d + 2 * X6_PLANE) = p2;
+            *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1;
         };
         // ---- phase A: u = Wb pooled + Wc other + b0 ; c1 = tanh(Wc0 pooled + bc0)   (rows = the group's 16 instances)
         {
@@ -1752,8 +1774,8 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
             WCOLX(wB, A.W0x, 0);                                    // Wa
             WCOLX(wC, A.W1x, 0);                                    // phase C
             const float4 b0v = *reinterpret_cast<const float4 *>(s_vec + col4), bc0v = *reinterpret_cast<const float4 *>(s_vec + HD + col4);
-            *reinterpret_cast<float4 *>(s_u + m * HD + col4) = make_float4(au[0] + b0v.x, au[1] + b0v.y, au[2] + b0v.z, au[3] + b0v.w);
-            const float c1v[4] = {fast_tanh(ac[0] + bc0v.x), fast_tanh(ac[1] + bc0v.y), fast_tanh(ac[2] + bc0v.z), fast_tanh(ac[3] + bc0v.w)};
+            *reinterpret_cast<float4 *>(s_u + m * HD + col4) = make_float4(fmaf(au[0], sW0, b0v.x), fmaf(au[1], sW0, b0v.y), fmaf(au[2], sW0, b0v.z), fmaf(au[3], sW0, b0v.w));
+            const float c1v[4] = {fast_tanh(fmaf(ac[0], sWc0, bc0v.x)), fast_tanh(fmaf(ac[1], sWc0, bc0v.y)), fast_tanh(fmaf(ac[2], sWc0, bc0v.z)), fast_tanh(fmaf(ac[3], sWc0, bc0v.w))};
             put_planes(s_c1p, c1v);
         }
         STAMP(1);
@@ -1768,22 +1790,22 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
                 }
                 const float4 xv4 = xnorm(xr[t], (tb + t) * 16 + sr < nrows);
                 const float v[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
-                uint2 p0, p1, p2;
-                split3x4(v, p0, p1, p2);
-                unsigned char *d = s_xs + t * X6_TILE + sr * X6_ROWB + (tid & 31) * 8;
-                *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1; *reinterpret_cast<uint2 *>(d + 2 * X6_PLANE) = p2;
+                uint2 p0, p1;
+                split2x4(v, p0, p1);
+                unsigned char *d = s_xs + t * X2_TILE + sr * X6_ROWB + (tid & 31) * 8;
+                *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1;
             }
             LDS_BARRIER();                                          // X planes, u and c1 are complete
             STAMP(2);
             // ---- phase B: Wa x for every tile of the chunk (accumulators held); first chunk: c2 = tanh(Wc1 c1 + bc1)
             f32x4 accb[HCH];
 #pragma unroll
-            for (int t = 0; t < HCH; t++) accb[t] = t < nt ? tile_x6(s_xs + t * X6_TILE, wB) : zero4;
+            for (int t = 0; t < HCH; t++) accb[t] = t < nt ? tile_x6(s_xs + t * X2_TILE, wB) : zero4;
             if (tb == 0) {
                 const f32x4 a0 = tile_x6(s_c1p, wA);
                 const float4 bc1v = *reinterpret_cast<const float4 *>(s_vec + 2 * HD + col4);
                 *reinterpret_cast<float4 *>(s_c2 + m * HX_CLDA + col4) =
-                    make_float4(fast_tanh(a0[0] + bc1v.x), fast_tanh(a0[1] + bc1v.y), fast_tanh(a0[2] + bc1v.z), fast_tanh(a0[3] + bc1v.w));
+                    make_float4(fast_tanh(fmaf(a0[0], sWc1, bc1v.x)), fast_tanh(fmaf(a0[1], sWc1, bc1v.y)), fast_tanh(fmaf(a0[2], sWc1, bc1v.z)), fast_tanh(fmaf(a0[3], sWc1, bc1v.w)));
             }
             LDS_BARRIER();                                          // every wave is done with the X planes: s1 overwrites them
             // s1 = tanh(Wa x + u[instance]) -> planes
@@ -1793,8 +1815,8 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
                     const int grow = (tb + t) * 16 + m;
                     const int i0 = grow < nrows ? (int)__umulhi((unsigned)grow, invR) : 0;
                     const float4 uv = *reinterpret_cast<const float4 *>(s_u + i0 * HD + col4);
-                    const float sv[4] = {fast_tanh(accb[t][0] + uv.x), fast_tanh(accb[t][1] + uv.y), fast_tanh(accb[t][2] + uv.z), fast_tanh(accb[t][3] + uv.w)};
-                    put_planes(s_xs + t * X6_TILE, sv);
+                    const float sv[4] = {fast_tanh(fmaf(accb[t][0], sW0, uv.x)), fast_tanh(fmaf(accb[t][1], sW0, uv.y)), fast_tanh(fmaf(accb[t][2], sW0, uv.z)), fast_tanh(fmaf(accb[t][3], sW0, uv.w))};
+                    put_planes(s_xs + t * X2_TILE, sv);
                 }
             }
             LDS_BARRIER();                                          // s1 planes and c2 are complete
@@ -1805,11 +1827,11 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
 #pragma unroll 1
                 for (int t = 0; t < HCH; t++) {                     // (rolled: this kernel runs once per workgroup from a cold instruction cache)
                     if (t < nt) {
-                        const f32x4 a0 = tile_x6(s_xs + t * X6_TILE, wC);
-                        float v = fast_tanh(a0[0] + b1v.x) * w2v.x;
-                        v = fmaf(fast_tanh(a0[1] + b1v.y), w2v.y, v);
-                        v = fmaf(fast_tanh(a0[2] + b1v.z), w2v.z, v);
-                        v = fmaf(fast_tanh(a0[3] + b1v.w), w2v.w, v);
+                        const f32x4 a0 = tile_x6(s_xs + t * X2_TILE, wC);
+                        float v = fast_tanh(fmaf(a0[0], sW1, b1v.x)) * w2v.x;
+                        v = fmaf(fast_tanh(fmaf(a0[1], sW1, b1v.y)), w2v.y, v);
+                        v = fmaf(fast_tanh(fmaf(a0[2], sW1, b1v.z)), w2v.z, v);
+                        v = fmaf(fast_tanh(fmaf(a0[3], sW1, b1v.w)), w2v.w, v);
                         v += __shfl_xor(v, 16);
                         v += __shfl_xor(v, 32);
                         if (q == 0) s_part[wave * (HCH * 16) + t * 16 + m] = v;
@@ -1899,7 +1921,7 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
     if (A.stamps && lane == 0) for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
 #endif
 }
-static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X6_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
+static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
 
 // ---------------------------------------------------------------------------------------------
 // GIN layer 0, first Linear (12 -> 128) fused with the neighbour aggregation of the raw task features
@@ -2370,9 +2392,10 @@ struct mtfjsp_encoder {
     std::map<std::string, float *> wt;      // transposed [in,out] copies of the 128-wide Linear weights (split per 128-block of `in`)
     std::map<std::string, std::vector<float>> hostw;   // host copies of gat_layer.W / m_fea_*_fcl.weight (inputs of the fused projections)
     std::map<std::string, float *> wfused;  // per prefix + "1"/"2": (m_fea_k_fcl.weight^T . gat_layer.W)^T, [128,6] / [128,8]
-    std::map<std::string, void *> wx6;      // 128x128 Linear weights as 3 bf16 planes in k_gemm_x6's register-image order
+    std::map<std::string, void *> wx6;      // 128x128 Linear weights as 2 f16 planes (scaled) in k_gemm_x6's register-image order; GAT W / first Linear: 3 bf16 planes
     std::map<std::string, void *> wx32;     // GIN Linear weights as operand-piece planes in k_gin_res's (32x32x16) register-image order
     std::map<std::string, float> wx32_sinv; // ... 1 / the power-of-two scale folded into that image
+    std::map<std::string, float> wx6_sinv;  // the same for the f16 images in wx6
     std::map<std::string, float *> wimg;    // the same blocks as per-wave register images for k_heads: [block][wave 8][g 8][lane 64][4]
     std::vector<void *> owned;
     int num_cu = 256;
@@ -2548,6 +2571,38 @@ extern "C" int mtfjsp_encoder_destroy(mtfjsp_encoder_t e)
 }
 extern "C" int mtfjsp_encoder_set_stream(mtfjsp_encoder_t e, void *s) { if (!e) return MTFJSP_ERR_ARG; e->stream = (hipStream_t)s; return MTFJSP_OK; }
 
+// host-side IEEE binary16 conversion (round to nearest even, subnormals kept) for the f16 operand-piece images
+static uint16_t f32_to_f16_bits(float x)
+{
+    uint32_t u; memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u; u &= 0x7fffffffu;
+    uint32_t o;
+    if (u >= ((127u + 16u) << 23)) o = u > (255u << 23) ? 0x7e00u : 0x7c00u;
+    else if (u < (113u << 23)) { float f, magic; const uint32_t mb = ((127u - 15u) + (23u - 10u) + 1u) << 23; memcpy(&f, &u, 4); memcpy(&magic, &mb, 4);
+                                 f += magic; uint32_t fu; memcpy(&fu, &f, 4); o = fu - mb; }
+    else { const uint32_t odd = (u >> 13) & 1u; u += ((15u - 127u) << 23) + 0xfffu; u += odd; o = u >> 13; }
+    return (uint16_t)(o | sign);
+}
+static float f16_bits_to_f32(uint16_t hbits)
+{
+    const uint32_t sgn = (uint32_t)(hbits & 0x8000u) << 16, ex = (hbits >> 10) & 31u, m = hbits & 0x3ffu;
+    float x;
+    if (ex == 0) { x = ldexpf((float)m, -24); return sgn ? -x : x; }
+    const uint32_t u = sgn | ((ex == 31 ? 255u : ex + 112u) << 23) | (m << 13);
+    memcpy(&x, &u, 4); return x;
+}
+// the power of two that puts max |w| into [2^13, 2^14): the low f16 piece of every weight then stays a normal number
+static float f16_image_scale(const float *data, int64_t numel, bool *finite)
+{
+    float mx = 0.f;
+    for (int64_t i = 0; i < numel; i++) mx = fmaxf(mx, fabsf(data[i]));
+    *finite = mx < INFINITY;
+    int ex = 0;
+    if (mx > 0.f && *finite) (void)frexpf(mx, &ex);               // mx = f * 2^ex, f in [0.5, 1)
+    int k = 14 - ex; k = k > 60 ? 60 : k < -60 ? -60 : k;
+    return ldexpf(1.0f, k);
+}
+
 // element count of every tensor the forwards read, by the reference's state_dict key (after the "job_actor." / "machine_actor."
 // / "global_critic." prefix): gcn:60-107 (GraphCNN / MLP), gcn:322-433 (MLPActor / MLPCritic), ac:60-100, 330-357, 540-585
 static int64_t expected_numel(const std::string &key)
@@ -2644,32 +2699,11 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
         const int in = (int)(numel / HD), KS = in == 12 ? 1 : in / 16, P = in == 12 ? 3 : 2;
         auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
         auto from_bf16 = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
-        auto to_f16 = [](float x) {                                // round to nearest even, subnormals kept
-            uint32_t u; memcpy(&u, &x, 4);
-            const uint32_t sign = (u >> 16) & 0x8000u; u &= 0x7fffffffu;
-            uint32_t o;
-            if (u >= ((127u + 16u) << 23)) o = u > (255u << 23) ? 0x7e00u : 0x7c00u;
-            else if (u < (113u << 23)) { float f, magic; const uint32_t mb = ((127u - 15u) + (23u - 10u) + 1u) << 23; memcpy(&f, &u, 4); memcpy(&magic, &mb, 4);
-                                         f += magic; uint32_t fu; memcpy(&fu, &f, 4); o = fu - mb; }
-            else { const uint32_t odd = (u >> 13) & 1u; u += ((15u - 127u) << 23) + 0xfffu; u += odd; o = u >> 13; }
-            return (uint16_t)(o | sign);
-        };
-        auto from_f16 = [](uint16_t hbits) {
-            const uint32_t sgn = (uint32_t)(hbits & 0x8000u) << 16, ex = (hbits >> 10) & 31u, m = hbits & 0x3ffu;
-            float x;
-            if (ex == 0) { x = ldexpf((float)m, -24); return sgn ? -x : x; }
-            const uint32_t u = sgn | ((ex == 31 ? 255u : ex + 112u) << 23) | (m << 13);
-            memcpy(&x, &u, 4); return x;
-        };
         float scale = 1.0f;
         if (P == 2) {
-            float mx = 0.f;
-            for (int64_t i = 0; i < numel; i++) mx = fmaxf(mx, fabsf(data[i]));
-            if (!(mx < INFINITY)) { e->err = "load_weight: non-finite value in " + key; return MTFJSP_ERR_ARG; }
-            int ex = 0;
-            if (mx > 0.f) (void)frexpf(mx, &ex);                   // mx = f * 2^ex, f in [0.5, 1)
-            int k = 14 - ex; k = k > 60 ? 60 : k < -60 ? -60 : k;
-            scale = ldexpf(1.0f, k);
+            bool finite = true;
+            scale = f16_image_scale(data, numel, &finite);
+            if (!finite) { e->err = "load_weight: non-finite value in " + key; return MTFJSP_ERR_ARG; }
         }
         std::vector<uint16_t> im((size_t)4 * P * KS * 64 * 8, 0);
         for (int w = 0; w < 4; w++)
@@ -2684,7 +2718,7 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
                             pl[0] = to_bf16(x); const float r1 = x - from_bf16(pl[0]);
                             pl[1] = to_bf16(r1); pl[2] = to_bf16(r1 - from_bf16(pl[1]));
                         } else {
-                            pl[0] = to_f16(x); pl[1] = to_f16(x - from_f16(pl[0]));
+                            pl[0] = f32_to_f16_bits(x); pl[1] = f32_to_f16_bits(x - f16_bits_to_f32(pl[0]));
                         }
                         for (int p = 0; p < P; p++) im[(((((size_t)w * P + p) * KS + ks) * 64 + lane) * 8) + j] = pl[p];
                     }
@@ -2754,12 +2788,13 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
             HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
         }
         if (!is_gat_w) {
-            // k_gemm_x6 / k_headsx: exact 3-way bf16 split (round-to-nearest-even each), per 128-wide input block
-            // img[blk][cg 4][c 2][plane 3][ks 4][lane 64][i 8] = plane(W[n = 32cg + 16c + (lane & 15)][blk*128 + 32ks + 8(lane >> 4) + i]);
-            // W is the torch layout [out n][in].  (cg, c) = column block w = 2cg + c of k_headsx's wave w.
-            auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
-            auto from_bf16 = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
-            std::vector<uint16_t> im((size_t)3 * numel);
+            // k_gemm_x6 / k_headsx: 2-way f16 split (round to nearest) of the weight scaled by a power of two, per 128-wide input block
+            // img[blk][cg 4][c 2][plane 2][ks 4][lane 64][i 8] = plane(s W[n = 32cg + 16c + (lane & 15)][blk*128 + 32ks + 8(lane >> 4) + i]);
+            // W is the torch layout [out n][in].  (cg, c) = column block w = 2cg + c of k_headsx's wave w.  1/s: wx6_sinv.
+            bool finite = true;
+            const float scale = f16_image_scale(data, numel, &finite);
+            if (!finite) { e->err = "load_weight: non-finite value in " + key; return MTFJSP_ERR_ARG; }
+            std::vector<uint16_t> im((size_t)2 * numel);
             const int in = blocks * HD;
             for (int blk = 0; blk < blocks; blk++)
                 for (int cgi = 0; cgi < 4; cgi++)
@@ -2768,12 +2803,12 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
                             for (int lane = 0; lane < 64; lane++)
                                 for (int i = 0; i < 8; i++) {
                                     const int n = 32 * cgi + 16 * c + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + i;
-                                    const float w = data[(size_t)n * in + blk * HD + k];
-                                    const uint16_t p0 = to_bf16(w); const float r1 = w - from_bf16(p0);
-                                    const uint16_t p1 = to_bf16(r1); const float r2 = r1 - from_bf16(p1);
-                                    const uint16_t pl[3] = {p0, p1, to_bf16(r2)};
-                                    for (int p = 0; p < 3; p++) im[(((((((size_t)blk * 4 + cgi) * 2 + c) * 3 + p) * 4 + ks) * 64 + lane) * 8) + i] = pl[p];
+                                    const float w = data[(size_t)n * in + blk * HD + k] * scale;
+                                    const uint16_t p0 = f32_to_f16_bits(w), p1 = f32_to_f16_bits(w - f16_bits_to_f32(p0));
+                                    const uint16_t pl[2] = {p0, p1};
+                                    for (int p = 0; p < 2; p++) im[(((((((size_t)blk * 4 + cgi) * 2 + c) * 2 + p) * 4 + ks) * 64 + lane) * 8) + i] = pl[p];
                                 }
+            e->wx6_sinv[key] = 1.0f / scale;
             void *dx = nullptr;
             auto kt = e->wx6.find(key);
             if (kt != e->wx6.end()) dx = kt->second;
@@ -2875,7 +2910,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         GemmArgs a = gemm_args(nullptr, N, nullptr, W(P + "mlps.0.linears.0.bias"), e->zA);
         a.tfea = tasks_fea; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64; a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
         a.epi_stats = st + 0 * STAT_REP * 256;
-        a.Wx6 = e->wx6.at(P + "mlps.0.linears.0.weight");
+        a.Wx6 = e->wx6.at(P + "mlps.0.linears.0.weight"); a.w_sinv = 1.0f;
         const int ntiles = (N + 15) / 16;
         int grid = (ntiles + 7) / 8;
         if (grid > e->num_cu) grid = e->num_cu;
@@ -2893,7 +2928,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         GemmArgs a = gemm_args(in, N, WT(P + lin + ".weight"), W(P + lin + ".bias"), out);
         a.pro_stats = st + sin * STAT_REP * 256; a.pro_gamma = W(P + bn + ".weight"); a.pro_beta = W(P + bn + ".bias"); a.pro_inv_rows = invN;
         a.epi_stats = st + sout * STAT_REP * 256;
-        a.Wx6 = e->wx6.at(P + lin + ".weight");
+        a.Wx6 = e->wx6.at(P + lin + ".weight"); a.w_sinv = e->wx6_sinv.at(P + lin + ".weight");
         launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_bn_relu");
     };
     bn_gemm(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1);
@@ -2903,7 +2938,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         a.pro_stats = st + 2 * STAT_REP * 256; a.pro_gamma = W(P + "batch_norms.0.weight"); a.pro_beta = W(P + "batch_norms.0.bias"); a.pro_inv_rows = invN;
         a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
         a.epi_stats = st + 3 * STAT_REP * 256;
-        a.Wx6 = e->wx6.at(P + "mlps.1.linears.0.weight");
+        a.Wx6 = e->wx6.at(P + "mlps.1.linears.0.weight"); a.w_sinv = e->wx6_sinv.at(P + "mlps.1.linears.0.weight");
         launch_gemm<PRO_AGG, EPI_STATS>(e, a, "gin_gemm_agg");
     }
     bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4);
@@ -3110,6 +3145,8 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
     if (e->f32_products & 4) { hipLaunchKernelGGL(k_heads, dim3(grid), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
     ha.W0x = e->wx6.at(policy + ".linears.0.weight"); ha.W1x = e->wx6.at(policy + ".linears.1.weight");
     ha.Wc0x = e->wx6.at(critic + ".linears.0.weight"); ha.Wc1x = e->wx6.at(critic + ".linears.1.weight");
+    ha.sW0 = e->wx6_sinv.at(policy + ".linears.0.weight"); ha.sW1 = e->wx6_sinv.at(policy + ".linears.1.weight");
+    ha.sWc0 = e->wx6_sinv.at(critic + ".linears.0.weight"); ha.sWc1 = e->wx6_sinv.at(critic + ".linears.1.weight");
     hipLaunchKernelGGL(k_headsx, dim3(grid), dim3(512), headsx_lds_bytes(), e->stream, ha);
 }
 static void arm_sampling(mtfjsp_encoder *e, int which, HeadArgs &ha)
