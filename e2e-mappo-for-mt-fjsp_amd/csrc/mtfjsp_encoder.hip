@@ -879,7 +879,8 @@ struct GatArgs {
     const float *W1, *W2;   // (m_fea_1_fcl.weight^T . gat W)^T [128,6], (m_fea_2_fcl.weight^T . gat W)^T [128,8]: input projection and
                             // the first pass' h W fused on the host (one 14 x 128 x 128 product per weight load)
     const float *Wt;        // gat_layer.W [in,out]
-    const void *Wx6;        // the same as bf16 x 3-plane operand fragments [c 8][plane 3][ks 4][lane 64][8] (k_gat3x)
+    const void *Wx6;        // the same (scaled by a power of two) as f16 x 2-plane operand fragments [c 8][plane 2][ks 4][lane 64][8] (k_gat3x)
+    float w_sinv;           // 1 / that scale
     const float *gat_a;     // [256] a_src | a_dst (gat:68-79)
     float *node;            // [R,128] (padded) pre-BatchNorm node mean
     double *epi_stats;
@@ -1040,37 +1041,39 @@ __global__ __launch_bounds__(512) void k_gat3(GatArgs A)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_gat3x — k_gat3 with passes 2 and 3 on the bf16 matrix cores at f32 accuracy (exact 3-way split, 6 piece products, see
-// k_gemm_x6).  Eight waves per workgroup, each keeping its own 16-row tile through all three passes:
-//   * the GAT weight lives in LDS as bf16 fragments in operand order [column block 8][plane 3][k-step 4][lane 64][16 B]
-//     (96 KiB, conflict-free 16-byte reads), streamed two column blocks at a time with the next pair in flight;
+// k_gat3x — k_gat3 with passes 2 and 3 on the 16-bit matrix cores at f32 accuracy (2-way f16 split, 3 piece products, weight
+// pre-scaled by a power of two: see k_gemm_x6 / DESIGN.md §4).  Eight waves per workgroup, each keeping its own 16-row tile
+// through all three passes:
+//   * the GAT weight lives in LDS as f16 fragments in operand order [column block 8][plane 2][k-step 4][lane 64][16 B]
+//     (64 KiB, conflict-free 16-byte reads), streamed two column blocks at a time with the next pair in flight;
 //   * the tile's activations are the A operand, held in registers: after each pass's epilogue wrote the new rows to the
 //     wave's f32 LDS tile (the C layout -> operand layout transpose, XOR-swizzled), they are read back as 8 x 16 bytes
-//     per lane and split into 3 planes x 4 k-steps of fragments (48 registers);
+//     per lane and split into 2 planes x 4 k-steps of fragments (32 registers);
 //   * the accumulators stay in the ordinary C layout (rows 4q+i in the lane, columns across the 16 lanes of a DPP row), so
 //     the attention epilogue is k_gat3's.
-// 2 passes x 8 column blocks x 24 products x 16 cycles = 6.1 k cycles per tile instead of 16.4 k with the f32 instruction.
-// f32 transpose tile without padding (weights 96 KiB + 8 tiles x 8 KiB = the whole 160 KiB of LDS): 16-byte chunk index
-// XOR (row & 7) makes the row-wise 16-byte operand reads, the C-layout word accesses and the row writes conflict-free
+// 2 passes x 8 column blocks x 12 products x 16 cycles = 3.1 k cycles per tile instead of 16.4 k with the f32 instruction.
+// f32 transpose tile without padding: 16-byte chunk index XOR (row & 7) makes the row-wise 16-byte operand reads, the
+// C-layout word accesses and the row writes conflict-free
 __device__ __forceinline__ int gx_off(int row, int col) { return row * HD + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); }
 __global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *s_wf = smem;                                   // 8*3*4*64*16 B
-    float *s_a = reinterpret_cast<float *>(smem + 8 * 3 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
+    unsigned char *s_wf = smem;                                   // 8*2*4*64*16 B
+    float *s_a = reinterpret_cast<float *>(smem + 8 * 2 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
     double *s_red = reinterpret_cast<double *>(s_a);              // (after the last tile)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 31, h = lane >> 5, c4 = j * 4;
     const int m = lane & 15, q = lane >> 4;
-    {   // stage the weight fragments: 98304 B = 12 x 16 B per thread, coalesced
+    {   // stage the weight fragments: 65536 B = 8 x 16 B per thread, coalesced
         const float4 *src = reinterpret_cast<const float4 *>(A.Wx6);
         float4 *dst = reinterpret_cast<float4 *>(s_wf);
-        float4 v[12];
+        float4 v[8];
 #pragma unroll
-        for (int i = 0; i < 12; i++) v[i] = src[i * 512 + tid];
+        for (int i = 0; i < 8; i++) v[i] = src[i * 512 + tid];
 #pragma unroll
-        for (int i = 0; i < 12; i++) dst[i * 512 + tid] = v[i];
+        for (int i = 0; i < 8; i++) dst[i * 512 + tid] = v[i];
     }
+    const float wsinv = A.w_sinv;
     float *my_a = s_a + wave * 16 * HD;
     float *my_f = my_a + 15 * HD;                                 // the tile's feature words live in its last row until that row is written (p = 7)
     const int N = 2 * A.R;
@@ -1103,7 +1106,7 @@ __global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
     float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t_cur < last) fpre = fetch_feat(t_cur);
     __syncthreads();                                              // weight fragments are staged
-    const unsigned char *wl = s_wf + lane * 16;                   // fragment (c, p, ks): wl + ((c*3 + p)*4 + ks) * 1024
+    const unsigned char *wl = s_wf + lane * 16;                   // fragment (c, p, ks): wl + ((c*2 + p)*4 + ks) * 1024
     while (t_cur < last) {
         const int row0 = t_cur * 16;
         // ---- input rows: tile rows 2p+h are node h of machine (row0/2 + p); W1/W2 arrive pre-multiplied with the GAT
@@ -1137,26 +1140,28 @@ __global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
                     for (int i = 0; i < 4; i++) acc[c][i] = my_a[gx_off(4 * q + i, c * 16 + m)];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else {
-                // the tile in operand layout: row m, k = 32ks + 8q .. +7, split into three bf16 planes
-                bf16x8 xf[3][4];
+                // the tile in operand layout: row m, k = 32ks + 8q .. +7, split into two f16 planes (the values are ELU outputs of
+                // attention mixtures — unbounded in principle, so they saturate at the f16 range instead of overflowing)
+                h16x8 xf[2][4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ks++) {
                     const float4 lo = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q));
                     const float4 hi = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q + 4));
-                    const float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
-                    uint2 a0, a1, a2, b0, b1, b2;
-                    split3x4(v0, a0, a1, a2); split3x4(v1, b0, b1, b2);
-                    xf[0][ks] = __builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
-                    xf[1][ks] = __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
-                    xf[2][ks] = __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y));
+                    const float FM = 65000.f;
+                    const float v0[4] = {__builtin_amdgcn_fmed3f(lo.x, -FM, FM), __builtin_amdgcn_fmed3f(lo.y, -FM, FM), __builtin_amdgcn_fmed3f(lo.z, -FM, FM), __builtin_amdgcn_fmed3f(lo.w, -FM, FM)};
+                    const float v1[4] = {__builtin_amdgcn_fmed3f(hi.x, -FM, FM), __builtin_amdgcn_fmed3f(hi.y, -FM, FM), __builtin_amdgcn_fmed3f(hi.z, -FM, FM), __builtin_amdgcn_fmed3f(hi.w, -FM, FM)};
+                    uint2 a0, a1, b0, b1;
+                    split2x4(v0, a0, a1); split2x4(v1, b0, b1);
+                    xf[0][ks] = __builtin_bit_cast(h16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+                    xf[1][ks] = __builtin_bit_cast(h16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
                 }
-                // column blocks in pairs (two accumulator chains); units u = (pair, k-step): 6 weight fragments each, the next
+                // column blocks in pairs (two accumulator chains); units u = (pair, k-step): 4 weight fragments each, the next
                 // unit's in flight
-                bf16x8 wr[2][2][3];
+                h16x8 wr[2][2][2];
 #pragma unroll
                 for (int cc = 0; cc < 2; cc++)
 #pragma unroll
-                    for (int p = 0; p < 3; p++) wr[0][cc][p] = *reinterpret_cast<const bf16x8 *>(wl + ((cc * 3 + p) * 4) * 1024);
+                    for (int p = 0; p < 2; p++) wr[0][cc][p] = *reinterpret_cast<const h16x8 *>(wl + ((cc * 2 + p) * 4) * 1024);
 #pragma unroll
                 for (int c = 0; c < 8; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1167,22 +1172,18 @@ __global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
 #pragma unroll
                         for (int cc = 0; cc < 2; cc++)
 #pragma unroll
-                            for (int p = 0; p < 3; p++) wr[(u + 1) & 1][cc][p] = *reinterpret_cast<const bf16x8 *>(wl + (((2 * cn + cc) * 3 + p) * 4 + kn) * 1024);
+                            for (int p = 0; p < 2; p++) wr[(u + 1) & 1][cc][p] = *reinterpret_cast<const h16x8 *>(wl + (((2 * cn + cc) * 2 + p) * 4 + kn) * 1024);
                     }
-                    const bf16x8 (*w)[3] = wr[u & 1];
+                    const h16x8 (*w)[2] = wr[u & 1];
 #pragma unroll
-                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[0][ks], w[cc][2], acc[2 * cp + cc], 0, 0, 0);
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
 #pragma unroll
-                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[2][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0][ks], w[cc][1], acc[2 * cp + cc], 0, 0, 0);
 #pragma unroll
-                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[1][ks], w[cc][1], acc[2 * cp + cc], 0, 0, 0);
-#pragma unroll
-                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[0][ks], w[cc][1], acc[2 * cp + cc], 0, 0, 0);
-#pragma unroll
-                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[1][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
-#pragma unroll
-                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[0][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
                 }
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[c] *= wsinv;                  // the weight image is scaled by a power of two
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {                                     // the lane's two machines: tile rows 4q+2u (node 0), +1 (node 1)
@@ -1241,7 +1242,7 @@ __global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
         atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
     }
 }
-static size_t gat3x_lds_bytes() { return (size_t)8 * 3 * 4 * 64 * 16 + (size_t)8 * 16 * HD * 4; }
+static size_t gat3x_lds_bytes() { return (size_t)8 * 2 * 4 * 64 * 16 + (size_t)8 * 16 * HD * 4; }
 
 // ---------------------------------------------------------------------------------------------
 // Fused actor heads (ac:205-293 / ac:444-495): for a group of 16 instances (= R 16-row tiles of scorer rows, since an
@@ -2766,21 +2767,23 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
             HIPCHK(e, hipMemcpy(di, im.data(), (size_t)numel * 4, hipMemcpyHostToDevice));
         }
         if (is_gat_w) {
-            // k_gat3x: B-operand fragments of W [in k][out n]: img[c 8][plane 3][ks 4][lane 64][i 8] = plane(W[32ks + 8(lane >> 4) + i][16c + (lane & 15)])
-            auto to_bf16 = [](float x) { uint32_t u; memcpy(&u, &x, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); };
-            auto from_bf16 = [](uint16_t b) { uint32_t u = (uint32_t)b << 16; float x; memcpy(&x, &u, 4); return x; };
-            std::vector<uint16_t> im((size_t)3 * HD * HD);
+            // k_gat3x: B-operand fragments of s W [in k][out n] as two f16 planes: img[c 8][plane 2][ks 4][lane 64][i 8] =
+            // plane(s W[32ks + 8(lane >> 4) + i][16c + (lane & 15)]), s = power of two (1/s: wx6_sinv)
+            bool finite = true;
+            const float scale = f16_image_scale(data, numel, &finite);
+            if (!finite) { e->err = "load_weight: non-finite value in " + key; return MTFJSP_ERR_ARG; }
+            std::vector<uint16_t> im((size_t)2 * HD * HD);
             for (int c = 0; c < 8; c++)
                 for (int ks = 0; ks < 4; ks++)
                     for (int lane = 0; lane < 64; lane++)
                         for (int i = 0; i < 8; i++) {
                             const int k = 32 * ks + 8 * (lane >> 4) + i, n = 16 * c + (lane & 15);
-                            const float w = data[(size_t)k * HD + n];
-                            const uint16_t p0 = to_bf16(w); const float r1 = w - from_bf16(p0);
-                            const uint16_t p1 = to_bf16(r1); const float r2 = r1 - from_bf16(p1);
-                            const uint16_t pl[3] = {p0, p1, to_bf16(r2)};
-                            for (int p = 0; p < 3; p++) im[(((((size_t)c * 3 + p) * 4 + ks) * 64 + lane) * 8) + i] = pl[p];
+                            const float w = data[(size_t)k * HD + n] * scale;
+                            const uint16_t p0 = f32_to_f16_bits(w), p1 = f32_to_f16_bits(w - f16_bits_to_f32(p0));
+                            const uint16_t pl[2] = {p0, p1};
+                            for (int p = 0; p < 2; p++) im[(((((size_t)c * 2 + p) * 4 + ks) * 64 + lane) * 8) + i] = pl[p];
                         }
+            e->wx6_sinv[key] = 1.0f / scale;
             void *dx = nullptr;
             auto kt = e->wx6.find(key);
             if (kt != e->wx6.end()) dx = kt->second;
@@ -3064,7 +3067,7 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
 #endif
         if (e->f32_products & 2) hipLaunchKernelGGL(k_gat3, dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, a);
         else {
-            a.Wx6 = e->wx6.at(pre + "gat_layer.W");
+            a.Wx6 = e->wx6.at(pre + "gat_layer.W"); a.w_sinv = e->wx6_sinv.at(pre + "gat_layer.W");
             hipLaunchKernelGGL(k_gat3x, dim3(grid), dim3(512), gat3x_lds_bytes(), e->stream, a);
         }
 #ifdef MTFJSP_STAMP
