@@ -951,6 +951,8 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
 #undef DIVM
 }
 
+#include "mtfjsp_env_grp.h"
+
 // ---------------------------------------------------------------------------------------------
 // instance preparation: min_dur/min_pt (env:1932-1950) and the means of pe:176-183. thread = (b,task)
 __global__ void k_prepare(int B, int T, int M, const double *t, const double *p, double2 *cst, double *mean3)
@@ -1520,8 +1522,23 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
     if (!d_st) (void)hipMalloc((void **)&d_st, (size_t)P.B * 64);
     P.stamps = d_st;
 #endif
-    static const int force_lds = getenv("MTFJSP_ENV_LDS") ? 1 : 0;        // diagnostic: force the LDS kernel
-    if (P.T <= 64 && P.M * P.M <= 64 && P.J <= 64 && !force_lds) {        // register-resident kernel (no LDS)
+    // diagnostic / test overrides of the kernel selection (read per call): MTFJSP_ENV_KERNEL = lds | reg1 | grp16 | grp4
+    const char *force = getenv("MTFJSP_ENV_KERNEL");
+    const bool force_lds = getenv("MTFJSP_ENV_LDS") || (force && !strcmp(force, "lds"));
+    const bool force_reg1 = force && !strcmp(force, "reg1");
+    const bool reg_ok = P.T <= 64 && P.M * P.M <= 64 && P.J <= 64 && !force_lds;
+    if (reg_ok && !force_reg1) {                                          // register kernel, groups of instances per workgroup
+        const bool small = force && !strcmp(force, "grp16") ? true : force && !strcmp(force, "grp4") ? false : P.B <= EG_SMALL_MAX_B;
+        if (small) {
+            const int grid = (P.B + EG_SMALL - 1) / EG_SMALL;
+            if (P.obs_f32) hipLaunchKernelGGL((k_env_grp16<float>), dim3(grid), dim3(EG_SMALL * WAVE), 0, h->stream, P);
+            else hipLaunchKernelGGL((k_env_grp16<double>), dim3(grid), dim3(EG_SMALL * WAVE), 0, h->stream, P);
+        } else {
+            const int grid = (P.B + EG_LARGE - 1) / EG_LARGE;
+            if (P.obs_f32) hipLaunchKernelGGL((k_env_grp4<float>), dim3(grid), dim3(EG_LARGE * WAVE), 0, h->stream, P);
+            else hipLaunchKernelGGL((k_env_grp4<double>), dim3(grid), dim3(EG_LARGE * WAVE), 0, h->stream, P);
+        }
+    } else if (reg_ok) {                                                  // one instance per workgroup (the A/B reference of the grouped form)
         if (P.obs_f32) hipLaunchKernelGGL((k_env_reg<float>), dim3(P.B), dim3(WAVE), 0, h->stream, P);
         else hipLaunchKernelGGL((k_env_reg<double>), dim3(P.B), dim3(WAVE), 0, h->stream, P);
     } else {

@@ -1,0 +1,422 @@
+// mtfjsp_env_grp.h — k_env_grp: the register step kernel (k_env_reg, T <= 64, M*M <= 64) for GROUPS of 16 instances.
+// Included by mtfjsp_env.hip (uses EnvParams, Link, MRec, rl_i, rl_d, uni, trunc_l and the S_* slots).
+//
+// Why: at the headline batch every SIMD holds four one-instance waves and the launch is bound by vector-instruction issue
+// (≈920 VALU instructions per wave, SQ counters), and a third of those compute per-INSTANCE scalars — makespan, energy and
+// idle sums, the four rewards, RewardScaling with its three f64 divisions and a square root, the machine feature row, the
+// job mask — on all 64 lanes for one useful lane.  Here a workgroup is 16 waves = 16 instances:
+//   * every wave runs the per-task part of the step for its instance exactly as k_env_reg does (lane = task: scheduling
+//     decision, route / estimate updates, observation rows, ELL rows, state write-back) and leaves the per-instance inputs
+//     of the scalar part in LDS;
+//   * after one barrier, wave 0 runs the scalar part ONCE for all 16 instances with lane = (instance, reward channel):
+//     the same f64 operations in the same order (the idle sum left to right over the terms in rank order, numpy's pairwise
+//     energy sum, pt:54-124 per channel), so the results are bit-identical to k_env_reg.
+// Nothing in the per-task part waits for the scalar part.
+#pragma once
+// Instances (= waves) per workgroup; the scalar part uses 4 lanes per instance.  Two builds (measured, tools/env_variants.py):
+// 16 instances and 4 waves per SIMD (no spills) while all waves of the batch are resident at once (<= 8192 instances: 14.4 us at
+// 4096 against 16.1 us for k_env_reg); 4 instances and 8 waves per SIMD for chip-filling batches, where occupancy and short
+// barrier waits matter more than the amortisation (262 144 instances: 335 us = 0.78 of the copy rate against 442 us = 0.59).
+#define EG_SMALL 16
+#define EG_LARGE 4
+#define EG_SMALL_MAX_B 8192
+enum { U_R0 = 0, U_NEWTR, U_D, U_PK, U_FTTAIL, U_TAIL = 8 };     // s_un slots (8..15: ragged tail of the pairwise energy sum)
+enum { I_VALID = 0, I_STATUS, I_NSCHED, I_M, I_JA };            // s_in slots
+
+template <typename OBS>
+__device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, const int lane, double *s_sorted, double *s_jmx, double *s_jrw,
+                                             int *s_cn, double *s_scl, double *s_mf, double *s_un, int *s_in)
+{
+    const int J = P.J, M = P.M, T = P.T;
+    const unsigned invM = P.inv_M;
+#define DIVM(x) ((int)__umulhi((unsigned)(x), invM))
+    const size_t bT = (size_t)b * T;
+    const int v = lane;
+    const bool isT = v < T;
+    // ---- bulk state (independent of the action)
+    int mach = -1, prev = -1, next = -1, pos = 0;
+    double st = 0.0, ft = 0.0, dur = 0.0, pte = 0.0;
+    if (isT) {
+        const Link l = P.link[bT + v];
+        mach = l.mach; prev = l.prev; pos = l.pos; next = l.pad;
+        st = P.st[bT + v]; ft = P.ft[bT + v]; dur = P.dur[bT + v]; pte = P.pte[bT + v];
+    }
+    const double ttv = lane < M * M ? P.tt[(size_t)b * M * M + lane] : 0.0;
+    int head_ = -1, tail_ = -1, len_ = 0;
+    if (lane < M) { const MRec r = P.mrec[(size_t)b * M + lane]; head_ = r.head; tail_ = r.tail; len_ = r.len; }
+    int cnt_ = 0; double jmax_ = -INFINITY, jrow_ = 0.0;
+    if (lane < J) { cnt_ = (int)P.jcnt[(size_t)b * J + lane]; jmax_ = P.jmax[(size_t)b * J + lane]; jrow_ = P.jrow[(size_t)b * J + lane]; }
+    const double sc = lane < SCAL_N ? P.scal[(size_t)b * SCAL_N + lane] : 0.0;
+    const int lastm = uni(P.lastm[b]);
+    int a = uni(P.task_idx[b]), m = uni(P.mach_idx[b]);
+    bool valid = a >= 0 && a < T && m >= 0 && m < M;
+    if (!valid) { a = 0; m = 0; }
+    const int ja = DIVM(a), op = a - ja * M;
+    // ---- second hop (depends on the action)
+    const double d = P.t[(bT + a) * M + m];
+    const double pk = P.p[(bT + a) * M + m];
+    const double md = lane < M ? P.cst[bT + ja * M + lane].x : 0.0;
+    const double mfr = lane < 8 ? P.mfea[((size_t)b * M + m) * 8 + lane] : 0.0;
+    const int jv = DIVM(v), opv = v - jv * M;
+    if (lane < SCAL_N) s_scl[lane] = sc;
+
+    // =========================================================================================
+    // A. scheduling (env:1476-1685)
+    int status = 0, path = 0, Pk = -1, Nk = -1, ipos = 0;
+    double st_k = 0.0;
+    int mach_p = -1;
+    if (valid) {
+        if (rl_i(mach, a) >= 0) valid = false;                                  // env:1504
+        else if (op != 0) { mach_p = rl_i(mach, a - 1); if (mach_p < 0) valid = false; }   // env:1520
+    }
+    const int len = rl_i(len_, m), head = rl_i(head_, m), tail = rl_i(tail_, m);
+    const double ttmm = rl_d(ttv, m * M + m);
+    if (valid) {
+        if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;                            // pe:246-248
+        const double arr_k = op == 0 ? 0.0 : rl_d(ft, a - 1) + rl_d(ttv, mach_p * M + m);   // dg:46-66
+        bool do_append = false;
+        if (len == 0) { path = MTFJSP_PATH_EMPTY; st_k = arr_k; ipos = 0; }                 // env:1684
+        else if (!P.left_shift) do_append = true;                                               // env:1680
+        else {
+            const double lb_ft = arr_k + d;
+            const int jh = DIVM(head);
+            const double arr_f = (head == jh * M) ? 0.0 : rl_d(ft, head - 1) + rl_d(ttv, rl_i(mach, head - 1) * M + m);
+            if (lb_ft <= arr_f) { path = MTFJSP_PATH_FRONT; st_k = arr_k; ipos = 0; Nk = head; }   // env:1548
+            else if (len == 1) do_append = true;                                                 // env:1577
+            else {
+                // gap test of env:1587-1604 on every lane at once, then the first hit in route order by a scalar walk
+                const int pi = prev >= 0 ? prev : 0, vi = v > 0 ? v - 1 : 0;
+                const double ftP = __shfl(ft, pi), ftj = __shfl(ft, vi);
+                const int mj = __shfl(mach, vi);
+                const double ttj = __shfl(ttv, (mj >= 0 ? mj : 0) * M + m);
+                const double jarr = (opv == 0) ? 0.0 : ftj + ttj;
+                const double x = (DIVM(pi) == jv) ? ttmm : 0.0;
+                const double nst = fmax(jarr, ftP + x);
+                const bool ok = isT && mach == m && prev >= 0 && !(lb_ft > nst) && !((nst - ftP) < d);
+                const unsigned long long okm = __ballot(ok);
+                int cur = rl_i(next, head);
+                while (cur >= 0) {
+                    if ((okm >> cur) & 1ull) { Nk = cur; break; }
+                    cur = rl_i(next, cur);
+                }
+                if (Nk >= 0) {
+                    path = MTFJSP_PATH_BETWEEN;
+                    ipos = rl_i(pos, Nk); Pk = rl_i(prev, Nk);
+                    const double xx = (DIVM(Pk) == ja) ? ttmm : 0.0;
+                    st_k = fmax(arr_k, rl_d(ft, Pk) + xx);                      // env:1619
+                } else do_append = true;                                        // env:1676
+            }
+        }
+        if (do_append) {                                                        // env:1689-1775
+            path = MTFJSP_PATH_APPEND;
+            const double xx = (DIVM(tail) == ja) ? ttmm : 0.0;
+            st_k = fmax(arr_k, rl_d(ft, tail) + xx);
+            ipos = len; Pk = tail;
+        }
+        status |= path;
+    } else status |= MTFJSP_ST_INVALID;
+    if (!valid) {                                                               // nothing changes; the scalar part reports it
+        if (lane == 0) { s_in[I_VALID] = 0; s_in[I_STATUS] = status; }
+        return;
+    }
+    const double ft_k = st_k + d;
+    // ---- apply: register updates on the owning lanes
+    if (isT && mach == m && pos >= ipos) pos += 1;
+    if (v == a) { mach = m; prev = Pk; next = Nk; pos = ipos; st = st_k; ft = ft_k; dur = d; pte = d * pk; }    // env:356,2175
+    if (v == Nk) prev = a;
+    if (v == Pk) next = a;
+    if (lane == m) { if (ipos == 0) head_ = a; if (ipos == len) tail_ = a; len_ = len + 1; }
+    if (lane == ja) cnt_ += 1;
+    const int nsched = (int)rl_d(sc, S_NSCHED) + 1;
+
+    // =========================================================================================
+    // B. per-task side of the costs
+    // estimated start/finish of the acting job's ops: the reference's left-to-right loop (env:1965-1995), run with
+    // scalar indices; lane ja*M+c keeps its own (ste, fte).  Ops of a job are scheduled in order: ops < op are scheduled
+    // (their estimate IS their finish time, already folded into the job's running row maximum jrow_), op is being scheduled
+    // now, ops > op are unscheduled -> only the tail is walked.
+    double my_ste = 0.0, my_fte = 0.0, accp = ft_k;
+    const double row_prev = rl_d(jrow_, ja);                                    // max real finish time of ops < op (0 if none)
+    double jrow_new = op == 0 ? ft_k : fmax(row_prev, ft_k);                    // ppo:265-275 row maximum of real finish times
+    double jmax_new = jrow_new;                                                 // estimated finish times of ops <= op are the real ones
+    if (v == a) { my_ste = st_k; my_fte = ft_k; }
+    if (ft_k == 0.0) {                                                          // env:1977: a zero finish time is treated as "not set"
+        accp = (op ? rl_d(ft, a - 1) : 0.0) + rl_d(md, op);
+        if (v == a) my_fte = accp;
+        jmax_new = op == 0 ? accp : fmax(row_prev, accp);
+    }
+    for (int c = op + 1; c < M; c++) {
+        const double fte_c = accp + rl_d(md, c);
+        if (v == ja * M + c) { my_ste = accp; my_fte = fte_c; }
+        accp = fte_c;
+        jmax_new = fmax(jmax_new, fte_c);
+    }
+    if (lane == ja) { jmax_ = jmax_new; jrow_ = jrow_new; }
+    if (lane < J) { s_jmx[lane] = jmax_; s_jrw[lane] = jrow_; s_cn[lane] = cnt_; }
+    // env:896 np.sum(pt_est), numpy's pairwise order: lanes 0..7 are its 8 accumulators r[k] = a[k] + a[k+8] + ... (in that
+    // order), then its fixed tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) as an xor butterfly (fp addition commutes); the ragged
+    // tail is added by the scalar part, in order
+    {
+        const int nb = T < 8 ? 0 : T - (T & 7);
+        if (nb) {
+            double r = pte;
+            for (int i = 8; i < nb; i += 8) r += __shfl(pte, (lane & 7) + i);
+            r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
+            if (lane == 0) s_un[U_R0] = r;
+        } else if (lane == 0) s_un[U_R0] = 0.0;
+        if (v >= nb && v < T) s_un[U_TAIL + v - nb] = pte;
+    }
+    // idle time (dg:144-170): one term per scheduled task, summed strictly left to right in (machine, route position)
+    // order: every scheduled lane computes its rank in that order = (tasks on lower machines) + (its route position) and
+    // drops its term at that index; the scalar part adds terms 0..nsched-1 in order.
+    {
+        const double ftPr = __shfl(ft, prev >= 0 ? prev : 0);
+        const double term = prev < 0 ? st : st - ftPr;
+        int incl = lane < M ? len_ : 0;                                         // M <= 8: three DPP row shifts with zero fill
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+        const int before = incl - (lane < M ? len_ : 0);
+        const bool sch = isT && mach >= 0;
+        const int below = __shfl(before, mach >= 0 ? mach : 0);                 // executed by ALL lanes: the source lanes must be active
+        // the other lanes fill the remaining slots with +0.0 (x + 0.0 == x: the running sum is never -0.0), so that the scalar
+        // part adds a fixed number of terms: unscheduled tasks take nsched.. in lane order, lanes >= T their own index
+        const unsigned long long um = __ballot(isT && mach < 0);
+        const int uidx = nsched + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+        s_sorted[sch ? below + pos : isT ? uidx : lane] = sch ? term : 0.0;
+    }
+    {
+        const double new_tr = (op == 0) ? 0.0 : rl_d(ttv, mach_p * M + m);      // env:872-876
+        const double ft_tail = rl_d(ft, rl_i(tail_, m));                        // env:2315-2340, column 0 of the acting machine's row
+        if (lane == 0) {
+            s_un[U_NEWTR] = new_tr; s_un[U_D] = d; s_un[U_PK] = pk; s_un[U_FTTAIL] = ft_tail;
+            s_in[I_VALID] = 1; s_in[I_STATUS] = status; s_in[I_NSCHED] = nsched; s_in[I_M] = m; s_in[I_JA] = ja;
+        }
+        if (lane < 8) s_mf[lane] = mfr;
+    }
+
+    // =========================================================================================
+    // C. the observation rows that changed
+    const double w30 = rl_d(sc, S_W3), w31 = rl_d(sc, S_W3 + 1), w32 = rl_d(sc, S_W3 + 2);
+    const bool merged_a = Pk >= 0 && op != 0 && Pk == a - 1;
+    if (isT && jv == ja && opv >= op) {                                         // feature rows a .. end of job (env:2245-2277)
+        const bool isa = v == a;
+        OBS f[12];
+        f[0] = (OBS)my_ste; f[1] = (OBS)my_fte; f[2] = (OBS)pte;
+        f[3] = (OBS)(isa ? 1.0 : 0.0);
+        f[4] = (OBS)(isa ? (1 + ((Pk >= 0 && !merged_a) ? 1 : 0)) : 1);
+        f[5] = (OBS)(isa ? m + 1 : 0);
+        f[6] = (OBS)(isa ? d : 0.0);
+        f[7] = (OBS)(isa ? pk : 0.0);
+        f[8] = (OBS)(ja + 1);
+        f[9] = (OBS)w30; f[10] = (OBS)w31; f[11] = (OBS)w32;
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + v) * 12);
+        const uint4 *src = reinterpret_cast<const uint4 *>(f);
+        for (int i = 0; i < (int)(12 * sizeof(OBS) / 16); i++) dst[i] = src[i];
+    }
+    {   // in-edge (ELL) rows of a, its job successor, its new route successor, and the node whose merged edge reverts:
+        // lanes 0..3 take one row each and gather what they need with shuffles (every lane executes the shuffles: their
+        // source lanes must be active), so the edge arithmetic runs once instead of four times with scalar reads
+        const int merged_now = merged_a ? a : -1;
+        const int vv0 = lane == 0 ? a : lane == 1 ? ((op + 1 < M) ? a + 1 : -1) : lane == 2 ? Nk : lane == 3 ? lastm : -1;
+        const bool act = vv0 >= 0;
+        const int vv = act ? vv0 : 0;
+        const int mv = __shfl(mach, vv), pr = __shfl(prev, vv);
+        const double st_v = __shfl(st, vv);
+        const int jvv = DIVM(vv), opvv = vv - jvv * M;
+        const int u = vv > 0 ? vv - 1 : 0;
+        const int mu = __shfl(mach, u);
+        const double dur_u = __shfl(dur, u), ft_u = __shfl(ft, u);
+        const int pri = pr >= 0 ? pr : 0;
+        const int mpr = __shfl(mach, pri);
+        const double dur_p = __shfl(dur, pri), ft_p = __shfl(ft, pri);
+        const double tt_uv = __shfl(ttv, (mu >= 0 ? mu : 0) * M + (mv >= 0 ? mv : 0));
+        const double tt_pv = __shfl(ttv, (mpr >= 0 ? mpr : 0) * M + (mv >= 0 ? mv : 0));
+        const bool s = mv >= 0;
+        const bool merged = pr >= 0 && opvv != 0 && pr == vv - 1;
+        int c_job = -1, c_mch = -1;
+        float a_job = 0.f, a_mch = 0.f;
+        if (opvv != 0) {
+            double w, nd;
+            if (mu < 0) { w = 1.0; nd = 1.0; }
+            else {
+                nd = dur_u;
+                if (merged && vv == merged_now) w = nd + tt_uv + (st_v - ft_u);                                             // env:1607-1675,1703-1765
+                else w = nd + (s ? tt_uv : 0.0);                                                                           // env:1384-1422
+            }
+            long A = trunc_l(w);
+            if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }                                   // env:2019, 2060-2062
+        }
+        if (pr >= 0 && !merged) {
+            const double x = (DIVM(pri) == jvv) ? tt_pv : 0.0;
+            const double w = dur_p + x + (st_v - ft_p);
+            long A = trunc_l(w);
+            if (A != 0) { A = trunc_l((double)A - dur_p) + 1; c_mch = pr; a_mch = (float)A; }
+        }
+        if (act) {
+            reinterpret_cast<int2 *>(P.obs.ell_col)[bT + vv] = make_int2(c_job, c_mch);
+            reinterpret_cast<float2 *>(P.obs.ell_val)[bT + vv] = make_float2(a_job, a_mch);
+            if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + vv) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
+        }
+        if (lane == 6) P.lastm[b] = merged_now;
+    }
+    // ---- candidate of the acting job (ppo:202-316; the mask is the scalar part's) and the state that changed
+    if (lane == ja) {
+        P.obs.candidate[(size_t)b * J + ja] = ja * M + (cnt_ < M ? cnt_ : M - 1);
+        P.jcnt[(size_t)b * J + ja] = (short)cnt_; P.jmax[(size_t)b * J + ja] = jmax_; P.jrow[(size_t)b * J + ja] = jrow_;
+    }
+    if (isT) {
+        Link l; l.mach = (short)mach; l.prev = (short)prev; l.pos = (short)pos; l.pad = (short)next;
+        P.link[bT + v] = l;
+        if (v == a) { P.st[bT + a] = st; P.ft[bT + a] = ft; P.dur[bT + a] = dur; P.psel[bT + a] = pk; P.pte[bT + a] = pte; }
+    }
+    if (lane == m) { MRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+#undef DIVM
+}
+
+// the per-instance scalar part for the 16 instances of the group: lane = (instance g = lane >> 2, reward channel ch = lane & 3)
+template <typename OBS, int EG>
+__device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, const int lane, const double (*s_sorted)[64], const double (*s_jmx)[64],
+                                             const double (*s_jrw)[64], const int (*s_cn)[64], const double (*s_scl)[SCAL_N], const double (*s_mf)[8],
+                                             const double (*s_un)[16], const int (*s_in)[8])
+{
+    const int g = lane >> 2, ch = lane & 3;
+    const int b = b0 + g;
+    if (g >= EG || b >= P.B) return;
+    const int J = P.J, M = P.M, T = P.T;
+    const double *sc = s_scl[g];
+    const int status = s_in[g][I_STATUS];
+    if (!s_in[g][I_VALID]) {                                                    // rejected action: nothing changed; observations persist
+        const bool all_done = sc[S_NSCHED] == (double)T;
+        P.obs.info[(size_t)b * 6 + ch] = (ch == 1 && all_done) ? 1.0 : 0.0;
+        if (ch < 2) P.obs.info[(size_t)b * 6 + 4 + ch] = 0.0;
+        if (P.obs.raw) { P.obs.raw[(size_t)b * 5 + ch] = 0.0; if (ch == 0) P.obs.raw[(size_t)b * 5 + 4] = 0.0; }
+        if (P.rec_r4) P.rec_r4[(size_t)ch * P.B + b] = 0.f;
+        if (P.rec_done && ch == 0) P.rec_done[b] = all_done ? 1.f : 0.f;
+        if (ch == 1) P.obs.status[b] = status;
+        return;
+    }
+    const int nsched = s_in[g][I_NSCHED], m = s_in[g][I_M];
+    // (loops in chunks whose LDS reads go out together: this wave runs alone, a read per dependent step would be all latency;
+    // indices past the end are clamped — max / min are idempotent — or hit zero-filled slots)
+    double mk = s_jmx[g][0];                                                    // env:894 np.amax
+    for (int j0 = 0; j0 < J; j0 += 4) {
+        double x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = s_jmx[g][j0 + k < J ? j0 + k : J - 1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) mk = fmax(mk, x[k]);
+    }
+    double e1 = s_un[g][U_R0];                                                  // env:896 np.sum: pairwise part, then the ragged tail in order
+    {
+        const int nt = T < 8 ? T : (T & 7);
+        double x[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) x[i] = s_un[g][U_TAIL + i];
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (i < nt) e1 += x[i];
+    }
+    e1 = 0.0 + e1;
+    double idle = 0.0;                                                          // dg:144-170, strictly left to right (slots >= nsched hold +0.0)
+    for (int i0 = 0; i0 < T; i0 += 8) {
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = s_sorted[g][i0 + k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) idle = idle + x[k];
+    }
+    const double new_tr = s_un[g][U_NEWTR], d = s_un[g][U_D], pk = s_un[g][U_PK];
+    const double trans_this = sc[S_TR_THIS] + new_tr;
+    const double mk_prev = sc[S_MK_PREV], e1_prev = sc[S_E1_PREV], tr_prev = sc[S_TR_PREV], id_prev = sc[S_ID_PREV];
+    const double r_t = 1.0 * mk_prev - mk;                                      // env:1066
+    double r_pt = 1.0 * e1_prev - e1;
+    r_pt = r_pt / (double)T;                                                    // env:1073-1076
+    const double r_tt = 1.0 * tr_prev - trans_this;                             // env:1083
+    const double r_idle = 1.0 * id_prev - idle;                                 // env:1088
+    const double tot_n = P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1;                  // env:1164
+    const double tot = P.divisor == 1.0 ? tot_n : tot_n / P.divisor;            // x / 1.0 == x exactly
+    const bool done = nsched == T;                                              // env:797-800
+    double *s = P.scal + (size_t)b * SCAL_N;
+    {   // reward scaling of channel ch (pt:54-124)
+        const double n = sc[S_N] + 1.0;
+        const double x = ch == 0 ? r_t : ch == 1 ? r_idle : ch == 2 ? r_pt : r_tt;
+        const double sR0 = sc[S_R + ch], sM0 = sc[S_MEAN + ch];
+        const double R = P.gamma * sR0 + x;
+        double mean, S = sc[S_S + ch], sd;
+        if (n == 1.0) { mean = R; sd = fabs(R); }
+        else { mean = sM0 + (R - sM0) / n; S = S + (R - sM0) * (R - mean); sd = sqrt(S / n); }
+        const double scaled = x / (sd + 1e-8);
+        s[S_R + ch] = R; s[S_MEAN + ch] = mean; s[S_S + ch] = S; s[S_STD + ch] = sd;
+        P.obs.info[(size_t)b * 6 + 2 + ch] = scaled;
+        if (P.rec_r4) P.rec_r4[(size_t)ch * P.B + b] = (float)scaled;
+        if (ch == 0) {
+            s[S_N] = n; s[S_NSCHED] = (double)nsched;
+            s[S_MK_PREV] = mk; s[S_E1_PREV] = e1; s[S_TR_PREV] = trans_this; s[S_ID_PREV] = idle;    // env:932-936
+            s[S_TR_THIS] = done ? 0.0 : trans_this;                              // env:950-960
+            P.obs.info[(size_t)b * 6 + 0] = tot;
+            P.obs.info[(size_t)b * 6 + 1] = done ? 1.0 : 0.0;
+            if (P.rec_done) P.rec_done[b] = done ? 1.f : 0.f;
+        }
+        if (P.obs.raw) {
+            P.obs.raw[(size_t)b * 5 + 1 + ch] = x;                            // raw: total, makespan, idle, energy, transport
+            if (ch == 0) P.obs.raw[(size_t)b * 5] = tot;
+        }
+        if (ch == 1) P.obs.status[b] = status;
+    }
+    {   // machine features of the acting machine (env:2315-2340): columns 0..3 on the four lanes, column 4 with lane 0
+        double mfr = s_mf[g][ch];
+        if (ch == 0) mfr = s_un[g][U_FTTAIL];
+        else if (ch == 1) mfr += (pk * d) / (double)T;
+        else if (ch == 2) mfr += new_tr;
+        else mfr += idle - id_prev;
+        const size_t o = ((size_t)b * M + m) * 8;
+        P.mfea[o + ch] = mfr;
+        reinterpret_cast<OBS *>(P.obs.m_fea2)[o + ch] = (OBS)mfr;
+        if (ch == 0) {
+            const double c4 = s_mf[g][4] + 1;
+            P.mfea[o + 4] = c4;
+            reinterpret_cast<OBS *>(P.obs.m_fea2)[o + 4] = (OBS)c4;
+        }
+    }
+    {   // job mask (ppo:202-316)
+        int cmin = M;
+        double mn = INFINITY;                                                   // min row maximum over the unfinished jobs
+        for (int j0 = 0; j0 < J; j0 += 4) {
+            int c[4]; double r[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int j = j0 + k < J ? j0 + k : J - 1; c[k] = s_cn[g][j]; r[k] = s_jrw[g][j]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { cmin = c[k] < cmin ? c[k] : cmin; mn = fmin(mn, c[k] != M ? r[k] : INFINITY); }
+        }
+        for (int j = ch; j < J; j += 4) {
+            const int cnt_ = s_cn[g][j];
+            unsigned char mk_;
+            if (cmin == 0) mk_ = cnt_ >= 1;
+            else if (cmin == M) mk_ = 1;
+            else mk_ = !((cnt_ == M ? INFINITY : s_jrw[g][j]) == mn);
+            P.obs.job_mask[(size_t)b * J + j] = mk_;
+        }
+    }
+}
+
+template <typename OBS, int EG>
+__device__ __forceinline__ void env_grp_body(const EnvParams &P)
+{
+    __shared__ double s_sorted[EG][64];        // idle terms in (machine, route position) rank order
+    __shared__ double s_jmx[EG][64], s_jrw[EG][64];
+    __shared__ int s_cn[EG][64];
+    __shared__ double s_scl[EG][SCAL_N];
+    __shared__ double s_mf[EG][8];
+    __shared__ double s_un[EG][16];
+    __shared__ int s_in[EG][8];
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b0 = blockIdx.x * EG;
+    const int lane = threadIdx.x & 63;
+    if (b0 + grp < P.B) env_grp_wave<OBS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp]);
+    __syncthreads();
+    if (grp == 0) env_grp_tail<OBS, EG>(P, b0, lane, s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in);
+}
+template <typename OBS>
+__global__ __launch_bounds__(EG_SMALL * WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_grp16(EnvParams P) { env_grp_body<OBS, EG_SMALL>(P); }
+template <typename OBS>
+__global__ __launch_bounds__(EG_LARGE * WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_env_grp4(EnvParams P) { env_grp_body<OBS, EG_LARGE>(P); }

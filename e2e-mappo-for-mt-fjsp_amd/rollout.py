@@ -117,8 +117,13 @@ class Rollout:
 
     def env_kernel_name(self):
         """which step kernel mtfjsp_step dispatches to for this shape (csrc/mtfjsp_env.hip launch selection)"""
-        small = self.T <= 64 and self.M * self.M <= 64 and self.J <= 64 and not os.environ.get("MTFJSP_ENV_LDS")
-        return "k_env_reg" if small else "k_env_step"
+        force = os.environ.get("MTFJSP_ENV_KERNEL", "")
+        small = self.T <= 64 and self.M * self.M <= 64 and self.J <= 64 and not os.environ.get("MTFJSP_ENV_LDS") and force != "lds"
+        if not small:
+            return "k_env_step"
+        if force == "reg1":
+            return "k_env_reg"
+        return "k_env_grp16" if (force == "grp16" or (force != "grp4" and self.B <= 8192)) else "k_env_grp4"
 
     def _refill_w3(self):
         self.w3_pool.copy_(torch.as_tensor(np.stack([random_weights(self.B, rng=self._w3_rng) for _ in range(self._w3_pool_n)])))

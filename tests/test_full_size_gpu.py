@@ -109,6 +109,14 @@ def test_j6m6e2_4096_all_instances_vs_oracle():
     _run(6, 6, 2, 4096, 1, seed=0, host_generator=True)
 
 
+@pytest.mark.parametrize("kernel", ["grp16", "grp4", "reg1", "lds"])
+def test_j6m6e2_every_step_kernel_vs_oracle(kernel, monkeypatch):
+    """the four step kernels that can serve this shape (grouped register kernel with 16 / 4 instances per workgroup, one
+    instance per workgroup, LDS kernel) against the oracle; 1000 instances: a last, partly filled group included"""
+    monkeypatch.setenv("MTFJSP_ENV_KERNEL", kernel)
+    _run(6, 6, 2, 1000, 1, seed=3)
+
+
 def test_j10m10e2_8192_all_instances_vs_oracle():
     _run(10, 10, 2, 8192, 2, seed=1)
 
