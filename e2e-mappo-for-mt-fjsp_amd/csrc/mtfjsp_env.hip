@@ -1555,6 +1555,14 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
         (void)hipMemcpy(hst.data(), d_st, (size_t)P.B * 64, hipMemcpyDeviceToHost);
         double m[8] = {0};
         for (int w = 0; w < P.B; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[(size_t)w * 8 + i] / P.B;
+        if (hst[1] > 1000000000ull) {                                       // grouped kernel: s_memrealtime stamps (100 MHz) of wave 0 per workgroup
+            const int ng = (P.B + 15) / 16; double r[8] = {0};
+            unsigned long long t0 = ~0ull;
+            for (int w = 0; w < ng; w++) t0 = hst[(size_t)w * 8] < t0 ? hst[(size_t)w * 8] : t0;
+            for (int w = 0; w < ng; w++) for (int i = 0; i < 8; i++) r[i] += (double)(hst[(size_t)w * 8 + i] - t0) / 100.0 / ng;
+            printf("STAMP k_env_grp16 B=%d (us since the first workgroup's start, wave 0): entry %.2f  first-hop data %.2f  decision %.2f  per-task costs done %.2f  wave done %.2f  barrier %.2f  tail issued %.2f  stores drained %.2f\n",
+                   P.B, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        } else
         printf("STAMP k_env B=%d: load %.0f  schedule %.0f  estimate+terms %.0f  lane0-costs %.0f  scaler+info %.0f  observation %.0f  mask %.0f+writeback-issue  drain %.0f  (cycles/wave)\n",
                P.B, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
     }

@@ -25,8 +25,13 @@ enum { I_VALID = 0, I_STATUS, I_NSCHED, I_M, I_JA };            // s_in slots
 
 template <typename OBS>
 __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, const int lane, double *s_sorted, double *s_jmx, double *s_jrw,
-                                             int *s_cn, double *s_scl, double *s_mf, double *s_un, int *s_in)
+                                             int *s_cn, double *s_scl, double *s_mf, double *s_un, int *s_in, unsigned long long *rt)
 {
+#ifdef MTFJSP_STAMP
+#define RT(i) do { __builtin_amdgcn_sched_barrier(0); rt[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RT(i) do { } while (0)
+#endif
     const int J = P.J, M = P.M, T = P.T;
     const unsigned invM = P.inv_M;
 #define DIVM(x) ((int)__umulhi((unsigned)(x), invM))
@@ -71,6 +76,7 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     }
     const int len = rl_i(len_, m), head = rl_i(head_, m), tail = rl_i(tail_, m);
     const double ttmm = rl_d(ttv, m * M + m);
+    RT(1);
     if (valid) {
         if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;                            // pe:246-248
         const double arr_k = op == 0 ? 0.0 : rl_d(ft, a - 1) + rl_d(ttv, mach_p * M + m);   // dg:46-66
@@ -120,6 +126,7 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
         return;
     }
     const double ft_k = st_k + d;
+    RT(2);
     // ---- apply: register updates on the owning lanes
     if (isT && mach == m && pos >= ipos) pos += 1;
     if (v == a) { mach = m; prev = Pk; next = Nk; pos = ipos; st = st_k; ft = ft_k; dur = d; pte = d * pk; }    // env:356,2175
@@ -195,6 +202,7 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
         if (lane < 8) s_mf[lane] = mfr;
     }
 
+    RT(3);
     // =========================================================================================
     // C. the observation rows that changed
     const double w30 = rl_d(sc, S_W3), w31 = rl_d(sc, S_W3 + 1), w32 = rl_d(sc, S_W3 + 2);
@@ -271,7 +279,9 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
         if (v == a) { P.st[bT + a] = st; P.ft[bT + a] = ft; P.dur[bT + a] = dur; P.psel[bT + a] = pk; P.pte[bT + a] = pte; }
     }
     if (lane == m) { MRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+    RT(4);
 #undef DIVM
+#undef RT
 }
 
 // the per-instance scalar part for the 16 instances of the group: lane = (instance g = lane >> 2, reward channel ch = lane & 3)
@@ -412,9 +422,25 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b0 = blockIdx.x * EG;
     const int lane = threadIdx.x & 63;
-    if (b0 + grp < P.B) env_grp_wave<OBS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp]);
+    unsigned long long rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef MTFJSP_STAMP
+    rt[0] = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (b0 + grp < P.B) env_grp_wave<OBS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp], rt);
     __syncthreads();
+#ifdef MTFJSP_STAMP
+    rt[5] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (grp == 0) env_grp_tail<OBS, EG>(P, b0, lane, s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in);
+#ifdef MTFJSP_STAMP
+    if (grp == 0) {
+        rt[6] = __builtin_amdgcn_s_memrealtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        rt[7] = __builtin_amdgcn_s_memrealtime();
+        if (P.stamps && lane == 0) for (int i = 0; i < 8; i++) P.stamps[(size_t)blockIdx.x * 8 + i] = rt[i];
+    }
+#endif
+    (void)rt;
 }
 template <typename OBS>
 __global__ __launch_bounds__(EG_SMALL * WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_grp16(EnvParams P) { env_grp_body<OBS, EG_SMALL>(P); }
