@@ -953,6 +953,327 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
 
 #include "mtfjsp_env_grp.h"
 
+// k_env_step_grp — k_env_step for GROUPS of instances per workgroup (one wave each, its own LDS region): the per-task part
+// of the step per wave, then — after one barrier — the per-instance scalar part (energy / idle sums, rewards, RewardScaling,
+// machine feature row, job mask) once for the whole group on wave 0 with lane = (instance, reward channel)
+// (env_grp_tail, mtfjsp_env_grp.h).  Same operations in the same order: bit-identical to k_env_step.
+struct EnvStepLds {                            // layout of one instance's LDS region (bytes from its start)
+    int T, Tp, M, J;
+    size_t o_stage, o_int, o_un, o_in, bytes;
+    __host__ __device__ EnvStepLds(int J_, int M_, int T_, bool f32) : T(T_), Tp((T_ + 7) & ~7), M(M_), J(J_)
+    {
+        size_t off = (size_t)(4 * T + Tp + M * M + 3 * M + 2 * J + SCAL_N + 8) * sizeof(double);
+        off = (off + 15) & ~(size_t)15;
+        o_stage = off; off += (size_t)M * 12 * (f32 ? 4 : 8);
+        off = (off + 15) & ~(size_t)15;
+        o_int = off; off += (size_t)(3 * T + J + 4 * M + 1 + 4) * sizeof(int);
+        off = (off + 15) & ~(size_t)15;
+        o_un = off; off += 16 * sizeof(double);
+        o_in = off; off += 8 * sizeof(int);
+        bytes = (off + 15) & ~(size_t)15;
+    }
+};
+struct EnvGrpLdsAcc {
+    static constexpr bool kBigT = true;
+    const unsigned char *base; EnvStepLds L;
+    __device__ __forceinline__ const double *d(int g, int off) const { return reinterpret_cast<const double *>(base + (size_t)g * L.bytes) + off; }
+    __device__ __forceinline__ const double *pte(int g) const { return d(g, 3 * L.T); }
+    __device__ __forceinline__ const double *sorted(int g) const { return d(g, 4 * L.T); }
+    __device__ __forceinline__ const double *jmx(int g) const { return d(g, 4 * L.T + L.Tp + L.M * L.M + 3 * L.M); }
+    __device__ __forceinline__ const double *jrw(int g) const { return jmx(g) + L.J; }
+    __device__ __forceinline__ const double *scl(int g) const { return jrw(g) + L.J; }
+    __device__ __forceinline__ const double *mf(int g) const { return scl(g) + SCAL_N; }
+    __device__ __forceinline__ const int *cn(int g) const { return reinterpret_cast<const int *>(base + (size_t)g * L.bytes + L.o_int) + 3 * L.T; }
+    __device__ __forceinline__ const double *un(int g) const { return reinterpret_cast<const double *>(base + (size_t)g * L.bytes + L.o_un); }
+    __device__ __forceinline__ const int *in(int g) const { return reinterpret_cast<const int *>(base + (size_t)g * L.bytes + L.o_in); }
+};
+template <typename OBS>
+__device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, const int lane, unsigned char *smem, const EnvStepLds &LL)
+{
+    const int J = P.J, M = P.M, T = P.T;
+    const unsigned invM = P.inv_M;
+#define DIVM(x) ((int)__umulhi((unsigned)(x), invM))
+    const int Tp = (T + 7) & ~7;
+    double *s_st = reinterpret_cast<double *>(smem);
+    double *s_ft = s_st + T;
+    double *s_dur = s_ft + T;
+    double *s_pte = s_dur + T;
+    double *s_term = s_pte + T;                // Tp
+    double *s_tt = s_term + Tp;                // M*M
+    double *s_mind = s_tt + M * M;             // M: min_dur of the acting job's ops
+    double *s_jste = s_mind + M;               // M: estimated start of the acting job's ops
+    double *s_jfte = s_jste + M;               // M
+    double *s_jmax = s_jfte + M;               // J: max estimated finish per job
+    double *s_jrow = s_jmax + J;               // J: max real finish of scheduled ops per job
+    double *s_sc = s_jrow + J;                 // SCAL_N
+    double *s_mfr = s_sc + SCAL_N;             // 8: m_fea2 row of machine m
+    size_t off = (size_t)((4 * T + Tp + M * M + 3 * M + 2 * J + SCAL_N + 8) * sizeof(double));
+    off = (off + 15) & ~(size_t)15;
+    OBS *s_stage = reinterpret_cast<OBS *>(smem + off);        // M rows x 12
+    off += (size_t)M * 12 * sizeof(OBS);
+    off = (off + 15) & ~(size_t)15;
+    int *s_mach = reinterpret_cast<int *>(smem + off);
+    int *s_prev = s_mach + T;
+    int *s_pos = s_prev + T;
+    int *s_cnt = s_pos + T;                    // J
+    int *s_head = s_cnt + J;                   // M
+    int *s_tail = s_head + M;
+    int *s_len = s_tail + M;
+    int *s_mstart = s_len + M;                 // M+1
+    double *s_un = reinterpret_cast<double *>(smem + LL.o_un);
+    int *s_in = reinterpret_cast<int *>(smem + LL.o_in);
+
+    const size_t bT = (size_t)b * T;
+    // ---- bulk state first (independent of the action), the action-dependent second hop right behind it
+    for (int v = lane; v < T; v += WAVE) {
+        s_st[v] = P.st[bT + v]; s_ft[v] = P.ft[bT + v]; s_dur[v] = P.dur[bT + v]; s_pte[v] = P.pte[bT + v];
+        const Link l = P.link[bT + v];
+        s_mach[v] = l.mach; s_prev[v] = l.prev; s_pos[v] = l.pos;
+    }
+    for (int i = lane; i < Tp; i += WAVE) s_term[i] = 0.0;
+    for (int i = lane; i < M * M; i += WAVE) s_tt[i] = P.tt[(size_t)b * M * M + i];
+    for (int i = lane; i < M; i += WAVE) { const MRec r = P.mrec[(size_t)b * M + i]; s_head[i] = r.head; s_tail[i] = r.tail; s_len[i] = r.len; }
+    for (int i = lane; i < J; i += WAVE) { s_cnt[i] = (int)P.jcnt[(size_t)b * J + i]; s_jmax[i] = P.jmax[(size_t)b * J + i]; s_jrow[i] = P.jrow[(size_t)b * J + i]; }
+    if (lane < SCAL_N) s_sc[lane] = P.scal[(size_t)b * SCAL_N + lane];
+    const int lastm = P.lastm[b];
+    int a = P.task_idx[b], m = P.mach_idx[b];
+    bool valid = a >= 0 && a < T && m >= 0 && m < M;
+    if (!valid) { a = 0; m = 0; }
+    const int ja = DIVM(a), op = a - ja * M;
+    const double d = P.t[(bT + a) * M + m];
+    const double pk = P.p[(bT + a) * M + m];
+    for (int i = lane; i < M; i += WAVE) s_mind[i] = P.cst[bT + ja * M + i].x;
+    if (lane < 8) s_mfr[lane] = P.mfea[((size_t)b * M + m) * 8 + lane];
+    WSYNC();
+
+    // =========================================================================================
+    // A. scheduling (env:1476-1685)
+    int status = 0, path = 0;
+    int Pk = -1, Nk = -1, ipos = 0;
+    double st_k = 0.0, ft_k = 0.0;
+    if (valid) {
+        if (s_mach[a] >= 0) valid = false;                         // already scheduled (env:1504)
+        else if (op != 0 && s_mach[a - 1] < 0) valid = false;      // job predecessor unscheduled (env:1520)
+    }
+    if (valid) {
+        if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;               // pe:246-248
+        const double ttmm = s_tt[m * M + m];
+        const double arr_k = op == 0 ? 0.0 : s_ft[a - 1] + s_tt[s_mach[a - 1] * M + m];      // dg:46-66 over the single in-edge
+        const int len = s_len[m], head = s_head[m], tail = s_tail[m];
+        bool do_append = false;
+        if (len == 0) { path = MTFJSP_PATH_EMPTY; st_k = arr_k; ipos = 0; }                      // env:1684
+        else if (!P.left_shift) do_append = true;                                                     // env:1680
+        else {
+            const double lb_ft = arr_k + d;
+            const int jh = DIVM(head);
+            const double arr_f = (head == jh * M) ? 0.0 : s_ft[head - 1] + s_tt[s_mach[head - 1] * M + m];
+            if (lb_ft <= arr_f) { path = MTFJSP_PATH_FRONT; st_k = arr_k; ipos = 0; Nk = head; }   // env:1548
+            else if (len == 1) do_append = true;                                                     // env:1577
+            else {
+                int key = 0x7fffffff;                               // gap search over all consecutive (P,N) at once (env:1587-1604)
+                for (int v = lane; v < T; v += WAVE) {
+                    if (s_mach[v] == m && s_prev[v] >= 0) {
+                        const int Pp = s_prev[v];
+                        const int jv = DIVM(v);
+                        const double jarr = (v == jv * M) ? 0.0 : s_ft[v - 1] + s_tt[s_mach[v - 1] * M + m];
+                        const double x = (DIVM(Pp) == jv) ? ttmm : 0.0;
+                        const double nst = fmax(jarr, s_ft[Pp] + x);
+                        const bool ok = !(lb_ft > nst) && !((nst - s_ft[Pp]) < d);
+                        if (ok) { const int kk = (s_pos[v] << 16) | v; key = kk < key ? kk : key; }
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(key, o); key = other < key ? other : key; }
+                if (key != 0x7fffffff) {
+                    path = MTFJSP_PATH_BETWEEN;
+                    Nk = key & 0xffff; ipos = key >> 16; Pk = s_prev[Nk];
+                    const double x = (DIVM(Pk) == ja) ? ttmm : 0.0;
+                    st_k = fmax(arr_k, s_ft[Pk] + x);                          // env:1619
+                } else do_append = true;                                       // env:1676
+            }
+        }
+        if (do_append) {                                                       // env:1689-1775
+            path = MTFJSP_PATH_APPEND;
+            const double x = (DIVM(tail) == ja) ? ttmm : 0.0;
+            st_k = fmax(arr_k, s_ft[tail] + x);
+            ipos = len; Pk = tail;
+        }
+        ft_k = st_k + d;
+        WSYNC();
+        if (ipos < len)
+            for (int v = lane; v < T; v += WAVE)
+                if (s_mach[v] == m && s_pos[v] >= ipos) s_pos[v] += 1;
+        WSYNC();
+        if (lane == 0) {
+            s_mach[a] = m; s_prev[a] = Pk; s_pos[a] = ipos;
+            s_st[a] = st_k; s_ft[a] = ft_k; s_dur[a] = d; s_pte[a] = d * pk;      // env:356,2175
+            if (Nk >= 0) s_prev[Nk] = a;
+            if (ipos == 0) s_head[m] = a;
+            if (ipos == len) s_tail[m] = a;
+            s_len[m] = len + 1;
+            s_cnt[ja] += 1;
+            s_sc[S_NSCHED] += 1.0;
+        }
+        status |= path;
+        WSYNC();
+    } else status |= MTFJSP_ST_INVALID;
+    if (!valid) {                                                               // nothing changes; the scalar part reports it
+        if (lane == 0) { s_in[I_VALID] = 0; s_in[I_STATUS] = status; }
+        return;
+    }
+
+    // =========================================================================================
+    // B. costs
+    {   // machine route offsets: exclusive scan of the route lengths
+        int x = lane < M ? s_len[lane] : 0, incl = x;
+        for (int o = 1; o < WAVE; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+        if (lane < M) s_mstart[lane] = incl - x;
+        if (lane == M - 1) s_mstart[M] = incl;
+    }
+    // estimated start/finish of the acting job's ops (env:1920-1999): lanes = ops of job ja; every lane replays the
+    // reference's left-to-right add sequence from the last op with a non-zero real finish time
+    double my_fte = -INFINITY, my_rft = 0.0;
+    if (lane < M) {
+        const int c = lane, v = ja * M + c;
+        const bool s = s_mach[v] >= 0;
+        double ste, fte;
+        if (s && s_ft[v] != 0.0) { ste = s_st[v]; fte = s_ft[v]; }
+        else {
+            int k0 = c;
+            while (k0 > 0 && !(s_mach[ja * M + k0 - 1] >= 0 && s_ft[ja * M + k0 - 1] != 0.0)) k0--;
+            double acc = k0 > 0 ? s_ft[ja * M + k0 - 1] : 0.0, prev = acc;
+            for (int k = k0; k <= c; k++) { prev = acc; acc = acc + s_mind[k]; }
+            fte = acc;
+            ste = s ? s_st[v] : (c == 0 ? 0.0 : prev);
+        }
+        s_jste[c] = ste; s_jfte[c] = fte;
+        my_fte = fte;
+        my_rft = s ? s_ft[v] : 0.0;
+    }
+    {   // per-job maxima of the acting job (row maximum of ft_est for the makespan; of real ft for the job mask, ppo:265-275)
+        double fm = my_fte, rm = lane < M ? my_rft : -INFINITY;
+        for (int o = 32; o > 0; o >>= 1) { fm = fmax(fm, __shfl_xor(fm, o)); rm = fmax(rm, __shfl_xor(rm, o)); }
+        if (lane == 0) { s_jmax[ja] = fm; s_jrow[ja] = rm; }
+    }
+    WSYNC();
+    for (int v = lane; v < T; v += WAVE)                                       // idle-time terms in (machine, position) order (dg:144-170)
+        if (s_mach[v] >= 0) {
+            const int pr = s_prev[v];
+            s_term[s_mstart[s_mach[v]] + s_pos[v]] = pr < 0 ? s_st[v] : s_st[v] - s_ft[pr];
+        }
+    WSYNC();
+    {   // what the scalar part needs beyond the arrays: env:896 np.sum's pairwise part (one leaf block: T <= 128) and the uniforms
+        if (T <= 128) {
+            const int nb = T < 8 ? 0 : T - (T & 7);
+            double r = 0.0;
+            if (nb) {
+                if (lane < 8) { r = s_pte[lane]; for (int i = 8 + lane; i < nb; i += 8) r += s_pte[i]; }
+                r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
+            }
+            if (lane == 0) s_un[U_R0] = r;
+            if (lane < T - nb) s_un[U_TAIL + lane] = s_pte[nb + lane];
+        }
+        if (lane == 0) {
+            s_un[U_NEWTR] = (op == 0) ? 0.0 : s_tt[s_mach[a - 1] * M + m];      // env:872-876
+            s_un[U_D] = d; s_un[U_PK] = pk; s_un[U_FTTAIL] = s_ft[s_tail[m]];  // env:2315-2340
+            s_in[I_VALID] = 1; s_in[I_STATUS] = status; s_in[I_NSCHED] = s_mstart[M]; s_in[I_M] = m; s_in[I_JA] = ja;
+        }
+    }
+
+    // =========================================================================================
+    // C. the observation rows that changed
+    {   // feature rows a .. end of job (env:2245-2277)
+        const int nrow = M - op;
+        if (lane < nrow) {
+            const int c = op + lane, v = a + lane;
+            const int pr = s_prev[a];
+            const bool merged0 = pr >= 0 && op != 0 && pr == a - 1;
+            OBS *f = s_stage + lane * 12;
+            f[0] = (OBS)s_jste[c]; f[1] = (OBS)s_jfte[c]; f[2] = (OBS)s_pte[v];
+            const bool isa = lane == 0;
+            f[3] = (OBS)(isa ? 1.0 : 0.0);
+            f[4] = (OBS)(isa ? (1 + ((pr >= 0 && !merged0) ? 1 : 0)) : 1);    // len(G.in_edges)
+            f[5] = (OBS)(isa ? m + 1 : 0);
+            f[6] = (OBS)(isa ? d : 0.0);
+            f[7] = (OBS)(isa ? pk : 0.0);
+            f[8] = (OBS)(ja + 1);
+            f[9] = (OBS)s_sc[S_W3]; f[10] = (OBS)s_sc[S_W3 + 1]; f[11] = (OBS)s_sc[S_W3 + 2];
+        }
+        WSYNC();
+        const int n16 = nrow * 12 * (int)sizeof(OBS) / 16;
+        const uint4 *src = reinterpret_cast<const uint4 *>(s_stage);
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + a) * 12);
+        for (int i = lane; i < n16; i += WAVE) dst[i] = src[i];
+    }
+    {   // in-edge (ELL) rows: a, its job successor, its new route successor, the node whose merged edge reverts
+        const int merged_now = (Pk >= 0 && op != 0 && Pk == a - 1) ? a : -1;
+        int v = -1;
+        if (lane == 0) v = a;
+        else if (lane == 1) v = (op + 1 < M) ? a + 1 : -1;
+        else if (lane == 2) v = Nk;
+        else if (lane == 3) v = lastm;
+        if (v >= 0) {
+            const int mv = s_mach[v];
+            const bool s = mv >= 0;
+            const int jv = DIVM(v), opv = v - jv * M;
+            const int pr = s_prev[v];
+            const bool merged = pr >= 0 && opv != 0 && pr == v - 1;
+            int c_job = -1, c_mch = -1;
+            float a_job = 0.f, a_mch = 0.f;
+            if (opv != 0) {
+                const int u = v - 1, mu = s_mach[u];
+                double w, nd;
+                if (mu < 0) { w = 1.0; nd = 1.0; }
+                else {
+                    nd = s_dur[u];
+                    if (merged && v == merged_now) w = s_dur[u] + s_tt[mu * M + mv] + (s_st[v] - s_ft[u]);     // env:1607-1675,1703-1765
+                    else w = s_dur[u] + (s ? s_tt[mu * M + mv] : 0.0);                                          // env:1384-1422
+                }
+                long A = trunc_l(w);
+                if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }                   // env:2019, 2060-2062
+            }
+            if (pr >= 0 && !merged) {
+                const double x = (DIVM(pr) == jv) ? s_tt[s_mach[pr] * M + mv] : 0.0;
+                const double w = s_dur[pr] + x + (s_st[v] - s_ft[pr]);
+                long A = trunc_l(w);
+                if (A != 0) { A = trunc_l((double)A - s_dur[pr]) + 1; c_mch = pr; a_mch = (float)A; }
+            }
+            reinterpret_cast<int2 *>(P.obs.ell_col)[bT + v] = make_int2(c_job, c_mch);
+            reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(a_job, a_mch);
+            if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + v) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
+        }
+        if (lane == 6) P.lastm[b] = merged_now;
+    }
+
+    // ---- candidate of the acting job (ppo:202-316; the mask is the scalar part's)
+    if (lane == 0) P.obs.candidate[(size_t)b * J + ja] = ja * M + (s_cnt[ja] < M ? s_cnt[ja] : M - 1);
+    // ---- write back the state that changed
+    for (int v = lane; v < T; v += WAVE) {
+        Link l; l.mach = (short)s_mach[v]; l.prev = (short)s_prev[v]; l.pos = (short)s_pos[v]; l.pad = 0;
+        P.link[bT + v] = l;
+    }
+    if (lane == 0) { P.st[bT + a] = st_k; P.ft[bT + a] = ft_k; P.dur[bT + a] = d; P.psel[bT + a] = pk; P.pte[bT + a] = d * pk; }
+    if (lane == 1) { P.jcnt[(size_t)b * J + ja] = (short)s_cnt[ja]; P.jmax[(size_t)b * J + ja] = s_jmax[ja]; P.jrow[(size_t)b * J + ja] = s_jrow[ja]; }
+    if (lane == 2) { MRec r; r.head = (short)s_head[m]; r.tail = (short)s_tail[m]; r.len = (short)s_len[m]; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+#undef DIVM
+}
+template <typename OBS>
+__global__ __launch_bounds__(1024) void k_env_step_grp(EnvParams P, int G)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const EnvStepLds LL(P.J, P.M, P.T, sizeof(OBS) == 4);
+    const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b0 = blockIdx.x * G;
+    const int lane = threadIdx.x & 63;
+    if (b0 + grp < P.B) env_step_wave<OBS>(P, b0 + grp, lane, smem + (size_t)grp * LL.bytes, LL);
+    __syncthreads();
+    if (grp == 0) {
+        const EnvGrpLdsAcc acc{smem, LL};
+        env_grp_tail<OBS>(P, b0, lane, G, acc);
+    }
+}
+
+
+
 // ---------------------------------------------------------------------------------------------
 // instance preparation: min_dur/min_pt (env:1932-1950) and the means of pe:176-183. thread = (b,task)
 __global__ void k_prepare(int B, int T, int M, const double *t, const double *p, double2 *cst, double *mean3)
@@ -1289,6 +1610,15 @@ extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
             mtfjsp_destroy(h);
             return MTFJSP_ERR_HIP;
         }
+    {   // the grouped LDS kernel takes up to a CU's worth of LDS (G instance regions)
+        const void *grp_kernels[] = {(const void *)k_env_step_grp<double>, (const void *)k_env_step_grp<float>};
+        for (const void *k : grp_kernels)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                g_create_err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+                mtfjsp_destroy(h);
+                return MTFJSP_ERR_HIP;
+            }
+    }
     *out = h;
     return MTFJSP_OK;
 }
@@ -1542,9 +1872,23 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
         if (P.obs_f32) hipLaunchKernelGGL((k_env_reg<float>), dim3(P.B), dim3(WAVE), 0, h->stream, P);
         else hipLaunchKernelGGL((k_env_reg<double>), dim3(P.B), dim3(WAVE), 0, h->stream, P);
     } else {
-        const size_t lds_s = env_step_lds_bytes(P.J, P.M, P.T, P.obs_f32);
-        if (P.obs_f32) hipLaunchKernelGGL((k_env_step<float>), dim3(P.B), dim3(WAVE), lds_s, h->stream, P);
-        else hipLaunchKernelGGL((k_env_step<double>), dim3(P.B), dim3(WAVE), lds_s, h->stream, P);
+        // LDS kernel: groups of G instances per workgroup where at least two instances' regions fit (MTFJSP_ENV_STEP_G overrides;
+        // 1 = the one-instance kernel k_env_step)
+        const EnvStepLds LL(P.J, P.M, P.T, P.obs_f32 != 0);
+        const int gmax = (int)((size_t)(160 * 1024 - 512) / LL.bytes);
+        int G = gmax >= 4 ? 4 : gmax >= 2 ? 2 : 1;
+        if (const char *gs = getenv("MTFJSP_ENV_STEP_G")) { G = atoi(gs); G = G < 1 ? 1 : G > 16 ? 16 : G; G = G > gmax ? (gmax < 1 ? 1 : gmax) : G; }
+        if (force && !strcmp(force, "lds1")) G = 1;
+        if (G > 1) {
+            const size_t lds_g = (size_t)G * LL.bytes;
+            const int grid = (P.B + G - 1) / G;
+            if (P.obs_f32) hipLaunchKernelGGL((k_env_step_grp<float>), dim3(grid), dim3(G * WAVE), lds_g, h->stream, P, G);
+            else hipLaunchKernelGGL((k_env_step_grp<double>), dim3(grid), dim3(G * WAVE), lds_g, h->stream, P, G);
+        } else {
+            const size_t lds_s = env_step_lds_bytes(P.J, P.M, P.T, P.obs_f32);
+            if (P.obs_f32) hipLaunchKernelGGL((k_env_step<float>), dim3(P.B), dim3(WAVE), lds_s, h->stream, P);
+            else hipLaunchKernelGGL((k_env_step<double>), dim3(P.B), dim3(WAVE), lds_s, h->stream, P);
+        }
     }
     if (ev) HIPCHK(h, hipEventRecord(ev->second, h->stream));
 #ifdef MTFJSP_STAMP

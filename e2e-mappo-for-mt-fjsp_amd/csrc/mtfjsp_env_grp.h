@@ -284,19 +284,33 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
 #undef RT
 }
 
-// the per-instance scalar part for the 16 instances of the group: lane = (instance g = lane >> 2, reward channel ch = lane & 3)
-template <typename OBS, int EG>
-__device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, const int lane, const double (*s_sorted)[64], const double (*s_jmx)[64],
-                                             const double (*s_jrw)[64], const int (*s_cn)[64], const double (*s_scl)[SCAL_N], const double (*s_mf)[8],
-                                             const double (*s_un)[16], const int (*s_in)[8])
+// where the per-instance inputs of the scalar part live: k_env_grp* keeps them in fixed-size arrays, k_env_step_grp in the
+// instance's own LDS region
+struct EnvGrpRegAcc {
+    static constexpr bool kBigT = false;                         // T <= 64: the pairwise energy sum is one leaf block
+    const double (*s_sorted)[64], (*s_jmx)[64], (*s_jrw)[64]; const int (*s_cn)[64];
+    const double (*s_scl)[SCAL_N], (*s_mf)[8], (*s_un)[16]; const int (*s_in)[8];
+    __device__ __forceinline__ const double *sorted(int g) const { return s_sorted[g]; }
+    __device__ __forceinline__ const double *jmx(int g) const { return s_jmx[g]; }
+    __device__ __forceinline__ const double *jrw(int g) const { return s_jrw[g]; }
+    __device__ __forceinline__ const int *cn(int g) const { return s_cn[g]; }
+    __device__ __forceinline__ const double *scl(int g) const { return s_scl[g]; }
+    __device__ __forceinline__ const double *mf(int g) const { return s_mf[g]; }
+    __device__ __forceinline__ const double *un(int g) const { return s_un[g]; }
+    __device__ __forceinline__ const int *in(int g) const { return s_in[g]; }
+    __device__ __forceinline__ const double *pte(int) const { return nullptr; }
+};
+// the per-instance scalar part for the instances of the group: lane = (instance g = lane >> 2, reward channel ch = lane & 3)
+template <typename OBS, typename ACC>
+__device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A)
 {
     const int g = lane >> 2, ch = lane & 3;
     const int b = b0 + g;
     if (g >= EG || b >= P.B) return;
     const int J = P.J, M = P.M, T = P.T;
-    const double *sc = s_scl[g];
-    const int status = s_in[g][I_STATUS];
-    if (!s_in[g][I_VALID]) {                                                    // rejected action: nothing changed; observations persist
+    const double *sc = A.scl(g);
+    const int status = A.in(g)[I_STATUS];
+    if (!A.in(g)[I_VALID]) {                                                    // rejected action: nothing changed; observations persist
         const bool all_done = sc[S_NSCHED] == (double)T;
         P.obs.info[(size_t)b * 6 + ch] = (ch == 1 && all_done) ? 1.0 : 0.0;
         if (ch < 2) P.obs.info[(size_t)b * 6 + 4 + ch] = 0.0;
@@ -306,23 +320,26 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
         if (ch == 1) P.obs.status[b] = status;
         return;
     }
-    const int nsched = s_in[g][I_NSCHED], m = s_in[g][I_M];
+    const int nsched = A.in(g)[I_NSCHED], m = A.in(g)[I_M];
     // (loops in chunks whose LDS reads go out together: this wave runs alone, a read per dependent step would be all latency;
     // indices past the end are clamped — max / min are idempotent — or hit zero-filled slots)
-    double mk = s_jmx[g][0];                                                    // env:894 np.amax
+    double mk = A.jmx(g)[0];                                                    // env:894 np.amax
     for (int j0 = 0; j0 < J; j0 += 4) {
         double x[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = s_jmx[g][j0 + k < J ? j0 + k : J - 1];
+        for (int k = 0; k < 4; k++) x[k] = A.jmx(g)[j0 + k < J ? j0 + k : J - 1];
 #pragma unroll
         for (int k = 0; k < 4; k++) mk = fmax(mk, x[k]);
     }
-    double e1 = s_un[g][U_R0];                                                  // env:896 np.sum: pairwise part, then the ragged tail in order
-    {
+    double e1 = A.un(g)[U_R0];                                                  // env:896 np.sum: pairwise part, then the ragged tail in order
+    bool big = false;
+    if constexpr (ACC::kBigT) big = T > 128;
+    if (big) { if constexpr (ACC::kBigT) e1 = pw_sum<6>(A.pte(g), T); }     // (more than one leaf block: numpy's recursion, on the instance's LDS array)
+    else {
         const int nt = T < 8 ? T : (T & 7);
         double x[7];
 #pragma unroll
-        for (int i = 0; i < 7; i++) x[i] = s_un[g][U_TAIL + i];
+        for (int i = 0; i < 7; i++) x[i] = A.un(g)[U_TAIL + i];
 #pragma unroll
         for (int i = 0; i < 7; i++) if (i < nt) e1 += x[i];
     }
@@ -331,11 +348,11 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
     for (int i0 = 0; i0 < T; i0 += 8) {
         double x[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = s_sorted[g][i0 + k];
+        for (int k = 0; k < 8; k++) x[k] = A.sorted(g)[i0 + k];
 #pragma unroll
         for (int k = 0; k < 8; k++) idle = idle + x[k];
     }
-    const double new_tr = s_un[g][U_NEWTR], d = s_un[g][U_D], pk = s_un[g][U_PK];
+    const double new_tr = A.un(g)[U_NEWTR], d = A.un(g)[U_D], pk = A.un(g)[U_PK];
     const double trans_this = sc[S_TR_THIS] + new_tr;
     const double mk_prev = sc[S_MK_PREV], e1_prev = sc[S_E1_PREV], tr_prev = sc[S_TR_PREV], id_prev = sc[S_ID_PREV];
     const double r_t = 1.0 * mk_prev - mk;                                      // env:1066
@@ -374,8 +391,8 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
         if (ch == 1) P.obs.status[b] = status;
     }
     {   // machine features of the acting machine (env:2315-2340): columns 0..3 on the four lanes, column 4 with lane 0
-        double mfr = s_mf[g][ch];
-        if (ch == 0) mfr = s_un[g][U_FTTAIL];
+        double mfr = A.mf(g)[ch];
+        if (ch == 0) mfr = A.un(g)[U_FTTAIL];
         else if (ch == 1) mfr += (pk * d) / (double)T;
         else if (ch == 2) mfr += new_tr;
         else mfr += idle - id_prev;
@@ -383,7 +400,7 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
         P.mfea[o + ch] = mfr;
         reinterpret_cast<OBS *>(P.obs.m_fea2)[o + ch] = (OBS)mfr;
         if (ch == 0) {
-            const double c4 = s_mf[g][4] + 1;
+            const double c4 = A.mf(g)[4] + 1;
             P.mfea[o + 4] = c4;
             reinterpret_cast<OBS *>(P.obs.m_fea2)[o + 4] = (OBS)c4;
         }
@@ -394,16 +411,16 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
         for (int j0 = 0; j0 < J; j0 += 4) {
             int c[4]; double r[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { const int j = j0 + k < J ? j0 + k : J - 1; c[k] = s_cn[g][j]; r[k] = s_jrw[g][j]; }
+            for (int k = 0; k < 4; k++) { const int j = j0 + k < J ? j0 + k : J - 1; c[k] = A.cn(g)[j]; r[k] = A.jrw(g)[j]; }
 #pragma unroll
             for (int k = 0; k < 4; k++) { cmin = c[k] < cmin ? c[k] : cmin; mn = fmin(mn, c[k] != M ? r[k] : INFINITY); }
         }
         for (int j = ch; j < J; j += 4) {
-            const int cnt_ = s_cn[g][j];
+            const int cnt_ = A.cn(g)[j];
             unsigned char mk_;
             if (cmin == 0) mk_ = cnt_ >= 1;
             else if (cmin == M) mk_ = 1;
-            else mk_ = !((cnt_ == M ? INFINITY : s_jrw[g][j]) == mn);
+            else mk_ = !((cnt_ == M ? INFINITY : A.jrw(g)[j]) == mn);
             P.obs.job_mask[(size_t)b * J + j] = mk_;
         }
     }
@@ -431,7 +448,10 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 #ifdef MTFJSP_STAMP
     rt[5] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (grp == 0) env_grp_tail<OBS, EG>(P, b0, lane, s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in);
+    if (grp == 0) {
+        const EnvGrpRegAcc acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
+        env_grp_tail<OBS>(P, b0, lane, EG, acc);
+    }
 #ifdef MTFJSP_STAMP
     if (grp == 0) {
         rt[6] = __builtin_amdgcn_s_memrealtime();

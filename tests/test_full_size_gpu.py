@@ -109,10 +109,11 @@ def test_j6m6e2_4096_all_instances_vs_oracle():
     _run(6, 6, 2, 4096, 1, seed=0, host_generator=True)
 
 
-@pytest.mark.parametrize("kernel", ["grp16", "grp4", "reg1", "lds"])
+@pytest.mark.parametrize("kernel", ["grp16", "grp4", "reg1", "lds", "lds1"])
 def test_j6m6e2_every_step_kernel_vs_oracle(kernel, monkeypatch):
-    """the four step kernels that can serve this shape (grouped register kernel with 16 / 4 instances per workgroup, one
-    instance per workgroup, LDS kernel) against the oracle; 1000 instances: a last, partly filled group included"""
+    """the five step kernels that can serve this shape (grouped register kernel with 16 / 4 instances per workgroup, one
+    instance per workgroup, LDS kernel grouped / one instance per workgroup) against the oracle; 1000 instances: a last,
+    partly filled group included"""
     monkeypatch.setenv("MTFJSP_ENV_KERNEL", kernel)
     _run(6, 6, 2, 1000, 1, seed=3)
 
@@ -123,6 +124,14 @@ def test_j10m10e2_8192_all_instances_vs_oracle():
 
 def test_j20m20e4_2048_sampled_vs_oracle():
     _run(20, 20, 4, 2048, 32, seed=2)
+
+
+@pytest.mark.parametrize("size", [(10, 10, 2, 1001), (20, 20, 4, 203)])
+def test_one_instance_lds_kernel_vs_oracle(size, monkeypatch):
+    """k_env_step (one instance per workgroup), which the grouped LDS kernel replaced as the default of these shapes"""
+    monkeypatch.setenv("MTFJSP_ENV_KERNEL", "lds1")
+    J, M, E, B = size
+    _run(J, M, E, B, 7, seed=4)
 
 
 def test_encoder_full_batch_permutation_equivariance():
