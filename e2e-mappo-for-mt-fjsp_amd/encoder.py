@@ -269,15 +269,15 @@ class ActorPair:
                         "bound": "mfma", "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None,
                         "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_flops_per_launch": flops,
                         "hbm_GBps_same_launch": rows * H * 4 * 2 / avg_s / 1e9}
-            nbytes = rows * H * 4 * 2 + 3 * H * H * 2 + 4 * H * 8 * 8     # rows in + rows out + weight planes + BatchNorm sums
+            nbytes = rows * H * 4 * 2 + 2 * H * H * 2 + 4 * H * 8 * 8     # rows in + rows out + weight planes + BatchNorm sums
             ach = nbytes / avg_s / 1e9
-            return {"kernel": f"k_gemm_x6<{name}> ([{rows},128]x[128,128] at f32 accuracy on the bf16 matrix cores: exact 3-way split, 6 piece "
+            return {"kernel": f"k_gemm_x6<{name}> ([{rows},128]x[128,128] at f32 accuracy on the f16 matrix cores: 2-way operand split, 3 piece "
                               "products, f32 accumulate; fused BN/aggregation prologue + BN-sums epilogue; 4 producer + 4 consumer waves)",
                     "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                     "frac_of_measured_copy_bw": ach / 6300.0, "traffic": None,
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_bytes_per_launch": nbytes,
                     "algorithmic_flops_per_launch": flops, "f32_equivalent_TFLOPs": flops / avg_s / 1e12,
-                    "bf16_matrix_TFLOPs": 6 * flops / avg_s / 1e12}
+                    "f16_matrix_TFLOPs": 3 * flops / avg_s / 1e12}
         if name == "gin_resident":
             # k_gin_res: the six Linear products of one forward in one launch.  Algorithmic work = the f32 products of the
             # reference (2 * rows * (12*128 + 5*128*128)); executed on the f16 matrix cores as 3 piece products each (the first

@@ -249,10 +249,10 @@ int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask
  * evaluation of validate.py:60-297 batched over the evaluation set.  Not applied to the global critic. */
 int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance);
 /* How the [rows,128]x[128,128] products of the actor forwards (Linear layers of gcn:95-153 / ac:205-293, the GAT weight of
- * gat:82) are formed.  0 (default): on the 16-bit matrix cores with f32 accumulation, from operands split into pieces —
- * three bf16 pieces (exact) and the six significant piece products in the streaming kernels, two f16 pieces (relative
- * representation error <= 2^-22) and the three significant products in the single-launch GIN kernel; both are as accurate as
- * an f32 FMA chain of the same length to within a small factor (tests/test_encoder_hip.py states the bounds).
+ * gat:82) are formed.  0 (default): on the 16-bit matrix cores with f32 accumulation, from f32 operands split into two f16
+ * pieces (relative representation error <= 2^-22; weights pre-scaled by a power of two) and the three significant piece
+ * products — measured as accurate as an f32 FMA chain of the same length (tests/test_encoder_hip.py states
+ * the bounds); the 12 -> 128 first Linear, whose inputs are raw features, uses an exact three-piece bf16 split instead.
  * Bits select the f32 matrix instruction instead, as the A/B reference: 1 = GIN products, 2 = GAT passes, 4 = actor/critic
  * heads, 8 = first GIN Linear (12 -> 128) on the vector ALU.  Bit 16 is not a numerics choice: it runs the GIN encoder as six
  * streaming launches (k_gemm_x6) even where the single-launch register-resident kernel (k_gin_res; in-kernel grid barriers for
