@@ -1269,6 +1269,9 @@ __global__ __launch_bounds__(1024) void k_env_step_grp(EnvParams P, int G)
     if (grp == 0) {
         const EnvGrpLdsAcc acc{smem, LL};
         env_grp_tail<OBS>(P, b0, lane, G, acc);
+    } else if (grp == 1) {
+        const EnvGrpLdsAcc acc{smem, LL};
+        env_grp_mask(P, b0, lane, G, acc);
     }
 }
 

@@ -21,11 +21,12 @@
 #define EG_LARGE 4
 #define EG_SMALL_MAX_B 8192
 enum { U_R0 = 0, U_NEWTR, U_D, U_PK, U_FTTAIL, U_TAIL = 8 };     // s_un slots (8..15: ragged tail of the pairwise energy sum)
-enum { I_VALID = 0, I_STATUS, I_NSCHED, I_M, I_JA };            // s_in slots
+enum { I_VALID = 0, I_STATUS, I_NSCHED, I_M, I_JA, I_A, I_NK, I_LASTM, I_MERGED };   // s_in slots (12 per instance)
 
 template <typename OBS>
 __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, const int lane, double *s_sorted, double *s_jmx, double *s_jrw,
-                                             int *s_cn, double *s_scl, double *s_mf, double *s_un, int *s_in, unsigned long long *rt)
+                                             int *s_cn, double *s_scl, double *s_mf, double *s_un, int *s_in, int *s_mp /*[128] mach | prev*/,
+                                             double *s_sdf /*[192] st | dur | ft*/, double *s_ttl /*[64]*/, unsigned long long *rt)
 {
 #ifdef MTFJSP_STAMP
 #define RT(i) do { __builtin_amdgcn_sched_barrier(0); rt[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
@@ -222,50 +223,12 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
         const uint4 *src = reinterpret_cast<const uint4 *>(f);
         for (int i = 0; i < (int)(12 * sizeof(OBS) / 16); i++) dst[i] = src[i];
     }
-    {   // in-edge (ELL) rows of a, its job successor, its new route successor, and the node whose merged edge reverts:
-        // lanes 0..3 take one row each and gather what they need with shuffles (every lane executes the shuffles: their
-        // source lanes must be active), so the edge arithmetic runs once instead of four times with scalar reads
+    {   // the in-edge (ELL) rows that changed — of a, its job successor, its new route successor and the node whose merged edge
+        // reverts — are computed by the group's second scalar wave (env_grp_ell: 4 lanes per instance); it gathers from these
         const int merged_now = merged_a ? a : -1;
-        const int vv0 = lane == 0 ? a : lane == 1 ? ((op + 1 < M) ? a + 1 : -1) : lane == 2 ? Nk : lane == 3 ? lastm : -1;
-        const bool act = vv0 >= 0;
-        const int vv = act ? vv0 : 0;
-        const int mv = __shfl(mach, vv), pr = __shfl(prev, vv);
-        const double st_v = __shfl(st, vv);
-        const int jvv = DIVM(vv), opvv = vv - jvv * M;
-        const int u = vv > 0 ? vv - 1 : 0;
-        const int mu = __shfl(mach, u);
-        const double dur_u = __shfl(dur, u), ft_u = __shfl(ft, u);
-        const int pri = pr >= 0 ? pr : 0;
-        const int mpr = __shfl(mach, pri);
-        const double dur_p = __shfl(dur, pri), ft_p = __shfl(ft, pri);
-        const double tt_uv = __shfl(ttv, (mu >= 0 ? mu : 0) * M + (mv >= 0 ? mv : 0));
-        const double tt_pv = __shfl(ttv, (mpr >= 0 ? mpr : 0) * M + (mv >= 0 ? mv : 0));
-        const bool s = mv >= 0;
-        const bool merged = pr >= 0 && opvv != 0 && pr == vv - 1;
-        int c_job = -1, c_mch = -1;
-        float a_job = 0.f, a_mch = 0.f;
-        if (opvv != 0) {
-            double w, nd;
-            if (mu < 0) { w = 1.0; nd = 1.0; }
-            else {
-                nd = dur_u;
-                if (merged && vv == merged_now) w = nd + tt_uv + (st_v - ft_u);                                             // env:1607-1675,1703-1765
-                else w = nd + (s ? tt_uv : 0.0);                                                                           // env:1384-1422
-            }
-            long A = trunc_l(w);
-            if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }                                   // env:2019, 2060-2062
-        }
-        if (pr >= 0 && !merged) {
-            const double x = (DIVM(pri) == jvv) ? tt_pv : 0.0;
-            const double w = dur_p + x + (st_v - ft_p);
-            long A = trunc_l(w);
-            if (A != 0) { A = trunc_l((double)A - dur_p) + 1; c_mch = pr; a_mch = (float)A; }
-        }
-        if (act) {
-            reinterpret_cast<int2 *>(P.obs.ell_col)[bT + vv] = make_int2(c_job, c_mch);
-            reinterpret_cast<float2 *>(P.obs.ell_val)[bT + vv] = make_float2(a_job, a_mch);
-            if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + vv) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
-        }
+        if (isT) { s_mp[v] = mach; s_mp[64 + v] = prev; s_sdf[v] = st; s_sdf[64 + v] = dur; s_sdf[128 + v] = ft; }
+        if (lane < M * M) s_ttl[lane] = ttv;
+        if (lane == 0) { s_in[I_A] = a; s_in[I_NK] = Nk; s_in[I_LASTM] = lastm; s_in[I_MERGED] = merged_now; }
         if (lane == 6) P.lastm[b] = merged_now;
     }
     // ---- candidate of the acting job (ppo:202-316; the mask is the scalar part's) and the state that changed
@@ -289,7 +252,7 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
 struct EnvGrpRegAcc {
     static constexpr bool kBigT = false;                         // T <= 64: the pairwise energy sum is one leaf block
     const double (*s_sorted)[64], (*s_jmx)[64], (*s_jrw)[64]; const int (*s_cn)[64];
-    const double (*s_scl)[SCAL_N], (*s_mf)[8], (*s_un)[16]; const int (*s_in)[8];
+    const double (*s_scl)[SCAL_N], (*s_mf)[8], (*s_un)[16]; const int (*s_in)[12];
     __device__ __forceinline__ const double *sorted(int g) const { return s_sorted[g]; }
     __device__ __forceinline__ const double *jmx(int g) const { return s_jmx[g]; }
     __device__ __forceinline__ const double *jrw(int g) const { return s_jrw[g]; }
@@ -405,6 +368,16 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
             reinterpret_cast<OBS *>(P.obs.m_fea2)[o + 4] = (OBS)c4;
         }
     }
+}
+
+// job mask (ppo:202-316) of the group's instances: lane = (instance, jobs ch, ch + 4, ...)
+template <typename ACC>
+__device__ __forceinline__ void env_grp_mask(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A)
+{
+    const int g = lane >> 2, ch = lane & 3;
+    const int b = b0 + g;
+    if (g >= EG || b >= P.B || !A.in(g)[I_VALID]) return;
+    const int J = P.J, M = P.M;
     {   // job mask (ppo:202-316)
         int cmin = M;
         double mn = INFINITY;                                                   // min row maximum over the unfinished jobs
@@ -426,6 +399,64 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
     }
 }
 
+// The <= 4 in-edge (ELL) rows a decision changes, for the group's instances: lane = (instance g, row r): r = 0 the acting
+// task a, 1 its job successor, 2 its new route successor, 3 the node whose merged job+machine edge reverts (env:1384-1422,
+// 1607-1675, 1703-1765, 2019, 2060-2062) — k_env_reg's arithmetic with the gathers going to the instance's LDS arrays.
+template <typename OBS>
+__device__ __forceinline__ void env_grp_ell(const EnvParams &P, const int b0, const int lane, const int EG, const int (*s_in)[12],
+                                            const int (*s_mp)[128], const double (*s_sdf)[192], const double (*s_ttl)[64])
+{
+    const int g = lane >> 2, r = lane & 3;
+    const int b = b0 + g;
+    if (g >= EG || b >= P.B || !s_in[g][I_VALID]) return;
+    const int M = P.M, T = P.T;
+    const unsigned invM = P.inv_M;
+#define DIVM(x) ((int)__umulhi((unsigned)(x), invM))
+    const size_t bT = (size_t)b * T;
+    const int a = s_in[g][I_A], Nk = s_in[g][I_NK], lastm = s_in[g][I_LASTM], merged_now = s_in[g][I_MERGED];
+    const int ja = DIVM(a), op = a - ja * M;
+    const int vv = r == 0 ? a : r == 1 ? ((op + 1 < M) ? a + 1 : -1) : r == 2 ? Nk : lastm;
+    if (vv < 0) return;
+    const int *mach = s_mp[g], *prev = s_mp[g] + 64;
+    const double *st = s_sdf[g], *dur = s_sdf[g] + 64, *ft = s_sdf[g] + 128, *tt = s_ttl[g];
+    const int mv = mach[vv], pr = prev[vv];
+    const double st_v = st[vv];
+    const int jvv = DIVM(vv), opvv = vv - jvv * M;
+    const int u = vv > 0 ? vv - 1 : 0;
+    const int mu = mach[u];
+    const double dur_u = dur[u], ft_u = ft[u];
+    const int pri = pr >= 0 ? pr : 0;
+    const int mpr = mach[pri];
+    const double dur_p = dur[pri], ft_p = ft[pri];
+    const double tt_uv = tt[(mu >= 0 ? mu : 0) * M + (mv >= 0 ? mv : 0)];
+    const double tt_pv = tt[(mpr >= 0 ? mpr : 0) * M + (mv >= 0 ? mv : 0)];
+    const bool s = mv >= 0;
+    const bool merged = pr >= 0 && opvv != 0 && pr == vv - 1;
+    int c_job = -1, c_mch = -1;
+    float a_job = 0.f, a_mch = 0.f;
+    if (opvv != 0) {
+        double w, nd;
+        if (mu < 0) { w = 1.0; nd = 1.0; }
+        else {
+            nd = dur_u;
+            if (merged && vv == merged_now) w = nd + tt_uv + (st_v - ft_u);                                             // env:1607-1675,1703-1765
+            else w = nd + (s ? tt_uv : 0.0);                                                                           // env:1384-1422
+        }
+        long A = trunc_l(w);
+        if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }                                   // env:2019, 2060-2062
+    }
+    if (pr >= 0 && !merged) {
+        const double x = (DIVM(pri) == jvv) ? tt_pv : 0.0;
+        const double w = dur_p + x + (st_v - ft_p);
+        long A = trunc_l(w);
+        if (A != 0) { A = trunc_l((double)A - dur_p) + 1; c_mch = pr; a_mch = (float)A; }
+    }
+    reinterpret_cast<int2 *>(P.obs.ell_col)[bT + vv] = make_int2(c_job, c_mch);
+    reinterpret_cast<float2 *>(P.obs.ell_val)[bT + vv] = make_float2(a_job, a_mch);
+    if (r == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + vv) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
+#undef DIVM
+}
+
 template <typename OBS, int EG>
 __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 {
@@ -435,7 +466,10 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
     __shared__ double s_scl[EG][SCAL_N];
     __shared__ double s_mf[EG][8];
     __shared__ double s_un[EG][16];
-    __shared__ int s_in[EG][8];
+    __shared__ int s_in[EG][12];
+    __shared__ int s_mp[EG][128];              // machine | route predecessor per task (after the step)
+    __shared__ double s_sdf[EG][192];          // start | duration | finish per task
+    __shared__ double s_ttl[EG][64];           // transport times
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b0 = blockIdx.x * EG;
     const int lane = threadIdx.x & 63;
@@ -443,14 +477,19 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 #ifdef MTFJSP_STAMP
     rt[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (b0 + grp < P.B) env_grp_wave<OBS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp], rt);
+    if (b0 + grp < P.B) env_grp_wave<OBS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp], s_mp[grp], s_sdf[grp], s_ttl[grp], rt);
     __syncthreads();
 #ifdef MTFJSP_STAMP
     rt[5] = __builtin_amdgcn_s_memrealtime();
 #endif
+    // two scalar-part waves (on different SIMDs): rewards / scaler / machine row | ELL rows + job mask
     if (grp == 0) {
         const EnvGrpRegAcc acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
         env_grp_tail<OBS>(P, b0, lane, EG, acc);
+    } else if (grp == 1) {
+        const EnvGrpRegAcc acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
+        env_grp_ell<OBS>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl);
+        env_grp_mask(P, b0, lane, EG, acc);
     }
 #ifdef MTFJSP_STAMP
     if (grp == 0) {
