@@ -16,7 +16,7 @@ from .batch_env import DeviceBatchEnv
 
 
 def validate_cost_batched(weights, t, p, tt, edge, args, greedy=True, device=0, obs_dtype="f32", actor=None,
-                          forced_actions=None, on_step=None):
+                          forced_actions=None, on_step=None, on_action=None):
     """weights: (job_actor_state_dict, machine_actor_state_dict) with the reference's key names (or an `ActorPair` via
     `actor=`); t, p [B,T,M], tt [B,M,M], edge [B,E,M/E]: the evaluation instances; args: the reference's config dict
     (n_job, n_machine, n_edge, weight_mk, weight_ec, weight_tt).
@@ -60,6 +60,8 @@ def validate_cost_batched(weights, t, p, tt, edge, args, greedy=True, device=0, 
                 actor.act(env, s, task, mach, job, force=(fa[:, s, 0].contiguous(), fa[:, s, 1].contiguous()))
                 if on_step is not None:
                     on_step(s, actor.enc.job_prob, actor.enc.mch_prob)
+            if on_action is not None:
+                on_action(s, task, mach)                            # the decisions about to be applied (tests)
             env.step(task, mach)
             cum += env.raw                                          # reward, r_mk, r_idle, r_pt, r_tt (env:1051-1171), unscaled
         torch.cuda.synchronize(dev)
