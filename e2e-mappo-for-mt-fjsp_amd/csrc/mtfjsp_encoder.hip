@@ -1747,17 +1747,13 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
         // one 16-row tile (planes at `tp`) x this wave's column block: 12 products on two chains, fragments of the next k-step in flight
         auto tile_x6 = [&](const unsigned char *tp, const h16x8 (&wv)[2][4]) __attribute__((always_inline)) -> f32x4 {
             f32x4 aA = zero4, aB = zero4;
-            h16x8 xv[2][2];
+            h16x8 xv[4][2];                                         // all 8 fragments of the tile requested at once: 3 matrix instructions do not cover an LDS round trip
 #pragma unroll
-            for (int p = 0; p < 2; p++) xv[0][p] = *reinterpret_cast<const h16x8 *>(tp + xoff + p * X6_PLANE);
+            for (int ks = 0; ks < 4; ks++)
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) {
-                if (ks < 3) {
+                for (int p = 0; p < 2; p++) xv[ks][p] = *reinterpret_cast<const h16x8 *>(tp + xoff + p * X6_PLANE + 64 * ks);
 #pragma unroll
-                    for (int p = 0; p < 2; p++) xv[(ks + 1) & 1][p] = *reinterpret_cast<const h16x8 *>(tp + xoff + p * X6_PLANE + 64 * (ks + 1));
-                }
-                X6_STEP(aA, aB, wv, xv[ks & 1], ks);
-            }
+            for (int ks = 0; ks < 4; ks++) X6_STEP(aA, aB, wv, xv[ks], ks);
             return aA + aB;
         };
         // a lane's 4 values of row m -> the two planes of a tile
