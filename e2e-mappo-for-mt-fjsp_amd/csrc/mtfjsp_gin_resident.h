@@ -67,7 +67,7 @@ struct GinResArgs {
                                           // the others: two f16 planes of W * wscale)
     float wsinv[6];                       // 1 / wscale of each image (a power of two; 1 for the first)
     const float *gamma[6], *beta[6];      // BatchNorm after each Linear (mlps.0.bn0, mlps.0.bn1, outer 0, mlps.1.bn0, mlps.1.bn1, outer 1)
-    double *stats;                        // this forward's accumulators (zero on entry): [6][8 groups][128][2] partial | [6][128][2] total
+    double *stats;                        // this forward's accumulators (zero on entry): [6 layers][8 groups][128][2]
     double *stats_next;                   // the set of the next forward: zeroed here
     unsigned long long *bar;              // barrier words (monotonic counters, never reset)
     unsigned long long epoch;             // launches on `bar` so far
@@ -82,7 +82,7 @@ struct GinResArgs {
     unsigned long long *stamps;           // diagnostic build only (-DGR_STAMP): [blocks][64] s_memrealtime at the phase boundaries
 };
 #define GR_STATS_PART (6 * 8 * HD * 2)                            // doubles: per layer, per dispatch group: (sum, sumsq) per column
-#define GR_STATS_SET (GR_STATS_PART + 6 * HD * 2)                 // + per layer totals
+#define GR_STATS_SET GR_STATS_PART
 #ifdef GR_STAMP
 #define GR_STAMP_AT(i) do { if (tid == 0 && A.stamps) A.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -118,12 +118,12 @@ __device__ __forceinline__ float gr_sum32(float x)
 // Grid-wide barrier over `nblk` co-resident workgroups that also completes a reduction: hierarchical over the 8 dispatch
 // groups blockIdx % 8 (observed to share an XCD; a different placement changes speed only).  Monotonic counters: generation
 // `gen` (1, 2, ...) is complete for a group when its counter reaches gen * group size.  Before the call every thread has
-// added its (sum | sumsq) word to part_group[tid] with a device-scope atomic and waited for it (s_waitcnt vmcnt(0)).
-// The last workgroup of a group to arrive folds the group's partial sums into `total` (again atomics, 8 adders per address);
-// the last group releases everybody.  On return (workgroup-wide) total[] may be read with sc1 loads: it is written by
-// memory-side atomics only and no line of it has been touched by this launch before.
-__device__ __forceinline__ void gr_grid_barrier(unsigned long long *bar, unsigned long long gen, unsigned nblk, unsigned *fail,
-                                                const double *part_group, double *total, unsigned *s_flag)
+// added its (sum | sumsq) word to its group's accumulators with a device-scope atomic and waited for it (s_waitcnt vmcnt(0)).
+// The last workgroup of a group to arrive reports the group; the last group releases everybody.  On return
+// (workgroup-wide) the 8 groups' accumulators are complete and may be read with sc1 loads — they are written by memory-side
+// atomics only and no line of them has been touched by this launch before — and are added up by every workgroup itself, in
+// a fixed order: two round trips less on the critical path than folding them into one total behind a second set of atomics.
+__device__ __forceinline__ void gr_grid_barrier(unsigned long long *bar, unsigned long long gen, unsigned nblk, unsigned *fail, unsigned *s_flag)
 {
     const int tid = threadIdx.x;
     const unsigned g = blockIdx.x & 7u;
@@ -136,13 +136,6 @@ __device__ __forceinline__ void gr_grid_barrier(unsigned long long *bar, unsigne
     }
     __syncthreads();
     if (*s_flag) {                                                // this workgroup completes its group (workgroup-uniform)
-        if (part_group) {
-            // the group's sums: every adder has drained its atomics before it arrived
-            const double v = __hip_atomic_load(&part_group[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            atomicAdd(&total[tid], v);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         if (tid == 0) {
             const unsigned long long old2 = __hip_atomic_fetch_add(&bar[16 * 8], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old2 + 1 == gen * ngroups)
@@ -176,7 +169,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     const unsigned nblk = gridDim.x;
     const unsigned long long gen0 = A.epoch * GR_NBAR;
     if (A.barrier_only) {
-        for (int k = 0; k < GR_NBAR; k++) gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, nullptr, nullptr, s_flag);
+        for (int k = 0; k < GR_NBAR; k++) gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, s_flag);
         return;
     }
     const int T = A.T;
@@ -437,7 +430,6 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         const float colsum = fold_stats();                        // (tile 17's sums were taken when it was stored)
         if (k == 1) GR_STAMP_AT(2);
         double *part = A.stats + ((size_t)k * 8 + (blockIdx.x & 7)) * (2 * HD);
-        double *total = A.stats + GR_STATS_PART + (size_t)k * (2 * HD);
         {
             atomicAdd(&part[tid], (double)colsum);                // [col][2] interleaved: thread tid -> (column tid >> 1, sum | sumsq)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -448,11 +440,19 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if constexpr (k < 5) load_weights(k + 1);
         const float ga = A.gamma[k][tid & (HD - 1)], be = A.beta[k][tid & (HD - 1)];
         GR_STAMP_AT(5 + 4 * k);
-        gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, part, total, s_flag);
+        gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, s_flag);
         GR_STAMP_AT(6 + 4 * k);
         if (tid < HD) {
-            const double su = __hip_atomic_load(&total[2 * tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const double sq = __hip_atomic_load(&total[2 * tid + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double *grp0 = A.stats + (size_t)k * 8 * (2 * HD) + 2 * tid;       // this column's (sum, sumsq) in group 0; groups are 2*HD apart
+            double gs[8], gq[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                gs[j] = __hip_atomic_load(&grp0[j * 2 * HD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gq[j] = __hip_atomic_load(&grp0[j * 2 * HD + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            double su = 0.0, sq = 0.0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { su += gs[j]; sq += gq[j]; }
             // the accumulators hold z * wscale (power of two, exact): statistics of z, scale applied to the stored value
             const double is = (double)A.wsinv[k];
             const double mean = su * A.inv_rows * is;
