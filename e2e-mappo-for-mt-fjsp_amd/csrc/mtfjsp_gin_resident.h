@@ -299,9 +299,15 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         return (s0 + s1) + (s2 + s3);
     };
     // BatchNorm + ReLU of columns 8g+4h..+3 of tile rt's resident values -> operand split -> planes of buffer buf
-    auto produce_quarter = [&](auto Tc, auto Gc, int buf) __attribute__((always_inline)) {
+    // Four plane buffers in the layers without aggregation (two of them in the ring area, free there): the tiles go in pairs —
+    // tiles 2p+2, 2p+3 are produced while tiles 2p, 2p+1 are multiplied — with ONE workgroup barrier per pair: half the
+    // barriers (each costs the wait for the slowest of the four waves, ~450 cycles measured).
+    unsigned char *const pl0 = s_planes, *const pl1 = s_planes + GR_TILE, *const pl2 = reinterpret_cast<unsigned char *>(s_ring),
+                  *const pl3 = reinterpret_cast<unsigned char *>(s_ring) + GR_TILE;
+    auto plane_buf = [&](int i) __attribute__((always_inline)) { return i == 0 ? pl0 : i == 1 ? pl1 : i == 2 ? pl2 : pl3; };
+    auto produce_quarter = [&](auto Tc, auto Gc, unsigned char *pbuf) __attribute__((always_inline)) {
         constexpr int rt = decltype(Tc)::value, g = decltype(Gc)::value;
-        unsigned char *dst = s_planes + buf * GR_TILE + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
+        unsigned char *dst = pbuf + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
         const float *bn = rt * 32 + n < nrows ? s_bn : s_zero;    // rows >= nrows: scale = shift = 0 -> zero planes
         const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);        // scale | shift of these 4 columns
         const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
@@ -312,8 +318,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         *reinterpret_cast<uint2 *>(dst) = p0;
         *reinterpret_cast<uint2 *>(dst + GR_PLANE) = p1;
     };
-    auto produce_tile = [&](auto Tc, int buf) __attribute__((always_inline)) {
-        gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) { produce_quarter(Tc, Gc, buf); });
+    auto produce_tile = [&](auto Tc, unsigned char *pbuf) __attribute__((always_inline)) {
+        gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) { produce_quarter(Tc, Gc, pbuf); });
         __builtin_amdgcn_sched_barrier(0);
     };
     // multiply tile RT (planes in buffer `buf`) by the resident weight fragments -> acc[RT]: per k-step the three significant
@@ -327,13 +333,14 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     const unsigned char *xa0 = s_planes + n * GR_ROWB + 16 * h;
 #define GR_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define GR_PIN_V() do { } while (0)
-    auto consume_tile = [&](auto Tc, auto NEXTc, int buf) __attribute__((always_inline)) {
+    auto consume_tile = [&](auto Tc) __attribute__((always_inline)) {
         constexpr int RT = decltype(Tc)::value;
-        constexpr bool NEXT = decltype(NEXTc)::value && (RT + 1 < GR_NT) && !(GR_ABL & 1);
+        constexpr int PT = RT + 2;                                        // the tile whose planes are produced here (the next pair's)
+        constexpr bool NEXT = (PT < GR_NT) && !(GR_ABL & 1);
         constexpr bool STATS = RT > 0 && RT - 1 < GR_NRES && !(GR_ABL & 4);     // (a spilled tile's sums are taken when it is stored)
-        const unsigned char *xa = xa0 + buf * GR_TILE;
-        const int nb = (RT + 1) & 1;
-        const float *bn = (RT + 1) * 32 + n < nrows ? s_bn : s_zero;      // rows >= nrows: scale = shift = 0 -> zero planes
+        const unsigned char *xa = plane_buf(RT % 4) + n * GR_ROWB + 16 * h;
+        unsigned char *pnext = plane_buf(PT % 4);
+        const float *bn = PT * 32 + n < nrows ? s_bn : s_zero;            // rows >= nrows: scale = shift = 0 -> zero planes
         gr_h8 xf[2][2];
 #pragma unroll
         for (int p = 0; p < 2; p++) xf[0][p] = *reinterpret_cast<const gr_h8 *>(xa + p * GR_PLANE);
@@ -345,15 +352,15 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         f32x16 atmp;
         f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : atmp;     // (its previous-layer values went into the planes one tile ago)
         a = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // the spilled tiles' old values: requested two tiles before the slices that turn them into planes
-        if constexpr (decltype(NEXTc)::value && RT + 2 >= GR_NRES && RT + 2 < GR_NT) zload(std::integral_constant<int, RT + 2 - GR_NRES>{});
+        // the spilled tiles' old values: requested a tile before the slices that turn them into planes
+        if constexpr (RT + 3 >= GR_NRES && RT + 3 < GR_NT) zload(std::integral_constant<int, RT + 3 - GR_NRES>{});
         gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
             constexpr int g = decltype(Pc)::value;                       // region = k-steps 2g, 2g+1 = column quarter g of the next tile
             const gr_h8 *x0 = xf[0], *x1 = xf[1];
             f32x2 v01 = {0.f, 0.f}, v23 = {0.f, 0.f}, e01 = v01, e23 = v01;
             gr_h2 p01 = {0, 0}, p23 = p01, q01 = p01, q23 = p01;
-            unsigned char *dst = s_planes + nb * GR_TILE + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
-            const f32x16 &nx = GR_TILEVAL(RT + 1 < GR_NT ? RT + 1 : RT);
+            unsigned char *dst = pnext + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
+            const f32x16 &nx = GR_TILEVAL(PT < GR_NT ? PT : RT);
             const f32x16 &pv = acc[RT > 0 && RT - 1 < GR_NRES ? RT - 1 : 0];
             auto M = [&](int ks, int wp, int xp) __attribute__((always_inline)) {
                 if (!(GR_ABL & 2)) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
@@ -528,15 +535,17 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     gr_static_for<5>([&](auto Lc) __attribute__((always_inline)) {
         constexpr int layer = decltype(Lc)::value + 1;
         if constexpr (layer != 3) {
-            produce_tile(std::integral_constant<int, 0>{}, 0);
+            produce_tile(std::integral_constant<int, 0>{}, pl0);
+            produce_tile(std::integral_constant<int, 1>{}, pl1);
             LDS_BARRIER();
             gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
                 constexpr int RT = decltype(Tc)::value;
-                consume_tile(Tc, std::true_type{}, RT & 1);       // produces tile RT+1 between its matrix instructions
+                consume_tile(Tc);                                 // produces tile RT+2 between its matrix instructions
                 GR_PIN_V();
-                LDS_BARRIER();
+                if constexpr (RT & 1) LDS_BARRIER();              // one barrier per pair of tiles
                 __builtin_amdgcn_sched_barrier(0);
             });
+            static_assert(GR_NT % 2 == 0, "tiles go in pairs");
         } else {
             // gcn:125-149: (A_w @ h) / nnz_row with h = relu(bn_outer0(z)), A_w incl. the self loop.  h tiles go through a ring of
             // GR_RING tiles in LDS; tile rt's rows and their in-edge sources (same instance, T <= 65 rows) lie in tiles rt-2..rt+2
