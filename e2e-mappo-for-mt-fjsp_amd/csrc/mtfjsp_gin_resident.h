@@ -47,6 +47,9 @@
 #define GR_ROWS (32 * GR_NT)
 #define GR_RING 6                         // row tiles in the f32 ring of the aggregation layer
 #define GR_NBAR 6                         // grid barriers per launch
+#ifndef GR_GRP
+#define GR_GRP 2                          // row tiles per workgroup barrier in the layers without aggregation (2 * GR_GRP plane buffers; measured 1: 142, 2: 135, 3: 138 us per launch)
+#endif
 #define GR_ROWB 272                       // plane row pitch in bytes (256 + 16: conflict-free 16-byte operand reads)
 #define GR_PLANE (32 * GR_ROWB)
 #define GR_TILE (2 * GR_PLANE)                // a tile buffer: the (high | low) f16 planes of 32 rows
@@ -302,9 +305,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     // Four plane buffers in the layers without aggregation (two of them in the ring area, free there): the tiles go in pairs —
     // tiles 2p+2, 2p+3 are produced while tiles 2p, 2p+1 are multiplied — with ONE workgroup barrier per pair: half the
     // barriers (each costs the wait for the slowest of the four waves, ~450 cycles measured).
-    unsigned char *const pl0 = s_planes, *const pl1 = s_planes + GR_TILE, *const pl2 = reinterpret_cast<unsigned char *>(s_ring),
-                  *const pl3 = reinterpret_cast<unsigned char *>(s_ring) + GR_TILE;
-    auto plane_buf = [&](int i) __attribute__((always_inline)) { return i == 0 ? pl0 : i == 1 ? pl1 : i == 2 ? pl2 : pl3; };
+    unsigned char *const pl0 = s_planes, *const pl1 = s_planes + GR_TILE, *const plr = reinterpret_cast<unsigned char *>(s_ring);
+    auto plane_buf = [&](int i) __attribute__((always_inline)) { return i == 0 ? pl0 : i == 1 ? pl1 : plr + (i - 2) * GR_TILE; };
     auto produce_quarter = [&](auto Tc, auto Gc, unsigned char *pbuf) __attribute__((always_inline)) {
         constexpr int rt = decltype(Tc)::value, g = decltype(Gc)::value;
         unsigned char *dst = pbuf + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
@@ -335,11 +337,11 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 #define GR_PIN_V() do { } while (0)
     auto consume_tile = [&](auto Tc) __attribute__((always_inline)) {
         constexpr int RT = decltype(Tc)::value;
-        constexpr int PT = RT + 2;                                        // the tile whose planes are produced here (the next pair's)
+        constexpr int PT = RT + GR_GRP;                                   // the tile whose planes are produced here (the next group's)
         constexpr bool NEXT = (PT < GR_NT) && !(GR_ABL & 1);
         constexpr bool STATS = RT > 0 && RT - 1 < GR_NRES && !(GR_ABL & 4);     // (a spilled tile's sums are taken when it is stored)
-        const unsigned char *xa = plane_buf(RT % 4) + n * GR_ROWB + 16 * h;
-        unsigned char *pnext = plane_buf(PT % 4);
+        const unsigned char *xa = plane_buf(RT % (2 * GR_GRP)) + n * GR_ROWB + 16 * h;
+        unsigned char *pnext = plane_buf(PT % (2 * GR_GRP));
         const float *bn = PT * 32 + n < nrows ? s_bn : s_zero;            // rows >= nrows: scale = shift = 0 -> zero planes
         gr_h8 xf[2][2];
 #pragma unroll
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : atmp;     // (its previous-layer values went into the planes one tile ago)
         a = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // the spilled tiles' old values: requested a tile before the slices that turn them into planes
-        if constexpr (RT + 3 >= GR_NRES && RT + 3 < GR_NT) zload(std::integral_constant<int, RT + 3 - GR_NRES>{});
+        if constexpr (RT + GR_GRP + 1 >= GR_NRES && RT + GR_GRP + 1 < GR_NT) zload(std::integral_constant<int, RT + GR_GRP + 1 - GR_NRES>{});
         gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
             constexpr int g = decltype(Pc)::value;                       // region = k-steps 2g, 2g+1 = column quarter g of the next tile
             const gr_h8 *x0 = xf[0], *x1 = xf[1];
@@ -535,17 +537,16 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     gr_static_for<5>([&](auto Lc) __attribute__((always_inline)) {
         constexpr int layer = decltype(Lc)::value + 1;
         if constexpr (layer != 3) {
-            produce_tile(std::integral_constant<int, 0>{}, pl0);
-            produce_tile(std::integral_constant<int, 1>{}, pl1);
+            gr_static_for<GR_GRP>([&](auto Ic) __attribute__((always_inline)) { produce_tile(Ic, plane_buf(decltype(Ic)::value)); });
             LDS_BARRIER();
             gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
                 constexpr int RT = decltype(Tc)::value;
                 consume_tile(Tc);                                 // produces tile RT+2 between its matrix instructions
                 GR_PIN_V();
-                if constexpr (RT & 1) LDS_BARRIER();              // one barrier per pair of tiles
+                if constexpr (RT % GR_GRP == GR_GRP - 1) LDS_BARRIER();     // one barrier per group of tiles
                 __builtin_amdgcn_sched_barrier(0);
             });
-            static_assert(GR_NT % 2 == 0, "tiles go in pairs");
+            static_assert(GR_NT % GR_GRP == 0 && GR_GRP >= 1 && GR_GRP <= 2 + (GR_RING * 32 * HD * 4) / GR_TILE / 2, "tile groups");
         } else {
             // gcn:125-149: (A_w @ h) / nnz_row with h = relu(bn_outer0(z)), A_w incl. the self loop.  h tiles go through a ring of
             // GR_RING tiles in LDS; tile rt's rows and their in-edge sources (same instance, T <= 65 rows) lie in tiles rt-2..rt+2
