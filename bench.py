@@ -146,6 +146,8 @@ def main():
                          "field of the reference's ReplayBuffer (device-resident TrajectoryBuffer, SURVEY 8f N2)")
     ap.add_argument("--min-seconds", type=float, default=0.5,
                     help="the timed region repeats blocks of exactly --steps steps until it has lasted at least this long")
+    ap.add_argument("--min-warmup-seconds", type=float, default=1.0,
+                    help="the untimed warm-up lasts at least this long (extra steps beyond --warmup; 0 = exactly --warmup + 20 probe steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-sweep", action="store_true", help="skip the step-kernel batch sweep (N=1 only)")
     args = ap.parse_args()
@@ -190,9 +192,26 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
 
+    t_w0 = time.perf_counter()
     for _ in range(args.warmup):
         ro.step()
     sync()
+    # a fresh box / first process needs more than a handful of steps to reach its steady state (lazy module loads, clock
+    # ramp): the untimed warm-up is extended to --min-warmup-seconds; the extra step count is agreed across ranks (the
+    # hand-off collective fires on a step count)
+    warm_steps = args.warmup
+    t_probe0 = time.perf_counter()
+    for _ in range(20):
+        ro.step()
+    sync()
+    warm_steps += 20
+    per_step = agree_max((time.perf_counter() - t_probe0) / 20)
+    extra = int(agree_max(float(max(0, int(np.ceil((args.min_warmup_seconds - (time.perf_counter() - t_w0)) / max(per_step, 1e-6)))))))
+    extra = min(extra, 20000)
+    for _ in range(extra):
+        ro.step()
+    sync()
+    warm_steps += extra
     # timed region: a whole number of blocks of --steps steps, bracketed by barrier + synchronize on both sides, long enough to
     # last --min-seconds (the driver's --steps 20 is 7 ms of work: too short to time).  The block count comes from one untimed
     # calibration block and is agreed across ranks, so every rank times the same number of steps.
@@ -203,7 +222,7 @@ def main():
         ro.step()
     sync()
     t_block = agree_max(time.perf_counter() - t0)
-    blocks = max(1, min(100000, int(np.ceil(args.min_seconds / max(t_block, 1e-6)))))
+    blocks = max(1, min(100000, int(np.ceil(1.15 * args.min_seconds / max(t_block, 1e-6)))))   # (margin: the calibration block runs a little slow)
     sync()
     t0 = time.perf_counter()
     for _ in range(blocks * args.steps):
@@ -268,7 +287,7 @@ def main():
         out = {
             "metric": "env-steps/sec (batched J%dM%dE%d)" % (J, M, E), "value": value, "unit": "env-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / steps_timed * 1e3,
-            "steps_timed": steps_timed, "timed_blocks": blocks, "timed_seconds": elapsed,
+            "steps_timed": steps_timed, "timed_blocks": blocks, "timed_seconds": elapsed, "warmup_steps_run": warm_steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64 (environment) / f32 (encoder: f32 storage and accumulation; 128x128 products on the 16-bit matrix cores from split f32 operands, f32-accurate: DESIGN.md §4)", "data": "synthetic",
             "config": {"workload": f"J{J}M{M}E{E}, {B} parallel instances per GPU ({ro.instances_desc}), {ro.describe()}",
                        "instances_per_gpu": B, "obs_dtype": args.obs, "policy": policy, "trajectory": args.trajectory,
