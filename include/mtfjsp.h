@@ -271,7 +271,9 @@ int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_ctx_t *ctx);
  * kernel synchronises its workgroups with in-kernel grid barriers whose spins are bounded; a timeout (not all workgroups
  * resident) is latched and returned here as MTFJSP_ERR_STATE.  *gin_resident_out (may be NULL) = 1 when that kernel is in use
  * for this handle (shape verified eligible by a census launch in mtfjsp_encoder_create, product-mode bits 1, 8, 16 clear), 0
- * when the six streaming launches are. */
+ * when the six streaming launches are.  The single-launch kernel needs all of its workgroups resident at once (one per CU):
+ * forwards of different handles must not overlap on the device (use one stream, or order them with events) — an overlap is
+ * not a hang but a barrier timeout, reported here. */
 int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_out);
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
 int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);
