@@ -157,17 +157,19 @@ def test_encoder_full_batch_permutation_equivariance():
     assert torch.allclose(prob2, prob[perm], atol=1e-5) and torch.allclose(h_o2, h_o[perm], atol=1e-4) and torch.allclose(v2, v[perm], atol=1e-4)
 
 
-def test_encoder_config2_full_size_vs_oracle():
-    """BASELINE config 2 at full size: J10M10E2 x 8192 = 819 200 node rows through the GIN kernels (remainder tiles, R = 10
-    chunked heads) and 81 920 machine rows through the GAT kernel, against the fp32 oracle restatement on the WHOLE batch
-    (training-mode BatchNorm couples every row) — at the J6M6 tolerances of tests/test_encoder_hip.py.  The oracle is pinned
-    against the reference modules at this size by tests/golden/encoder_j10m10e2_rand.npz."""
+@pytest.mark.parametrize("size", [(10, 10, 2, 8192), (20, 20, 4, 2048)])
+def test_encoder_config2_full_size_vs_oracle(size):
+    """BASELINE config 2 at full size — J10M10E2 x 8192 = 819 200 node rows through the GIN kernels (remainder tiles, R = 10
+    chunked heads) and 81 920 machine rows through the GAT kernel — and one GPU's shard of config 4 (J20M20E4 x 2048: 819 200
+    node rows of 400-row instances, the stand-alone pool/gather kernel, R = 20), against the fp32 oracle restatement on the
+    WHOLE batch (training-mode BatchNorm couples every row) at the J6M6 tolerances of tests/test_encoder_hip.py.  The oracle is
+    pinned against the reference modules at these sizes by tests/golden/encoder_j10m10e2_rand.npz / encoder_j20m20e4_rand.npz."""
     import torch
     import mtfjsp_amd  # noqa: F401
     enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
     rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
     from oracle import encoder_oracle as eo
-    J, M, E, B = 10, 10, 2, 8192
+    J, M, E, B = size
     T = J * M
     ja, ma = enc_mod.random_init_weights(seed=1010)
     rs = np.random.RandomState(5)
@@ -176,7 +178,7 @@ def test_encoder_config2_full_size_vs_oracle():
             if "batch_norms" in k or k.startswith("bn."):
                 d[k] = (rs.uniform(0.5, 1.5, d[k].shape) if k.endswith("weight") else rs.uniform(-0.5, 0.5, d[k].shape)).astype(np.float32)
     gen = import_module("e2e-mappo-for-mt-fjsp_amd.batch_env").DeviceBatchEnv(J, M, E, B, obs_dtype="f32")
-    gen.generate_instances(seed=9)                                               # 8192 distinct instances, drawn on the device
+    gen.generate_instances(seed=9)                                               # B distinct instances, drawn on the device
     ins = gen.read_instances()
     del gen
     ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=(ja, ma), collect=False, instances=ins)
@@ -203,7 +205,7 @@ def test_encoder_config2_full_size_vs_oracle():
     mo = eo.machine_actor_forward(ma, env.m_fea1.cpu().numpy(), env.m_fea2.cpu().numpy(), o["h_pooled"], env.mmask.cpu().numpy(), B, M)
     np.testing.assert_allclose(mprob.cpu().numpy(), mo["prob"], rtol=0, atol=1e-4)
     np.testing.assert_allclose(mach_v.cpu().numpy(), mo["mach_v"], rtol=1e-3, atol=1e-3)
-    # graph embedding after three GAT passes + BatchNorm over 81 920 rows: 1e-4 of the tensor's scale against the f32 oracle,
+    # graph embedding after three GAT passes + BatchNorm over B*M rows: 1e-4 of the tensor's scale against the f32 oracle,
     # and no further from a binary64 evaluation of the same network than that f32 evaluation is itself (x2)
     mscale = max(1.0, float(np.abs(mo["h_pooled"]).max()))
     np.testing.assert_allclose(h_m.cpu().numpy(), mo["h_pooled"], rtol=0, atol=1e-4 * mscale)
