@@ -184,6 +184,13 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     GR_STAMP_AT(32);
     for (int i = blockIdx.x * 256 + tid; i < GR_STATS_SET; i += (int)nblk * 256) A.stats_next[i] = 0.0;
     {
+        // (the candidate indices are requested with everything else: their use below would otherwise be a second memory round trip)
+        int cand_pre[(GR_MAXCAND + 255) / 256];
+#pragma unroll
+        for (int k = 0; k < (GR_MAXCAND + 255) / 256; k++) {
+            const int i = tid + 256 * k;
+            cand_pre[k] = (A.candidate && i < ninst * A.J) ? A.candidate[(size_t)inst0 * A.J + i] : -1;
+        }
         float *s_feat = s_ring;                                   // [nrows][12]
         if (A.feat_f64) {
             const double *src = reinterpret_cast<const double *>(A.tfea) + grow0 * 12;
@@ -207,9 +214,10 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         for (int i = tid; i < 2 * GR_TILE / 16; i += 256) reinterpret_cast<float4 *>(s_planes)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (A.candidate) {                                        // row -> candidate slot (ac:197-207 gathers h of one row per job)
             __syncthreads();
-            for (int i = tid; i < ninst * A.J; i += 256) {
-                const int c = A.candidate[(size_t)inst0 * A.J + i];
-                if (c >= 0 && c < T && atomicExch(&s_rowcand[(i / A.J) * T + c], i) != -1) s_flag[1] = 1u;   // two slots on one row: fixed up at the end
+#pragma unroll
+            for (int k = 0; k < (GR_MAXCAND + 255) / 256; k++) {
+                const int i = tid + 256 * k, c = cand_pre[k];
+                if (i < ninst * A.J && c >= 0 && c < T && atomicExch(&s_rowcand[(i / A.J) * T + c], i) != -1) s_flag[1] = 1u;   // two slots on one row: fixed up at the end
             }
         }
         s_zero[tid] = 0.f;
