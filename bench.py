@@ -74,7 +74,9 @@ def env_kernel_large_batch(J, M, E, device, B=262144, episodes=2):
     ach = B * env_bytes(J, M) / sec / 1e9
     del env
     torch.cuda.empty_cache()
-    return {"kernel": ("k_env_grp16" if B <= 8192 else "k_env_grp4") if (T <= 64 and M * M <= 64) else "k_env_step", "instances": B, "bound": "hbm", "achieved": ach,
+    kname = (("k_env_grp16" if B <= 8192 else "k_env_grp4") if (T <= 64 and M * M <= 64) else
+             ("k_env_grp16x2" if B <= 4096 else "k_env_grp4x2") if (T <= 128 and M * M <= 128 and M <= 16) else "k_env_step_grp")
+    return {"kernel": kname, "instances": B, "bound": "hbm", "achieved": ach,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBPS,
             "avg_launch_us": sec * 1e6, "launches": n, "env_steps_per_s": B / sec}
 

@@ -1857,10 +1857,22 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
 #endif
     // diagnostic / test overrides of the kernel selection (read per call): MTFJSP_ENV_KERNEL = lds | reg1 | grp16 | grp4
     const char *force = getenv("MTFJSP_ENV_KERNEL");
-    const bool force_lds = getenv("MTFJSP_ENV_LDS") || (force && !strcmp(force, "lds"));
+    const bool force_lds = getenv("MTFJSP_ENV_LDS") || (force && (!strcmp(force, "lds") || !strcmp(force, "lds1")));
     const bool force_reg1 = force && !strcmp(force, "reg1");
     const bool reg_ok = P.T <= 64 && P.M * P.M <= 64 && P.J <= 64 && !force_lds;
-    if (reg_ok && !force_reg1) {                                          // register kernel, groups of instances per workgroup
+    const bool reg2_ok = !reg_ok && P.T <= 128 && P.M * P.M <= 128 && P.M <= 16 && P.J <= 64 && !force_lds && !force_reg1;
+    if (reg2_ok) {                                                        // register kernel with two task slots per lane
+        const bool small = force && !strcmp(force, "grp16") ? true : force && !strcmp(force, "grp4") ? false : P.B <= EG_SMALL_MAX_B / 2;
+        if (small) {
+            const int grid = (P.B + EG_SMALL - 1) / EG_SMALL;
+            if (P.obs_f32) hipLaunchKernelGGL((k_env_grp16x2<float>), dim3(grid), dim3(EG_SMALL * WAVE), 0, h->stream, P);
+            else hipLaunchKernelGGL((k_env_grp16x2<double>), dim3(grid), dim3(EG_SMALL * WAVE), 0, h->stream, P);
+        } else {
+            const int grid = (P.B + EG_LARGE - 1) / EG_LARGE;
+            if (P.obs_f32) hipLaunchKernelGGL((k_env_grp4x2<float>), dim3(grid), dim3(EG_LARGE * WAVE), 0, h->stream, P);
+            else hipLaunchKernelGGL((k_env_grp4x2<double>), dim3(grid), dim3(EG_LARGE * WAVE), 0, h->stream, P);
+        }
+    } else if (reg_ok && !force_reg1) {                                   // register kernel, groups of instances per workgroup
         const bool small = force && !strcmp(force, "grp16") ? true : force && !strcmp(force, "grp4") ? false : P.B <= EG_SMALL_MAX_B;
         if (small) {
             const int grid = (P.B + EG_SMALL - 1) / EG_SMALL;

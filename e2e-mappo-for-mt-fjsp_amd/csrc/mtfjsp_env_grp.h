@@ -23,31 +23,51 @@
 enum { U_R0 = 0, U_NEWTR, U_D, U_PK, U_FTTAIL, U_TAIL = 8 };     // s_un slots (8..15: ragged tail of the pairwise energy sum)
 enum { I_VALID = 0, I_STATUS, I_NSCHED, I_M, I_JA, I_A, I_NK, I_LASTM, I_MERGED };   // s_in slots (12 per instance)
 
-template <typename OBS>
+// NS task slots per lane: NS = 1 for T <= 64 (lane = task), NS = 2 for T <= 128 (lane holds tasks lane and lane + 64, and two
+// transport-time entries: M*M <= 128).  Gathers with a uniform index pick the slot with a scalar condition and read one lane;
+// gathers with a per-lane index read both slots' lanes and select.  The per-task LDS arrays have 64*NS entries.
+template <typename OBS, int NS>
 __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, const int lane, double *s_sorted, double *s_jmx, double *s_jrw,
-                                             int *s_cn, double *s_scl, double *s_mf, double *s_un, int *s_in, int *s_mp /*[128] mach | prev*/,
-                                             double *s_sdf /*[192] st | dur | ft*/, double *s_ttl /*[64]*/, unsigned long long *rt)
+                                             int *s_cn, double *s_scl, double *s_mf, double *s_un, int *s_in, int *s_mp /*[2][64 NS] mach | prev*/,
+                                             double *s_sdf /*[3][64 NS] st | dur | ft*/, double *s_ttl /*[64 NS]*/, unsigned long long *rt)
 {
 #ifdef MTFJSP_STAMP
 #define RT(i) do { __builtin_amdgcn_sched_barrier(0); rt[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define RT(i) do { } while (0)
 #endif
+    constexpr int NL = 64 * NS;
     const int J = P.J, M = P.M, T = P.T;
     const unsigned invM = P.inv_M;
 #define DIVM(x) ((int)__umulhi((unsigned)(x), invM))
+    auto RLI = [&](const int (&x)[NS], int idx) __attribute__((always_inline)) { return NS == 1 ? rl_i(x[0], idx) : rl_i(idx < 64 ? x[0] : x[NS - 1], idx & 63); };
+    auto RLD = [&](const double (&x)[NS], int idx) __attribute__((always_inline)) { return NS == 1 ? rl_d(x[0], idx) : rl_d(idx < 64 ? x[0] : x[NS - 1], idx & 63); };
+    auto SHI = [&](const int (&x)[NS], int idx) __attribute__((always_inline)) {
+        if (NS == 1) return __shfl(x[0], idx);
+        const int a = __shfl(x[0], idx & 63), c = __shfl(x[NS - 1], idx & 63);
+        return idx < 64 ? a : c;
+    };
+    auto SHD = [&](const double (&x)[NS], int idx) __attribute__((always_inline)) {
+        if (NS == 1) return __shfl(x[0], idx);
+        const double a = __shfl(x[0], idx & 63), c = __shfl(x[NS - 1], idx & 63);
+        return idx < 64 ? a : c;
+    };
     const size_t bT = (size_t)b * T;
-    const int v = lane;
-    const bool isT = v < T;
+    int v[NS]; bool isT[NS];
     // ---- bulk state (independent of the action)
-    int mach = -1, prev = -1, next = -1, pos = 0;
-    double st = 0.0, ft = 0.0, dur = 0.0, pte = 0.0;
-    if (isT) {
-        const Link l = P.link[bT + v];
-        mach = l.mach; prev = l.prev; pos = l.pos; next = l.pad;
-        st = P.st[bT + v]; ft = P.ft[bT + v]; dur = P.dur[bT + v]; pte = P.pte[bT + v];
+    int mach[NS], prev[NS], next[NS], pos[NS];
+    double st[NS], ft[NS], dur[NS], pte[NS], ttv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        v[s] = lane + 64 * s; isT[s] = v[s] < T;
+        mach[s] = -1; prev[s] = -1; next[s] = -1; pos[s] = 0; st[s] = 0.0; ft[s] = 0.0; dur[s] = 0.0; pte[s] = 0.0;
+        if (isT[s]) {
+            const Link l = P.link[bT + v[s]];
+            mach[s] = l.mach; prev[s] = l.prev; pos[s] = l.pos; next[s] = l.pad;
+            st[s] = P.st[bT + v[s]]; ft[s] = P.ft[bT + v[s]]; dur[s] = P.dur[bT + v[s]]; pte[s] = P.pte[bT + v[s]];
+        }
+        ttv[s] = v[s] < M * M ? P.tt[(size_t)b * M * M + v[s]] : 0.0;
     }
-    const double ttv = lane < M * M ? P.tt[(size_t)b * M * M + lane] : 0.0;
     int head_ = -1, tail_ = -1, len_ = 0;
     if (lane < M) { const MRec r = P.mrec[(size_t)b * M + lane]; head_ = r.head; tail_ = r.tail; len_ = r.len; }
     int cnt_ = 0; double jmax_ = -INFINITY, jrow_ = 0.0;
@@ -63,7 +83,9 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     const double pk = P.p[(bT + a) * M + m];
     const double md = lane < M ? P.cst[bT + ja * M + lane].x : 0.0;
     const double mfr = lane < 8 ? P.mfea[((size_t)b * M + m) * 8 + lane] : 0.0;
-    const int jv = DIVM(v), opv = v - jv * M;
+    int jv[NS], opv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) { jv[s] = DIVM(v[s]); opv[s] = v[s] - jv[s] * M; }
     if (lane < SCAL_N) s_scl[lane] = sc;
 
     // =========================================================================================
@@ -72,52 +94,57 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     double st_k = 0.0;
     int mach_p = -1;
     if (valid) {
-        if (rl_i(mach, a) >= 0) valid = false;                                  // env:1504
-        else if (op != 0) { mach_p = rl_i(mach, a - 1); if (mach_p < 0) valid = false; }   // env:1520
+        if (RLI(mach, a) >= 0) valid = false;                                   // env:1504
+        else if (op != 0) { mach_p = RLI(mach, a - 1); if (mach_p < 0) valid = false; }    // env:1520
     }
     const int len = rl_i(len_, m), head = rl_i(head_, m), tail = rl_i(tail_, m);
-    const double ttmm = rl_d(ttv, m * M + m);
+    const double ttmm = RLD(ttv, m * M + m);
     RT(1);
     if (valid) {
         if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;                            // pe:246-248
-        const double arr_k = op == 0 ? 0.0 : rl_d(ft, a - 1) + rl_d(ttv, mach_p * M + m);   // dg:46-66
+        const double arr_k = op == 0 ? 0.0 : RLD(ft, a - 1) + RLD(ttv, mach_p * M + m);     // dg:46-66
         bool do_append = false;
         if (len == 0) { path = MTFJSP_PATH_EMPTY; st_k = arr_k; ipos = 0; }                 // env:1684
         else if (!P.left_shift) do_append = true;                                               // env:1680
         else {
             const double lb_ft = arr_k + d;
             const int jh = DIVM(head);
-            const double arr_f = (head == jh * M) ? 0.0 : rl_d(ft, head - 1) + rl_d(ttv, rl_i(mach, head - 1) * M + m);
+            const double arr_f = (head == jh * M) ? 0.0 : RLD(ft, head - 1) + RLD(ttv, RLI(mach, head - 1) * M + m);
             if (lb_ft <= arr_f) { path = MTFJSP_PATH_FRONT; st_k = arr_k; ipos = 0; Nk = head; }   // env:1548
             else if (len == 1) do_append = true;                                                 // env:1577
             else {
-                // gap test of env:1587-1604 on every lane at once, then the first hit in route order by a scalar walk
-                const int pi = prev >= 0 ? prev : 0, vi = v > 0 ? v - 1 : 0;
-                const double ftP = __shfl(ft, pi), ftj = __shfl(ft, vi);
-                const int mj = __shfl(mach, vi);
-                const double ttj = __shfl(ttv, (mj >= 0 ? mj : 0) * M + m);
-                const double jarr = (opv == 0) ? 0.0 : ftj + ttj;
-                const double x = (DIVM(pi) == jv) ? ttmm : 0.0;
-                const double nst = fmax(jarr, ftP + x);
-                const bool ok = isT && mach == m && prev >= 0 && !(lb_ft > nst) && !((nst - ftP) < d);
-                const unsigned long long okm = __ballot(ok);
-                int cur = rl_i(next, head);
+                // gap test of env:1587-1604 on every task at once, then the first hit in route order by a scalar walk
+                unsigned long long okm[NS];
+#pragma unroll
+                for (int s = 0; s < NS; s++) {
+                    const int pi = prev[s] >= 0 ? prev[s] : 0, vi = v[s] > 0 ? v[s] - 1 : 0;
+                    const double ftP = SHD(ft, pi), ftj = SHD(ft, vi);
+                    const int mj = SHI(mach, vi);
+                    const double ttj = SHD(ttv, (mj >= 0 ? mj : 0) * M + m);
+                    const double jarr = (opv[s] == 0) ? 0.0 : ftj + ttj;
+                    const double x = (DIVM(pi) == jv[s]) ? ttmm : 0.0;
+                    const double nst = fmax(jarr, ftP + x);
+                    const bool ok = isT[s] && mach[s] == m && prev[s] >= 0 && !(lb_ft > nst) && !((nst - ftP) < d);
+                    okm[s] = __ballot(ok);
+                }
+                int cur = RLI(next, head);
                 while (cur >= 0) {
-                    if ((okm >> cur) & 1ull) { Nk = cur; break; }
-                    cur = rl_i(next, cur);
+                    const unsigned long long mk_ = NS == 1 ? okm[0] : (cur < 64 ? okm[0] : okm[NS - 1]);
+                    if ((mk_ >> (cur & 63)) & 1ull) { Nk = cur; break; }
+                    cur = RLI(next, cur);
                 }
                 if (Nk >= 0) {
                     path = MTFJSP_PATH_BETWEEN;
-                    ipos = rl_i(pos, Nk); Pk = rl_i(prev, Nk);
+                    ipos = RLI(pos, Nk); Pk = RLI(prev, Nk);
                     const double xx = (DIVM(Pk) == ja) ? ttmm : 0.0;
-                    st_k = fmax(arr_k, rl_d(ft, Pk) + xx);                      // env:1619
+                    st_k = fmax(arr_k, RLD(ft, Pk) + xx);                       // env:1619
                 } else do_append = true;                                        // env:1676
             }
         }
         if (do_append) {                                                        // env:1689-1775
             path = MTFJSP_PATH_APPEND;
             const double xx = (DIVM(tail) == ja) ? ttmm : 0.0;
-            st_k = fmax(arr_k, rl_d(ft, tail) + xx);
+            st_k = fmax(arr_k, RLD(ft, tail) + xx);
             ipos = len; Pk = tail;
         }
         status |= path;
@@ -129,10 +156,13 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     const double ft_k = st_k + d;
     RT(2);
     // ---- apply: register updates on the owning lanes
-    if (isT && mach == m && pos >= ipos) pos += 1;
-    if (v == a) { mach = m; prev = Pk; next = Nk; pos = ipos; st = st_k; ft = ft_k; dur = d; pte = d * pk; }    // env:356,2175
-    if (v == Nk) prev = a;
-    if (v == Pk) next = a;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        if (isT[s] && mach[s] == m && pos[s] >= ipos) pos[s] += 1;
+        if (v[s] == a) { mach[s] = m; prev[s] = Pk; next[s] = Nk; pos[s] = ipos; st[s] = st_k; ft[s] = ft_k; dur[s] = d; pte[s] = d * pk; }    // env:356,2175
+        if (v[s] == Nk) prev[s] = a;
+        if (v[s] == Pk) next[s] = a;
+    }
     if (lane == m) { if (ipos == 0) head_ = a; if (ipos == len) tail_ = a; len_ = len + 1; }
     if (lane == ja) cnt_ += 1;
     const int nsched = (int)rl_d(sc, S_NSCHED) + 1;
@@ -140,62 +170,74 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     // =========================================================================================
     // B. per-task side of the costs
     // estimated start/finish of the acting job's ops: the reference's left-to-right loop (env:1965-1995), run with
-    // scalar indices; lane ja*M+c keeps its own (ste, fte).  Ops of a job are scheduled in order: ops < op are scheduled
-    // (their estimate IS their finish time, already folded into the job's running row maximum jrow_), op is being scheduled
-    // now, ops > op are unscheduled -> only the tail is walked.
-    double my_ste = 0.0, my_fte = 0.0, accp = ft_k;
+    // scalar indices; the lane of task ja*M+c keeps its own (ste, fte).  Ops of a job are scheduled in order: ops < op are
+    // scheduled (their estimate IS their finish time, already folded into the job's running row maximum jrow_), op is being
+    // scheduled now, ops > op are unscheduled -> only the tail is walked.
+    double my_ste[NS], my_fte[NS], accp = ft_k;
+#pragma unroll
+    for (int s = 0; s < NS; s++) { my_ste[s] = 0.0; my_fte[s] = 0.0; }
     const double row_prev = rl_d(jrow_, ja);                                    // max real finish time of ops < op (0 if none)
     double jrow_new = op == 0 ? ft_k : fmax(row_prev, ft_k);                    // ppo:265-275 row maximum of real finish times
     double jmax_new = jrow_new;                                                 // estimated finish times of ops <= op are the real ones
-    if (v == a) { my_ste = st_k; my_fte = ft_k; }
+#pragma unroll
+    for (int s = 0; s < NS; s++) if (v[s] == a) { my_ste[s] = st_k; my_fte[s] = ft_k; }
     if (ft_k == 0.0) {                                                          // env:1977: a zero finish time is treated as "not set"
-        accp = (op ? rl_d(ft, a - 1) : 0.0) + rl_d(md, op);
-        if (v == a) my_fte = accp;
+        accp = (op ? RLD(ft, a - 1) : 0.0) + rl_d(md, op);
+#pragma unroll
+        for (int s = 0; s < NS; s++) if (v[s] == a) my_fte[s] = accp;
         jmax_new = op == 0 ? accp : fmax(row_prev, accp);
     }
     for (int c = op + 1; c < M; c++) {
         const double fte_c = accp + rl_d(md, c);
-        if (v == ja * M + c) { my_ste = accp; my_fte = fte_c; }
+#pragma unroll
+        for (int s = 0; s < NS; s++) if (v[s] == ja * M + c) { my_ste[s] = accp; my_fte[s] = fte_c; }
         accp = fte_c;
         jmax_new = fmax(jmax_new, fte_c);
     }
     if (lane == ja) { jmax_ = jmax_new; jrow_ = jrow_new; }
     if (lane < J) { s_jmx[lane] = jmax_; s_jrw[lane] = jrow_; s_cn[lane] = cnt_; }
-    // env:896 np.sum(pt_est), numpy's pairwise order: lanes 0..7 are its 8 accumulators r[k] = a[k] + a[k+8] + ... (in that
-    // order), then its fixed tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) as an xor butterfly (fp addition commutes); the ragged
-    // tail is added by the scalar part, in order
+    // env:896 np.sum(pt_est), numpy's pairwise order (one leaf block: T <= 128): lanes 0..7 are its 8 accumulators r[k] = a[k] +
+    // a[k+8] + ... (in that order), then its fixed tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) as an xor butterfly (fp addition
+    // commutes); the ragged tail is added by the scalar part, in order
     {
         const int nb = T < 8 ? 0 : T - (T & 7);
         if (nb) {
-            double r = pte;
-            for (int i = 8; i < nb; i += 8) r += __shfl(pte, (lane & 7) + i);
+            double r = pte[0];
+            for (int i = 8; i < nb; i += 8) r += SHD(pte, (lane & 7) + i);
             r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
             if (lane == 0) s_un[U_R0] = r;
         } else if (lane == 0) s_un[U_R0] = 0.0;
-        if (v >= nb && v < T) s_un[U_TAIL + v - nb] = pte;
+#pragma unroll
+        for (int s = 0; s < NS; s++) if (v[s] >= nb && v[s] < T) s_un[U_TAIL + v[s] - nb] = pte[s];
     }
     // idle time (dg:144-170): one term per scheduled task, summed strictly left to right in (machine, route position)
-    // order: every scheduled lane computes its rank in that order = (tasks on lower machines) + (its route position) and
-    // drops its term at that index; the scalar part adds terms 0..nsched-1 in order.
+    // order: every scheduled task's lane computes its rank in that order = (tasks on lower machines) + (its route position) and
+    // drops its term at that index; the scalar part adds terms in order.
     {
-        const double ftPr = __shfl(ft, prev >= 0 ? prev : 0);
-        const double term = prev < 0 ? st : st - ftPr;
-        int incl = lane < M ? len_ : 0;                                         // M <= 8: three DPP row shifts with zero fill
+        int incl = lane < M ? len_ : 0;                                         // M <= 16: four DPP row shifts with zero fill
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true);   // row_shr:4
+        if (NS > 1) incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);   // row_shr:8 (M > 8 only with two slots)
         const int before = incl - (lane < M ? len_ : 0);
-        const bool sch = isT && mach >= 0;
-        const int below = __shfl(before, mach >= 0 ? mach : 0);                 // executed by ALL lanes: the source lanes must be active
         // the other lanes fill the remaining slots with +0.0 (x + 0.0 == x: the running sum is never -0.0), so that the scalar
-        // part adds a fixed number of terms: unscheduled tasks take nsched.. in lane order, lanes >= T their own index
-        const unsigned long long um = __ballot(isT && mach < 0);
-        const int uidx = nsched + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
-        s_sorted[sch ? below + pos : isT ? uidx : lane] = sch ? term : 0.0;
+        // part adds a fixed number of terms: unscheduled tasks take nsched.. in task order, indices >= T their own index
+        int ubase = nsched;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            const double ftPr = SHD(ft, prev[s] >= 0 ? prev[s] : 0);
+            const double term = prev[s] < 0 ? st[s] : st[s] - ftPr;
+            const bool sch = isT[s] && mach[s] >= 0;
+            const int below = __shfl(before, mach[s] >= 0 ? mach[s] : 0);       // executed by ALL lanes: the source lanes must be active
+            const unsigned long long um = __ballot(isT[s] && mach[s] < 0);
+            const int uidx = ubase + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+            s_sorted[sch ? below + pos[s] : isT[s] ? uidx : v[s]] = sch ? term : 0.0;
+            ubase += __builtin_popcountll(um);
+        }
     }
     {
-        const double new_tr = (op == 0) ? 0.0 : rl_d(ttv, mach_p * M + m);      // env:872-876
-        const double ft_tail = rl_d(ft, rl_i(tail_, m));                        // env:2315-2340, column 0 of the acting machine's row
+        const double new_tr = (op == 0) ? 0.0 : RLD(ttv, mach_p * M + m);       // env:872-876
+        const double ft_tail = RLD(ft, rl_i(tail_, m));                         // env:2315-2340, column 0 of the acting machine's row
         if (lane == 0) {
             s_un[U_NEWTR] = new_tr; s_un[U_D] = d; s_un[U_PK] = pk; s_un[U_FTTAIL] = ft_tail;
             s_in[I_VALID] = 1; s_in[I_STATUS] = status; s_in[I_NSCHED] = nsched; s_in[I_M] = m; s_in[I_JA] = ja;
@@ -208,26 +250,31 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     // C. the observation rows that changed
     const double w30 = rl_d(sc, S_W3), w31 = rl_d(sc, S_W3 + 1), w32 = rl_d(sc, S_W3 + 2);
     const bool merged_a = Pk >= 0 && op != 0 && Pk == a - 1;
-    if (isT && jv == ja && opv >= op) {                                         // feature rows a .. end of job (env:2245-2277)
-        const bool isa = v == a;
-        OBS f[12];
-        f[0] = (OBS)my_ste; f[1] = (OBS)my_fte; f[2] = (OBS)pte;
-        f[3] = (OBS)(isa ? 1.0 : 0.0);
-        f[4] = (OBS)(isa ? (1 + ((Pk >= 0 && !merged_a) ? 1 : 0)) : 1);
-        f[5] = (OBS)(isa ? m + 1 : 0);
-        f[6] = (OBS)(isa ? d : 0.0);
-        f[7] = (OBS)(isa ? pk : 0.0);
-        f[8] = (OBS)(ja + 1);
-        f[9] = (OBS)w30; f[10] = (OBS)w31; f[11] = (OBS)w32;
-        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + v) * 12);
-        const uint4 *src = reinterpret_cast<const uint4 *>(f);
-        for (int i = 0; i < (int)(12 * sizeof(OBS) / 16); i++) dst[i] = src[i];
-    }
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (isT[s] && jv[s] == ja && opv[s] >= op) {                            // feature rows a .. end of job (env:2245-2277)
+            const bool isa = v[s] == a;
+            OBS f[12];
+            f[0] = (OBS)my_ste[s]; f[1] = (OBS)my_fte[s]; f[2] = (OBS)pte[s];
+            f[3] = (OBS)(isa ? 1.0 : 0.0);
+            f[4] = (OBS)(isa ? (1 + ((Pk >= 0 && !merged_a) ? 1 : 0)) : 1);
+            f[5] = (OBS)(isa ? m + 1 : 0);
+            f[6] = (OBS)(isa ? d : 0.0);
+            f[7] = (OBS)(isa ? pk : 0.0);
+            f[8] = (OBS)(ja + 1);
+            f[9] = (OBS)w30; f[10] = (OBS)w31; f[11] = (OBS)w32;
+            uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + v[s]) * 12);
+            const uint4 *src = reinterpret_cast<const uint4 *>(f);
+            for (int i = 0; i < (int)(12 * sizeof(OBS) / 16); i++) dst[i] = src[i];
+        }
     {   // the in-edge (ELL) rows that changed — of a, its job successor, its new route successor and the node whose merged edge
         // reverts — are computed by the group's second scalar wave (env_grp_ell: 4 lanes per instance); it gathers from these
         const int merged_now = merged_a ? a : -1;
-        if (isT) { s_mp[v] = mach; s_mp[64 + v] = prev; s_sdf[v] = st; s_sdf[64 + v] = dur; s_sdf[128 + v] = ft; }
-        if (lane < M * M) s_ttl[lane] = ttv;
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+            if (isT[s]) { s_mp[v[s]] = mach[s]; s_mp[NL + v[s]] = prev[s]; s_sdf[v[s]] = st[s]; s_sdf[NL + v[s]] = dur[s]; s_sdf[2 * NL + v[s]] = ft[s]; }
+            if (v[s] < M * M) s_ttl[v[s]] = ttv[s];
+        }
         if (lane == 0) { s_in[I_A] = a; s_in[I_NK] = Nk; s_in[I_LASTM] = lastm; s_in[I_MERGED] = merged_now; }
         if (lane == 6) P.lastm[b] = merged_now;
     }
@@ -236,11 +283,13 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
         P.obs.candidate[(size_t)b * J + ja] = ja * M + (cnt_ < M ? cnt_ : M - 1);
         P.jcnt[(size_t)b * J + ja] = (short)cnt_; P.jmax[(size_t)b * J + ja] = jmax_; P.jrow[(size_t)b * J + ja] = jrow_;
     }
-    if (isT) {
-        Link l; l.mach = (short)mach; l.prev = (short)prev; l.pos = (short)pos; l.pad = (short)next;
-        P.link[bT + v] = l;
-        if (v == a) { P.st[bT + a] = st; P.ft[bT + a] = ft; P.dur[bT + a] = dur; P.psel[bT + a] = pk; P.pte[bT + a] = pte; }
-    }
+#pragma unroll
+    for (int s = 0; s < NS; s++)
+        if (isT[s]) {
+            Link l; l.mach = (short)mach[s]; l.prev = (short)prev[s]; l.pos = (short)pos[s]; l.pad = (short)next[s];
+            P.link[bT + v[s]] = l;
+            if (v[s] == a) { P.st[bT + a] = st[s]; P.ft[bT + a] = ft[s]; P.dur[bT + a] = dur[s]; P.psel[bT + a] = pk; P.pte[bT + a] = pte[s]; }
+        }
     if (lane == m) { MRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
     RT(4);
 #undef DIVM
@@ -249,9 +298,10 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
 
 // where the per-instance inputs of the scalar part live: k_env_grp* keeps them in fixed-size arrays, k_env_step_grp in the
 // instance's own LDS region
+template <int NL>
 struct EnvGrpRegAcc {
-    static constexpr bool kBigT = false;                         // T <= 64: the pairwise energy sum is one leaf block
-    const double (*s_sorted)[64], (*s_jmx)[64], (*s_jrw)[64]; const int (*s_cn)[64];
+    static constexpr bool kBigT = false;                         // T <= 128: the pairwise energy sum is one leaf block
+    const double (*s_sorted)[NL], (*s_jmx)[64], (*s_jrw)[64]; const int (*s_cn)[64];
     const double (*s_scl)[SCAL_N], (*s_mf)[8], (*s_un)[16]; const int (*s_in)[12];
     __device__ __forceinline__ const double *sorted(int g) const { return s_sorted[g]; }
     __device__ __forceinline__ const double *jmx(int g) const { return s_jmx[g]; }
@@ -402,9 +452,9 @@ __device__ __forceinline__ void env_grp_mask(const EnvParams &P, const int b0, c
 // The <= 4 in-edge (ELL) rows a decision changes, for the group's instances: lane = (instance g, row r): r = 0 the acting
 // task a, 1 its job successor, 2 its new route successor, 3 the node whose merged job+machine edge reverts (env:1384-1422,
 // 1607-1675, 1703-1765, 2019, 2060-2062) — k_env_reg's arithmetic with the gathers going to the instance's LDS arrays.
-template <typename OBS>
+template <typename OBS, int NL>
 __device__ __forceinline__ void env_grp_ell(const EnvParams &P, const int b0, const int lane, const int EG, const int (*s_in)[12],
-                                            const int (*s_mp)[128], const double (*s_sdf)[192], const double (*s_ttl)[64])
+                                            const int (*s_mp)[2 * NL], const double (*s_sdf)[3 * NL], const double (*s_ttl)[NL])
 {
     const int g = lane >> 2, r = lane & 3;
     const int b = b0 + g;
@@ -417,8 +467,8 @@ __device__ __forceinline__ void env_grp_ell(const EnvParams &P, const int b0, co
     const int ja = DIVM(a), op = a - ja * M;
     const int vv = r == 0 ? a : r == 1 ? ((op + 1 < M) ? a + 1 : -1) : r == 2 ? Nk : lastm;
     if (vv < 0) return;
-    const int *mach = s_mp[g], *prev = s_mp[g] + 64;
-    const double *st = s_sdf[g], *dur = s_sdf[g] + 64, *ft = s_sdf[g] + 128, *tt = s_ttl[g];
+    const int *mach = s_mp[g], *prev = s_mp[g] + NL;
+    const double *st = s_sdf[g], *dur = s_sdf[g] + NL, *ft = s_sdf[g] + 2 * NL, *tt = s_ttl[g];
     const int mv = mach[vv], pr = prev[vv];
     const double st_v = st[vv];
     const int jvv = DIVM(vv), opvv = vv - jvv * M;
@@ -457,19 +507,20 @@ __device__ __forceinline__ void env_grp_ell(const EnvParams &P, const int b0, co
 #undef DIVM
 }
 
-template <typename OBS, int EG>
+template <typename OBS, int EG, int NS>
 __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 {
-    __shared__ double s_sorted[EG][64];        // idle terms in (machine, route position) rank order
+    constexpr int NL = 64 * NS;                // task slots per instance
+    __shared__ double s_sorted[EG][NL];        // idle terms in (machine, route position) rank order
     __shared__ double s_jmx[EG][64], s_jrw[EG][64];
     __shared__ int s_cn[EG][64];
     __shared__ double s_scl[EG][SCAL_N];
     __shared__ double s_mf[EG][8];
     __shared__ double s_un[EG][16];
     __shared__ int s_in[EG][12];
-    __shared__ int s_mp[EG][128];              // machine | route predecessor per task (after the step)
-    __shared__ double s_sdf[EG][192];          // start | duration | finish per task
-    __shared__ double s_ttl[EG][64];           // transport times
+    __shared__ int s_mp[EG][2 * NL];           // machine | route predecessor per task (after the step)
+    __shared__ double s_sdf[EG][3 * NL];       // start | duration | finish per task
+    __shared__ double s_ttl[EG][NL];           // transport times
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b0 = blockIdx.x * EG;
     const int lane = threadIdx.x & 63;
@@ -477,18 +528,18 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 #ifdef MTFJSP_STAMP
     rt[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (b0 + grp < P.B) env_grp_wave<OBS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp], s_mp[grp], s_sdf[grp], s_ttl[grp], rt);
+    if (b0 + grp < P.B) env_grp_wave<OBS, NS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp], s_mp[grp], s_sdf[grp], s_ttl[grp], rt);
     __syncthreads();
 #ifdef MTFJSP_STAMP
     rt[5] = __builtin_amdgcn_s_memrealtime();
 #endif
     // two scalar-part waves (on different SIMDs): rewards / scaler / machine row | ELL rows + job mask
     if (grp == 0) {
-        const EnvGrpRegAcc acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
+        const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
         env_grp_tail<OBS>(P, b0, lane, EG, acc);
     } else if (grp == 1) {
-        const EnvGrpRegAcc acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
-        env_grp_ell<OBS>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl);
+        const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
+        env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl);
         env_grp_mask(P, b0, lane, EG, acc);
     }
 #ifdef MTFJSP_STAMP
@@ -502,6 +553,11 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
     (void)rt;
 }
 template <typename OBS>
-__global__ __launch_bounds__(EG_SMALL * WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_grp16(EnvParams P) { env_grp_body<OBS, EG_SMALL>(P); }
+__global__ __launch_bounds__(EG_SMALL * WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_grp16(EnvParams P) { env_grp_body<OBS, EG_SMALL, 1>(P); }
 template <typename OBS>
-__global__ __launch_bounds__(EG_LARGE * WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_env_grp4(EnvParams P) { env_grp_body<OBS, EG_LARGE>(P); }
+__global__ __launch_bounds__(EG_LARGE * WAVE) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_env_grp4(EnvParams P) { env_grp_body<OBS, EG_LARGE, 1>(P); }
+// two task slots per lane: 64 < T <= 128, M*M <= 128, M <= 16 (J10M10 and the like)
+template <typename OBS>
+__global__ __launch_bounds__(EG_SMALL * WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_grp16x2(EnvParams P) { env_grp_body<OBS, EG_SMALL, 2>(P); }
+template <typename OBS>
+__global__ __launch_bounds__(EG_LARGE * WAVE) void k_env_grp4x2(EnvParams P) { env_grp_body<OBS, EG_LARGE, 2>(P); }

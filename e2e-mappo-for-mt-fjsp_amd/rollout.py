@@ -118,9 +118,13 @@ class Rollout:
     def env_kernel_name(self):
         """which step kernel mtfjsp_step dispatches to for this shape (csrc/mtfjsp_env.hip launch selection)"""
         force = os.environ.get("MTFJSP_ENV_KERNEL", "")
-        small = self.T <= 64 and self.M * self.M <= 64 and self.J <= 64 and not os.environ.get("MTFJSP_ENV_LDS") and force != "lds"
-        if not small:
-            return "k_env_step"
+        lds = bool(os.environ.get("MTFJSP_ENV_LDS")) or force in ("lds", "lds1")
+        one = self.T <= 64 and self.M * self.M <= 64 and self.J <= 64 and not lds
+        two = (not one) and self.T <= 128 and self.M * self.M <= 128 and self.M <= 16 and self.J <= 64 and not lds and force != "reg1"
+        if two:
+            return "k_env_grp16x2" if (force == "grp16" or (force != "grp4" and self.B <= 4096)) else "k_env_grp4x2"
+        if not one:
+            return "k_env_step" if force == "lds1" else "k_env_step_grp"
         if force == "reg1":
             return "k_env_reg"
         return "k_env_grp16" if (force == "grp16" or (force != "grp4" and self.B <= 8192)) else "k_env_grp4"

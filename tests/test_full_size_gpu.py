@@ -128,10 +128,24 @@ def test_j20m20e4_2048_sampled_vs_oracle():
 
 @pytest.mark.parametrize("size", [(10, 10, 2, 1001), (20, 20, 4, 203)])
 def test_one_instance_lds_kernel_vs_oracle(size, monkeypatch):
-    """k_env_step (one instance per workgroup), which the grouped LDS kernel replaced as the default of these shapes"""
+    """k_env_step (one instance per workgroup), which the grouped kernels replaced as the default of these shapes"""
     monkeypatch.setenv("MTFJSP_ENV_KERNEL", "lds1")
     J, M, E, B = size
     _run(J, M, E, B, 7, seed=4)
+
+
+@pytest.mark.parametrize("kernel", ["grp16", "grp4", "lds"])
+def test_j10m10e2_every_step_kernel_vs_oracle(kernel, monkeypatch):
+    """J10M10 (T = 100: two task slots per lane in the register kernels): 16 / 4 instances per workgroup and the grouped LDS
+    kernel, every instance against the oracle; 1001 instances: a partly filled last group"""
+    monkeypatch.setenv("MTFJSP_ENV_KERNEL", kernel)
+    _run(10, 10, 2, 1001, 1, seed=5)
+
+
+def test_two_slot_register_kernel_other_shapes(monkeypatch):
+    """T = 72 (J12M6), T = 128 (J16M8) and T = 121 (J11M11, M*M = 121 transport entries, M > 8 route prefix)"""
+    for J, M, E, B in ((12, 6, 2, 130), (16, 8, 2, 67), (11, 11, 1, 35)):
+        _run(J, M, E, B, 1, seed=6)
 
 
 def test_encoder_full_batch_permutation_equivariance():
