@@ -3186,9 +3186,11 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     // the heads kernel does BatchNorm+ReLU, graph pool and candidate gather itself — while T is small: a workgroup pools 16
-    // instances with 512 threads, which is too little parallelism for 400-row instances (J20M20: 199 vs 81+113 us measured)
+    // instances with 512 threads, which is too little parallelism for 100- or 400-row instances (measured: J20M20 x 2048 199 vs
+    // 81+113 us; J10M10 x 8192 job+machine heads 264 us fused vs 110 + 130 us with the stand-alone pool/gather kernel)
     const bool resident = !e->bn_mode && e->res_ok && !(e->f32_products & (1 | 8 | 16));
-    const bool fuse_pool = !e->bn_mode && !resident && !h_nodes && e->T <= 128;
+    static const int fuse_maxT = getenv("MTFJSP_FUSE_POOL_MAXT") ? atoi(getenv("MTFJSP_FUSE_POOL_MAXT")) : 64;   // (J10M10 x 8192: 264 us fused, 240 us apart)
+    const bool fuse_pool = !e->bn_mode && !resident && !h_nodes && e->T <= fuse_maxT;
     rc = e->bn_mode ? run_gin_inst(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
          : resident ? run_gin_resident(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
                     : run_gin(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, fuse_pool ? nullptr : h_pooled, e->cand_feat, h_nodes);
