@@ -1996,13 +1996,23 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(int B, int T, int J, co
         mean[q] = (float)mean_d; rstd[q] = 1.0f / sqrtf((float)(var + BN_EPS)); g[q] = gamma[c]; be[q] = beta[c];
     }
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int v = rg; v < T; v += 8) {
-        const size_t off = ((size_t)b * T + v) * HD + c4;
-        const float4 x = *reinterpret_cast<const float4 *>(z + off);
-        float hv[4] = {bn_relu(x.x, mean[0], rstd[0], g[0], be[0]), bn_relu(x.y, mean[1], rstd[1], g[1], be[1]),
-                       bn_relu(x.z, mean[2], rstd[2], g[2], be[2]), bn_relu(x.w, mean[3], rstd[3], g[3], be[3])};
-        for (int q = 0; q < 4; q++) acc[q] += hv[q];
-        if (h_nodes) *reinterpret_cast<float4 *>(h_nodes + off) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+    for (int v0 = rg; v0 < T; v0 += 32) {                                          // four rows in flight per thread (same summation order)
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int v = v0 + 8 * u;
+            x[u] = v < T ? *reinterpret_cast<const float4 *>(z + ((size_t)b * T + v) * HD + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int v = v0 + 8 * u;
+            if (v < T) {
+                float hv[4] = {bn_relu(x[u].x, mean[0], rstd[0], g[0], be[0]), bn_relu(x[u].y, mean[1], rstd[1], g[1], be[1]),
+                               bn_relu(x[u].z, mean[2], rstd[2], g[2], be[2]), bn_relu(x[u].w, mean[3], rstd[3], g[3], be[3])};
+                for (int q = 0; q < 4; q++) acc[q] += hv[q];
+                if (h_nodes) *reinterpret_cast<float4 *>(h_nodes + ((size_t)b * T + v) * HD + c4) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+            }
+        }
     }
     for (int q = 0; q < 4; q++) s_part[rg][c4 + q] = acc[q];
     for (int jj = rg; jj < J; jj += 8) {                                           // candidate gather (ac:197-207); J = 0: skipped
