@@ -495,6 +495,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define X6_ROWB 272
 #define X6_PLANE (16 * X6_ROWB)
 #define X6_TILE (3 * X6_PLANE)
+#define X6_TRB (16 * 144)                   // k_gemm_x6: a consumer wave's output transposition buffer (16 rows x 128 B, 144-byte pitch)
+#define X6_TR_OFF (8 * X6_TILE + 2 * HD * 8 + 2 * HD * 4 + 64)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // exact 3-way split of four f32 values into bf16 pieces (round-to-nearest-even), two packed dwords per plane
@@ -771,6 +773,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 #pragma unroll
             for (int i = 0; i < 4; i++) { ts[c][i] = 0.f; tq[c][i] = 0.f; }
         const unsigned char *xa0 = s_tiles + m * X6_ROWB + 16 * q; // operand fragment (slot t, plane p, k-step ks): + t*XT + p*X6_PLANE + 64*ks
+        unsigned char *s_tr = smem + X6_TR_OFF + cg * 2 * X6_TRB;  // this wave's two output transposition buffers
         LDS_BARRIER();                                            // step 0: the producers fill buffer 0
         STAMP(4);
         for (int s = 1; s <= nsteps; s++) {
@@ -817,13 +820,23 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                     for (int c = 0; c < 2; c++) acc[c] = acc[c] * wsinv + biasv[c];
                     const int row = (tb + t) * 16 + m;
                     const bool ok = FULL || row < A.N;
-                    float *ob = A.out + (size_t)row * HD + 32 * cg + 4 * q;
+                    // stores as WHOLE 128-byte lines: the accumulator layout gives a lane two 16-byte chunks (q and 4 + q) of row m's 128
+                    // bytes of this wave, i.e. 16 rows x 64 bytes per store instruction — measured 2.35 TB/s against 3.24 TB/s for 8
+                    // rows x 128 bytes (tools/ubench/store_patterns.hip).  The wave's tile goes through a private LDS buffer
+                    // (144-byte row pitch: conflict-free both ways; LDS executes a wave's instructions in order).
+                    unsigned char *trb = s_tr + (t & 1) * X6_TRB;
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
                         const f32x4 v = acc[c];
-                        *reinterpret_cast<float4 *>(ob + 16 * c) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4 *>(trb + m * 144 + 16 * (4 * c + q)) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
                         for (int i = 0; i < 4; i++) { const float x = ok ? v[i] : 0.f; ts[c][i] += x; tq[c][i] = __builtin_fmaf(x, x, tq[c][i]); }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 2; i++) {
+                        const int r8 = 8 * i + (lane >> 3);
+                        const float4 v = *reinterpret_cast<const float4 *>(trb + r8 * 144 + 16 * (lane & 7));
+                        *reinterpret_cast<float4 *>(A.out + ((size_t)(tb + t) * 16 + r8) * HD + 32 * cg + 4 * (lane & 7)) = v;
                     }
                 }
             };
@@ -857,7 +870,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
 #endif
 }
-static size_t gemm_x6_lds_bytes() { return (size_t)8 * X6_TILE + 2 * HD * 8 + 2 * HD * 4 + 64; }
+static size_t gemm_x6_lds_bytes() { return (size_t)X6_TR_OFF + 4 * 2 * X6_TRB; }
 
 #include "mtfjsp_gin_resident.h"
 
@@ -2867,6 +2880,7 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
     b.stamps = d_st;
 #endif
     if constexpr (PRO == PRO_PLAIN) hipLaunchKernelGGL((k_gemm16<EPI, ACC>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
+    else if constexpr (PRO == PRO_GIN0) hipLaunchKernelGGL((k_gemm_x6<PRO>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
     else {
         if (b.Wx6 && !(e->f32_products & 1)) hipLaunchKernelGGL((k_gemm_x6<PRO>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
         else hipLaunchKernelGGL((k_gemm16p<PRO>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
@@ -2915,15 +2929,11 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     const double invN = 1.0 / (double)N;
     const int pgrid = e->num_cu * 8;
     if (!(e->f32_products & 8)) {   // layer 0 / linear 0 with aggregation of the raw features, on the producer/consumer product kernel
-        Timed t(e, "gin0_agg_linear12");
         GemmArgs a = gemm_args(nullptr, N, nullptr, W(P + "mlps.0.linears.0.bias"), e->zA);
         a.tfea = tasks_fea; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64; a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
         a.epi_stats = st + 0 * STAT_REP * 256;
         a.Wx6 = e->wx6.at(P + "mlps.0.linears.0.weight"); a.w_sinv = 1.0f;
-        const int ntiles = (N + 15) / 16;
-        int grid = (ntiles + 7) / 8;
-        if (grid > e->num_cu) grid = e->num_cu;
-        hipLaunchKernelGGL((k_gemm_x6<PRO_GIN0>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, a);
+        launch_gemm<PRO_GIN0, EPI_STATS>(e, a, "gin0_agg_linear12");
     } else {
         Timed t(e, "gin0_agg_linear12");
         if (e->cfg.obs_dtype == MTFJSP_OBS_F32)

@@ -26,19 +26,31 @@ __global__ __launch_bounds__(512) void k_b(float *out, int rows_per_wg)
             *reinterpret_cast<float4 *>(ob) = make_float4(1.f, 2.f, 3.f, (float)t);
         }
 }
+// C = whole 128-byte lines: per instruction 8 rows x 128 bytes (a wave's 32 columns of 8 rows, after a cross-lane exchange)
+__global__ __launch_bounds__(512) void k_c(float *out, int rows_per_wg)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (wave >= 4) return;
+    const size_t row0 = (size_t)blockIdx.x * rows_per_wg;
+    for (int t = 0; t < rows_per_wg / 16; t++)
+        for (int i = 0; i < 2; i++) {
+            float *ob = out + (row0 + t * 16 + 8 * i + (lane >> 3)) * 128 + 32 * wave + 4 * (lane & 7);
+            *reinterpret_cast<float4 *>(ob) = make_float4(1.f, 2.f, 3.f, (float)t);
+        }
+}
 int main()
 {
     const size_t rows = 819200;
     float *d; hipMalloc(&d, rows * 512);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int which = 0; which < 2; which++) {
+    for (int which = 0; which < 3; which++) {
         const int grid = 256, rpw = (int)(rows / grid);
-        for (int rep = 0; rep < 3; rep++) { if (which) hipLaunchKernelGGL(k_b, dim3(grid), dim3(512), 0, 0, d, rpw); else hipLaunchKernelGGL(k_a, dim3(grid), dim3(512), 0, 0, d, rpw); }
+        for (int rep = 0; rep < 3; rep++) { if (which == 2) hipLaunchKernelGGL(k_c, dim3(grid), dim3(512), 0, 0, d, rpw); else if (which) hipLaunchKernelGGL(k_b, dim3(grid), dim3(512), 0, 0, d, rpw); else hipLaunchKernelGGL(k_a, dim3(grid), dim3(512), 0, 0, d, rpw); }
         hipEventRecord(e0, 0);
-        for (int rep = 0; rep < 10; rep++) { if (which) hipLaunchKernelGGL(k_b, dim3(grid), dim3(512), 0, 0, d, rpw); else hipLaunchKernelGGL(k_a, dim3(grid), dim3(512), 0, 0, d, rpw); }
+        for (int rep = 0; rep < 10; rep++) { if (which == 2) hipLaunchKernelGGL(k_c, dim3(grid), dim3(512), 0, 0, d, rpw); else if (which) hipLaunchKernelGGL(k_b, dim3(grid), dim3(512), 0, 0, d, rpw); else hipLaunchKernelGGL(k_a, dim3(grid), dim3(512), 0, 0, d, rpw); }
         hipEventRecord(e1, 0); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("%s: %.1f us per launch, %.2f TB/s (%zu MB, 256 workgroups x 4 storing waves)\n", which ? "B full rows (1 KB contiguous per instruction)" : "A accumulator layout (16 x 64 B per instruction)",
+        printf("%s: %.1f us per launch, %.2f TB/s (%zu MB, 256 workgroups x 4 storing waves)\n", which == 2 ? "C whole lines (8 x 128 B per instruction)" : which ? "B full rows (1 KB contiguous per instruction)" : "A accumulator layout (16 x 64 B per instruction)",
                ms * 100, rows * 512 / (ms / 10 * 1e-3) / 1e12, rows * 512 >> 20);
     }
     return 0;
