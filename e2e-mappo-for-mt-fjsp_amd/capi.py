@@ -85,6 +85,7 @@ PROTOTYPES = {
     "mtfjsp_sample_categorical": (_I, [_VP, _VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
     "mtfjsp_encoder_set_bn_mode": (_I, [_VP, C.c_int32]),
     "mtfjsp_encoder_set_product_mode": (_I, [_VP, C.c_int32]),
+    "mtfjsp_encoder_set_stats_reduce": (_I, [_VP, C.c_void_p, _VP, C.c_int64]),
     "mtfjsp_get_mfea1_context": (_I, [_VP, _VP, _VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_mfea1": (_I, [_VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_selection": (_I, [_VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),

@@ -2429,6 +2429,8 @@ struct mtfjsp_encoder {
     bool gin_stats_clean = false;           // slots 0..5 are zero (the job-actor heads kernel zeroes them after their last reader)
     bool gat_stats_clean[2] = {false, false};
     int bn_mode = 0;                        // 0: BatchNorm statistics over the whole device batch; 1: per instance (validate.py semantics)
+    mtfjsp_stats_reduce_fn reduce_fn = nullptr; void *reduce_user = nullptr;   // exact multi-shard BatchNorm: sums of every BN summed over the shards
+    double reduce_scale = 1.0;              // global rows / local rows
     // which products run with the f32 matrix instruction instead of the exact bf16 split (A/B reference; bits: 1 GIN products,
     // 2 GAT passes, 4 heads, 8 first GIN Linear on the VALU); default from MTFJSP_GEMM_F32MFMA / _GAT_ / _HEADS_ / MTFJSP_GIN0_VALU
     int f32_products = (getenv("MTFJSP_GEMM_F32MFMA") ? 1 : 0) | (getenv("MTFJSP_GAT_F32MFMA") ? 2 : 0) |
@@ -2916,6 +2918,7 @@ static GemmArgs gemm_args(const float *in, int N, const float *Wt, const float *
 
 // GIN encoder (gcn:109-197) with the weights under `pre` ("job_actor." / "global_critic."), followed by the graph mean
 // pool and (optionally) the candidate gather.  Uses BatchNorm accumulator slots 0..5.
+static int reduce_stats(mtfjsp_encoder *e, double *st);
 static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
                    const int32_t *candidate, int J, float *h_pooled, float *cand_feat, float *h_nodes)
 {
@@ -2926,14 +2929,16 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     double *st = e->stats;
     if (!e->gin_stats_clean) HIPCHK(e, hipMemsetAsync(st, 0, 6 * STAT_REP * 256 * sizeof(double), e->stream));
     e->gin_stats_clean = false; e->gin_slot5_dirty = false;
-    const double invN = 1.0 / (double)N;
+    const double invN = 1.0 / ((double)N * e->reduce_scale);      // (exact multi-shard BatchNorm: rows of all shards)
     const int pgrid = e->num_cu * 8;
+    int rrc = 0;
     if (!(e->f32_products & 8)) {   // layer 0 / linear 0 with aggregation of the raw features, on the producer/consumer product kernel
         GemmArgs a = gemm_args(nullptr, N, nullptr, W(P + "mlps.0.linears.0.bias"), e->zA);
         a.tfea = tasks_fea; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64; a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
         a.epi_stats = st + 0 * STAT_REP * 256;
         a.Wx6 = e->wx6.at(P + "mlps.0.linears.0.weight"); a.w_sinv = 1.0f;
         launch_gemm<PRO_GIN0, EPI_STATS>(e, a, "gin0_agg_linear12");
+        if ((rrc = reduce_stats(e, st + 0 * STAT_REP * 256))) return rrc;
     } else {
         Timed t(e, "gin0_agg_linear12");
         if (e->cfg.obs_dtype == MTFJSP_OBS_F32)
@@ -2949,6 +2954,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         a.epi_stats = st + sout * STAT_REP * 256;
         a.Wx6 = e->wx6.at(P + lin + ".weight"); a.w_sinv = e->wx6_sinv.at(P + lin + ".weight");
         launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_bn_relu");
+        if (!rrc) rrc = reduce_stats(e, st + sout * STAT_REP * 256);
     };
     bn_gemm(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1);
     bn_gemm(e->zB, e->zA, 1, "mlps.0.batch_norms.1", "mlps.0.linears.2", 2);
@@ -2959,9 +2965,11 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         a.epi_stats = st + 3 * STAT_REP * 256;
         a.Wx6 = e->wx6.at(P + "mlps.1.linears.0.weight"); a.w_sinv = e->wx6_sinv.at(P + "mlps.1.linears.0.weight");
         launch_gemm<PRO_AGG, EPI_STATS>(e, a, "gin_gemm_agg");
+        if (!rrc) rrc = reduce_stats(e, st + 3 * STAT_REP * 256);
     }
     bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4);
     bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5);
+    if (rrc) return rrc;
     if (h_pooled) {                                               // h_pooled == NULL: the consumer (k_heads) normalises, pools and gathers itself
         Timed t(e, "job_pool_gather");
         hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(256), 0, e->stream, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
@@ -3099,9 +3107,13 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
         }
 #endif
     }
+    {
+        const int rrc = reduce_stats(e, st);                                     // exact multi-shard BatchNorm of the machine nodes
+        if (rrc) return rrc;
+    }
     if (h_pooled) {
         Timed t(e, "mach_bn_pool");
-        hipLaunchKernelGGL(k_mach_bn_pool, dim3(B), dim3(128), 0, e->stream, B, M, e->node, st, 1.0 / (double)R, W(pre + "bn.weight"),
+        hipLaunchKernelGGL(k_mach_bn_pool, dim3(B), dim3(128), 0, e->stream, B, M, e->node, st, 1.0 / ((double)R * e->reduce_scale), W(pre + "bn.weight"),
                            W(pre + "bn.bias"), h_pooled);
     }
     HIPCHK(e, hipGetLastError());
@@ -3149,6 +3161,21 @@ extern "C" int mtfjsp_encoder_set_product_mode(mtfjsp_encoder_t e, int32_t f32_i
 {
     if (!e || f32_instruction_mask < 0 || f32_instruction_mask > 31) return MTFJSP_ERR_ARG;
     e->f32_products = f32_instruction_mask;
+    return MTFJSP_OK;
+}
+// exact multi-shard BatchNorm: after the launch that completes a BatchNorm's column sums, hand them to the caller's reduction
+static int reduce_stats(mtfjsp_encoder *e, double *st)
+{
+    if (!e->reduce_fn) return MTFJSP_OK;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->reduce_fn(e->reduce_user, st, STAT_REP * 256) != 0) { e->err = "the BatchNorm statistics reduction callback failed"; return MTFJSP_ERR_STATE; }
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_encoder_set_stats_reduce(mtfjsp_encoder_t e, mtfjsp_stats_reduce_fn fn, void *user, int64_t global_batch)
+{
+    if (!e || (fn && global_batch < e->cfg.batch)) return MTFJSP_ERR_ARG;
+    e->reduce_fn = fn; e->reduce_user = user;
+    e->reduce_scale = fn ? (double)global_batch / (double)e->cfg.batch : 1.0;
     return MTFJSP_OK;
 }
 extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance)
@@ -3208,7 +3235,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     // the heads kernel does BatchNorm+ReLU, graph pool and candidate gather itself — while T is small: a workgroup pools 16
     // instances with 512 threads, which is too little parallelism for 100- or 400-row instances (measured: J20M20 x 2048 199 vs
     // 81+113 us; J10M10 x 8192 job+machine heads 264 us fused vs 110 + 130 us with the stand-alone pool/gather kernel)
-    const bool resident = !e->bn_mode && e->res_ok && !(e->f32_products & (1 | 8 | 16));
+    const bool resident = !e->bn_mode && e->res_ok && !e->reduce_fn && !(e->f32_products & (1 | 8 | 16));   // (a cross-shard reduction cannot happen inside the single launch)
     static const int fuse_maxT = getenv("MTFJSP_FUSE_POOL_MAXT") ? atoi(getenv("MTFJSP_FUSE_POOL_MAXT")) : 64;   // (J10M10 x 8192: 264 us fused, 240 us apart)
     const bool fuse_pool = !e->bn_mode && !resident && !h_nodes && e->T <= fuse_maxT;
     rc = e->bn_mode ? run_gin_inst(e, "job_actor.", tasks_fea, ell_col, ell_val, candidate, J, h_pooled, e->cand_feat, h_nodes)
@@ -3237,7 +3264,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
             const std::string P = "job_actor.encoder.feature_extract.";
             ha.X = e->zB; ha.pooled = nullptr; ha.pooled_out = h_pooled; ha.xgather = candidate; ha.xT = e->T; ha.xrelu = 1;
             ha.xbn_stats = e->stats + 5 * STAT_REP * 256; ha.xbn_gamma = W(P + "batch_norms.1.weight"); ha.xbn_beta = W(P + "batch_norms.1.bias");
-            ha.xbn_inv_rows = 1.0 / ((double)B * (double)e->T);
+            ha.xbn_inv_rows = 1.0 / ((double)B * (double)e->T * e->reduce_scale);
             ha.zero_stats = e->stats; ha.zero_count = 5 * STAT_REP * 256;    // slots 0..4 are consumed; slot 5 is being read by this very
             e->gin_slot5_dirty = true;                                       // kernel and is zeroed by the machine heads (or a memset)
         } else if (!e->bn_mode && !resident) {
@@ -3294,7 +3321,7 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
         else {
             ha.pooled = nullptr;
             ha.xbn_stats = e->stats + (6 + slot) * STAT_REP * 256; ha.xbn_gamma = W("machine_actor.bn.weight"); ha.xbn_beta = W("machine_actor.bn.bias");
-            ha.xbn_inv_rows = 1.0 / (double)R; ha.pooled_out = h_pooled;
+            ha.xbn_inv_rows = 1.0 / ((double)R * e->reduce_scale); ha.pooled_out = h_pooled;
             ha.zero_stats = e->stats + (6 + (slot ^ 1)) * STAT_REP * 256; ha.zero_count = STAT_REP * 256;   // the slot of the next machine forward
             e->gat_stats_clean[slot ^ 1] = true;
             if (e->gin_slot5_dirty) {                                 // left by a job forward that pooled inside its heads kernel
@@ -3341,7 +3368,7 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
     const int B = e->cfg.batch;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
-    const bool resident = e->res_ok && !(e->f32_products & (1 | 8 | 16));
+    const bool resident = e->res_ok && !e->reduce_fn && !(e->f32_products & (1 | 8 | 16));
     int rc = resident ? run_gin_resident(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr)
                       : run_gin(e, "global_critic.", tasks_fea, ell_col, ell_val, nullptr, 0, e->pooled_int, e->cand_feat, nullptr);
     if (rc) return rc;
@@ -3401,7 +3428,7 @@ extern "C" int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_ou
     if (!e) return MTFJSP_ERR_ARG;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (gin_resident_out) *gin_resident_out = (e->res_ok && !(e->f32_products & (1 | 8 | 16))) ? 1 : 0;
+    if (gin_resident_out) *gin_resident_out = (e->res_ok && !e->reduce_fn && !(e->f32_products & (1 | 8 | 16))) ? 1 : 0;
     if (e->res_ok) {
         unsigned failed = 0;
         HIPCHK(e, hipMemcpy(&failed, e->res_fail, 4, hipMemcpyDeviceToHost));

@@ -78,3 +78,29 @@ def normalize_advantages_global(adv_local, group=None, eps=1e-5):
     full = all_gather_columns(adv_local, group)
     mean, std = full.mean(), full.std()
     return (adv_local - mean) / (std + eps)
+
+
+class _DeviceF64:
+    """`count` doubles at a raw device address, as something torch.as_tensor(..., device="cuda") can wrap without a copy"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 3, "strides": None}
+
+
+def bn_stats_allreduce(group=None):
+    """reduction callback for Encoder.set_stats_reduce: the BatchNorm column sums of a layer, summed over the ranks of `group`
+    in place (RCCL directly on the device buffer; with a CPU backend such as gloo through a host copy).  SURVEY §8e's
+    optional exact big-batch BatchNorm: 7 all-reduces of 2048 doubles per actor-pair forward."""
+    import torch
+    import torch.distributed as td
+
+    def fn(ptr, count):
+        t = torch.as_tensor(_DeviceF64(ptr, count), device="cuda")
+        if td.get_backend(group) == "nccl":
+            td.all_reduce(t, group=group)
+        else:
+            c = t.cpu()
+            td.all_reduce(c, group=group)
+            t.copy_(c)
+        torch.cuda.synchronize()
+    return fn

@@ -144,6 +144,27 @@ class Encoder:
         single-launch kernel is eligible (check() tells which one runs)"""
         capi.check(self.L.mtfjsp_encoder_set_product_mode(self.h, int(f32_instruction_mask)), self.h, enc=True)
 
+    def set_stats_reduce(self, fn, global_batch=0):
+        """exact big-batch BatchNorm over several shards (include/mtfjsp.h): fn(ptr, count) replaces the `count` f64 values at
+        DEVICE address ptr by their sum over the shards (dist.bn_stats_allreduce() builds one on torch.distributed);
+        global_batch = instances of all shards.  fn = None switches it off."""
+        if fn is None:
+            capi.check(self.L.mtfjsp_encoder_set_stats_reduce(self.h, None, None, 0), self.h, enc=True)
+            self._reduce_cb = None
+            return
+
+        def tramp(user, ptr, n):
+            try:
+                fn(int(ptr), int(n))
+                return 0
+            except Exception:                                       # a Python exception must not unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._reduce_cb = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32)(tramp)
+        capi.check(self.L.mtfjsp_encoder_set_stats_reduce(self.h, C.cast(self._reduce_cb, C.c_void_p), None, int(global_batch)), self.h, enc=True)
+
     def check(self):
         """synchronise and raise if a forward failed asynchronously (bounded grid-barrier spins of the single-launch GIN kernel);
         -> True when that kernel is in use for this shape, False when the six streaming launches are"""

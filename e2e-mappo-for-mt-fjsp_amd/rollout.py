@@ -26,11 +26,14 @@ def actor_available():
 class Rollout:
     def __init__(self, n_job, n_machine, n_edge, batch, device=0, policy="random", obs_dtype="f32",
                  instance_seed=0, rank=0, world=1, weights=None, w3_pool_episodes=32, greedy=False, seed=1234,
-                 buffer_episodes=5, gamma=0.99, lam=0.98, collect=True, instances=None, w3_episodes=None, w3="device"):
+                 buffer_episodes=5, gamma=0.99, lam=0.98, collect=True, instances=None, w3_episodes=None, w3="device",
+                 exact_bn=False):
         """instances: (t, p, tt, edge) host arrays for THIS shard; default = rows [rank*batch, (rank+1)*batch) of the
         reference generator's `Instance_Dataset(samples=world*batch, seed=instance_seed)` (every
         instance distinct).  w3_episodes: [n,B,3] reward weights to use episode by episode (tests); otherwise w3 = "device"
-        (default) or "host", see below."""
+        (default) or "host", see below.  exact_bn (world > 1, torch.distributed initialised): every BatchNorm of the actor
+        forwards normalises over the rows of ALL shards (one small all-reduce per BatchNorm, streaming GIN launches) instead of
+        per shard — the reference's semantics for env_batch = world*batch; off by default."""
         self.J, self.M, self.E, self.B = n_job, n_machine, n_edge, batch
         self.T = n_job * n_machine
         self.policy = policy
@@ -107,6 +110,9 @@ class Rollout:
             from . import encoder
             self.actor = encoder.ActorPair(n_job, n_machine, batch, device=device, obs_dtype=obs_dtype, weights=weights,
                                            greedy=greedy, seed=self.seed)
+            if exact_bn and world > 1:
+                from . import dist as _dist
+                self.actor.enc.set_stats_reduce(_dist.bn_stats_allreduce(), world * batch)
 
     def describe(self):
         if self.policy == "actor":

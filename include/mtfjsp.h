@@ -248,6 +248,15 @@ int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask
  * per_instance = 1: over the rows of ONE instance = B independent reference runs with env_batch = 1, i.e. the greedy
  * evaluation of validate.py:60-297 batched over the evaluation set.  Not applied to the global critic. */
 int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance);
+/* Exact big-batch BatchNorm over several shards (optional): with a reduction callback set, every BatchNorm of the
+ * forwards normalises over the rows of ALL shards.  After the launch that completes a BatchNorm's column sums the library
+ * synchronises its stream and calls fn(user, sums, count): `sums` is DEVICE memory holding `count` doubles, which the callback
+ * replaces by their element-wise sum over the shards (e.g. one all-reduce) and returns 0 once that is in place.
+ * global_batch = instances of all shards together (>= this handle's batch).  7 calls per actor pair forward; the GIN encoder
+ * then runs as its six streaming launches (the single-launch kernel cannot exchange data mid-launch).  fn = NULL: off.  Per-shard
+ * statistics (the default) are what DESIGN.md §7 describes: each GPU behaves like a reference run with env_batch = its shard. */
+typedef int (*mtfjsp_stats_reduce_fn)(void *user, double *sums, int32_t count);
+int mtfjsp_encoder_set_stats_reduce(mtfjsp_encoder_t e, mtfjsp_stats_reduce_fn fn, void *user, int64_t global_batch);
 /* How the [rows,128]x[128,128] products of the actor forwards (Linear layers of gcn:95-153 / ac:205-293, the GAT weight of
  * gat:82) are formed.  0 (default): on the 16-bit matrix cores with f32 accumulation, from f32 operands split into two f16
  * pieces (relative representation error <= 2^-22; weights pre-scaled by a power of two) and the three significant piece
