@@ -315,7 +315,13 @@ class ActorPair:
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "executed_matrix_flops_per_launch": executed,
                     "algorithmic_flops_per_launch": flops, "f32_equivalent_TFLOPs": flops / avg_s / 1e12,
                     "f32_equivalent_frac_of_f32_matrix_peak_157.3": flops / avg_s / 1e12 / 157.3,
-                    "hbm_bytes_algorithmic_per_launch": rows * (12 * 4 + 16) + B * (H + J * H) * 4}
+                    "hbm_bytes_algorithmic_per_launch": rows * (12 * 4 + 16) + B * (H + J * H) * 4,
+                    # SURVEY §8(d) prices the job encoder at 64*T + 6 BatchNorm boundaries x 1024*T + 512*(J+1) bytes per env-step,
+                    # i.e. WITH the [rows,128] f32 activations written and re-read at every boundary; this kernel keeps them in
+                    # registers, so the same work priced on those bytes exceeds what a streaming design could reach
+                    "survey_8d_job_encoder_bytes_per_launch": B * (64 * T + 6 * 1024 * T + 512 * (J + 1)),
+                    "survey_8d_bytes_over_time_GBps": B * (64 * T + 6 * 1024 * T + 512 * (J + 1)) / avg_s / 1e9,
+                    "survey_8d_bytes_over_time_frac_of_hbm_peak": B * (64 * T + 6 * 1024 * T + 512 * (J + 1)) / avg_s / 1e9 / 8000.0}
         if name == "gat3":
             rows = 2 * B * M
             flops = 2.0 * rows * H * H * 3
