@@ -21,6 +21,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the cpu_baseline legs pin their OpenMP threads (one place per physical core); read when the first libgomp loads
+os.environ.setdefault("OMP_PLACES", "cores")
+os.environ.setdefault("OMP_PROC_BIND", "spread")
 
 import numpy as np
 import torch
@@ -92,46 +95,74 @@ def cpu_model():
     return platform.processor() or platform.machine()
 
 
-def cpu_baseline(J, M, E, seconds_per_leg=6.0):
+def cpu_topology():
+    """(logical CPUs this process may run on, physical cores among them) from /proc/cpuinfo + the affinity mask"""
+    try:
+        allowed = set(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = set(range(os.cpu_count() or 1))
+    cores, cur = set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in allowed:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in allowed:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+    except (OSError, ValueError):
+        pass
+    n = len(allowed)
+    return n, (len(cores) if cores else n)
+
+
+def cpu_baseline(J, M, E, batch=4096, seconds_per_leg=5.0):
     """The CPU oracle port (oracle/mtfjsp_oracle.c) timed on the host cores, SURVEY §8d leg (ii): per env and step what the
-    reference's batched step does per env (env.step + RewardScaling + candidate/job-mask update + observation), random valid
-    actions chosen in C.  Three legs on bounded samples of the same generator stream as the GPU workload: one thread and
-    all cores (OpenMP over instances) at B = 1024, and BASELINE config 0's batch (B = 16) on one thread.  Environment only:
-    the GPU `value` additionally contains both actor forwards, sampling and m_fea1 — compare it with `roofline_env_step`'s
-    env-steps/s for like with like."""
+    reference's batched step does per env (env.step + RewardScaling + candidate/job-mask update + observation; pe:229-265),
+    random valid actions chosen in C, on the GPU workload's own instances (the first `batch` of the same generator stream).
+    Envs are independent, so the multi-core legs give every thread a contiguous block of envs for whole episodes
+    (or_batch_bench_blocks: thread-local env copies, no per-step barrier).  Legs: one thread at the GPU's batch; all physical
+    cores; all hardware threads (when SMT is on); BASELINE config 0's batch (16) on one thread.  ENVIRONMENT ONLY: compare
+    with `roofline_env_step.env_steps_per_s`, not with `value` (which also contains both actor forwards)."""
     from oracle.env_oracle import OracleBatch, max_threads
     from importlib import import_module
     inst = import_module("e2e-mappo-for-mt-fjsp_amd.instances")
-    T = J * M
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
-    nthreads = max(1, min(ncores, max_threads()))
-    B = 1024
+    nlogical, ncores = cpu_topology()
+    cap = max(1, max_threads())
+    B = batch
     t, p, tt, edge = inst.generate_instances(B, J, M, E, seed=0)
     w3 = np.full((B, 3), 1.0 / 3)
 
-    def leg(batch, threads):
-        orc = OracleBatch(t[:batch], p[:batch], tt[:batch], edge[:batch])
-        orc.scaler_init()
-        n, sec, _ = orc.bench(1, threads, w3[:batch])                                  # calibrate (and warm the caches)
-        episodes = max(1, int(seconds_per_leg / max(sec, 1e-6)))
-        n, sec, sec_reset = orc.bench(episodes, threads, w3[:batch])
-        return {"env_steps_per_s": n / sec, "env_steps_per_s_incl_resets": n / sec_reset, "threads": threads, "batch": batch,
-                "episodes": episodes, "env_steps": n}
+    def leg(nb, threads):
+        threads = max(1, min(threads, cap, nb))
+        orc = OracleBatch(t[:nb], p[:nb], tt[:nb], edge[:nb])
+        n, wall, _ = orc.bench_blocks(1, threads, w3[:nb])                               # calibrate (and warm the caches)
+        episodes = max(1, min(20000, int(seconds_per_leg / max(wall, 1e-6))))
+        n, wall, steps = orc.bench_blocks(episodes, threads, w3[:nb])
+        return {"env_steps_per_s": n / wall, "env_steps_per_s_step_loops_only": n / steps, "threads": threads, "batch": nb,
+                "episodes": episodes, "env_steps": n, "seconds": wall}
 
     one = leg(B, 1)
-    allc = leg(B, nthreads) if nthreads > 1 else dict(one)
-    c1 = leg(16, 1)
-    best = max(one, allc, key=lambda d: d["env_steps_per_s"])
-    return {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
-            "cpu_model": cpu_model(), "nproc": ncores,
-            "single_thread": one, "all_cores": allc, "config0_B16_single_thread": c1,
-            "sample": f"J{J}M{M}E{E}: first {B} instances of Instance_Dataset(seed=0), {best['episodes']} episodes ({best['env_steps']} env-steps) per leg, "
-                      "ENVIRONMENT ONLY (step + reward scaling + job mask + ELL observation per env and step, random valid actions; "
-                      "no actor forwards) — oracle/mtfjsp_oracle.c -O2, OpenMP over instances; the reference's own Python path "
-                      "measured in the build container: tests/golden/reference_cpu_speed.txt (about 330 env-steps/s, 1 core)"}
+    phys = leg(B, ncores) if ncores > 1 else dict(one)
+    smt = leg(B, nlogical) if nlogical > ncores else None
+    c0 = leg(16, 1)
+    legs = [one, phys] + ([smt] if smt else [])
+    best = max(legs, key=lambda d: d["env_steps_per_s"])
+    out = {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
+           "cpu_model": cpu_model(), "logical_cpus": nlogical, "physical_cores": ncores,
+           "omp": {k: os.environ.get(k) for k in ("OMP_PLACES", "OMP_PROC_BIND")},
+           "single_thread": one, "all_cores": phys, "all_smt_threads": smt, "config0_B16_single_thread": c0,
+           "all_cores_over_single_thread": phys["env_steps_per_s"] / one["env_steps_per_s"],
+           "sample": f"J{J}M{M}E{E}: the first {B} instances of Instance_Dataset(seed=0) (the GPU's batch), {best['episodes']} episodes "
+                     f"({best['env_steps']} env-steps, {best['seconds']:.1f} s) in the reported leg; per-episode resets inside the timed region; "
+                     "ENVIRONMENT ONLY (step + reward scaling + job mask + ELL observation per env and step, random valid actions; no actor "
+                     "forwards) — compare with roofline_env_step.env_steps_per_s; oracle/mtfjsp_oracle.c -O2, every OpenMP thread owns a block "
+                     "of envs for whole episodes; the reference's own Python path measured in the build container: "
+                     "tests/golden/reference_cpu_speed.txt (about 330 env-steps/s, 1 core)"}
+    return out
 
 
 def main():

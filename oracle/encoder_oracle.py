@@ -51,11 +51,12 @@ def ell_from_dense(adj):
     return col, val
 
 
-def gin_encoder(w, tfea, ell_col, ell_val, B, T):
+def gin_encoder(w, tfea, ell_col, ell_val, B, T, dtype=torch.float32):
     """E1+E2: GraphCNN.forward with neighbor_pooling_type='average', learn_eps=False (gcn:109-197).
-    Aggregation in f64 on f32-representable inputs, then cast to f32 (gcn:125,244)."""
+    Aggregation in f64 on f32-representable inputs, then cast to f32 (gcn:125,244).
+    dtype=torch.float64: the same network in binary64 on the f32-rounded inputs and weights (yardstick, not the reference)."""
     pre = "encoder.feature_extract."
-    h = torch.as_tensor(np.asarray(tfea), dtype=torch.float64).float()          # ac:143 .float()
+    h = torch.as_tensor(np.asarray(tfea), dtype=torch.float64).float().to(dtype)  # ac:143 .float()
     col = torch.as_tensor(np.asarray(ell_col).reshape(B * T, 2), dtype=torch.long)
     val = torch.as_tensor(np.asarray(ell_val).reshape(B * T, 2), dtype=torch.float64).float().double()
     base = (torch.arange(B * T) // T * T).unsqueeze(1)
@@ -67,7 +68,7 @@ def gin_encoder(w, tfea, ell_col, ell_val, B, T):
         pooled = hd.clone()                                                      # self loop, weight 1
         for s in range(2):
             pooled = pooled + torch.where(has[:, s:s + 1], val[:, s:s + 1] * hd[gidx[:, s]], torch.zeros_like(hd))
-        pooled = (pooled / deg.unsqueeze(1)).float()
+        pooled = (pooled / deg.unsqueeze(1)).to(dtype)
         m = pre + f"mlps.{layer}."
         z = torch.relu(_bn(_lin(pooled, w, m + "linears.0"), w[m + "batch_norms.0.weight"], w[m + "batch_norms.0.bias"]))
         z = torch.relu(_bn(_lin(z, w, m + "linears.1"), w[m + "batch_norms.1.weight"], w[m + "batch_norms.1.bias"]))
@@ -77,10 +78,10 @@ def gin_encoder(w, tfea, ell_col, ell_val, B, T):
     return h, h_pooled
 
 
-def job_actor_forward(w, tfea, ell_col, ell_val, cand, mask, h_m_prev, B, T):
+def job_actor_forward(w, tfea, ell_col, ell_val, cand, mask, h_m_prev, B, T, dtype=torch.float32):
     """E3: Operation_Actor_JointAction_selfCritic.forward (ac:104-296), greedy + sampling-free outputs."""
-    w = {k: torch.as_tensor(v) for k, v in w.items()}
-    h, h_pooled = gin_encoder(w, tfea, ell_col, ell_val, B, T)
+    w = {k: torch.as_tensor(v).to(dtype) for k, v in w.items()}
+    h, h_pooled = gin_encoder(w, tfea, ell_col, ell_val, B, T, dtype=dtype)
     J = np.asarray(cand).shape[1]
     Hd = h.shape[1]
     cand_t = torch.as_tensor(np.asarray(cand), dtype=torch.long)
@@ -89,7 +90,7 @@ def job_actor_forward(w, tfea, ell_col, ell_val, cand, mask, h_m_prev, B, T):
     if h_m_prev is None or np.asarray(h_m_prev).size == 0:
         hm = w["_input"][None, None, :].expand(B, J, Hd)                          # ac:229-233
     else:
-        hm = torch.as_tensor(np.asarray(h_m_prev), dtype=torch.float32).unsqueeze(1).expand(B, J, Hd)
+        hm = torch.as_tensor(np.asarray(h_m_prev), dtype=torch.float32).to(dtype).unsqueeze(1).expand(B, J, Hd)
     score = _mlp_tanh(torch.cat([feat, hp, hm], -1), w, "o_policy").squeeze(-1)
     score = score.masked_fill(torch.as_tensor(np.asarray(mask)).bool(), float("-inf"))
     prob = torch.softmax(score, -1)

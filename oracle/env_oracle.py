@@ -47,6 +47,8 @@ def lib():
         L.or_batch_valid_action_mask.argtypes = [C.c_void_p, _bp]
         L.or_batch_bench.restype = C.c_long
         L.or_batch_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.or_batch_bench_blocks.restype = C.c_long
+        L.or_batch_bench_blocks.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.or_max_threads.restype = C.c_int
         L.or_np_sum.restype = C.c_double
         L.or_np_sum.argtypes = [_dp, C.c_long]
@@ -147,6 +149,15 @@ class OracleBatch:
         n = self.L.or_batch_bench(self.h, int(episodes), int(nthreads), np.ascontiguousarray(w3, np.float64), C.byref(s1), C.byref(s2))
         if n < 0:
             raise ValueError("or_batch_bench: n_job > 64")
+        return n, s1.value, s2.value
+
+    def bench_blocks(self, episodes, nthreads, w3):
+        """the multi-core CPU baseline: every thread owns a contiguous block of envs (thread-local copies, first-touch) for
+        whole episodes, no barrier between steps -> (env_steps, wall seconds incl. resets, max per-thread seconds in the step loops)"""
+        s1, s2 = C.c_double(), C.c_double()
+        n = self.L.or_batch_bench_blocks(self.h, int(episodes), int(nthreads), np.ascontiguousarray(w3, np.float64), C.byref(s1), C.byref(s2))
+        if n < 0:
+            raise ValueError("or_batch_bench_blocks: n_job > 64")
         return n, s1.value, s2.value
 
     def valid_action_mask(self):

@@ -579,8 +579,10 @@ void or_job_mask_update(Env *e, int job_action, int *cand /*[J]*/, unsigned char
     for (int j = 0; j < J; j++) if (e->remaining[j] == 0) e->base_mask[j] = 1;
     for (int j = 0; j < J; j++) mask[j] = e->base_mask[j];
     /* finish_time is not None  <=>  scheduled */
-    double *rowmax = (double *)malloc(sizeof(double) * J);
-    int *colsum = (int *)calloc(M, sizeof(int));
+    double rowmax_s[64]; int colsum_s[64];                     /* (no allocator call per env-step for the usual sizes) */
+    double *rowmax = J <= 64 ? rowmax_s : (double *)malloc(sizeof(double) * J);
+    int *colsum = M <= 64 ? colsum_s : (int *)malloc(sizeof(int) * M);
+    for (int c = 0; c < M; c++) colsum[c] = 0;
     for (int j = 0; j < J; j++) {
         double mx = 0.0;
         for (int c = 0; c < M; c++) {
@@ -604,7 +606,8 @@ void or_job_mask_update(Env *e, int job_action, int *cand /*[J]*/, unsigned char
         }
     }
     for (int j = 0; j < J; j++) cand[j] = e->pool[j] - 1;
-    free(rowmax); free(colsum);
+    if (rowmax != rowmax_s) free(rowmax);
+    if (colsum != colsum_s) free(colsum);
 }
 void or_job_mask_state(const Env *e, int *cand, unsigned char *mask)
 {
@@ -788,4 +791,99 @@ long or_batch_bench(Batch *b, int episodes, int nthreads, const double *w3, doub
     if (seconds) *seconds = t_steps;
     if (seconds_with_reset) *seconds_with_reset = t_all;
     return n;
+}
+
+
+/* The same per-env work as or_batch_bench, organised the way a multi-core host would run pe:229's loop over independent
+ * envs: every thread OWNS a contiguous block of envs for the whole run — it builds its own copies of them (first-touch: their
+ * memory is local to the thread's core / NUMA node), and for every episode resets them and walks the T batched steps over
+ * its block (step-major inside the block, as pe:229 does for the batch) with NO barrier between steps: nothing in the
+ * environment couples two envs (a policy that needs the whole batch would add one join per step).
+ * Returns env-steps; *seconds = wall time of the parallel region (per-episode resets included), *seconds_steps = the largest
+ * per-thread time spent in the step loops alone. */
+long or_batch_bench_blocks(Batch *b, int episodes, int nthreads, const double *w3, double *seconds, double *seconds_steps)
+{
+    const int B = b->B, T = b->env[0]->h.T, M = b->env[0]->h.M, J = b->env[0]->h.J;
+    if (J > 64) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > B) nthreads = B;
+    double *tstep = (double *)calloc((size_t)nthreads, sizeof(double));
+    double t_begin = 0.0, t_end = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+#ifdef _OPENMP
+        const int th = omp_get_thread_num(), nth = omp_get_num_threads();
+#else
+        const int th = 0, nth = 1;
+#endif
+        const int lo = (int)((long)B * th / nth), hi = (int)((long)B * (th + 1) / nth), nb = hi - lo;
+        /* thread-private copies of this block's envs + observation scratch, allocated and first touched here */
+        Env **env = (Env **)malloc(sizeof(Env *) * (size_t)(nb > 0 ? nb : 1));
+        uint64_t *rng = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(nb > 0 ? nb : 1));
+        for (int k = 0; k < nb; k++) {
+            const Env *src = b->env[lo + k];
+            env[k] = or_env_create(J, M, src->h.left_shift, src->h.t, src->h.p, src->h.tt, src->h.shop,
+                                   src->h.w_mk, src->h.w_ec, src->h.w_tt, src->h.divisor, src->h.gamma);
+            or_scaler_init(env[k]);
+            rng[k] = 0x9E3779B97F4A7C15ull * (uint64_t)(lo + k + 1);
+        }
+        int *ec = (int *)malloc(sizeof(int) * (size_t)T * 2);
+        double *ev = (double *)malloc(sizeof(double) * (size_t)T * 2);
+        double *tf = (double *)malloc(sizeof(double) * (size_t)T * 12);
+        double *mf = (double *)malloc(sizeof(double) * (size_t)M * 8);
+        int cand[64]; unsigned char mask[64];
+        double mine = 0.0;
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+        t_begin = now_s();
+#ifdef _OPENMP
+#pragma omp barrier
+#endif
+        for (int ep = 0; ep < episodes; ep++) {
+            for (int k = 0; k < nb; k++) { or_scaler_reset_returns(env[k]); or_env_reset(env[k], w3 + (long)(lo + k) * 3); or_mask_reset(env[k]); }
+            const double t1 = now_s();
+            for (int s = 0; s < T; s++)
+                for (int k = 0; k < nb; k++) {
+                    Env *e = env[k];
+                    uint64_t x = rng[k];
+                    or_job_mask_state(e, cand, mask);
+                    int nj = 0, jsel = -1, msel = -1;
+                    for (int j = 0; j < J; j++) nj += !mask[j];
+                    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                    int pick = (int)(x % (uint64_t)nj);
+                    for (int j = 0; j < J; j++) if (!mask[j] && pick-- == 0) { jsel = j; break; }
+                    const int a = cand[jsel];
+                    int nm = 0;
+                    for (int m = 0; m < M; m++) nm += e->h.t[a * M + m] >= 0;
+                    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                    pick = (int)(x % (uint64_t)nm);
+                    for (int m = 0; m < M; m++) if (e->h.t[a * M + m] >= 0 && pick-- == 0) { msel = m; break; }
+                    rng[k] = x;
+                    double r5[5], s4[4]; int path;
+                    or_env_step(e, a, msel, r5, &path);
+                    or_scaler_apply(e, r5 + 1, s4);
+                    or_job_mask_update(e, jsel, cand, mask);
+                    or_env_observe_ell(e, ec, ev, tf, mf);
+                }
+            mine += now_s() - t1;
+        }
+#ifdef _OPENMP
+#pragma omp barrier
+#pragma omp master
+#endif
+        t_end = now_s();
+        tstep[th] = mine;
+        for (int k = 0; k < nb; k++) or_env_destroy(env[k]);
+        free(env); free(rng); free(ec); free(ev); free(tf); free(mf);
+    }
+    double mx = 0.0;
+    for (int i = 0; i < nthreads; i++) if (tstep[i] > mx) mx = tstep[i];
+    free(tstep);
+    if (seconds) *seconds = t_end - t_begin;
+    if (seconds_steps) *seconds_steps = mx;
+    return (long)B * T * episodes;
 }

@@ -315,7 +315,7 @@ def encoder_vectors(ins, weights, B=16, steps=(0, 17), seed=0, size=(6, 6, 2), k
                 p + "mfea1": mfea1.copy(), p + "mfea2": mfea2.copy(), p + "mmask": mm.numpy().astype(np.uint8),
                 p + "task_index": task_index.numpy().astype(np.int32), p + "job_index": action_index.numpy().astype(np.int32),
                 p + "job_logp": log_a.numpy(), p + "job_prob": prob.numpy(), p + "h_o": h_o.numpy(),
-                p + "job_v": job_v.numpy(), p + "h_nodes": h_nodes.numpy(),
+                p + "job_v": job_v.numpy(), **({p + "h_nodes": h_nodes.numpy()} if keep_h_nodes else {}),
                 p + "mch_prob": mch_prob.numpy(), p + "h_m": h_m.numpy(), p + "mach_v": mach_v.numpy(),
                 p + "global_v": gv.numpy(),
             })
@@ -408,6 +408,20 @@ def main():
         # BASELINE configs 2 and 4 sizes: seeded random weights with perturbed BatchNorm affine, steps 0 and T/2
         save("encoder_j10m10e2_rand", encoder_vectors(ref_generate(4, 10, 10, 2, 14), "rand", B=4, steps=(0, 50), seed=124, size=(10, 10, 2)))
         save("encoder_j20m20e4_rand", encoder_vectors(ref_generate(2, 20, 20, 4, 15), "rand", B=2, steps=(0, 200), seed=125, size=(20, 20, 4)))
+    if want("enc_mid"):
+        # the partition the headline runs k_gin_res in: more than 256 instances, i.e. 2 instances per workgroup (B = 320: a
+        # ragged last workgroup set; B = 512: every workgroup full), whole-batch BatchNorm over B*T rows (gcn:109-197,
+        # ac:104-296); one weight set (seed 126), node embeddings not stored
+        ins = ref_generate(512, 6, 6, 2, 16)
+        a = encoder_vectors(ins, "rand", B=320, steps=(9,), seed=126, keep_h_nodes=False)
+        b = encoder_vectors(ins, "rand", B=512, steps=(17,), seed=126, keep_h_nodes=False)
+        assert all(np.array_equal(a[k], b[k]) for k in a if k.startswith("w_")), "same seed, same weights"
+        d = {k: v for k, v in a.items() if k.startswith("w_")}
+        for tag, src in (("b320_", a), ("b512_", b)):
+            for k, v in src.items():
+                if not k.startswith("w_"):
+                    d[tag + k] = v
+        save("encoder_j6m6e2_mid", d)
     if speed:
         import platform
         with open(os.path.join(out_dir, "reference_cpu_speed.txt"), "a") as f:

@@ -82,6 +82,59 @@ def test_actor_forwards_match_reference_outputs(name, obs, gin):
     enc.check()
 
 
+@pytest.mark.parametrize("batch", ["b320", "b512"])
+@pytest.mark.parametrize("gin", ["resident", "streaming"])
+def test_actor_forwards_match_reference_outputs_two_instances_per_workgroup(batch, gin):
+    """tests/golden/encoder_j6m6e2_mid.npz: the reference modules (whole-batch training-mode BatchNorm, gcn:109-197,
+    ac:104-296, 359-498) on B = 320 and B = 512 J6M6E2 instances — more than 256 instances, so k_gin_res runs with 2 instances
+    (72 rows, 3 row tiles of which the third is partly filled) per workgroup, B = 320 with 160 workgroups; instance boundaries
+    inside row tiles and pooling chunks, candidate slots of two instances per workgroup.  Same tolerances as the B <= 16
+    fixtures; the streaming launches are held to the same outputs."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    from oracle import encoder_oracle as eo
+    g = np.load(os.path.join(GOLDEN, "encoder_j6m6e2_mid.npz"))
+    J, M, E, B = [int(x) for x in g[batch + "_meta"]]
+    T = J * M
+    assert B == int(batch[1:])
+    ja, ma = eo.split_weights(g)
+    enc = enc_mod.Encoder(J, M, B, obs_dtype="f32")
+    enc.load_weights(ja, ma, eo.critic_weights(g))
+    if gin == "streaming":
+        enc.set_product_mode(16)
+    assert enc.check() == (gin == "resident")
+    for s in g[batch + "_steps"]:
+        p = f"{batch}_s{int(s)}_"
+        col, val = eo.ell_from_dense(g[p + "adj"])
+        hm_in = g[p + "h_m_in"]
+        prob, h_o, job_v = enc.job_actor_forward(
+            _t(g[p + "tfea"], torch.float32), _t(col.reshape(B * T, 2).astype(np.int32)), _t(val.reshape(B * T, 2).astype(np.float32)),
+            _t(g[p + "cand"].astype(np.int32)), _t(g[p + "mask"].astype(np.uint8)),
+            None if hm_in.size == 0 else _t(hm_in.astype(np.float32)))
+        torch.cuda.synchronize()
+        prob, h_o, job_v = prob.cpu().numpy(), h_o.cpu().numpy(), job_v.cpu().numpy()
+        scale = max(1.0, float(np.abs(g[p + "h_o"]).max()))
+        np.testing.assert_allclose(h_o, g[p + "h_o"], rtol=0, atol=1e-4 * scale)
+        np.testing.assert_allclose(prob, g[p + "job_prob"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(job_v, g[p + "job_v"], rtol=1e-3, atol=1e-3)
+        # greedy decisions: identical wherever the reference's own top-2 probabilities are further apart than the tolerance
+        top2 = np.sort(g[p + "job_prob"], axis=1)[:, -2:]
+        clear = top2[:, 1] - top2[:, 0] > 2e-4
+        assert clear.mean() > 0.9 and np.array_equal(prob.argmax(1)[clear], g[p + "job_index"][clear])
+        mprob, h_m, mach_v = enc.machine_actor_forward(_t(g[p + "mfea1"], torch.float32), _t(g[p + "mfea2"], torch.float32),
+                                                       _t(g[p + "h_o"].astype(np.float32)), _t(g[p + "mmask"].reshape(B, M).astype(np.uint8)))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(mprob.cpu().numpy(), g[p + "mch_prob"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(h_m.cpu().numpy(), g[p + "h_m"], rtol=0, atol=1e-4 * max(1.0, float(np.abs(g[p + "h_m"]).max())))
+        np.testing.assert_allclose(mach_v.cpu().numpy(), g[p + "mach_v"], rtol=1e-3, atol=1e-3)
+        gv = enc.global_critic_forward(_t(g[p + "tfea"], torch.float32), _t(col.reshape(B * T, 2).astype(np.int32)),
+                                       _t(val.reshape(B * T, 2).astype(np.float32)), _t(g[p + "mfea1"], torch.float32), _t(g[p + "mfea2"], torch.float32))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(gv.cpu().numpy(), g[p + "global_v"], rtol=1e-3, atol=1e-3)
+    enc.check()
+
+
 def test_sampling_follows_the_distribution():
     import torch
     import mtfjsp_amd  # noqa: F401

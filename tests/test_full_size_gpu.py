@@ -106,7 +106,7 @@ def _run(J, M, E, B, sample_stride, seed, host_generator=False):
 
 
 def test_j6m6e2_4096_all_instances_vs_oracle():
-    _run(6, 6, 2, 4096, 1, seed=0, host_generator=True)
+    _run(6, 6, 2, 4096, 1, seed=0, host_generator=True)          # sample_stride 1: every instance
 
 
 @pytest.mark.parametrize("kernel", ["grp16", "grp4", "reg1", "lds", "lds1"])
@@ -118,7 +118,7 @@ def test_j6m6e2_every_step_kernel_vs_oracle(kernel, monkeypatch):
     _run(6, 6, 2, 1000, 1, seed=3)
 
 
-def test_j10m10e2_8192_all_instances_vs_oracle():
+def test_j10m10e2_8192_every_second_instance_vs_oracle():
     _run(10, 10, 2, 8192, 2, seed=1)
 
 
@@ -169,6 +169,95 @@ def test_encoder_full_batch_permutation_equivariance():
     ev = env.ell_val.view(B, T, 2)[perm].reshape(B * T, 2).contiguous()
     prob2, h_o2, v2 = enc.job_actor_forward(tf, ec, ev, env.candidate[perm].contiguous(), env.job_mask[perm].contiguous(), None)
     assert torch.allclose(prob2, prob[perm], atol=1e-5) and torch.allclose(h_o2, h_o[perm], atol=1e-4) and torch.allclose(v2, v[perm], atol=1e-4)
+
+
+def _encoder_case(size, gin):
+    """-> the encoder, the rollout it belongs to (after 37 policy steps) and the oracle's view of the same observation"""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    J, M, E, B = size
+    ja, ma = enc_mod.random_init_weights(seed=1010)
+    rs = np.random.RandomState(5)
+    for d in (ja, ma):
+        for k in d:
+            if "batch_norms" in k or k.startswith("bn."):
+                d[k] = (rs.uniform(0.5, 1.5, d[k].shape) if k.endswith("weight") else rs.uniform(-0.5, 0.5, d[k].shape)).astype(np.float32)
+    gen = import_module("e2e-mappo-for-mt-fjsp_amd.batch_env").DeviceBatchEnv(J, M, E, B, obs_dtype="f32")
+    gen.generate_instances(seed=9)                                               # B distinct instances, drawn on the device
+    ins = gen.read_instances()
+    del gen
+    ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=(ja, ma), collect=False, instances=ins)
+    if gin == "streaming":
+        ro.actor.enc.set_product_mode(16)
+    for _ in range(min(37, J * M - 3)):
+        ro.step()
+    torch.cuda.synchronize()
+    return ro, ja, ma
+
+
+# the headline partition of k_gin_res — (6,6,2,4096): 16 instances = 576 rows = 18 row tiles per workgroup, the two tiles that
+# round-trip through global memory, pooling chunks that straddle instance boundaries, the aggregation ring across tiles — plus
+# ragged batches: 4095 (last workgroup one instance short), 1000 (4 per workgroup, 250 workgroups), (5,7,1,3000) (T = 35: 12
+# instances = 420 rows per workgroup, 250 workgroups); every one through the resident kernel AND the streaming launches
+@pytest.mark.parametrize("gin", ["resident", "streaming"])
+@pytest.mark.parametrize("size", [(6, 6, 2, 4096), (6, 6, 2, 4095), (6, 6, 2, 1000), (5, 7, 1, 3000)])
+def test_encoder_headline_partition_vs_oracle(size, gin):
+    """BASELINE config 1 (J6M6E2 x 4096) and ragged batches against the fp32 oracle restatement on the WHOLE batch
+    (training-mode BatchNorm couples all B*T rows: gcn:109-197, ac:104-296), tolerances of tests/test_encoder_hip.py, with an
+    f64 evaluation of the same network as the yardstick for the embeddings."""
+    import torch
+    from oracle import encoder_oracle as eo
+    J, M, E, B = size
+    T = J * M
+    ro, ja, ma = _encoder_case(size, gin)
+    env, e = ro.env, ro.actor.enc
+    assert e.check() == (gin == "resident")
+    hm = e.h_pooled_m.clone()
+    h_nodes = torch.zeros(B * T, 128, dtype=torch.float32, device="cuda")
+    prob, h_o, job_v = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, h_nodes=h_nodes)
+    torch.cuda.synchronize()
+    tf = env.tasks_fea.cpu().numpy()
+    col = env.ell_col.cpu().numpy().reshape(B, T, 2); val = env.ell_val.cpu().numpy().reshape(B, T, 2)
+    cand, mask = env.candidate.cpu().numpy(), env.job_mask.cpu().numpy()
+    o = eo.job_actor_forward(ja, tf, col, val, cand, mask, hm.cpu().numpy(), B, T)
+    scale = max(1.0, float(np.abs(o["h_nodes"]).max()))
+    np.testing.assert_allclose(h_nodes.cpu().numpy(), o["h_nodes"], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(h_o.cpu().numpy(), o["h_pooled"], rtol=0, atol=1e-4 * scale)
+    np.testing.assert_allclose(prob.cpu().numpy(), o["prob"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(job_v.cpu().numpy(), o["job_v"], rtol=1e-3, atol=1e-3)
+    o64 = eo.job_actor_forward(ja, tf, col, val, cand, mask, hm.cpu().numpy(), B, T, dtype=torch.float64)
+    err_hip = float(np.abs(h_nodes.cpu().numpy() - o64["h_nodes"]).max()); err_f32 = float(np.abs(o["h_nodes"] - o64["h_nodes"]).max())
+    print(f"{size} {gin}: h_nodes vs binary64: HIP {err_hip:.3g}, f32 oracle {err_f32:.3g}, scale {scale:.3g}")
+    assert err_hip <= max(2 * err_f32, 1e-4 * scale)
+    e.check()
+
+
+def test_resident_equals_streaming_at_the_headline_batch():
+    """the single-launch kernel and the six streaming launches on the same B = 4096 observation: two f32-accurate evaluations
+    of the same network, <= 1e-5 of the tensor's scale apart (accumulation order only)"""
+    import torch
+    size = (6, 6, 2, 4096)
+    J, M, E, B = size
+    T = J * M
+    ro, ja, ma = _encoder_case(size, "resident")
+    env, e = ro.env, ro.actor.enc
+    hm = e.h_pooled_m.clone()
+    outs = []
+    for mode in (0, 16):
+        e.set_product_mode(mode)
+        assert e.check() == (mode == 0)
+        h_nodes = torch.zeros(B * T, 128, dtype=torch.float32, device="cuda")
+        prob, h_o, job_v = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, h_nodes=h_nodes)
+        torch.cuda.synchronize()
+        outs.append([x.clone() for x in (h_nodes, h_o, prob, job_v)])
+    e.set_product_mode(0)
+    scale = max(1.0, float(outs[1][0].abs().max()))
+    for a, b, name in zip(outs[0], outs[1], ("h_nodes", "h_pooled", "prob", "job_v")):
+        d = float((a - b).abs().max())
+        tol = 1e-5 * (scale if name in ("h_nodes", "h_pooled") else max(1.0, float(b.abs().max())))
+        assert d <= tol, (name, d, tol)
 
 
 @pytest.mark.parametrize("size", [(10, 10, 2, 8192), (20, 20, 4, 2048)])
