@@ -21,12 +21,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the cpu_baseline legs pin their OpenMP threads (one place per physical core); read when the first libgomp loads
-os.environ.setdefault("OMP_PLACES", "cores")
-os.environ.setdefault("OMP_PROC_BIND", "spread")
 
 import numpy as np
-import torch
+
+torch = None                    # imported by main(): the cpu_baseline worker process must stay free of torch (and its OpenMP runtime)
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_MEASURED_GBPS = 6290.0
@@ -165,7 +163,28 @@ def cpu_baseline(J, M, E, batch=4096, seconds_per_leg=5.0):
     return out
 
 
+def cpu_baseline_subprocess(J, M, E, batch):
+    """cpu_baseline() in a fresh interpreter WITHOUT torch, started before this process touches the GPU: torch carries its own
+    OpenMP runtime, and with thread binding requested the first runtime to initialise pins the main thread to one core, after
+    which a second runtime sees only that core (measured: 2 logical CPUs reported on a 128-thread host).  The child pins one
+    OpenMP place per physical core (OMP_PLACES=cores, OMP_PROC_BIND=spread unless the caller set them)."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("OMP_PLACES", "cores")
+    env.setdefault("OMP_PROC_BIND", "spread")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(J), str(M), str(E), str(batch)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    if r.returncode != 0:
+        return {"error": "cpu_baseline worker failed", "stderr": r.stderr[-2000:]}
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
 def main():
+    global torch
+    if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-baseline-worker":
+        J, M, E, batch = [int(x) for x in sys.argv[2:6]]
+        print(json.dumps(cpu_baseline(J, M, E, batch=batch)), flush=True)
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=720)
@@ -188,6 +207,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    cpu_leg = None
+    if world == 1 and not args.no_cpu_baseline:        # before anything initialises the GPU or loads torch in this process
+        Jc, Mc, Ec = [int(x) for x in args.size.split("x")]
+        cpu_leg = cpu_baseline_subprocess(Jc, Mc, Ec, args.batch)
+    import torch as _torch
+    torch = _torch
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
@@ -337,8 +362,8 @@ def main():
             sweep = [env_kernel_large_batch(J, M, E, local_rank, B=b, episodes=1 if b >= 65536 else 2) for b in (4096, 16384, 65536, 262144)]
             out["roofline_env_step_batch_sweep"] = sweep
             out["roofline_env_step_large_batch"] = sweep[-1]
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(J, M, E)
+        if cpu_leg is not None:
+            out["cpu_baseline"] = cpu_leg
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
