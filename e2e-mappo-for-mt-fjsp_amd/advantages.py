@@ -65,3 +65,34 @@ def global_advantages(env, r4, multi_v, multi_v_, done, gamma, lam, group=None):
     norm = normalise(raw, group=group)
     targets = [norm[i] + multi_v[..., i] for i in range(4)]
     return norm, targets, raw
+
+
+def full_handoff(env, r4, job_v, job_v_, machine_v, machine_v_, multi_v, multi_v_, done, gamma, lam, group=None, timed=False,
+                 gather_values=True):
+    """The complete rollout -> update hand-off of ppo:628-703 in ONE collective: the four global-critic advantages
+    (separate_cal_4_reward_GAE, ppo:491-536) and the four local-critic advantages (cal_local_job_machine_reward_GAE, ppo:437-489)
+    are computed per shard (`mtfjsp_gae` reverse scans) and exchanged as one packed buffer — with gather_values the eight value
+    tensors their targets are built from ride along, so that every rank ends with what the reference's single process holds:
+    16 tensors x [S, B_total] f32 (SURVEY §8e sizes the exchange so: 47 MB per rank at 8 x 4096 J6M6 instances); a data-parallel
+    trainer that only consumes its own columns sets gather_values=False (8 tensors).  Normalisation (adv - mean) / (std + 1e-5)
+    per tensor over ALL shards' columns (ppo:485,532), value target = normalised advantage + value at act time (ppo:668-671,689).
+    Channel order mk, pt, tt, it everywhere.
+    -> dict(global_adv[4], global_targets[4], local_adv[4], local_targets[4], raw_global[4], raw_local[4], gather=info,
+            full_adv / full_values: the gathered [S,B_total] tensors when more than one rank took part)"""
+    order = (0, 2, 3, 1)                                   # mk, pt, tt, it inside r4's (mk, idle, pt, tt)
+    raw_g = [env.gae(r4[:, order[i]], multi_v[..., i], multi_v_[..., i], done, gamma, lam) for i in range(4)]
+    pairs = [(r4[:, 0], job_v[..., 0], job_v_[..., 0]), (r4[:, 2], machine_v[..., 0], machine_v_[..., 0]),
+             (r4[:, 3], machine_v[..., 1], machine_v_[..., 1]), (r4[:, 1], job_v[..., 1], job_v_[..., 1])]
+    raw_l = [env.gae(r, v, v_, done, gamma, lam) for r, v, v_ in pairs]
+    vals = [multi_v[..., i] for i in range(4)] + [p[1] for p in pairs]
+    packed = raw_g + raw_l + (vals if gather_values else [])
+    res = D.all_gather_advantages(packed, group=group, timed=timed)
+    full, info = res if timed else (res, None)
+    norm = []
+    for a_full, a_loc in zip(full[:8], raw_g + raw_l):
+        mean, std = a_full.mean(), a_full.std()
+        norm.append((a_loc - mean) / (std + 1e-5))
+    out = dict(global_adv=norm[:4], local_adv=norm[4:], raw_global=raw_g, raw_local=raw_l,
+               global_targets=[norm[i] + vals[i] for i in range(4)], local_targets=[norm[4 + i] + vals[4 + i] for i in range(4)],
+               gather=info, full_adv=full[:8], full_values=full[8:] if gather_values else None)
+    return out

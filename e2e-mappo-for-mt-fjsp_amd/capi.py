@@ -10,7 +10,7 @@ from . import _build
 _LIB = None
 
 OBS_F64, OBS_F32 = 0, 1
-OK, ERR_ARG, ERR_STATE, ERR_HIP, ERR_ACTION = 0, -1, -2, -3, -4
+OK, ERR_ARG, ERR_STATE, ERR_HIP, ERR_ACTION, ERR_RETRY = 0, -1, -2, -3, -4, -5
 PATH_MASK, ST_INVALID, ST_INFEASIBLE = 0x7, 0x100, 0x200
 STATE_MACHINE, STATE_START, STATE_FINISH, STATE_ROUTES, STATE_PREV_COSTS, STATE_SCALER, STATE_W3 = range(7)
 
@@ -90,6 +90,7 @@ PROTOTYPES = {
     "mtfjsp_encoder_arm_mfea1": (_I, [_VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_selection": (_I, [_VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
     "mtfjsp_encoder_check": (_I, [_VP, C.POINTER(C.c_int32)]),
+    "mtfjsp_encoder_resident_failures": (_I, [_VP, C.POINTER(C.c_int64)]),
     "mtfjsp_encoder_timing_begin": (_I, [_VP]),
     "mtfjsp_encoder_timing_end": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mtfjsp_encoder_timing_query": (_I, [_VP, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

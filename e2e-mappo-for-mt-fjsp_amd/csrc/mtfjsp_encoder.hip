@@ -2439,7 +2439,11 @@ struct mtfjsp_encoder {
     bool res_ok = false; int res_ipc = 0, res_grid = 0;
     double *res_stats = nullptr;            // [2 sets][GR_STATS_SET]; forward n uses set n & 1 and zeroes the other one
     unsigned long long *res_bar = nullptr;  // [17 * 16] barrier words
-    unsigned *res_fail = nullptr;
+    unsigned *res_fail = nullptr;           // device address of *res_fail_host
+    volatile unsigned *res_fail_host = nullptr;   // host-mapped word the kernel sets when a grid barrier times out: polled at every forward entry (no synchronisation)
+    bool res_eligible = false;              // the shape can use the single-launch kernel (res_ok: and the census passed / no failure since)
+    long long res_failures = 0, res_launches = 0;
+    long long res_fail_at = getenv("MTFJSP_GIN_RES_FAIL_AT") ? atoll(getenv("MTFJSP_GIN_RES_FAIL_AT")) : 0;   // diagnostic: this launch's barriers time out
     float *res_zspill = nullptr;            // [grid][4][2][1024] f32: the two row tiles per workgroup that do not fit the registers
     unsigned long long res_epoch = 0;
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
@@ -2500,6 +2504,50 @@ static const char *REQUIRED[] = {
     "machine_actor.machine_critic.linears.2.weight", "machine_actor.machine_critic.linears.2.bias",
 };
 
+// the host-mapped failure word of the single-launch GIN kernel
+static int res_alloc_fail_word(mtfjsp_encoder *e)
+{
+    void *h = nullptr, *d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return 1;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return 1; }
+    e->res_fail_host = (volatile unsigned *)h; e->res_fail = (unsigned *)d;
+    *e->res_fail_host = 0u;
+    return 0;
+}
+// census: every workgroup must be resident at once for the grid barriers to complete (bounded spins report it).  Synchronises the device.
+static bool res_census(mtfjsp_encoder *e)
+{
+    if (hipDeviceSynchronize() != hipSuccess) return false;
+    if (hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8) != hipSuccess) return false;      // fresh barrier words (a timed-out launch leaves them inconsistent)
+    e->res_epoch = 0;
+    *e->res_fail_host = 0u;
+    GinResArgs a{};
+    a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail; a.barrier_only = 1;
+    hipLaunchKernelGGL(k_gin_res, dim3(e->res_grid), dim3(256), gin_res_lds_bytes(), nullptr, a);
+    if (hipDeviceSynchronize() != hipSuccess || *e->res_fail_host) {
+        (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); e->res_epoch = 0; *e->res_fail_host = 0u;
+        return false;
+    }
+    return true;
+}
+// Polled at the entry of every forward that may use the single-launch kernel (a plain read of host memory) and, after a stream
+// synchronisation, by mtfjsp_encoder_check: a grid barrier of an earlier launch timed out (its workgroups were not all resident,
+// e.g. another process or stream held compute units).  Everything enqueued on this handle since that launch is invalid.  The
+// handle falls back to the six streaming launches (mtfjsp_encoder_check re-runs the census and re-enables the single launch
+// when the device can hold the grid again) and the caller is told to repeat the work: MTFJSP_ERR_RETRY.
+static int res_poll_failure(mtfjsp_encoder *e)
+{
+    if (!e->res_fail_host || !*e->res_fail_host) return MTFJSP_OK;
+    (void)hipStreamSynchronize(e->stream);
+    e->res_ok = false; e->res_failures++;
+    *e->res_fail_host = 0u;
+    (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); e->res_epoch = 0;
+    (void)hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8);
+    e->err = "single-launch GIN kernel: a grid barrier timed out (its workgroups were not co-resident); every output enqueued since that "
+             "launch is invalid and must be recomputed; the handle now uses the streaming launches";
+    return MTFJSP_ERR_RETRY;
+}
+
 extern "C" const char *mtfjsp_encoder_last_error(mtfjsp_encoder_t e) { return e ? e->err.c_str() : g_enc_err.c_str(); }
 
 extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_encoder_t *out)
@@ -2558,20 +2606,12 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
             const int grid = (B + ipc - 1) / ipc;
             if (ipc * T <= GR_ROWS && ipc <= GR_MAXIPC && grid <= e->num_cu && ipc * cfg->n_job <= GR_MAXCAND &&
                 hipFuncSetAttribute((const void *)k_gin_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gin_res_lds_bytes()) == hipSuccess) {
-                int rc = dalloc(e, &e->res_stats, (size_t)2 * GR_STATS_SET) | dalloc(e, &e->res_bar, (size_t)17 * 16) | dalloc(e, &e->res_fail, (size_t)4) |
+                int rc = dalloc(e, &e->res_stats, (size_t)2 * GR_STATS_SET) | dalloc(e, &e->res_bar, (size_t)17 * 16) | res_alloc_fail_word(e) |
                          dalloc(e, &e->res_zspill, (size_t)grid * 4 * (GR_NT - GR_NRES) * 1024);
                 if (!rc && hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8) == hipSuccess &&
-                    hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8) == hipSuccess && hipMemset(e->res_fail, 0, 16) == hipSuccess) {
-                    // census: every workgroup must be resident at once for the grid barriers to complete (bounded spins report it)
-                    GinResArgs a{};
-                    a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail; a.barrier_only = 1;
-                    hipLaunchKernelGGL(k_gin_res, dim3(grid), dim3(256), gin_res_lds_bytes(), nullptr, a);
-                    unsigned failed = 1;
-                    if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(&failed, e->res_fail, 4, hipMemcpyDeviceToHost) == hipSuccess && !failed) {
-                        e->res_ok = true; e->res_ipc = ipc; e->res_grid = grid;
-                    } else {       // leave the streaming kernels in charge; fresh barrier words in case the census is retried elsewhere
-                        (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); (void)hipMemset(e->res_fail, 0, 16);
-                    }
+                    hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8) == hipSuccess) {
+                    e->res_ipc = ipc; e->res_grid = grid; e->res_eligible = true;
+                    e->res_ok = res_census(e);
                 }
             }
         }
@@ -2586,6 +2626,7 @@ extern "C" int mtfjsp_encoder_destroy(mtfjsp_encoder_t e)
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipDeviceSynchronize();
     for (void *p : e->owned) (void)hipFree(p);
+    if (e->res_fail_host) (void)hipHostFree((void *)e->res_fail_host);
     for (auto &kv : e->ev) for (auto &p : kv.second) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (auto &p : e->ev_free) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     delete e;
@@ -3003,6 +3044,7 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
     a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail;
     a.candidate = candidate; a.pooled = h_pooled; a.cand_feat = cand_feat; a.h_nodes = h_nodes; a.zspill = e->res_zspill;
     a.inv_rows = 1.0 / ((double)B * (double)T);
+    if (++e->res_launches == e->res_fail_at) a.expect_extra = 1u;      // (diagnostic) this launch's barriers never complete
 #ifdef GR_STAMP
     static unsigned long long *d_st = nullptr;
     if (!d_st) (void)hipMalloc((void **)&d_st, 256 * 64 * 8);
@@ -3229,6 +3271,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     int rc = mtfjsp_encoder_weights_ready(e);
     if (rc) return rc;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    if ((rc = res_poll_failure(e))) return rc;
     const int B = e->cfg.batch, J = e->cfg.n_job;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
@@ -3365,6 +3408,7 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
     for (const char *k : need)
         if (!e->w.count(k)) { e->err = std::string("missing weight: ") + k; return MTFJSP_ERR_STATE; }
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    { const int prc = res_poll_failure(e); if (prc) return prc; }
     const int B = e->cfg.batch;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };
@@ -3428,12 +3472,19 @@ extern "C" int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_ou
     if (!e) return MTFJSP_ERR_ARG;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (gin_resident_out) *gin_resident_out = (e->res_ok && !e->reduce_fn && !(e->f32_products & (1 | 8 | 16))) ? 1 : 0;
-    if (e->res_ok) {
-        unsigned failed = 0;
-        HIPCHK(e, hipMemcpy(&failed, e->res_fail, 4, hipMemcpyDeviceToHost));
-        if (failed) { e->err = "resident GIN kernel: a grid barrier timed out (workgroups not co-resident); outputs since then are invalid"; return MTFJSP_ERR_STATE; }
+    int rc = res_poll_failure(e);                                  // (the stream is idle: the word is final)
+    if (!rc && e->res_eligible && !e->res_ok && e->res_failures > 0 && !getenv("MTFJSP_NO_RESIDENT_GIN")) {
+        // a failure was reported earlier: the stream is idle now, so the census can run again; when the device holds the whole
+        // grid again the single launch comes back (one transient overlap does not leave the handle on the slow path for good)
+        e->res_ok = res_census(e);
     }
+    if (gin_resident_out) *gin_resident_out = (e->res_ok && !e->reduce_fn && !(e->f32_products & (1 | 8 | 16))) ? 1 : 0;
+    return rc;
+}
+extern "C" int mtfjsp_encoder_resident_failures(mtfjsp_encoder_t e, int64_t *count_out)
+{
+    if (!e || !count_out) return MTFJSP_ERR_ARG;
+    *count_out = e->res_failures;
     return MTFJSP_OK;
 }
 

@@ -58,6 +58,12 @@
 #define GR_MINT 16                        // ... and a 16-row run spans at most two instances (pooling)
 #define GR_MAXIPC 64                      // instances per workgroup (u8 instance ids; pool accumulators in the ring area)
 
+#ifndef GR_MIX
+#define GR_MIX 0                          // 1: the low operand piece as fma(f16 high piece, -1, x) = v_fma_mix_f32 (no separate f16 -> f32 conversion); same bits
+#endif
+#ifndef GR_PK
+#define GR_PK 1                           // 1: two-wide f32 vector arithmetic (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32); 0: one instruction per element
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 gr_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 gr_h2 __attribute__((ext_vector_type(2)));
@@ -82,6 +88,7 @@ struct GinResArgs {
     float *zspill;                        // [blocks][4 waves][2 tiles][4][64 lanes][4] f32: the pre-BatchNorm values of row tiles 16, 17
     double inv_rows;                      // 1 / (B*T)
     int barrier_only;                     // census launch: barriers only
+    unsigned expect_extra;                // diagnostic (MTFJSP_GIN_RES_FAIL_AT): the barriers wait for this many workgroups that do not exist -> time-out path
     unsigned long long *stamps;           // diagnostic build only (-DGR_STAMP): [blocks][64] s_memrealtime at the phase boundaries
 };
 #define GR_STATS_PART (6 * 8 * HD * 2)                            // doubles: per layer, per dispatch group: (sum, sumsq) per column
@@ -106,6 +113,37 @@ struct GinResArgs {
 static size_t gin_res_lds_bytes() { return (size_t)GR_LDS_BYTES; }
 static_assert(GR_LDS_BYTES <= 160 * 1024, "resident GIN kernel: LDS budget");
 
+#if GR_PK == 1
+__device__ __forceinline__ f32x2 gr_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 gr_add2(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 gr_sub2(f32x2 a, f32x2 b) { return a - b; }
+__device__ __forceinline__ f32x2 gr_mul2(f32x2 a, f32x2 b) { return a * b; }
+#else
+// (element by element, each result pinned so that no later pass pairs them up again)
+#if GR_PK == 2
+__device__ __forceinline__ float gr_pin(float x) { return x; }     // (with -fno-slp-vectorize)
+#else
+__device__ __forceinline__ float gr_pin(float x) { asm("" : "+v"(x)); return x; }
+#endif
+__device__ __forceinline__ f32x2 gr_fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{gr_pin(__builtin_fmaf(a[0], b[0], c[0])), gr_pin(__builtin_fmaf(a[1], b[1], c[1]))}; }
+__device__ __forceinline__ f32x2 gr_add2(f32x2 a, f32x2 b) { return f32x2{gr_pin(a[0] + b[0]), gr_pin(a[1] + b[1])}; }
+__device__ __forceinline__ f32x2 gr_sub2(f32x2 a, f32x2 b) { return f32x2{gr_pin(a[0] - b[0]), gr_pin(a[1] - b[1])}; }
+__device__ __forceinline__ f32x2 gr_mul2(f32x2 a, f32x2 b) { return f32x2{gr_pin(a[0] * b[0]), gr_pin(a[1] * b[1])}; }
+#endif
+// x - (float)high piece, elementwise (exactly rounded either way: the product by -1 is exact)
+__device__ __forceinline__ f32x2 gr_rem2(f32x2 v, gr_h2 p)
+{
+#if GR_MIX
+    // (written as instructions: the optimiser turns fma(x, -1, v) back into a subtraction behind a conversion)
+    float r0, r1;
+    const unsigned pp = __builtin_bit_cast(unsigned, p);
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(pp), "v"(v[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(pp), "v"(v[1]));
+    return f32x2{r0, r1};
+#else
+    return gr_sub2(v, __builtin_convertvector(p, f32x2));
+#endif
+}
 template <typename F, int... I>
 __device__ __forceinline__ void gr_static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F>
@@ -145,7 +183,10 @@ __device__ __forceinline__ void gr_grid_barrier(unsigned long long *bar, unsigne
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(&bar[16 * (9 + g)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) {
             __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) { *fail = 1u; break; }     // 4 ms at 100 MHz: not all workgroups are resident
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) {                           // 4 ms at 100 MHz: not all workgroups are resident
+                __hip_atomic_store(fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);       // (host-mapped word: the host polls it without synchronising)
+                break;
+            }
         }
     }
     __syncthreads();
@@ -165,7 +206,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     unsigned *s_flag = reinterpret_cast<unsigned *>(smem + GR_OFF_FLAG);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = lane & 31, h = lane >> 5;
-    const unsigned nblk = gridDim.x;
+    const unsigned nblk = gridDim.x + A.expect_extra;
     const unsigned long long gen0 = A.epoch * GR_NBAR;
     if (A.barrier_only) {
         for (int k = 0; k < GR_NBAR; k++) gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, s_flag);
@@ -182,7 +223,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 
     // ---------------------------------------------------------------- prologue: features + adjacency to LDS, zero the planes
     GR_STAMP_AT(32);
-    for (int i = blockIdx.x * 256 + tid; i < GR_STATS_SET; i += (int)nblk * 256) A.stats_next[i] = 0.0;
+    for (int i = blockIdx.x * 256 + tid; i < GR_STATS_SET; i += (int)gridDim.x * 256) A.stats_next[i] = 0.0;
     {
         // (the candidate indices are requested with everything else: their use below would otherwise be a second memory round trip)
         int cand_pre[(GR_MAXCAND + 255) / 256];
@@ -260,7 +301,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     // the two statistics updates of a column pair, pinned where they are written (hipcc would sink a whole layer's sums to their use)
     auto stat2 = [&](int i, float x, float y) __attribute__((always_inline)) {
         const f32x2 v = {x, y};
-        ts[i] += v; tq[i] = __builtin_elementwise_fma(v, v, tq[i]);
+        ts[i] = gr_add2(ts[i], v); tq[i] = gr_fma2(v, v, tq[i]);
         asm volatile("" : "+v"(ts[i]), "+v"(tq[i]));
     };
     auto stats_all = [&](const f32x16 &a) __attribute__((always_inline)) {
@@ -271,7 +312,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     // exact-to-2^-22 operand split of 4 values: high = f16(v), low = f16(v - high) (both round-to-nearest) -> packed pairs
     auto split2x4 = [&](f32x2 v01, f32x2 v23, uint2 &p0, uint2 &p1) __attribute__((always_inline)) {
         const gr_h2 a = __builtin_convertvector(v01, gr_h2), b = __builtin_convertvector(v23, gr_h2);
-        const f32x2 r01 = v01 - __builtin_convertvector(a, f32x2), r23 = v23 - __builtin_convertvector(b, f32x2);
+        const f32x2 r01 = gr_rem2(v01, a), r23 = gr_rem2(v23, b);
         const gr_h2 c = __builtin_convertvector(r01, gr_h2), d = __builtin_convertvector(r23, gr_h2);
         p0 = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
         p1 = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
@@ -374,8 +415,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             // slice 0
             M(2 * g, 0, 1);
             xf[1][0] = *reinterpret_cast<const gr_h8 *>(xa + 32 * (2 * g + 1));
-            if constexpr (NEXT) { v01 = __builtin_elementwise_fma(f32x2{nx[4 * g], nx[4 * g + 1]}, f32x2{s4.x, s4.y}, f32x2{h4.x, h4.y});
-                                  v23 = __builtin_elementwise_fma(f32x2{nx[4 * g + 2], nx[4 * g + 3]}, f32x2{s4.z, s4.w}, f32x2{h4.z, h4.w}); }
+            if constexpr (NEXT) { v01 = gr_fma2(f32x2{nx[4 * g], nx[4 * g + 1]}, f32x2{s4.x, s4.y}, f32x2{h4.x, h4.y});
+                                  v23 = gr_fma2(f32x2{nx[4 * g + 2], nx[4 * g + 3]}, f32x2{s4.z, s4.w}, f32x2{h4.z, h4.w}); }
             GR_FENCE();
             // slice 1
             M(2 * g, 1, 0);
@@ -390,13 +431,13 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             // slice 3: the k-step 2g operands are dead once its three instructions have issued
             M(2 * g + 1, 0, 1);
             if constexpr (g < 3) xf[0][0] = *reinterpret_cast<const gr_h8 *>(xa + 32 * (2 * g + 2));
-            if constexpr (NEXT) { e01 = __builtin_convertvector(p01, f32x2); e23 = __builtin_convertvector(p23, f32x2); }
+            if constexpr (NEXT && !GR_MIX) { e01 = __builtin_convertvector(p01, f32x2); e23 = __builtin_convertvector(p23, f32x2); }
             if constexpr (NEXT && g < 3) h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * (g + 1) + 4 * h);
             GR_FENCE();
             // slice 4
             M(2 * g + 1, 1, 0);
             if constexpr (g < 3) xf[0][1] = *reinterpret_cast<const gr_h8 *>(xa + GR_PLANE + 32 * (2 * g + 2));
-            if constexpr (NEXT) { v01 -= e01; v23 -= e23;
+            if constexpr (NEXT) { if constexpr (GR_MIX) { v01 = gr_rem2(v01, p01); v23 = gr_rem2(v23, p23); } else { v01 = gr_sub2(v01, e01); v23 = gr_sub2(v23, e23); }
                                   if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23));
                                   q01 = __builtin_convertvector(v01, gr_h2); q23 = __builtin_convertvector(v23, gr_h2); }
             GR_FENCE();
@@ -595,8 +636,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                 const float4 x = *reinterpret_cast<const float4 *>(r.px + 4 * (chl ^ r.s1));
                 const float4 y = *reinterpret_cast<const float4 *>(r.py + 4 * (chl ^ r.s2));
                 const f32x2 W0 = {r.w0, r.w0}, W1 = {r.w1, r.w1}, IV = {r.inv, r.inv};
-                const f32x2 v01 = __builtin_elementwise_fma(W1, f32x2{y.x, y.y}, __builtin_elementwise_fma(W0, f32x2{x.x, x.y}, f32x2{o.x, o.y})) * IV;
-                const f32x2 v23 = __builtin_elementwise_fma(W1, f32x2{y.z, y.w}, __builtin_elementwise_fma(W0, f32x2{x.z, x.w}, f32x2{o.z, o.w})) * IV;
+                const f32x2 v01 = gr_mul2(gr_fma2(W1, f32x2{y.x, y.y}, gr_fma2(W0, f32x2{x.x, x.y}, f32x2{o.x, o.y})), IV);
+                const f32x2 v23 = gr_mul2(gr_fma2(W1, f32x2{y.z, y.w}, gr_fma2(W0, f32x2{x.z, x.w}, f32x2{o.z, o.w})), IV);
                 uint2 p0, p1;
                 split2x4(v01, v23, p0, p1);
                 *reinterpret_cast<uint2 *>(dst + 16 * g) = p0;
@@ -654,30 +695,30 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                     // slice 1
                     M(2 * g, 1, 0);
                     xf[1][1] = *reinterpret_cast<const gr_h8 *>(xa + GR_PLANE + 32 * (2 * g + 1));
-                    if constexpr (WH) { u01 = __builtin_elementwise_max(__builtin_elementwise_fma(f32x2{wv[4 * g], wv[4 * g + 1]}, f32x2{s4.x, s4.y}, f32x2{h4.x, h4.y}), f32x2{0.f, 0.f});
-                                        u23 = __builtin_elementwise_max(__builtin_elementwise_fma(f32x2{wv[4 * g + 2], wv[4 * g + 3]}, f32x2{s4.z, s4.w}, f32x2{h4.z, h4.w}), f32x2{0.f, 0.f}); }
+                    if constexpr (WH) { u01 = __builtin_elementwise_max(gr_fma2(f32x2{wv[4 * g], wv[4 * g + 1]}, f32x2{s4.x, s4.y}, f32x2{h4.x, h4.y}), f32x2{0.f, 0.f});
+                                        u23 = __builtin_elementwise_max(gr_fma2(f32x2{wv[4 * g + 2], wv[4 * g + 3]}, f32x2{s4.z, s4.w}, f32x2{h4.z, h4.w}), f32x2{0.f, 0.f}); }
                     GR_FENCE();
                     // slice 2
                     M(2 * g, 0, 0);
                     if constexpr (WH) *reinterpret_cast<float4 *>(hbase + 4 * (chl ^ (n & 7))) = make_float4(u01[0], u01[1], u23[0], u23[1]);
-                    if constexpr (NEXT) { v01 = __builtin_elementwise_fma(W0, f32x2{x.x, x.y}, f32x2{o.x, o.y}); v23 = __builtin_elementwise_fma(W0, f32x2{x.z, x.w}, f32x2{o.z, o.w}); }
+                    if constexpr (NEXT) { v01 = gr_fma2(W0, f32x2{x.x, x.y}, f32x2{o.x, o.y}); v23 = gr_fma2(W0, f32x2{x.z, x.w}, f32x2{o.z, o.w}); }
                     if constexpr (WH && g < 3) s4 = *reinterpret_cast<const float4 *>(bnw + 32 * wave + 8 * (g + 1) + 4 * h);
                     GR_FENCE();
                     // slice 3
                     M(2 * g + 1, 0, 1);
                     if constexpr (g < 3) xf[0][0] = *reinterpret_cast<const gr_h8 *>(xa + 32 * (2 * g + 2));
-                    if constexpr (NEXT) { v01 = __builtin_elementwise_fma(W1, f32x2{y.x, y.y}, v01); v23 = __builtin_elementwise_fma(W1, f32x2{y.z, y.w}, v23); }
+                    if constexpr (NEXT) { v01 = gr_fma2(W1, f32x2{y.x, y.y}, v01); v23 = gr_fma2(W1, f32x2{y.z, y.w}, v23); }
                     if constexpr (WH && g < 3) h4 = *reinterpret_cast<const float4 *>(bnw + HD + 32 * wave + 8 * (g + 1) + 4 * h);
                     GR_FENCE();
                     // slice 4
                     M(2 * g + 1, 1, 0);
                     if constexpr (g < 3) xf[0][1] = *reinterpret_cast<const gr_h8 *>(xa + GR_PLANE + 32 * (2 * g + 2));
-                    if constexpr (NEXT) { v01 *= IV; v23 *= IV; p01 = __builtin_convertvector(v01, gr_h2); p23 = __builtin_convertvector(v23, gr_h2);
-                                          e01 = __builtin_convertvector(p01, f32x2); e23 = __builtin_convertvector(p23, f32x2); }
+                    if constexpr (NEXT) { v01 = gr_mul2(v01, IV); v23 = gr_mul2(v23, IV); p01 = __builtin_convertvector(v01, gr_h2); p23 = __builtin_convertvector(v23, gr_h2);
+                                          if constexpr (!GR_MIX) { e01 = __builtin_convertvector(p01, f32x2); e23 = __builtin_convertvector(p23, f32x2); } }
                     GR_FENCE();
                     // slice 5
                     M(2 * g + 1, 0, 0);
-                    if constexpr (NEXT) { v01 -= e01; v23 -= e23; q01 = __builtin_convertvector(v01, gr_h2); q23 = __builtin_convertvector(v23, gr_h2);
+                    if constexpr (NEXT) { if constexpr (GR_MIX) { v01 = gr_rem2(v01, p01); v23 = gr_rem2(v23, p23); } else { v01 = gr_sub2(v01, e01); v23 = gr_sub2(v23, e23); } q01 = __builtin_convertvector(v01, gr_h2); q23 = __builtin_convertvector(v23, gr_h2);
                                           *reinterpret_cast<uint2 *>(dst + 16 * g) = make_uint2(__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23));
                                           *reinterpret_cast<uint2 *>(dst + 16 * g + GR_PLANE) = make_uint2(__builtin_bit_cast(unsigned, q01), __builtin_bit_cast(unsigned, q23)); }
                     GR_FENCE();

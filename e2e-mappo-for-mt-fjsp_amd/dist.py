@@ -61,7 +61,12 @@ def all_gather_advantages(tensors, group=None, timed=False):
     if timed and packed.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    dist.all_gather_into_tensor(out, packed, group=group)
+    if packed.is_cuda and dist.get_backend(group) != "nccl":     # CPU backend (gloo in the two-process tests): through host copies
+        oc = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(oc, packed.cpu(), group=group)
+        out.copy_(oc)
+    else:
+        dist.all_gather_into_tensor(out, packed, group=group)
     if ev is not None:
         ev[1].record()
         ev[1].synchronize()

@@ -27,9 +27,10 @@ def available():
         return False
 
 
-def random_init_weights(seed=0):
+def random_init_weights(seed=0, with_critic=False):
     """Random weights with the reference modules' default initialisers (nn.Linear: U(+-1/sqrt(in)); BatchNorm: 1/0;
-    `_input`: U(-1,1) ac:76-77; GAT W, a: xavier normal gat:60-66) under the reference's state_dict key names."""
+    `_input`: U(-1,1) ac:76-77; GAT W, a: xavier normal gat:60-66) under the reference's state_dict key names.
+    -> (job actor, machine actor[, global critic (ac:506-586: own GIN encoder, own GAT path, MLPCritic(256 -> 128 -> 128 -> 4))])"""
     g = torch.Generator().manual_seed(seed)
 
     def lin(out, inp, bias=True):
@@ -56,7 +57,24 @@ def random_init_weights(seed=0):
     ma["m_fea_1_fcl.weight"] = lin(H, 6, False)[0]; ma["m_fea_2_fcl.weight"] = lin(H, 8, False)[0]
     ma["gat_layer.W"] = torch.randn(H, H, generator=g) * math.sqrt(2.0 / (H + H))
     ma["gat_layer.a"] = torch.randn(1, 2 * H, 1, generator=g) * math.sqrt(2.0 / (2 * H + 1 * 1))
-    return {k: v.numpy() for k, v in ja.items()}, {k: v.numpy() for k, v in ma.items()}
+    if not with_critic:
+        return {k: v.numpy() for k, v in ja.items()}, {k: v.numpy() for k, v in ma.items()}
+    gc = {}
+    for l, inp in ((0, 12), (1, H)):
+        for i, (o, k) in enumerate(((H, inp), (H, H), (H, H))):
+            w, b = lin(o, k)
+            gc[f"{pre}mlps.{l}.linears.{i}.weight"], gc[f"{pre}mlps.{l}.linears.{i}.bias"] = w, b
+        for i in range(2):
+            gc[f"{pre}mlps.{l}.batch_norms.{i}.weight"] = torch.ones(H); gc[f"{pre}mlps.{l}.batch_norms.{i}.bias"] = torch.zeros(H)
+        gc[f"{pre}batch_norms.{l}.weight"] = torch.ones(H); gc[f"{pre}batch_norms.{l}.bias"] = torch.zeros(H)
+    for i, (o, k) in enumerate(((H, 2 * H), (H, H), (4, H))):
+        w, b = lin(o, k)
+        gc[f"critic.linears.{i}.weight"], gc[f"critic.linears.{i}.bias"] = w, b
+    gc["bn.weight"] = torch.ones(H); gc["bn.bias"] = torch.zeros(H)
+    gc["m_fea_1_fcl.weight"] = lin(H, 6, False)[0]; gc["m_fea_2_fcl.weight"] = lin(H, 8, False)[0]
+    gc["gat_layer.W"] = torch.randn(H, H, generator=g) * math.sqrt(2.0 / (H + H))
+    gc["gat_layer.a"] = torch.randn(1, 2 * H, 1, generator=g) * math.sqrt(2.0 / (2 * H + 1 * 1))
+    return tuple({k: v.numpy() for k, v in d.items()} for d in (ja, ma, gc))
 
 
 class Encoder:
@@ -166,11 +184,19 @@ class Encoder:
         capi.check(self.L.mtfjsp_encoder_set_stats_reduce(self.h, C.cast(self._reduce_cb, C.c_void_p), None, int(global_batch)), self.h, enc=True)
 
     def check(self):
-        """synchronise and raise if a forward failed asynchronously (bounded grid-barrier spins of the single-launch GIN kernel);
+        """synchronise and raise if a forward failed asynchronously (bounded grid-barrier spins of the single-launch GIN kernel:
+        MtfjspError with code capi.ERR_RETRY — the handle has then switched to the streaming launches and whatever was enqueued
+        since the failed launch has to be recomputed; the forwards poll the same condition on entry without synchronising);
         -> True when that kernel is in use for this shape, False when the six streaming launches are"""
         r = C.c_int32(0)
         capi.check(self.L.mtfjsp_encoder_check(self.h, C.byref(r)), self.h, enc=True)
         return bool(r.value)
+
+    def resident_failures(self):
+        """grid-barrier time-outs of the single-launch GIN kernel reported on this handle so far"""
+        n = C.c_int64(0)
+        capi.check(self.L.mtfjsp_encoder_resident_failures(self.h, C.byref(n)), self.h, enc=True)
+        return int(n.value)
 
     def arm_selection(self, which, greedy, seed, counter, idx_out, logp_out=None, gather_from=None, gathered_out=None):
         """fuse the action selection of the next job (which=0) / machine (which=1) actor forward into its heads kernel; same
@@ -205,8 +231,9 @@ class ActorPair:
 
     def __init__(self, n_job, n_machine, batch, device=0, obs_dtype="f32", weights=None, greedy=False, seed=0):
         self.enc = Encoder(n_job, n_machine, batch, device=device, obs_dtype=obs_dtype)
-        ja, ma = weights if weights is not None else random_init_weights(seed)
-        self.enc.load_weights(ja, ma)
+        w = weights if weights is not None else random_init_weights(seed)
+        self.enc.load_weights(w[0], w[1], w[2] if len(w) > 2 else None)   # (job actor, machine actor[, global critic])
+        self.has_critic = len(w) > 2
         self.greedy, self.seed = greedy, seed
         self._mf_ctx, self._mf_env = None, None
         self.fused = not os.environ.get("MTFJSP_NO_FUSED_SELECT")   # action selection inside the heads kernels (same stream either way)

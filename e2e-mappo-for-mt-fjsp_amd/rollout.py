@@ -27,13 +27,17 @@ class Rollout:
     def __init__(self, n_job, n_machine, n_edge, batch, device=0, policy="random", obs_dtype="f32",
                  instance_seed=0, rank=0, world=1, weights=None, w3_pool_episodes=32, greedy=False, seed=1234,
                  buffer_episodes=5, gamma=0.99, lam=0.98, collect=True, instances=None, w3_episodes=None, w3="device",
-                 exact_bn=False):
+                 exact_bn=False, global_handoff=True, time_handoff=False):
         """instances: (t, p, tt, edge) host arrays for THIS shard; default = rows [rank*batch, (rank+1)*batch) of the
         reference generator's `Instance_Dataset(samples=world*batch, seed=instance_seed)` (every
         instance distinct).  w3_episodes: [n,B,3] reward weights to use episode by episode (tests); otherwise w3 = "device"
         (default) or "host", see below.  exact_bn (world > 1, torch.distributed initialised): every BatchNorm of the actor
         forwards normalises over the rows of ALL shards (one small all-reduce per BatchNorm, streaming GIN launches) instead of
-        per shard — the reference's semantics for env_batch = world*batch; off by default."""
+        per shard — the reference's semantics for env_batch = world*batch; off by default.
+        weights = (job actor, machine actor[, global critic]) state dicts.  With collect="full" and global-critic weights the
+        hand-off is the reference's whole one (global_handoff; ppo:628-703).  time_handoff (bench.py): device events around the
+        all-gather and a synchronisation to read them — off in production, where the hand-off stays asynchronous.
+        Only rank's own instances are generated when none are passed (generate_instances(first=...))."""
         self.J, self.M, self.E, self.B = n_job, n_machine, n_edge, batch
         self.T = n_job * n_machine
         self.policy = policy
@@ -87,6 +91,9 @@ class Rollout:
         self.last_adv = None
         self.last_gather = None
         self.n_handoffs = 0
+        self.n_resident_failures = 0
+        self.global_handoff, self.time_handoff = global_handoff, time_handoff
+        self.last_full = None
         self.traj = None
         # local critic values: T+1 slots per episode — slot t<T is the value at act time of step t, slot T the value of
         # the terminal state from the post-terminal forward pair (run:455-475); v_ of step t is slot t+1 (run:451-454)
@@ -147,6 +154,26 @@ class Rollout:
         return self.w3_pool[self.episode % n]
 
     def step(self, force=None):
+        """one batched decision step; a reported time-out of the single-launch GIN kernel (capi.ERR_RETRY: every output since that
+        launch is invalid, the encoder has switched to the streaming launches) discards the trajectory buffer collected so far and
+        restarts the episode."""
+        try:
+            self._step(force)
+        except capi.MtfjspError as ex:
+            if ex.code != capi.ERR_RETRY:
+                raise
+            self._restart_after_failure()
+            self._step(force)
+
+    def _restart_after_failure(self):
+        self.n_resident_failures += 1
+        self.buf_pos = 0
+        self.t_in_ep = 0                                   # the next step resets every instance (fresh weights, scaler returns)
+        if self.full:
+            self.traj.reset()
+        self.actor.begin_episode()
+
+    def _step(self, force=None):
         """one batched decision step.  force = (task [B], machine [B]) int32 device tensors: apply these decisions instead of
         the sampled ones (teacher forcing for the parity tests; the forwards and everything recorded are unchanged)."""
         env = self.env
@@ -203,13 +230,25 @@ class Rollout:
         GLOBAL normalisation (adv - mean) / (std + 1e-5) — leaving normalised advantages + value targets on device."""
         from . import advantages as A
         S, T, B = self.S, self.T, self.B
+        # one synchronisation per buffer: a forward of this buffer that failed asynchronously (single-launch GIN kernel, see
+        # Encoder.check) must not reach the update — raises capi.ERR_RETRY, which step() turns into a restart of the buffer
+        self.actor.enc.check()
         # v of step t = slot t, v_ of step t = slot t+1 of its episode; the terminal step's v_ is the post-terminal forward
         # (run:451-475).  The deltas carry NO (1-done) factor (ppo:473,523): the terminal v_ enters every advantage of the
         # episode; (1-done) only stops the carried gae at episode boundaries.
         jv, mv = self.buf_jv[:, :T].reshape(S, B, 2), self.buf_mv[:, :T].reshape(S, B, 2)
         jv_, mv_ = self.buf_jv[:, 1:].reshape(S, B, 2), self.buf_mv[:, 1:].reshape(S, B, 2)
-        norm, targets, raw, self.last_gather = A.local_advantages(self.env, self.buf_r, jv, jv_, mv, mv_, self.buf_done,
-                                                                  self.gamma, self.lam, timed=True)
+        if self.full and self.actor.has_critic and self.global_handoff:
+            # the whole hand-off of ppo:628-703: the global critic sampled on every stored pre- and post-decision state (2 S
+            # forwards, no gradient), 4 global + 4 local advantages and the 8 value tensors in ONE all-gather
+            mv4, mv4_ = A.sample_global_values(self.actor.enc, self.traj)
+            h = A.full_handoff(self.env, self.buf_r, jv, jv_, mv, mv_, mv4, mv4_, self.buf_done, self.gamma, self.lam,
+                               timed=self.time_handoff)
+            self.last_full = h
+            norm, targets, raw, self.last_gather = h["local_adv"], h["local_targets"], h["raw_local"], h["gather"]
+        else:
+            norm, targets, raw, self.last_gather = A.local_advantages(self.env, self.buf_r, jv, jv_, mv, mv_, self.buf_done,
+                                                                      self.gamma, self.lam, timed=self.time_handoff)
         self.last_adv = (norm, targets)
         self.last_raw_adv = raw
         self.n_handoffs += 1

@@ -40,7 +40,10 @@ typedef enum {
     MTFJSP_ERR_ARG = -1,      /* bad argument / configuration */
     MTFJSP_ERR_STATE = -2,    /* call order (e.g. step before load_instances/reset) */
     MTFJSP_ERR_HIP = -3,      /* HIP runtime error (no device, launch failure, OOM) */
-    MTFJSP_ERR_ACTION = -4    /* *_host step: at least one action was invalid */
+    MTFJSP_ERR_ACTION = -4,   /* *_host step: at least one action was invalid */
+    MTFJSP_ERR_RETRY = -5     /* encoder: an earlier forward on the single-launch GIN kernel failed asynchronously (grid-barrier time-out);
+                               * everything enqueued on the handle since then is invalid, the handle has switched to the streaming
+                               * launches — repeat the work (see mtfjsp_encoder_check) */
 } mtfjsp_status;
 
 enum { MTFJSP_OBS_F64 = 0, MTFJSP_OBS_F32 = 1 };
@@ -276,14 +279,21 @@ int mtfjsp_encoder_arm_selection(mtfjsp_encoder_t e, int32_t which, int32_t gree
 /* One-shot like mtfjsp_encoder_arm_selection (and only together with it, which = 0): the next job actor forward also
  * writes m_fea1 / the machine mask of every instance's selected task (== mtfjsp_observe_mfea1 on gathered_out). */
 int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_ctx_t *ctx);
-/* Synchronises the encoder's stream and reports asynchronous failures of the forwards enqueued so far: the single-launch GIN
- * kernel synchronises its workgroups with in-kernel grid barriers whose spins are bounded; a timeout (not all workgroups
- * resident) is latched and returned here as MTFJSP_ERR_STATE.  *gin_resident_out (may be NULL) = 1 when that kernel is in use
- * for this handle (shape verified eligible by a census launch in mtfjsp_encoder_create, product-mode bits 1, 8, 16 clear), 0
- * when the six streaming launches are.  The single-launch kernel needs all of its workgroups resident at once (one per CU):
- * forwards of different handles must not overlap on the device (use one stream, or order them with events) — an overlap is
- * not a hang but a barrier timeout, reported here. */
+/* Synchronises the encoder's stream and reports asynchronous failures of the forwards enqueued so far.  The single-launch GIN
+ * kernel synchronises its workgroups with in-kernel grid barriers whose spins are bounded (4 ms); it needs all of its workgroups
+ * resident at once (one per CU), which another process or another stream using the same GPU can prevent — not a hang but a
+ * time-out.  The kernel then sets a host-mapped word that EVERY job-actor / global-critic forward polls on entry (a plain host
+ * read, no synchronisation) and that this call reads after synchronising: the first call to see it returns MTFJSP_ERR_RETRY,
+ * switches the handle to the six streaming launches (slower, no co-residency requirement) and leaves the caller to recompute what
+ * it enqueued since the failed launch (the Python rollout restarts the episode and discards the trajectory buffer).  A later
+ * mtfjsp_encoder_check re-runs the residency census on the idle stream and re-enables the single launch when it passes.
+ * *gin_resident_out (may be NULL) = 1 when the single-launch kernel is in use for this handle (shape eligible, census passed in
+ * mtfjsp_encoder_create or here, product-mode bits 1, 8, 16 clear), 0 when the streaming launches are.  Only one process / stream
+ * per GPU should use the single-launch path at a time (use one stream, or order handles with events).
+ * Diagnostic: MTFJSP_GIN_RES_FAIL_AT=n makes the n-th single-launch forward of a handle time out (tests). */
 int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_out);
+/* number of grid-barrier time-outs reported on this handle so far */
+int mtfjsp_encoder_resident_failures(mtfjsp_encoder_t e, int64_t *count_out);
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
 int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);
 /* per kernel family (between begin and the next begin): "gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg",

@@ -139,14 +139,14 @@ def test_gae_kernel_reproduces_the_reference_advantages():
         np.testing.assert_allclose(targets[i].cpu().numpy(), f["global_target"][i], rtol=1e-5, atol=1e-5)
 
 
-def _forced_rollout(f, collect, gin="streaming"):
+def _forced_rollout(f, collect, gin="streaming", critic=False):
     _mods()
     rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
     J, M, E, B, eps = [int(x) for x in f["meta"]]
     g, lam = [float(x) for x in f["gamma_lambda"]]
     w = _weights(f)
-    ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=(w["ja"], w["ma"]), collect=collect,
-                         buffer_episodes=eps, gamma=g, lam=lam, instances=(f["t"], f["p"], f["tt"], f["edge"]),
+    ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=(w["ja"], w["ma"]) + ((w["gc"],) if critic else ()),
+                         collect=collect, buffer_episodes=eps, gamma=g, lam=lam, instances=(f["t"], f["p"], f["tt"], f["edge"]),
                          w3_episodes=f["w3"])
     if gin == "resident":                               # single-launch GIN kernel: the default, J6M6 is eligible
         assert ro.actor.enc.check()
@@ -242,6 +242,127 @@ def test_device_trajectory_buffer_equals_the_reference_buffer_and_global_critic_
         np.testing.assert_allclose(targets[i].cpu().numpy(), f["global_target"][i], rtol=2e-3, atol=2e-3)
     finish(); reset()
     assert tb.count_operation == 0 and ro.last_adv is not None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gin", ["streaming", "resident"])
+def test_rollout_full_handoff_reproduces_all_eight_reference_advantages(gin):
+    """Rollout(collect="full") with the global critic's weights: finish_buffer runs the WHOLE hand-off of ppo:628-703 itself —
+    global critic over the stored pre-/post-decision states, 4 global + 4 local GAE scans, one packed exchange of the 8 advantage
+    and 8 value tensors, normalisation, value targets — teacher-forced on the reference's own rollout"""
+    f = np.load(FIX)
+    ro, (J, M, E, B, eps) = _forced_rollout(f, "full", gin, critic=True)
+    S = eps * J * M
+    i32 = lambda a: torch.tensor(a.astype(np.int32)).cuda()
+    for s in range(S):
+        ro.step(force=(i32(f["task"][s]), i32(f["mach"][s]), i32(f["job"][s])))
+    torch.cuda.synchronize()
+    assert ro.n_handoffs == 1 and ro.last_full is not None
+    h = ro.last_full
+    assert h["gather"] is None or h["gather"]["world"] == 1
+    for i in range(4):
+        np.testing.assert_allclose(h["global_adv"][i].cpu().numpy(), f["global_adv"][i], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(h["global_targets"][i].cpu().numpy(), f["global_target"][i], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(h["local_adv"][i].cpu().numpy(), f["local_adv"][i], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(h["local_targets"][i].cpu().numpy(), f["local_target"][i], rtol=2e-3, atol=2e-3)
+    assert len(h["full_adv"]) == 8 and len(h["full_values"]) == 8            # 16 tensors x [S,B]: SURVEY 8(e)'s exchange
+
+
+def _two_shard_worker(rank, world, port, q):
+    import torch.distributed as td
+    _mods()
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    D = import_module("e2e-mappo-for-mt-fjsp_amd.dist")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        f = np.load(FIX)
+        J, M, E, B, eps = [int(x) for x in f["meta"]]
+        g, lam = [float(x) for x in f["gamma_lambda"]]
+        lo, hi = D.shard_range(B, rank, world)
+        w = _weights(f)
+        ro = rollout.Rollout(J, M, E, hi - lo, policy="actor", obs_dtype="f32", weights=(w["ja"], w["ma"], w["gc"]), collect="full",
+                             buffer_episodes=eps, gamma=g, lam=lam, rank=rank, world=world, exact_bn=True,
+                             instances=tuple(f[k][lo:hi] for k in ("t", "p", "tt", "edge")), w3_episodes=f["w3"][:, lo:hi], time_handoff=True)
+        S = eps * J * M
+        i32 = lambda a: torch.tensor(np.ascontiguousarray(a).astype(np.int32)).cuda()
+        for s in range(S):
+            ro.step(force=(i32(f["task"][s, lo:hi]), i32(f["mach"][s, lo:hi]), i32(f["job"][s, lo:hi])))
+        torch.cuda.synchronize()
+        h = ro.last_full
+        worst = 0.0
+        for i in range(4):
+            for got, want in ((h["global_adv"][i], f["global_adv"][i]), (h["global_targets"][i], f["global_target"][i]),
+                              (h["local_adv"][i], f["local_adv"][i]), (h["local_targets"][i], f["local_target"][i])):
+                worst = max(worst, float(np.abs(got.cpu().numpy() - want[:, lo:hi]).max()))
+        # every rank holds the complete [S, B_total] exchange, rank-major columns
+        full_ok = all(tuple(x.shape) == (S, B) for x in h["full_adv"] + h["full_values"])
+        q.put((rank, worst, full_ok, h["gather"]["world"], h["gather"]["bytes_per_rank"], S * (hi - lo) * 4 * 16))
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_shards_full_handoff_through_rollout_reproduces_the_reference():
+    """two processes (gloo; RCCL on a multi-GPU node), each a Rollout over HALF of the reference run's instances with all-reduced
+    BatchNorm statistics (the shards then ARE the reference's whole-batch run): each rank's finish_buffer — global critic sampling,
+    8 GAE scans, ONE all-gather of 16 tensors, normalisation over all shards' columns — reproduces the reference's 4 global + 4
+    local advantages and value targets on its columns"""
+    import torch.multiprocessing as tmp_mp
+    ctx = tmp_mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_two_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    out = [q.get(timeout=600) for _ in procs]
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    for rank, worst, full_ok, world, nbytes, want_bytes in out:
+        assert worst < 3e-3 and full_ok and world == 2 and nbytes == want_bytes, (rank, worst, full_ok, world, nbytes, want_bytes)
+
+
+@pytest.mark.gpu
+def test_grid_barrier_timeout_is_reported_and_the_rollout_recovers(monkeypatch):
+    """MTFJSP_GIN_RES_FAIL_AT=n lets the n-th single-launch GIN forward's grid barriers time out (as if a compute unit were held
+    by somebody else): the failure is latched in a host-mapped word, the next forward entry returns MTFJSP_ERR_RETRY, the handle
+    falls back to the streaming launches, Rollout.step discards the buffer and restarts the episode — and check() brings the single
+    launch back once the census passes again."""
+    _mods()
+    monkeypatch.setenv("MTFJSP_GIN_RES_FAIL_AT", "7")
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    capi = import_module("e2e-mappo-for-mt-fjsp_amd.capi")
+    ro = rollout.Rollout(6, 6, 2, 512, policy="actor", obs_dtype="f32", collect=True, buffer_episodes=1)
+    enc = ro.actor.enc
+    assert enc.check() and enc.resident_failures() == 0
+    for _ in range(5):
+        ro.step()
+    assert ro.n_resident_failures == 0
+    for _ in range(40):                                          # launch 7 fails (6 x 4 ms of bounded spins); noticed at the next forward entry
+        ro.step()
+    torch.cuda.synchronize()
+    assert ro.n_resident_failures == 1 and enc.resident_failures() == 1
+    assert ro.buf_pos == ro.t_in_ep                               # the buffer restarted together with the episode
+    assert torch.isfinite(enc.job_prob).all() and torch.isfinite(enc.mch_prob).all()
+    assert int((ro.env.status & capi.ST_INVALID).sum().item()) == 0
+    assert enc.check()                                            # idle stream: census re-run, single launch re-enabled
+    for _ in range(40):
+        ro.step()
+    torch.cuda.synchronize()
+    assert ro.n_resident_failures == 1 and ro.n_handoffs >= 1
+    ro.check_finished_cleanly()
+    # a bare Encoder user (no Rollout) sees the error code instead of silent garbage
+    monkeypatch.setenv("MTFJSP_GIN_RES_FAIL_AT", "2")
+    ro2 = rollout.Rollout(6, 6, 2, 512, policy="actor", obs_dtype="f32", collect=False)
+    env, e2 = ro2.env, ro2.actor.enc
+    ro2.step()                                                    # launch 1: fine
+    e2.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, None)
+    with pytest.raises(capi.MtfjspError) as ei:
+        e2.check()
+    assert ei.value.code == capi.ERR_RETRY
+    p1 = e2.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, None)[0].clone()
+    assert torch.isfinite(p1).all()
 
 
 @pytest.mark.gpu
