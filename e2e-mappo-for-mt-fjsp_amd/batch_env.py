@@ -195,6 +195,11 @@ class DeviceBatchEnv:
         capi.check(self.L.mtfjsp_valid_action_mask(self.h, out.data_ptr()), self.h)
         return out
 
+    def set_scaler_state(self, first, state17):
+        """restore the RewardScaling state ([n,17], MTFJSP_STATE_SCALER layout) of instances first..first+n-1"""
+        a = np.ascontiguousarray(state17, np.float64).reshape(-1, 17)
+        capi.check(self.L.mtfjsp_set_scaler_state_host(self.h, int(first), a.shape[0], a.ctypes.data), self.h)
+
     def read_state(self, which):
         B, T, M = self.B, self.T, self.M
         shape, dt = {capi.STATE_MACHINE: ((B, T), np.int32), capi.STATE_START: ((B, T), np.float64),

@@ -70,6 +70,7 @@ PROTOTYPES = {
     "mtfjsp_export_dense_adj_host": (_I, [_VP, _VP]),
     "mtfjsp_valid_action_mask": (_I, [_VP, _VP]),
     "mtfjsp_read_state_host": (_I, [_VP, _I, _VP]),
+    "mtfjsp_set_scaler_state_host": (_I, [_VP, _I, _I, _VP]),
     "mtfjsp_copy_to_host": (_I, [_VP, _VP, _VP, _SZ]),
     "mtfjsp_timing_begin": (_I, [_VP]),
     "mtfjsp_timing_end": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

@@ -1536,6 +1536,8 @@ struct mtfjsp_env {
     double2 *cst = nullptr;
     int *shop = nullptr;
     double *st = nullptr, *ft = nullptr, *dur = nullptr, *psel = nullptr, *mfea = nullptr, *scal = nullptr;
+    size_t lds_max = 64 * 1024;        // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device (160 KiB on gfx950)
+    bool grp_lds_ok = true;            // the grouped LDS step kernel may be launched with lds_max bytes
     Link *link = nullptr;
     MRec *mrec = nullptr;
     short *jcnt = nullptr;
@@ -1593,7 +1595,11 @@ extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
     const size_t B = cfg->batch, T = h->T, M = cfg->n_machine;
     size_t lds = env_step_lds_bytes(cfg->n_job, cfg->n_machine, h->T, cfg->obs_dtype == MTFJSP_OBS_F32);
     if (env_reset_lds_bytes(h->T, false) > lds) lds = env_reset_lds_bytes(h->T, false);
-    if (lds > 160 * 1024) { g_create_err = "instance too large for one CU's LDS"; delete h; return MTFJSP_ERR_ARG; }
+    {   // LDS a workgroup may use on THIS device (gfx950: 160 KiB; asked, not assumed)
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, cfg->device_id) == hipSuccess && v > 0) h->lds_max = (size_t)v;
+    }
+    if (lds > h->lds_max) { g_create_err = "instance too large for one CU's LDS"; delete h; return MTFJSP_ERR_ARG; }
     int rc = 0;
     rc |= dalloc(h, &h->t, B * T * M); rc |= dalloc(h, &h->p, B * T * M); rc |= dalloc(h, &h->tt, B * M * M);
     rc |= dalloc(h, &h->mean3, B * T * 3); rc |= dalloc(h, &h->cst, B * T); rc |= dalloc(h, &h->shop, B * M);
@@ -1615,12 +1621,8 @@ extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
         }
     {   // the grouped LDS kernel takes up to a CU's worth of LDS (G instance regions)
         const void *grp_kernels[] = {(const void *)k_env_step_grp<double>, (const void *)k_env_step_grp<float>};
-        for (const void *k : grp_kernels)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                g_create_err = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
-                mtfjsp_destroy(h);
-                return MTFJSP_ERR_HIP;
-            }
+        for (const void *k : grp_kernels)                                  // a refusal only means "no grouped LDS kernel": G = 1 (k_env_step) serves
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_max) != hipSuccess) h->grp_lds_ok = false;
     }
     *out = h;
     return MTFJSP_OK;
@@ -1890,7 +1892,7 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
         // LDS kernel: groups of G instances per workgroup where at least two instances' regions fit (MTFJSP_ENV_STEP_G overrides;
         // 1 = the one-instance kernel k_env_step)
         const EnvStepLds LL(P.J, P.M, P.T, P.obs_f32 != 0);
-        const int gmax = (int)((size_t)(160 * 1024 - 512) / LL.bytes);
+        const int gmax = h->grp_lds_ok ? (int)((h->lds_max - 512) / LL.bytes) : 1;
         int G = gmax >= 4 ? 4 : gmax >= 2 ? 2 : 1;
         if (const char *gs = getenv("MTFJSP_ENV_STEP_G")) { G = atoi(gs); G = G < 1 ? 1 : G > 16 ? 16 : G; G = G > gmax ? (gmax < 1 ? 1 : gmax) : G; }
         if (force && !strcmp(force, "lds1")) G = 1;
@@ -2104,6 +2106,27 @@ extern "C" int mtfjsp_read_state_host(mtfjsp_handle_t h, int which, void *out)
         h->err = "read_state: unknown selector";
         return MTFJSP_ERR_ARG;
     }
+}
+
+// restores the RewardScaling state of instances [first, first + count) from the layout MTFJSP_STATE_SCALER reads (R[4], n, mean[4],
+// S[4], std[4]): the per-env gym step of the Python mirror drives ONE instance through the fused step kernel, which also applies
+// RewardScaling — the reference's env.step (env:716-974) never touches the scaler, only the batched step does (pe:255-260)
+extern "C" int mtfjsp_set_scaler_state_host(mtfjsp_handle_t h, int32_t first, int32_t count, const double *state17)
+{
+    if (!h || !state17 || first < 0 || count < 1 || (size_t)first + (size_t)count > (size_t)h->cfg.batch) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    std::vector<double> sc((size_t)count * SCAL_N);
+    int rc = mtfjsp_copy_to_host(h, sc.data(), h->scal + (size_t)first * SCAL_N, (size_t)count * SCAL_N * 8);
+    if (rc) return rc;
+    for (int b = 0; b < count; b++) {
+        double *s = &sc[(size_t)b * SCAL_N];
+        const double *o = state17 + (size_t)b * 17;
+        for (int i = 0; i < 4; i++) { s[S_R + i] = o[i]; s[S_MEAN + i] = o[5 + i]; s[S_S + i] = o[9 + i]; s[S_STD + i] = o[13 + i]; }
+        s[S_N] = o[4];
+    }
+    HIPCHK(h, hipMemcpyAsync(h->scal + (size_t)first * SCAL_N, sc.data(), (size_t)count * SCAL_N * 8, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return MTFJSP_OK;
 }
 
 extern "C" int mtfjsp_gae(mtfjsp_handle_t h, int32_t S, const float *r, int64_t r_ss, int64_t r_sb, const float *v, int64_t v_ss, int64_t v_sb,

@@ -239,24 +239,41 @@ class Parallel_env(object):
         return adj, self.oenv_info, mfea2, tfea
 
     def _step_one(self, i, a, m):
-        """per-env gym step of instance i (proxy.step): every other instance gets task index -1, which the kernel rejects
-        leaving it untouched (MTFJSP_ST_INVALID)"""
+        """per-env gym step of instance i (proxy.step / DisjunctiveGraphJspEnv_singleStep.step, env:716-974): every other instance
+        gets task index -1, which the kernel rejects leaving its STATE untouched (MTFJSP_ST_INVALID; its info / raw reward rows of
+        the last batched step are cleared).  The fused step kernel also applies RewardScaling, which the reference's env.step never
+        does (only the batched step, pe:255-260): instance i's scaler state is saved before and restored after the launch, so
+        mixing proxy steps with DGFJSPEnv_paral_step leaves the scaled rewards exactly the reference's."""
         B, T, M = self.batch_size, self.ntasks, self.nmachines
         ta = torch.full((B,), -1, dtype=torch.int32); ma = torch.zeros(B, dtype=torch.int32)
         ta[i], ma[i] = a, m
         self._flush_scaler_resets()
+        scaler_i = self._dev.read_state(capi.STATE_SCALER)[i].copy()
         self._dev.step(ta.to(self._dev.device), ma.to(self._dev.device))
+        self._dev.set_scaler_state(i, scaler_i)
         self._cache = {}
         status = int(self._dev.status[i].item())
         if status & capi.ST_INVALID:
             raise ValueError(f"invalid action for instance {i}: task {a} is scheduled already, its job predecessor is not, or an index is out of range")
         raw = self._dev.raw[i].cpu().numpy()
         done = bool(self._dev.info[i, 1].item())
-        adj = self._dev.dense_adj()[i].cpu().numpy()
+        adj = self._dense_adj_row(i)
         tfea = self._dev.tasks_fea.view(B, T, 12)[i].cpu().numpy().copy()
         mfea = self._dev.m_fea2[i].cpu().numpy().copy()
         return (None, float(raw[0]), done, {}, float(raw[1]), float(raw[2]), float(raw[3]), float(raw[4]), None, None,
                 adj, None, mfea, tfea)
+
+    def _dense_adj_row(self, i):
+        """dense adj_wrk [T,T] of ONE instance from its 2 T ELL entries (row = destination, self loop 1; env:2019-2073) — not the
+        whole [B,T,T] export"""
+        T = self.ntasks
+        col = self._dev.ell_col.view(self.batch_size, T, 2)[i].cpu().numpy()
+        val = self._dev.ell_val.view(self.batch_size, T, 2)[i].cpu().numpy()
+        adj = np.eye(T)
+        for k in range(2):
+            ok = col[:, k] >= 0
+            adj[np.flatnonzero(ok), col[ok, k]] = val[ok, k]
+        return adj
 
     def reset_data(self):
         """pe:271-282"""

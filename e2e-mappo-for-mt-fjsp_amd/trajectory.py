@@ -179,8 +179,13 @@ class TrajectoryBuffer:
         self.a_logprob[k].copy_(self._t(a_m_logprob, torch.float32).reshape(self.B))
         self.machine_fea2_[k].copy_(self._t(mch_fea2_, od).reshape(self.B, self.M, 8))
         self.random_weight[k].copy_(self._t(rw, torch.float32).reshape(self.B, 3))
-        self.job_v[k].copy_(self._t(j_v, torch.float32).reshape(self.B, 2))
-        self.machine_v[k].copy_(self._t(m_v, torch.float32).reshape(self.B, 2))
+        if self.alias_v_next:                                  # slot t of episode e (the same mapping slot() uses)
+            e, t = divmod(k, self.total_task)
+            self._jv[e, t].copy_(self._t(j_v, torch.float32).reshape(self.B, 2))
+            self._mv[e, t].copy_(self._t(m_v, torch.float32).reshape(self.B, 2))
+        else:
+            self.job_v[k].copy_(self._t(j_v, torch.float32).reshape(self.B, 2))
+            self.machine_v[k].copy_(self._t(m_v, torch.float32).reshape(self.B, 2))
         self.count_operation += 1
 
     def store_v_next(self, j_v_, m_v_):

@@ -178,6 +178,10 @@ enum {
     MTFJSP_STATE_W3 = 6         /* f64   [B,3]   reward_random_weight                   (run:478)                   */
 };
 int mtfjsp_read_state_host(mtfjsp_handle_t h, int which, void *out_host);
+/* writes back the RewardScaling state (MTFJSP_STATE_SCALER layout, [count,17]) of instances [first, first+count): lets a caller
+ * drive ONE instance through mtfjsp_step the way the reference's gym-style env.step does (env:716-974 — no reward scaling;
+ * only the batched step applies it, pe:255-260) by restoring that instance's scaler afterwards */
+int mtfjsp_set_scaler_state_host(mtfjsp_handle_t h, int32_t first, int32_t count, const double *state17);
 /* copy `nbytes` from a device buffer of this handle's context to host (synchronises the stream) */
 int mtfjsp_copy_to_host(mtfjsp_handle_t h, void *dst_host, const void *src_dev, size_t nbytes);
 

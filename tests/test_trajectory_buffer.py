@@ -75,6 +75,19 @@ def test_buffer_returns_what_the_reference_buffer_returns(ell_inputs):
     assert buf.count_operation == 0 and buf.count_operation_ == 0
 
 
+def test_store_operation_on_an_aliased_buffer_lands_in_the_shifted_value_slots():
+    """alias_v_next (the device rollout's layout): the reference-interface store must write job_v / machine_v through the same
+    (episode, step) mapping slot() uses — v_ of step t is then the stored v of step t+1"""
+    traj = import_module("e2e-mappo-for-mt-fjsp_amd.trajectory")
+    args = {"n_job": 6, "n_machine": 6, "buffer_size": 1, "env_batch": 2, "gcn_input_dim": 12}
+    buf = traj.TrajectoryBuffer(args, device="cpu", obs_dtype=torch.float64, alias_v_next=True)
+    buf.store_v_next = lambda *a: None                       # (the aliased layout has nothing to store there)
+    f, (J, M, B, T) = _fill(buf, False)
+    jv, mv, jv_, mv_ = buf.local_values()
+    assert np.array_equal(jv.numpy(), f["out_job_v"]) and np.array_equal(mv.numpy(), f["out_machine_v"])
+    assert np.array_equal(jv_.numpy()[:T - 1], f["out_job_v"][1:T]) and np.array_equal(mv_.numpy()[:T - 1], f["out_machine_v"][1:T])
+
+
 def test_dense_to_ell_round_trip_and_rejects_non_graph_input():
     traj = import_module("e2e-mappo-for-mt-fjsp_amd.trajectory")
     g = np.load(os.path.join(GOLDEN, "trace_j10m10e2_b2_mask.npz"))
