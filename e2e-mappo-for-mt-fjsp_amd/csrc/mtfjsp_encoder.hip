@@ -1153,16 +1153,16 @@ __global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
                     for (int i = 0; i < 4; i++) acc[c][i] = my_a[gx_off(4 * q + i, c * 16 + m)];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             } else {
-                // the tile in operand layout: row m, k = 32ks + 8q .. +7, split into two f16 planes (the values are ELU outputs of
-                // attention mixtures — unbounded in principle, so they saturate at the f16 range instead of overflowing)
+                // the tile in operand layout: row m, k = 32ks + 8q .. +7, split into two f16 planes.  The values are ELU outputs of
+                // attention mixtures — unbounded in principle: one beyond the f16 range becomes (inf | -inf) pieces, their products
+                // a NaN that reaches every output of the forward, where the heads kernel reports it (range_flag) and the host
+                // repeats the forward on the f32-instruction kernels — never a silently saturated value
                 h16x8 xf[2][4];
 #pragma unroll
                 for (int ks = 0; ks < 4; ks++) {
                     const float4 lo = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q));
                     const float4 hi = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q + 4));
-                    const float FM = 65000.f;
-                    const float v0[4] = {__builtin_amdgcn_fmed3f(lo.x, -FM, FM), __builtin_amdgcn_fmed3f(lo.y, -FM, FM), __builtin_amdgcn_fmed3f(lo.z, -FM, FM), __builtin_amdgcn_fmed3f(lo.w, -FM, FM)};
-                    const float v1[4] = {__builtin_amdgcn_fmed3f(hi.x, -FM, FM), __builtin_amdgcn_fmed3f(hi.y, -FM, FM), __builtin_amdgcn_fmed3f(hi.z, -FM, FM), __builtin_amdgcn_fmed3f(hi.w, -FM, FM)};
+                    const float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
                     uint2 a0, a1, b0, b1;
                     split2x4(v0, a0, a1); split2x4(v1, b0, b1);
                     xf[0][ks] = __builtin_bit_cast(h16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
@@ -1333,6 +1333,7 @@ struct HeadArgs {
     double *zero_stats; int zero_count;  // BatchNorm accumulators no kernel reads any more: zeroed here for the next forward
     double *zero_stats2; int zero_count2;
     unsigned long long *stamps;
+    unsigned *range_flag;                  // host-mapped word, set when an output is not a number (an f16 operand piece overflowed somewhere upstream); NULL on the f32-instruction path
 };
 #define HG 16                            // instances per group
 #define HCH 6                            // scorer tiles per chunk (even; X tiles and s1 tiles are separate LDS buffers)
@@ -1853,7 +1854,11 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
                 float p0 = 0.f, p1 = 0.f;
                 for (int k = 0; k < 4; k++) { const float x = s_c2[r * HX_CLDA + part * 4 + k]; p0 = fmaf(x, s_wc2[part * 4 + k], p0); p1 = fmaf(x, s_wc2[HD + part * 4 + k], p1); }
                 for (int o = 16; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
-                if (part == 0 && r < ng) { A.value[(size_t)(g0 + r) * 2] = p0 + A.bc2[0]; A.value[(size_t)(g0 + r) * 2 + 1] = p1 + A.bc2[1]; }
+                if (part == 0 && r < ng) {
+                    const float v0 = p0 + A.bc2[0], v1 = p1 + A.bc2[1];
+                    A.value[(size_t)(g0 + r) * 2] = v0; A.value[(size_t)(g0 + r) * 2 + 1] = v1;
+                    if (A.range_flag && (v0 != v0 || v1 != v1)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
             LDS_BARRIER();
             if (tid < nt * 16) {
@@ -1878,6 +1883,7 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
                 for (int r = l; r < R; r += 16) {
                     const float pr = s_mask[r0 * R + r] ? 0.f : __expf(s_score[r0 * R + r] - mx) / sum;
                     A.prob[(size_t)(g0 + r0) * R + r] = pr;
+                    if (A.range_flag && pr != pr) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     s_score[r0 * R + r] = pr;                           // lanes of one wave: visible to lane l == 0 below
                 }
                 if (A.sample_mode) {
@@ -2441,6 +2447,8 @@ struct mtfjsp_encoder {
     unsigned long long *res_bar = nullptr;  // [17 * 16] barrier words
     unsigned *res_fail = nullptr;           // device address of *res_fail_host
     volatile unsigned *res_fail_host = nullptr;   // host-mapped word the kernel sets when a grid barrier times out: polled at every forward entry (no synchronisation)
+    unsigned *range_flag = nullptr;         // device address of the next word of the same host-mapped block (flags_host[1]): an output was not a number
+    long long range_fallbacks = 0;          // times the handle switched to the f32-instruction kernels because of it
     bool res_eligible = false;              // the shape can use the single-launch kernel (res_ok: and the census passed / no failure since)
     long long res_failures = 0, res_launches = 0;
     long long res_fail_at = getenv("MTFJSP_GIN_RES_FAIL_AT") ? atoll(getenv("MTFJSP_GIN_RES_FAIL_AT")) : 0;   // diagnostic: this launch's barriers time out
@@ -2510,8 +2518,8 @@ static int res_alloc_fail_word(mtfjsp_encoder *e)
     void *h = nullptr, *d = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) return 1;
     if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipHostFree(h); return 1; }
-    e->res_fail_host = (volatile unsigned *)h; e->res_fail = (unsigned *)d;
-    *e->res_fail_host = 0u;
+    e->res_fail_host = (volatile unsigned *)h; e->res_fail = (unsigned *)d; e->range_flag = (unsigned *)d + 1;
+    e->res_fail_host[0] = 0u; e->res_fail_host[1] = 0u;
     return 0;
 }
 // census: every workgroup must be resident at once for the grid barriers to complete (bounded spins report it).  Synchronises the device.
@@ -2535,12 +2543,30 @@ static bool res_census(mtfjsp_encoder *e)
 // e.g. another process or stream held compute units).  Everything enqueued on this handle since that launch is invalid.  The
 // handle falls back to the six streaming launches (mtfjsp_encoder_check re-runs the census and re-enables the single launch
 // when the device can hold the grid again) and the caller is told to repeat the work: MTFJSP_ERR_RETRY.
+static bool split_products_in_use(const mtfjsp_encoder *e) { return (e->f32_products & 15) != 15; }
 static int res_poll_failure(mtfjsp_encoder *e)
 {
-    if (!e->res_fail_host || !*e->res_fail_host) return MTFJSP_OK;
+    if (!e->res_fail_host) return MTFJSP_OK;
+    if (e->res_fail_host[1]) {
+        // An output of an earlier forward was not a number.  On the split-product kernels that is what an activation beyond the
+        // f16 range (65 504) turns into — BatchNorm outputs scaled by a large gamma, neighbour sums with large edge weights, GAT
+        // mixtures — (inf | -inf) operand pieces whose products cancel to NaN and spread through the BatchNorm statistics to every
+        // output.  The reference computes in f32 / f64 and has no such limit: the handle switches to the f32-instruction kernels
+        // (product mode 15; mtfjsp_encoder_set_product_mode(0) goes back) and the caller repeats the forward.
+        (void)hipStreamSynchronize(e->stream);
+        e->res_fail_host[1] = 0u;
+        if (split_products_in_use(e)) {
+            e->f32_products |= 15; e->range_fallbacks++;
+            e->gin_stats_clean = false; e->gat_stats_clean[0] = e->gat_stats_clean[1] = false;   // the accumulators hold NaNs
+            e->err = "an activation left the f16 range of the split products (outputs were not numbers): the handle now uses the "
+                     "f32-instruction kernels; repeat the forward(s) enqueued since";
+            return MTFJSP_ERR_RETRY;
+        }
+    }
+    if (!e->res_fail_host[0]) return MTFJSP_OK;
     (void)hipStreamSynchronize(e->stream);
     e->res_ok = false; e->res_failures++;
-    *e->res_fail_host = 0u;
+    e->res_fail_host[0] = 0u;
     (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); e->res_epoch = 0;
     (void)hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8);
     e->err = "single-launch GIN kernel: a grid barrier timed out (its workgroups were not co-resident); every output enqueued since that "
@@ -2581,6 +2607,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     rc |= dalloc_rows(&e->pooled_int, B);
     rc |= dalloc_rows(&e->node, B * M);
     rc |= dalloc(e, &e->stats, 8 * STAT_REP * 256);
+    rc |= res_alloc_fail_word(e);
     if (!rc && hipMemset(e->stats, 0, 8 * STAT_REP * 256 * sizeof(double)) == hipSuccess) { e->gin_stats_clean = true; e->gat_stats_clean[0] = e->gat_stats_clean[1] = true; }
     if (rc) { g_enc_err = e->err; mtfjsp_encoder_destroy(e); return MTFJSP_ERR_HIP; }
     const int lds16 = (int)gemm16_lds_bytes();
@@ -2606,7 +2633,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
             const int grid = (B + ipc - 1) / ipc;
             if (ipc * T <= GR_ROWS && ipc <= GR_MAXIPC && grid <= e->num_cu && ipc * cfg->n_job <= GR_MAXCAND &&
                 hipFuncSetAttribute((const void *)k_gin_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gin_res_lds_bytes()) == hipSuccess) {
-                int rc = dalloc(e, &e->res_stats, (size_t)2 * GR_STATS_SET) | dalloc(e, &e->res_bar, (size_t)17 * 16) | res_alloc_fail_word(e) |
+                int rc = dalloc(e, &e->res_stats, (size_t)2 * GR_STATS_SET) | dalloc(e, &e->res_bar, (size_t)17 * 16) |
                          dalloc(e, &e->res_zspill, (size_t)grid * 4 * (GR_NT - GR_NRES) * 1024);
                 if (!rc && hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8) == hipSuccess &&
                     hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8) == hipSuccess) {
@@ -3231,6 +3258,7 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
 {
     const int grid = (ha.B + HG - 1) / HG;
     if (e->f32_products & 4) { hipLaunchKernelGGL(k_heads, dim3(grid), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
+    ha.range_flag = e->range_flag;
     ha.W0x = e->wx6.at(policy + ".linears.0.weight"); ha.W1x = e->wx6.at(policy + ".linears.1.weight");
     ha.Wc0x = e->wx6.at(critic + ".linears.0.weight"); ha.Wc1x = e->wx6.at(critic + ".linears.1.weight");
     ha.sW0 = e->wx6_sinv.at(policy + ".linears.0.weight"); ha.sW1 = e->wx6_sinv.at(policy + ".linears.1.weight");
@@ -3350,6 +3378,7 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
     int rc = mtfjsp_encoder_weights_ready(e);
     if (rc) return rc;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    if ((rc = res_poll_failure(e))) return rc;
     const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
@@ -3387,14 +3416,16 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
 }
 
 // out[b][o] = W[o,:] . x[b,:] + bias[o]   (the last 128 -> O linear of a critic head), thread = (b, o)
-__global__ void k_linear_small(int B, int O, const float *x, const float *W, const float *bias, float *out)
+__global__ void k_linear_small(int B, int O, const float *x, const float *W, const float *bias, float *out, unsigned *range_flag)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * O) return;
     const int b = i / O, o = i % O;
     float p = 0.f;
     for (int k = 0; k < HD; k++) p = fmaf(x[(size_t)b * HD + k], W[o * HD + k], p);
-    out[i] = p + bias[o];
+    p += bias[o];
+    out[i] = p;
+    if (range_flag && p != p) __hip_atomic_store(range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // = Global_Critic_JointAction_GAT.forward (ac:587-750): own GIN encoder -> graph pool, own GAT machine path
@@ -3428,7 +3459,7 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
     {
         Timed t(e, "small");
         hipLaunchKernelGGL(k_linear_small, dim3((B * 4 + 255) / 256), dim3(256), 0, e->stream, B, 4, e->c2, W("global_critic.critic.linears.2.weight"),
-                           W("global_critic.critic.linears.2.bias"), value4);
+                           W("global_critic.critic.linears.2.bias"), value4, split_products_in_use(e) ? e->range_flag : nullptr);
     }
     HIPCHK(e, hipGetLastError());
     return MTFJSP_OK;
@@ -3485,6 +3516,14 @@ extern "C" int mtfjsp_encoder_resident_failures(mtfjsp_encoder_t e, int64_t *cou
 {
     if (!e || !count_out) return MTFJSP_ERR_ARG;
     *count_out = e->res_failures;
+    return MTFJSP_OK;
+}
+
+extern "C" int mtfjsp_encoder_range_fallbacks(mtfjsp_encoder_t e, int64_t *count_out, int32_t *product_mode_out)
+{
+    if (!e || !count_out) return MTFJSP_ERR_ARG;
+    *count_out = e->range_fallbacks;
+    if (product_mode_out) *product_mode_out = e->f32_products;
     return MTFJSP_OK;
 }
 

@@ -16,8 +16,13 @@
 // <= 2^-22 |w x| too.  The rounding of a 128-term f32 FMA chain is of the same size, and the tests hold the kernel to the same
 // bounds as the exact 6-product bf16 split of the streaming kernels (which it replaced here: half the matrix work and about
 // half the vector work per element; measured 16.5 us instead of 23.4 us per layer).  f16 overflows at 65504: the operands are
-// BatchNorm outputs (|.| <= sqrt(rows) * |gamma| + |beta|) and 3-term neighbour sums of them.  The first Linear (12 raw
-// features, unbounded) keeps the exact bf16 split.  Matrix work: 14.5 GFLOP of piece products per layer = 6.4 us at the
+// BatchNorm outputs (|.| <= sqrt(rows) * |gamma| + |beta|) and, in the second GIN layer, their neighbour sums WEIGHTED BY THE EDGE
+// WEIGHTS (values to 309 at J6M6, larger on larger instances: (h + w0 h0 + w1 h1) / nnz can reach ~100 |h|) — comfortably inside
+// the range for trained checkpoints, but not guaranteed: an operand beyond it becomes (inf | -inf) pieces whose products cancel
+// to NaN; the NaN reaches the BatchNorm sums of the layer and through them every output of the forward, where the heads kernel
+// raises the handle's range flag and the host repeats the forward on the f32-instruction kernels (mtfjsp_encoder.hip:
+// res_poll_failure) — never a silent inf or a saturated value.  The first Linear (12 raw features, unbounded) keeps the exact
+// bf16 split.  Matrix work: 14.5 GFLOP of piece products per layer = 6.4 us at the
 // measured 2.27 PFLOP/s.
 //
 // Layout.  v_mfma_f32_32x32x16_f16 with the operands swapped (A := weight fragments, resident in registers; B := activation

@@ -198,6 +198,12 @@ class Encoder:
         capi.check(self.L.mtfjsp_encoder_resident_failures(self.h, C.byref(n)), self.h, enc=True)
         return int(n.value)
 
+    def range_fallbacks(self):
+        """-> (times the handle left the f16 split products because an activation exceeded their range, product mode in force)"""
+        n, m = C.c_int64(0), C.c_int32(0)
+        capi.check(self.L.mtfjsp_encoder_range_fallbacks(self.h, C.byref(n), C.byref(m)), self.h, enc=True)
+        return int(n.value), int(m.value)
+
     def arm_selection(self, which, greedy, seed, counter, idx_out, logp_out=None, gather_from=None, gathered_out=None):
         """fuse the action selection of the next job (which=0) / machine (which=1) actor forward into its heads kernel; same
         stream and outputs as sample() on that forward's prob"""

@@ -296,6 +296,15 @@ int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_ctx_t *ctx);
  * per GPU should use the single-launch path at a time (use one stream, or order handles with events).
  * Diagnostic: MTFJSP_GIN_RES_FAIL_AT=n makes the n-th single-launch forward of a handle time out (tests). */
 int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_out);
+/* Range of the split products.  The default kernels run every 128-deep product on the f16 matrix cores from operands split into
+ * two f16 pieces: f32-accurate, but an activation beyond 65 504 (a BatchNorm gamma of several hundred, an edge weight of several
+ * thousand — nothing a trained reference checkpoint produces, nothing the reference's f32/f64 arithmetic forbids) cannot be
+ * represented.  It is never clamped and never silent: its pieces are (inf | -inf), their products NaN, the NaN reaches every output
+ * of that forward, the heads kernel sets a host-mapped word, and the next forward entry (or mtfjsp_encoder_check) returns
+ * MTFJSP_ERR_RETRY after switching the handle to the f32-instruction kernels (product mode 15, no range limit, slower): repeat
+ * the forward.  mtfjsp_encoder_set_product_mode(0) returns to the split products.  *count_out = number of such switches,
+ * *product_mode_out (may be NULL) = the product mode now in force. */
+int mtfjsp_encoder_range_fallbacks(mtfjsp_encoder_t e, int64_t *count_out, int32_t *product_mode_out);
 /* number of grid-barrier time-outs reported on this handle so far */
 int mtfjsp_encoder_resident_failures(mtfjsp_encoder_t e, int64_t *count_out);
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);

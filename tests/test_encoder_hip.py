@@ -135,6 +135,78 @@ def test_actor_forwards_match_reference_outputs_two_instances_per_workgroup(batc
     enc.check()
 
 
+def test_activation_beyond_the_f16_range_falls_back_to_the_f32_kernels():
+    """BatchNorm gammas x64 and an in-edge weight of 3000 (gcn:125 aggregates with the raw edge weights; the reference has no
+    range limit): the neighbour sums of the second GIN layer exceed 65 504, which the f16 operand pieces cannot hold.  Never a
+    clamp, never a silent inf: the forward's outputs are NaN, the heads kernel latches the range flag, check() returns
+    MTFJSP_ERR_RETRY after switching the handle to the f32-instruction kernels, and the repeated forward matches the oracle at
+    the usual tolerance.  Same for the GAT (machine features x 3e4).  set_product_mode(0) goes back to the split products."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    capi = import_module("e2e-mappo-for-mt-fjsp_amd.capi")
+    from oracle import encoder_oracle as eo
+    g = np.load(os.path.join(GOLDEN, "encoder_j6m6e2_rand.npz"))
+    J, M, E, B = [int(x) for x in g["meta"]]
+    T = J * M
+    ja, ma = eo.split_weights(g)
+    ja = {k: (v * 64 if ("batch_norms" in k and k.endswith("weight")) else v).astype(np.float32) for k, v in ja.items()}
+    p = f"s{int(g['steps'][1])}_"
+    col, val = eo.ell_from_dense(g[p + "adj"])
+    val = val.copy()
+    has = col >= 0
+    assert has.any()
+    val[has] = np.where(np.arange(has.sum()) % 3 == 0, 3000.0, val[has])
+    hm_in = g[p + "h_m_in"]
+    args = lambda: (_t(g[p + "tfea"], torch.float32), _t(col.reshape(B * T, 2).astype(np.int32)), _t(val.reshape(B * T, 2).astype(np.float32)),
+                    _t(g[p + "cand"].astype(np.int32)), _t(g[p + "mask"].astype(np.uint8)), None if hm_in.size == 0 else _t(hm_in.astype(np.float32)))
+    o = eo.job_actor_forward(ja, g[p + "tfea"], col, val, g[p + "cand"], g[p + "mask"], hm_in, B, T)
+    for gin in ("resident", "streaming"):
+        enc = enc_mod.Encoder(J, M, B, obs_dtype="f32")
+        enc.load_weights(ja, ma)
+        if gin == "streaming":
+            enc.set_product_mode(16)
+        prob = enc.job_actor_forward(*args())[0]
+        torch.cuda.synchronize()
+        assert not torch.isfinite(prob).all(), "the operand pieces overflowed: the split products cannot have produced numbers"
+        with pytest.raises(capi.MtfjspError) as ei:
+            enc.check()
+        assert ei.value.code == capi.ERR_RETRY
+        n, mode = enc.range_fallbacks()
+        assert n == 1 and (mode & 15) == 15
+        h_nodes = torch.zeros(B * T, 128, dtype=torch.float32, device="cuda")
+        prob, h_o, job_v = enc.job_actor_forward(*args(), h_nodes=h_nodes)
+        torch.cuda.synchronize()
+        assert not enc.check()
+        scale = max(1.0, float(np.abs(o["h_nodes"]).max()))
+        np.testing.assert_allclose(h_nodes.cpu().numpy(), o["h_nodes"], rtol=0, atol=1e-4 * scale)
+        np.testing.assert_allclose(h_o.cpu().numpy(), o["h_pooled"], rtol=0, atol=1e-4 * scale)
+        np.testing.assert_allclose(prob.cpu().numpy(), o["prob"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(job_v.cpu().numpy(), o["job_v"], rtol=1e-3, atol=1e-3)
+        assert enc.range_fallbacks()[0] == 1
+    # the GAT: node features far beyond the range after the first pass
+    enc = enc_mod.Encoder(J, M, B, obs_dtype="f32")
+    enc.load_weights(ja, ma)
+    mf1, mf2 = g[p + "mfea1"] * 3e4, g[p + "mfea2"] * 3e4
+    margs = lambda: (_t(mf1, torch.float32), _t(mf2, torch.float32), _t(g[p + "h_o"].astype(np.float32)), _t(g[p + "mmask"].reshape(B, M).astype(np.uint8)))
+    mo = eo.machine_actor_forward(ma, mf1, mf2, g[p + "h_o"], g[p + "mmask"], B, M)
+    enc.machine_actor_forward(*margs())
+    with pytest.raises(capi.MtfjspError) as ei:
+        enc.check()
+    assert ei.value.code == capi.ERR_RETRY
+    mprob, h_m, mach_v = enc.machine_actor_forward(*margs())
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(mprob.cpu().numpy(), mo["prob"], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(h_m.cpu().numpy(), mo["h_pooled"], rtol=0, atol=1e-4 * max(1.0, float(np.abs(mo["h_pooled"]).max())))
+    # in range again on the split products once asked to
+    enc.set_product_mode(0)
+    mprob2 = enc.machine_actor_forward(_t(g[p + "mfea1"], torch.float32), _t(g[p + "mfea2"], torch.float32), _t(g[p + "h_o"].astype(np.float32)),
+                                       _t(g[p + "mmask"].reshape(B, M).astype(np.uint8)))[0]
+    torch.cuda.synchronize()
+    enc.check()
+    np.testing.assert_allclose(mprob2.cpu().numpy(), g[p + "mch_prob"], rtol=0, atol=1e-4)
+
+
 def test_sampling_follows_the_distribution():
     import torch
     import mtfjsp_amd  # noqa: F401
