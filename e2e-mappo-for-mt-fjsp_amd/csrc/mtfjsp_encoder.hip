@@ -59,6 +59,7 @@ struct GemmArgs {
     double *epi_stats;      // EPI_STATS: [STAT_REP][256] accumulated with atomics (zeroed by the host per forward)
     unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
     int dbg;                // diagnostic build only: timing ablations of k_gemm16p (1 no stores/sums, 2 no row requests/transform)
+    unsigned *range_flag;             // host-mapped word: raised when the BatchNorm sums this launch consumes are not numbers (an f16 operand piece overflowed upstream; ReLU would hide the NaN)
 };
 
 #ifdef MTFJSP_STAMP
@@ -571,6 +572,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             double su = 0, sq = 0;
 #pragma unroll
             for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
+            if (A.range_flag && (su != su || sq != sq)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const double mean = su * A.pro_inv_rows;
             double var = sq * A.pro_inv_rows - mean * mean;       // biased variance (training-mode BN)
             if (var < 0) var = 0;
@@ -1704,6 +1706,7 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
                 double su = 0, sq = 0;
 #pragma unroll
                 for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
+                if (A.range_flag && (su != su || sq != sq)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 const double mean = su * A.xbn_inv_rows;
                 double var = sq * A.xbn_inv_rows - mean * mean;
                 if (var < 0) var = 0;
@@ -1996,7 +1999,7 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
 // ---------------------------------------------------------------------------------------------
 // After the last GIN BatchNorm: h = relu(bn(z)); graph mean pool (gcn:192) and candidate gather (ac:197-207).
 // One 128-thread block per instance, thread = column.
-__global__ __launch_bounds__(256) void k_job_pool_gather(int B, int T, int J, const float *z, const double *stats, double inv_rows,
+__global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, int B, int T, int J, const float *z, const double *stats, double inv_rows,
                                                         const float *gamma, const float *beta, const int *cand,
                                                         float *h_pooled, float *cand_feat, float *h_nodes)
 {
@@ -2009,6 +2012,7 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(int B, int T, int J, co
         const int c = c4 + q;
         double su = 0, sq = 0;
         for (int r = 0; r < STAT_REP; r++) { su += stats[r * 256 + c]; sq += stats[r * 256 + HD + c]; }
+        if (range_flag && (su != su || sq != sq)) __hip_atomic_store(range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const double mean_d = su * inv_rows;
         double var = sq * inv_rows - mean_d * mean_d;
         if (var < 0) var = 0;
@@ -2057,12 +2061,13 @@ __global__ void k_bcast128(int B, const float *v, float *out)
 }
 
 // machine nodes: BatchNorm over all B*M rows (ac:434) and mean over M (ac:444). block = instance, thread = column
-__global__ __launch_bounds__(128) void k_mach_bn_pool(int B, int M, float *node /*in: pre-BN, out: normalised*/, const double *stats, double inv_rows,
+__global__ __launch_bounds__(128) void k_mach_bn_pool(unsigned *range_flag, int B, int M, float *node /*in: pre-BN, out: normalised*/, const double *stats, double inv_rows,
                                                      const float *gamma, const float *beta, float *h_pooled)
 {
     const int b = blockIdx.x, c = threadIdx.x;
     double su = 0, sq = 0;
     for (int r = 0; r < STAT_REP; r++) { su += stats[r * 256 + c]; sq += stats[r * 256 + HD + c]; }
+    if (range_flag && (su != su || sq != sq)) __hip_atomic_store(range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     const double mean_d = su * inv_rows;
     double var = sq * inv_rows - mean_d * mean_d;
     if (var < 0) var = 0;
@@ -2941,6 +2946,7 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
     int grid = (ntiles + 7) / 8;
     if (grid > e->num_cu) grid = e->num_cu;
     GemmArgs b = a;
+    b.range_flag = (b.Wx6 && !(e->f32_products & 1)) ? e->range_flag : nullptr;
     static const int dbg_env = getenv("MTFJSP_GEMM_DBG") ? atoi(getenv("MTFJSP_GEMM_DBG")) : 0;
     b.dbg = dbg_env;
 #ifdef MTFJSP_STAMP
@@ -3040,7 +3046,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     if (rrc) return rrc;
     if (h_pooled) {                                               // h_pooled == NULL: the consumer (k_heads) normalises, pools and gathers itself
         Timed t(e, "job_pool_gather");
-        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(256), 0, e->stream, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
+        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
                            W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, cand_feat, h_nodes);
     }
     HIPCHK(e, hipGetLastError());
@@ -3068,7 +3074,7 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
     const int set = (int)(e->res_epoch & 1);
     a.stats = e->res_stats + (size_t)set * GR_STATS_SET;
     a.stats_next = e->res_stats + (size_t)(set ^ 1) * GR_STATS_SET;
-    a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail;
+    a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail; a.range_flag = e->range_flag;
     a.candidate = candidate; a.pooled = h_pooled; a.cand_feat = cand_feat; a.h_nodes = h_nodes; a.zspill = e->res_zspill;
     a.inv_rows = 1.0 / ((double)B * (double)T);
     if (++e->res_launches == e->res_fail_at) a.expect_extra = 1u;      // (diagnostic) this launch's barriers never complete
@@ -3182,7 +3188,7 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
     }
     if (h_pooled) {
         Timed t(e, "mach_bn_pool");
-        hipLaunchKernelGGL(k_mach_bn_pool, dim3(B), dim3(128), 0, e->stream, B, M, e->node, st, 1.0 / ((double)R * e->reduce_scale), W(pre + "bn.weight"),
+        hipLaunchKernelGGL(k_mach_bn_pool, dim3(B), dim3(128), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, B, M, e->node, st, 1.0 / ((double)R * e->reduce_scale), W(pre + "bn.weight"),
                            W(pre + "bn.bias"), h_pooled);
     }
     HIPCHK(e, hipGetLastError());

@@ -86,6 +86,7 @@ struct GinResArgs {
     unsigned long long *bar;              // barrier words (monotonic counters, never reset)
     unsigned long long epoch;             // launches on `bar` so far
     unsigned *fail;                       // set when a barrier timed out (the outputs are then garbage)
+    unsigned *range_flag;                 // set when a layer's BatchNorm sums are not numbers (an operand beyond the f16 range upstream)
     const int *candidate;                 // [B,J] or NULL
     float *pooled;                        // [B,128] graph mean pool of h (gcn:192)
     float *cand_feat;                     // [B*J,128] h rows of the candidates (ac:197-207)
@@ -512,6 +513,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             double su = 0.0, sq = 0.0;
 #pragma unroll
             for (int j = 0; j < 8; j++) { su += gs[j]; sq += gq[j]; }
+            // (inf | -inf) operand pieces give NaN products, which the ReLU of the next layer would turn into silent zeros
+            if (blockIdx.x == 0 && A.range_flag && (su != su || sq != sq)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             // the accumulators hold z * wscale (power of two, exact): statistics of z, scale applied to the stored value
             const double is = (double)A.wsinv[k];
             const double mean = su * A.inv_rows * is;

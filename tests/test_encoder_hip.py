@@ -136,9 +136,10 @@ def test_actor_forwards_match_reference_outputs_two_instances_per_workgroup(batc
 
 
 def test_activation_beyond_the_f16_range_falls_back_to_the_f32_kernels():
-    """BatchNorm gammas x64 and an in-edge weight of 3000 (gcn:125 aggregates with the raw edge weights; the reference has no
-    range limit): the neighbour sums of the second GIN layer exceed 65 504, which the f16 operand pieces cannot hold.  Never a
-    clamp, never a silent inf: the forward's outputs are NaN, the heads kernel latches the range flag, check() returns
+    """BatchNorm gammas x128 and in-edge weights of 3000 (gcn:125 aggregates with the raw edge weights; the reference has no
+    range limit): the neighbour sums of the second GIN layer reach ~2.5e5 (x64 with a third of the edges at 3000 peaks at 64 512,
+    just inside), beyond the 65 504 the f16 operand pieces can hold.  Never a
+    clamp, never silent: the NaN products show in the layer's BatchNorm sums, whose consumer latches the range flag, check() returns
     MTFJSP_ERR_RETRY after switching the handle to the f32-instruction kernels, and the repeated forward matches the oracle at
     the usual tolerance.  Same for the GAT (machine features x 3e4).  set_product_mode(0) goes back to the split products."""
     import torch
@@ -150,13 +151,13 @@ def test_activation_beyond_the_f16_range_falls_back_to_the_f32_kernels():
     J, M, E, B = [int(x) for x in g["meta"]]
     T = J * M
     ja, ma = eo.split_weights(g)
-    ja = {k: (v * 64 if ("batch_norms" in k and k.endswith("weight")) else v).astype(np.float32) for k, v in ja.items()}
+    ja = {k: (v * 128 if ("batch_norms" in k and k.endswith("weight")) else v).astype(np.float32) for k, v in ja.items()}
     p = f"s{int(g['steps'][1])}_"
     col, val = eo.ell_from_dense(g[p + "adj"])
     val = val.copy()
     has = col >= 0
     assert has.any()
-    val[has] = np.where(np.arange(has.sum()) % 3 == 0, 3000.0, val[has])
+    val[has] = 3000.0
     hm_in = g[p + "h_m_in"]
     args = lambda: (_t(g[p + "tfea"], torch.float32), _t(col.reshape(B * T, 2).astype(np.int32)), _t(val.reshape(B * T, 2).astype(np.float32)),
                     _t(g[p + "cand"].astype(np.int32)), _t(g[p + "mask"].astype(np.uint8)), None if hm_in.size == 0 else _t(hm_in.astype(np.float32)))
@@ -166,9 +167,7 @@ def test_activation_beyond_the_f16_range_falls_back_to_the_f32_kernels():
         enc.load_weights(ja, ma)
         if gin == "streaming":
             enc.set_product_mode(16)
-        prob = enc.job_actor_forward(*args())[0]
-        torch.cuda.synchronize()
-        assert not torch.isfinite(prob).all(), "the operand pieces overflowed: the split products cannot have produced numbers"
+        enc.job_actor_forward(*args())                   # (its outputs may even look like numbers: ReLU turns the NaN rows into zeros)
         with pytest.raises(capi.MtfjspError) as ei:
             enc.check()
         assert ei.value.code == capi.ERR_RETRY
