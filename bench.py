@@ -82,6 +82,75 @@ def env_kernel_large_batch(J, M, E, device, B=262144, episodes=2):
             "avg_launch_us": sec * 1e6, "launches": n, "env_steps_per_s": B / sec}
 
 
+def config_leg(rollout_mod, J, M, E, B, device, steps=240, warm=120):
+    """A short leg of another BASELINE.json configuration on this GPU (extra keys of the N=1 line; `value` stays the headline
+    configuration's): B distinct instances drawn by the on-device generator (the host stream is python-loop bound at these
+    sizes), full rollout step, wall-clock rate over `steps` steps after `warm`, then HIP-event times per kernel family."""
+    T = J * M
+    be = import_module_("e2e-mappo-for-mt-fjsp_amd.batch_env")
+    gen = be.DeviceBatchEnv(J, M, E, B, obs_dtype="f32", device=device)
+    gen.generate_instances(seed=2024)
+    ins = gen.read_instances()
+    del gen
+    ro = rollout_mod.Rollout(J, M, E, B, device=device, policy="actor", obs_dtype="f32", instances=ins, collect=True)
+    for _ in range(warm):
+        ro.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ro.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = min(steps, 2 * T)
+    ro.timing_begin()
+    for _ in range(prof):
+        ro.step()
+    kt = ro.timing_end()
+    torch.cuda.synchronize()
+    ro.check_finished_cleanly()
+    dom = max(kt, key=lambda k: kt[k]["ms_total"])
+    ke = kt["env_step"]
+    sec_env = ke["ms_total"] / max(ke["launches"], 1) * 1e-3
+    alg = B * env_bytes(J, M)
+    out = {"workload": f"J{J}M{M}E{E}, {B} parallel instances (on-device generator, all distinct), full rollout step",
+           "value": B * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps_timed": steps,
+           "roofline": ro.roofline(dom, kt[dom]) if dom != "env_step" else None,
+           "roofline_env_step": {"kernel": ro.env_kernel_name(), "bound": "hbm", "achieved": alg / sec_env / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": alg / sec_env / 1e9 / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": alg / sec_env / 1e9 / HBM_MEASURED_GBPS,
+                                 "avg_launch_us": sec_env * 1e6, "algorithmic_bytes_per_launch": alg, "env_steps_per_s": B / sec_env},
+           "kernel_times_us_per_launch": {k: v["ms_total"] / max(v["launches"], 1) * 1e3 for k, v in kt.items()}}
+    del ro
+    torch.cuda.empty_cache()
+    return out
+
+
+def import_module_(name):
+    from importlib import import_module
+    import mtfjsp_amd  # noqa: F401
+    return import_module(name)
+
+
+def full_handoff_leg(rollout_mod, J, M, E, B, device, rank, world):
+    """The reference's whole rollout -> update hand-off once, outside the timed region (N > 1): a Rollout with the complete
+    device trajectory buffer and a (random-init) global critic runs one buffer; its finish_buffer samples the global critic on
+    every stored state, runs the 8 GAE scans and exchanges 16 tensors x [S, B] f32 in ONE all-gather."""
+    enc_mod = import_module_("e2e-mappo-for-mt-fjsp_amd.encoder")
+    ro = rollout_mod.Rollout(J, M, E, B, device=device, policy="actor", obs_dtype="f32", instance_seed=0, rank=rank, world=world,
+                             collect="full", weights=enc_mod.random_init_weights(1234, with_critic=True), time_handoff=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while ro.n_handoffs == 0:
+        ro.step()
+    torch.cuda.synchronize()
+    g = ro.last_gather or {}
+    out = {"tensors": 16, "buffer_steps": ro.S, "world": g.get("world"), "allgather_bytes_per_rank": g.get("bytes_per_rank"),
+           "allgather_ms": g.get("ms"), "buffer_plus_handoff_seconds": time.perf_counter() - t0,
+           "what": "global critic on 2 S stored states + 8 GAE scans + ONE packed all-gather of 8 advantage and 8 value tensors [16,S,B] f32 + normalisation (ppo:628-703)"}
+    del ro
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -202,6 +271,8 @@ def main():
                     help="the untimed warm-up lasts at least this long (extra steps beyond --warmup; 0 = exactly --warmup + 20 probe steps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-env-sweep", action="store_true", help="skip the step-kernel batch sweep (N=1 only)")
+    ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs of BASELINE configs 2 and 4's shard (N=1, headline size only)")
+    ap.add_argument("--no-full-handoff", action="store_true", help="skip the untimed full hand-off leg (N>1)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -235,7 +306,8 @@ def main():
         policy = "actor" if rollout_mod.actor_available() else "random"
     # Instance_Dataset(samples = world*B, seed = 0), shard `rank` owns rows [rank*B, (rank+1)*B) — all distinct
     ro = rollout_mod.Rollout(J, M, E, B, device=local_rank, policy=policy, obs_dtype=args.obs,
-                             instance_seed=0, rank=rank, world=world, collect="full" if args.trajectory == "full" else True)
+                             instance_seed=0, rank=rank, world=world, collect="full" if args.trajectory == "full" else True,
+                             time_handoff=True)
 
     def sync():
         torch.cuda.synchronize()
@@ -308,6 +380,16 @@ def main():
     sync()
     ro.check_finished_cleanly()
 
+    full_handoff = None
+    if world > 1 and policy == "actor" and not args.no_full_handoff:
+        try:
+            del ro.traj
+        except AttributeError:
+            pass
+        try:
+            full_handoff = full_handoff_leg(rollout_mod, J, M, E, B, local_rank, rank, world)
+        except Exception as ex:                                     # never lose the headline line over the extra leg
+            full_handoff = {"error": repr(ex)}
     if rank == 0:
         value = world * B * steps_timed / elapsed
         # dominant kernel by measured device time
@@ -356,12 +438,22 @@ def main():
                         "what": "local-critic GAE (4 reverse scans) + ONE packed all-gather of the 4 advantage tensors [4,S,B] f32 + global normalisation"},
             "kernel_times_ms": {k: v for k, v in ktimes.items()}, "kernel_times_steps": prof_steps,
         }
+        if full_handoff is not None:
+            out["handoff_full"] = full_handoff
         if world == 1 and not args.no_env_sweep:
             del ro
             torch.cuda.empty_cache()
             sweep = [env_kernel_large_batch(J, M, E, local_rank, B=b, episodes=1 if b >= 65536 else 2) for b in (4096, 16384, 65536, 262144)]
             out["roofline_env_step_batch_sweep"] = sweep
             out["roofline_env_step_large_batch"] = sweep[-1]
+        if world == 1 and headline and policy == "actor" and not args.no_config_legs:
+            legs = {}
+            for name, (cj, cm, ce, cb) in (("J10M10E2_x8192", (10, 10, 2, 8192)), ("J20M20E4_x2048", (20, 20, 4, 2048))):
+                try:
+                    legs[name] = config_leg(rollout_mod, cj, cm, ce, cb, local_rank)
+                except Exception as ex:
+                    legs[name] = {"error": repr(ex)}
+            out["configs"] = legs
         if cpu_leg is not None:
             out["cpu_baseline"] = cpu_leg
         print(json.dumps(out), flush=True)

@@ -6,7 +6,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmtfjsp.so")
-SOURCES = ["mtfjsp_env.hip", "mtfjsp_encoder.hip"]
+SOURCES = ["mtfjsp_env.hip", "mtfjsp_encoder.hip", "mtfjsp_hostgen.cpp"]
 # -ffp-contract=off: the scheduling state must follow the reference's binary64 operation order exactly
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
          "-Wall"]

@@ -90,6 +90,8 @@ PROTOTYPES = {
     "mtfjsp_get_mfea1_context": (_I, [_VP, _VP, _VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_mfea1": (_I, [_VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_selection": (_I, [_VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
+    "mtfjsp_hostgen_infeasible": (_I, [_VP, C.POINTER(C.c_int32), C.c_int64, _I, _I, C.c_int64, C.c_int64, _VP]),
+    "mtfjsp_hostgen_transport": (_I, [_VP, C.POINTER(C.c_int32), C.c_int64, _I, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64, _VP]),
     "mtfjsp_encoder_check": (_I, [_VP, C.POINTER(C.c_int32)]),
     "mtfjsp_encoder_resident_failures": (_I, [_VP, C.POINTER(C.c_int64)]),
     "mtfjsp_encoder_range_fallbacks": (_I, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),

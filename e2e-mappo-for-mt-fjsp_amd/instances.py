@@ -23,52 +23,102 @@ def split_machines(n_machine, n_edge):
     return out
 
 
-def generate_instances(samples, n_job=6, n_machine=6, n_edge=2, seed=None, scope=None):
+def _uniform_rows(rs, low, high, samples, tail, first, count, chunk=256):
+    """rs.uniform(low, high, (samples,) + tail)[first:first+count] without materialising the other rows: the legacy stream fills
+    an array element by element in C order, so consecutive chunks of samples are the same draws"""
+    out = np.empty((count,) + tuple(tail))
+    s = 0
+    while s < samples:
+        c = min(chunk, samples - s)
+        x = rs.uniform(low, high, (c,) + tuple(tail))
+        a, b = max(s, first), min(s + c, first + count)
+        if a < b:
+            out[a - first:b - first] = x[a - s:b - s]
+        s += c
+    return out
+
+
+def _native():
+    try:
+        from . import capi
+        return capi.lib()
+    except Exception:
+        return None
+
+
+def generate_instances(samples, n_job=6, n_machine=6, n_edge=2, seed=None, scope=None, first=0, count=None, native=None):
+    """-> rows [first, first+count) (default: all) of the reference's Instance_Dataset(samples, n_job, n_machine, n_edge, seed).
+    The random stream is sequential, so every draw of the whole set is taken, but only the requested rows are kept: a rank of a
+    sharded run generates ITS instances in O(shard) memory.  native (default: when libmtfjsp.so is present): the two per-draw
+    loops of the reference (infeasible machines, transport times) run in csrc/mtfjsp_hostgen.cpp on the same MT19937 state —
+    seconds instead of minutes at 16384 x J20M20; native=False is the pure-numpy form, bit-identical (tests/test_instances.py)."""
     sc = dict(DEFAULT_SCOPE)
     if scope:
         sc.update(scope)
     S, J, M, E = int(samples), int(n_job), int(n_machine), int(n_edge)
     T = J * M
+    first = int(first)
+    n = S - first if count is None else int(count)
+    if first < 0 or n < 0 or first + n > S:
+        raise ValueError("rows [first, first+count) must lie inside the set")
     rs = np.random.RandomState(seed) if seed is not None else np.random.mtrand._rand
+    L = _native() if native is None or native else None
+    if native and L is None:
+        raise RuntimeError("native generator requested but libmtfjsp.so is not built")
     # draw order of generate…py:161-176
-    avg_t = rs.uniform(sc["t_low"], sc["t_high"], (S, T))
-    avg_p = rs.uniform(sc["p_low"], sc["p_high"], (S, T))
-    t_w = rs.uniform(sc["weight_low"], sc["weight_high"], (S, T, M))
-    p_w = rs.uniform(sc["weight_low"], sc["weight_high"], (S, T, M))
-    rs.uniform(1, 5, (S, 1, M))                       # idle powers m_p2: drawn, never used downstream (env:371 forces 1)
-    t = avg_t[:, :, None] * t_w
+    avg_t = rs.uniform(sc["t_low"], sc["t_high"], (S, T))[first:first + n]
+    avg_p = rs.uniform(sc["p_low"], sc["p_high"], (S, T))[first:first + n]
+    t_w = _uniform_rows(rs, sc["weight_low"], sc["weight_high"], S, (T, M), first, n)
+    p_w = _uniform_rows(rs, sc["weight_low"], sc["weight_high"], S, (T, M), first, n)
+    _uniform_rows(rs, 1, 5, S, (1, M), 0, 0)           # idle powers m_p2: drawn, never used downstream (env:371 forces 1)
+    t = np.ascontiguousarray(avg_t[:, :, None] * t_w)
     p = avg_p[:, :, None] * p_w
-    # generate…py:204-216: per task a uniform number k in [0,M) of machines made infeasible
-    for s in range(S):
-        ts = t[s]
-        for row in range(T):
-            k = rs.randint(0, M)
-            idx = rs.choice(M, size=k, replace=False)
-            ts[row, idx] *= -1
-    neg = t < 0
-    p[neg] = -p[neg]
+    del t_w, p_w
     shops = split_machines(M, E)
     if len({len(x) for x in shops}) != 1:
         raise ValueError("n_machine must be divisible by n_edge (the reference stacks the shop lists into an array)")
-    edge = np.tile(np.array(shops, dtype=np.int64)[None], (S, 1, 1))
     shop_of = np.zeros(M, np.int64)
     for e, ms in enumerate(shops):
         shop_of[ms] = e
-    tt = np.zeros((S, M, M))
     in_lo, in_hi, out_hi = sc["transT_in_low"], sc["transT_in_high"], sc["transT_out_high"]
-    for s in range(S):
-        a = np.zeros((M, M))
-        for i in range(M):
-            for j in range(M):
-                if i == j:
-                    continue
-                d = abs(int(shop_of[i]) - int(shop_of[j]))
-                if d == 0:
-                    a[i, j] = rs.uniform(low=in_lo, high=in_hi, size=1).item()
-                else:
-                    a[i, j] = rs.uniform(low=in_hi * d, high=out_hi * d, size=1).item()   # generate…py:262-266
-        U = np.triu(a, k=1)
-        tt[s] = U + U.T - np.diag(np.diag(a))
+    tt = np.zeros((n, M, M))
+    if L is not None:
+        import ctypes as C
+        st = rs.get_state()
+        key = np.ascontiguousarray(st[1], np.uint32)
+        pos = C.c_int32(int(st[2]))
+        if L.mtfjsp_hostgen_infeasible(key.ctypes.data, C.byref(pos), S, T, M, first, n, t.ctypes.data) != 0:
+            raise RuntimeError("mtfjsp_hostgen_infeasible failed")
+        if L.mtfjsp_hostgen_transport(key.ctypes.data, C.byref(pos), S, M, shop_of.ctypes.data, float(in_lo), float(in_hi), float(out_hi),
+                                      first, n, tt.ctypes.data) != 0:
+            raise RuntimeError("mtfjsp_hostgen_transport failed")
+        rs.set_state((st[0], key, int(pos.value), 0, 0.0))
+    else:
+        # generate…py:204-216: per task a uniform number k in [0,M) of machines made infeasible
+        for s in range(S):
+            ts = t[s - first] if first <= s < first + n else None
+            for row in range(T):
+                k = rs.randint(0, M)
+                idx = rs.choice(M, size=k, replace=False)
+                if ts is not None:
+                    ts[row, idx] *= -1
+        for s in range(S):
+            a = np.zeros((M, M))
+            for i in range(M):
+                for j in range(M):
+                    if i == j:
+                        continue
+                    d = abs(int(shop_of[i]) - int(shop_of[j]))
+                    if d == 0:
+                        a[i, j] = rs.uniform(low=in_lo, high=in_hi, size=1).item()
+                    else:
+                        a[i, j] = rs.uniform(low=in_hi * d, high=out_hi * d, size=1).item()   # generate…py:262-266
+            if first <= s < first + n:
+                U = np.triu(a, k=1)
+                tt[s - first] = U + U.T - np.diag(np.diag(a))
+    neg = t < 0
+    p[neg] = -p[neg]
+    edge = np.tile(np.array(shops, dtype=np.int64)[None], (n, 1, 1))
     return t, p, tt, edge
 
 

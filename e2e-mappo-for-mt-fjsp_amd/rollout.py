@@ -45,9 +45,8 @@ class Rollout:
         self.env = DeviceBatchEnv(n_job, n_machine, n_edge, batch, obs_dtype=obs_dtype, device=device)
         dev = self.env.device
         if instances is None:
-            t, p, tt, edge = generate_instances(world * batch, n_job, n_machine, n_edge, seed=instance_seed)
-            lo, hi = rank * batch, (rank + 1) * batch
-            instances = (t[lo:hi], p[lo:hi], tt[lo:hi], edge[lo:hi])
+            lo, hi = rank * batch, (rank + 1) * batch               # only this rank's rows are kept (the stream is the whole set's)
+            instances = generate_instances(world * batch, n_job, n_machine, n_edge, seed=instance_seed, first=lo, count=batch)
             self.instances_desc = (f"Instance_Dataset(samples={world * batch}, n_job={n_job}, n_machine={n_machine}, n_edge={n_edge}, "
                                    f"seed={instance_seed}) rows [{lo},{hi}) — all distinct")
         else:

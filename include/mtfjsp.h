@@ -283,6 +283,14 @@ int mtfjsp_encoder_arm_selection(mtfjsp_encoder_t e, int32_t which, int32_t gree
 /* One-shot like mtfjsp_encoder_arm_selection (and only together with it, which = 0): the next job actor forward also
  * writes m_fea1 / the machine mask of every instance's selected task (== mtfjsp_observe_mfea1 on gathered_out). */
 int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_ctx_t *ctx);
+/* ---- host-side helpers of the instance generator (instance/generate_allsize_mofjsp_dataset.py:204-216, 241-272).
+ * The reference draws "k machines infeasible per task" and the transport times from numpy's legacy RandomState one python call at
+ * a time; these take the same draws from the same MT19937 state (key[624] + *pos as RandomState.get_state() returns them; updated
+ * in place for set_state()) at native speed, bit for bit, and keep only samples [first, first+count): t [count,T,M] gets the sign
+ * flips, tt [count,M,M] is written.  No GPU involved. */
+int mtfjsp_hostgen_infeasible(uint32_t *key, int32_t *pos, int64_t samples, int32_t T, int32_t M, int64_t first, int64_t count, double *t);
+int mtfjsp_hostgen_transport(uint32_t *key, int32_t *pos, int64_t samples, int32_t M, const int64_t *shop_of_machine,
+                             double in_lo, double in_hi, double out_hi, int64_t first, int64_t count, double *tt);
 /* Synchronises the encoder's stream and reports asynchronous failures of the forwards enqueued so far.  The single-launch GIN
  * kernel synchronises its workgroups with in-kernel grid barriers whose spins are bounded (4 ms); it needs all of its workgroups
  * resident at once (one per CU), which another process or another stream using the same GPU can prevent — not a hang but a

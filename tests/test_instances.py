@@ -21,6 +21,30 @@ def test_generator_reproduces_reference_stream(tag):
     assert np.array_equal(edge, G[tag + "_edge"])
 
 
+@pytest.mark.parametrize("tag", ["j6m6e2_s0", "j10m10e2_s5", "j20m20e4_s7", "j10m6e2_s2"])
+@pytest.mark.parametrize("native", [False, True])
+def test_both_generator_forms_reproduce_the_reference_stream(tag, native):
+    """the pure-numpy loops and the native MT19937 consumer (csrc/mtfjsp_hostgen.cpp) against the reference's own output"""
+    s, j, m, e, seed = [int(x) for x in G[tag + "_args"]]
+    t, p, tt, edge = inst.generate_instances(s, j, m, e, seed, native=native)
+    assert np.array_equal(t, G[tag + "_t"]) and np.array_equal(p, G[tag + "_p"]) and np.array_equal(tt, G[tag + "_tt"])
+    assert np.array_equal(edge, G[tag + "_edge"])
+
+
+@pytest.mark.parametrize("native", [False, True])
+def test_a_shard_of_the_set_is_the_same_rows(native):
+    """rows [first, first+count) generated alone == those rows of the whole set (what a rank of a sharded run generates),
+    and the generator's state afterwards is the whole set's"""
+    full = inst.generate_instances(37, 6, 6, 2, 3, native=native)
+    for first, count in ((0, 5), (11, 9), (30, 7), (36, 1)):
+        part = inst.generate_instances(37, 6, 6, 2, 3, first=first, count=count, native=native)
+        for a, b in zip(part, full):
+            assert np.array_equal(a, b[first:first + count])
+    other = inst.generate_instances(100, 6, 6, 2, 1, first=98, count=2, native=native)
+    for k, a in zip(("t", "p", "tt", "edge"), other):
+        assert np.array_equal(a, G["eval100_s1_tail_" + k])
+
+
 def test_generator_reproduces_shipped_eval_set():
     t, p, tt, edge = inst.generate_instances(100, 6, 6, 2, 1)
     for k, a in zip(("t", "p", "tt", "edge"), (t, p, tt, edge)):
