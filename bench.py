@@ -186,7 +186,23 @@ def cpu_topology():
     return n, (len(cores) if cores else n)
 
 
-def cpu_baseline(J, M, E, batch=4096, seconds_per_leg=5.0):
+def cpu_quota():
+    """CPU time this container may use, in CPUs (cgroup v2 cpu.max / v1 cfs quota); None = unlimited.  A pod on a shared host can
+    see every hardware thread (nproc) and still be throttled to a fraction of them."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(J, M, E, batch=4096, seconds_per_leg=3.0):
     """The CPU oracle port (oracle/mtfjsp_oracle.c) timed on the host cores, SURVEY §8d leg (ii): per env and step what the
     reference's batched step does per env (env.step + RewardScaling + candidate/job-mask update + observation; pe:229-265),
     random valid actions chosen in C, on the GPU workload's own instances (the first `batch` of the same generator stream).
@@ -206,23 +222,37 @@ def cpu_baseline(J, M, E, batch=4096, seconds_per_leg=5.0):
     def leg(nb, threads):
         threads = max(1, min(threads, cap, nb))
         orc = OracleBatch(t[:nb], p[:nb], tt[:nb], edge[:nb])
-        n, wall, _ = orc.bench_blocks(1, threads, w3[:nb])                               # calibrate (and warm the caches)
-        episodes = max(1, min(20000, int(seconds_per_leg / max(wall, 1e-6))))
+        orc.bench_blocks(1, threads, w3[:nb])                                            # warm the caches, start the threads
+        n, wall, _ = orc.bench_blocks(8, threads, w3[:nb])                               # calibrate
+        episodes = max(1, min(20000, int(seconds_per_leg / max(wall / 8, 1e-6))))
         n, wall, steps = orc.bench_blocks(episodes, threads, w3[:nb])
         return {"env_steps_per_s": n / wall, "env_steps_per_s_step_loops_only": n / steps, "threads": threads, "batch": nb,
                 "episodes": episodes, "env_steps": n, "seconds": wall}
 
+    quota = cpu_quota()
+    try:
+        load1 = float(open("/proc/loadavg").read().split()[0])
+    except (OSError, ValueError):
+        load1 = None
     one = leg(B, 1)
     phys = leg(B, ncores) if ncores > 1 else dict(one)
     smt = leg(B, nlogical) if nlogical > ncores else None
+    # thread counts in between: on a shared or quota-limited host the rate saturates well below the core count — the curve shows where
+    curve = {}
+    for th in (8, 16, 32, 64):
+        if th < ncores:
+            curve[str(th)] = leg(B, th)
     c0 = leg(16, 1)
-    legs = [one, phys] + ([smt] if smt else [])
+    legs = [one, phys] + ([smt] if smt else []) + list(curve.values())
     best = max(legs, key=lambda d: d["env_steps_per_s"])
     out = {"value": best["env_steps_per_s"], "unit": "env-steps/s", "cores": best["threads"], "kind": "port",
-           "cpu_model": cpu_model(), "logical_cpus": nlogical, "physical_cores": ncores,
+           "cpu_model": cpu_model(), "logical_cpus": nlogical, "physical_cores": ncores, "cgroup_cpu_quota": quota,
+           "host_loadavg_1min_before": load1, "thread_scaling": {k: {"env_steps_per_s": v["env_steps_per_s"], "per_thread": v["env_steps_per_s"] / v["threads"]} for k, v in curve.items()},
            "omp": {k: os.environ.get(k) for k in ("OMP_PLACES", "OMP_PROC_BIND")},
            "single_thread": one, "all_cores": phys, "all_smt_threads": smt, "config0_B16_single_thread": c0,
            "all_cores_over_single_thread": phys["env_steps_per_s"] / one["env_steps_per_s"],
+           "best_over_single_thread": best["env_steps_per_s"] / one["env_steps_per_s"],
+           "best_over_config0_single_thread": best["env_steps_per_s"] / c0["env_steps_per_s"],
            "sample": f"J{J}M{M}E{E}: the first {B} instances of Instance_Dataset(seed=0) (the GPU's batch), {best['episodes']} episodes "
                      f"({best['env_steps']} env-steps, {best['seconds']:.1f} s) in the reported leg; per-episode resets inside the timed region; "
                      "ENVIRONMENT ONLY (step + reward scaling + job mask + ELL observation per env and step, random valid actions; no actor "
