@@ -31,7 +31,7 @@ class Obs(C.Structure):
 class Mfea1Ctx(C.Structure):
     _fields_ = [("t", C.c_void_p), ("p", C.c_void_p), ("tt", C.c_void_p), ("mean3", C.c_void_p), ("shop", C.c_void_p),
                 ("link", C.c_void_p), ("m_fea1_out", C.c_void_p), ("mmask_out", C.c_void_p),
-                ("T", C.c_int32), ("M", C.c_int32), ("obs_f32", C.c_int32)]
+                ("T", C.c_int32), ("M", C.c_int32), ("obs_f32", C.c_int32), ("m_fea2", C.c_void_p)]
 
 
 class EncoderConfig(C.Structure):

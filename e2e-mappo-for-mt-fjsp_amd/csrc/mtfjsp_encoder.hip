@@ -1073,189 +1073,7 @@ __device__ __forceinline__ int gx_off(int row, int col) { return row * HD + ((((
 __global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *s_wf = smem;                                   // 8*2*4*64*16 B
-    float *s_a = reinterpret_cast<float *>(smem + 8 * 2 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
-    double *s_red = reinterpret_cast<double *>(s_a);              // (after the last tile)
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int j = lane & 31, h = lane >> 5, c4 = j * 4;
-    const int m = lane & 15, q = lane >> 4;
-    {   // stage the weight fragments: 65536 B = 8 x 16 B per thread, coalesced
-        const float4 *src = reinterpret_cast<const float4 *>(A.Wx6);
-        float4 *dst = reinterpret_cast<float4 *>(s_wf);
-        float4 v[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = src[i * 512 + tid];
-#pragma unroll
-        for (int i = 0; i < 8; i++) dst[i * 512 + tid] = v[i];
-    }
-    const float wsinv = A.w_sinv;
-    float *my_a = s_a + wave * 16 * HD;
-    float *my_f = my_a + 15 * HD;                                 // the tile's feature words live in its last row until that row is written (p = 7)
-    const int N = 2 * A.R;
-    const int ntiles = (N + 15) / 16;
-    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
-    const int first = blockIdx.x * per;
-    const int last = first + per < ntiles ? first + per : ntiles;
-    float st_sum[8], st_sq[8];                                    // per lane: <= 2 machines x (tiles per wave) values — f32 partial sums, f64 from the fold on
-    for (int c = 0; c < 8; c++) { st_sum[c] = 0.f; st_sq[c] = 0.f; }
-    float wp[4][8];                                               // this lane's 4 output columns of W1 (h = 0) or W2 (h = 1)
-    for (int x = 0; x < 4; x++)
-        for (int k = 0; k < 8; k++) wp[x][k] = h == 0 ? (k < 6 ? A.W1[(c4 + x) * 6 + k] : 0.f) : A.W2[(c4 + x) * 8 + k];
-    float asrc[8], adst[8];
-    for (int c = 0; c < 8; c++) { asrc[c] = A.gat_a[c * 16 + m]; adst[c] = A.gat_a[HD + c * 16 + m]; }
-    auto fetch_feat = [&](int tile) __attribute__((always_inline)) -> float4 {   // lane L < 32: 4 of the 128 feature words of a tile
-        const int r = tile * 16 + (lane >> 1), k0 = (lane & 1) * 4;
-        float x[4] = {0.f, 0.f, 0.f, 0.f};
-        if (lane < 32 && r < N) {
-            const int u = r >> 1, node = r & 1, width = node ? 8 : 6;
-            for (int k = 0; k < 4; k++)
-                if (k0 + k < width) {
-                    const size_t idx = (size_t)u * width + k0 + k;
-                    x[k] = A.feat_f64 ? (float)reinterpret_cast<const double *>(node ? A.f2 : A.f1)[idx]
-                                      : reinterpret_cast<const float *>(node ? A.f2 : A.f1)[idx];
-                }
-        }
-        return make_float4(x[0], x[1], x[2], x[3]);
-    };
-    int t_cur = first + wave, t_n1 = t_cur + 8;
-    float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (t_cur < last) fpre = fetch_feat(t_cur);
-    __syncthreads();                                              // weight fragments are staged
-    const unsigned char *wl = s_wf + lane * 16;                   // fragment (c, p, ks): wl + ((c*2 + p)*4 + ks) * 1024
-    while (t_cur < last) {
-        const int row0 = t_cur * 16;
-        // ---- input rows: tile rows 2p+h are node h of machine (row0/2 + p); W1/W2 arrive pre-multiplied with the GAT
-        // weight, so these rows ARE z of the first pass
-        if (lane < 32) *reinterpret_cast<float4 *>(my_f + lane * 4) = fpre;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const int r = 2 * p + h;
-            const float4 fa = *reinterpret_cast<const float4 *>(my_f + r * 8), fb = *reinterpret_cast<const float4 *>(my_f + r * 8 + 4);
-            const float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
-            float o[4];
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                float a = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; k++) a = fmaf(ff[k], wp[x][k], a);
-                o[x] = a;
-            }
-            *reinterpret_cast<float4 *>(my_a + gx_off(r, c4)) = make_float4(o[0], o[1], o[2], o[3]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (t_n1 < last) fpre = fetch_feat(t_n1);
-#pragma unroll 1
-        for (int pass = 0; pass < 3; pass++) {
-            f32x4 acc[8];
-            if (pass == 0) {
-#pragma unroll
-                for (int c = 0; c < 8; c++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) acc[c][i] = my_a[gx_off(4 * q + i, c * 16 + m)];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            } else {
-                // the tile in operand layout: row m, k = 32ks + 8q .. +7, split into two f16 planes.  The values are ELU outputs of
-                // attention mixtures — unbounded in principle: one beyond the f16 range becomes (inf | -inf) pieces, their products
-                // a NaN that reaches every output of the forward, where the heads kernel reports it (range_flag) and the host
-                // repeats the forward on the f32-instruction kernels — never a silently saturated value
-                h16x8 xf[2][4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-                    const float4 lo = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q));
-                    const float4 hi = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q + 4));
-                    const float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
-                    uint2 a0, a1, b0, b1;
-                    split2x4(v0, a0, a1); split2x4(v1, b0, b1);
-                    xf[0][ks] = __builtin_bit_cast(h16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
-                    xf[1][ks] = __builtin_bit_cast(h16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
-                }
-                // column blocks in pairs (two accumulator chains); units u = (pair, k-step): 4 weight fragments each, the next
-                // unit's in flight
-                h16x8 wr[2][2][2];
-#pragma unroll
-                for (int cc = 0; cc < 2; cc++)
-#pragma unroll
-                    for (int p = 0; p < 2; p++) wr[0][cc][p] = *reinterpret_cast<const h16x8 *>(wl + ((cc * 2 + p) * 4) * 1024);
-#pragma unroll
-                for (int c = 0; c < 8; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < 16; u++) {
-                    const int cp = u >> 2, ks = u & 3;
-                    if (u + 1 < 16) {
-                        const int cn = (u + 1) >> 2, kn = (u + 1) & 3;
-#pragma unroll
-                        for (int cc = 0; cc < 2; cc++)
-#pragma unroll
-                            for (int p = 0; p < 2; p++) wr[(u + 1) & 1][cc][p] = *reinterpret_cast<const h16x8 *>(wl + (((2 * cn + cc) * 2 + p) * 4 + kn) * 1024);
-                    }
-                    const h16x8 (*w)[2] = wr[u & 1];
-#pragma unroll
-                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
-#pragma unroll
-                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0][ks], w[cc][1], acc[2 * cp + cc], 0, 0, 0);
-#pragma unroll
-                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
-                }
-#pragma unroll
-                for (int c = 0; c < 8; c++) acc[c] *= wsinv;                  // the weight image is scaled by a power of two
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {                                     // the lane's two machines: tile rows 4q+2u (node 0), +1 (node 1)
-                const int i = 2 * u;
-                float s0 = 0.f, d0 = 0.f, d1 = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; c++) { const float z0 = acc[c][i], z1 = acc[c][i + 1]; s0 += asrc[c] * z0; d0 += adst[c] * z0; d1 += adst[c] * z1; }
-                s0 = row_sum16(s0); d0 = row_sum16(d0); d1 = row_sum16(d1);
-                float e00 = s0 + d0, e01 = s0 + d1;
-                e00 = e00 > 0.f ? e00 : 0.2f * e00;
-                e01 = e01 > 0.f ? e01 : 0.2f * e01;
-                const float mx = fmaxf(e00, e01);
-                const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
-                const float inv = 1.0f / (x0 + x1);
-                const float al0 = x0 * inv, al1 = x1 * inv;
-                const int r = 4 * q + i;
-                if (pass < 2) {
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
-                        float n0 = al0 * z0 + al1 * z1, n1 = z1;
-                        n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;               // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
-                        n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
-                        my_a[gx_off(r, c * 16 + m)] = n0;
-                        my_a[gx_off(r + 1, c * 16 + m)] = n1;
-                    }
-                } else {
-                    const bool valid = row0 + r < N;
-                    float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + m;
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
-                        float mv = (al0 * z0 + al1 * z1 + z1) * 0.5f;        // mean over the 2 nodes (ac:420)
-                        nd[c * 16] = mv;
-                        if (!valid) mv = 0.f;
-                        st_sum[c] += mv; st_sq[c] = __builtin_fmaf(mv, mv, st_sq[c]);
-                    }
-                }
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tile is complete before the next pass reads it
-        }
-        t_cur = t_n1; t_n1 += 8;
-    }
-    // column sums: fold the 4 row quarters, then the 8 waves through LDS
-    __syncthreads();                                              // every tile is done: s_red aliases them
-    for (int c = 0; c < 8; c++) {
-        double a = (double)st_sum[c], b = (double)st_sq[c];
-        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-        if (q == 0) { s_red[wave * 256 + c * 16 + m] = a; s_red[wave * 256 + HD + c * 16 + m] = b; }
-    }
-    __syncthreads();
-    if (tid < 256) {
-        double v = 0;
-        for (int w = 0; w < 8; w++) v += s_red[w * 256 + tid];
-        atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
-    }
+#include "mtfjsp_gat3x_body.h"
 }
 static size_t gat3x_lds_bytes() { return (size_t)8 * 2 * 4 * 64 * 16 + (size_t)8 * 16 * HD * 4; }
 
@@ -1641,304 +1459,26 @@ static size_t heads_lds_bytes() { return (size_t)((2 * HCH + 4) * 16 * LDA16 + H
 __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned char *s_xs = smem;                                    // HCH tiles of 2 planes: X rows, then s1
-    unsigned char *s_pp = s_xs + HCH * X2_TILE;                    // pooled planes
-    unsigned char *s_op = s_pp + X2_TILE;                          // other planes
-    unsigned char *s_c1p = s_op + X2_TILE;                         // c1 planes
-    float *s_c2 = reinterpret_cast<float *>(s_c1p + X2_TILE);      // [16][HX_CLDA] f32
-    float *s_u = s_c2 + 16 * HX_CLDA;                              // [16][128]
-    float *s_part = s_u + HG * HD;                                 // 8 waves * (HCH*16) rows
-    float *s_score = s_part + 8 * HCH * 16;                        // HG * 64
-    float *s_wc2 = s_score + HG * 64;                              // 2 * 128
-    float *s_vec = s_wc2 + 2 * HD;                                 // b0 | bc0 | bc1 | b1 | w2
-    unsigned char *s_mask = reinterpret_cast<unsigned char *>(s_vec + 5 * HD);   // HG * 64
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int m = lane & 15, q = lane >> 4;
-    const int col4 = 16 * wave + 4 * q;                            // this lane's 4 output columns
-#ifdef MTFJSP_STAMP
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
-#endif
-    const int R = A.R;
-    const unsigned invR = (unsigned)((0x100000000ull + (unsigned)R - 1) / (unsigned)R);
-    const int sr = tid >> 5, sc4 = (tid & 31) * 4;                  // staging: thread -> (row sr of 16, 4 columns)
-    const int xoff = m * X6_ROWB + 16 * q;                          // operand fragment of (plane p, k-step ks): + p*X6_PLANE + 64*ks
-    const float b2 = A.b2[0];
-    if (tid < 2 * HD) s_wc2[tid] = A.wc2[tid];
-    if (tid < HD) { s_vec[tid] = A.b0[tid]; s_vec[HD + tid] = A.bc0[tid]; s_vec[2 * HD + tid] = A.bc1[tid]; s_vec[3 * HD + tid] = A.b1[tid]; s_vec[4 * HD + tid] = A.w2[tid]; }
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
-    if (A.zero_stats2 && blockIdx.x == 0) for (int i = tid; i < A.zero_count2; i += 512) A.zero_stats2[i] = 0.0;
-    float xs0 = 1.f, xs1 = 1.f, xs2 = 1.f, xs3 = 1.f, xh0 = 0.f, xh1 = 0.f, xh2 = 0.f, xh3 = 0.f;   // X scale / shift of this thread's 4 columns
-    // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of X, the gathered X rows of the
-    // first chunk (index -> row: two dependent round trips), the weights of phase A; only then the pooling stream
-    double bsu[STAT_REP], bsq[STAT_REP];
-    float bga = 0.f, bbe = 0.f;
-    if (A.xbn_stats && tid < HD) {
-#pragma unroll
-        for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.xbn_stats[r * 256 + tid]; bsq[r] = A.xbn_stats[r * 256 + HD + tid]; }
-        bga = A.xbn_gamma[tid]; bbe = A.xbn_beta[tid];
+#include "mtfjsp_headsx_body.h"
+}
+// The job actor's heads and the machine path's three GAT passes in ONE launch.  Both kernels give workgroup g the instances
+// 16g .. 16g+15 (heads: HG = 16; GAT: 2 M row tiles per workgroup when the grids agree), and the only thing the GAT needs from
+// the job actor is m_fea1 of the task each instance has just selected — written a few lines above by the same workgroup
+// (mtfjsp_encoder_arm_mfea1).  So the GAT part starts as soon as its own workgroup's selections are made: one launch boundary and
+// one launch ramp less per rollout step, no grid-wide dependency (the GAT's BatchNorm sums are consumed by the NEXT launch, the
+// machine actor's heads).  __syncthreads() orders the m_fea1 stores before the loads (same workgroup, same CU).
+__global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    {
+        const HeadArgs &A = HA;
+#include "mtfjsp_headsx_body.h"
     }
-    {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
-        // 64-bit weight addresses into registers and spill them)
-        const int g0 = blockIdx.x * HG;
-        const int ng = (A.B - g0) < HG ? (A.B - g0) : HG;
-        const int nrows = ng * R;
-        // scorer row `grow` of the group (instance grow / R, candidate / machine grow % R) -> its source row in X
-        auto xrow = [&](int grow) __attribute__((always_inline)) -> const float * {
-            if (!A.xgather) return A.X + ((size_t)g0 * R + grow) * HD + sc4;
-            const int il = (int)__umulhi((unsigned)grow, invR);
-            return A.X + ((size_t)(g0 + il) * A.xT + A.xgather[(size_t)g0 * R + grow]) * HD + sc4;
-        };
-        float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
-#pragma unroll
-        for (int t = 0; t < HCH; t++) {
-            const int grow = t * 16 + sr;
-            xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        h16x8 wA[2][4], wB[2][4], wC[2][4];
-        const float sW0 = A.sW0, sW1 = A.sW1, sWc0 = A.sWc0, sWc1 = A.sWc1;   // 1 / scale of the weight images
-        WCOLX(wA, A.W0x, 1);                                        // Wb
-        WCOLX(wB, A.W0x, 2);                                        // Wc
-        WCOLX(wC, A.Wc0x, 0);
-        if (A.xbn_stats) {
-            if (tid < HD) {                                         // stage_bn() from the registers requested above; s_u is free until phase A
-                double su = 0, sq = 0;
-#pragma unroll
-                for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
-                if (A.range_flag && (su != su || sq != sq)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                const double mean = su * A.xbn_inv_rows;
-                double var = sq * A.xbn_inv_rows - mean * mean;
-                if (var < 0) var = 0;
-                const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
-                const float sc = rstd * bga;
-                s_u[tid] = sc;
-                s_u[HD + tid] = bbe - (float)mean * sc;
-            }
-            LDS_BARRIER();
-            xs0 = s_u[sc4]; xs1 = s_u[sc4 + 1]; xs2 = s_u[sc4 + 2]; xs3 = s_u[sc4 + 3];
-            xh0 = s_u[HD + sc4]; xh1 = s_u[HD + sc4 + 1]; xh2 = s_u[HD + sc4 + 2]; xh3 = s_u[HD + sc4 + 3];
-            LDS_BARRIER();
-        }
-        STAMP(6);
-        {
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            float4 xp = z;
-            if (A.xbn_stats) {                                      // pooled = mean over the instance's normalised rows (ac:444 / gcn:192)
-                if (sr < ng) {
-                    const int nr = A.xgather ? A.xT : R;
-                    const float *src = A.X + (size_t)(g0 + sr) * nr * HD + sc4;
-                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 12
-                    for (int r = 0; r < nr; r++) {                   // 12 rows in flight per thread
-                        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)r * HD);
-                        float y0 = fmaf(v.x, xs0, xh0), y1 = fmaf(v.y, xs1, xh1), y2 = fmaf(v.z, xs2, xh2), y3 = fmaf(v.w, xs3, xh3);
-                        if (A.xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
-                        a0 += y0; a1 += y1; a2 += y2; a3 += y3;
-                    }
-                    const float ir = 1.0f / (float)nr;
-                    xp = make_float4(a0 * ir, a1 * ir, a2 * ir, a3 * ir);
-                    *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
-                }
-            } else if (sr < ng) xp = *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4);
-            STAMP(7);
-            const float4 xo = sr < ng ? *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + sr) * HD + sc4) : z;
-            {
-                const float vp[4] = {xp.x, xp.y, xp.z, xp.w}, vo[4] = {xo.x, xo.y, xo.z, xo.w};
-                uint2 a0, a1, b0, b1;
-                split2x4(vp, a0, a1); split2x4(vo, b0, b1);
-                unsigned char *dp = s_pp + sr * X6_ROWB + (tid & 31) * 8, *dq = s_op + sr * X6_ROWB + (tid & 31) * 8;
-                *reinterpret_cast<uint2 *>(dp) = a0; *reinterpret_cast<uint2 *>(dp + X6_PLANE) = a1;
-                *reinterpret_cast<uint2 *>(dq) = b0; *reinterpret_cast<uint2 *>(dq + X6_PLANE) = b1;
-            }
-        }
-        for (int i = tid; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
-        LDS_BARRIER();
-        STAMP(0);
-        auto xnorm = [&](float4 v, bool valid) __attribute__((always_inline)) {
-            if (!valid) return make_float4(0.f, 0.f, 0.f, 0.f);
-            float y0 = fmaf(v.x, xs0, xh0), y1 = fmaf(v.y, xs1, xh1), y2 = fmaf(v.z, xs2, xh2), y3 = fmaf(v.w, xs3, xh3);
-            if (A.xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
-            return make_float4(y0, y1, y2, y3);
-        };
-        // one 16-row tile (planes at `tp`) x this wave's column block: 12 products on two chains, fragments of the next k-step in flight
-        auto tile_x6 = [&](const unsigned char *tp, const h16x8 (&wv)[2][4]) __attribute__((always_inline)) -> f32x4 {
-            f32x4 aA = zero4, aB = zero4;
-            h16x8 xv[4][2];                                         // all 8 fragments of the tile requested at once: 3 matrix instructions do not cover an LDS round trip
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-                for (int p = 0; p < 2; p++) xv[ks][p] = *reinterpret_cast<const h16x8 *>(tp + xoff + p * X6_PLANE + 64 * ks);
-#pragma unroll
-            for (int ks = 0; ks < 4; ks++) X6_STEP(aA, aB, wv, xv[ks], ks);
-            return aA + aB;
-        };
-        // a lane's 4 values of row m -> the two planes of a tile
-        auto put_planes = [&](unsigned char *tp, const float (&v)[4]) __attribute__((always_inline)) {
-            uint2 p0, p1;
-            split2x4(v, p0, p1);
-            unsigned char *d = tp + m * X6_ROWB + col4 * 2;
-            *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1;
-        };
-        // ---- phase A: u = Wb pooled + Wc other + b0 ; c1 = tanh(Wc0 pooled + bc0)   (rows = the group's 16 instances)
-        {
-            const f32x4 au = tile_x6(s_pp, wA) + tile_x6(s_op, wB);
-            const f32x4 ac = tile_x6(s_pp, wC);
-            WCOLX(wA, A.Wc1x, 0);                                   // requested now, used in phase B
-            WCOLX(wB, A.W0x, 0);                                    // Wa
-            WCOLX(wC, A.W1x, 0);                                    // phase C
-            const float4 b0v = *reinterpret_cast<const float4 *>(s_vec + col4), bc0v = *reinterpret_cast<const float4 *>(s_vec + HD + col4);
-            *reinterpret_cast<float4 *>(s_u + m * HD + col4) = make_float4(fmaf(au[0], sW0, b0v.x), fmaf(au[1], sW0, b0v.y), fmaf(au[2], sW0, b0v.z), fmaf(au[3], sW0, b0v.w));
-            const float c1v[4] = {fast_tanh(fmaf(ac[0], sWc0, bc0v.x)), fast_tanh(fmaf(ac[1], sWc0, bc0v.y)), fast_tanh(fmaf(ac[2], sWc0, bc0v.z)), fast_tanh(fmaf(ac[3], sWc0, bc0v.w))};
-            put_planes(s_c1p, c1v);
-        }
-        STAMP(1);
-        for (int tb = 0; tb < R; tb += HCH) {
-            const int nt = (R - tb) < HCH ? (R - tb) : HCH;
-            // ---- X rows of this chunk -> planes (rows beyond the group's are zero)
-#pragma unroll
-            for (int t = 0; t < HCH; t++) {
-                if (tb > 0) {
-                    const int grow = (tb + t) * 16 + sr;
-                    xr[t] = (tb + t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                const float4 xv4 = xnorm(xr[t], (tb + t) * 16 + sr < nrows);
-                const float v[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
-                uint2 p0, p1;
-                split2x4(v, p0, p1);
-                unsigned char *d = s_xs + t * X2_TILE + sr * X6_ROWB + (tid & 31) * 8;
-                *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1;
-            }
-            LDS_BARRIER();                                          // X planes, u and c1 are complete
-            STAMP(2);
-            // ---- phase B: Wa x for every tile of the chunk (accumulators held); first chunk: c2 = tanh(Wc1 c1 + bc1)
-            f32x4 accb[HCH];
-#pragma unroll
-            for (int t = 0; t < HCH; t++) accb[t] = t < nt ? tile_x6(s_xs + t * X2_TILE, wB) : zero4;
-            if (tb == 0) {
-                const f32x4 a0 = tile_x6(s_c1p, wA);
-                const float4 bc1v = *reinterpret_cast<const float4 *>(s_vec + 2 * HD + col4);
-                *reinterpret_cast<float4 *>(s_c2 + m * HX_CLDA + col4) =
-                    make_float4(fast_tanh(fmaf(a0[0], sWc1, bc1v.x)), fast_tanh(fmaf(a0[1], sWc1, bc1v.y)), fast_tanh(fmaf(a0[2], sWc1, bc1v.z)), fast_tanh(fmaf(a0[3], sWc1, bc1v.w)));
-            }
-            LDS_BARRIER();                                          // every wave is done with the X planes: s1 overwrites them
-            // s1 = tanh(Wa x + u[instance]) -> planes
-#pragma unroll
-            for (int t = 0; t < HCH; t++) {
-                if (t < nt) {
-                    const int grow = (tb + t) * 16 + m;
-                    const int i0 = grow < nrows ? (int)__umulhi((unsigned)grow, invR) : 0;
-                    const float4 uv = *reinterpret_cast<const float4 *>(s_u + i0 * HD + col4);
-                    const float sv[4] = {fast_tanh(fmaf(accb[t][0], sW0, uv.x)), fast_tanh(fmaf(accb[t][1], sW0, uv.y)), fast_tanh(fmaf(accb[t][2], sW0, uv.z)), fast_tanh(fmaf(accb[t][3], sW0, uv.w))};
-                    put_planes(s_xs + t * X2_TILE, sv);
-                }
-            }
-            LDS_BARRIER();                                          // s1 planes and c2 are complete
-            STAMP(3);
-            // ---- phase C: s2 = tanh(W1 s1 + b1) ; partial scores of this wave's 16 columns
-            {
-                const float4 b1v = *reinterpret_cast<const float4 *>(s_vec + 3 * HD + col4), w2v = *reinterpret_cast<const float4 *>(s_vec + 4 * HD + col4);
-#pragma unroll 1
-                for (int t = 0; t < HCH; t++) {                     // (rolled: this kernel runs once per workgroup from a cold instruction cache)
-                    if (t < nt) {
-                        const f32x4 a0 = tile_x6(s_xs + t * X2_TILE, wC);
-                        float v = fast_tanh(fmaf(a0[0], sW1, b1v.x)) * w2v.x;
-                        v = fmaf(fast_tanh(fmaf(a0[1], sW1, b1v.y)), w2v.y, v);
-                        v = fmaf(fast_tanh(fmaf(a0[2], sW1, b1v.z)), w2v.z, v);
-                        v = fmaf(fast_tanh(fmaf(a0[3], sW1, b1v.w)), w2v.w, v);
-                        v += __shfl_xor(v, 16);
-                        v += __shfl_xor(v, 32);
-                        if (q == 0) s_part[wave * (HCH * 16) + t * 16 + m] = v;
-                    }
-                }
-            }
-            if (tb == 0) {   // value head: 32 threads per instance row, 4 columns each, both outputs
-                const int r = tid >> 5, part = tid & 31;
-                float p0 = 0.f, p1 = 0.f;
-                for (int k = 0; k < 4; k++) { const float x = s_c2[r * HX_CLDA + part * 4 + k]; p0 = fmaf(x, s_wc2[part * 4 + k], p0); p1 = fmaf(x, s_wc2[HD + part * 4 + k], p1); }
-                for (int o = 16; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
-                if (part == 0 && r < ng) {
-                    const float v0 = p0 + A.bc2[0], v1 = p1 + A.bc2[1];
-                    A.value[(size_t)(g0 + r) * 2] = v0; A.value[(size_t)(g0 + r) * 2 + 1] = v1;
-                    if (A.range_flag && (v0 != v0 || v1 != v1)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-            }
-            LDS_BARRIER();
-            if (tid < nt * 16) {
-                const int grow = tb * 16 + tid;
-                float v = b2;
-                for (int w = 0; w < 8; w++) v += s_part[w * (HCH * 16) + tid];
-                if (grow < nrows) s_score[grow] = v * A.scale;
-            }
-            LDS_BARRIER();                                          // planes / s_part are reused by the next chunk
-            STAMP(4);
-        }
-        // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance; optional action selection
-        {
-            const int r0 = tid >> 4, l = tid & 15;
-            if (r0 < ng) {
-                float mx = -INFINITY;
-                for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) mx = fmaxf(mx, s_score[r0 * R + r]);
-                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-                float sum = 0.f;
-                for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) sum += __expf(s_score[r0 * R + r] - mx);
-                for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-                for (int r = l; r < R; r += 16) {
-                    const float pr = s_mask[r0 * R + r] ? 0.f : __expf(s_score[r0 * R + r] - mx) / sum;
-                    A.prob[(size_t)(g0 + r0) * R + r] = pr;
-                    if (A.range_flag && pr != pr) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    s_score[r0 * R + r] = pr;                           // lanes of one wave: visible to lane l == 0 below
-                }
-                if (A.sample_mode) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (l == 0) {
-                        const int b = g0 + r0;
-                        const int pick = pick_action(s_score + r0 * R, R, b, A.sample_mode == 2, A.seed, A.counter);
-                        A.idx_out[b] = pick;
-                        if (A.logp_out) A.logp_out[b] = logf(s_score[r0 * R + pick]);
-                        const int gsel = A.gather_from ? A.gather_from[(size_t)b * R + pick] : pick;
-                        if (A.gather_from && A.gathered_out) A.gathered_out[b] = gsel;
-                        s_part[r0] = __int_as_float(gsel);                     // hand the selected task to the instance's 16 lanes (s_part is free now)
-                    }
-                    if (A.mf_on) {
-                        // = k_mfea1 (pe:152-214) for the task just selected: the 16 lanes of the instance take the machines
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        const int b = g0 + r0, T_ = A.mf.T, M_ = A.mf.M;
-                        int a = __float_as_int(s_part[r0]);
-                        if (a < 0 || a >= T_) a = 0;
-                        const size_t row = (size_t)b * T_ + a;
-                        int pm = 0;
-                        if (a % M_ != 0) {
-                            pm = reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
-                            if (pm < 0) pm += M_;                                             // python negative index (pe:206)
-                        }
-                        for (int mm = l; mm < M_; mm += 16) {
-                            const double tv = A.mf.t[row * M_ + mm], pv = A.mf.p[row * M_ + mm];
-                            const double ptv = tv * fabs(pv);
-                            const unsigned char mk = (unsigned char)!(tv >= 0);              // run:258-259 ~(t >= 0)
-                            const double x = (a % M_ != 0) ? A.mf.tt[((size_t)b * M_ + pm) * M_ + mm] : 0.0;
-                            const double f0 = tv > 0 ? tv : A.mf.mean3[row * 3 + 0], f1 = ptv > 0 ? ptv : A.mf.mean3[row * 3 + 1];
-                            const double f4 = pv > 0 ? pv : A.mf.mean3[row * 3 + 2];
-                            const size_t o = ((size_t)b * M_ + mm) * 6;
-                            const double f3 = (double)(1 - (int)mk), f5 = (double)(A.mf.shop[(size_t)b * M_ + mm] + 1);
-                            if (A.mf.obs_f32) {
-                                float *of = reinterpret_cast<float *>(A.mf.m_fea1_out) + o;
-                                of[0] = (float)f0; of[1] = (float)f1; of[2] = (float)x; of[3] = (float)f3; of[4] = (float)f4; of[5] = (float)f5;
-                            } else {
-                                double *od = reinterpret_cast<double *>(A.mf.m_fea1_out) + o;
-                                od[0] = f0; od[1] = f1; od[2] = x; od[3] = f3; od[4] = f4; od[5] = f5;
-                            }
-                            A.mf.mmask_out[(size_t)b * M_ + mm] = mk;
-                        }
-                    }
-                }
-            }
-        }
-        STAMP(5);
+    __syncthreads();
+    {
+        const GatArgs &A = GA;
+#include "mtfjsp_gat3x_body.h"
     }
-#ifdef MTFJSP_STAMP
-    if (A.stamps && lane == 0) for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
-#endif
 }
 static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
 
@@ -2460,6 +2000,8 @@ struct mtfjsp_encoder {
     float *res_zspill = nullptr;            // [grid][4][2][1024] f32: the two row tiles per workgroup that do not fit the registers
     unsigned long long res_epoch = 0;
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
+    struct { bool valid = false; const void *f1 = nullptr, *f2 = nullptr; int slot = 0; } prefused;   // the GAT passes of the coming machine forward already ran inside the job actor's heads launch (k_headsx_gat3x)
+    bool fuse_gat = !getenv("MTFJSP_NO_FUSED_GAT");
     mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
     struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
                          const int32_t *gather_from = nullptr; int32_t *gathered = nullptr; } fs[2];   // [0] job actor, [1] machine actor
@@ -2631,6 +2173,8 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_headsx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)headsx_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)(headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes()));
     {   // resident GIN kernel: whole instances per workgroup, at most 576 rows, one workgroup per CU
         const int T = e->T, B = cfg->batch;
         if (!getenv("MTFJSP_NO_RESIDENT_GIN") && T >= GR_MINT && T <= GR_MAXT) {
@@ -3136,6 +2680,31 @@ static int fused_projection(mtfjsp_encoder *e, const std::string &pre, int which
 }
 // h_pooled == nullptr: leave `node` pre-BatchNorm for a consumer that normalises and pools it itself (k_heads); *slot_out = the
 // accumulator slot holding the column sums.
+// the arguments of k_gat3x for the machine path under `pre`, accumulating the node statistics into slot `slot` (which is made clean)
+static int gat3x_args(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, int slot, GatArgs *out)
+{
+    const int R = e->cfg.batch * e->cfg.n_machine;
+    double *st = e->stats + (6 + slot) * STAT_REP * 256;
+    if (!e->gat_stats_clean[slot]) HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
+    e->gat_stats_clean[slot] = false;
+    GatArgs a{};
+    a.R = R; a.f1 = m_fea1; a.f2 = m_fea2; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
+    int frc = fused_projection(e, pre, 1, &a.W1);
+    if (!frc) frc = fused_projection(e, pre, 2, &a.W2);
+    if (frc) return frc;
+    a.Wt = e->wt.at(pre + "gat_layer.W"); a.gat_a = e->w.at(pre + "gat_layer.a"); a.node = e->node; a.epi_stats = st;
+    a.Wx6 = e->wx6.at(pre + "gat_layer.W"); a.w_sinv = e->wx6_sinv.at(pre + "gat_layer.W");
+    *out = a;
+    return MTFJSP_OK;
+}
+// can the machine actor's GAT passes ride in the job actor's heads launch (k_headsx_gat3x)?  Same instances per workgroup in both
+// parts (16), m_fea1 produced by that launch itself, whole-batch statistics without a cross-shard reduction, split products.
+static bool gat_fusable(const mtfjsp_encoder *e)
+{
+    // (up to one workgroup per CU: measured 47.7 us against 24.6 + 26.8 at J6M6 x 4096; at J10M10 x 8192, two rounds of workgroups, 130 against 128)
+    return e->fuse_gat && !e->bn_mode && !e->reduce_fn && !(e->f32_products & (2 | 4)) && e->cfg.batch % HG == 0 && e->cfg.batch / HG <= e->num_cu &&
+           e->w.count("machine_actor.gat_layer.W") && e->wx6.count("machine_actor.gat_layer.W");
+}
 static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, float *h_pooled, int *slot_out = nullptr)
 {
     const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
@@ -3260,7 +2829,7 @@ extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instan
     return MTFJSP_OK;
 }
 
-static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic)
+static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic, const GatArgs *fused_gat = nullptr)
 {
     const int grid = (ha.B + HG - 1) / HG;
     if (e->f32_products & 4) { hipLaunchKernelGGL(k_heads, dim3(grid), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
@@ -3269,6 +2838,11 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
     ha.Wc0x = e->wx6.at(critic + ".linears.0.weight"); ha.Wc1x = e->wx6.at(critic + ".linears.1.weight");
     ha.sW0 = e->wx6_sinv.at(policy + ".linears.0.weight"); ha.sW1 = e->wx6_sinv.at(policy + ".linears.1.weight");
     ha.sWc0 = e->wx6_sinv.at(critic + ".linears.0.weight"); ha.sWc1 = e->wx6_sinv.at(critic + ".linears.1.weight");
+    if (fused_gat) {                                                // + the machine path's GAT passes of the same 16 instances
+        const size_t lds = headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes();
+        hipLaunchKernelGGL(k_headsx_gat3x, dim3(grid), dim3(512), lds, e->stream, ha, *fused_gat);
+        return;
+    }
     hipLaunchKernelGGL(k_headsx, dim3(grid), dim3(512), headsx_lds_bytes(), e->stream, ha);
 }
 static void arm_sampling(mtfjsp_encoder *e, int which, HeadArgs &ha)
@@ -3327,7 +2901,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         hm = e->hm_b;
     }
     {
-        Timed t(e, "heads");
+        Timed t(e, (e->mf_armed && e->mf_ctx.m_fea2 && gat_fusable(e)) ? "heads_gat3" : "heads");
         HeadArgs ha{};
         ha.B = B; ha.R = J; ha.X = e->cand_feat; ha.pooled = h_pooled; ha.other = hm;
         ha.W0i = WI("job_actor.o_policy.linears.0.weight"); ha.b0 = W("job_actor.o_policy.linears.0.bias");
@@ -3359,7 +2933,17 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         if (!d_st) (void)hipMalloc((void **)&d_st, 4096 * 8 * 8);
         ha.stamps = d_st;
 #endif
-        launch_heads(e, ha, "job_actor.o_policy", "job_actor.job_critic");
+        e->prefused.valid = false;
+        GatArgs ga{};
+        const bool with_gat = ha.mf_on && ha.mf.m_fea2 && gat_fusable(e);
+        if (with_gat) {                                                  // the machine forward that follows finds its GAT passes done
+            const int slot = e->gat_slot;
+            e->gat_slot ^= 1;
+            const int grc = gat3x_args(e, "machine_actor.", ha.mf.m_fea1_out, ha.mf.m_fea2, slot, &ga);
+            if (grc) return grc;
+            e->prefused.valid = true; e->prefused.f1 = ha.mf.m_fea1_out; e->prefused.f2 = ha.mf.m_fea2; e->prefused.slot = slot;
+        }
+        launch_heads(e, ha, "job_actor.o_policy", "job_actor.job_critic", with_gat ? &ga : nullptr);
 #ifdef MTFJSP_STAMP
         static int printed = 0;
         if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
@@ -3389,7 +2973,9 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     int slot = 0;
-    rc = e->bn_mode ? run_gat_inst(e, "machine_actor.", m_fea1, m_fea2, h_pooled) : run_gat(e, "machine_actor.", m_fea1, m_fea2, nullptr, &slot);
+    if (e->prefused.valid && !e->bn_mode && m_fea1 == e->prefused.f1 && m_fea2 == e->prefused.f2) slot = e->prefused.slot;   // k_headsx_gat3x did it
+    else rc = e->bn_mode ? run_gat_inst(e, "machine_actor.", m_fea1, m_fea2, h_pooled) : run_gat(e, "machine_actor.", m_fea1, m_fea2, nullptr, &slot);
+    e->prefused.valid = false;
     if (rc) return rc;
     {
         Timed t(e, "heads");

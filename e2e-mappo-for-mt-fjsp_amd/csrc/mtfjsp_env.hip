@@ -1976,6 +1976,7 @@ extern "C" int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uin
     ctx->t = h->t; ctx->p = h->p; ctx->tt = h->tt; ctx->mean3 = h->mean3; ctx->shop = h->shop; ctx->link = h->link;
     ctx->m_fea1_out = m_fea1_out; ctx->mmask_out = mmask_out;
     ctx->T = h->T; ctx->M = h->cfg.n_machine; ctx->obs_f32 = h->cfg.obs_dtype == MTFJSP_OBS_F32;
+    ctx->m_fea2 = h->obs_bound ? h->obs.m_fea2 : nullptr;
     return MTFJSP_OK;
 }
 

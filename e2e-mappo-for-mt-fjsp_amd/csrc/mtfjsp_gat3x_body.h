@@ -1,0 +1,188 @@
+// mtfjsp_gat3x_body.h — the statements of k_gat3x (csrc/mtfjsp_encoder.hip), to be included inside a kernel that has `A` (GatArgs) and
+// `smem` (the dynamic LDS base) in scope: once in k_gat3x itself and once, behind the job actor's heads, in k_headsx_gat3x.
+// Textual inclusion on purpose: as a __forceinline__ device function called from a wrapper kernel the same statements came out with
+// a different instruction schedule whose FIRST launch in a process produced a few wrong row tiles (later launches were right;
+// tests/test_first_launch_gpu.py keeps watch) — the stand-alone form never did.
+    unsigned char *s_wf = smem;                                   // 8*2*4*64*16 B
+    float *s_a = reinterpret_cast<float *>(smem + 8 * 2 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
+    double *s_red = reinterpret_cast<double *>(s_a);              // (after the last tile)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5, c4 = j * 4;
+    const int m = lane & 15, q = lane >> 4;
+    {   // stage the weight fragments: 65536 B = 8 x 16 B per thread, coalesced
+        const float4 *src = reinterpret_cast<const float4 *>(A.Wx6);
+        float4 *dst = reinterpret_cast<float4 *>(s_wf);
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = src[i * 512 + tid];
+#pragma unroll
+        for (int i = 0; i < 8; i++) dst[i * 512 + tid] = v[i];
+    }
+    const float wsinv = A.w_sinv;
+    float *my_a = s_a + wave * 16 * HD;
+    float *my_f = my_a + 15 * HD;                                 // the tile's feature words live in its last row until that row is written (p = 7)
+    const int N = 2 * A.R;
+    const int ntiles = (N + 15) / 16;
+    const int per = (ntiles + gridDim.x - 1) / gridDim.x;
+    const int first = blockIdx.x * per;
+    const int last = first + per < ntiles ? first + per : ntiles;
+    float st_sum[8], st_sq[8];                                    // per lane: <= 2 machines x (tiles per wave) values — f32 partial sums, f64 from the fold on
+    for (int c = 0; c < 8; c++) { st_sum[c] = 0.f; st_sq[c] = 0.f; }
+    float wp[4][8];                                               // this lane's 4 output columns of W1 (h = 0) or W2 (h = 1)
+    for (int x = 0; x < 4; x++)
+        for (int k = 0; k < 8; k++) wp[x][k] = h == 0 ? (k < 6 ? A.W1[(c4 + x) * 6 + k] : 0.f) : A.W2[(c4 + x) * 8 + k];
+    float asrc[8], adst[8];
+    for (int c = 0; c < 8; c++) { asrc[c] = A.gat_a[c * 16 + m]; adst[c] = A.gat_a[HD + c * 16 + m]; }
+    auto fetch_feat = [&](int tile) __attribute__((always_inline)) -> float4 {   // lane L < 32: 4 of the 128 feature words of a tile
+        const int r = tile * 16 + (lane >> 1), k0 = (lane & 1) * 4;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane < 32 && r < N) {
+            const int u = r >> 1, node = r & 1, width = node ? 8 : 6;
+            for (int k = 0; k < 4; k++)
+                if (k0 + k < width) {
+                    const size_t idx = (size_t)u * width + k0 + k;
+                    x[k] = A.feat_f64 ? (float)reinterpret_cast<const double *>(node ? A.f2 : A.f1)[idx]
+                                      : reinterpret_cast<const float *>(node ? A.f2 : A.f1)[idx];
+                }
+        }
+        return make_float4(x[0], x[1], x[2], x[3]);
+    };
+    int t_cur = first + wave, t_n1 = t_cur + 8;
+    float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t_cur < last) fpre = fetch_feat(t_cur);
+    __syncthreads();                                              // weight fragments are staged
+    const unsigned char *wl = s_wf + lane * 16;                   // fragment (c, p, ks): wl + ((c*2 + p)*4 + ks) * 1024
+    while (t_cur < last) {
+        const int row0 = t_cur * 16;
+        // ---- input rows: tile rows 2p+h are node h of machine (row0/2 + p); W1/W2 arrive pre-multiplied with the GAT
+        // weight, so these rows ARE z of the first pass
+        if (lane < 32) *reinterpret_cast<float4 *>(my_f + lane * 4) = fpre;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int p = 0; p < 8; p++) {
+            const int r = 2 * p + h;
+            const float4 fa = *reinterpret_cast<const float4 *>(my_f + r * 8), fb = *reinterpret_cast<const float4 *>(my_f + r * 8 + 4);
+            const float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
+            float o[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                float a = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; k++) a = fmaf(ff[k], wp[x][k], a);
+                o[x] = a;
+            }
+            *reinterpret_cast<float4 *>(my_a + gx_off(r, c4)) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (t_n1 < last) fpre = fetch_feat(t_n1);
+#pragma unroll 1
+        for (int pass = 0; pass < 3; pass++) {
+            f32x4 acc[8];
+            if (pass == 0) {
+#pragma unroll
+                for (int c = 0; c < 8; c++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[c][i] = my_a[gx_off(4 * q + i, c * 16 + m)];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            } else {
+                // the tile in operand layout: row m, k = 32ks + 8q .. +7, split into two f16 planes.  The values are ELU outputs of
+                // attention mixtures — unbounded in principle: one beyond the f16 range becomes (inf | -inf) pieces, their products
+                // a NaN that reaches every output of the forward, where the heads kernel reports it (range_flag) and the host
+                // repeats the forward on the f32-instruction kernels — never a silently saturated value
+                h16x8 xf[2][4];
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+                    const float4 lo = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q));
+                    const float4 hi = *reinterpret_cast<const float4 *>(my_a + gx_off(m, 32 * ks + 8 * q + 4));
+                    const float v0[4] = {lo.x, lo.y, lo.z, lo.w}, v1[4] = {hi.x, hi.y, hi.z, hi.w};
+                    uint2 a0, a1, b0, b1;
+                    split2x4(v0, a0, a1); split2x4(v1, b0, b1);
+                    xf[0][ks] = __builtin_bit_cast(h16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+                    xf[1][ks] = __builtin_bit_cast(h16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+                }
+                // column blocks in pairs (two accumulator chains); units u = (pair, k-step): 4 weight fragments each, the next
+                // unit's in flight
+                h16x8 wr[2][2][2];
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                    for (int p = 0; p < 2; p++) wr[0][cc][p] = *reinterpret_cast<const h16x8 *>(wl + ((cc * 2 + p) * 4) * 1024);
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int cp = u >> 2, ks = u & 3;
+                    if (u + 1 < 16) {
+                        const int cn = (u + 1) >> 2, kn = (u + 1) & 3;
+#pragma unroll
+                        for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                            for (int p = 0; p < 2; p++) wr[(u + 1) & 1][cc][p] = *reinterpret_cast<const h16x8 *>(wl + (((2 * cn + cc) * 2 + p) * 4 + kn) * 1024);
+                    }
+                    const h16x8 (*w)[2] = wr[u & 1];
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0][ks], w[cc][1], acc[2 * cp + cc], 0, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < 8; c++) acc[c] *= wsinv;                  // the weight image is scaled by a power of two
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {                                     // the lane's two machines: tile rows 4q+2u (node 0), +1 (node 1)
+                const int i = 2 * u;
+                float s0 = 0.f, d0 = 0.f, d1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; c++) { const float z0 = acc[c][i], z1 = acc[c][i + 1]; s0 += asrc[c] * z0; d0 += adst[c] * z0; d1 += adst[c] * z1; }
+                s0 = row_sum16(s0); d0 = row_sum16(d0); d1 = row_sum16(d1);
+                float e00 = s0 + d0, e01 = s0 + d1;
+                e00 = e00 > 0.f ? e00 : 0.2f * e00;
+                e01 = e01 > 0.f ? e01 : 0.2f * e01;
+                const float mx = fmaxf(e00, e01);
+                const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
+                const float inv = 1.0f / (x0 + x1);
+                const float al0 = x0 * inv, al1 = x1 * inv;
+                const int r = 4 * q + i;
+                if (pass < 2) {
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
+                        float n0 = al0 * z0 + al1 * z1, n1 = z1;
+                        n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;               // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
+                        n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
+                        my_a[gx_off(r, c * 16 + m)] = n0;
+                        my_a[gx_off(r + 1, c * 16 + m)] = n1;
+                    }
+                } else {
+                    const bool valid = row0 + r < N;
+                    float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + m;
+#pragma unroll
+                    for (int c = 0; c < 8; c++) {
+                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
+                        float mv = (al0 * z0 + al1 * z1 + z1) * 0.5f;        // mean over the 2 nodes (ac:420)
+                        nd[c * 16] = mv;
+                        if (!valid) mv = 0.f;
+                        st_sum[c] += mv; st_sq[c] = __builtin_fmaf(mv, mv, st_sq[c]);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tile is complete before the next pass reads it
+        }
+        t_cur = t_n1; t_n1 += 8;
+    }
+    // column sums: fold the 4 row quarters, then the 8 waves through LDS
+    __syncthreads();                                              // every tile is done: s_red aliases them
+    for (int c = 0; c < 8; c++) {
+        double a = (double)st_sum[c], b = (double)st_sq[c];
+        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+        if (q == 0) { s_red[wave * 256 + c * 16 + m] = a; s_red[wave * 256 + HD + c * 16 + m] = b; }
+    }
+    __syncthreads();
+    if (tid < 256) {
+        double v = 0;
+        for (int w = 0; w < 8; w++) v += s_red[w * 256 + tid];
+        atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
+    }

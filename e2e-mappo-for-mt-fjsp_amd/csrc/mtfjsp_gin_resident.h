@@ -55,6 +55,12 @@
 #ifndef GR_GRP
 #define GR_GRP 2                          // row tiles per workgroup barrier in the layers without aggregation (2 * GR_GRP plane buffers; measured 1: 142, 2: 135, 3: 138 us per launch)
 #endif
+#ifndef GR_LOOK
+#define GR_LOOK 2                         // layers without aggregation: the planes of tile RT + GR_LOOK are produced while tile RT is multiplied; 2 * GR_LOOK
+#endif                                    // plane buffers.  GR_LOOK == GR_GRP: one workgroup barrier per group of tiles (4 buffers); GR_LOOK == 2 * GR_GRP: the four
+                                          // waves synchronise through one LDS counter per group with a whole group of slack, no barrier inside a layer —
+                                          // correct (same tests), measured SLOWER: 144 vs 135 us per launch (the four waves run in step anyway, and the
+                                          // deeper look-ahead costs 20 more spilled registers); kept as a build option
 #define GR_ROWB 272                       // plane row pitch in bytes (256 + 16: conflict-free 16-byte operand reads)
 #define GR_PLANE (32 * GR_ROWB)
 #define GR_TILE (2 * GR_PLANE)                // a tile buffer: the (high | low) f16 planes of 32 rows
@@ -64,7 +70,7 @@
 #define GR_MAXIPC 64                      // instances per workgroup (u8 instance ids; pool accumulators in the ring area)
 
 #ifndef GR_MIX
-#define GR_MIX 0                          // 1: the low operand piece as fma(f16 high piece, -1, x) = v_fma_mix_f32 (no separate f16 -> f32 conversion); same bits
+#define GR_MIX 1                          // 1: the low operand piece as fma(f16 high piece, -1, x) = v_fma_mix_f32 (no separate f16 -> f32 conversion); same bits
 #endif
 #ifndef GR_PK
 #define GR_PK 1                           // 1: two-wide f32 vector arithmetic (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32); 0: one instruction per element
@@ -108,14 +114,16 @@ struct GinResArgs {
 // LDS map (bytes)
 #define GR_OFF_PLANES 0                                           // [2][2 planes][32 rows][272] (first Linear: 3 bf16 planes of 8 tiles side by side)
 #define GR_OFF_RING (2 * GR_TILE)                                 // f32 [6 tiles * 32 rows][128], swizzled (first phase: features [576][12])
-#define GR_OFF_ELLC (GR_OFF_RING + GR_RING * 32 * HD * 4)         // u32 [576]: workgroup-relative rows of the <= 2 in-edges, 0xffff = none
+#define GR_RING_BYTES ((2 * GR_LOOK - 2) * GR_TILE > GR_RING * 32 * HD * 4 ? (2 * GR_LOOK - 2) * GR_TILE : GR_RING * 32 * HD * 4)   // (also plane buffers 2 .. 2 * GR_LOOK - 1)
+#define GR_OFF_ELLC (GR_OFF_RING + GR_RING_BYTES)                 // u32 [576]: workgroup-relative rows of the <= 2 in-edges, 0xffff = none
 #define GR_OFF_ELLV0 (GR_OFF_ELLC + GR_ROWS * 4)
 #define GR_OFF_ELLV1 (GR_OFF_ELLV0 + GR_ROWS * 4)
 #define GR_OFF_BN (GR_OFF_ELLV1 + GR_ROWS * 4)                    // f32 [256] scale | shift
 #define GR_OFF_CAND (GR_OFF_BN + 2 * HD * 4)                      // i32 [576]: candidate slot of a row (instance-local slot + J * local instance), -1 = none
 #define GR_OFF_ZERO (GR_OFF_CAND + GR_ROWS * 4)                   // f32 [256] zeros: the "scale | shift" of rows >= nrows
 #define GR_OFF_FLAG (GR_OFF_ZERO + 2 * HD * 4)
-#define GR_LDS_BYTES (GR_OFF_FLAG + 64)
+#define GR_OFF_CNT (GR_OFF_FLAG + 64)                             // u32 [5 layers][GR_NT / GR_GRP]: waves that finished a group of tiles (GR_LOOK > GR_GRP)
+#define GR_LDS_BYTES (GR_OFF_CNT + 5 * (GR_NT / GR_GRP) * 4 + 12)
 static size_t gin_res_lds_bytes() { return (size_t)GR_LDS_BYTES; }
 static_assert(GR_LDS_BYTES <= 160 * 1024, "resident GIN kernel: LDS budget");
 
@@ -210,6 +218,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     int *s_rowcand = reinterpret_cast<int *>(smem + GR_OFF_CAND);
     float *s_zero = reinterpret_cast<float *>(smem + GR_OFF_ZERO);
     unsigned *s_flag = reinterpret_cast<unsigned *>(smem + GR_OFF_FLAG);
+    unsigned *s_cnt = reinterpret_cast<unsigned *>(smem + GR_OFF_CNT);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = lane & 31, h = lane >> 5;
     const unsigned nblk = gridDim.x + A.expect_extra;
@@ -258,6 +267,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             s_ellc[r] = cp; s_ellv0[r] = v0; s_ellv1[r] = v1; s_rowcand[r] = -1;
         }
         if (tid == 0) s_flag[1] = 0u;
+        if (tid < 5 * (GR_NT / GR_GRP)) s_cnt[tid] = 0u;
         for (int i = tid; i < 2 * GR_TILE / 16; i += 256) reinterpret_cast<float4 *>(s_planes)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (A.candidate) {                                        // row -> candidate slot (ac:197-207 gathers h of one row per job)
             __syncthreads();
@@ -388,11 +398,11 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 #define GR_PIN_V() do { } while (0)
     auto consume_tile = [&](auto Tc) __attribute__((always_inline)) {
         constexpr int RT = decltype(Tc)::value;
-        constexpr int PT = RT + GR_GRP;                                   // the tile whose planes are produced here (the next group's)
+        constexpr int PT = RT + GR_LOOK;                                  // the tile whose planes are produced here
         constexpr bool NEXT = (PT < GR_NT) && !(GR_ABL & 1);
         constexpr bool STATS = RT > 0 && RT - 1 < GR_NRES && !(GR_ABL & 4);     // (a spilled tile's sums are taken when it is stored)
-        const unsigned char *xa = plane_buf(RT % (2 * GR_GRP)) + n * GR_ROWB + 16 * h;
-        unsigned char *pnext = plane_buf(PT % (2 * GR_GRP));
+        const unsigned char *xa = plane_buf(RT % (2 * GR_LOOK)) + n * GR_ROWB + 16 * h;
+        unsigned char *pnext = plane_buf(PT % (2 * GR_LOOK));
         const float *bn = PT * 32 + n < nrows ? s_bn : s_zero;            // rows >= nrows: scale = shift = 0 -> zero planes
         gr_h8 xf[2][2];
 #pragma unroll
@@ -406,7 +416,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : atmp;     // (its previous-layer values went into the planes one tile ago)
         a = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // the spilled tiles' old values: requested a tile before the slices that turn them into planes
-        if constexpr (RT + GR_GRP + 1 >= GR_NRES && RT + GR_GRP + 1 < GR_NT) zload(std::integral_constant<int, RT + GR_GRP + 1 - GR_NRES>{});
+        if constexpr (RT + GR_LOOK + 1 >= GR_NRES && RT + GR_LOOK + 1 < GR_NT) zload(std::integral_constant<int, RT + GR_LOOK + 1 - GR_NRES>{});
         gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
             constexpr int g = decltype(Pc)::value;                       // region = k-steps 2g, 2g+1 = column quarter g of the next tile
             const gr_h8 *x0 = xf[0], *x1 = xf[1];
@@ -590,16 +600,32 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     gr_static_for<5>([&](auto Lc) __attribute__((always_inline)) {
         constexpr int layer = decltype(Lc)::value + 1;
         if constexpr (layer != 3) {
-            gr_static_for<GR_GRP>([&](auto Ic) __attribute__((always_inline)) { produce_tile(Ic, plane_buf(decltype(Ic)::value)); });
+            gr_static_for<GR_LOOK>([&](auto Ic) __attribute__((always_inline)) { produce_tile(Ic, plane_buf(decltype(Ic)::value)); });
             LDS_BARRIER();
+            unsigned *cnt = s_cnt + (layer - 1) * (GR_NT / GR_GRP);
             gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
                 constexpr int RT = decltype(Tc)::value;
-                consume_tile(Tc);                                 // produces tile RT+2 between its matrix instructions
+                constexpr int step = RT / GR_GRP, back = GR_LOOK / GR_GRP;
+                if constexpr (GR_LOOK > GR_GRP && RT % GR_GRP == 0 && step >= back) {
+                    // this group's planes were written during group step - back, by all four waves (each its 32 columns), after they had
+                    // finished reading the group that held these buffers before: one counter says both
+                    while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(&cnt[step - back], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < 4u)
+                        __builtin_amdgcn_s_sleep(1);
+                    asm volatile("" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                consume_tile(Tc);                                 // produces tile RT + GR_LOOK between its matrix instructions
                 GR_PIN_V();
-                if constexpr (RT % GR_GRP == GR_GRP - 1) LDS_BARRIER();     // one barrier per group of tiles
+                if constexpr (RT % GR_GRP == GR_GRP - 1) {
+                    if constexpr (GR_LOOK > GR_GRP) {             // (LDS executes a wave's operations in issue order: the add lands after its plane writes and reads)
+                        asm volatile("" ::: "memory");
+                        if (lane == 0) __hip_atomic_fetch_add(&cnt[step], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    } else LDS_BARRIER();                         // one barrier per group of tiles
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
-            static_assert(GR_NT % GR_GRP == 0 && GR_GRP >= 1 && GR_GRP <= 2 + (GR_RING * 32 * HD * 4) / GR_TILE / 2, "tile groups");
+            if constexpr (GR_LOOK > GR_GRP) LDS_BARRIER();        // (the boundary parks its sums in the ring area, i.e. in plane buffers)
+            static_assert(GR_NT % GR_GRP == 0 && GR_GRP >= 1 && (GR_LOOK == GR_GRP || GR_LOOK == 2 * GR_GRP) && GR_LOOK <= GR_NRES, "tile groups");
         } else {
             // gcn:125-149: (A_w @ h) / nnz_row with h = relu(bn_outer0(z)), A_w incl. the self loop.  h tiles go through a ring of
             // GR_RING tiles in LDS; tile rt's rows and their in-edge sources (same instance, T <= 65 rows) lie in tiles rt-2..rt+2

@@ -1,0 +1,300 @@
+// mtfjsp_headsx_body.h — the statements of k_headsx (csrc/mtfjsp_encoder.hip), included inside a kernel with `A` (HeadArgs) and `smem`
+// in scope: k_headsx and k_headsx_gat3x (see mtfjsp_gat3x_body.h for why this is textual).
+    unsigned char *s_xs = smem;                                    // HCH tiles of 2 planes: X rows, then s1
+    unsigned char *s_pp = s_xs + HCH * X2_TILE;                    // pooled planes
+    unsigned char *s_op = s_pp + X2_TILE;                          // other planes
+    unsigned char *s_c1p = s_op + X2_TILE;                         // c1 planes
+    float *s_c2 = reinterpret_cast<float *>(s_c1p + X2_TILE);      // [16][HX_CLDA] f32
+    float *s_u = s_c2 + 16 * HX_CLDA;                              // [16][128]
+    float *s_part = s_u + HG * HD;                                 // 8 waves * (HCH*16) rows
+    float *s_score = s_part + 8 * HCH * 16;                        // HG * 64
+    float *s_wc2 = s_score + HG * 64;                              // 2 * 128
+    float *s_vec = s_wc2 + 2 * HD;                                 // b0 | bc0 | bc1 | b1 | w2
+    unsigned char *s_mask = reinterpret_cast<unsigned char *>(s_vec + 5 * HD);   // HG * 64
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int m = lane & 15, q = lane >> 4;
+    const int col4 = 16 * wave + 4 * q;                            // this lane's 4 output columns
+#ifdef MTFJSP_STAMP
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
+#endif
+    const int R = A.R;
+    const unsigned invR = (unsigned)((0x100000000ull + (unsigned)R - 1) / (unsigned)R);
+    const int sr = tid >> 5, sc4 = (tid & 31) * 4;                  // staging: thread -> (row sr of 16, 4 columns)
+    const int xoff = m * X6_ROWB + 16 * q;                          // operand fragment of (plane p, k-step ks): + p*X6_PLANE + 64*ks
+    const float b2 = A.b2[0];
+    if (tid < 2 * HD) s_wc2[tid] = A.wc2[tid];
+    if (tid < HD) { s_vec[tid] = A.b0[tid]; s_vec[HD + tid] = A.bc0[tid]; s_vec[2 * HD + tid] = A.bc1[tid]; s_vec[3 * HD + tid] = A.b1[tid]; s_vec[4 * HD + tid] = A.w2[tid]; }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
+    if (A.zero_stats2 && blockIdx.x == 0) for (int i = tid; i < A.zero_count2; i += 512) A.zero_stats2[i] = 0.0;
+    float xs0 = 1.f, xs1 = 1.f, xs2 = 1.f, xs3 = 1.f, xh0 = 0.f, xh1 = 0.f, xh2 = 0.f, xh3 = 0.f;   // X scale / shift of this thread's 4 columns
+    // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of X, the gathered X rows of the
+    // first chunk (index -> row: two dependent round trips), the weights of phase A; only then the pooling stream
+    double bsu[STAT_REP], bsq[STAT_REP];
+    float bga = 0.f, bbe = 0.f;
+    if (A.xbn_stats && tid < HD) {
+#pragma unroll
+        for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.xbn_stats[r * 256 + tid]; bsq[r] = A.xbn_stats[r * 256 + HD + tid]; }
+        bga = A.xbn_gamma[tid]; bbe = A.xbn_beta[tid];
+    }
+    {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
+        // 64-bit weight addresses into registers and spill them)
+        const int g0 = blockIdx.x * HG;
+        const int ng = (A.B - g0) < HG ? (A.B - g0) : HG;
+        const int nrows = ng * R;
+        // scorer row `grow` of the group (instance grow / R, candidate / machine grow % R) -> its source row in X
+        auto xrow = [&](int grow) __attribute__((always_inline)) -> const float * {
+            if (!A.xgather) return A.X + ((size_t)g0 * R + grow) * HD + sc4;
+            const int il = (int)__umulhi((unsigned)grow, invR);
+            return A.X + ((size_t)(g0 + il) * A.xT + A.xgather[(size_t)g0 * R + grow]) * HD + sc4;
+        };
+        float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
+#pragma unroll
+        for (int t = 0; t < HCH; t++) {
+            const int grow = t * 16 + sr;
+            xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        h16x8 wA[2][4], wB[2][4], wC[2][4];
+        const float sW0 = A.sW0, sW1 = A.sW1, sWc0 = A.sWc0, sWc1 = A.sWc1;   // 1 / scale of the weight images
+        WCOLX(wA, A.W0x, 1);                                        // Wb
+        WCOLX(wB, A.W0x, 2);                                        // Wc
+        WCOLX(wC, A.Wc0x, 0);
+        if (A.xbn_stats) {
+            if (tid < HD) {                                         // stage_bn() from the registers requested above; s_u is free until phase A
+                double su = 0, sq = 0;
+#pragma unroll
+                for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
+                if (A.range_flag && (su != su || sq != sq)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const double mean = su * A.xbn_inv_rows;
+                double var = sq * A.xbn_inv_rows - mean * mean;
+                if (var < 0) var = 0;
+                const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
+                const float sc = rstd * bga;
+                s_u[tid] = sc;
+                s_u[HD + tid] = bbe - (float)mean * sc;
+            }
+            LDS_BARRIER();
+            xs0 = s_u[sc4]; xs1 = s_u[sc4 + 1]; xs2 = s_u[sc4 + 2]; xs3 = s_u[sc4 + 3];
+            xh0 = s_u[HD + sc4]; xh1 = s_u[HD + sc4 + 1]; xh2 = s_u[HD + sc4 + 2]; xh3 = s_u[HD + sc4 + 3];
+            LDS_BARRIER();
+        }
+        STAMP(6);
+        {
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 xp = z;
+            if (A.xbn_stats) {                                      // pooled = mean over the instance's normalised rows (ac:444 / gcn:192)
+                if (sr < ng) {
+                    const int nr = A.xgather ? A.xT : R;
+                    const float *src = A.X + (size_t)(g0 + sr) * nr * HD + sc4;
+                    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 12
+                    for (int r = 0; r < nr; r++) {                   // 12 rows in flight per thread
+                        const float4 v = *reinterpret_cast<const float4 *>(src + (size_t)r * HD);
+                        float y0 = fmaf(v.x, xs0, xh0), y1 = fmaf(v.y, xs1, xh1), y2 = fmaf(v.z, xs2, xh2), y3 = fmaf(v.w, xs3, xh3);
+                        if (A.xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+                        a0 += y0; a1 += y1; a2 += y2; a3 += y3;
+                    }
+                    const float ir = 1.0f / (float)nr;
+                    xp = make_float4(a0 * ir, a1 * ir, a2 * ir, a3 * ir);
+                    *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
+                }
+            } else if (sr < ng) xp = *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4);
+            STAMP(7);
+            const float4 xo = sr < ng ? *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + sr) * HD + sc4) : z;
+            {
+                const float vp[4] = {xp.x, xp.y, xp.z, xp.w}, vo[4] = {xo.x, xo.y, xo.z, xo.w};
+                uint2 a0, a1, b0, b1;
+                split2x4(vp, a0, a1); split2x4(vo, b0, b1);
+                unsigned char *dp = s_pp + sr * X6_ROWB + (tid & 31) * 8, *dq = s_op + sr * X6_ROWB + (tid & 31) * 8;
+                *reinterpret_cast<uint2 *>(dp) = a0; *reinterpret_cast<uint2 *>(dp + X6_PLANE) = a1;
+                *reinterpret_cast<uint2 *>(dq) = b0; *reinterpret_cast<uint2 *>(dq + X6_PLANE) = b1;
+            }
+        }
+        for (int i = tid; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
+        LDS_BARRIER();
+        STAMP(0);
+        auto xnorm = [&](float4 v, bool valid) __attribute__((always_inline)) {
+            if (!valid) return make_float4(0.f, 0.f, 0.f, 0.f);
+            float y0 = fmaf(v.x, xs0, xh0), y1 = fmaf(v.y, xs1, xh1), y2 = fmaf(v.z, xs2, xh2), y3 = fmaf(v.w, xs3, xh3);
+            if (A.xrelu) { y0 = fmaxf(y0, 0.f); y1 = fmaxf(y1, 0.f); y2 = fmaxf(y2, 0.f); y3 = fmaxf(y3, 0.f); }
+            return make_float4(y0, y1, y2, y3);
+        };
+        // one 16-row tile (planes at `tp`) x this wave's column block: 12 products on two chains, fragments of the next k-step in flight
+        auto tile_x6 = [&](const unsigned char *tp, const h16x8 (&wv)[2][4]) __attribute__((always_inline)) -> f32x4 {
+            f32x4 aA = zero4, aB = zero4;
+            h16x8 xv[4][2];                                         // all 8 fragments of the tile requested at once: 3 matrix instructions do not cover an LDS round trip
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+                for (int p = 0; p < 2; p++) xv[ks][p] = *reinterpret_cast<const h16x8 *>(tp + xoff + p * X6_PLANE + 64 * ks);
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++) X6_STEP(aA, aB, wv, xv[ks], ks);
+            return aA + aB;
+        };
+        // a lane's 4 values of row m -> the two planes of a tile
+        auto put_planes = [&](unsigned char *tp, const float (&v)[4]) __attribute__((always_inline)) {
+            uint2 p0, p1;
+            split2x4(v, p0, p1);
+            unsigned char *d = tp + m * X6_ROWB + col4 * 2;
+            *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1;
+        };
+        // ---- phase A: u = Wb pooled + Wc other + b0 ; c1 = tanh(Wc0 pooled + bc0)   (rows = the group's 16 instances)
+        {
+            const f32x4 au = tile_x6(s_pp, wA) + tile_x6(s_op, wB);
+            const f32x4 ac = tile_x6(s_pp, wC);
+            WCOLX(wA, A.Wc1x, 0);                                   // requested now, used in phase B
+            WCOLX(wB, A.W0x, 0);                                    // Wa
+            WCOLX(wC, A.W1x, 0);                                    // phase C
+            const float4 b0v = *reinterpret_cast<const float4 *>(s_vec + col4), bc0v = *reinterpret_cast<const float4 *>(s_vec + HD + col4);
+            *reinterpret_cast<float4 *>(s_u + m * HD + col4) = make_float4(fmaf(au[0], sW0, b0v.x), fmaf(au[1], sW0, b0v.y), fmaf(au[2], sW0, b0v.z), fmaf(au[3], sW0, b0v.w));
+            const float c1v[4] = {fast_tanh(fmaf(ac[0], sWc0, bc0v.x)), fast_tanh(fmaf(ac[1], sWc0, bc0v.y)), fast_tanh(fmaf(ac[2], sWc0, bc0v.z)), fast_tanh(fmaf(ac[3], sWc0, bc0v.w))};
+            put_planes(s_c1p, c1v);
+        }
+        STAMP(1);
+        for (int tb = 0; tb < R; tb += HCH) {
+            const int nt = (R - tb) < HCH ? (R - tb) : HCH;
+            // ---- X rows of this chunk -> planes (rows beyond the group's are zero)
+#pragma unroll
+            for (int t = 0; t < HCH; t++) {
+                if (tb > 0) {
+                    const int grow = (tb + t) * 16 + sr;
+                    xr[t] = (tb + t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                const float4 xv4 = xnorm(xr[t], (tb + t) * 16 + sr < nrows);
+                const float v[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+                uint2 p0, p1;
+                split2x4(v, p0, p1);
+                unsigned char *d = s_xs + t * X2_TILE + sr * X6_ROWB + (tid & 31) * 8;
+                *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1;
+            }
+            LDS_BARRIER();                                          // X planes, u and c1 are complete
+            STAMP(2);
+            // ---- phase B: Wa x for every tile of the chunk (accumulators held); first chunk: c2 = tanh(Wc1 c1 + bc1)
+            f32x4 accb[HCH];
+#pragma unroll
+            for (int t = 0; t < HCH; t++) accb[t] = t < nt ? tile_x6(s_xs + t * X2_TILE, wB) : zero4;
+            if (tb == 0) {
+                const f32x4 a0 = tile_x6(s_c1p, wA);
+                const float4 bc1v = *reinterpret_cast<const float4 *>(s_vec + 2 * HD + col4);
+                *reinterpret_cast<float4 *>(s_c2 + m * HX_CLDA + col4) =
+                    make_float4(fast_tanh(fmaf(a0[0], sWc1, bc1v.x)), fast_tanh(fmaf(a0[1], sWc1, bc1v.y)), fast_tanh(fmaf(a0[2], sWc1, bc1v.z)), fast_tanh(fmaf(a0[3], sWc1, bc1v.w)));
+            }
+            LDS_BARRIER();                                          // every wave is done with the X planes: s1 overwrites them
+            // s1 = tanh(Wa x + u[instance]) -> planes
+#pragma unroll
+            for (int t = 0; t < HCH; t++) {
+                if (t < nt) {
+                    const int grow = (tb + t) * 16 + m;
+                    const int i0 = grow < nrows ? (int)__umulhi((unsigned)grow, invR) : 0;
+                    const float4 uv = *reinterpret_cast<const float4 *>(s_u + i0 * HD + col4);
+                    const float sv[4] = {fast_tanh(fmaf(accb[t][0], sW0, uv.x)), fast_tanh(fmaf(accb[t][1], sW0, uv.y)), fast_tanh(fmaf(accb[t][2], sW0, uv.z)), fast_tanh(fmaf(accb[t][3], sW0, uv.w))};
+                    put_planes(s_xs + t * X2_TILE, sv);
+                }
+            }
+            LDS_BARRIER();                                          // s1 planes and c2 are complete
+            STAMP(3);
+            // ---- phase C: s2 = tanh(W1 s1 + b1) ; partial scores of this wave's 16 columns
+            {
+                const float4 b1v = *reinterpret_cast<const float4 *>(s_vec + 3 * HD + col4), w2v = *reinterpret_cast<const float4 *>(s_vec + 4 * HD + col4);
+#pragma unroll 1
+                for (int t = 0; t < HCH; t++) {                     // (rolled: this kernel runs once per workgroup from a cold instruction cache)
+                    if (t < nt) {
+                        const f32x4 a0 = tile_x6(s_xs + t * X2_TILE, wC);
+                        float v = fast_tanh(fmaf(a0[0], sW1, b1v.x)) * w2v.x;
+                        v = fmaf(fast_tanh(fmaf(a0[1], sW1, b1v.y)), w2v.y, v);
+                        v = fmaf(fast_tanh(fmaf(a0[2], sW1, b1v.z)), w2v.z, v);
+                        v = fmaf(fast_tanh(fmaf(a0[3], sW1, b1v.w)), w2v.w, v);
+                        v += __shfl_xor(v, 16);
+                        v += __shfl_xor(v, 32);
+                        if (q == 0) s_part[wave * (HCH * 16) + t * 16 + m] = v;
+                    }
+                }
+            }
+            if (tb == 0) {   // value head: 32 threads per instance row, 4 columns each, both outputs
+                const int r = tid >> 5, part = tid & 31;
+                float p0 = 0.f, p1 = 0.f;
+                for (int k = 0; k < 4; k++) { const float x = s_c2[r * HX_CLDA + part * 4 + k]; p0 = fmaf(x, s_wc2[part * 4 + k], p0); p1 = fmaf(x, s_wc2[HD + part * 4 + k], p1); }
+                for (int o = 16; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+                if (part == 0 && r < ng) {
+                    const float v0 = p0 + A.bc2[0], v1 = p1 + A.bc2[1];
+                    A.value[(size_t)(g0 + r) * 2] = v0; A.value[(size_t)(g0 + r) * 2 + 1] = v1;
+                    if (A.range_flag && (v0 != v0 || v1 != v1)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            LDS_BARRIER();
+            if (tid < nt * 16) {
+                const int grow = tb * 16 + tid;
+                float v = b2;
+                for (int w = 0; w < 8; w++) v += s_part[w * (HCH * 16) + tid];
+                if (grow < nrows) s_score[grow] = v * A.scale;
+            }
+            LDS_BARRIER();                                          // planes / s_part are reused by the next chunk
+            STAMP(4);
+        }
+        // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance; optional action selection
+        {
+            const int r0 = tid >> 4, l = tid & 15;
+            if (r0 < ng) {
+                float mx = -INFINITY;
+                for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) mx = fmaxf(mx, s_score[r0 * R + r]);
+                for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+                float sum = 0.f;
+                for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) sum += __expf(s_score[r0 * R + r] - mx);
+                for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                for (int r = l; r < R; r += 16) {
+                    const float pr = s_mask[r0 * R + r] ? 0.f : __expf(s_score[r0 * R + r] - mx) / sum;
+                    A.prob[(size_t)(g0 + r0) * R + r] = pr;
+                    if (A.range_flag && pr != pr) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    s_score[r0 * R + r] = pr;                           // lanes of one wave: visible to lane l == 0 below
+                }
+                if (A.sample_mode) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (l == 0) {
+                        const int b = g0 + r0;
+                        const int pick = pick_action(s_score + r0 * R, R, b, A.sample_mode == 2, A.seed, A.counter);
+                        A.idx_out[b] = pick;
+                        if (A.logp_out) A.logp_out[b] = logf(s_score[r0 * R + pick]);
+                        const int gsel = A.gather_from ? A.gather_from[(size_t)b * R + pick] : pick;
+                        if (A.gather_from && A.gathered_out) A.gathered_out[b] = gsel;
+                        s_part[r0] = __int_as_float(gsel);                     // hand the selected task to the instance's 16 lanes (s_part is free now)
+                    }
+                    if (A.mf_on) {
+                        // = k_mfea1 (pe:152-214) for the task just selected: the 16 lanes of the instance take the machines
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const int b = g0 + r0, T_ = A.mf.T, M_ = A.mf.M;
+                        int a = __float_as_int(s_part[r0]);
+                        if (a < 0 || a >= T_) a = 0;
+                        const size_t row = (size_t)b * T_ + a;
+                        int pm = 0;
+                        if (a % M_ != 0) {
+                            pm = reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
+                            if (pm < 0) pm += M_;                                             // python negative index (pe:206)
+                        }
+                        for (int mm = l; mm < M_; mm += 16) {
+                            const double tv = A.mf.t[row * M_ + mm], pv = A.mf.p[row * M_ + mm];
+                            const double ptv = tv * fabs(pv);
+                            const unsigned char mk = (unsigned char)!(tv >= 0);              // run:258-259 ~(t >= 0)
+                            const double x = (a % M_ != 0) ? A.mf.tt[((size_t)b * M_ + pm) * M_ + mm] : 0.0;
+                            const double f0 = tv > 0 ? tv : A.mf.mean3[row * 3 + 0], f1 = ptv > 0 ? ptv : A.mf.mean3[row * 3 + 1];
+                            const double f4 = pv > 0 ? pv : A.mf.mean3[row * 3 + 2];
+                            const size_t o = ((size_t)b * M_ + mm) * 6;
+                            const double f3 = (double)(1 - (int)mk), f5 = (double)(A.mf.shop[(size_t)b * M_ + mm] + 1);
+                            if (A.mf.obs_f32) {
+                                float *of = reinterpret_cast<float *>(A.mf.m_fea1_out) + o;
+                                of[0] = (float)f0; of[1] = (float)f1; of[2] = (float)x; of[3] = (float)f3; of[4] = (float)f4; of[5] = (float)f5;
+                            } else {
+                                double *od = reinterpret_cast<double *>(A.mf.m_fea1_out) + o;
+                                od[0] = f0; od[1] = f1; od[2] = x; od[3] = f3; od[4] = f4; od[5] = f5;
+                            }
+                            A.mf.mmask_out[(size_t)b * M_ + mm] = mk;
+                        }
+                    }
+                }
+            }
+        }
+        STAMP(5);
+    }
+#ifdef MTFJSP_STAMP
+    if (A.stamps && lane == 0) for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
+#endif

@@ -248,6 +248,9 @@ typedef struct {
     void *m_fea1_out;                   /* [B,M,6] obs dtype */
     uint8_t *mmask_out;                 /* [B,M] */
     int32_t T, M, obs_f32;
+    const void *m_fea2;                 /* [B,M,8] obs dtype: the environment's bound machine features (may be NULL).  With it the
+                                         * job actor's heads launch can also run the machine actor's GAT passes on (m_fea1_out, m_fea2)
+                                         * — the mtfjsp_machine_actor_forward that follows with exactly these two pointers skips them */
 } mtfjsp_mfea1_ctx_t;
 int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask_out, mtfjsp_mfea1_ctx_t *ctx);
 /* BatchNorm statistics of the two actor forwards (every BatchNorm in the reference is in training mode):

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(512) void k_layer8(Args A)
             static_for<4>([&](auto Kc) __attribute__((always_inline)) {
                 constexpr int ks = decltype(Kc)::value;
                 h8 nh = xh, nl = xl;
-                if constexpr (ks < 3) {
+                if constexpr (ks < 3 && !(ABL & 16)) {
                     nh = *reinterpret_cast<const h8 *>(slot + rd0 + (((4 * (ks + 1) + q) ^ n) << 4));
                     nl = *reinterpret_cast<const h8 *>(slot + rd0 + (((4 * (ks + 1) + q) ^ n) << 4) + 4096);
                 }
