@@ -1417,14 +1417,32 @@ __global__ void k_draw_w3(int B, uint64_t seed, uint64_t episode, double *w3)
     w3[(size_t)b * 3 + 0] = u[0] / sum; w3[(size_t)b * 3 + 1] = u[1] / sum; w3[(size_t)b * 3 + 2] = u[2] / sum;
 }
 
-// GAE reverse scan (ppo:444-457 / 500-510): thread = instance, coalesced over b at every step
+// GAE reverse scan (ppo:444-457 / 500-510): thread = instance, coalesced over b at every step.  The recurrence is serial in s but its
+// inputs are not: the four loads of GAE_U steps are issued together and the chain then runs from registers (180 dependent
+// memory round trips per thread before: 54.6 us per call at [180, 4096]; same operations in the same order, same bits).
+#define GAE_U 12
 __global__ void k_gae(int B, int S, const float *r, long r_ss, long r_sb, const float *v, long v_ss, long v_sb, const float *vn, long n_ss, long n_sb,
                       const float *done, float gamma, float lam, float *adv)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     float g = 0.f;
-    for (int s = S - 1; s >= 0; s--) {
+    int s = S - 1;
+    for (; s >= GAE_U - 1; s -= GAE_U) {
+        float rr[GAE_U], vv[GAE_U], nn[GAE_U], dd[GAE_U];
+#pragma unroll
+        for (int u = 0; u < GAE_U; u++) {
+            const long t = s - u;
+            rr[u] = r[t * r_ss + b * r_sb]; nn[u] = vn[t * n_ss + b * n_sb]; vv[u] = v[t * v_ss + b * v_sb]; dd[u] = done[(size_t)t * B + b];
+        }
+#pragma unroll
+        for (int u = 0; u < GAE_U; u++) {
+            const float delta = rr[u] + gamma * nn[u] - vv[u];
+            g = delta + gamma * lam * g * (1.0f - dd[u]);
+            adv[(size_t)(s - u) * B + b] = g;
+        }
+    }
+    for (; s >= 0; s--) {
         const float delta = r[s * r_ss + b * r_sb] + gamma * vn[s * n_ss + b * n_sb] - v[s * v_ss + b * v_sb];
         g = delta + gamma * lam * g * (1.0f - done[(size_t)s * B + b]);
         adv[(size_t)s * B + b] = g;
@@ -2136,7 +2154,7 @@ extern "C" int mtfjsp_gae(mtfjsp_handle_t h, int32_t S, const float *r, int64_t 
     if (!h || S < 1 || !r || !v || !v_next || !done || !adv) return MTFJSP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int B = h->cfg.batch;
-    hipLaunchKernelGGL(k_gae, dim3((B + 255) / 256), dim3(256), 0, h->stream, B, (int)S, r, (long)r_ss, (long)r_sb, v, (long)v_ss, (long)v_sb,
+    hipLaunchKernelGGL(k_gae, dim3((B + 63) / 64), dim3(64), 0, h->stream, B, (int)S, r, (long)r_ss, (long)r_sb, v, (long)v_ss, (long)v_sb,
                        v_next, (long)n_ss, (long)n_sb, done, gamma, lambda, adv);
     HIPCHK(h, hipGetLastError());
     return MTFJSP_OK;

@@ -6,7 +6,7 @@ mkdir -p gpurun_out
 i=0
 for set in "$@"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_gr_$i -- python3 bench.py --steps 36 --warmup 36 --min-seconds 0.01 --no-cpu-baseline --no-env-sweep > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d gpurun_out/pmc_gr_$i -- python3 bench.py --steps 36 --warmup 36 --min-seconds 0.01 --no-cpu-baseline --no-env-sweep --no-config-legs > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, glob, collections

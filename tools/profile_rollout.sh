@@ -7,9 +7,9 @@ tag=${1:-prof}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p gpurun_out
 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --no-cpu-baseline --no-env-sweep > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch_${tag} -- python3 bench.py --no-cpu-baseline --no-env-sweep --steps 72 --warmup 36 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write_${tag} -- python3 bench.py --no-cpu-baseline --no-env-sweep --steps 72 --warmup 36 > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag} -- python3 bench.py --no-cpu-baseline --no-env-sweep --no-config-legs > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch_${tag} -- python3 bench.py --no-cpu-baseline --no-env-sweep --no-config-legs --steps 72 --warmup 36 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write_${tag} -- python3 bench.py --no-cpu-baseline --no-env-sweep --no-config-legs --steps 72 --warmup 36 > /dev/null 2>&1
 python3 - "$tag" <<'PY'
 import csv, collections, glob, json, shutil, sys
 tag = sys.argv[1]
