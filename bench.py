@@ -36,11 +36,11 @@ def env_bytes(J, M):
     return 136 * T + 156 * M + 483
 
 
-PMC_FILE = "r02_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"
 
 
 def pmc_traffic(family):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r02_pmc_traffic.json: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  PMC
     collection cannot run inside the timed process, so bench.py reports the last committed measurement (B=4096 J6M6E2)."""
     try:

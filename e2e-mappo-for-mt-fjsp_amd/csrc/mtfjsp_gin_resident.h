@@ -49,6 +49,9 @@
 #ifndef GR_NRES
 #define GR_NRES 16                        // ... of which this many stay in registers; the others go through zspill (see below)
 #endif
+#ifndef GR_VRES
+#define GR_VRES 1                         // 1: row tiles GR_NRES.. stay on chip too — in the VECTOR registers that used to stage their round trip through global
+#endif                                    // memory (the matrix instructions on them are written out with vector-register accumulators); 0: the round trip
 #define GR_ROWS (32 * GR_NT)
 #define GR_RING 6                         // row tiles in the f32 ring of the aggregation layer
 #define GR_NBAR 6                         // grid barriers per launch
@@ -288,6 +291,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     float *zsp = A.zspill + ((size_t)(blockIdx.x * 4 + wave) * (GR_NT - GR_NRES)) * 1024 + lane * 4;
     auto zload = [&](auto Jc) __attribute__((always_inline)) {
         constexpr int j = decltype(Jc)::value;
+        if constexpr (GR_VRES) return;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             const float4 v = *reinterpret_cast<const float4 *>(zsp + j * 1024 + g * 256);
@@ -296,10 +300,17 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     };
     auto zstore = [&](auto Jc, const f32x16 &a) __attribute__((always_inline)) {
         constexpr int j = decltype(Jc)::value;
+        if constexpr (GR_VRES) return;
 #pragma unroll
         for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(zsp + j * 1024 + g * 256) = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
     };
 #define GR_TILEVAL(rt) ((rt) < GR_NRES ? acc[(rt) < GR_NRES ? (rt) : 0] : zs[(rt) >= GR_NRES ? ((rt) - GR_NRES) & 1 : 0])
+    // v_mfma with its accumulator in VECTOR registers, written out: the compiler's intrinsic would allocate it in the accumulation
+    // file (full) and move it back and forth.  ZERO: the first product of a tile (C = 0).
+    auto mfma_v = [&](f32x16 &c, const gr_h8 &a, const gr_h8 &b, bool zero) __attribute__((always_inline)) {
+        if (zero) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+    };
     gr_h8 wf[2][8];
     bf16x8 w0f[3];                                                // (first Linear only)
     f32x2 ts[8], tq[8];                                           // per-lane column (sum, sumsq) of this layer, two columns per register pair
@@ -400,7 +411,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         constexpr int RT = decltype(Tc)::value;
         constexpr int PT = RT + GR_LOOK;                                  // the tile whose planes are produced here
         constexpr bool NEXT = (PT < GR_NT) && !(GR_ABL & 1);
-        constexpr bool STATS = RT > 0 && RT - 1 < GR_NRES && !(GR_ABL & 4);     // (a spilled tile's sums are taken when it is stored)
+        constexpr bool STATS = RT > 0 && (GR_VRES || RT - 1 < GR_NRES) && !(GR_ABL & 4);     // (a spilled tile's sums are taken when it is stored)
         const unsigned char *xa = plane_buf(RT % (2 * GR_LOOK)) + n * GR_ROWB + 16 * h;
         unsigned char *pnext = plane_buf(PT % (2 * GR_LOOK));
         const float *bn = PT * 32 + n < nrows ? s_bn : s_zero;            // rows >= nrows: scale = shift = 0 -> zero planes
@@ -412,9 +423,10 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 4 * h);
             h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 4 * h);
         }
+        constexpr bool VT = GR_VRES && RT >= GR_NRES;                    // this tile lives in vector registers
         f32x16 atmp;
-        f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : atmp;     // (its previous-layer values went into the planes one tile ago)
-        a = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : VT ? zs[RT >= GR_NRES ? (RT - GR_NRES) & 1 : 0] : atmp;     // (its previous-layer values went into the planes one tile ago)
+        if constexpr (!VT) a = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         // the spilled tiles' old values: requested a tile before the slices that turn them into planes
         if constexpr (RT + GR_LOOK + 1 >= GR_NRES && RT + GR_LOOK + 1 < GR_NT) zload(std::integral_constant<int, RT + GR_LOOK + 1 - GR_NRES>{});
         gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
@@ -424,9 +436,11 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             gr_h2 p01 = {0, 0}, p23 = p01, q01 = p01, q23 = p01;
             unsigned char *dst = pnext + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
             const f32x16 &nx = GR_TILEVAL(PT < GR_NT ? PT : RT);
-            const f32x16 &pv = acc[RT > 0 && RT - 1 < GR_NRES ? RT - 1 : 0];
+            const f32x16 &pv = GR_TILEVAL(RT > 0 ? RT - 1 : 0);
             auto M = [&](int ks, int wp, int xp) __attribute__((always_inline)) {
-                if (!(GR_ABL & 2)) a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
+                if (GR_ABL & 2) return;
+                if constexpr (VT) mfma_v(a, wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], ks == 0 && wp == 0 && xp == 1);
+                else a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
             };
             // slice 0
             M(2 * g, 0, 1);
@@ -464,7 +478,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             if constexpr (STATS) { stat2(2 * g, pv[4 * g], pv[4 * g + 1]); stat2(2 * g + 1, pv[4 * g + 2], pv[4 * g + 3]); }
             GR_FENCE();
         });
-        if constexpr (RT >= GR_NRES) {                                // not resident: BatchNorm sums now, then out to its spill slot
+        if constexpr (RT >= GR_NRES && !GR_VRES) {                    // not resident: BatchNorm sums now, then out to its spill slot
             stats_all(a);
             zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
             GR_FENCE();
@@ -485,11 +499,12 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[1], x[0], a, 0, 0, 0);
         a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0f[0], x[0], a, 0, 0, 0);
         if constexpr (RT < GR_NRES) acc[RT] = a;
+        else if constexpr (GR_VRES) zs[(RT - GR_NRES) & 1] = a;
         else {
             stats_all(a);
             zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
         }
-        if constexpr (RT > 0 && RT - 1 < GR_NRES) stats_tile(std::integral_constant<int, RT - 1>{});
+        if constexpr (RT > 0 && (GR_VRES || RT - 1 < GR_NRES)) stats_tile(std::integral_constant<int, RT - 1>{});
         __builtin_amdgcn_sched_barrier(0);
     };
     // this workgroup's column sums -> its dispatch group's accumulators, grid barrier `k` (which folds the groups into the totals),
@@ -497,7 +512,11 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     auto layer_boundary = [&](auto Kc) __attribute__((always_inline)) {
         constexpr int k = decltype(Kc)::value;
         GR_STAMP_AT(4 + 4 * k);
-        const float colsum = fold_stats();                        // (tile 17's sums were taken when it was stored)
+        if constexpr (GR_VRES && GR_NT > GR_NRES) {               // the last tile's sums (it has no successor to take them beside)
+            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // (its matrix instructions were written as text: no compiler-inserted wait before the reads)
+            stats_all(zs[(GR_NT - 1 - GR_NRES) & 1]);
+        }
+        const float colsum = fold_stats();                        // (GR_VRES 0: tile 17's sums were taken when it was stored)
         if (k == 1) GR_STAMP_AT(2);
         double *part = A.stats + ((size_t)k * 8 + (blockIdx.x & 7)) * (2 * HD);
         {
@@ -684,7 +703,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                 constexpr bool NEXT = RT + 1 < GR_NT && !(GR_ABL & 1);
                 constexpr bool WH = RT + 4 < GR_NT && !(GR_ABL & 1);
                 constexpr int WT = WH ? RT + 4 : RT;
-                constexpr bool STATS = RT > 0 && RT - 1 < GR_NRES && !(GR_ABL & 4);
+                constexpr bool STATS = RT > 0 && (GR_VRES || RT - 1 < GR_NRES) && !(GR_ABL & 4);
+                constexpr bool VT = GR_VRES && RT >= GR_NRES;
                 const unsigned char *xa = xa0 + (RT & 1) * GR_TILE;
                 gr_h8 xf[2][2];
 #pragma unroll
@@ -699,14 +719,14 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                     h4 = *reinterpret_cast<const float4 *>(bnw + HD + 32 * wave + 4 * h);
                 }
                 f32x16 atmp;
-                f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : atmp;
+                f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : VT ? zs[RT >= GR_NRES ? (RT - GR_NRES) & 1 : 0] : atmp;
                 // the spilled tiles' old values: requested two tiles before they are turned into h
                 if constexpr (RT + 6 >= GR_NRES && RT + 6 < GR_NT) zload(std::integral_constant<int, RT + 6 - GR_NRES>{});
                 gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
                     constexpr int g = decltype(Pc)::value;
                     const gr_h8 *x0 = xf[0], *x1 = xf[1];
                     const f32x16 &wv = GR_TILEVAL(WT);
-                    const f32x16 &pv = acc[RT > 0 && RT - 1 < GR_NRES ? RT - 1 : 0];
+                    const f32x16 &pv = GR_TILEVAL(RT > 0 ? RT - 1 : 0);
                     const int chl = 8 * wave + 2 * g + h;
                     float4 o = make_float4(0.f, 0.f, 0.f, 0.f), x = o, y = o;
                     f32x2 v01 = {0.f, 0.f}, v23 = v01, e01 = v01, e23 = v01, u01 = v01, u23 = v01;
@@ -714,7 +734,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                     const f32x2 W0 = {r.w0, r.w0}, W1 = {r.w1, r.w1}, IV = {r.inv, r.inv};
                     auto M = [&](int ks, int wp, int xp) __attribute__((always_inline)) {
                         if (!(GR_ABL & 2)) {
-                            if (g == 0 && ks == 0 && wp == 0 && xp == 1)
+                            if constexpr (VT) mfma_v(a, wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], g == 0 && ks == 0 && wp == 0 && xp == 1);
+                            else if (g == 0 && ks == 0 && wp == 0 && xp == 1)
                                 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], x0[xp], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                             else a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
                         }
@@ -757,7 +778,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                                           *reinterpret_cast<uint2 *>(dst + 16 * g + GR_PLANE) = make_uint2(__builtin_bit_cast(unsigned, q01), __builtin_bit_cast(unsigned, q23)); }
                     GR_FENCE();
                 });
-                if constexpr (RT >= GR_NRES) {
+                if constexpr (RT >= GR_NRES && !GR_VRES) {
                     stats_all(a);
                     zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
                     GR_FENCE();
