@@ -345,6 +345,7 @@ class ActorPair:
                               "6 in-kernel grid barriers; graph pool + candidate gather fused)",
                     "bound": "mfma", "achieved": ach, "peak": 2500.0, "unit": "TFLOP/s", "frac": ach / 2500.0, "traffic": None,
                     "what_is_counted": "executed piece-product flops (3 per algorithmic f32 product; 6 in the 12->128 Linear)",
+                    "frac_executed_flops": ach / 2500.0, "frac_algorithmic_flops": flops / avg_s / 1e12 / 2500.0,
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "executed_matrix_flops_per_launch": executed,
                     "algorithmic_flops_per_launch": flops, "f32_equivalent_TFLOPs": flops / avg_s / 1e12,
                     "f32_equivalent_frac_of_f32_matrix_peak_157.3": flops / avg_s / 1e12 / 157.3,
