@@ -319,11 +319,19 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
+    # MTFJSP_BENCH_ONE_DEVICE=1 (diagnostic, tests/test_bench_two_ranks_gpu.py): every rank on cuda:0 over gloo — exercises the N > 1
+    # control flow of this file on a single-GPU box; its numbers mean nothing (the ranks share one GPU)
+    one_device = bool(os.environ.get("MTFJSP_BENCH_ONE_DEVICE"))
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from importlib import import_module
     import mtfjsp_amd  # noqa: F401
@@ -348,7 +356,7 @@ def main():
     def agree_max(x):
         if dist is None:
             return x
-        tmax = torch.tensor([x], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([x], dtype=torch.float64, device="cpu" if one_device else "cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         return float(tmax.item())
 
