@@ -710,17 +710,18 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                 for (int p = 0; p < 8; p++) {
                     float v[4] = {bn_relu_ss(pre[p].x, sc0, sh0), bn_relu_ss(pre[p].y, sc1, sh1), bn_relu_ss(pre[p].z, sc2, sh2), bn_relu_ss(pre[p].w, sc3, sh3)};
                     if (PRO == PRO_AGG) {
-                        // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1); f64 accumulate, then cast
+                        // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1).  Small-integer edge weights, <= 3 terms: an f32
+                        // FMA chain — the form k_gin_res uses — is within 2 ulp of the reference's f64-then-cast (the f64 form cost this
+                        // producer twelve double-rate instructions per row quad; k_gemm16p, the f32-instruction A/B path, keeps it)
                         const int pp = p < NA ? p : 0;
                         const int r = 2 * p + h;
-                        const double wx = (double)__shfl(e_vx, r), wy = (double)__shfl(e_vy, r);
+                        const float wx = __shfl(e_vx, r), wy = __shfl(e_vy, r);
                         const float dg = __shfl(e_dg, r);
-                        const double inv = dg == 1.f ? 1.0 : dg == 2.f ? 0.5 : (1.0 / 3.0);
-                        const double a0 = (double)v[0] + wx * (double)bn_relu_ss(nb0[pp].x, sc0, sh0) + wy * (double)bn_relu_ss(nb1[pp].x, sc0, sh0);
-                        const double a1 = (double)v[1] + wx * (double)bn_relu_ss(nb0[pp].y, sc1, sh1) + wy * (double)bn_relu_ss(nb1[pp].y, sc1, sh1);
-                        const double a2 = (double)v[2] + wx * (double)bn_relu_ss(nb0[pp].z, sc2, sh2) + wy * (double)bn_relu_ss(nb1[pp].z, sc2, sh2);
-                        const double a3 = (double)v[3] + wx * (double)bn_relu_ss(nb0[pp].w, sc3, sh3) + wy * (double)bn_relu_ss(nb1[pp].w, sc3, sh3);
-                        v[0] = (float)(a0 * inv); v[1] = (float)(a1 * inv); v[2] = (float)(a2 * inv); v[3] = (float)(a3 * inv);
+                        const float inv = dg == 1.f ? 1.0f : dg == 2.f ? 0.5f : (1.0f / 3.0f);
+                        v[0] = __builtin_fmaf(wy, bn_relu_ss(nb1[pp].x, sc0, sh0), __builtin_fmaf(wx, bn_relu_ss(nb0[pp].x, sc0, sh0), v[0])) * inv;
+                        v[1] = __builtin_fmaf(wy, bn_relu_ss(nb1[pp].y, sc1, sh1), __builtin_fmaf(wx, bn_relu_ss(nb0[pp].y, sc1, sh1), v[1])) * inv;
+                        v[2] = __builtin_fmaf(wy, bn_relu_ss(nb1[pp].z, sc2, sh2), __builtin_fmaf(wx, bn_relu_ss(nb0[pp].z, sc2, sh2), v[2])) * inv;
+                        v[3] = __builtin_fmaf(wy, bn_relu_ss(nb1[pp].w, sc3, sh3), __builtin_fmaf(wx, bn_relu_ss(nb0[pp].w, sc3, sh3), v[3])) * inv;
                     }
                     uint2 p0, p1;
                     split2x4(v, p0, p1);
@@ -1543,10 +1544,12 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
                                                         const float *gamma, const float *beta, const int *cand,
                                                         float *h_pooled, float *cand_feat, float *h_nodes)
 {
-    // one 256-thread block per instance: thread = (row group rg = tid/32 of 8, 4 columns); rows rg, rg+8, ... are
-    // streamed with 16-byte loads, the 8 partial sums are folded through LDS.
+    // a 256-thread block takes instances blockIdx.x, + gridDim.x, ... (the BatchNorm scale/shift of its 4 columns is computed once per
+    // block, not once per instance: 64 dependent loads that were a third of a block's life at T = 100); thread = (row group
+    // rg = tid/32 of 8, 4 columns); rows rg, rg+8, ... are streamed with 16-byte loads, eight in flight per thread, the 8 partial
+    // sums are folded through LDS.
     __shared__ float s_part[8][HD];
-    const int b = blockIdx.x, tid = threadIdx.x, rg = tid >> 5, c4 = (tid & 31) * 4;
+    const int tid = threadIdx.x, rg = tid >> 5, c4 = (tid & 31) * 4;
     float mean[4], rstd[4], g[4], be[4];
     for (int q = 0; q < 4; q++) {
         const int c = c4 + q;
@@ -1558,38 +1561,41 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
         if (var < 0) var = 0;
         mean[q] = (float)mean_d; rstd[q] = 1.0f / sqrtf((float)(var + BN_EPS)); g[q] = gamma[c]; be[q] = beta[c];
     }
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int v0 = rg; v0 < T; v0 += 32) {                                          // four rows in flight per thread (same summation order)
-        float4 x[4];
+    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int v0 = rg; v0 < T; v0 += 64) {                                      // eight rows in flight per thread (same summation order)
+            float4 x[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int v = v0 + 8 * u;
-            x[u] = v < T ? *reinterpret_cast<const float4 *>(z + ((size_t)b * T + v) * HD + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+            for (int u = 0; u < 8; u++) {
+                const int v = v0 + 8 * u;
+                x[u] = v < T ? *reinterpret_cast<const float4 *>(z + ((size_t)b * T + v) * HD + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int v = v0 + 8 * u;
-            if (v < T) {
-                float hv[4] = {bn_relu(x[u].x, mean[0], rstd[0], g[0], be[0]), bn_relu(x[u].y, mean[1], rstd[1], g[1], be[1]),
-                               bn_relu(x[u].z, mean[2], rstd[2], g[2], be[2]), bn_relu(x[u].w, mean[3], rstd[3], g[3], be[3])};
-                for (int q = 0; q < 4; q++) acc[q] += hv[q];
-                if (h_nodes) *reinterpret_cast<float4 *>(h_nodes + ((size_t)b * T + v) * HD + c4) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+            for (int u = 0; u < 8; u++) {
+                const int v = v0 + 8 * u;
+                if (v < T) {
+                    float hv[4] = {bn_relu(x[u].x, mean[0], rstd[0], g[0], be[0]), bn_relu(x[u].y, mean[1], rstd[1], g[1], be[1]),
+                                   bn_relu(x[u].z, mean[2], rstd[2], g[2], be[2]), bn_relu(x[u].w, mean[3], rstd[3], g[3], be[3])};
+                    for (int q = 0; q < 4; q++) acc[q] += hv[q];
+                    if (h_nodes) *reinterpret_cast<float4 *>(h_nodes + ((size_t)b * T + v) * HD + c4) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+                }
             }
         }
-    }
-    for (int q = 0; q < 4; q++) s_part[rg][c4 + q] = acc[q];
-    for (int jj = rg; jj < J; jj += 8) {                                           // candidate gather (ac:197-207); J = 0: skipped
-        const int v = cand[b * J + jj];
-        const float4 x = *reinterpret_cast<const float4 *>(z + ((size_t)b * T + v) * HD + c4);
-        *reinterpret_cast<float4 *>(cand_feat + ((size_t)b * J + jj) * HD + c4) =
-            make_float4(bn_relu(x.x, mean[0], rstd[0], g[0], be[0]), bn_relu(x.y, mean[1], rstd[1], g[1], be[1]),
-                        bn_relu(x.z, mean[2], rstd[2], g[2], be[2]), bn_relu(x.w, mean[3], rstd[3], g[3], be[3]));
-    }
-    __syncthreads();
-    if (tid < HD) {
-        float t = 0.f;
-        for (int r = 0; r < 8; r++) t += s_part[r][tid];
-        h_pooled[(size_t)b * HD + tid] = t * (1.0f / (float)T);                    // sparse mm with 1/T entries (gcn:192)
+        for (int q = 0; q < 4; q++) s_part[rg][c4 + q] = acc[q];
+        for (int jj = rg; jj < J; jj += 8) {                                       // candidate gather (ac:197-207); J = 0: skipped
+            const int v = cand[b * J + jj];
+            const float4 x = *reinterpret_cast<const float4 *>(z + ((size_t)b * T + v) * HD + c4);
+            *reinterpret_cast<float4 *>(cand_feat + ((size_t)b * J + jj) * HD + c4) =
+                make_float4(bn_relu(x.x, mean[0], rstd[0], g[0], be[0]), bn_relu(x.y, mean[1], rstd[1], g[1], be[1]),
+                            bn_relu(x.z, mean[2], rstd[2], g[2], be[2]), bn_relu(x.w, mean[3], rstd[3], g[3], be[3]));
+        }
+        __syncthreads();
+        if (tid < HD) {
+            float t = 0.f;
+            for (int r = 0; r < 8; r++) t += s_part[r][tid];
+            h_pooled[(size_t)b * HD + tid] = t * (1.0f / (float)T);                // sparse mm with 1/T entries (gcn:192)
+        }
+        __syncthreads();                                                           // s_part is reused by the next instance
     }
 }
 
@@ -2590,7 +2596,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     if (rrc) return rrc;
     if (h_pooled) {                                               // h_pooled == NULL: the consumer (k_heads) normalises, pools and gathers itself
         Timed t(e, "job_pool_gather");
-        hipLaunchKernelGGL(k_job_pool_gather, dim3(B), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
+        hipLaunchKernelGGL(k_job_pool_gather, dim3(B < e->num_cu * 8 ? B : e->num_cu * 8), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
                            W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, cand_feat, h_nodes);
     }
     HIPCHK(e, hipGetLastError());
@@ -2701,8 +2707,12 @@ static int gat3x_args(mtfjsp_encoder *e, const std::string &pre, const void *m_f
 // parts (16), m_fea1 produced by that launch itself, whole-batch statistics without a cross-shard reduction, split products.
 static bool gat_fusable(const mtfjsp_encoder *e)
 {
-    // (up to one workgroup per CU: measured 47.7 us against 24.6 + 26.8 at J6M6 x 4096; at J10M10 x 8192, two rounds of workgroups, 130 against 128)
-    return e->fuse_gat && !e->bn_mode && !e->reduce_fn && !(e->f32_products & (2 | 4)) && e->cfg.batch % HG == 0 && e->cfg.batch / HG <= e->num_cu &&
+    // Worth it when the heads' grid (B / 16 workgroups) is exactly as wide as the GAT launch would make its own — min(row tiles / 8,
+    // CUs) — and fits the chip in one round: J6M6 x 4096: 47.7 us against 24.6 + 26.8.  Fewer workgroups than the GAT's own grid leave
+    // CUs idle during the GAT part (J20M20 x 2048, 128 workgroups: 110 against 53 + 38), two rounds of workgroups gain nothing
+    // (J10M10 x 8192: 130 against 128).
+    const int hgrid = e->cfg.batch / HG, gtiles = (2 * e->cfg.batch * e->cfg.n_machine + 15) / 16, ggrid = (gtiles + 7) / 8 < e->num_cu ? (gtiles + 7) / 8 : e->num_cu;
+    return e->fuse_gat && !e->bn_mode && !e->reduce_fn && !(e->f32_products & (2 | 4)) && e->cfg.batch % HG == 0 && hgrid <= e->num_cu && hgrid >= ggrid &&
            e->w.count("machine_actor.gat_layer.W") && e->wx6.count("machine_actor.gat_layer.W");
 }
 static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, float *h_pooled, int *slot_out = nullptr)

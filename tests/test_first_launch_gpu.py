@@ -58,7 +58,7 @@ enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
 fused = sys.argv[1] == "fused"
 if not fused:
     os.environ["MTFJSP_NO_FUSED_GAT"] = "1"
-J, M, E, B = 6, 6, 2, 320
+J, M, E, B = 6, 6, 2, 4096
 w = enc_mod.random_init_weights(7)
 ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=w, collect=False, greedy=True)
 env, e = ro.env, ro.actor.enc
@@ -93,5 +93,6 @@ def test_first_forward_of_a_fresh_process_matches_the_reference(what, mode):
 
 @pytest.mark.parametrize("kind", ["fused", "unfused"])
 def test_first_rollout_decision_of_a_fresh_process_matches_the_oracle(kind):
+    """B = 4096: the shape at which the job heads and the GAT passes share a launch (heads grid == the GAT's own grid)"""
     for _ in range(2):
         assert _run(ROLLOUT_CHILD, kind) < 1e-4
