@@ -417,6 +417,12 @@ def main():
     ktimes = ro.timing_end()
     sync()
     ro.check_finished_cleanly()
+    enc_status = None
+    if ro.actor is not None:        # a fallback (time-out of the single-launch GIN kernel / f16 range) would be a silent performance cliff: say so
+        enc = ro.actor.enc
+        n_range, mode = enc.range_fallbacks()
+        enc_status = {"gin_single_launch_in_use": bool(enc.check()), "grid_barrier_timeouts": enc.resident_failures(),
+                      "range_fallbacks": n_range, "product_mode": mode, "rollout_restarts": ro.n_resident_failures}
 
     full_handoff = None
     if world > 1 and policy == "actor" and not args.no_full_handoff:
@@ -475,6 +481,7 @@ def main():
                         "allgather_bytes_per_rank": (gather or {}).get("bytes_per_rank"), "allgather_ms": (gather or {}).get("ms"),
                         "what": "local-critic GAE (4 reverse scans) + ONE packed all-gather of the 4 advantage tensors [4,S,B] f32 + global normalisation"},
             "kernel_times_ms": {k: v for k, v in ktimes.items()}, "kernel_times_steps": prof_steps,
+            "encoder_status": enc_status,
         }
         if full_handoff is not None:
             out["handoff_full"] = full_handoff
