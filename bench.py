@@ -130,13 +130,25 @@ def import_module_(name):
     return import_module(name)
 
 
-def full_handoff_leg(rollout_mod, J, M, E, B, device, rank, world):
+def full_handoff_leg(rollout_mod, J, M, E, B, device, rank, world, dist=None):
     """The reference's whole rollout -> update hand-off once, outside the timed region (N > 1): a Rollout with the complete
     device trajectory buffer and a (random-init) global critic runs one buffer; its finish_buffer samples the global critic on
-    every stored state, runs the 8 GAE scans and exchanges 16 tensors x [S, B] f32 in ONE all-gather."""
+    every stored state, runs the 8 GAE scans and exchanges 16 tensors x [S, B] f32 in ONE all-gather.  The ranks first
+    agree that every one of them could set the leg up (a rank that could not would leave the others waiting in the collective)."""
     enc_mod = import_module_("e2e-mappo-for-mt-fjsp_amd.encoder")
-    ro = rollout_mod.Rollout(J, M, E, B, device=device, policy="actor", obs_dtype="f32", instance_seed=0, rank=rank, world=world,
-                             collect="full", weights=enc_mod.random_init_weights(1234, with_critic=True), time_handoff=True)
+    ro, err = None, None
+    try:
+        ro = rollout_mod.Rollout(J, M, E, B, device=device, policy="actor", obs_dtype="f32", instance_seed=0, rank=rank, world=world,
+                                 collect="full", weights=enc_mod.random_init_weights(1234, with_critic=True), time_handoff=True)
+    except Exception as ex:
+        err = repr(ex)
+    if dist is not None:
+        ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else "cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 0.5:
+            return {"error": err or "another rank could not set the leg up"}
+    elif err:
+        return {"error": err}
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     while ro.n_handoffs == 0:
@@ -431,7 +443,7 @@ def main():
         except AttributeError:
             pass
         try:
-            full_handoff = full_handoff_leg(rollout_mod, J, M, E, B, local_rank, rank, world)
+            full_handoff = full_handoff_leg(rollout_mod, J, M, E, B, local_rank, rank, world, dist)
         except Exception as ex:                                     # never lose the headline line over the extra leg
             full_handoff = {"error": repr(ex)}
     if rank == 0:
