@@ -72,6 +72,8 @@ struct EnvParams {
     mtfjsp_obs_t obs;
     unsigned long long *stamps;        // diagnostic build only
     float *rec_r4, *rec_done;          // optional f32 trajectory record of this step ([4,B], [B])
+    const short *pw_tab;               // leaves and merges of numpy's pairwise sum over T elements (pw_table; T > 128 only)
+    int pw_nleaf;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -130,6 +132,39 @@ __device__ __forceinline__ long trunc_l(double x) { return (long)x; }   // numpy
 __device__ __forceinline__ double wave_max(double x)
 {
     for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o));
+    return x;
+}
+// the same reductions on the cross-lane data path (DPP: no LDS round trip per step): after four row shifts lane 15 of every row
+// of 16 holds its row's result, row_bcast:15 / :31 carry it on; the wave's result is in LANE 63 only.  Lanes without a source
+// keep their own value (max / min are idempotent).
+#define DPP_I(x, ctrl) __builtin_amdgcn_update_dpp((x), (x), (ctrl), 0xF, 0xF, false)
+__device__ __forceinline__ double wave_max_lane63(double x)
+{
+#define STEP_(ctrl)                                                                                       \
+    {                                                                                                    \
+        const int lo = DPP_I(__double2loint(x), ctrl), hi = DPP_I(__double2hiint(x), ctrl);              \
+        x = fmax(x, __hiloint2double(hi, lo));                                                           \
+    }
+    STEP_(0x111) STEP_(0x112) STEP_(0x114) STEP_(0x118) STEP_(0x142) STEP_(0x143)
+#undef STEP_
+    return x;
+}
+__device__ __forceinline__ int wave_min_lane63(int x)
+{
+#define STEP_(ctrl) { const int y = DPP_I(x, ctrl); x = y < x ? y : x; }
+    STEP_(0x111) STEP_(0x112) STEP_(0x114) STEP_(0x118) STEP_(0x142) STEP_(0x143)
+#undef STEP_
+    return x;
+}
+// inclusive prefix sum over the wave's lanes (zero fill; row_bcast adds the previous rows' totals)
+__device__ __forceinline__ int wave_scan_incl(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);      // rows 1, 3 += lane 15 of the row before
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);      // rows 2, 3 += lane 31
     return x;
 }
 
@@ -957,33 +992,55 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
 // of the step per wave, then — after one barrier — the per-instance scalar part (energy / idle sums, rewards, RewardScaling,
 // machine feature row, job mask) once for the whole group on wave 0 with lane = (instance, reward channel)
 // (env_grp_tail, mtfjsp_env_grp.h).  Same operations in the same order: bit-identical to k_env_step.
-struct EnvStepLds {                            // layout of one instance's LDS region (bytes from its start)
-    int T, Tp, M, J;
-    size_t o_stage, o_int, o_un, o_in, bytes;
-    __host__ __device__ EnvStepLds(int J_, int M_, int T_, bool f32) : T(T_), Tp((T_ + 7) & ~7), M(M_), J(J_)
+#define ENV_LDS_GMAX 8                         // instances (= waves) per workgroup of k_env_step_grp at most
+struct EnvStepLds {                            // layout of one instance's LDS region
+    int T, Tp, M, J, nleaf;
+    // f64 part, offsets in doubles: start | finish | processing energy per task, idle terms in rank order, column m of the transport
+    // times, the acting job's min durations / estimated starts / finishes, per-job maxima, scalars, the acting machine's feature
+    // row, leaf sums of the pairwise energy sum.  (Round 3: 18.0 KB per J20M20 instance instead of 26.7 — durations and the other
+    // transport columns are read from memory by the few lanes that need one, route links are 16-bit — so that 8 instances fit a CU
+    // and 2048 of them run in ONE round of workgroups: 2 x 29 us of dependent chain -> 1 x.)
+    int d_ft, d_pte, d_term, d_ttc, d_mind, d_jste, d_jfte, d_jmax, d_jrow, d_sc, d_mfr, d_leaf, d_end;
+    size_t o_stage, o_link, o_int, o_un, o_in, bytes;          // bytes from the region's start
+    __host__ __device__ EnvStepLds(int J_, int M_, int T_, bool f32, int nleaf_) : T(T_), Tp((T_ + 7) & ~7), M(M_), J(J_), nleaf(nleaf_)
     {
-        size_t off = (size_t)(4 * T + Tp + M * M + 3 * M + 2 * J + SCAL_N + 8) * sizeof(double);
+        d_ft = T; d_pte = 2 * T; d_term = 3 * T; d_ttc = d_term + Tp; d_mind = d_ttc + M; d_jste = d_mind + M; d_jfte = d_jste + M;
+        d_jmax = d_jfte + M; d_jrow = d_jmax + J; d_sc = d_jrow + J; d_mfr = d_sc + SCAL_N; d_leaf = d_mfr + 8; d_end = d_leaf + nleaf;
+        size_t off = (size_t)d_end * sizeof(double);
         off = (off + 15) & ~(size_t)15;
         o_stage = off; off += (size_t)M * 12 * (f32 ? 4 : 8);
         off = (off + 15) & ~(size_t)15;
-        o_int = off; off += (size_t)(3 * T + J + 4 * M + 1 + 4) * sizeof(int);
+        o_link = off; off += (size_t)3 * T * sizeof(short);     // machine | route predecessor | rank per task
+        off = (off + 15) & ~(size_t)15;
+        o_int = off; off += (size_t)(J + 4 * M + 1 + 4) * sizeof(int);
         off = (off + 15) & ~(size_t)15;
         o_un = off; off += 16 * sizeof(double);
         o_in = off; off += 8 * sizeof(int);
         bytes = (off + 15) & ~(size_t)15;
     }
 };
+// numpy's pairwise recursion (n > 128: halves, the left one rounded down to a multiple of 8) as a table the step kernel walks:
+// [2l], [2l+1] = offset, length of leaf l (in order); then nleaf - 1 merges (i, j): leaf-sum slot i += slot j, in post-order, so
+// that the total ends in slot 0.  Depends on T only; built once per handle.
+static int pw_table(int off, int n, int depth, std::vector<short> &leaves, std::vector<short> &merges)
+{
+    if (n <= 128 || depth == 0) { const int idx = (int)leaves.size() / 2; leaves.push_back((short)off); leaves.push_back((short)n); return idx; }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const int l = pw_table(off, n2, depth - 1, leaves, merges), r = pw_table(off + n2, n - n2, depth - 1, leaves, merges);
+    merges.push_back((short)l); merges.push_back((short)r);
+    return l;
+}
 struct EnvGrpLdsAcc {
     static constexpr bool kBigT = true;
     const unsigned char *base; EnvStepLds L;
     __device__ __forceinline__ const double *d(int g, int off) const { return reinterpret_cast<const double *>(base + (size_t)g * L.bytes) + off; }
-    __device__ __forceinline__ const double *pte(int g) const { return d(g, 3 * L.T); }
-    __device__ __forceinline__ const double *sorted(int g) const { return d(g, 4 * L.T); }
-    __device__ __forceinline__ const double *jmx(int g) const { return d(g, 4 * L.T + L.Tp + L.M * L.M + 3 * L.M); }
-    __device__ __forceinline__ const double *jrw(int g) const { return jmx(g) + L.J; }
-    __device__ __forceinline__ const double *scl(int g) const { return jrw(g) + L.J; }
-    __device__ __forceinline__ const double *mf(int g) const { return scl(g) + SCAL_N; }
-    __device__ __forceinline__ const int *cn(int g) const { return reinterpret_cast<const int *>(base + (size_t)g * L.bytes + L.o_int) + 3 * L.T; }
+    __device__ __forceinline__ const double *sorted(int g) const { return d(g, L.d_term); }
+    __device__ __forceinline__ const double *jmx(int g) const { return d(g, L.d_jmax); }
+    __device__ __forceinline__ const double *jrw(int g) const { return d(g, L.d_jrow); }
+    __device__ __forceinline__ const double *scl(int g) const { return d(g, L.d_sc); }
+    __device__ __forceinline__ const double *mf(int g) const { return d(g, L.d_mfr); }
+    __device__ __forceinline__ const int *cn(int g) const { return reinterpret_cast<const int *>(base + (size_t)g * L.bytes + L.o_int); }
     __device__ __forceinline__ const double *un(int g) const { return reinterpret_cast<const double *>(base + (size_t)g * L.bytes + L.o_un); }
     __device__ __forceinline__ const int *in(int g) const { return reinterpret_cast<const int *>(base + (size_t)g * L.bytes + L.o_in); }
 };
@@ -993,29 +1050,25 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
     const int J = P.J, M = P.M, T = P.T;
     const unsigned invM = P.inv_M;
 #define DIVM(x) ((int)__umulhi((unsigned)(x), invM))
-    const int Tp = (T + 7) & ~7;
+    const int Tp = LL.Tp;
     double *s_st = reinterpret_cast<double *>(smem);
-    double *s_ft = s_st + T;
-    double *s_dur = s_ft + T;
-    double *s_pte = s_dur + T;
-    double *s_term = s_pte + T;                // Tp
-    double *s_tt = s_term + Tp;                // M*M
-    double *s_mind = s_tt + M * M;             // M: min_dur of the acting job's ops
-    double *s_jste = s_mind + M;               // M: estimated start of the acting job's ops
-    double *s_jfte = s_jste + M;               // M
-    double *s_jmax = s_jfte + M;               // J: max estimated finish per job
-    double *s_jrow = s_jmax + J;               // J: max real finish of scheduled ops per job
-    double *s_sc = s_jrow + J;                 // SCAL_N
-    double *s_mfr = s_sc + SCAL_N;             // 8: m_fea2 row of machine m
-    size_t off = (size_t)((4 * T + Tp + M * M + 3 * M + 2 * J + SCAL_N + 8) * sizeof(double));
-    off = (off + 15) & ~(size_t)15;
-    OBS *s_stage = reinterpret_cast<OBS *>(smem + off);        // M rows x 12
-    off += (size_t)M * 12 * sizeof(OBS);
-    off = (off + 15) & ~(size_t)15;
-    int *s_mach = reinterpret_cast<int *>(smem + off);
-    int *s_prev = s_mach + T;
-    int *s_pos = s_prev + T;
-    int *s_cnt = s_pos + T;                    // J
+    double *s_ft = s_st + LL.d_ft;
+    double *s_pte = s_st + LL.d_pte;
+    double *s_term = s_st + LL.d_term;         // Tp
+    double *s_ttc = s_st + LL.d_ttc;           // M: transport times INTO the acting machine (column m of tt)
+    double *s_mind = s_st + LL.d_mind;         // M: min_dur of the acting job's ops
+    double *s_jste = s_st + LL.d_jste;         // M: estimated start of the acting job's ops
+    double *s_jfte = s_st + LL.d_jfte;         // M
+    double *s_jmax = s_st + LL.d_jmax;         // J: max estimated finish per job
+    double *s_jrow = s_st + LL.d_jrow;         // J: max real finish of scheduled ops per job
+    double *s_sc = s_st + LL.d_sc;             // SCAL_N
+    double *s_mfr = s_st + LL.d_mfr;           // 8: m_fea2 row of machine m
+    double *s_leaf = s_st + LL.d_leaf;         // leaf sums of the pairwise energy sum (T > 128)
+    OBS *s_stage = reinterpret_cast<OBS *>(smem + LL.o_stage);        // M rows x 12
+    short *s_mach = reinterpret_cast<short *>(smem + LL.o_link);
+    short *s_prev = s_mach + T;
+    short *s_pos = s_prev + T;
+    int *s_cnt = reinterpret_cast<int *>(smem + LL.o_int);            // J
     int *s_head = s_cnt + J;                   // M
     int *s_tail = s_head + M;
     int *s_len = s_tail + M;
@@ -1024,28 +1077,53 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
     int *s_in = reinterpret_cast<int *>(smem + LL.o_in);
 
     const size_t bT = (size_t)b * T;
-    // ---- bulk state first (independent of the action), the action-dependent second hop right behind it
-    for (int v = lane; v < T; v += WAVE) {
-        s_st[v] = P.st[bT + v]; s_ft[v] = P.ft[bT + v]; s_dur[v] = P.dur[bT + v]; s_pte[v] = P.pte[bT + v];
-        const Link l = P.link[bT + v];
-        s_mach[v] = l.mach; s_prev[v] = l.prev; s_pos[v] = l.pos;
+#ifdef MTFJSP_STAMP
+#define ESW_RT(i) do { if (P.stamps && lane == 0) { __builtin_amdgcn_sched_barrier(0); P.stamps[(size_t)b * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define ESW_RT(i) do { } while (0)
+#endif
+    ESW_RT(0);
+    // ---- the action first; then the bulk state with every request of up to 8 task slots per lane in flight before the first
+    // LDS write (a plain loop pays one memory round trip per 64 tasks); the action-dependent requests go out behind the bulk
+    // requests and before any of them is waited for (loads return in order: the action's two words are there first)
+    const int lastm = P.lastm[b];
+    int a = P.task_idx[b], m = P.mach_idx[b];
+    const double *ttb = P.tt + (size_t)b * M * M;
+    bool valid = false;
+    int ja = 0, op = 0;
+    double d = 0.0, pk = 0.0, x_mind = 0.0, x_ttc = 0.0, x_mfr = 0.0;
+    for (int v0 = 0; v0 < T; v0 += 8 * WAVE) {
+        double x_st[8], x_ft[8], x_pte[8]; Link x_l[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int v = v0 + k * WAVE + lane;
+            if (v < T) { x_st[k] = P.st[bT + v]; x_ft[k] = P.ft[bT + v]; x_pte[k] = P.pte[bT + v]; x_l[k] = P.link[bT + v]; }
+        }
+        if (v0 == 0) {
+            valid = a >= 0 && a < T && m >= 0 && m < M;
+            if (!valid) { a = 0; m = 0; }
+            ja = DIVM(a); op = a - ja * M;
+            d = P.t[(bT + a) * M + m];
+            pk = P.p[(bT + a) * M + m];
+            if (lane < M) { x_mind = P.cst[bT + ja * M + lane].x; x_ttc = ttb[lane * M + m]; }
+            if (lane < 8) x_mfr = P.mfea[((size_t)b * M + m) * 8 + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int v = v0 + k * WAVE + lane;
+            if (v < T) { s_st[v] = x_st[k]; s_ft[v] = x_ft[k]; s_pte[v] = x_pte[k]; s_mach[v] = x_l[k].mach; s_prev[v] = x_l[k].prev; s_pos[v] = x_l[k].pos; }
+        }
     }
     for (int i = lane; i < Tp; i += WAVE) s_term[i] = 0.0;
-    for (int i = lane; i < M * M; i += WAVE) s_tt[i] = P.tt[(size_t)b * M * M + i];
     for (int i = lane; i < M; i += WAVE) { const MRec r = P.mrec[(size_t)b * M + i]; s_head[i] = r.head; s_tail[i] = r.tail; s_len[i] = r.len; }
     for (int i = lane; i < J; i += WAVE) { s_cnt[i] = (int)P.jcnt[(size_t)b * J + i]; s_jmax[i] = P.jmax[(size_t)b * J + i]; s_jrow[i] = P.jrow[(size_t)b * J + i]; }
     if (lane < SCAL_N) s_sc[lane] = P.scal[(size_t)b * SCAL_N + lane];
-    const int lastm = P.lastm[b];
-    int a = P.task_idx[b], m = P.mach_idx[b];
-    bool valid = a >= 0 && a < T && m >= 0 && m < M;
-    if (!valid) { a = 0; m = 0; }
-    const int ja = DIVM(a), op = a - ja * M;
-    const double d = P.t[(bT + a) * M + m];
-    const double pk = P.p[(bT + a) * M + m];
-    for (int i = lane; i < M; i += WAVE) s_mind[i] = P.cst[bT + ja * M + i].x;
-    if (lane < 8) s_mfr[lane] = P.mfea[((size_t)b * M + m) * 8 + lane];
+    if (lane < M) { s_mind[lane] = x_mind; s_ttc[lane] = x_ttc; }
+    for (int i = WAVE + lane; i < M; i += WAVE) { s_mind[i] = P.cst[bT + ja * M + i].x; s_ttc[i] = ttb[i * M + m]; }
+    if (lane < 8) s_mfr[lane] = x_mfr;
     WSYNC();
 
+    ESW_RT(1);
     // =========================================================================================
     // A. scheduling (env:1476-1685)
     int status = 0, path = 0;
@@ -1057,8 +1135,8 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
     }
     if (valid) {
         if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;               // pe:246-248
-        const double ttmm = s_tt[m * M + m];
-        const double arr_k = op == 0 ? 0.0 : s_ft[a - 1] + s_tt[s_mach[a - 1] * M + m];      // dg:46-66 over the single in-edge
+        const double ttmm = s_ttc[m];
+        const double arr_k = op == 0 ? 0.0 : s_ft[a - 1] + s_ttc[s_mach[a - 1]];      // dg:46-66 over the single in-edge
         const int len = s_len[m], head = s_head[m], tail = s_tail[m];
         bool do_append = false;
         if (len == 0) { path = MTFJSP_PATH_EMPTY; st_k = arr_k; ipos = 0; }                      // env:1684
@@ -1066,7 +1144,7 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
         else {
             const double lb_ft = arr_k + d;
             const int jh = DIVM(head);
-            const double arr_f = (head == jh * M) ? 0.0 : s_ft[head - 1] + s_tt[s_mach[head - 1] * M + m];
+            const double arr_f = (head == jh * M) ? 0.0 : s_ft[head - 1] + s_ttc[s_mach[head - 1]];
             if (lb_ft <= arr_f) { path = MTFJSP_PATH_FRONT; st_k = arr_k; ipos = 0; Nk = head; }   // env:1548
             else if (len == 1) do_append = true;                                                     // env:1577
             else {
@@ -1075,14 +1153,14 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
                     if (s_mach[v] == m && s_prev[v] >= 0) {
                         const int Pp = s_prev[v];
                         const int jv = DIVM(v);
-                        const double jarr = (v == jv * M) ? 0.0 : s_ft[v - 1] + s_tt[s_mach[v - 1] * M + m];
+                        const double jarr = (v == jv * M) ? 0.0 : s_ft[v - 1] + s_ttc[s_mach[v - 1]];
                         const double x = (DIVM(Pp) == jv) ? ttmm : 0.0;
                         const double nst = fmax(jarr, s_ft[Pp] + x);
                         const bool ok = !(lb_ft > nst) && !((nst - s_ft[Pp]) < d);
-                        if (ok) { const int kk = (s_pos[v] << 16) | v; key = kk < key ? kk : key; }
+                        if (ok) { const int kk = ((int)s_pos[v] << 16) | v; key = kk < key ? kk : key; }
                     }
                 }
-                for (int o = 32; o > 0; o >>= 1) { const int other = __shfl_xor(key, o); key = other < key ? other : key; }
+                key = rl_i(wave_min_lane63(key), 63);
                 if (key != 0x7fffffff) {
                     path = MTFJSP_PATH_BETWEEN;
                     Nk = key & 0xffff; ipos = key >> 16; Pk = s_prev[Nk];
@@ -1100,13 +1178,23 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
         ft_k = st_k + d;
         WSYNC();
         if (ipos < len)
-            for (int v = lane; v < T; v += WAVE)
-                if (s_mach[v] == m && s_pos[v] >= ipos) s_pos[v] += 1;
+            for (int v0 = 0; v0 < T; v0 += 8 * WAVE) {
+                short mc[8], ps[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const int v = v0 + k * WAVE + lane;
+                    mc[k] = -1; ps[k] = -1;
+                    if (v < T) { mc[k] = s_mach[v]; ps[k] = s_pos[v]; }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (mc[k] == m && ps[k] >= ipos) s_pos[v0 + k * WAVE + lane] = (short)(ps[k] + 1);
+            }
         WSYNC();
         if (lane == 0) {
-            s_mach[a] = m; s_prev[a] = Pk; s_pos[a] = ipos;
-            s_st[a] = st_k; s_ft[a] = ft_k; s_dur[a] = d; s_pte[a] = d * pk;      // env:356,2175
-            if (Nk >= 0) s_prev[Nk] = a;
+            s_mach[a] = (short)m; s_prev[a] = (short)Pk; s_pos[a] = (short)ipos;
+            s_st[a] = st_k; s_ft[a] = ft_k; s_pte[a] = d * pk;                    // env:356,2175
+            if (Nk >= 0) s_prev[Nk] = (short)a;
             if (ipos == 0) s_head[m] = a;
             if (ipos == len) s_tail[m] = a;
             s_len[m] = len + 1;
@@ -1121,48 +1209,86 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
         return;
     }
 
+    ESW_RT(2);
+    // the <= 4 in-edge (ELL) rows that change (written in part C): a, its job successor, its new route successor, the node whose
+    // merged edge reverts.  Durations and transport times of their predecessors are requested from memory HERE (the step's own
+    // duration is not there yet; column m of the transport times is in LDS) and used after the cost part
+    const int merged_now = (Pk >= 0 && op != 0 && Pk == a - 1) ? a : -1;
+    int ev = -1;
+    if (lane == 0) ev = a;
+    else if (lane == 1) ev = (op + 1 < M) ? a + 1 : -1;
+    else if (lane == 2) ev = Nk;
+    else if (lane == 3) ev = lastm;
+    int e_mv = -1, e_pr = -1, e_mu = -1, e_opv = 0, e_jv = 0;
+    double e_nd = 1.0, e_dp = 0.0, e_tt1 = 0.0, e_tt2 = 0.0, e_gap1 = 0.0, e_gap2 = 0.0;
+    if (ev >= 0) {
+        auto durg = [&](int x) __attribute__((always_inline)) { return x == a ? d : P.dur[bT + x]; };
+        auto ttg = [&](int r, int c) __attribute__((always_inline)) { return c == m ? s_ttc[r] : ttb[r * M + c]; };
+        e_mv = s_mach[ev];
+        e_jv = DIVM(ev); e_opv = ev - e_jv * M;
+        e_pr = s_prev[ev];
+        if (e_opv != 0) {
+            e_mu = s_mach[ev - 1];
+            if (e_mu >= 0) { e_nd = durg(ev - 1); if (e_mv >= 0) e_tt1 = ttg(e_mu, e_mv); e_gap1 = s_st[ev] - s_ft[ev - 1]; }
+        }
+        if (e_pr >= 0) { e_dp = durg(e_pr); if (DIVM(e_pr) == e_jv) e_tt2 = ttg(s_mach[e_pr], e_mv); e_gap2 = s_st[ev] - s_ft[e_pr]; }
+    }
     // =========================================================================================
     // B. costs
     {   // machine route offsets: exclusive scan of the route lengths
-        int x = lane < M ? s_len[lane] : 0, incl = x;
-        for (int o = 1; o < WAVE; o <<= 1) { const int y = __shfl_up(incl, o); if (lane >= o) incl += y; }
+        const int x = lane < M ? s_len[lane] : 0, incl = wave_scan_incl(x);
         if (lane < M) s_mstart[lane] = incl - x;
         if (lane == M - 1) s_mstart[M] = incl;
     }
-    // estimated start/finish of the acting job's ops (env:1920-1999): lanes = ops of job ja; every lane replays the
-    // reference's left-to-right add sequence from the last op with a non-zero real finish time
+    // estimated start/finish of the acting job's ops (env:1920-1999): lanes = ops of job ja.  The reference restarts a
+    // left-to-right add sequence behind the last op with a non-zero real finish time; every lane's sequence is a prefix of one
+    // chain: chain(c) = (op c-1 has a real finish ? that finish : chain(c-1)) + min_dur(c), chain(-1) = 0 — walked ONCE with
+    // uniform lane reads instead of a dependent LDS loop per lane (4.0 -> 0.5 us of this kernel at M = 20)
     double my_fte = -INFINITY, my_rft = 0.0;
-    if (lane < M) {
-        const int c = lane, v = ja * M + c;
-        const bool s = s_mach[v] >= 0;
-        double ste, fte;
-        if (s && s_ft[v] != 0.0) { ste = s_st[v]; fte = s_ft[v]; }
-        else {
-            int k0 = c;
-            while (k0 > 0 && !(s_mach[ja * M + k0 - 1] >= 0 && s_ft[ja * M + k0 - 1] != 0.0)) k0--;
-            double acc = k0 > 0 ? s_ft[ja * M + k0 - 1] : 0.0, prev = acc;
-            for (int k = k0; k <= c; k++) { prev = acc; acc = acc + s_mind[k]; }
-            fte = acc;
-            ste = s ? s_st[v] : (c == 0 ? 0.0 : prev);
+    {
+        const int c = lane, v = ja * M + (lane < M ? lane : 0);
+        const bool s = lane < M && s_mach[v] >= 0;
+        const double ftv = s_ft[v], stv = s_st[v], mdv = lane < M ? s_mind[lane] : 0.0;
+        const bool q = s && ftv != 0.0;
+        const unsigned long long qm = __ballot(q);
+        double acc = 0.0, fte_c = 0.0, base_c = 0.0;
+        const int kfirst = __builtin_ctzll(~qm);                   // the ops before the first one without a real finish use their real times: the chain starts there
+        for (int k = kfirst; k < M; k++) {
+            const bool pq = k > 0 && ((qm >> (k - 1)) & 1ull);
+            const double base = pq ? rl_d(ftv, k > 0 ? k - 1 : 0) : acc;
+            acc = base + rl_d(mdv, k);
+            if (lane == k) { fte_c = acc; base_c = base; }
         }
-        s_jste[c] = ste; s_jfte[c] = fte;
-        my_fte = fte;
-        my_rft = s ? s_ft[v] : 0.0;
+        if (lane < M) {
+            const double ste = q ? stv : s ? stv : (c == 0 ? 0.0 : base_c);
+            const double fte = q ? ftv : fte_c;
+            s_jste[c] = ste; s_jfte[c] = fte;
+            my_fte = fte;
+            my_rft = s ? ftv : 0.0;
+        }
     }
     {   // per-job maxima of the acting job (row maximum of ft_est for the makespan; of real ft for the job mask, ppo:265-275)
-        double fm = my_fte, rm = lane < M ? my_rft : -INFINITY;
-        for (int o = 32; o > 0; o >>= 1) { fm = fmax(fm, __shfl_xor(fm, o)); rm = fmax(rm, __shfl_xor(rm, o)); }
-        if (lane == 0) { s_jmax[ja] = fm; s_jrow[ja] = rm; }
+        const double fm = wave_max_lane63(my_fte), rm = wave_max_lane63(lane < M ? my_rft : -INFINITY);
+        if (lane == 63) { s_jmax[ja] = fm; s_jrow[ja] = rm; }
     }
     WSYNC();
-    for (int v = lane; v < T; v += WAVE)                                       // idle-time terms in (machine, position) order (dg:144-170)
-        if (s_mach[v] >= 0) {
-            const int pr = s_prev[v];
-            s_term[s_mstart[s_mach[v]] + s_pos[v]] = pr < 0 ? s_st[v] : s_st[v] - s_ft[pr];
+    ESW_RT(3);
+    for (int v0 = 0; v0 < T; v0 += 8 * WAVE) {                                 // idle-time terms in (machine, position) order (dg:144-170); the reads of 8 slots per level together
+        int mc[8], pr[8], ps[8]; double sv[8], fp[8]; int ms[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int v = v0 + k * WAVE + lane;
+            mc[k] = -1; pr[k] = -1; ps[k] = 0; sv[k] = 0.0;
+            if (v < T) { mc[k] = s_mach[v]; pr[k] = s_prev[v]; ps[k] = s_pos[v]; sv[k] = s_st[v]; }
         }
-    WSYNC();
-    {   // what the scalar part needs beyond the arrays: env:896 np.sum's pairwise part (one leaf block: T <= 128) and the uniforms
-        if (T <= 128) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) { ms[k] = s_mstart[mc[k] >= 0 ? mc[k] : 0]; fp[k] = s_ft[pr[k] >= 0 ? pr[k] : 0]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (mc[k] >= 0) s_term[ms[k] + ps[k]] = pr[k] < 0 ? sv[k] : sv[k] - fp[k];
+    }
+    {   // what the scalar part needs beyond the arrays: env:896 np.sum's pairwise part and the uniforms
+        if (T <= 128) {                                                          // one leaf block: its 8 accumulators on 8 lanes; the ragged tail goes to the scalar part
             const int nb = T < 8 ? 0 : T - (T & 7);
             double r = 0.0;
             if (nb) {
@@ -1171,14 +1297,45 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
             }
             if (lane == 0) s_un[U_R0] = r;
             if (lane < T - nb) s_un[U_TAIL + lane] = s_pte[nb + lane];
+        } else {
+            // numpy's recursion over the table of its leaves (pw_table): 8 lanes per leaf = its 8 accumulators, 8 leaves per
+            // round; every lane's <= 16 reads go out together, the adds follow in numpy's order; ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7))
+            // by three exchanges (the pairs commute), the leaf's ragged tail left to right on its first lane; then the merges
+            const short *tab = P.pw_tab;
+            const int nleaf = LL.nleaf;
+            for (int l0 = 0; l0 < nleaf; l0 += 8) {
+                const int lf = l0 + (lane >> 3), k = lane & 7;
+                const bool on = lf < nleaf;
+                const int off = on ? tab[2 * lf] : 0, n = on ? tab[2 * lf + 1] : 8;
+                const int nb = n - (n & 7);
+                const double *src = s_pte + off + k;
+                double x[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) x[i] = 8 * i < nb ? src[8 * i] : 0.0;
+                double r = x[0];
+#pragma unroll
+                for (int i = 1; i < 16; i++) if (8 * i < nb) r += x[i];
+                r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
+                if (on && k == 0) {
+                    for (int i = nb; i < n; i++) r += s_pte[off + i];
+                    s_leaf[lf] = r;
+                }
+            }
+            WSYNC();
+            if (lane == 0) {
+                const short *mg = tab + 2 * nleaf;
+                for (int q = 0; q < nleaf - 1; q++) { const int i = mg[2 * q], j = mg[2 * q + 1]; s_leaf[i] = s_leaf[i] + s_leaf[j]; }
+                s_un[U_R0] = s_leaf[0];
+            }
         }
         if (lane == 0) {
-            s_un[U_NEWTR] = (op == 0) ? 0.0 : s_tt[s_mach[a - 1] * M + m];      // env:872-876
+            s_un[U_NEWTR] = (op == 0) ? 0.0 : s_ttc[s_mach[a - 1]];             // env:872-876
             s_un[U_D] = d; s_un[U_PK] = pk; s_un[U_FTTAIL] = s_ft[s_tail[m]];  // env:2315-2340
             s_in[I_VALID] = 1; s_in[I_STATUS] = status; s_in[I_NSCHED] = s_mstart[M]; s_in[I_M] = m; s_in[I_JA] = ja;
         }
     }
 
+    ESW_RT(4);
     // =========================================================================================
     // C. the observation rows that changed
     {   // feature rows a .. end of job (env:2245-2277)
@@ -1204,63 +1361,67 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
         uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + a) * 12);
         for (int i = lane; i < n16; i += WAVE) dst[i] = src[i];
     }
-    {   // in-edge (ELL) rows: a, its job successor, its new route successor, the node whose merged edge reverts
-        const int merged_now = (Pk >= 0 && op != 0 && Pk == a - 1) ? a : -1;
-        int v = -1;
-        if (lane == 0) v = a;
-        else if (lane == 1) v = (op + 1 < M) ? a + 1 : -1;
-        else if (lane == 2) v = Nk;
-        else if (lane == 3) v = lastm;
-        if (v >= 0) {
-            const int mv = s_mach[v];
-            const bool s = mv >= 0;
-            const int jv = DIVM(v), opv = v - jv * M;
-            const int pr = s_prev[v];
-            const bool merged = pr >= 0 && opv != 0 && pr == v - 1;
-            int c_job = -1, c_mch = -1;
-            float a_job = 0.f, a_mch = 0.f;
-            if (opv != 0) {
-                const int u = v - 1, mu = s_mach[u];
-                double w, nd;
-                if (mu < 0) { w = 1.0; nd = 1.0; }
-                else {
-                    nd = s_dur[u];
-                    if (merged && v == merged_now) w = s_dur[u] + s_tt[mu * M + mv] + (s_st[v] - s_ft[u]);     // env:1607-1675,1703-1765
-                    else w = s_dur[u] + (s ? s_tt[mu * M + mv] : 0.0);                                          // env:1384-1422
-                }
-                long A = trunc_l(w);
-                if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }                   // env:2019, 2060-2062
+    if (ev >= 0) {   // the in-edge (ELL) rows from the values requested after the scheduling part
+        const int v = ev, mv = e_mv, pr = e_pr, opv = e_opv;
+        const bool s = mv >= 0;
+        const bool merged = pr >= 0 && opv != 0 && pr == v - 1;
+        int c_job = -1, c_mch = -1;
+        float a_job = 0.f, a_mch = 0.f;
+        if (opv != 0) {
+            const int u = v - 1;
+            double w_, nd;
+            if (e_mu < 0) { w_ = 1.0; nd = 1.0; }
+            else {
+                nd = e_nd;
+                if (merged && v == merged_now) w_ = nd + e_tt1 + e_gap1;                         // env:1607-1675,1703-1765
+                else w_ = nd + (s ? e_tt1 : 0.0);                                                // env:1384-1422
             }
-            if (pr >= 0 && !merged) {
-                const double x = (DIVM(pr) == jv) ? s_tt[s_mach[pr] * M + mv] : 0.0;
-                const double w = s_dur[pr] + x + (s_st[v] - s_ft[pr]);
-                long A = trunc_l(w);
-                if (A != 0) { A = trunc_l((double)A - s_dur[pr]) + 1; c_mch = pr; a_mch = (float)A; }
-            }
-            reinterpret_cast<int2 *>(P.obs.ell_col)[bT + v] = make_int2(c_job, c_mch);
-            reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(a_job, a_mch);
-            if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + v) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
+            long A = trunc_l(w_);
+            if (A != 0) { A = trunc_l((double)A - nd) + 1; c_job = u; a_job = (float)A; }       // env:2019, 2060-2062
         }
-        if (lane == 6) P.lastm[b] = merged_now;
+        if (pr >= 0 && !merged) {
+            const double w_ = e_dp + e_tt2 + e_gap2;
+            long A = trunc_l(w_);
+            if (A != 0) { A = trunc_l((double)A - e_dp) + 1; c_mch = pr; a_mch = (float)A; }
+        }
+        reinterpret_cast<int2 *>(P.obs.ell_col)[bT + v] = make_int2(c_job, c_mch);
+        reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(a_job, a_mch);
+        if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + v) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
     }
+    if (lane == 6) P.lastm[b] = merged_now;
 
+    ESW_RT(5);
     // ---- candidate of the acting job (ppo:202-316; the mask is the scalar part's)
     if (lane == 0) P.obs.candidate[(size_t)b * J + ja] = ja * M + (s_cnt[ja] < M ? s_cnt[ja] : M - 1);
-    // ---- write back the state that changed
-    for (int v = lane; v < T; v += WAVE) {
-        Link l; l.mach = (short)s_mach[v]; l.prev = (short)s_prev[v]; l.pos = (short)s_pos[v]; l.pad = 0;
-        P.link[bT + v] = l;
+    // ---- write back the state that changed: the links of machine m's route from the insertion point on (the acting task, its new
+    // successor with a new predecessor, the ranks that moved up)
+    for (int v0 = 0; v0 < T; v0 += 8 * WAVE) {
+        short mc[8], pr[8], ps[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int v = v0 + k * WAVE + lane;
+            mc[k] = -1; pr[k] = -1; ps[k] = -1;
+            if (v < T) { mc[k] = s_mach[v]; pr[k] = s_prev[v]; ps[k] = s_pos[v]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (mc[k] == m && ps[k] >= ipos) {
+                Link l; l.mach = mc[k]; l.prev = pr[k]; l.pos = ps[k]; l.pad = 0;
+                P.link[bT + v0 + k * WAVE + lane] = l;
+            }
     }
     if (lane == 0) { P.st[bT + a] = st_k; P.ft[bT + a] = ft_k; P.dur[bT + a] = d; P.psel[bT + a] = pk; P.pte[bT + a] = d * pk; }
     if (lane == 1) { P.jcnt[(size_t)b * J + ja] = (short)s_cnt[ja]; P.jmax[(size_t)b * J + ja] = s_jmax[ja]; P.jrow[(size_t)b * J + ja] = s_jrow[ja]; }
     if (lane == 2) { MRec r; r.head = (short)s_head[m]; r.tail = (short)s_tail[m]; r.len = (short)s_len[m]; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+    ESW_RT(6);
+#undef ESW_RT
 #undef DIVM
 }
 template <typename OBS>
-__global__ __launch_bounds__(1024) void k_env_step_grp(EnvParams P, int G)
+__global__ __launch_bounds__(ENV_LDS_GMAX * WAVE) void k_env_step_grp(EnvParams P, int G)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const EnvStepLds LL(P.J, P.M, P.T, sizeof(OBS) == 4);
+    const EnvStepLds LL(P.J, P.M, P.T, sizeof(OBS) == 4, P.pw_nleaf);
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b0 = blockIdx.x * G;
     const int lane = threadIdx.x & 63;
@@ -1269,6 +1430,9 @@ __global__ __launch_bounds__(1024) void k_env_step_grp(EnvParams P, int G)
     if (grp == 0) {
         const EnvGrpLdsAcc acc{smem, LL};
         env_grp_tail<OBS>(P, b0, lane, G, acc);
+#ifdef MTFJSP_STAMP
+        if (P.stamps && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P.stamps[(size_t)b0 * 8 + 7] = __builtin_amdgcn_s_memrealtime(); }
+#endif
     } else if (grp == 1) {
         const EnvGrpLdsAcc acc{smem, LL};
         env_grp_mask(P, b0, lane, G, acc);
@@ -1563,6 +1727,8 @@ struct mtfjsp_env {
     int *lastm = nullptr;
     int *d_task = nullptr, *d_mach = nullptr;
     double *d_w3 = nullptr;
+    short *pw_tab = nullptr;           // pw_table(T) on the device
+    int pw_nleaf = 1;
     double *dense_scratch = nullptr;   // [B,T,T] f64, allocated on the first mtfjsp_export_dense_adj_host
     mtfjsp_obs_t obs{};
     bool obs_bound = false;
@@ -1628,6 +1794,15 @@ extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
     rc |= dalloc(h, &h->d_task, B); rc |= dalloc(h, &h->d_mach, B); rc |= dalloc(h, &h->d_w3, B * 3);
     if (rc) { g_create_err = h->err; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
     if (hipMemset(h->scal, 0, B * SCAL_N * sizeof(double)) != hipSuccess) { g_create_err = "memset failed"; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
+    {   // the pairwise-sum table of T elements (walked by k_env_step_grp when T > 128)
+        std::vector<short> leaves, merges;
+        pw_table(0, (int)T, 6, leaves, merges);
+        h->pw_nleaf = (int)leaves.size() / 2;
+        leaves.insert(leaves.end(), merges.begin(), merges.end());
+        if (dalloc(h, &h->pw_tab, leaves.size()) || hipMemcpy(h->pw_tab, leaves.data(), leaves.size() * sizeof(short), hipMemcpyHostToDevice) != hipSuccess) {
+            g_create_err = "pairwise table upload failed"; mtfjsp_destroy(h); return MTFJSP_ERR_HIP;
+        }
+    }
     // opt in to large dynamic LDS (every kernel that is launched with a dynamic allocation sized from T)
     const void *dyn_kernels[] = {(const void *)k_env_step<double>, (const void *)k_env_step<float>,
                                  (const void *)k_env_reset<double>, (const void *)k_env_reset<float>};
@@ -1808,6 +1983,7 @@ static EnvParams make_params(mtfjsp_env *h)
     P.st = h->st; P.ft = h->ft; P.dur = h->dur; P.psel = h->psel; P.link = h->link; P.mrec = h->mrec; P.jcnt = h->jcnt; P.pte = h->pte; P.jmax = h->jmax; P.jrow = h->jrow; P.lastm = h->lastm; P.mfea = h->mfea; P.scal = h->scal;
     P.inv_M = (unsigned)((0x100000000ull + (unsigned long long)P.M - 1) / (unsigned long long)P.M);
     P.obs = h->obs;
+    P.pw_tab = h->pw_tab; P.pw_nleaf = h->pw_nleaf;
     return P;
 }
 
@@ -1909,10 +2085,10 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
     } else {
         // LDS kernel: groups of G instances per workgroup where at least two instances' regions fit (MTFJSP_ENV_STEP_G overrides;
         // 1 = the one-instance kernel k_env_step)
-        const EnvStepLds LL(P.J, P.M, P.T, P.obs_f32 != 0);
+        const EnvStepLds LL(P.J, P.M, P.T, P.obs_f32 != 0, P.pw_nleaf);
         const int gmax = h->grp_lds_ok ? (int)((h->lds_max - 512) / LL.bytes) : 1;
-        int G = gmax >= 4 ? 4 : gmax >= 2 ? 2 : 1;
-        if (const char *gs = getenv("MTFJSP_ENV_STEP_G")) { G = atoi(gs); G = G < 1 ? 1 : G > 16 ? 16 : G; G = G > gmax ? (gmax < 1 ? 1 : gmax) : G; }
+        int G = gmax >= 8 ? 8 : gmax >= 4 ? 4 : gmax >= 2 ? 2 : 1;
+        if (const char *gs = getenv("MTFJSP_ENV_STEP_G")) { G = atoi(gs); G = G < 1 ? 1 : G > ENV_LDS_GMAX ? ENV_LDS_GMAX : G; G = G > gmax ? (gmax < 1 ? 1 : gmax) : G; }
         if (force && !strcmp(force, "lds1")) G = 1;
         if (G > 1) {
             const size_t lds_g = (size_t)G * LL.bytes;
@@ -1934,7 +2110,15 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
         (void)hipMemcpy(hst.data(), d_st, (size_t)P.B * 64, hipMemcpyDeviceToHost);
         double m[8] = {0};
         for (int w = 0; w < P.B; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[(size_t)w * 8 + i] / P.B;
-        if (hst[1] > 1000000000ull) {                                       // grouped kernel: s_memrealtime stamps (100 MHz) of wave 0 per workgroup
+        if (P.T > 128) {                                                    // grouped LDS kernel: s_memrealtime stamps (100 MHz) per instance; slot 7 by the group's first
+            unsigned long long t0 = ~0ull; double r[8] = {0}; int n7 = 0;
+            for (int w = 0; w < P.B; w++) t0 = hst[(size_t)w * 8] < t0 ? hst[(size_t)w * 8] : t0;
+            for (int w = 0; w < P.B; w++) for (int i = 0; i < 8; i++) { if (i == 7 && hst[(size_t)w * 8 + 7] < t0) continue; r[i] += (double)(hst[(size_t)w * 8 + i] - t0) / 100.0; if (i == 7) n7++; }
+            for (int i = 0; i < 7; i++) r[i] /= P.B;
+            r[7] /= n7 ? n7 : 1;
+            printf("STAMP k_env_step_grp B=%d (us since the first wave's start): entry %.2f  loads in LDS %.2f  scheduled %.2f  estimates %.2f  terms+energy sum %.2f  observation+ELL %.2f  wave done %.2f  tail drained %.2f\n",
+                   P.B, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+        } else if (hst[1] > 1000000000ull) {                                // grouped kernel: s_memrealtime stamps (100 MHz) of wave 0 per workgroup
             const int ng = (P.B + 15) / 16; double r[8] = {0};
             unsigned long long t0 = ~0ull;
             for (int w = 0; w < ng; w++) t0 = hst[(size_t)w * 8] < t0 ? hst[(size_t)w * 8] : t0;

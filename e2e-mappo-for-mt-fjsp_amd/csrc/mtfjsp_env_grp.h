@@ -311,7 +311,6 @@ struct EnvGrpRegAcc {
     __device__ __forceinline__ const double *mf(int g) const { return s_mf[g]; }
     __device__ __forceinline__ const double *un(int g) const { return s_un[g]; }
     __device__ __forceinline__ const int *in(int g) const { return s_in[g]; }
-    __device__ __forceinline__ const double *pte(int) const { return nullptr; }
 };
 // the per-instance scalar part for the instances of the group: lane = (instance g = lane >> 2, reward channel ch = lane & 3)
 template <typename OBS, typename ACC>
@@ -346,9 +345,8 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
     }
     double e1 = A.un(g)[U_R0];                                                  // env:896 np.sum: pairwise part, then the ragged tail in order
     bool big = false;
-    if constexpr (ACC::kBigT) big = T > 128;
-    if (big) { if constexpr (ACC::kBigT) e1 = pw_sum<6>(A.pte(g), T); }     // (more than one leaf block: numpy's recursion, on the instance's LDS array)
-    else {
+    if constexpr (ACC::kBigT) big = T > 128;                                    // (more than one leaf block: the instance's wave walked numpy's recursion, U_R0 is the total)
+    if (!big) {
         const int nt = T < 8 ? T : (T & 7);
         double x[7];
 #pragma unroll
@@ -357,13 +355,24 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
         for (int i = 0; i < 7; i++) if (i < nt) e1 += x[i];
     }
     e1 = 0.0 + e1;
-    double idle = 0.0;                                                          // dg:144-170, strictly left to right (slots >= nsched hold +0.0)
-    for (int i0 = 0; i0 < T; i0 += 8) {
+    // dg:144-170, strictly left to right.  Slots >= nsched hold +0.0 and the running sum starts at +0.0, so it is never -0.0 and
+    // adding them changes nothing: the loop stops at nsched; the next chunk's reads are in flight under the 8 dependent adds
+    double idle = 0.0;
+    {
+        const double *so = A.sorted(g);
         double x[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = A.sorted(g)[i0 + k];
+        for (int k = 0; k < 8; k++) x[k] = so[k];
+        for (int i0 = 0; i0 < nsched; i0 += 8) {
+            double y[8];
+            const bool more = i0 + 8 < nsched;
 #pragma unroll
-        for (int k = 0; k < 8; k++) idle = idle + x[k];
+            for (int k = 0; k < 8; k++) y[k] = more ? so[i0 + 8 + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) idle = idle + x[k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = y[k];
+        }
     }
     const double new_tr = A.un(g)[U_NEWTR], d = A.un(g)[U_D], pk = A.un(g)[U_PK];
     const double trans_this = sc[S_TR_THIS] + new_tr;

@@ -142,6 +142,13 @@ def test_j10m10e2_every_step_kernel_vs_oracle(kernel, monkeypatch):
     _run(10, 10, 2, 1001, 1, seed=5)
 
 
+def test_grouped_lds_kernel_ragged_pairwise_leaves():
+    """T > 128: the LDS kernel walks numpy's pairwise recursion leaf by leaf (pw_table).  T = 130 (leaves 64 | 66, a ragged tail
+    of 2), T = 165 (80 | 85: tail of 5), T = 300 (72 | 72 | 72 | 84: two levels, tail of 4); every instance against the oracle"""
+    for J, M, E, B in ((13, 10, 2, 70), (15, 11, 1, 50), (20, 15, 3, 37)):
+        _run(J, M, E, B, 1, seed=8)
+
+
 def test_two_slot_register_kernel_other_shapes(monkeypatch):
     """T = 72 (J12M6), T = 128 (J16M8) and T = 121 (J11M11, M*M = 121 transport entries, M > 8 route prefix)"""
     for J, M, E, B in ((12, 6, 2, 130), (16, 8, 2, 67), (11, 11, 1, 35)):
