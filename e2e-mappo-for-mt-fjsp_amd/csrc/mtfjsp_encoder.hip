@@ -60,6 +60,10 @@ struct GemmArgs {
     unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
     int dbg;                // diagnostic build only: timing ablations of k_gemm16p (1 no stores/sums, 2 no row requests/transform)
     unsigned *range_flag;             // host-mapped word: raised when the BatchNorm sums this launch consumes are not numbers (an f16 operand piece overflowed upstream; ReLU would hide the NaN)
+    // k_gemm_x6, matrices beyond the 256 MB memory-side cache (tools/ubench/mall_order.hip): a workgroup walks its tile range
+    // from the END when `rev` is set — the launches of a chain alternate, so that each starts on what its predecessor wrote
+    // last — and reads `in` with non-temporal loads (read once: it must not displace the matrix being written)
+    int rev, nt;
 };
 
 #ifdef MTFJSP_STAMP
@@ -550,6 +554,9 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     const int first = blockIdx.x * per;
     const int last = first + per < ntiles ? first + per : ntiles;
     const int nsteps = last > first ? (last - first + 3) >> 2 : 0;
+    // logical tile t of [first, last) (the order of the steps) -> the tile of the matrix it stands for
+    const int rev_sum = A.rev ? first + last - 1 : 0;
+    auto PT = [&](int t) __attribute__((always_inline)) { return A.rev ? rev_sum - t : t; };
     constexpr int KS = (PRO == PRO_GIN0) ? 1 : 4;                 // k-steps of 32: the 12 -> 128 first Linear is one (k >= 12 are zero)
 #ifdef MTFJSP_STAMP
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last, rt0, rt1;
@@ -596,11 +603,20 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         int e_ox = 0, e_oy = 0, en_ox = 0, en_oy = 0;
         float e_vx = 0.f, e_vy = 0.f, en_vx = 0.f, en_vy = 0.f, e_dg = 1.f, en_dg = 1.f;
         auto request_rows = [&](float4 (&pre)[8], int tile) __attribute__((always_inline)) {
-            const float *tb = A.in + (size_t)tile * 16 * HD;
+            const float *tb = A.in + (size_t)PT(tile) * 16 * HD;
+            if (A.nt) {
 #pragma unroll
-            for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
+                for (int p = 0; p < 8; p++) {
+                    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tb + p * 2 * HD + lane_off));
+                    pre[p] = make_float4(v[0], v[1], v[2], v[3]);
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
+            }
         };
-        auto fetch_ell = [&](int tile) __attribute__((always_inline)) {
+        auto fetch_ell = [&](int ltile) __attribute__((always_inline)) {
+            const int tile = PT(ltile);
             const int g = tile * 16 + m;
             int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
             if (g < A.N) { cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
@@ -611,7 +627,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         };
         auto request_nb = [&](int tile) __attribute__((always_inline)) {   // neighbour rows of `tile`, whose ELL entries are in en_*
             e_ox = en_ox; e_oy = en_oy; e_vx = en_vx; e_vy = en_vy; e_dg = en_dg;
-            const float *tb = A.in + (size_t)tile * 16 * HD;
+            const float *tb = A.in + (size_t)PT(tile) * 16 * HD;
 #pragma unroll
             for (int p = 0; p < 8; p++) {
                 const int ox = __shfl(e_ox, 2 * p + h), oy = __shfl(e_oy, 2 * p + h);
@@ -633,12 +649,12 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                 else { const float *p = reinterpret_cast<const float *>(A.tfea) + row * 12 + k0; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
             };
             auto req_ell = [&](Ell &e, int tile) __attribute__((always_inline)) {
-                const int g = tile * 16 + r;
+                const int g = (tile < last ? PT(tile) : 0) * 16 + r;
                 e.cc = make_int2(-1, -1); e.vv = make_float2(0.f, 0.f);
                 if (tile < last && g < A.N) { e.cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); e.vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
             };
             auto req_feat = [&](Stage &x, const Ell &e, int tile) __attribute__((always_inline)) {
-                const int g = tile * 16 + r;
+                const int g = (tile < last ? PT(tile) : 0) * 16 + r;
                 x.cc = e.cc; x.vv = e.vv;
 #pragma unroll
                 for (int i = 0; i < 3; i++) { x.fo[i] = 0.f; x.fx[i] = 0.f; x.fy[i] = 0.f; }
@@ -821,7 +837,8 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                     }
 #pragma unroll
                     for (int c = 0; c < 2; c++) acc[c] = acc[c] * wsinv + biasv[c];
-                    const int row = (tb + t) * 16 + m;
+                    const int ptile = FULL || tb + t < last ? PT(tb + t) : 0;
+                    const int row = ptile * 16 + m;
                     const bool ok = FULL || row < A.N;
                     // stores as WHOLE 128-byte lines: the accumulator layout gives a lane two 16-byte chunks (q and 4 + q) of row m's 128
                     // bytes of this wave, i.e. 16 rows x 64 bytes per store instruction — measured 2.35 TB/s against 3.24 TB/s for 8
@@ -839,11 +856,11 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                     for (int i = 0; i < 2; i++) {
                         const int r8 = 8 * i + (lane >> 3);
                         const float4 v = *reinterpret_cast<const float4 *>(trb + r8 * 144 + 16 * (lane & 7));
-                        *reinterpret_cast<float4 *>(A.out + ((size_t)(tb + t) * 16 + r8) * HD + 32 * cg + 4 * (lane & 7)) = v;
+                        *reinterpret_cast<float4 *>(A.out + ((size_t)ptile * 16 + r8) * HD + 32 * cg + 4 * (lane & 7)) = v;
                     }
                 }
             };
-            if (tb + 4 <= last && (tb + 4) * 16 <= A.N) tiles4(std::true_type{});
+            if (tb + 4 <= last && ((A.rev ? PT(tb) : tb + 3) + 1) * 16 <= A.N) tiles4(std::true_type{});
             else tiles4(std::false_type{});
             STAMP(5);
             // column sums: 16 rows (lanes m) -> one value per column, f64 from there on; every 4th step (f32 partial sums of
@@ -1540,7 +1557,7 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
 // ---------------------------------------------------------------------------------------------
 // After the last GIN BatchNorm: h = relu(bn(z)); graph mean pool (gcn:192) and candidate gather (ac:197-207).
 // One 128-thread block per instance, thread = column.
-__global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, int B, int T, int J, const float *z, const double *stats, double inv_rows,
+__global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, int nt, int B, int T, int J, const float *z, const double *stats, double inv_rows,
                                                         const float *gamma, const float *beta, const int *cand,
                                                         float *h_pooled, float *cand_feat, float *h_nodes)
 {
@@ -1568,7 +1585,12 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
 #pragma unroll
             for (int u = 0; u < 8; u++) {
                 const int v = v0 + 8 * u;
-                x[u] = v < T ? *reinterpret_cast<const float4 *>(z + ((size_t)b * T + v) * HD + c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v < T) {
+                    const f32x4 *src = reinterpret_cast<const f32x4 *>(z + ((size_t)b * T + v) * HD + c4);
+                    const f32x4 t = nt ? __builtin_nontemporal_load(src) : *src;       // (GemmArgs::nt)
+                    x[u] = make_float4(t[0], t[1], t[2], t[3]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 8; u++) {
@@ -2008,6 +2030,8 @@ struct mtfjsp_encoder {
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
     struct { bool valid = false; const void *f1 = nullptr, *f2 = nullptr; int slot = 0; } prefused;   // the GAT passes of the coming machine forward already ran inside the job actor's heads launch (k_headsx_gat3x)
     bool fuse_gat = !getenv("MTFJSP_NO_FUSED_GAT");
+    int stream_order = getenv("MTFJSP_NO_STREAM_ORDER") ? 0 : 1;   // streaming GIN launches: alternating row direction + non-temporal input reads (A/B switch)
+    int stream_nt = getenv("MTFJSP_STREAM_NT") ? atoi(getenv("MTFJSP_STREAM_NT")) : 1;   // which readers use non-temporal loads: 1 BatchNorm+ReLU products, 2 aggregation product, 4 pool / gather
     mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
     struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
                          const int32_t *gather_from = nullptr; int32_t *gathered = nullptr; } fs[2];   // [0] job actor, [1] machine actor
@@ -2560,6 +2584,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         GemmArgs a = gemm_args(nullptr, N, nullptr, W(P + "mlps.0.linears.0.bias"), e->zA);
         a.tfea = tasks_fea; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64; a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
         a.epi_stats = st + 0 * STAT_REP * 256;
+        a.rev = e->stream_order;
         a.Wx6 = e->wx6.at(P + "mlps.0.linears.0.weight"); a.w_sinv = 1.0f;
         launch_gemm<PRO_GIN0, EPI_STATS>(e, a, "gin0_agg_linear12");
         if ((rrc = reduce_stats(e, st + 0 * STAT_REP * 256))) return rrc;
@@ -2572,31 +2597,37 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
             hipLaunchKernelGGL((k_gin0<double>), dim3(pgrid), dim3(256), 0, e->stream, N, T, (const double *)tasks_fea, ell_col, ell_val,
                                W(P + "mlps.0.linears.0.weight"), W(P + "mlps.0.linears.0.bias"), e->zA, st + 0 * STAT_REP * 256);
     }
-    auto bn_gemm = [&](const float *in, float *out, int sin, const std::string &bn, const std::string &lin, int sout) {
+    // the launches alternate the direction in which a workgroup walks its rows (GemmArgs::rev): each starts on the part of its
+    // input that is still in the memory-side cache.  The aggregation product walks FORWARD (a row's job predecessor is the row
+    // before it: read a moment ago and still in L2; backward it was measured 251 against 234 us), which fixes the others
+    const int so = e->stream_order;
+    auto bn_gemm = [&](const float *in, float *out, int sin, const std::string &bn, const std::string &lin, int sout, int rev) {
         GemmArgs a = gemm_args(in, N, WT(P + lin + ".weight"), W(P + lin + ".bias"), out);
+        a.rev = so ? rev : 0; a.nt = so && (e->stream_nt & 1);
         a.pro_stats = st + sin * STAT_REP * 256; a.pro_gamma = W(P + bn + ".weight"); a.pro_beta = W(P + bn + ".bias"); a.pro_inv_rows = invN;
         a.epi_stats = st + sout * STAT_REP * 256;
         a.Wx6 = e->wx6.at(P + lin + ".weight"); a.w_sinv = e->wx6_sinv.at(P + lin + ".weight");
         launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_bn_relu");
         if (!rrc) rrc = reduce_stats(e, st + sout * STAT_REP * 256);
     };
-    bn_gemm(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1);
-    bn_gemm(e->zB, e->zA, 1, "mlps.0.batch_norms.1", "mlps.0.linears.2", 2);
+    bn_gemm(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1, 0);
+    bn_gemm(e->zB, e->zA, 1, "mlps.0.batch_norms.1", "mlps.0.linears.2", 2, 1);
     {   // layer 1 / linear 0: aggregation of h = relu(bn_outer0(z)) over the ELL adjacency
         GemmArgs a = gemm_args(e->zA, N, WT(P + "mlps.1.linears.0.weight"), W(P + "mlps.1.linears.0.bias"), e->zB);
         a.pro_stats = st + 2 * STAT_REP * 256; a.pro_gamma = W(P + "batch_norms.0.weight"); a.pro_beta = W(P + "batch_norms.0.bias"); a.pro_inv_rows = invN;
         a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
+        a.rev = 0; a.nt = so && (e->stream_nt & 2);
         a.epi_stats = st + 3 * STAT_REP * 256;
         a.Wx6 = e->wx6.at(P + "mlps.1.linears.0.weight"); a.w_sinv = e->wx6_sinv.at(P + "mlps.1.linears.0.weight");
         launch_gemm<PRO_AGG, EPI_STATS>(e, a, "gin_gemm_agg");
         if (!rrc) rrc = reduce_stats(e, st + 3 * STAT_REP * 256);
     }
-    bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4);
-    bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5);
+    bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4, 1);
+    bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5, 0);
     if (rrc) return rrc;
     if (h_pooled) {                                               // h_pooled == NULL: the consumer (k_heads) normalises, pools and gathers itself
         Timed t(e, "job_pool_gather");
-        hipLaunchKernelGGL(k_job_pool_gather, dim3(B < e->num_cu * 8 ? B : e->num_cu * 8), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
+        hipLaunchKernelGGL(k_job_pool_gather, dim3(B < e->num_cu * 8 ? B : e->num_cu * 8), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, (so && (e->stream_nt & 4)) ? 1 : 0, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
                            W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, cand_feat, h_nodes);
     }
     HIPCHK(e, hipGetLastError());
