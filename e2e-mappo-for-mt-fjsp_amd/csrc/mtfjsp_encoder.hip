@@ -599,9 +599,13 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         const int lane_off = h * HD + c4;
         float4 preA[8], preB[8];
         constexpr int NA = (PRO == PRO_AGG) ? 8 : 1;
-        float4 nb0[NA], nb1[NA];
-        int e_ox = 0, e_oy = 0, en_ox = 0, en_oy = 0;
-        float e_vx = 0.f, e_vy = 0.f, en_vx = 0.f, en_vy = 0.f, e_dg = 1.f, en_dg = 1.f;
+        // PRO_AGG: neighbour rows TWO steps ahead like the tile's own rows (two register stages), the ELL entries they depend on
+        // three (ring of 4).  (Round 2 requested the neighbour rows of step s+1 behind the transform of step s: with the consumers
+        // waiting for the producers — 258 k of 466 k cycles at their barrier — that round trip was exposed in every step.)
+        struct NbRows { float4 r0[NA], r1[NA]; } nbA, nbB;
+        struct EllSlot { int ox, oy; float vx, vy, dg; } el[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { el[i].ox = 0; el[i].oy = 0; el[i].vx = 0.f; el[i].vy = 0.f; el[i].dg = 1.f; }
         auto request_rows = [&](float4 (&pre)[8], int tile) __attribute__((always_inline)) {
             const float *tb = A.in + (size_t)PT(tile) * 16 * HD;
             if (A.nt) {
@@ -615,24 +619,23 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                 for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
             }
         };
-        auto fetch_ell = [&](int ltile) __attribute__((always_inline)) {
+        auto fetch_ell = [&](EllSlot &E, int ltile) __attribute__((always_inline)) {
             const int tile = PT(ltile);
             const int g = tile * 16 + m;
             int2 cc = make_int2(-1, -1); float2 vv = make_float2(0.f, 0.f);
             if (g < A.N) { cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
             const int base = (g / A.T) * A.T - tile * 16;         // instance's first row relative to the tile
-            en_ox = cc.x >= 0 ? base + cc.x : m; en_vx = cc.x >= 0 ? vv.x : 0.f;
-            en_oy = cc.y >= 0 ? base + cc.y : m; en_vy = cc.y >= 0 ? vv.y : 0.f;
-            en_dg = (float)(1 + (cc.x >= 0) + (cc.y >= 0));
+            E.ox = cc.x >= 0 ? base + cc.x : m; E.vx = cc.x >= 0 ? vv.x : 0.f;
+            E.oy = cc.y >= 0 ? base + cc.y : m; E.vy = cc.y >= 0 ? vv.y : 0.f;
+            E.dg = (float)(1 + (cc.x >= 0) + (cc.y >= 0));
         };
-        auto request_nb = [&](int tile) __attribute__((always_inline)) {   // neighbour rows of `tile`, whose ELL entries are in en_*
-            e_ox = en_ox; e_oy = en_oy; e_vx = en_vx; e_vy = en_vy; e_dg = en_dg;
+        auto request_nb = [&](NbRows &nb, const EllSlot &E, int tile) __attribute__((always_inline)) {   // neighbour rows of `tile`, whose ELL entries are in E
             const float *tb = A.in + (size_t)PT(tile) * 16 * HD;
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                const int ox = __shfl(e_ox, 2 * p + h), oy = __shfl(e_oy, 2 * p + h);
-                nb0[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)ox * HD + c4);
-                nb1[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)oy * HD + c4);
+                const int ox = __shfl(E.ox, 2 * p + h), oy = __shfl(E.oy, 2 * p + h);
+                nb.r0[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)ox * HD + c4);
+                nb.r1[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)oy * HD + c4);
             }
         };
         const int t0 = first + pw;
@@ -709,16 +712,23 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             }
             LDS_BARRIER();                                        // the consumers' last step
         } else {
+        if (PRO == PRO_AGG) {
+            if (t0 < last) fetch_ell(el[0], t0);
+            if (t0 + 4 < last) fetch_ell(el[1], t0 + 4);
+            if (t0 + 8 < last) fetch_ell(el[2], t0 + 8);
+        }
         if (t0 < last) request_rows(preA, t0);
-        if (PRO == PRO_AGG && t0 < last) { fetch_ell(t0); request_nb(t0); }
+        if (PRO == PRO_AGG && t0 < last) request_nb(nbA, el[0], t0);
         if (t0 + 4 < last) request_rows(preB, t0 + 4);
-        if (PRO == PRO_AGG && t0 + 4 < last) fetch_ell(t0 + 4);
+        if (PRO == PRO_AGG && t0 + 4 < last) request_nb(nbB, el[1], t0 + 4);
         stage_scale_shift();
         LDS_BARRIER();
         STAMP(0);
         const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
         const float sh0 = s_bn[HD + c4], sh1 = s_bn[HD + c4 + 1], sh2 = s_bn[HD + c4 + 2], sh3 = s_bn[HD + c4 + 3];
-        auto produce = [&](float4 (&pre)[8], int s) __attribute__((always_inline)) {
+        auto produce = [&](float4 (&pre)[8], NbRows &nb, auto Kc, int s) __attribute__((always_inline)) {
+            constexpr int K = decltype(Kc)::value;                // s & 3: the step's ELL slot
+            const EllSlot &E = el[K];
             const int tile = t0 + 4 * s;
             if (tile < last) {
                 unsigned char *dst = s_tiles + ((s & 1) * 4 + pw) * XT + h * X6_ROWB + j * 8;
@@ -731,13 +741,13 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                         // producer twelve double-rate instructions per row quad; k_gemm16p, the f32-instruction A/B path, keeps it)
                         const int pp = p < NA ? p : 0;
                         const int r = 2 * p + h;
-                        const float wx = __shfl(e_vx, r), wy = __shfl(e_vy, r);
-                        const float dg = __shfl(e_dg, r);
+                        const float wx = __shfl(E.vx, r), wy = __shfl(E.vy, r);
+                        const float dg = __shfl(E.dg, r);
                         const float inv = dg == 1.f ? 1.0f : dg == 2.f ? 0.5f : (1.0f / 3.0f);
-                        v[0] = __builtin_fmaf(wy, bn_relu_ss(nb1[pp].x, sc0, sh0), __builtin_fmaf(wx, bn_relu_ss(nb0[pp].x, sc0, sh0), v[0])) * inv;
-                        v[1] = __builtin_fmaf(wy, bn_relu_ss(nb1[pp].y, sc1, sh1), __builtin_fmaf(wx, bn_relu_ss(nb0[pp].y, sc1, sh1), v[1])) * inv;
-                        v[2] = __builtin_fmaf(wy, bn_relu_ss(nb1[pp].z, sc2, sh2), __builtin_fmaf(wx, bn_relu_ss(nb0[pp].z, sc2, sh2), v[2])) * inv;
-                        v[3] = __builtin_fmaf(wy, bn_relu_ss(nb1[pp].w, sc3, sh3), __builtin_fmaf(wx, bn_relu_ss(nb0[pp].w, sc3, sh3), v[3])) * inv;
+                        v[0] = __builtin_fmaf(wy, bn_relu_ss(nb.r1[pp].x, sc0, sh0), __builtin_fmaf(wx, bn_relu_ss(nb.r0[pp].x, sc0, sh0), v[0])) * inv;
+                        v[1] = __builtin_fmaf(wy, bn_relu_ss(nb.r1[pp].y, sc1, sh1), __builtin_fmaf(wx, bn_relu_ss(nb.r0[pp].y, sc1, sh1), v[1])) * inv;
+                        v[2] = __builtin_fmaf(wy, bn_relu_ss(nb.r1[pp].z, sc2, sh2), __builtin_fmaf(wx, bn_relu_ss(nb.r0[pp].z, sc2, sh2), v[2])) * inv;
+                        v[3] = __builtin_fmaf(wy, bn_relu_ss(nb.r1[pp].w, sc3, sh3), __builtin_fmaf(wx, bn_relu_ss(nb.r0[pp].w, sc3, sh3), v[3])) * inv;
                     }
                     uint2 p0, p1;
                     split2x4(v, p0, p1);
@@ -745,18 +755,20 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                     *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + X6_PLANE) = p1;
                 }
             }
-            // requests, oldest-needed first (vmcnt retires in order): neighbour rows of step s+1, ELL entries of step s+2, then
-            // the rows of step s+2 into the registers this tile just left
-            if (PRO == PRO_AGG && tile + 4 < last) request_nb(tile + 4);
-            if (PRO == PRO_AGG && tile + 8 < last) fetch_ell(tile + 8);
+            // requests (vmcnt retires in order): the ELL entries of step s+3 first — step s+1 turns them into addresses and must not
+            // wait for the rows behind them —, then the rows and neighbour rows of step s+2 into the registers this tile just left
+            if (PRO == PRO_AGG && tile + 12 < last) fetch_ell(el[(K + 3) & 3], tile + 12);
             if (tile + 8 < last) request_rows(pre, tile + 8);
+            if (PRO == PRO_AGG && tile + 8 < last) request_nb(nb, el[(K + 2) & 3], tile + 8);
             STAMP(1);
             LDS_BARRIER();
             STAMP(4);
         };
-        for (int s = 0; s < nsteps; s += 2) {
-            produce(preA, s);
-            if (s + 1 < nsteps) produce(preB, s + 1);
+        for (int s = 0; s < nsteps; s += 4) {
+            produce(preA, nbA, std::integral_constant<int, 0>{}, s);
+            if (s + 1 < nsteps) produce(preB, nbB, std::integral_constant<int, 1>{}, s + 1);
+            if (s + 2 < nsteps) produce(preA, nbA, std::integral_constant<int, 2>{}, s + 2);
+            if (s + 3 < nsteps) produce(preB, nbB, std::integral_constant<int, 3>{}, s + 3);
         }
         LDS_BARRIER();                                            // the consumers' last step
         }
@@ -1557,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
 // ---------------------------------------------------------------------------------------------
 // After the last GIN BatchNorm: h = relu(bn(z)); graph mean pool (gcn:192) and candidate gather (ac:197-207).
 // One 128-thread block per instance, thread = column.
-__global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, int nt, int B, int T, int J, const float *z, const double *stats, double inv_rows,
+__global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, int nt, int rpr, int S, int B, int T, int J, const float *z, const double *stats, double inv_rows,
                                                         const float *gamma, const float *beta, const int *cand,
                                                         float *h_pooled, float *cand_feat, float *h_nodes)
 {
@@ -1578,7 +1590,18 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
         if (var < 0) var = 0;
         mean[q] = (float)mean_d; rstd[q] = 1.0f / sqrtf((float)(var + BN_EPS)); g[q] = gamma[c]; be[q] = beta[c];
     }
-    for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    // instance order: rpr == 0: blockIdx.x, + gridDim.x, ...; else (matrix beyond the memory-side cache) the instances of the row
+    // range [g rpr, (g+1) rpr) that ONE workgroup of the last product wrote front to back are taken from the back — what is still
+    // cached first — by the S blocks (g, s), s = blockIdx.x / ranges
+    int i_hi = 0, n_g = 0, l = 0, lstep = 1;
+    if (rpr) {
+        const int nranges = gridDim.x / S, g = blockIdx.x % nranges, sub = blockIdx.x / nranges;
+        const long long r0 = (long long)g * rpr, r1 = r0 + rpr;
+        const int i_lo = (int)((r0 + T - 1) / T);
+        i_hi = (int)((r1 + T - 1) / T); if (i_hi > B) i_hi = B;
+        n_g = i_hi - i_lo; l = sub; lstep = S;
+    }
+    for (int b = rpr ? i_hi - 1 - l : blockIdx.x; rpr ? l < n_g : b < B; rpr ? (l += lstep, b = i_hi - 1 - l) : (b += gridDim.x)) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int v0 = rg; v0 < T; v0 += 64) {                                      // eight rows in flight per thread (same summation order)
             float4 x[8];
@@ -2031,7 +2054,8 @@ struct mtfjsp_encoder {
     struct { bool valid = false; const void *f1 = nullptr, *f2 = nullptr; int slot = 0; } prefused;   // the GAT passes of the coming machine forward already ran inside the job actor's heads launch (k_headsx_gat3x)
     bool fuse_gat = !getenv("MTFJSP_NO_FUSED_GAT");
     int stream_order = getenv("MTFJSP_NO_STREAM_ORDER") ? 0 : 1;   // streaming GIN launches: alternating row direction + non-temporal input reads (A/B switch)
-    int stream_nt = getenv("MTFJSP_STREAM_NT") ? atoi(getenv("MTFJSP_STREAM_NT")) : 1;   // which readers use non-temporal loads: 1 BatchNorm+ReLU products, 2 aggregation product, 4 pool / gather
+    int pool_s = getenv("MTFJSP_POOL_S") ? atoi(getenv("MTFJSP_POOL_S")) : 4;      // k_job_pool_gather: blocks per row range of the last product (0: plain instance order)
+    int stream_nt = getenv("MTFJSP_STREAM_NT") ? atoi(getenv("MTFJSP_STREAM_NT")) : 5;   // which readers use non-temporal loads: 1 BatchNorm+ReLU products, 2 aggregation product, 4 pool / gather
     mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
     struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
                          const int32_t *gather_from = nullptr; int32_t *gathered = nullptr; } fs[2];   // [0] job actor, [1] machine actor
@@ -2627,7 +2651,10 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     if (rrc) return rrc;
     if (h_pooled) {                                               // h_pooled == NULL: the consumer (k_heads) normalises, pools and gathers itself
         Timed t(e, "job_pool_gather");
-        hipLaunchKernelGGL(k_job_pool_gather, dim3(B < e->num_cu * 8 ? B : e->num_cu * 8), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, (so && (e->stream_nt & 4)) ? 1 : 0, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
+        // (the last product's partition: launch_gemm's grid and k_gemm_x6's tiles per workgroup)
+        const int ntiles = (N + 15) / 16, ggrid = std::min((ntiles + 7) / 8, e->num_cu), rpr = so && e->pool_s > 0 ? ((ntiles + ggrid - 1) / ggrid) * 16 : 0;
+        const int pool_grid = rpr ? ggrid * e->pool_s : (B < e->num_cu * 8 ? B : e->num_cu * 8);
+        hipLaunchKernelGGL(k_job_pool_gather, dim3(pool_grid), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, (so && (e->stream_nt & 4)) ? 1 : 0, rpr, e->pool_s, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
                            W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, cand_feat, h_nodes);
     }
     HIPCHK(e, hipGetLastError());
