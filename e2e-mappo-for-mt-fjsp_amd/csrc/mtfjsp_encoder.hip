@@ -537,6 +537,22 @@ __device__ __forceinline__ void split2x4(const float (&v)[4], uint2 &p0, uint2 &
     p0 = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
     p1 = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
 }
+// the same split with the remainders taken by v_fma_mix_f32 (f16 piece as an f32 operand: x - (float)hi in ONE instruction
+// instead of two conversions and a subtraction; exactly rounded either way, see gr_rem2 in mtfjsp_gin_resident.h)
+__device__ __forceinline__ void split2x4m(const float (&v)[4], uint2 &p0, uint2 &p1)
+{
+    const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+    const h16x2 a = __builtin_convertvector(v01, h16x2), b = __builtin_convertvector(v23, h16x2);
+    const unsigned pa = __builtin_bit_cast(unsigned, a), pb = __builtin_bit_cast(unsigned, b);
+    float r0, r1, r2, r3;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(pa), "v"(v[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(pa), "v"(v[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(pb), "v"(v[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(pb), "v"(v[3]));
+    const h16x2 c = __builtin_convertvector(f32x2{r0, r1}, h16x2), d = __builtin_convertvector(f32x2{r2, r3}, h16x2);
+    p0 = make_uint2(pa, pb);
+    p1 = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+}
 template <int PRO>
 __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 {
@@ -554,6 +570,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     const int first = blockIdx.x * per;
     const int last = first + per < ntiles ? first + per : ntiles;
     const int nsteps = last > first ? (last - first + 3) >> 2 : 0;
+    const int nsteps_c = PRO == PRO_GIN0 ? nsteps : (nsteps + 3) & ~3;     // steps the barriers are counted in (see the producers)
     // logical tile t of [first, last) (the order of the steps) -> the tile of the matrix it stands for
     const int rev_sum = A.rev ? first + last - 1 : 0;
     auto PT = [&](int t) __attribute__((always_inline)) { return A.rev ? rev_sum - t : t; };
@@ -602,21 +619,30 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         // PRO_AGG: neighbour rows TWO steps ahead like the tile's own rows (two register stages), the ELL entries they depend on
         // three (ring of 4).  (Round 2 requested the neighbour rows of step s+1 behind the transform of step s: with the consumers
         // waiting for the producers — 258 k of 466 k cycles at their barrier — that round trip was exposed in every step.)
-        struct NbRows { float4 r0[NA], r1[NA]; } nbA, nbB;
+#ifndef X6_NB_AHEAD
+#define X6_NB_AHEAD 1                       // steps the aggregation's neighbour rows are requested ahead (2: a second register stage = 64 registers more, 256 + 52 B of scratch: 203 / 196 us against 198 / 193 at J20M20 / J10M10)
+#endif
+        struct NbRows { float4 r0[NA], r1[NA]; } nbA, nbB_;
+        NbRows &nbB = X6_NB_AHEAD == 2 ? nbB_ : nbA;
         struct EllSlot { int ox, oy; float vx, vy, dg; } el[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) { el[i].ox = 0; el[i].oy = 0; el[i].vx = 0.f; el[i].vy = 0.f; el[i].dg = 1.f; }
+        // (32-bit byte offsets from a workgroup-uniform base: scalar base + vector offset addressing, no 64-bit vector arithmetic
+        // per request.  The base is the first row this workgroup can touch — its first tile's, less one instance for the
+        // aggregation's neighbour rows — so the offsets are small and never negative whatever the size of the matrix.)
+        const int base_row = (PRO == PRO_AGG) ? (first * 16 > A.T ? first * 16 - A.T : 0) : first * 16;
+        const char *inb = reinterpret_cast<const char *>(A.in + (size_t)base_row * HD);
         auto request_rows = [&](float4 (&pre)[8], int tile) __attribute__((always_inline)) {
-            const float *tb = A.in + (size_t)PT(tile) * 16 * HD;
+            const unsigned tb = ((unsigned)(PT(tile) * 16 - base_row) * HD + lane_off) * 4u;
             if (A.nt) {
 #pragma unroll
                 for (int p = 0; p < 8; p++) {
-                    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(tb + p * 2 * HD + lane_off));
+                    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(inb + (tb + p * 2 * HD * 4)));
                     pre[p] = make_float4(v[0], v[1], v[2], v[3]);
                 }
             } else {
 #pragma unroll
-                for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(tb + p * 2 * HD + lane_off);
+                for (int p = 0; p < 8; p++) pre[p] = *reinterpret_cast<const float4 *>(inb + (tb + p * 2 * HD * 4));
             }
         };
         auto fetch_ell = [&](EllSlot &E, int ltile) __attribute__((always_inline)) {
@@ -629,13 +655,22 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             E.oy = cc.y >= 0 ? base + cc.y : m; E.vy = cc.y >= 0 ? vv.y : 0.f;
             E.dg = (float)(1 + (cc.x >= 0) + (cc.y >= 0));
         };
+        // lane m's value (m = lane & 15: the same in all four 16-lane rows) of the tile row 2p + h this lane works on: two DPP row
+        // broadcasts, row_newbcast:2p into lanes 0..31 and row_newbcast:2p+1 into lanes 32..63 — no LDS round trip (the ds_bpermute
+        // form: 40 per tile, each with its own wait on an LDS pipe the consumer waves keep busy), no scalar detour (v_readlane: 4.5
+        // instructions per value)
+        auto row_pick = [&](int x, int p) __attribute__((always_inline)) {
+#define RP_(P) case P: { const int t_ = __builtin_amdgcn_update_dpp(0, x, 0x150 + 2 * P, 0x3, 0xF, false); return __builtin_amdgcn_update_dpp(t_, x, 0x150 + 2 * P + 1, 0xC, 0xF, false); }
+            switch (p) { RP_(0) RP_(1) RP_(2) RP_(3) RP_(4) RP_(5) RP_(6) default: RP_(7) }
+#undef RP_
+        };
         auto request_nb = [&](NbRows &nb, const EllSlot &E, int tile) __attribute__((always_inline)) {   // neighbour rows of `tile`, whose ELL entries are in E
-            const float *tb = A.in + (size_t)PT(tile) * 16 * HD;
+            const int tb = (PT(tile) * 16 - base_row) * HD + c4;  // (neighbour offsets are relative to the tile and may be negative; the row relative to base_row is not)
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                const int ox = __shfl(E.ox, 2 * p + h), oy = __shfl(E.oy, 2 * p + h);
-                nb.r0[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)ox * HD + c4);
-                nb.r1[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(tb + (ptrdiff_t)oy * HD + c4);
+                const int ox = row_pick(E.ox, p), oy = row_pick(E.oy, p);
+                nb.r0[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(inb + (unsigned)(tb + ox * HD) * 4u);
+                nb.r1[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(inb + (unsigned)(tb + oy * HD) * 4u);
             }
         };
         const int t0 = first + pw;
@@ -712,15 +747,20 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             }
             LDS_BARRIER();                                        // the consumers' last step
         } else {
-        if (PRO == PRO_AGG) {
-            if (t0 < last) fetch_ell(el[0], t0);
-            if (t0 + 4 < last) fetch_ell(el[1], t0 + 4);
-            if (t0 + 8 < last) fetch_ell(el[2], t0 + 8);
-        }
-        if (t0 < last) request_rows(preA, t0);
-        if (PRO == PRO_AGG && t0 < last) request_nb(nbA, el[0], t0);
-        if (t0 + 4 < last) request_rows(preB, t0 + 4);
-        if (PRO == PRO_AGG && t0 + 4 < last) request_nb(nbB, el[1], t0 + 4);
+        // Every step issues the SAME requests, unconditionally: a tile beyond the range is clamped to the last one (a few wasted
+        // cache hits at the end of a range) and the steps are padded to a multiple of four (the consumers run the same number of
+        // barriers).  With `if (tile < last)` around them, the compiler's wait counters had to assume the shorter path at every
+        // join — "nothing younger in flight" — and drained ALL outstanding requests at the top of every step (s_waitcnt vmcnt(7..0)
+        // in the ISA): the two-step prefetch was never in effect and the aggregation producer sat 8.6 k cycles per tile in here.
+        if (nsteps == 0) { stage_scale_shift(); LDS_BARRIER(); LDS_BARRIER(); }
+        else {
+        const int lastm1 = last - 1;
+        auto CL = [&](int t) __attribute__((always_inline)) { return t < lastm1 ? t : lastm1; };
+        if (PRO == PRO_AGG) { fetch_ell(el[0], CL(t0)); fetch_ell(el[1], CL(t0 + 4)); fetch_ell(el[2], CL(t0 + 8)); }
+        request_rows(preA, CL(t0));
+        if (PRO == PRO_AGG) request_nb(nbA, el[0], CL(t0));
+        request_rows(preB, CL(t0 + 4));
+        if (PRO == PRO_AGG && X6_NB_AHEAD == 2) request_nb(nbB, el[1], CL(t0 + 4));
         stage_scale_shift();
         LDS_BARRIER();
         STAMP(0);
@@ -734,43 +774,51 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                 unsigned char *dst = s_tiles + ((s & 1) * 4 + pw) * XT + h * X6_ROWB + j * 8;
 #pragma unroll
                 for (int p = 0; p < 8; p++) {
-                    float v[4] = {bn_relu_ss(pre[p].x, sc0, sh0), bn_relu_ss(pre[p].y, sc1, sh1), bn_relu_ss(pre[p].z, sc2, sh2), bn_relu_ss(pre[p].w, sc3, sh3)};
+                    // BatchNorm of a row quad as two packed FMAs, ReLU per element (no packed f32 max on this target)
+                    auto bnr4 = [&](const float4 &x, float (&o)[4]) __attribute__((always_inline)) {
+                        const f32x2 a = __builtin_elementwise_fma(f32x2{x.x, x.y}, f32x2{sc0, sc1}, f32x2{sh0, sh1});
+                        const f32x2 b = __builtin_elementwise_fma(f32x2{x.z, x.w}, f32x2{sc2, sc3}, f32x2{sh2, sh3});
+                        o[0] = fmaxf(a[0], 0.f); o[1] = fmaxf(a[1], 0.f); o[2] = fmaxf(b[0], 0.f); o[3] = fmaxf(b[1], 0.f);
+                    };
+                    float v[4];
+                    bnr4(pre[p], v);
                     if (PRO == PRO_AGG) {
                         // gcn:125-149: (A_w @ h) / nnz_row, A_w includes the self loop (1).  Small-integer edge weights, <= 3 terms: an f32
                         // FMA chain — the form k_gin_res uses — is within 2 ulp of the reference's f64-then-cast (the f64 form cost this
                         // producer twelve double-rate instructions per row quad; k_gemm16p, the f32-instruction A/B path, keeps it)
                         const int pp = p < NA ? p : 0;
-                        const int r = 2 * p + h;
-                        const float wx = __shfl(E.vx, r), wy = __shfl(E.vy, r);
-                        const float dg = __shfl(E.dg, r);
+                        const float wx = __builtin_bit_cast(float, row_pick(__builtin_bit_cast(int, E.vx), p)), wy = __builtin_bit_cast(float, row_pick(__builtin_bit_cast(int, E.vy), p));
+                        const float dg = __builtin_bit_cast(float, row_pick(__builtin_bit_cast(int, E.dg), p));
                         const float inv = dg == 1.f ? 1.0f : dg == 2.f ? 0.5f : (1.0f / 3.0f);
-                        v[0] = __builtin_fmaf(wy, bn_relu_ss(nb.r1[pp].x, sc0, sh0), __builtin_fmaf(wx, bn_relu_ss(nb.r0[pp].x, sc0, sh0), v[0])) * inv;
-                        v[1] = __builtin_fmaf(wy, bn_relu_ss(nb.r1[pp].y, sc1, sh1), __builtin_fmaf(wx, bn_relu_ss(nb.r0[pp].y, sc1, sh1), v[1])) * inv;
-                        v[2] = __builtin_fmaf(wy, bn_relu_ss(nb.r1[pp].z, sc2, sh2), __builtin_fmaf(wx, bn_relu_ss(nb.r0[pp].z, sc2, sh2), v[2])) * inv;
-                        v[3] = __builtin_fmaf(wy, bn_relu_ss(nb.r1[pp].w, sc3, sh3), __builtin_fmaf(wx, bn_relu_ss(nb.r0[pp].w, sc3, sh3), v[3])) * inv;
+                        float n0[4], n1[4];
+                        bnr4(nb.r0[pp], n0); bnr4(nb.r1[pp], n1);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) v[i] = __builtin_fmaf(wy, n1[i], __builtin_fmaf(wx, n0[i], v[i])) * inv;
                     }
                     uint2 p0, p1;
-                    split2x4(v, p0, p1);
+                    split2x4m(v, p0, p1);
                     *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB) = p0;
                     *reinterpret_cast<uint2 *>(dst + p * 2 * X6_ROWB + X6_PLANE) = p1;
                 }
             }
             // requests (vmcnt retires in order): the ELL entries of step s+3 first — step s+1 turns them into addresses and must not
             // wait for the rows behind them —, then the rows and neighbour rows of step s+2 into the registers this tile just left
-            if (PRO == PRO_AGG && tile + 12 < last) fetch_ell(el[(K + 3) & 3], tile + 12);
-            if (tile + 8 < last) request_rows(pre, tile + 8);
-            if (PRO == PRO_AGG && tile + 8 < last) request_nb(nb, el[(K + 2) & 3], tile + 8);
+            if (PRO == PRO_AGG) fetch_ell(el[(K + 3) & 3], CL(tile + 12));
+            if (PRO == PRO_AGG && X6_NB_AHEAD == 1) request_nb(nb, el[(K + 1) & 3], CL(tile + 4));    // (needed first at the next step: ahead of the rows of s+2)
+            request_rows(pre, CL(tile + 8));
+            if (PRO == PRO_AGG && X6_NB_AHEAD == 2) request_nb(nb, el[(K + 2) & 3], CL(tile + 8));
             STAMP(1);
             LDS_BARRIER();
             STAMP(4);
         };
-        for (int s = 0; s < nsteps; s += 4) {
+        for (int s = 0; s < nsteps_c; s += 4) {
             produce(preA, nbA, std::integral_constant<int, 0>{}, s);
-            if (s + 1 < nsteps) produce(preB, nbB, std::integral_constant<int, 1>{}, s + 1);
-            if (s + 2 < nsteps) produce(preA, nbA, std::integral_constant<int, 2>{}, s + 2);
-            if (s + 3 < nsteps) produce(preB, nbB, std::integral_constant<int, 3>{}, s + 3);
+            produce(preB, nbB, std::integral_constant<int, 1>{}, s + 1);
+            produce(preA, nbA, std::integral_constant<int, 2>{}, s + 2);
+            produce(preB, nbB, std::integral_constant<int, 3>{}, s + 3);
         }
         LDS_BARRIER();                                            // the consumers' last step
+        }
         }
     } else {
         // ================================ consumer ================================
@@ -807,7 +855,8 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         unsigned char *s_tr = smem + X6_TR_OFF + cg * 2 * X6_TRB;  // this wave's two output transposition buffers
         LDS_BARRIER();                                            // step 0: the producers fill buffer 0
         STAMP(4);
-        for (int s = 1; s <= nsteps; s++) {
+        for (int s = 1; s <= nsteps_c; s++) {
+            if (s > nsteps) { LDS_BARRIER(); continue; }           // padding step: nothing was produced
             const int tb = first + 4 * (s - 1);
             const unsigned char *xa = xa0 + ((s - 1) & 1) * 4 * XT;
             auto tiles4 = [&](auto FULLc) __attribute__((always_inline)) {
