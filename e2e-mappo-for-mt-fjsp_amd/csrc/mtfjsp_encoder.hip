@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     const int first = blockIdx.x * per;
     const int last = first + per < ntiles ? first + per : ntiles;
     const int nsteps = last > first ? (last - first + 3) >> 2 : 0;
-    const int nsteps_c = PRO == PRO_GIN0 ? nsteps : (nsteps + 3) & ~3;     // steps the barriers are counted in (see the producers)
+    const int nsteps_c = (nsteps + 3) & ~3;                       // steps the barriers are counted in (see the producers)
     // logical tile t of [first, last) (the order of the steps) -> the tile of the matrix it stands for
     const int rev_sum = A.rev ? first + last - 1 : 0;
     auto PT = [&](int t) __attribute__((always_inline)) { return A.rev ? rev_sum - t : t; };
@@ -679,30 +679,34 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             // neighbours (gcn:125-153: f64 accumulate, divided by the row's entry count — 1, 2 or 3, as a multiplication).
             // The consumers' step is short here (one k-step), shorter than an HBM round trip, so the requests run FOUR steps
             // ahead (ring of 4 register stages) and the ELL entries they depend on eight.
+            // (the whole producer once per feature type: a run-time branch per request is a join per request, see below)
+            auto gin0_producer = [&](auto ft_tag) __attribute__((always_inline)) {
+            using FT = decltype(ft_tag);
             const int r = lane >> 2, k0 = 3 * (lane & 3);
-            struct Stage { float fo[3], fx[3], fy[3]; int2 cc; float2 vv; } st[4];
+            struct Stage { float fo[3], fx[3], fy[3]; int2 cc; float2 vv; int gt; } st[4];
             struct Ell { int2 cc; float2 vv; } el[4];
             auto feat3 = [&](size_t row, float (&o)[3]) __attribute__((always_inline)) {
-                if (A.feat_f64) { const double *p = reinterpret_cast<const double *>(A.tfea) + row * 12 + k0; o[0] = (float)p[0]; o[1] = (float)p[1]; o[2] = (float)p[2]; }
-                else { const float *p = reinterpret_cast<const float *>(A.tfea) + row * 12 + k0; o[0] = p[0]; o[1] = p[1]; o[2] = p[2]; }
+                const FT *p = reinterpret_cast<const FT *>(A.tfea) + row * 12 + k0; o[0] = (float)p[0]; o[1] = (float)p[1]; o[2] = (float)p[2];
             };
+            // Requests are unconditional (see the other producers below: a request behind an `if` makes the compiler drain every
+            // outstanding one at the join — the four-steps-ahead ring had never been in effect): a tile beyond the range or a row
+            // beyond N is clamped to the last one and its values are zeroed afterwards, an absent neighbour reads the row itself
+            const int lastm1 = last - 1;
             auto req_ell = [&](Ell &e, int tile) __attribute__((always_inline)) {
-                const int g = (tile < last ? PT(tile) : 0) * 16 + r;
-                e.cc = make_int2(-1, -1); e.vv = make_float2(0.f, 0.f);
-                if (tile < last && g < A.N) { e.cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2); e.vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2); }
+                const int gt = PT(tile < lastm1 ? tile : lastm1) * 16 + r, g = gt < A.N ? gt : A.N - 1;
+                e.cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2);
+                e.vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2);
             };
             auto req_feat = [&](Stage &x, const Ell &e, int tile) __attribute__((always_inline)) {
-                const int g = (tile < last ? PT(tile) : 0) * 16 + r;
-                x.cc = e.cc; x.vv = e.vv;
-#pragma unroll
-                for (int i = 0; i < 3; i++) { x.fo[i] = 0.f; x.fx[i] = 0.f; x.fy[i] = 0.f; }
-                if (tile < last && g < A.N) {
-                    const size_t base = (size_t)(g / A.T) * A.T;
-                    feat3((size_t)g, x.fo);
-                    if (x.cc.x >= 0) feat3(base + x.cc.x, x.fx);
-                    if (x.cc.y >= 0) feat3(base + x.cc.y, x.fy);
-                }
+                const int gt = PT(tile < lastm1 ? tile : lastm1) * 16 + r, g = gt < A.N ? gt : A.N - 1;
+                x.cc = e.cc; x.vv = e.vv; x.gt = gt;               // (rows beyond N are zeroed where the values are used, not here: a select
+                const int base = (g / A.T) * A.T;                 // on the loaded values is turned back into a branch around the loads)
+                feat3((size_t)g, x.fo);
+                feat3((size_t)(x.cc.x >= 0 ? base + x.cc.x : g), x.fx);
+                feat3((size_t)(x.cc.y >= 0 ? base + x.cc.y : g), x.fy);
             };
+            if (nsteps == 0) { stage_scale_shift(); LDS_BARRIER(); LDS_BARRIER(); }
+            else {
 #pragma unroll
             for (int i = 0; i < 4; i++) req_ell(el[i], t0 + 4 * i);
 #pragma unroll
@@ -710,11 +714,11 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             stage_scale_shift();
             LDS_BARRIER();
             STAMP(0);
-            for (int s0 = 0; s0 < nsteps; s0 += 4) {
+            for (int s0 = 0; s0 < nsteps_c; s0 += 4) {
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const int s = s0 + i;
-                    if (s < nsteps) {
+                    {
                         const int tile = t0 + 4 * s;
                         if (tile < last) {
                             const Stage &x = st[i];
@@ -723,10 +727,12 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                             float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                             for (int f = 0; f < 3; f++) {
+                                // (an absent neighbour has weight 0 and read the row itself: the sum is formed unconditionally, so that
+                                // the compiler cannot sink the neighbour requests under the condition of their use)
                                 double acc = (double)x.fo[f];
-                                if (x.cc.x >= 0) acc += (double)x.vv.x * (double)x.fx[f];
-                                if (x.cc.y >= 0) acc += (double)x.vv.y * (double)x.fy[f];
-                                v[f] = (float)(acc * inv);
+                                acc += (double)x.vv.x * (double)x.fx[f];
+                                acc += (double)x.vv.y * (double)x.fy[f];
+                                v[f] = x.gt < A.N ? (float)(acc * inv) : 0.f;
                             }
                             uint2 p0, p1, p2;
                             split3x4(v, p0, p1, p2);                  // element 3 is padding
@@ -746,6 +752,9 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                 }
             }
             LDS_BARRIER();                                        // the consumers' last step
+            }
+            };
+            if (A.feat_f64) gin0_producer(double{}); else gin0_producer(float{});
         } else {
         // Every step issues the SAME requests, unconditionally: a tile beyond the range is clamped to the last one (a few wasted
         // cache hits at the end of a range) and the steps are padded to a multiple of four (the consumers run the same number of
