@@ -23,20 +23,22 @@
     const int sr = tid >> 5, sc4 = (tid & 31) * 4;                  // staging: thread -> (row sr of 16, 4 columns)
     const int xoff = m * X6_ROWB + 16 * q;                          // operand fragment of (plane p, k-step ks): + p*X6_PLANE + 64*ks
     const float b2 = A.b2[0];
-    if (tid < 2 * HD) s_wc2[tid] = A.wc2[tid];
-    if (tid < HD) { s_vec[tid] = A.b0[tid]; s_vec[HD + tid] = A.bc0[tid]; s_vec[2 * HD + tid] = A.bc1[tid]; s_vec[3 * HD + tid] = A.b1[tid]; s_vec[4 * HD + tid] = A.w2[tid]; }
+    // EVERY request of the kernel's first phase goes out before anything is waited for, unconditionally (indices clamped or
+    // masked into range, values discarded where they are used): the small vectors, the BatchNorm sums of X, the X rows of the
+    // first chunk (gather indices first, rows behind them), the weights of phase A.  (Round 2's source staged the small vectors
+    // through LDS first and put every request behind its own `if`: in the ISA that was a chain of s_waitcnt vmcnt(0) — four to
+    // twelve round trips, one after the other, before the first product.)
+    const float r_wc2 = A.wc2[tid & (2 * HD - 1)];
+    const int tc = tid & (HD - 1);
+    const float r_v0 = A.b0[tc], r_v1 = A.bc0[tc], r_v2 = A.bc1[tc], r_v3 = A.b1[tc], r_v4 = A.w2[tc];
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
-    if (A.zero_stats2 && blockIdx.x == 0) for (int i = tid; i < A.zero_count2; i += 512) A.zero_stats2[i] = 0.0;
     float xs0 = 1.f, xs1 = 1.f, xs2 = 1.f, xs3 = 1.f, xh0 = 0.f, xh1 = 0.f, xh2 = 0.f, xh3 = 0.f;   // X scale / shift of this thread's 4 columns
-    // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of X, the gathered X rows of the
-    // first chunk (index -> row: two dependent round trips), the weights of phase A; only then the pooling stream
     double bsu[STAT_REP], bsq[STAT_REP];
     float bga = 0.f, bbe = 0.f;
-    if (A.xbn_stats && tid < HD) {
+    if (A.xbn_stats) {
 #pragma unroll
-        for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.xbn_stats[r * 256 + tid]; bsq[r] = A.xbn_stats[r * 256 + HD + tid]; }
-        bga = A.xbn_gamma[tid]; bbe = A.xbn_beta[tid];
+        for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.xbn_stats[r * 256 + tc]; bsq[r] = A.xbn_stats[r * 256 + HD + tc]; }
+        bga = A.xbn_gamma[tc]; bbe = A.xbn_beta[tc];
     }
     {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
         // 64-bit weight addresses into registers and spill them)
@@ -50,16 +52,31 @@
             return A.X + ((size_t)(g0 + il) * A.xT + A.xgather[(size_t)g0 * R + grow]) * HD + sc4;
         };
         float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
+        {   // (rows beyond the group's are clamped to its last one here and zeroed by xnorm() where they are used)
+            int gi[HCH];
 #pragma unroll
-        for (int t = 0; t < HCH; t++) {
-            const int grow = t * 16 + sr;
-            xr[t] = (t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = 0; t < HCH; t++) {
+                const int grow = t * 16 + sr, gc = grow < nrows ? grow : nrows - 1;
+                gi[t] = A.xgather ? A.xgather[(size_t)g0 * R + gc] : gc;
+            }
+#pragma unroll
+            for (int t = 0; t < HCH; t++) {
+                const int grow = t * 16 + sr, gc = grow < nrows ? grow : nrows - 1;
+                const int il = (int)__umulhi((unsigned)gc, invR);
+                const float *src = A.xgather ? A.X + ((size_t)(g0 + il) * A.xT + gi[t]) * HD + sc4 : A.X + ((size_t)g0 * R + gc) * HD + sc4;
+                xr[t] = *reinterpret_cast<const float4 *>(src);
+            }
         }
         h16x8 wA[2][4], wB[2][4], wC[2][4];
         const float sW0 = A.sW0, sW1 = A.sW1, sWc0 = A.sWc0, sWc1 = A.sWc1;   // 1 / scale of the weight images
         WCOLX(wA, A.W0x, 1);                                        // Wb
         WCOLX(wB, A.W0x, 2);                                        // Wc
         WCOLX(wC, A.Wc0x, 0);
+        // (everything is in flight: now the stores that only needed the first few words)
+        if (tid < 2 * HD) s_wc2[tid] = r_wc2;
+        if (tid < HD) { s_vec[tid] = r_v0; s_vec[HD + tid] = r_v1; s_vec[2 * HD + tid] = r_v2; s_vec[3 * HD + tid] = r_v3; s_vec[4 * HD + tid] = r_v4; }
+        if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
+        if (A.zero_stats2 && blockIdx.x == 0) for (int i = tid; i < A.zero_count2; i += 512) A.zero_stats2[i] = 0.0;
         if (A.xbn_stats) {
             if (tid < HD) {                                         // stage_bn() from the registers requested above; s_u is free until phase A
                 double su = 0, sq = 0;
