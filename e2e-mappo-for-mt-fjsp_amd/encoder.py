@@ -329,6 +329,9 @@ class ActorPair:
                               "products, f32 accumulate; fused BN/aggregation prologue + BN-sums epilogue; 4 producer + 4 consumer waves)",
                     "bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0,
                     "frac_of_measured_copy_bw": ach / 6300.0, "traffic": None,
+                    "copy_bw_note": "6.3 TB/s is the copy rate of buffers that fit the 256 MB memory-side cache; a chain of read-one-write-one passes "
+                                    "over matrices of this size (419 MB at 819 200 rows) runs at 5.0-5.5 TB/s in one direction and at 6.5 TB/s with "
+                                    "alternating directions + non-temporal reads, which these launches use (profiles/r03d_ubench_mall_order.txt)",
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_bytes_per_launch": nbytes,
                     "algorithmic_flops_per_launch": flops, "f32_equivalent_TFLOPs": flops / avg_s / 1e12,
                     "f16_matrix_TFLOPs": 3 * flops / avg_s / 1e12}
