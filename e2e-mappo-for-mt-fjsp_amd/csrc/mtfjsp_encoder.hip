@@ -2866,14 +2866,27 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
         }
 #ifdef MTFJSP_STAMP
         static int printed = 0;
-        if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
+        if (printed++ % 40 == 30 && printed < 200 && getenv("MTFJSP_STAMP_PRINT")) {
             (void)hipStreamSynchronize(e->stream);
             std::vector<unsigned long long> hst(2048 * 8);
             (void)hipMemcpy(hst.data(), d_st, 2048 * 8 * 8, hipMemcpyDeviceToHost);
+            if (!(e->f32_products & 2)) {                                   // k_gat3x: s_memrealtime stamps (100 MHz) per wave
+                unsigned long long t0 = ~0ull;
+                for (int w = 0; w < grid * 8; w++) t0 = hst[w * 8] < t0 ? hst[w * 8] : t0;
+                double a1[5] = {0}, a2[5] = {0}; int n1 = 0, n2 = 0;
+                for (int w = 0; w < grid * 8; w++) {
+                    const bool two = hst[w * 8 + 3] != 0;
+                    for (int i = 0; i < 5; i++) { const double v = hst[w * 8 + i] ? (double)(hst[w * 8 + i] - t0) / 100.0 : 0.0; (two ? a2 : a1)[i] += v; }
+                    (two ? n2 : n1)++;
+                }
+                printf("STAMP k_gat3x R=%d grid=%d (us since the first wave's start)  waves with one tile (%d): entry %.2f staged %.2f tile done %.2f end %.2f | with two tiles (%d): entry %.2f staged %.2f first tile %.2f second tile %.2f end %.2f\n",
+                       R, grid, n1, a1[0] / (n1 ? n1 : 1), a1[1] / (n1 ? n1 : 1), a1[2] / (n1 ? n1 : 1), a1[4] / (n1 ? n1 : 1), n2, a2[0] / (n2 ? n2 : 1), a2[1] / (n2 ? n2 : 1), a2[2] / (n2 ? n2 : 1), a2[3] / (n2 ? n2 : 1), a2[4] / (n2 ? n2 : 1));
+            } else {
             double m[8] = {0};
             for (int w = 0; w < grid * 8; w++) for (int i = 0; i < 8; i++) m[i] += (double)hst[w * 8 + i] / (grid * 8);
             printf("STAMP k_gat3 R=%d grid=%d  Wload %.0f  feat0 %.0f  rows %.0f  mfma %.0f  gat-epilogue %.0f  tail %.0f (cycles/wave, summed)\n",
                    R, grid, m[0], m[1], m[2], m[3], m[4], m[6]);
+            }
         }
 #endif
     }

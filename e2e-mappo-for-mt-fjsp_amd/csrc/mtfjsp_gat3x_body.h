@@ -9,6 +9,12 @@
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 31, h = lane >> 5, c4 = j * 4;
     const int m = lane & 15, q = lane >> 4;
+#ifdef MTFJSP_STAMP
+#define GAT_RT(i) do { if (A.stamps && lane == 0) { __builtin_amdgcn_sched_barrier(0); A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define GAT_RT(i) do { } while (0)
+#endif
+    GAT_RT(0);
     {   // stage the weight fragments: 65536 B = 8 x 16 B per thread, coalesced
         const float4 *src = reinterpret_cast<const float4 *>(A.Wx6);
         float4 *dst = reinterpret_cast<float4 *>(s_wf);
@@ -51,6 +57,10 @@
     float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t_cur < last) fpre = fetch_feat(t_cur);
     __syncthreads();                                              // weight fragments are staged
+    GAT_RT(1);
+#ifdef MTFJSP_STAMP
+    int gat_rt_i = 2;
+#endif
     const unsigned char *wl = s_wf + lane * 16;                   // fragment (c, p, ks): wl + ((c*2 + p)*4 + ks) * 1024
     while (t_cur < last) {
         const int row0 = t_cur * 16;
@@ -171,6 +181,10 @@
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tile is complete before the next pass reads it
         }
         t_cur = t_n1; t_n1 += 8;
+#ifdef MTFJSP_STAMP
+        if (gat_rt_i == 2) GAT_RT(2); else if (gat_rt_i == 3) GAT_RT(3);
+        gat_rt_i++;
+#endif
     }
     // column sums: fold the 4 row quarters, then the 8 waves through LDS
     __syncthreads();                                              // every tile is done: s_red aliases them
@@ -186,3 +200,5 @@
         for (int w = 0; w < 8; w++) v += s_red[w * 256 + tid];
         atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
     }
+    GAT_RT(4);
+#undef GAT_RT
