@@ -1218,6 +1218,7 @@ __device__ __forceinline__ int pick_action(const float *p, int n, int b, int gre
 
 struct HeadArgs {
     int B, R;
+    int hg;                              // instances per workgroup of k_headsx: HG (16), or 8 where 16 would leave half the CUs without a workgroup (the LDS layout is HG's either way)
     const float *X;                      // [B*R,128] candidate / machine node embeddings
     const float *pooled, *other;         // [B,128]
     const float *W0i;                    // register images (mtfjsp_encoder::wimg) of the 3 blocks of linears.0: X | pooled | other
@@ -2111,6 +2112,7 @@ struct mtfjsp_encoder {
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
     struct { bool valid = false; const void *f1 = nullptr, *f2 = nullptr; int slot = 0; } prefused;   // the GAT passes of the coming machine forward already ran inside the job actor's heads launch (k_headsx_gat3x)
     bool fuse_gat = !getenv("MTFJSP_NO_FUSED_GAT");
+    bool heads_hg8 = !getenv("MTFJSP_NO_HEADS_HG8");          // groups of 8 instances in k_headsx when groups of 16 fill at most half the CUs
     int stream_order = getenv("MTFJSP_NO_STREAM_ORDER") ? 0 : 1;   // streaming GIN launches: alternating row direction + non-temporal input reads (A/B switch)
     int pool_s = getenv("MTFJSP_POOL_S") ? atoi(getenv("MTFJSP_POOL_S")) : 4;      // k_job_pool_gather: blocks per row range of the last product (0: plain instance order)
     int stream_nt = getenv("MTFJSP_STREAM_NT") ? atoi(getenv("MTFJSP_STREAM_NT")) : 5;   // which readers use non-temporal loads: 1 BatchNorm+ReLU products, 2 aggregation product, 4 pool / gather
@@ -2970,8 +2972,9 @@ extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instan
 
 static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic, const GatArgs *fused_gat = nullptr)
 {
-    const int grid = (ha.B + HG - 1) / HG;
-    if (e->f32_products & 4) { hipLaunchKernelGGL(k_heads, dim3(grid), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
+    if (e->f32_products & 4) { hipLaunchKernelGGL(k_heads, dim3((ha.B + HG - 1) / HG), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
+    ha.hg = (!fused_gat && e->heads_hg8 && 2 * ((ha.B + HG - 1) / HG) <= e->num_cu) ? HG / 2 : HG;
+    const int grid = (ha.B + ha.hg - 1) / ha.hg;
     ha.range_flag = e->range_flag;
     ha.W0x = e->wx6.at(policy + ".linears.0.weight"); ha.W1x = e->wx6.at(policy + ".linears.1.weight");
     ha.Wc0x = e->wx6.at(critic + ".linears.0.weight"); ha.Wc1x = e->wx6.at(critic + ".linears.1.weight");

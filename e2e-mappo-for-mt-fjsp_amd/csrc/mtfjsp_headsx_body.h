@@ -42,8 +42,8 @@
     }
     {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
         // 64-bit weight addresses into registers and spill them)
-        const int g0 = blockIdx.x * HG;
-        const int ng = (A.B - g0) < HG ? (A.B - g0) : HG;
+        const int g0 = blockIdx.x * A.hg;
+        const int ng = (A.B - g0) < A.hg ? (A.B - g0) : A.hg;
         const int nrows = ng * R;
         // scorer row `grow` of the group (instance grow / R, candidate / machine grow % R) -> its source row in X
         auto xrow = [&](int grow) __attribute__((always_inline)) -> const float * {
