@@ -169,14 +169,15 @@
             put_planes(s_c1p, c1v);
         }
         STAMP(1);
-        for (int tb = 0; tb < R; tb += HCH) {
-            const int nt = (R - tb) < HCH ? (R - tb) : HCH;
+        const int ntl = (nrows + 15) >> 4;                          // 16-row tiles of this group (R for a full group of 16 instances)
+        for (int tb = 0; tb < ntl; tb += HCH) {
+            const int nt = (ntl - tb) < HCH ? (ntl - tb) : HCH;
             // ---- X rows of this chunk -> planes (rows beyond the group's are zero)
 #pragma unroll
             for (int t = 0; t < HCH; t++) {
                 if (tb > 0) {
                     const int grow = (tb + t) * 16 + sr;
-                    xr[t] = (tb + t < R && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    xr[t] = (tb + t < ntl && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 const float4 xv4 = xnorm(xr[t], (tb + t) * 16 + sr < nrows);
                 const float v[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
