@@ -74,3 +74,40 @@ def test_encoder_matches_oracle_at_other_sizes(J, M, E, B, steps, obs):
         assert dh.max() < htol * 4 and np.median(dh) < htol / 4, (dh.max(), np.median(dh))
         np.testing.assert_allclose(mach_v.cpu().numpy(), mo["mach_v"], rtol=5e-3, atol=5e-3)
     e.set_bn_mode(False)
+
+
+def test_streaming_order_switches_do_not_change_results(monkeypatch):
+    """The streaming GIN launches alternate the direction in which a workgroup walks its rows, read their input with non-temporal
+    loads, and the pool / gather kernel follows the last product's row ranges from the back (the memory-side
+    cache).  None of that may change a value: the same forward on a handle created with round 2's order
+    (MTFJSP_NO_STREAM_ORDER) agrees to the accumulation-order noise of the BatchNorm sums.  J10M10 x 333: 33 300 rows, a ragged
+    last tile, 261 row tiles over the workgroups, groups of 16 and of 8 instances in the heads."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    J, M, E, B = 10, 10, 2, 333
+    ja, ma = enc_mod.random_init_weights(seed=77)
+    _perturb(ja, ma, 5)
+    ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=(ja, ma), collect=False)
+    for _ in range(37):
+        ro.step()
+    env = ro.env
+    hm = ro.actor.enc.h_pooled_m.clone()
+    outs = []
+    for switches in ({}, {"MTFJSP_NO_STREAM_ORDER": "1"}, {"MTFJSP_POOL_S": "0", "MTFJSP_STREAM_NT": "0"}, {"MTFJSP_NO_HEADS_HG8": "1"}):
+        for k in ("MTFJSP_NO_STREAM_ORDER", "MTFJSP_POOL_S", "MTFJSP_STREAM_NT", "MTFJSP_NO_HEADS_HG8"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in switches.items():
+            monkeypatch.setenv(k, v)
+        e = enc_mod.Encoder(J, M, B, obs_dtype="f32")            # the switches are read when the handle is created
+        e.load_weights(ja, ma)
+        prob, h_o, job_v = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm)
+        torch.cuda.synchronize()
+        outs.append((prob.cpu().numpy().copy(), h_o.cpu().numpy().copy(), job_v.cpu().numpy().copy()))
+        e.close()
+    scale = max(1.0, float(np.abs(outs[0][1]).max()))
+    for o in outs[1:]:
+        np.testing.assert_allclose(o[1], outs[0][1], rtol=0, atol=2e-5 * scale)
+        np.testing.assert_allclose(o[0], outs[0][0], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(o[2], outs[0][2], rtol=1e-4, atol=1e-4)
