@@ -55,6 +55,7 @@ class DeviceBatchEnv:
         obs = capi.Obs(*[x.data_ptr() for x in (self.tasks_fea, self.ell_col, self.ell_val, self.m_fea2, self.info,
                                                   self.raw, self.candidate, self.job_mask, self.status)])
         capi.check(self.L.mtfjsp_bind_obs(self.h, C.byref(obs)), self.h)
+        self._sp_buf = None
         self.use_current_stream()
 
     def use_current_stream(self):
@@ -150,6 +151,18 @@ class DeviceBatchEnv:
         """device step that also writes this step's f32 trajectory entries: r4_out [4,B], done_out [B] (contiguous views)"""
         assert r4_out.is_contiguous() and done_out.is_contiguous() and r4_out.dtype == torch.float32
         capi.check(self.L.mtfjsp_step_record(self.h, task_idx.data_ptr(), mach_idx.data_ptr(), r4_out.data_ptr(), done_out.data_ptr()), self.h)
+
+    def step_params(self, task_idx, mach_idx, r4_out=None, done_out=None):
+        """the parameter block of exactly the step that step() / step_record() with these arguments would launch, for
+        Encoder.arm_env_step (the step then rides in the machine actor's heads launch) — or None when this environment's step
+        cannot (shape, kernel-time recording, diagnostic overrides): then call step() / step_record() as usual"""
+        if self._sp_buf is None:
+            self._sp_buf = C.create_string_buffer(int(self.L.mtfjsp_step_params_bytes()))
+        rc = self.L.mtfjsp_step_params(self.h, task_idx.data_ptr(), mach_idx.data_ptr(), r4_out.data_ptr() if r4_out is not None else None,
+                                       done_out.data_ptr() if done_out is not None else None, self._sp_buf, len(self._sp_buf))
+        if rc < 0:
+            capi.check(rc, self.h)
+        return self._sp_buf if rc == 1 else None
 
     def gae(self, r, v, v_next, done, gamma, lam, out=None):
         """un-normalised GAE advantages [S,B] for one reward channel (views with arbitrary (s,b) strides allowed for r/v/v_next)"""

@@ -63,6 +63,8 @@ PROTOTYPES = {
     "mtfjsp_step": (_I, [_VP, _VP, _VP]),
     "mtfjsp_step_host": (_I, [_VP, _VP, _VP]),
     "mtfjsp_step_record": (_I, [_VP, _VP, _VP, _VP, _VP]),
+    "mtfjsp_step_params_bytes": (C.c_int32, []),
+    "mtfjsp_step_params": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int32]),
     "mtfjsp_gae": (_I, [_VP, C.c_int32, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int64, _VP, C.c_float, C.c_float, _VP]),
     "mtfjsp_observe_mfea1": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_random_actions": (_I, [_VP, _U64, _U64, _VP, _VP, _VP]),
@@ -89,6 +91,8 @@ PROTOTYPES = {
     "mtfjsp_encoder_set_stats_reduce": (_I, [_VP, C.c_void_p, _VP, C.c_int64]),
     "mtfjsp_get_mfea1_context": (_I, [_VP, _VP, _VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_mfea1": (_I, [_VP, C.POINTER(Mfea1Ctx)]),
+    "mtfjsp_encoder_arm_env_step": (_I, [_VP, _VP, C.c_int32]),
+    "mtfjsp_encoder_env_step_fused": (_I, [_VP]),
     "mtfjsp_encoder_arm_selection": (_I, [_VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
     "mtfjsp_hostgen_infeasible": (_I, [_VP, C.POINTER(C.c_int32), C.c_int64, _I, _I, C.c_int64, C.c_int64, _VP]),
     "mtfjsp_hostgen_transport": (_I, [_VP, C.POINTER(C.c_int32), C.c_int64, _I, _VP, C.c_double, C.c_double, C.c_double, C.c_int64, C.c_int64, _VP]),

@@ -963,6 +963,10 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 static size_t gemm_x6_lds_bytes() { return (size_t)X6_TR_OFF + 4 * 2 * X6_TRB; }
 
 #include "mtfjsp_gin_resident.h"
+// the grouped environment step as a device function (k_headsx_envstep below)
+#define MTFJSP_ENV_GRP_NO_KERNELS
+#include "mtfjsp_env_dev.h"
+#include "mtfjsp_env_grp.h"
 
 // ---------------------------------------------------------------------------------------------
 // Machine path of the machine actor / global critic (ac:383-434, gat:82-159) in ONE launch.  The three applications of
@@ -1569,6 +1573,21 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
 #include "mtfjsp_gat3x_body.h"
     }
 }
+// The machine actor's heads and the environment step of the same 16 instances in ONE launch (round-2 review, item 3): the heads end
+// with the machine selection of exactly the instances k_env_grp16 would give this blockIdx, and nothing else the step reads is written
+// by this launch.  __syncthreads() orders the selected indices' stores before the step's loads (same workgroup, same CU); the step's
+// arrays take the heads' LDS; 8 waves take the 16 instances in two rounds.  The step is mtfjsp_env_grp.h's own code: bit-identical.
+template <typename OBS>
+__global__ __launch_bounds__(512) void k_headsx_envstep(HeadArgs HA, EnvParams EP)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    {
+        const HeadArgs &A = HA;
+#include "mtfjsp_headsx_body.h"
+    }
+    __syncthreads();
+    env_grp_body_dyn<OBS, 1, 8>(EP, smem);
+}
 static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
 
 // ---------------------------------------------------------------------------------------------
@@ -2112,7 +2131,13 @@ struct mtfjsp_encoder {
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
     struct { bool valid = false; const void *f1 = nullptr, *f2 = nullptr; int slot = 0; } prefused;   // the GAT passes of the coming machine forward already ran inside the job actor's heads launch (k_headsx_gat3x)
     bool fuse_gat = !getenv("MTFJSP_NO_FUSED_GAT");
-    bool heads_hg8 = !getenv("MTFJSP_NO_HEADS_HG8");          // groups of 8 instances in k_headsx when groups of 16 fill at most half the CUs
+    bool heads_hg8 = !getenv("MTFJSP_NO_HEADS_HG8");
+    // the environment step as the tail of the machine heads' launch (mtfjsp_encoder_arm_env_step).  OFF unless MTFJSP_FUSED_ENV is set:
+    // bit-identical (tests/test_fused_env_step_gpu.py) and one launch less per step, but measured SLOWER at the headline shape —
+    // 220.4 against 217.6 us per step, three alternating runs on one box — because the heads' 8 waves take the 16 instances in two
+    // rounds where k_env_grp16's 16 waves take them in one: the second round costs more than the launch boundary saves
+    bool fuse_env = getenv("MTFJSP_FUSED_ENV") != nullptr;
+    struct { bool armed = false, done = false; EnvParams P; } env_step;          // groups of 8 instances in k_headsx when groups of 16 fill at most half the CUs
     int stream_order = getenv("MTFJSP_NO_STREAM_ORDER") ? 0 : 1;   // streaming GIN launches: alternating row direction + non-temporal input reads (A/B switch)
     int pool_s = getenv("MTFJSP_POOL_S") ? atoi(getenv("MTFJSP_POOL_S")) : 4;      // k_job_pool_gather: blocks per row range of the last product (0: plain instance order)
     int stream_nt = getenv("MTFJSP_STREAM_NT") ? atoi(getenv("MTFJSP_STREAM_NT")) : 5;   // which readers use non-temporal loads: 1 BatchNorm+ReLU products, 2 aggregation product, 4 pool / gather
@@ -2287,6 +2312,8 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_headsx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)headsx_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_headsx_envstep<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(headsx_lds_bytes() > EnvGrpDynLds<1>::bytes ? headsx_lds_bytes() : EnvGrpDynLds<1>::bytes));
+    (void)hipFuncSetAttribute((const void *)k_headsx_envstep<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(headsx_lds_bytes() > EnvGrpDynLds<1>::bytes ? headsx_lds_bytes() : EnvGrpDynLds<1>::bytes));
     (void)hipFuncSetAttribute((const void *)k_headsx_gat3x, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes()));
     {   // resident GIN kernel: whole instances per workgroup, at most 576 rows, one workgroup per CU
@@ -2970,10 +2997,11 @@ extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instan
     return MTFJSP_OK;
 }
 
-static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic, const GatArgs *fused_gat = nullptr)
+static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic, const GatArgs *fused_gat = nullptr,
+                         const EnvParams *env_tail = nullptr)
 {
     if (e->f32_products & 4) { hipLaunchKernelGGL(k_heads, dim3((ha.B + HG - 1) / HG), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
-    ha.hg = (!fused_gat && e->heads_hg8 && 2 * ((ha.B + HG - 1) / HG) <= e->num_cu) ? HG / 2 : HG;
+    ha.hg = (!fused_gat && !env_tail && e->heads_hg8 && 2 * ((ha.B + HG - 1) / HG) <= e->num_cu) ? HG / 2 : HG;
     const int grid = (ha.B + ha.hg - 1) / ha.hg;
     ha.range_flag = e->range_flag;
     ha.W0x = e->wx6.at(policy + ".linears.0.weight"); ha.W1x = e->wx6.at(policy + ".linears.1.weight");
@@ -2983,6 +3011,12 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
     if (fused_gat) {                                                // + the machine path's GAT passes of the same 16 instances
         const size_t lds = headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes();
         hipLaunchKernelGGL(k_headsx_gat3x, dim3(grid), dim3(512), lds, e->stream, ha, *fused_gat);
+        return;
+    }
+    if (env_tail) {                                                 // + the environment step of the same 16 instances (k_env_grp16's partition)
+        const size_t lds = headsx_lds_bytes() > EnvGrpDynLds<1>::bytes ? headsx_lds_bytes() : EnvGrpDynLds<1>::bytes;
+        if (env_tail->obs_f32) hipLaunchKernelGGL(k_headsx_envstep<float>, dim3(grid), dim3(512), lds, e->stream, ha, *env_tail);
+        else hipLaunchKernelGGL(k_headsx_envstep<double>, dim3(grid), dim3(512), lds, e->stream, ha, *env_tail);
         return;
     }
     hipLaunchKernelGGL(k_headsx, dim3(grid), dim3(512), headsx_lds_bytes(), e->stream, ha);
@@ -3012,6 +3046,16 @@ extern "C" int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_c
     e->mf_ctx = *ctx; e->mf_armed = true;
     return MTFJSP_OK;
 }
+
+extern "C" int mtfjsp_encoder_arm_env_step(mtfjsp_encoder_t e, const void *params, int32_t bytes)
+{
+    if (!e || !params) return MTFJSP_ERR_ARG;
+    if (bytes != (int32_t)sizeof(EnvParams)) { e->err = "mtfjsp_encoder_arm_env_step: parameter block of another library version"; return MTFJSP_ERR_ARG; }
+    memcpy(&e->env_step.P, params, sizeof(EnvParams));
+    e->env_step.armed = true; e->env_step.done = false;
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_encoder_env_step_fused(mtfjsp_encoder_t e) { return e && e->env_step.done ? 1 : 0; }
 
 static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
                                   const int32_t *candidate, const uint8_t *job_mask, const float *h_m_prev,
@@ -3143,7 +3187,13 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
         ha.Wc1i = WI("machine_actor.machine_critic.linears.1.weight"); ha.bc1 = W("machine_actor.machine_critic.linears.1.bias");
         ha.wc2 = W("machine_actor.machine_critic.linears.2.weight"); ha.bc2 = W("machine_actor.machine_critic.linears.2.bias");
         ha.mask = mmask; ha.scale = 10.0f; ha.prob = prob; ha.value = machine_v;
-        launch_heads(e, ha, "machine_actor.m_policy", "machine_actor.machine_critic");
+        // an armed environment step (mtfjsp_encoder_arm_env_step) rides in this launch when the selection made here is the one it
+        // reads, the shapes agree and the launch is the split-product heads kernel; otherwise the caller steps the environment itself
+        const EnvParams &EP = e->env_step.P;
+        const bool env_tail = e->env_step.armed && e->fuse_env && !e->timing && !e->bn_mode && !(e->f32_products & 4) && ha.sample_mode &&
+                              (const void *)ha.idx_out == (const void *)EP.mach_idx && EP.B == B && EP.M == M && EP.T <= 64 && EP.M * EP.M <= 64 && EP.J <= 64;
+        e->env_step.armed = false; e->env_step.done = env_tail;
+        launch_heads(e, ha, "machine_actor.m_policy", "machine_actor.machine_critic", nullptr, env_tail ? &EP : nullptr);
     }
     HIPCHK(e, hipGetLastError());
     return MTFJSP_OK;

@@ -29,52 +29,7 @@
 
 #include "../../include/mtfjsp.h"
 
-#define WAVE 64
-#define SCAL_N 28          // doubles of per-instance scalar state
-// scalar slots
-#define S_MK_PREV 0
-#define S_E1_PREV 1
-#define S_TR_PREV 2
-#define S_ID_PREV 3
-#define S_TR_THIS 4
-#define S_W3 5             // 5,6,7
-#define S_R 8              // 8..11   RewardScaling.R
-#define S_MEAN 12          // 12..15
-#define S_S 16             // 16..19
-#define S_STD 20           // 20..23
-#define S_N 24             // RunningMeanStd.n
-#define S_NSCHED 25        // number of scheduled tasks
-
-struct __align__(8) Link { short mach, prev, pos, pad; };      // per task: machine (-1), route predecessor (-1), rank in route
-struct __align__(8) MRec { short head, tail, len, pad; };      // per machine
-
-struct EnvParams {
-    int B, J, M, T, left_shift, obs_f32;
-    unsigned inv_M;                    // ceil(2^32 / M)
-    double w_mk, w_ec, w_tt, divisor, gamma;
-    // instance constants
-    const double *t, *p, *tt;          // [B,T,M] [B,T,M] [B,M,M]
-    const double2 *cst;                // [B,T] {min_dur, min_pt}
-    // dynamic state
-    double *st, *ft, *dur, *psel;      // [B,T]
-    Link *link;                        // [B,T]
-    MRec *mrec;                        // [B,M]
-    short *jcnt;                       // [B,J] scheduled ops per job (ops of a job are scheduled in order)
-    double *pte;                       // [B,T] estimated / real processing energy per task (env:1995)
-    double *jmax, *jrow;               // [B,J] max estimated finish / max real finish per job
-    int *lastm;                        // [B]   node whose merged job+machine edge was created by the previous step (-1)
-    double *mfea;                      // [B,M,8] f64 master copy of machines_fea
-    double *scal;                      // [B,SCAL_N]
-    // inputs
-    const int *task_idx, *mach_idx;    // [B]
-    const double *w3;                  // [B,3] (reset)
-    // outputs
-    mtfjsp_obs_t obs;
-    unsigned long long *stamps;        // diagnostic build only
-    float *rec_r4, *rec_done;          // optional f32 trajectory record of this step ([4,B], [B])
-    const short *pw_tab;               // leaves and merges of numpy's pairwise sum over T elements (pw_table; T > 128 only)
-    int pw_nleaf;
-};
+#include "mtfjsp_env_dev.h"
 
 // ---------------------------------------------------------------------------------------------
 // numpy float64 add.reduce order: 0 + pairwise_sum (8 accumulators, 128-element leaf blocks).
@@ -108,7 +63,6 @@ template <>
 __device__ __noinline__ double pw_sum<0>(const double *a, int n) { return pw_leaf(a, n); }
 __device__ __forceinline__ double np_sum(const double *a, int n) { return 0.0 + pw_sum<6>(a, n); }   // n <= 8192
 
-__device__ __forceinline__ long trunc_l(double x) { return (long)x; }   // numpy astype(int): toward zero
 
 // ---------------------------------------------------------------------------------------------
 #ifdef MTFJSP_STAMP
@@ -648,12 +602,7 @@ static size_t env_step_lds_bytes(int J, int M, int T, bool f32)
 // wave-uniform, so every gather of the scheduling decision is a v_readlane with a scalar index (no memory hop), the
 // left-shift gap test runs on all lanes at once (ballot) and routes are walked by scalar loops.  Same incremental
 // output contract as k_env_step.  The whole step is ~2 global round trips + register/scalar work.
-__device__ __forceinline__ int rl_i(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
-__device__ __forceinline__ double rl_d(double x, int l)
-{
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
-}
-__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+// (rl_i / rl_d / uni: mtfjsp_env_dev.h)
 
 template <typename OBS>
 __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
@@ -2027,6 +1976,24 @@ extern "C" int mtfjsp_step_record(mtfjsp_handle_t h, const int32_t *task_idx, co
 {
     if (!r4_out || !done_out) return MTFJSP_ERR_ARG;
     return step_impl(h, task_idx, mach_idx, r4_out, done_out);
+}
+// The parameter block of the step kernel for a launch that runs the step as its own tail (mtfjsp_encoder_arm_env_step: the machine
+// actor's heads kernel).  Returns 1 and fills `out` when this handle's step is the 16-instance register kernel (k_env_grp16) and
+// nothing asks for the stand-alone launch (kernel-time recording, MTFJSP_ENV_KERNEL); 0 when the caller has to call mtfjsp_step /
+// mtfjsp_step_record itself; < 0 on errors.  The step has no host-side state: a parameter block that is never used costs nothing.
+extern "C" int32_t mtfjsp_step_params_bytes(void) { return (int32_t)sizeof(EnvParams); }
+extern "C" int mtfjsp_step_params(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx, float *r4_out, float *done_out, void *out, int32_t out_bytes)
+{
+    if (!h || !task_idx || !mach_idx || !out || out_bytes != (int32_t)sizeof(EnvParams)) return MTFJSP_ERR_ARG;
+    if ((r4_out == nullptr) != (done_out == nullptr)) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, true);
+    if (rc) return rc;
+    EnvParams P = make_params(h);
+    P.task_idx = task_idx; P.mach_idx = mach_idx; P.rec_r4 = r4_out; P.rec_done = done_out;
+    const bool eligible = !h->timing && !getenv("MTFJSP_ENV_KERNEL") && !getenv("MTFJSP_ENV_LDS") && P.T <= 64 && P.M * P.M <= 64 && P.J <= 64 && P.B <= EG_SMALL_MAX_B;
+    if (!eligible) return 0;
+    memcpy(out, &P, sizeof(EnvParams));
+    return 1;
 }
 static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx, float *r4, float *dn)
 {

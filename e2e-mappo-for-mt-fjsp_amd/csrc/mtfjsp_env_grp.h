@@ -1,5 +1,6 @@
 // mtfjsp_env_grp.h — k_env_grp: the register step kernel (k_env_reg, T <= 64, M*M <= 64) for GROUPS of 16 instances.
-// Included by mtfjsp_env.hip (uses EnvParams, Link, MRec, rl_i, rl_d, uni, trunc_l and the S_* slots).
+// Included by mtfjsp_env.hip and (without the kernels: MTFJSP_ENV_GRP_NO_KERNELS) by mtfjsp_encoder.hip; uses EnvParams, Link, MRec,
+// rl_i, rl_d, uni, trunc_l and the S_* slots of mtfjsp_env_dev.h.
 //
 // Why: at the headline batch every SIMD holds four one-instance waves and the launch is bound by vector-instruction issue
 // (≈920 VALU instructions per wave, SQ counters), and a third of those compute per-INSTANCE scalars — makespan, energy and
@@ -561,6 +562,53 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 #endif
     (void)rt;
 }
+// The same step for a group of EG_SMALL instances as the TAIL of another kernel's workgroup (k_headsx_envstep, mtfjsp_encoder.hip:
+// the machine actor's heads have just selected the machines of exactly these instances): the per-instance arrays are carved from
+// the caller's dynamic LDS (free once the caller's own phases are done) and NW waves take the instances in EG_SMALL / NW rounds.
+// Same functions, same operations: bit-identical to k_env_grp16.
+template <int NS>
+struct EnvGrpDynLds {
+    static constexpr int NL = 64 * NS, EG = EG_SMALL;
+    static constexpr size_t o_sorted = 0, o_jmx = o_sorted + sizeof(double) * EG * NL, o_jrw = o_jmx + sizeof(double) * EG * 64,
+                            o_cn = o_jrw + sizeof(double) * EG * 64, o_scl = o_cn + sizeof(int) * EG * 64, o_mf = o_scl + sizeof(double) * EG * SCAL_N,
+                            o_un = o_mf + sizeof(double) * EG * 8, o_in = o_un + sizeof(double) * EG * 16, o_mp = o_in + sizeof(int) * EG * 12,
+                            o_sdf = o_mp + sizeof(int) * EG * 2 * NL, o_ttl = o_sdf + sizeof(double) * EG * 3 * NL, bytes = o_ttl + sizeof(double) * EG * NL;
+};
+template <typename OBS, int NS, int NW>
+__device__ __forceinline__ void env_grp_body_dyn(const EnvParams &P, unsigned char *smem)
+{
+    using L = EnvGrpDynLds<NS>;
+    constexpr int NL = L::NL, EG = L::EG;
+    auto s_sorted = reinterpret_cast<double (*)[NL]>(smem + L::o_sorted);
+    auto s_jmx = reinterpret_cast<double (*)[64]>(smem + L::o_jmx);
+    auto s_jrw = reinterpret_cast<double (*)[64]>(smem + L::o_jrw);
+    auto s_cn = reinterpret_cast<int (*)[64]>(smem + L::o_cn);
+    auto s_scl = reinterpret_cast<double (*)[SCAL_N]>(smem + L::o_scl);
+    auto s_mf = reinterpret_cast<double (*)[8]>(smem + L::o_mf);
+    auto s_un = reinterpret_cast<double (*)[16]>(smem + L::o_un);
+    auto s_in = reinterpret_cast<int (*)[12]>(smem + L::o_in);
+    auto s_mp = reinterpret_cast<int (*)[2 * NL]>(smem + L::o_mp);
+    auto s_sdf = reinterpret_cast<double (*)[3 * NL]>(smem + L::o_sdf);
+    auto s_ttl = reinterpret_cast<double (*)[NL]>(smem + L::o_ttl);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b0 = blockIdx.x * EG;
+    const int lane = threadIdx.x & 63;
+    unsigned long long rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll 1
+    for (int g = w; g < EG; g += NW)
+        if (b0 + g < P.B) env_grp_wave<OBS, NS>(P, b0 + g, lane, s_sorted[g], s_jmx[g], s_jrw[g], s_cn[g], s_scl[g], s_mf[g], s_un[g], s_in[g], s_mp[g], s_sdf[g], s_ttl[g], rt);
+    __syncthreads();
+    if (w == 0) {
+        const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
+        env_grp_tail<OBS>(P, b0, lane, EG, acc);
+    } else if (w == 1) {
+        const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
+        env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl);
+        env_grp_mask(P, b0, lane, EG, acc);
+    }
+    (void)rt;
+}
+#ifndef MTFJSP_ENV_GRP_NO_KERNELS
 template <typename OBS>
 __global__ __launch_bounds__(EG_SMALL * WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_grp16(EnvParams P) { env_grp_body<OBS, EG_SMALL, 1>(P); }
 template <typename OBS>
@@ -570,3 +618,4 @@ template <typename OBS>
 __global__ __launch_bounds__(EG_SMALL * WAVE) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_env_grp16x2(EnvParams P) { env_grp_body<OBS, EG_SMALL, 2>(P); }
 template <typename OBS>
 __global__ __launch_bounds__(EG_LARGE * WAVE) void k_env_grp4x2(EnvParams P) { env_grp_body<OBS, EG_LARGE, 2>(P); }
+#endif

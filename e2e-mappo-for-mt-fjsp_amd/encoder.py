@@ -216,6 +216,14 @@ class Encoder:
         """the next job actor forward (with an armed selection) also writes m_fea1 / the machine mask of the selected tasks"""
         capi.check(self.L.mtfjsp_encoder_arm_mfea1(self.h, C.byref(ctx)), self.h, enc=True)
 
+    def arm_env_step(self, params):
+        """the next machine actor forward (with an armed selection into the `mach_idx` of DeviceBatchEnv.step_params) also runs that
+        environment step in its heads launch; env_step_fused() tells afterwards whether it did"""
+        capi.check(self.L.mtfjsp_encoder_arm_env_step(self.h, params, len(params)), self.h, enc=True)
+
+    def env_step_fused(self):
+        return bool(self.L.mtfjsp_encoder_env_step_fused(self.h))
+
     def timing_begin(self):
         capi.check(self.L.mtfjsp_encoder_timing_begin(self.h), self.h, enc=True)
 
@@ -242,6 +250,8 @@ class ActorPair:
         self.has_critic = len(w) > 2
         self.greedy, self.seed = greedy, seed
         self._mf_ctx, self._mf_env = None, None
+        self.n_env_fused = 0                                     # decisions whose environment step rode in the machine heads' launch
+        self.fuse_env = bool(os.environ.get("MTFJSP_FUSED_ENV")) # (the library reads the same switch when the handle is created; off by default: DESIGN.md §9)
         self.fused = not os.environ.get("MTFJSP_NO_FUSED_SELECT")   # action selection inside the heads kernels (same stream either way)
         dev = self.enc.device
         self.job_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
@@ -252,7 +262,7 @@ class ActorPair:
         self.have_hm = False                                    # run:280 h_mch_pooled = None
 
     def act(self, env, counter, task_idx, mach_idx, job_idx, jv_out=None, mv_out=None, job_logp=None, mach_logp=None,
-            after_mfea1=None, force=None):
+            after_mfea1=None, force=None, env_step=None):
         """one joint decision for every instance; the optional outputs let a trajectory buffer receive action indices,
         log-probabilities and critic values in place (no copies).  force = (task [B], machine [B][, job [B]]) int32 tensors:
         replay these decisions instead of the selected ones (teacher forcing; the forwards and their outputs are unchanged,
@@ -280,15 +290,24 @@ class ActorPair:
             env.observe_mfea1(task_idx)                         # -> env.m_fea1, env.mmask (else: written by the heads kernel)
         if after_mfea1 is not None:
             after_mfea1(env)
+        stepped = False
         if self.fused:
             e.arm_selection(1, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
+            if self.fuse_env and env_step is not None and force is None:
+                # env_step = () or (r4_out, done_out): let the environment step of this decision ride in the machine heads' launch
+                params = env.step_params(task_idx, mach_idx, *env_step)
+                if params is not None:
+                    e.arm_env_step(params)
             e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
+            stepped = self.fuse_env and env_step is not None and force is None and e.env_step_fused()
         else:
             mprob, _, _ = e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
             e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
         if force is not None:
             mach_idx.copy_(force[1])
         self.have_hm = True
+        self.n_env_fused += int(stepped)
+        return stepped                                           # True: the environment has already taken this step
 
     def terminal_values(self, env, prev_job_mask, jv_out, mv_out):
         """The post-terminal forward pair of Run.py:455-475, to be called right after the env step that finished the

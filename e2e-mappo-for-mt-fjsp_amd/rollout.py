@@ -189,9 +189,10 @@ class Rollout:
             tb = self.traj
             sl = tb.slot()
             tb.snapshot(env, "pre")
-            self.actor.act(env, self.nsteps, self.task, sl["mach_idx"], sl["job_idx"], sl["job_v"], sl["mach_v"],
-                           job_logp=sl["job_logp"], mach_logp=sl["mach_logp"], after_mfea1=tb.after_decision, force=force)
-            env.step_record(self.task, sl["mach_idx"], sl["r4"], sl["done"])
+            if not self.actor.act(env, self.nsteps, self.task, sl["mach_idx"], sl["job_idx"], sl["job_v"], sl["mach_v"],
+                                  job_logp=sl["job_logp"], mach_logp=sl["mach_logp"], after_mfea1=tb.after_decision, force=force,
+                                  env_step=(sl["r4"], sl["done"])):
+                env.step_record(self.task, sl["mach_idx"], sl["r4"], sl["done"])
             if last:           # value of the terminal state (run:455-475) with the mask the last decision was taken under
                 jv_t, mv_t = tb.terminal_slot()
                 self.actor.terminal_values(env, tb.mask_operation[tb.count_operation], jv_t, mv_t)
@@ -204,19 +205,22 @@ class Rollout:
             e, t = divmod(self.buf_pos, self.T)   # critic values and rewards land directly in the trajectory slots (no copies)
             if last:
                 self.prev_job_mask.copy_(env.job_mask)
-            self.actor.act(env, self.nsteps, self.task, self.mach, self.job, self.buf_jv[e, t], self.buf_mv[e, t], force=force)
-            env.step_record(self.task, self.mach, self.buf_r[self.buf_pos], self.buf_done[self.buf_pos])
+            if not self.actor.act(env, self.nsteps, self.task, self.mach, self.job, self.buf_jv[e, t], self.buf_mv[e, t], force=force,
+                                  env_step=(self.buf_r[self.buf_pos], self.buf_done[self.buf_pos])):
+                env.step_record(self.task, self.mach, self.buf_r[self.buf_pos], self.buf_done[self.buf_pos])
             if last:
                 self.actor.terminal_values(env, self.prev_job_mask, self.buf_jv[e, self.T], self.buf_mv[e, self.T])
             self.buf_pos += 1
             if self.buf_pos == self.S:
                 self.finish_buffer()
         else:
+            stepped = False
             if self.actor is not None:
-                self.actor.act(env, self.nsteps, self.task, self.mach, self.job, force=force)
+                stepped = self.actor.act(env, self.nsteps, self.task, self.mach, self.job, force=force, env_step=())
             else:
                 env.random_actions(self.seed, self.nsteps, self.task, self.mach, self.job)
-            env.step(self.task, self.mach)
+            if not stepped:
+                env.step(self.task, self.mach)
         self.nsteps += 1
         self.t_in_ep += 1
         if self.t_in_ep == self.T:

@@ -147,6 +147,15 @@ int mtfjsp_step(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_
 /* same launch, additionally recording this step's trajectory entries as f32 for the advantage computation
  * (SURVEY Appendix A rows 11,17-20): r4_out [4,B] = scaled mk, idle, pt, tt (pe:255-262 order) ; done_out [B]. */
 int mtfjsp_step_record(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx, float *r4_out, float *done_out);
+/* The step as the TAIL of the launch that selects the machines (Run.py:363-427: machine actor forward, then env.step, nothing in
+ * between): mtfjsp_step_params fills an opaque parameter block (mtfjsp_step_params_bytes() bytes) for exactly the step that
+ * mtfjsp_step / mtfjsp_step_record (r4_out, done_out both given or both NULL) with these arguments would run, and returns 1; or
+ * returns 0 when this handle's step cannot ride in another launch (shapes beyond the 16-instance register kernel, kernel-time
+ * recording on, a diagnostic kernel override) and the caller must call mtfjsp_step itself; < 0 on errors.  The block is handed to
+ * mtfjsp_encoder_arm_env_step before the mtfjsp_machine_actor_forward whose armed selection writes `mach_idx`. */
+int32_t mtfjsp_step_params_bytes(void);
+int mtfjsp_step_params(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *mach_idx, float *r4_out, float *done_out,
+                       void *params_out, int32_t params_bytes);
 /* host variant: returns MTFJSP_ERR_ACTION if any status word carries MTFJSP_ST_INVALID */
 int mtfjsp_step_host(mtfjsp_handle_t h, const int32_t *task_idx_host, const int32_t *mach_idx_host);
 
@@ -286,6 +295,15 @@ int mtfjsp_encoder_arm_selection(mtfjsp_encoder_t e, int32_t which, int32_t gree
 /* One-shot like mtfjsp_encoder_arm_selection (and only together with it, which = 0): the next job actor forward also
  * writes m_fea1 / the machine mask of every instance's selected task (== mtfjsp_observe_mfea1 on gathered_out). */
 int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_ctx_t *ctx);
+/* One-shot: the NEXT mtfjsp_machine_actor_forward also runs the environment step described by `params` (mtfjsp_step_params) in its
+ * heads launch — one launch and one launch boundary less per rollout step — provided its armed selection (which = 1) writes the
+ * `mach_idx` the block names and the shapes agree.  mtfjsp_encoder_env_step_fused() tells afterwards whether it did (1) or the
+ * caller still has to call mtfjsp_step / mtfjsp_step_record (0: the default — the combined launch is enabled with the environment
+ * variable MTFJSP_FUSED_ENV when the handle is created, because it measured slower than two launches at the headline shape —, also
+ * per-instance BatchNorm mode, f32-instruction heads, kernel-time recording).  Results are those of mtfjsp_step, bit for bit (the
+ * same device code). */
+int mtfjsp_encoder_arm_env_step(mtfjsp_encoder_t e, const void *params, int32_t params_bytes);
+int mtfjsp_encoder_env_step_fused(mtfjsp_encoder_t e);
 /* ---- host-side helpers of the instance generator (instance/generate_allsize_mofjsp_dataset.py:204-216, 241-272).
  * The reference draws "k machines infeasible per task" and the transport times from numpy's legacy RandomState one python call at
  * a time; these take the same draws from the same MT19937 state (key[624] + *pos as RandomState.get_state() returns them; updated
