@@ -1589,6 +1589,18 @@ __global__ __launch_bounds__(512) void k_headsx_envstep(HeadArgs HA, EnvParams E
     env_grp_body_dyn<OBS, 1, 8>(EP, smem);
 }
 static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
+// The same kernel with TEN scorer tiles per chunk: a group of 16 instances with 7..10 candidates / machines each (J10M10: R = 10)
+// goes through the product phases once instead of twice (6 + 4 tiles, each chunk with its own staging, four barriers and latency chain)
+#undef HCH
+#define HCH 10
+__global__ __launch_bounds__(512) void k_headsx10(HeadArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+#include "mtfjsp_headsx_body.h"
+}
+static size_t headsx10_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
+#undef HCH
+#define HCH 6
 
 // ---------------------------------------------------------------------------------------------
 // GIN layer 0, first Linear (12 -> 128) fused with the neighbour aggregation of the raw task features
@@ -2132,6 +2144,7 @@ struct mtfjsp_encoder {
     struct { bool valid = false; const void *f1 = nullptr, *f2 = nullptr; int slot = 0; } prefused;   // the GAT passes of the coming machine forward already ran inside the job actor's heads launch (k_headsx_gat3x)
     bool fuse_gat = !getenv("MTFJSP_NO_FUSED_GAT");
     bool heads_hg8 = !getenv("MTFJSP_NO_HEADS_HG8");
+    bool heads10 = !getenv("MTFJSP_NO_HEADS10");              // k_headsx10 (ten tiles per chunk) for groups of 7..10 tiles
     // the environment step as the tail of the machine heads' launch (mtfjsp_encoder_arm_env_step).  OFF unless MTFJSP_FUSED_ENV is set:
     // bit-identical (tests/test_fused_env_step_gpu.py) and one launch less per step, but measured SLOWER at the headline shape —
     // 220.4 against 217.6 us per step, three alternating runs on one box — because the heads' 8 waves take the 16 instances in two
@@ -2312,6 +2325,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_heads, hipFuncAttributeMaxDynamicSharedMemorySize, (int)heads_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_headsx, hipFuncAttributeMaxDynamicSharedMemorySize, (int)headsx_lds_bytes());
+    if (hipFuncSetAttribute((const void *)k_headsx10, hipFuncAttributeMaxDynamicSharedMemorySize, (int)headsx10_lds_bytes()) != hipSuccess) e->heads10 = false;
     (void)hipFuncSetAttribute((const void *)k_headsx_envstep<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(headsx_lds_bytes() > EnvGrpDynLds<1>::bytes ? headsx_lds_bytes() : EnvGrpDynLds<1>::bytes));
     (void)hipFuncSetAttribute((const void *)k_headsx_envstep<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(headsx_lds_bytes() > EnvGrpDynLds<1>::bytes ? headsx_lds_bytes() : EnvGrpDynLds<1>::bytes));
     (void)hipFuncSetAttribute((const void *)k_headsx_gat3x, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3019,6 +3033,8 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
         else hipLaunchKernelGGL(k_headsx_envstep<double>, dim3(grid), dim3(512), lds, e->stream, ha, *env_tail);
         return;
     }
+    const int ntl = (ha.hg * ha.R + 15) / 16;                       // tiles of a full group
+    if (e->heads10 && ntl > 6 && ntl <= 10) { hipLaunchKernelGGL(k_headsx10, dim3(grid), dim3(512), headsx10_lds_bytes(), e->stream, ha); return; }
     hipLaunchKernelGGL(k_headsx, dim3(grid), dim3(512), headsx_lds_bytes(), e->stream, ha);
 }
 static void arm_sampling(mtfjsp_encoder *e, int which, HeadArgs &ha)
