@@ -2,7 +2,9 @@
 """bench.py — env-steps/sec of the batched MT-FJSP hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+    N > 1, either form: `python bench.py --gpus N ...` starts its N ranks itself (a child `python -m torch.distributed.run`, one
+    process per GPU, before this process has loaded torch or touched a GPU), or the launcher form
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...`.
 
 One "step" = one pass of the hot path over one batch: every one of the B instances on this GPU takes one
 (task, machine) decision — policy forward passes (when --policy actor), m_fea1, the fused env step kernel
@@ -34,6 +36,28 @@ def env_bytes(J, M):
     """algorithmic bytes per env-step of the step kernel."""
     T = J * M
     return 136 * T + 156 * M + 483
+
+
+def env_bytes_rw(J, M):
+    """the read and write halves of env_bytes() (same terms): what a same-footprint streaming kernel must move"""
+    T = J * M
+    return 64 * T + 100 * M + 176, 72 * T + 56 * M + 307
+
+
+def same_footprint_copy(env, B, J, M):
+    """SURVEY §8(d)'s denominator for the step kernel: a plain streaming kernel that reads and writes the step's algorithmic bytes
+    at this batch (mtfjsp_footprint_copy: HIP events around every launch, 40 launches per setting), best grid per access width.
+    16-byte accesses are the fastest a copy can do; 8-byte ones are the step kernel's own dominant width (f64 state)."""
+    r, w = env_bytes_rw(J, M)
+    out = {"read_bytes": B * r, "write_bytes": B * w}
+    for acc in (16, 8):
+        best = None
+        for grid in (256, 512, 1024, 2048, 4096, 8192):
+            avg, mn = env.footprint_copy(B * r, B * w, access_bytes=acc, grid=grid, reps=40)
+            if best is None or avg < best["avg_launch_us"]:
+                best = {"avg_launch_us": avg, "min_launch_us": mn, "grid": grid, "GBps": B * (r + w) / avg / 1e3}
+        out[f"access_{acc}B"] = best
+    return out
 
 
 PMC_FILE = "r03_pmc_traffic.json"
@@ -73,13 +97,18 @@ def env_kernel_large_batch(J, M, E, device, B=262144, episodes=2):
     assert bool(env.info[:, 1].all()) and int((env.status & 0x100).sum()) == 0
     sec = ms / n * 1e-3
     ach = B * env_bytes(J, M) / sec / 1e9
+    copy = same_footprint_copy(env, B, J, M)
     del env
     torch.cuda.empty_cache()
     kname = (("k_env_grp16" if B <= 8192 else "k_env_grp4") if (T <= 64 and M * M <= 64) else
              ("k_env_grp16x2" if B <= 4096 else "k_env_grp4x2") if (T <= 128 and M * M <= 128 and M <= 16) else "k_env_step_grp")
     return {"kernel": kname, "instances": B, "bound": "hbm", "achieved": ach,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBPS,
-            "avg_launch_us": sec * 1e6, "launches": n, "env_steps_per_s": B / sec}
+            "avg_launch_us": sec * 1e6, "launches": n, "env_steps_per_s": B / sec,
+            # SURVEY §8(d)'s own denominator: the same bytes through a plain streaming launch at the same batch
+            "same_footprint_copy": copy,
+            "frac_of_same_footprint_copy": copy["access_16B"]["avg_launch_us"] / (sec * 1e6),
+            "frac_of_same_footprint_copy_8B_accesses": copy["access_8B"]["avg_launch_us"] / (sec * 1e6)}
 
 
 def config_leg(rollout_mod, J, M, E, B, device, steps=240, warm=120):
@@ -290,6 +319,28 @@ def cpu_baseline_subprocess(J, M, E, batch):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: one process per GPU through `python -m torch.distributed.run` on
+    127.0.0.1 (free port), started as a child process of this GPU-free parent.  Rank 0's output is relayed line by line; the
+    return code is the child's."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return p.wait()
+
+
 def main():
     global torch
     if len(sys.argv) >= 6 and sys.argv[1] == "--cpu-baseline-worker":
@@ -317,19 +368,23 @@ def main():
     ap.add_argument("--no-full-handoff", action="store_true", help="skip the untimed full hand-off leg (N>1)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # plain `python bench.py --gpus N` (N > 1): this process has not imported torch or touched a GPU; it starts the N ranks as a
+        # CHILD torch.distributed.run (never an exec), relays rank 0's JSON line and exits with the child's return code
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:          # checked before the CPU legs and before torch is loaded: a mis-launched run exits at once
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     cpu_leg = None
     if world == 1 and not args.no_cpu_baseline:        # before anything initialises the GPU or loads torch in this process
         Jc, Mc, Ec = [int(x) for x in args.size.split("x")]
         cpu_leg = cpu_baseline_subprocess(Jc, Mc, Ec, args.batch)
     import torch as _torch
     torch = _torch
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with python -m torch.distributed.run --nproc-per-node N (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU fallback for the product path"
     # MTFJSP_BENCH_ONE_DEVICE=1 (diagnostic, tests/test_bench_two_ranks_gpu.py): every rank on cuda:0 over gloo — exercises the N > 1
     # control flow of this file on a single-GPU box; its numbers mean nothing (the ranks share one GPU)
@@ -442,10 +497,10 @@ def main():
             del ro.traj
         except AttributeError:
             pass
-        try:
-            full_handoff = full_handoff_leg(rollout_mod, J, M, E, B, local_rank, rank, world, dist)
-        except Exception as ex:                                     # never lose the headline line over the extra leg
-            full_handoff = {"error": repr(ex)}
+        # set-up failures are agreed across the ranks inside the leg and reported in the line; an exception while the ranks are
+        # stepping towards the collective is fatal on purpose (the launcher then ends every rank — catching it on one rank would
+        # leave the others waiting in the all-gather)
+        full_handoff = full_handoff_leg(rollout_mod, J, M, E, B, local_rank, rank, world, dist)
     if rank == 0:
         value = world * B * steps_timed / elapsed
         # dominant kernel by measured device time

@@ -226,6 +226,13 @@ class DeviceBatchEnv:
     def synchronize(self):
         capi.check(self.L.mtfjsp_synchronize(self.h), self.h)
 
+    def footprint_copy(self, read_bytes, write_bytes, access_bytes=16, grid=2048, reps=50):
+        """measurement only: (average, minimum) microseconds per launch of a plain streaming kernel with this footprint"""
+        a, m = C.c_double(), C.c_double()
+        capi.check(self.L.mtfjsp_footprint_copy(self.h, int(read_bytes), int(write_bytes), int(access_bytes), int(grid), int(reps),
+                                                C.byref(a), C.byref(m)), self.h)
+        return a.value, m.value
+
     def timing_begin(self):
         capi.check(self.L.mtfjsp_timing_begin(self.h), self.h)
 

@@ -74,6 +74,7 @@ PROTOTYPES = {
     "mtfjsp_read_state_host": (_I, [_VP, _I, _VP]),
     "mtfjsp_set_scaler_state_host": (_I, [_VP, _I, _I, _VP]),
     "mtfjsp_copy_to_host": (_I, [_VP, _VP, _VP, _SZ]),
+    "mtfjsp_footprint_copy": (_I, [_VP, _SZ, _SZ, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "mtfjsp_timing_begin": (_I, [_VP]),
     "mtfjsp_timing_end": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mtfjsp_encoder_create": (_I, [C.POINTER(EncoderConfig), C.POINTER(_VP)]),

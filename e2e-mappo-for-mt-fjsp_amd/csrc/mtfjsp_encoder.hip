@@ -1162,10 +1162,20 @@ __global__ __launch_bounds__(512) void k_gat3(GatArgs A)
 // f32 transpose tile without padding: 16-byte chunk index XOR (row & 7) makes the row-wise 16-byte operand reads, the
 // C-layout word accesses and the row writes conflict-free
 __device__ __forceinline__ int gx_off(int row, int col) { return row * HD + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); }
+#ifdef MTFJSP_BODY_FUNCS     // diagnostic build: the bodies as __forceinline__ functions (the form whose first launch miscomputed)
+__device__ __forceinline__ void gat3x_body(const GatArgs &A, unsigned char *smem)
+{
+#include "mtfjsp_gat3x_body.h"
+}
+#endif
 __global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MTFJSP_BODY_FUNCS
+    gat3x_body(A, smem);
+#else
 #include "mtfjsp_gat3x_body.h"
+#endif
 }
 static size_t gat3x_lds_bytes() { return (size_t)8 * 2 * 4 * 64 * 16 + (size_t)8 * 16 * HD * 4; }
 
@@ -1549,10 +1559,20 @@ static size_t heads_lds_bytes() { return (size_t)((2 * HCH + 4) * 16 * LDA16 + H
         accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[1][ks], xv[0], accB, 0, 0, 0);           \
     } while (0)
 #define HX_CLDA 132
+#ifdef MTFJSP_BODY_FUNCS
+__device__ __forceinline__ void headsx_body(const HeadArgs &A, unsigned char *smem)
+{
+#include "mtfjsp_headsx_body.h"
+}
+#endif
 __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MTFJSP_BODY_FUNCS
+    headsx_body(A, smem);
+#else
 #include "mtfjsp_headsx_body.h"
+#endif
 }
 // The job actor's heads and the machine path's three GAT passes in ONE launch.  Both kernels give workgroup g the instances
 // 16g .. 16g+15 (heads: HG = 16; GAT: 2 M row tiles per workgroup when the grids agree), and the only thing the GAT needs from
@@ -1563,6 +1583,19 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
 __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
 {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef MTFJSP_BODY_FUNCS
+    headsx_body(HA, smem);
+#ifdef MTFJSP_DBG_VMWAIT        // bisection aid: every global store of the heads part acknowledged and visible device-wide
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __threadfence();
+#endif
+    __syncthreads();
+#ifdef MTFJSP_DBG_POISON        // bisection aid: whatever the GAT part reads from LDS without having written it is a NaN
+    for (int i = threadIdx.x; i < MTFJSP_DBG_POISON / 4; i += 512) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u;
+    __syncthreads();
+#endif
+    gat3x_body(GA, smem);
+#else
     {
         const HeadArgs &A = HA;
 #include "mtfjsp_headsx_body.h"
@@ -1572,6 +1605,7 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
         const GatArgs &A = GA;
 #include "mtfjsp_gat3x_body.h"
     }
+#endif
 }
 // The machine actor's heads and the environment step of the same 16 instances in ONE launch (round-2 review, item 3): the heads end
 // with the machine selection of exactly the instances k_env_grp16 would give this blockIdx, and nothing else the step reads is written
@@ -2129,7 +2163,7 @@ struct mtfjsp_encoder {
                        (getenv("MTFJSP_HEADS_F32MFMA") ? 4 : 0) | (getenv("MTFJSP_GIN0_VALU") ? 8 : 0);
     // resident GIN kernel (mtfjsp_gin_resident.h): eligibility decided at create time, then verified by a census launch
     bool res_ok = false; int res_ipc = 0, res_grid = 0;
-    double *res_stats = nullptr;            // [2 sets][GR_STATS_SET]; forward n uses set n & 1 and zeroes the other one
+    double *res_stats = nullptr;            // [2 sets][GR_STATS_SET] 64-bit count-carrying fixed-point words (mtfjsp_gin_resident.h); forward n uses set n & 1 and zeroes the other one
     unsigned long long *res_bar = nullptr;  // [17 * 16] barrier words
     unsigned *res_fail = nullptr;           // device address of *res_fail_host
     volatile unsigned *res_fail_host = nullptr;   // host-mapped word the kernel sets when a grid barrier times out: polled at every forward entry (no synchronisation)
@@ -2780,9 +2814,17 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
         a.wsinv[i] = e->wx32_sinv.at(P + lin[i] + ".weight");
         a.gamma[i] = W(P + bn[i] + ".weight"); a.beta[i] = W(P + bn[i] + ".bias");
     }
+    for (int i = 0; i < 6; i++) {                                 // the image scales are powers of two: their exponents (the fixed-point statistics divide them out)
+        int ex = 0;
+        const float mant = frexpf(a.wsinv[i], &ex);                // wsinv = 0.5 * 2^ex
+        if (mant != 0.5f) { e->err = "resident GIN: a weight image scale is not a power of two"; return MTFJSP_ERR_STATE; }
+        a.wexp[i] = 1 - ex;                                        // log2(wscale) = -log2(wsinv)
+    }
+    static const int poll_mode = getenv("MTFJSP_GIN_RES_POLL") ? atoi(getenv("MTFJSP_GIN_RES_POLL")) : 0;
+    a.poll_mode = poll_mode;
     const int set = (int)(e->res_epoch & 1);
-    a.stats = e->res_stats + (size_t)set * GR_STATS_SET;
-    a.stats_next = e->res_stats + (size_t)(set ^ 1) * GR_STATS_SET;
+    a.stats = reinterpret_cast<unsigned long long *>(e->res_stats) + (size_t)set * GR_STATS_SET;
+    a.stats_next = reinterpret_cast<unsigned long long *>(e->res_stats) + (size_t)(set ^ 1) * GR_STATS_SET;
     a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail; a.range_flag = e->range_flag;
     a.candidate = candidate; a.pooled = h_pooled; a.cand_feat = cand_feat; a.h_nodes = h_nodes; a.zspill = e->res_zspill;
     a.inv_rows = 1.0 / ((double)B * (double)T);
@@ -2987,6 +3029,7 @@ extern "C" int mtfjsp_encoder_set_product_mode(mtfjsp_encoder_t e, int32_t f32_i
 {
     if (!e || f32_instruction_mask < 0 || f32_instruction_mask > 31) return MTFJSP_ERR_ARG;
     e->f32_products = f32_instruction_mask;
+    e->prefused.valid = false;                       // (GAT passes done ahead by another kernel family are not reused across a mode change)
     return MTFJSP_OK;
 }
 // exact multi-shard BatchNorm: after the launch that completes a BatchNorm's column sums, hand them to the caller's reduction
@@ -3001,6 +3044,7 @@ extern "C" int mtfjsp_encoder_set_stats_reduce(mtfjsp_encoder_t e, mtfjsp_stats_
 {
     if (!e || (fn && global_batch < e->cfg.batch)) return MTFJSP_ERR_ARG;
     e->reduce_fn = fn; e->reduce_user = user;
+    e->prefused.valid = false;
     e->reduce_scale = fn ? (double)global_batch / (double)e->cfg.batch : 1.0;
     return MTFJSP_OK;
 }
@@ -3008,6 +3052,7 @@ extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instan
 {
     if (!e || per_instance < 0 || per_instance > 1) return MTFJSP_ERR_ARG;
     e->bn_mode = per_instance;
+    e->prefused.valid = false;
     return MTFJSP_OK;
 }
 
@@ -3239,6 +3284,9 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
     for (const char *k : need)
         if (!e->w.count(k)) { e->err = std::string("missing weight: ") + k; return MTFJSP_ERR_STATE; }
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    // this forward's GAT passes overwrite e->node and move on to another statistics slot: GAT passes the job actor's heads launch
+    // ran ahead for a coming machine-actor forward (k_headsx_gat3x) are gone, that forward has to redo them
+    e->prefused.valid = false;
     { const int prc = res_poll_failure(e); if (prc) return prc; }
     const int B = e->cfg.batch;
     auto W = [&](const std::string &k) { return e->w.at(k); };

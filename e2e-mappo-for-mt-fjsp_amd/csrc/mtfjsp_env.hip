@@ -2311,6 +2311,61 @@ extern "C" int mtfjsp_gae(mtfjsp_handle_t h, int32_t S, const float *r, int64_t 
     return MTFJSP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Measurement only ("fraction = achieved / measured copy bandwidth of a same-footprint streaming kernel"): a launch
+// that reads `read_bytes` and writes `write_bytes` with W-byte accesses, perfectly coalesced, nothing else — the denominator the
+// step kernel's achieved bytes/s are compared with at the same batch.  Word i of the read stream is copied to word i of the write
+// stream while both last; the rest of the longer stream is read into a checksum / filled with it.
+template <typename WORD>
+__global__ __launch_bounds__(256) void k_footprint_copy(const WORD *__restrict__ src, WORD *__restrict__ dst, size_t nr, size_t nw, unsigned *sink)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n = nr > nw ? nr : nw;
+    unsigned acc = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        WORD v = {};
+        if (i < nr) { v = src[i]; acc ^= reinterpret_cast<const unsigned *>(&v)[0]; }
+        if (i < nw) dst[i] = v;
+    }
+    if (acc == 0x9e3779b9u) *sink = acc;                      // keeps the read-only tail alive
+}
+extern "C" int mtfjsp_footprint_copy(mtfjsp_handle_t h, size_t read_bytes, size_t write_bytes, int32_t access_bytes, int32_t grid, int32_t reps,
+                                     double *avg_us_out, double *min_us_out)
+{
+    if (!h || (access_bytes != 4 && access_bytes != 8 && access_bytes != 16) || grid < 1 || reps < 1 || !avg_us_out) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    const size_t nr = read_bytes / access_bytes, nw = write_bytes / access_bytes;
+    void *src = nullptr, *dst = nullptr; unsigned *sink = nullptr;
+    HIPCHK(h, hipMalloc(&src, nr * access_bytes + 16)); HIPCHK(h, hipMalloc(&dst, nw * access_bytes + 16)); HIPCHK(h, hipMalloc((void **)&sink, 4));
+    HIPCHK(h, hipMemsetAsync(src, 1, nr * access_bytes + 16, h->stream));
+    std::vector<hipEvent_t> ev(2 * (size_t)reps);
+    for (auto &e : ev) HIPCHK(h, hipEventCreate(&e));
+    auto launch = [&]() {
+        if (access_bytes == 16) hipLaunchKernelGGL(k_footprint_copy<uint4>, dim3(grid), dim3(256), 0, h->stream, (const uint4 *)src, (uint4 *)dst, nr, nw, sink);
+        else if (access_bytes == 8) hipLaunchKernelGGL(k_footprint_copy<uint2>, dim3(grid), dim3(256), 0, h->stream, (const uint2 *)src, (uint2 *)dst, nr, nw, sink);
+        else hipLaunchKernelGGL(k_footprint_copy<unsigned>, dim3(grid), dim3(256), 0, h->stream, (const unsigned *)src, (unsigned *)dst, nr, nw, sink);
+    };
+    for (int i = 0; i < 3; i++) launch();                     // warm: code object, clocks, caches in the state repeated launches see
+    for (int i = 0; i < reps; i++) {
+        HIPCHK(h, hipEventRecord(ev[2 * i], h->stream));
+        launch();
+        HIPCHK(h, hipEventRecord(ev[2 * i + 1], h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double tot = 0, mn = 1e30;
+    for (int i = 0; i < reps; i++) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        tot += ms; mn = ms < mn ? ms : mn;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    (void)hipFree(src); (void)hipFree(dst); (void)hipFree(sink);
+    *avg_us_out = tot / reps * 1e3;
+    if (min_us_out) *min_us_out = mn * 1e3;
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+
 extern "C" int mtfjsp_timing_begin(mtfjsp_handle_t h)
 {
     if (!h) return MTFJSP_ERR_ARG;

@@ -90,8 +90,10 @@ struct GinResArgs {
                                           // the others: two f16 planes of W * wscale)
     float wsinv[6];                       // 1 / wscale of each image (a power of two; 1 for the first)
     const float *gamma[6], *beta[6];      // BatchNorm after each Linear (mlps.0.bn0, mlps.0.bn1, outer 0, mlps.1.bn0, mlps.1.bn1, outer 1)
-    double *stats;                        // this forward's accumulators (zero on entry): [6 layers][8 groups][128][2]
-    double *stats_next;                   // the set of the next forward: zeroed here
+    unsigned long long *stats;            // this forward's accumulators (zero on entry): [6 layers][8 groups][128 columns][sum | sumsq][2 limbs], see gr_fix_encode
+    unsigned long long *stats_next;       // the set of the next forward: zeroed here
+    int wexp[6];                          // log2 of each weight image's scale (wsinv = 2^-wexp)
+    int poll_mode;                        // 0: every thread polls its own 16 words; 1: one word per group first (diagnostic A/B)
     unsigned long long *bar;              // barrier words (monotonic counters, never reset)
     unsigned long long epoch;             // launches on `bar` so far
     unsigned *fail;                       // set when a barrier timed out (the outputs are then garbage)
@@ -106,7 +108,7 @@ struct GinResArgs {
     unsigned expect_extra;                // diagnostic (MTFJSP_GIN_RES_FAIL_AT): the barriers wait for this many workgroups that do not exist -> time-out path
     unsigned long long *stamps;           // diagnostic build only (-DGR_STAMP): [blocks][64] s_memrealtime at the phase boundaries
 };
-#define GR_STATS_PART (6 * 8 * HD * 2)                            // doubles: per layer, per dispatch group: (sum, sumsq) per column
+#define GR_STATS_PART (6 * 8 * HD * 2 * 2)                        // 64-bit words: per layer, per dispatch group: (sum, sumsq) per column, two limbs each
 #define GR_STATS_SET GR_STATS_PART
 #ifdef GR_STAMP
 #define GR_STAMP_AT(i) do { if (tid == 0 && A.stamps) A.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -171,6 +173,36 @@ __device__ __forceinline__ float gr_sum32(float x)
 {
     x = row_sum16(x);
     return x + __shfl_xor(x, 16);
+}
+
+// ---- BatchNorm column sums across the grid WITHOUT a separate barrier: every 64-bit accumulator word carries its own arrival count.
+// A workgroup's f32 column sum x is turned into a 102-bit fixed-point integer round-free (x * 2^44 is an integer for |x| >= 2^-20;
+// smaller values lose the bits below 2^-44) and split into two limbs of 48 + 54 bits; each limb goes out as ONE integer atomic add
+// of (1 << 58 | limb) — the low limb is non-negative, the high limb is biased by 2^51 — so after n contributions a word holds
+// n in its top 6 bits and the exact sum of the limbs below (n <= 63 workgroups per dispatch group, |x| < 2^54).  A reader that
+// finds the expected count in a word HAS that word's complete sum: no data atomics to wait for before signalling, no counter
+// atomics, no release flag, no second read — the five dependent memory round trips of the counter barrier become one atomic and
+// one read.  Integer sums are exact and order-independent: the statistics (and the forward) are bit-reproducible run to run,
+// which the f64 atomics of the streaming launches are not.  The scale of the weight image (a power of two) is divided out of the
+// exponent here, so the range |sum| < 2^54 is that of the true z.
+#define GR_FIX_FRAC 44
+#define GR_FIX_LIMIT 0x1p54f
+#define GR_FIX_BIAS (1ull << 51)
+#define GR_FIX_ONE (1ull << 58)
+#define GR_FIX_PAYLOAD (GR_FIX_ONE - 1ull)
+__device__ __forceinline__ void gr_fix_encode(float x, int exp2, unsigned long long &lo, unsigned long long &hi)
+{
+    const double y = __builtin_ldexp((double)x, GR_FIX_FRAC - exp2);          // exact
+    const double hd = __builtin_floor(y * 0x1p-48);
+    const double ld = y - hd * 0x1p48;                                        // exact, in [0, 2^48)
+    lo = GR_FIX_ONE | (unsigned long long)ld;
+    hi = GR_FIX_ONE | (unsigned long long)((long long)hd + (long long)GR_FIX_BIAS);
+}
+// total of `n` contributions from the summed payloads of their two limbs
+__device__ __forceinline__ double gr_fix_decode(unsigned long long lo_sum, unsigned long long hi_sum, unsigned n)
+{
+    const long long hs = (long long)hi_sum - (long long)n * (long long)GR_FIX_BIAS;
+    return ((double)hs * 0x1p48 + (double)lo_sum) * 0x1p-44;
 }
 
 // Grid-wide barrier over `nblk` co-resident workgroups that also completes a reduction: hierarchical over the 8 dispatch
@@ -241,7 +273,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 
     // ---------------------------------------------------------------- prologue: features + adjacency to LDS, zero the planes
     GR_STAMP_AT(32);
-    for (int i = blockIdx.x * 256 + tid; i < GR_STATS_SET; i += (int)gridDim.x * 256) A.stats_next[i] = 0.0;
+    for (int i = blockIdx.x * 256 + tid; i < GR_STATS_SET; i += (int)gridDim.x * 256) A.stats_next[i] = 0ull;
     {
         // (the candidate indices are requested with everything else: their use below would otherwise be a second memory round trip)
         int cand_pre[(GR_MAXCAND + 255) / 256];
@@ -518,41 +550,82 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         }
         const float colsum = fold_stats();                        // (GR_VRES 0: tile 17's sums were taken when it was stored)
         if (k == 1) GR_STAMP_AT(2);
-        double *part = A.stats + ((size_t)k * 8 + (blockIdx.x & 7)) * (2 * HD);
+        // thread tid holds this workgroup's (column tid >> 1, sum | sumsq): two integer atomics, fire and forget
+        const unsigned grp = blockIdx.x & 7u;
+        unsigned long long *part = A.stats + (((size_t)k * 8 + grp) * 256 + tid) * 2;
         {
-            atomicAdd(&part[tid], (double)colsum);                // [col][2] interleaved: thread tid -> (column tid >> 1, sum | sumsq)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int kind = tid & 1;
+            float x = colsum;
+            if (!(__builtin_fabsf(x) * (kind ? A.wsinv[k] * A.wsinv[k] : A.wsinv[k]) < GR_FIX_LIMIT)) {
+                // not a number (an operand beyond the f16 range upstream: (inf | -inf) pieces) or beyond the fixed-point range: the host
+                // repeats the forward on the f32-instruction kernels; the contribution still goes out so that nobody waits for it
+                if (A.range_flag) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                x = 0.f;
+            }
+            unsigned long long lo, hi;
+            gr_fix_encode(x, kind ? 2 * A.wexp[k] : A.wexp[k], lo, hi);
+            (void)__hip_atomic_fetch_add(&part[0], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(&part[1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (k == 1) GR_STAMP_AT(3);
-        // requests that do not depend on the other workgroups go out before the wait: the next Linear's weight fragments
+        // requests that do not depend on the other workgroups go out behind them: the next Linear's weight fragments
         // and this BatchNorm's affine parameters
         if constexpr (k < 5) load_weights(k + 1);
-        const float ga = A.gamma[k][tid & (HD - 1)], be = A.beta[k][tid & (HD - 1)];
+        const float ga = A.gamma[k][tid >> 1], be = A.beta[k][tid >> 1];
         GR_STAMP_AT(5 + 4 * k);
-        gr_grid_barrier(A.bar, gen0 + k + 1, nblk, A.fail, s_flag);
-        GR_STAMP_AT(6 + 4 * k);
-        if (tid < HD) {
-            const double *grp0 = A.stats + (size_t)k * 8 * (2 * HD) + 2 * tid;       // this column's (sum, sumsq) in group 0; groups are 2*HD apart
-            double gs[8], gq[8];
+        {
+            // every thread collects its own (column, kind) from the 8 dispatch groups: 16 words, complete when each carries its
+            // group's size in the count field
+            const unsigned long long *w0 = A.stats + ((size_t)k * 8 * 256 + tid) * 2;
+            unsigned long long want[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                gs[j] = __hip_atomic_load(&grp0[j * 2 * HD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                gq[j] = __hip_atomic_load(&grp0[j * 2 * HD + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int j = 0; j < 8; j++) want[j] = (unsigned long long)((nblk >> 3) + ((unsigned)j < (nblk & 7u) ? 1u : 0u));
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            unsigned long long slo = 0, shi = 0;
+            if (A.poll_mode == 1) {                                // one word per group first: lanes 0..7 of every wave (no LDS hand-off)
+                const unsigned long long *sw = A.stats + (((size_t)k * 8 + (lane & 7)) * 256 + 255) * 2 + 1;
+                const unsigned long long sneed = (unsigned long long)((nblk >> 3) + ((unsigned)(lane & 7) < (nblk & 7u) ? 1u : 0u));
+                for (;;) {
+                    const unsigned long long v = __hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_read_exec() == __builtin_amdgcn_ballot_w64((v >> 58) >= sneed)) break;
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) break;
+                }
             }
-            double su = 0.0, sq = 0.0;
+            for (;;) {
+                unsigned long long vl[8], vh[8];
 #pragma unroll
-            for (int j = 0; j < 8; j++) { su += gs[j]; sq += gq[j]; }
-            // (inf | -inf) operand pieces give NaN products, which the ReLU of the next layer would turn into silent zeros
-            if (blockIdx.x == 0 && A.range_flag && (su != su || sq != sq)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            // the accumulators hold z * wscale (power of two, exact): statistics of z, scale applied to the stored value
-            const double is = (double)A.wsinv[k];
-            const double mean = su * A.inv_rows * is;
-            double var = sq * A.inv_rows * is * is - mean * mean; // biased variance (training-mode BN)
-            if (var < 0) var = 0;
-            const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
-            const float s = rstd * ga;
-            s_bn[tid] = s * A.wsinv[k];
-            s_bn[HD + tid] = be - (float)mean * s;
+                for (int j = 0; j < 8; j++) {
+                    vl[j] = __hip_atomic_load(w0 + (size_t)j * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    vh[j] = __hip_atomic_load(w0 + (size_t)j * 512 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool done = true;
+                slo = 0; shi = 0;
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    done = done && (vl[j] >> 58) == want[j] && (vh[j] >> 58) == want[j];
+                    slo += vl[j] & GR_FIX_PAYLOAD; shi += vh[j] & GR_FIX_PAYLOAD;
+                }
+                if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;                  // (wave-uniform exit: the pair exchange below is cross-lane)
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) {                 // 4 ms at 100 MHz: not all workgroups are resident
+                    __hip_atomic_store(A.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (host-mapped word: the host polls it without synchronising)
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            GR_STAMP_AT(6 + 4 * k);
+            const double tot = gr_fix_decode(slo, shi, nblk);      // the true-z (sum | sumsq) of this thread's column over all rows
+            const double oth = __shfl_xor(tot, 1);
+            if (!(tid & 1)) {
+                const double mean = tot * A.inv_rows;
+                double var = oth * A.inv_rows - mean * mean;       // biased variance (training-mode BN)
+                if (var < 0) var = 0;
+                const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
+                const float s = rstd * ga;
+                // the accumulators hold z * wscale (power of two, exact): statistics of z, scale applied to the stored value
+                s_bn[tid >> 1] = s * A.wsinv[k];
+                s_bn[HD + (tid >> 1)] = be - (float)mean * s;
+            }
         }
         LDS_BARRIER();
         GR_STAMP_AT(7 + 4 * k);

@@ -5,8 +5,41 @@ advantage normalisation `(adv - mean) / (std + 1e-5)` of ppo:485,532 (RCCL over 
 gloo in the CPU tests).  GAE itself (ppo:438-536) is a reverse scan over the S stored steps and is per-instance,
 so it runs on each shard locally.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def active(group=None):
+    """is there a collective to run?  A process group with more than one rank — or, for the tests that drive the RCCL branches on
+    a single GPU, any initialised group when MTFJSP_DIST_ALWAYS_COLLECT is set (a world-size-1 all-gather is a copy, but it goes
+    through the same calls)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or bool(os.environ.get("MTFJSP_DIST_ALWAYS_COLLECT"))
+
+
+def device_collectives(group=None):
+    """can `group` run collectives on device tensors (RCCL: backend "nccl", also as the cuda half of "cpu:gloo,cuda:nccl" or of a
+    group created without a backend name)?  Decided by capability, not by the configured name; gloo-only groups go through host
+    copies."""
+    try:
+        return "nccl" in str(dist.get_backend(group)).lower() or \
+            "nccl" in str((group or dist.group.WORLD)._get_backend(torch.device("cuda")).name()).lower()
+    except Exception:
+        return False
+
+
+def agree_any(flag, group=None):
+    """True on every rank iff `flag` is true on at least one (MAX all-reduce of one word; the ranks call it at the same point of
+    their step sequence — Rollout.finish_buffer before the hand-off's all-gather)."""
+    if not active(group):
+        return bool(flag)
+    dev = "cuda" if device_collectives(group) else "cpu"
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t.item() > 0.5)
 
 
 def shard_range(total, rank, world):
@@ -31,12 +64,17 @@ def gae(rewards, values, next_values, dones, gamma, lam):
 
 def all_gather_columns(x, group=None):
     """[S,B_local] on every rank -> [S,B_total] (rank-major column blocks) on every rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not active(group):
         return x
     world = dist.get_world_size(group)
     xs = x.contiguous()
     out = torch.empty((world * xs.shape[0],) + tuple(xs.shape[1:]), dtype=xs.dtype, device=xs.device)   # dim-0 concat form
-    dist.all_gather_into_tensor(out, xs, group=group)
+    if xs.is_cuda and not device_collectives(group):
+        oc = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(oc, xs.cpu(), group=group)
+        out.copy_(oc)
+    else:
+        dist.all_gather_into_tensor(out, xs, group=group)
     out = out.view((world,) + tuple(xs.shape))
     return torch.cat(list(out.unbind(0)), dim=1)
 
@@ -51,7 +89,7 @@ def all_gather_advantages(tensors, group=None, timed=False):
         return ([], info) if timed else []
     packed = torch.stack([t.contiguous() for t in tensors], 0)
     info["bytes_per_rank"] = packed.numel() * packed.element_size()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not active(group):
         out = list(packed.unbind(0))
         return (out, info) if timed else out
     world = dist.get_world_size(group)
@@ -61,7 +99,7 @@ def all_gather_advantages(tensors, group=None, timed=False):
     if timed and packed.is_cuda:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    if packed.is_cuda and dist.get_backend(group) != "nccl":     # CPU backend (gloo in the two-process tests): through host copies
+    if packed.is_cuda and not device_collectives(group):          # CPU-only group (gloo in the two-process tests): through host copies
         oc = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(oc, packed.cpu(), group=group)
         out.copy_(oc)
@@ -101,7 +139,7 @@ def bn_stats_allreduce(group=None):
 
     def fn(ptr, count):
         t = torch.as_tensor(_DeviceF64(ptr, count), device="cuda")
-        if td.get_backend(group) == "nccl":
+        if device_collectives(group):
             td.all_reduce(t, group=group)
         else:
             c = t.cpu()

@@ -91,6 +91,10 @@ class Rollout:
         self.last_gather = None
         self.n_handoffs = 0
         self.n_resident_failures = 0
+        self.n_dropped_buffers = 0         # buffers every rank dropped together because one of them reported a failure (world > 1)
+        self.tainted = False               # this rank's current buffer contains invalid steps and will be dropped at its boundary
+        self._new_episode = False
+        self.exact_bn = False
         self.global_handoff, self.time_handoff = global_handoff, time_handoff
         self.last_full = None
         self.traj = None
@@ -119,6 +123,7 @@ class Rollout:
             if exact_bn and world > 1:
                 from . import dist as _dist
                 self.actor.enc.set_stats_reduce(_dist.bn_stats_allreduce(), world * batch)
+                self.exact_bn = True
 
     def describe(self):
         if self.policy == "actor":
@@ -153,9 +158,13 @@ class Rollout:
         return self.w3_pool[self.episode % n]
 
     def step(self, force=None):
-        """one batched decision step; a reported time-out of the single-launch GIN kernel (capi.ERR_RETRY: every output since that
-        launch is invalid, the encoder has switched to the streaming launches) discards the trajectory buffer collected so far and
-        restarts the episode."""
+        """one batched decision step; a reported time-out of the single-launch GIN kernel or an operand beyond the f16 range
+        (capi.ERR_RETRY: every output since that launch is invalid, the encoder has switched kernels) discards the trajectory
+        buffer collected so far and restarts the episode.
+        Single process: the buffer restarts at once.  With a process group (`_lockstep`): the hand-off at the end of a buffer is
+        a collective, so every rank must reach it after the same number of step() calls — the failing rank keeps its position in
+        the buffer, marks the buffer as tainted, restarts its episode and runs the rest of the buffer without recording; at the
+        buffer boundary the ranks agree (one MAX all-reduce of a flag, finish_buffer) and ALL of them drop the buffer."""
         try:
             self._step(force)
         except capi.MtfjspError as ex:
@@ -164,12 +173,20 @@ class Rollout:
             self._restart_after_failure()
             self._step(force)
 
+    @property
+    def _lockstep(self):
+        from . import dist as _dist
+        return self.collect and _dist.active()
+
     def _restart_after_failure(self):
         self.n_resident_failures += 1
-        self.buf_pos = 0
         self.t_in_ep = 0                                   # the next step resets every instance (fresh weights, scaler returns)
-        if self.full:
-            self.traj.reset()
+        if self._lockstep:
+            self.tainted = True                            # buf_pos keeps counting: the collective stays aligned across ranks
+        else:
+            self.buf_pos = 0
+            if self.full:
+                self.traj.reset()
         self.actor.begin_episode()
 
     def _step(self, force=None):
@@ -185,7 +202,18 @@ class Rollout:
             if self.full:
                 self.traj.begin_episode(w3)
         last = self.t_in_ep == self.T - 1
-        if self.full:
+        if self.exact_bn:
+            # the BatchNorm all-reduces make the ranks' forwards collective: every rank must notice an asynchronous failure flag
+            # at the SAME step, so the device is drained before the forward entry polls it (this mode synchronises after each of
+            # its seven all-reduces anyway)
+            torch.cuda.synchronize()
+        if self.tainted:
+            # rest of a buffer that will be dropped (see step()): decisions and env steps without recording
+            self.actor.act(env, self.nsteps, self.task, self.mach, self.job, force=force, env_step=()) or env.step(self.task, self.mach)
+            self.buf_pos += 1
+            if self.buf_pos == self.S:
+                self.finish_buffer()
+        elif self.full:
             tb = self.traj
             sl = tb.slot()
             tb.snapshot(env, "pre")
@@ -223,7 +251,8 @@ class Rollout:
                 env.step(self.task, self.mach)
         self.nsteps += 1
         self.t_in_ep += 1
-        if self.t_in_ep == self.T:
+        if self.t_in_ep == self.T or self._new_episode:
+            self._new_episode = False
             self.t_in_ep = 0
             self.episode += 1
 
@@ -232,19 +261,48 @@ class Rollout:
         collective of the data path — all-gather of the per-shard advantages (RCCL over xGMI when world > 1) for the
         GLOBAL normalisation (adv - mean) / (std + 1e-5) — leaving normalised advantages + value targets on device."""
         from . import advantages as A
+        from . import dist as _dist
         S, T, B = self.S, self.T, self.B
         # one synchronisation per buffer: a forward of this buffer that failed asynchronously (single-launch GIN kernel, see
-        # Encoder.check) must not reach the update — raises capi.ERR_RETRY, which step() turns into a restart of the buffer
-        self.actor.enc.check()
+        # Encoder.check) must not reach the update.  Single process: capi.ERR_RETRY propagates and step() restarts the buffer.
+        # With a process group the ranks first AGREE (MAX all-reduce of one flag) whether any of them has a tainted buffer; if so
+        # every rank drops its buffer here and none enters the all-gather — the collective sequence stays identical on all ranks.
+        mv4 = mv4_ = None
+        whole = self.full and self.actor.has_critic and self.global_handoff
+        if self._lockstep:
+            failed = self.tainted
+            try:
+                self.actor.enc.check()
+                if whole and not failed:
+                    mv4, mv4_ = A.sample_global_values(self.actor.enc, self.traj)
+                    self.actor.enc.check()                  # (the 2 S critic forwards may have failed asynchronously as well)
+            except capi.MtfjspError as ex:
+                if ex.code != capi.ERR_RETRY:
+                    raise
+                if not failed:
+                    self.n_resident_failures += 1
+                failed = True
+            if _dist.agree_any(failed):
+                self.n_dropped_buffers += 1
+                self.buf_pos = 0
+                if self.full:
+                    self.traj.reset()
+                if failed:                                  # this rank's episode is not aligned with the buffer any more (or invalid)
+                    self._new_episode = True
+                self.tainted = False
+                return
+        else:
+            self.actor.enc.check()
         # v of step t = slot t, v_ of step t = slot t+1 of its episode; the terminal step's v_ is the post-terminal forward
         # (run:451-475).  The deltas carry NO (1-done) factor (ppo:473,523): the terminal v_ enters every advantage of the
         # episode; (1-done) only stops the carried gae at episode boundaries.
         jv, mv = self.buf_jv[:, :T].reshape(S, B, 2), self.buf_mv[:, :T].reshape(S, B, 2)
         jv_, mv_ = self.buf_jv[:, 1:].reshape(S, B, 2), self.buf_mv[:, 1:].reshape(S, B, 2)
-        if self.full and self.actor.has_critic and self.global_handoff:
+        if whole:
             # the whole hand-off of ppo:628-703: the global critic sampled on every stored pre- and post-decision state (2 S
             # forwards, no gradient), 4 global + 4 local advantages and the 8 value tensors in ONE all-gather
-            mv4, mv4_ = A.sample_global_values(self.actor.enc, self.traj)
+            if mv4 is None:
+                mv4, mv4_ = A.sample_global_values(self.actor.enc, self.traj)
             h = A.full_handoff(self.env, self.buf_r, jv, jv_, mv, mv_, mv4, mv4_, self.buf_done, self.gamma, self.lam,
                                timed=self.time_handoff)
             self.last_full = h

@@ -206,6 +206,14 @@ int mtfjsp_gae(mtfjsp_handle_t h, int32_t S, const float *r, int64_t r_ss, int64
 int mtfjsp_timing_begin(mtfjsp_handle_t h);
 int mtfjsp_timing_end(mtfjsp_handle_t h, double *step_ms_total, int64_t *step_launches);
 
+/* measurement only (the step kernel's achieved bytes/s are to be compared with "the measured copy bandwidth of a
+ * same-footprint streaming kernel on the same GPU"): `reps` launches of a kernel that reads read_bytes and writes write_bytes
+ * with access_bytes-wide (4, 8 or 16), fully coalesced accesses on `grid` workgroups of 256 threads, HIP events around every
+ * launch on the handle's stream; returns the average and the minimum launch duration in microseconds.  Scratch buffers are
+ * allocated and freed inside the call.  Replaces nothing in the reference (no reference counterpart). */
+int mtfjsp_footprint_copy(mtfjsp_handle_t h, size_t read_bytes, size_t write_bytes, int32_t access_bytes, int32_t grid, int32_t reps,
+                          double *avg_us_out, double *min_us_out);
+
 /* ------------------------------------------------------------------ encoder (rollout forward passes) */
 typedef struct {
     int32_t n_job, n_machine, batch;
