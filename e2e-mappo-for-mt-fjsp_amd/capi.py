@@ -100,6 +100,7 @@ PROTOTYPES = {
     "mtfjsp_encoder_check": (_I, [_VP, C.POINTER(C.c_int32)]),
     "mtfjsp_encoder_resident_failures": (_I, [_VP, C.POINTER(C.c_int64)]),
     "mtfjsp_encoder_range_fallbacks": (_I, [_VP, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "mtfjsp_encoder_peek_nodes_host": (_I, [_VP, _VP, C.c_int64]),
     "mtfjsp_encoder_timing_begin": (_I, [_VP]),
     "mtfjsp_encoder_timing_end": (_I, [_VP, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "mtfjsp_encoder_timing_query": (_I, [_VP, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

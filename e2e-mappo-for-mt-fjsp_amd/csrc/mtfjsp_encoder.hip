@@ -528,6 +528,17 @@ __device__ __forceinline__ void split3x4(const float (&v)[4], uint2 &p0, uint2 &
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 #define X2_TILE (2 * X6_PLANE)
+// the low pieces f16(x - (float)high piece) of a value pair in two instructions: v_fma_mixlo_f16 / v_fma_mixhi_f16 take the f16
+// high piece as an f32 operand and round the (exact) f32 remainder to f16 themselves — the same single rounding as a subtraction
+// followed by a conversion, two instructions less per pair
+__device__ __forceinline__ unsigned rem16x2(unsigned hi_pair, float x0, float x1)
+{
+    unsigned r;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hi_pair), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(hi_pair), "v"(x1));
+    return r;
+}
+#ifdef MTFJSP_SPLIT_PLAIN    // A/B: the split written as conversions and subtractions
 __device__ __forceinline__ void split2x4(const float (&v)[4], uint2 &p0, uint2 &p1)
 {
     const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
@@ -537,6 +548,16 @@ __device__ __forceinline__ void split2x4(const float (&v)[4], uint2 &p0, uint2 &
     p0 = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
     p1 = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
 }
+#else
+__device__ __forceinline__ void split2x4(const float (&v)[4], uint2 &p0, uint2 &p1)
+{
+    const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
+    const h16x2 a = __builtin_convertvector(v01, h16x2), b = __builtin_convertvector(v23, h16x2);
+    const unsigned pa = __builtin_bit_cast(unsigned, a), pb = __builtin_bit_cast(unsigned, b);
+    p0 = make_uint2(pa, pb);
+    p1 = make_uint2(rem16x2(pa, v[0], v[1]), rem16x2(pb, v[2], v[3]));
+}
+#endif
 // the same split with the remainders taken by v_fma_mix_f32 (f16 piece as an f32 operand: x - (float)hi in ONE instruction
 // instead of two conversions and a subtraction; exactly rounded either way, see gr_rem2 in mtfjsp_gin_resident.h)
 __device__ __forceinline__ void split2x4m(const float (&v)[4], uint2 &p0, uint2 &p1)
@@ -544,14 +565,8 @@ __device__ __forceinline__ void split2x4m(const float (&v)[4], uint2 &p0, uint2 
     const f32x2 v01 = {v[0], v[1]}, v23 = {v[2], v[3]};
     const h16x2 a = __builtin_convertvector(v01, h16x2), b = __builtin_convertvector(v23, h16x2);
     const unsigned pa = __builtin_bit_cast(unsigned, a), pb = __builtin_bit_cast(unsigned, b);
-    float r0, r1, r2, r3;
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(pa), "v"(v[0]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(pa), "v"(v[1]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r2) : "v"(pb), "v"(v[2]));
-    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r3) : "v"(pb), "v"(v[3]));
-    const h16x2 c = __builtin_convertvector(f32x2{r0, r1}, h16x2), d = __builtin_convertvector(f32x2{r2, r3}, h16x2);
     p0 = make_uint2(pa, pb);
-    p1 = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+    p1 = make_uint2(rem16x2(pa, v[0], v[1]), rem16x2(pb, v[2], v[3]));
 }
 template <int PRO>
 __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
@@ -1162,7 +1177,10 @@ __global__ __launch_bounds__(512) void k_gat3(GatArgs A)
 // f32 transpose tile without padding: 16-byte chunk index XOR (row & 7) makes the row-wise 16-byte operand reads, the
 // C-layout word accesses and the row writes conflict-free
 __device__ __forceinline__ int gx_off(int row, int col) { return row * HD + ((((col >> 2) ^ (row & 7)) << 2) | (col & 3)); }
-#ifdef MTFJSP_BODY_FUNCS     // diagnostic build: the bodies as __forceinline__ functions (the form whose first launch miscomputed)
+#ifndef MTFJSP_BODY_FUNCS
+#define MTFJSP_BODY_FUNCS 0   // diagnostic builds: bit 0 = the GAT statements, bit 1 = the heads statements as __forceinline__ functions
+#endif
+#if MTFJSP_BODY_FUNCS & 1
 __device__ __forceinline__ void gat3x_body(const GatArgs &A, unsigned char *smem)
 {
 #include "mtfjsp_gat3x_body.h"
@@ -1171,7 +1189,7 @@ __device__ __forceinline__ void gat3x_body(const GatArgs &A, unsigned char *smem
 __global__ __launch_bounds__(512) void k_gat3x(GatArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-#ifdef MTFJSP_BODY_FUNCS
+#if MTFJSP_BODY_FUNCS & 1
     gat3x_body(A, smem);
 #else
 #include "mtfjsp_gat3x_body.h"
@@ -1559,7 +1577,7 @@ static size_t heads_lds_bytes() { return (size_t)((2 * HCH + 4) * 16 * LDA16 + H
         accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(wv[1][ks], xv[0], accB, 0, 0, 0);           \
     } while (0)
 #define HX_CLDA 132
-#ifdef MTFJSP_BODY_FUNCS
+#if MTFJSP_BODY_FUNCS & 2
 __device__ __forceinline__ void headsx_body(const HeadArgs &A, unsigned char *smem)
 {
 #include "mtfjsp_headsx_body.h"
@@ -1568,7 +1586,7 @@ __device__ __forceinline__ void headsx_body(const HeadArgs &A, unsigned char *sm
 __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-#ifdef MTFJSP_BODY_FUNCS
+#if MTFJSP_BODY_FUNCS & 2
     headsx_body(A, smem);
 #else
 #include "mtfjsp_headsx_body.h"
@@ -1583,8 +1601,14 @@ __global__ __launch_bounds__(512) void k_headsx(HeadArgs A)
 __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-#ifdef MTFJSP_BODY_FUNCS
+#if MTFJSP_BODY_FUNCS & 2
     headsx_body(HA, smem);
+#else
+    {
+        const HeadArgs &A = HA;
+#include "mtfjsp_headsx_body.h"
+    }
+#endif
 #ifdef MTFJSP_DBG_VMWAIT        // bisection aid: every global store of the heads part acknowledged and visible device-wide
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __threadfence();
@@ -1594,13 +1618,9 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
     for (int i = threadIdx.x; i < MTFJSP_DBG_POISON / 4; i += 512) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u;
     __syncthreads();
 #endif
+#if MTFJSP_BODY_FUNCS & 1
     gat3x_body(GA, smem);
 #else
-    {
-        const HeadArgs &A = HA;
-#include "mtfjsp_headsx_body.h"
-    }
-    __syncthreads();
     {
         const GatArgs &A = GA;
 #include "mtfjsp_gat3x_body.h"
@@ -2280,6 +2300,19 @@ static bool split_products_in_use(const mtfjsp_encoder *e) { return (e->f32_prod
 static int res_poll_failure(mtfjsp_encoder *e)
 {
     if (!e->res_fail_host) return MTFJSP_OK;
+    if (e->res_fail_host[0]) {
+        // (first: a launch whose statistics never completed computes on garbage and may well have raised the range word too — that
+        // says nothing about the operands)
+        (void)hipStreamSynchronize(e->stream);
+        e->res_ok = false; e->res_failures++;
+        e->res_fail_host[0] = 0u; e->res_fail_host[1] = 0u;
+        (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); e->res_epoch = 0;
+        (void)hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8);
+        e->gin_stats_clean = false; e->gat_stats_clean[0] = e->gat_stats_clean[1] = false;   // (the heads launches behind it may have summed NaNs)
+        e->err = "single-launch GIN kernel: the grid-wide statistics timed out (its workgroups were not co-resident); every output enqueued since that "
+                 "launch is invalid and must be recomputed; the handle now uses the streaming launches";
+        return MTFJSP_ERR_RETRY;
+    }
     if (e->res_fail_host[1]) {
         // An output of an earlier forward was not a number.  On the split-product kernels that is what an activation beyond the
         // f16 range (65 504) turns into — BatchNorm outputs scaled by a large gamma, neighbour sums with large edge weights, GAT
@@ -2296,15 +2329,7 @@ static int res_poll_failure(mtfjsp_encoder *e)
             return MTFJSP_ERR_RETRY;
         }
     }
-    if (!e->res_fail_host[0]) return MTFJSP_OK;
-    (void)hipStreamSynchronize(e->stream);
-    e->res_ok = false; e->res_failures++;
-    e->res_fail_host[0] = 0u;
-    (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); e->res_epoch = 0;
-    (void)hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8);
-    e->err = "single-launch GIN kernel: a grid barrier timed out (its workgroups were not co-resident); every output enqueued since that "
-             "launch is invalid and must be recomputed; the handle now uses the streaming launches";
-    return MTFJSP_ERR_RETRY;
+    return MTFJSP_OK;
 }
 
 extern "C" const char *mtfjsp_encoder_last_error(mtfjsp_encoder_t e) { return e ? e->err.c_str() : g_enc_err.c_str(); }
@@ -2819,9 +2844,8 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
         const float mant = frexpf(a.wsinv[i], &ex);                // wsinv = 0.5 * 2^ex
         if (mant != 0.5f) { e->err = "resident GIN: a weight image scale is not a power of two"; return MTFJSP_ERR_STATE; }
         a.wexp[i] = 1 - ex;                                        // log2(wscale) = -log2(wsinv)
+        a.ffrac[i] = i == 0 ? GR_FIX_FRAC_FIRST : GR_FIX_FRAC_DEFAULT;
     }
-    static const int poll_mode = getenv("MTFJSP_GIN_RES_POLL") ? atoi(getenv("MTFJSP_GIN_RES_POLL")) : 0;
-    a.poll_mode = poll_mode;
     const int set = (int)(e->res_epoch & 1);
     a.stats = reinterpret_cast<unsigned long long *>(e->res_stats) + (size_t)set * GR_STATS_SET;
     a.stats_next = reinterpret_cast<unsigned long long *>(e->res_stats) + (size_t)(set ^ 1) * GR_STATS_SET;
@@ -3367,6 +3391,16 @@ extern "C" int mtfjsp_encoder_resident_failures(mtfjsp_encoder_t e, int64_t *cou
     return MTFJSP_OK;
 }
 
+// diagnostic: the machine path's node rows as the GAT passes left them ([B*M,128] f32, pre-BatchNorm unless a pooling kernel has
+// normalised them in place) copied to host memory — what tools/first_launch/ compares between two builds of the same kernel
+extern "C" int mtfjsp_encoder_peek_nodes_host(mtfjsp_encoder_t e, float *out_host, int64_t count)
+{
+    if (!e || !out_host || count < 0 || count > (int64_t)e->cfg.batch * e->cfg.n_machine * HD) return MTFJSP_ERR_ARG;
+    HIPCHK(e, hipSetDevice(e->cfg.device_id));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out_host, e->node, (size_t)count * sizeof(float), hipMemcpyDeviceToHost));
+    return MTFJSP_OK;
+}
 extern "C" int mtfjsp_encoder_range_fallbacks(mtfjsp_encoder_t e, int64_t *count_out, int32_t *product_mode_out)
 {
     if (!e || !count_out) return MTFJSP_ERR_ARG;

@@ -82,6 +82,9 @@
                 o[x] = a;
             }
             *reinterpret_cast<float4 *>(my_a + gx_off(r, c4)) = make_float4(o[0], o[1], o[2], o[3]);
+#if defined(MTFJSP_DBG_DSNOP) && (MTFJSP_DBG_DSNOP & 1)      // bisection aid: distance between an LDS store and the next write to its data registers
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (t_n1 < last) fpre = fetch_feat(t_n1);
@@ -164,6 +167,9 @@
                         n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
                         my_a[gx_off(r, c * 16 + m)] = n0;
                         my_a[gx_off(r + 1, c * 16 + m)] = n1;
+#if defined(MTFJSP_DBG_DSNOP) && (MTFJSP_DBG_DSNOP & 2)
+                        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
                     }
                 } else {
                     const bool valid = row0 + r < N;

@@ -73,7 +73,11 @@
 #define GR_MAXIPC 64                      // instances per workgroup (u8 instance ids; pool accumulators in the ring area)
 
 #ifndef GR_MIX
-#define GR_MIX 1                          // 1: the low operand piece as fma(f16 high piece, -1, x) = v_fma_mix_f32 (no separate f16 -> f32 conversion); same bits
+#define GR_MIX 2                          // 1: the low operand piece as fma(f16 high piece, -1, x) = v_fma_mix_f32 (no separate f16 -> f32 conversion); same bits
+#endif                                    // 2: ... and rounded to f16 by the same instruction (v_fma_mixlo_f16 / v_fma_mixhi_f16: the remainder is exact in f32,
+                                          //    so this is the one rounding the separate conversion performed): a packed conversion less per value pair; same bits
+#ifndef GR_FOLD_DPP
+#define GR_FOLD_DPP 1                     // 1: the per-lane column sums of a layer are folded over the 32 row lanes in registers (DPP reduce-scatter); 0: through LDS
 #endif
 #ifndef GR_PK
 #define GR_PK 1                           // 1: two-wide f32 vector arithmetic (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32); 0: one instruction per element
@@ -90,10 +94,11 @@ struct GinResArgs {
                                           // the others: two f16 planes of W * wscale)
     float wsinv[6];                       // 1 / wscale of each image (a power of two; 1 for the first)
     const float *gamma[6], *beta[6];      // BatchNorm after each Linear (mlps.0.bn0, mlps.0.bn1, outer 0, mlps.1.bn0, mlps.1.bn1, outer 1)
-    unsigned long long *stats;            // this forward's accumulators (zero on entry): [6 layers][8 groups][128 columns][sum | sumsq][2 limbs], see gr_fix_encode
+    unsigned long long *stats;            // this forward's accumulators (zero on entry): [6 layers][8 groups][128 columns][sum | sumsq], see gr_fix_encode
     unsigned long long *stats_next;       // the set of the next forward: zeroed here
     int wexp[6];                          // log2 of each weight image's scale (wsinv = 2^-wexp)
-    int poll_mode;                        // 0: every thread polls its own 16 words; 1: one word per group first (diagnostic A/B)
+    int ffrac[6];                         // fractional bits of each layer's fixed-point statistics (gr_fix_encode): 20, and 8 for the first Linear, whose
+                                          // outputs inherit the range of the raw features (start / finish times in the thousands)
     unsigned long long *bar;              // barrier words (monotonic counters, never reset)
     unsigned long long epoch;             // launches on `bar` so far
     unsigned *fail;                       // set when a barrier timed out (the outputs are then garbage)
@@ -108,7 +113,7 @@ struct GinResArgs {
     unsigned expect_extra;                // diagnostic (MTFJSP_GIN_RES_FAIL_AT): the barriers wait for this many workgroups that do not exist -> time-out path
     unsigned long long *stamps;           // diagnostic build only (-DGR_STAMP): [blocks][64] s_memrealtime at the phase boundaries
 };
-#define GR_STATS_PART (6 * 8 * HD * 2 * 2)                        // 64-bit words: per layer, per dispatch group: (sum, sumsq) per column, two limbs each
+#define GR_STATS_PART (6 * 8 * HD * 2)                            // 64-bit words: per layer, per dispatch group: (sum, sumsq) per column
 #define GR_STATS_SET GR_STATS_PART
 #ifdef GR_STAMP
 #define GR_STAMP_AT(i) do { if (tid == 0 && A.stamps) A.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -163,6 +168,15 @@ __device__ __forceinline__ f32x2 gr_rem2(f32x2 v, gr_h2 p)
     return gr_sub2(v, __builtin_convertvector(p, f32x2));
 #endif
 }
+// f16(x - (float)high piece), both elements, packed
+__device__ __forceinline__ gr_h2 gr_rem16(f32x2 v, gr_h2 p)
+{
+    unsigned r;
+    const unsigned pp = __builtin_bit_cast(unsigned, p);
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(pp), "v"(v[0]));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r) : "v"(pp), "v"(v[1]));
+    return __builtin_bit_cast(gr_h2, r);
+}
 template <typename F, int... I>
 __device__ __forceinline__ void gr_static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, typename F>
@@ -176,33 +190,40 @@ __device__ __forceinline__ float gr_sum32(float x)
 }
 
 // ---- BatchNorm column sums across the grid WITHOUT a separate barrier: every 64-bit accumulator word carries its own arrival count.
-// A workgroup's f32 column sum x is turned into a 102-bit fixed-point integer round-free (x * 2^44 is an integer for |x| >= 2^-20;
-// smaller values lose the bits below 2^-44) and split into two limbs of 48 + 54 bits; each limb goes out as ONE integer atomic add
-// of (1 << 58 | limb) — the low limb is non-negative, the high limb is biased by 2^51 — so after n contributions a word holds
-// n in its top 6 bits and the exact sum of the limbs below (n <= 63 workgroups per dispatch group, |x| < 2^54).  A reader that
-// finds the expected count in a word HAS that word's complete sum: no data atomics to wait for before signalling, no counter
-// atomics, no release flag, no second read — the five dependent memory round trips of the counter barrier become one atomic and
-// one read.  Integer sums are exact and order-independent: the statistics (and the forward) are bit-reproducible run to run,
-// which the f64 atomics of the streaming launches are not.  The scale of the weight image (a power of two) is divided out of the
-// exponent here, so the range |sum| < 2^54 is that of the true z.
-#define GR_FIX_FRAC 44
-#define GR_FIX_LIMIT 0x1p54f
+// A workgroup's f32 column sum x (of the true z: the power-of-two scale of the weight image is divided out of the exponent) goes
+// out as ONE integer atomic add of (1 << 58) | (trunc(x * 2^frac) + 2^51), frac = 20: after n contributions a word holds n
+// in its top 6 bits and, below, the exact sum of the fixed-point values (n <= 63 workgroups per dispatch group, |x| < 2^31).  A
+// reader that finds the expected count in a word HAS that word's complete sum: no data atomics to wait for before signalling, no
+// counter atomics, no release flag, no second read.  Integer sums are exact and order-independent: the statistics (and with them
+// the whole forward) are bit-reproducible run to run, which f64 atomics are not.  Resolution: 2^-20 per contribution, i.e. an
+// absolute error below 256 * 2^-20 / rows = 1.7e-9 on a mean or a mean square over the 147 456 rows of the headline batch — four
+// orders of magnitude under the BatchNorm epsilon (1e-5) the variance is added to.  Range: a workgroup's sum of squares must stay
+// below 2^31 (|z| < 1900 rms over its 576 rows); beyond it — or for a NaN — the contribution is flagged (range word) and the host
+// repeats the forward on the streaming f32-instruction kernels, exactly as for an operand beyond the f16 range.  The first Linear's
+// outputs inherit the range of the raw features (times in the thousands): its words carry 8 fractional bits (range 2^43).
+#define GR_FIX_FRAC_DEFAULT 20
+#define GR_FIX_FRAC_FIRST 8
 #define GR_FIX_BIAS (1ull << 51)
 #define GR_FIX_ONE (1ull << 58)
 #define GR_FIX_PAYLOAD (GR_FIX_ONE - 1ull)
-__device__ __forceinline__ void gr_fix_encode(float x, int exp2, unsigned long long &lo, unsigned long long &hi)
+__device__ __forceinline__ unsigned long long gr_fix_encode(float x, int exp2, int frac)
 {
-    const double y = __builtin_ldexp((double)x, GR_FIX_FRAC - exp2);          // exact
-    const double hd = __builtin_floor(y * 0x1p-48);
-    const double ld = y - hd * 0x1p48;                                        // exact, in [0, 2^48)
-    lo = GR_FIX_ONE | (unsigned long long)ld;
-    hi = GR_FIX_ONE | (unsigned long long)((long long)hd + (long long)GR_FIX_BIAS);
+    // integer arithmetic only (an f64 form — ldexp, floor, conversion to a 64-bit integer — took 0.8 us of every boundary):
+    // x = (-1)^s * mant * 2^(e - 150)  ->  V = (-1)^s * (mant << sh), sh = e - 150 + FRAC - exp2 <= 27 by the caller's range check
+    // (mant < 2^24: |V| < 2^51); for sh < 0 the bits below 2^-FRAC are dropped (truncation toward zero)
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const int e = (int)((u >> 23) & 255u);
+    const unsigned long long mant = (unsigned long long)((u & 0x7fffffu) | (e ? 0x800000u : 0u));
+    const int sh = (e ? e : 1) - 150 + frac - exp2;
+    long long v = sh >= 0 ? (long long)(mant << (sh > 27 ? 27 : sh)) : (sh > -24 ? (long long)(mant >> (-sh)) : 0ll);
+    if (u >> 31) v = -v;
+    return GR_FIX_ONE | (unsigned long long)(v + (long long)GR_FIX_BIAS);
 }
-// total of `n` contributions from the summed payloads of their two limbs
-__device__ __forceinline__ double gr_fix_decode(unsigned long long lo_sum, unsigned long long hi_sum, unsigned n)
+// total of `n` contributions from the summed payloads
+__device__ __forceinline__ double gr_fix_decode(unsigned long long sum, unsigned n, int frac)
 {
-    const long long hs = (long long)hi_sum - (long long)n * (long long)GR_FIX_BIAS;
-    return ((double)hs * 0x1p48 + (double)lo_sum) * 0x1p-44;
+    const long long v = (long long)sum - (long long)n * (long long)GR_FIX_BIAS;
+    return __builtin_ldexp((double)v, -frac);
 }
 
 // Grid-wide barrier over `nblk` co-resident workgroups that also completes a reduction: hierarchical over the 8 dispatch
@@ -343,6 +364,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if (zero) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
         else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     };
+    bool timed_out = false;                                       // a statistics wait of this launch gave up: everything after it is garbage
     gr_h8 wf[2][8];
     bf16x8 w0f[3];                                                // (first Linear only)
     f32x2 ts[8], tq[8];                                           // per-lane column (sum, sumsq) of this layer, two columns per register pair
@@ -371,8 +393,12 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     // exact-to-2^-22 operand split of 4 values: high = f16(v), low = f16(v - high) (both round-to-nearest) -> packed pairs
     auto split2x4 = [&](f32x2 v01, f32x2 v23, uint2 &p0, uint2 &p1) __attribute__((always_inline)) {
         const gr_h2 a = __builtin_convertvector(v01, gr_h2), b = __builtin_convertvector(v23, gr_h2);
+#if GR_MIX == 2
+        const gr_h2 c = gr_rem16(v01, a), d = gr_rem16(v23, b);
+#else
         const f32x2 r01 = gr_rem2(v01, a), r23 = gr_rem2(v23, b);
         const gr_h2 c = __builtin_convertvector(r01, gr_h2), d = __builtin_convertvector(r23, gr_h2);
+#endif
         p0 = make_uint2(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b));
         p1 = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
     };
@@ -404,6 +430,36 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 #pragma unroll
         for (int i = 0; i < 32; i += 4) { s0 += src[i * 36]; s1 += src[(i + 1) * 36]; s2 += src[(i + 2) * 36]; s3 += src[(i + 3) * 36]; }
         return (s0 + s1) + (s2 + s3);
+    };
+    // The same fold without LDS and without a workgroup barrier (round 4; GR_FOLD_DPP): a reduce-scatter over the 32 row lanes of a
+    // half wave in five halving steps — partner = lane ^ 16 (ds_bpermute), ^ 15 (row mirror), ^ 7 (half-row mirror), ^ 2, ^ 1 (quad
+    // permutes): at each step a lane keeps the half of its values selected by one of its own lane bits (bit 4, 3, 2, 1, 0), hands the
+    // other half to its partner and adds what it receives, the exchange riding on the add as a DPP operand.  {16, 15, 7, 2, 1} span all
+    // 32 lanes, so after the fifth step lane n holds the total of value n: kind = n >> 4 (sum | sumsq), column slot c = n & 15, i.e.
+    // column 32 wave + 8 (c >> 2) + 4 h + (c & 3).  ~110 vector instructions instead of 8 stores + barrier + 32 loads + 31 adds.
+    auto fold_stats_dpp = [&]() __attribute__((always_inline)) {
+        const bool b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0, b0 = (lane & 1) != 0;
+        auto dpp = [&](float x, auto Ctrl) __attribute__((always_inline)) {
+            return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(Ctrl)::value, 0xF, 0xF, true));
+        };
+        float v16[16];
+#pragma unroll
+        for (int c = 0; c < 16; c++) {                                // bit 4: lanes 0..15 keep the sums, lanes 16..31 the sums of squares
+            const float a = ts[c >> 1][c & 1], q_ = tq[c >> 1][c & 1];
+            v16[c] = (b4 ? q_ : a) + __shfl_xor(b4 ? a : q_, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) { ts[i] = f32x2{0.f, 0.f}; tq[i] = f32x2{0.f, 0.f}; }
+        float v8[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) v8[c] = (b3 ? v16[c + 8] : v16[c]) + dpp(b3 ? v16[c] : v16[c + 8], std::integral_constant<int, 0x140>{});    // row mirror: lane ^ 15
+        float v4[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) v4[c] = (b2 ? v8[c + 4] : v8[c]) + dpp(b2 ? v8[c] : v8[c + 4], std::integral_constant<int, 0x141>{});        // half-row mirror: lane ^ 7
+        float v2[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) v2[c] = (b1 ? v4[c + 2] : v4[c]) + dpp(b1 ? v4[c] : v4[c + 2], std::integral_constant<int, 0x4E>{});         // quad_perm [2,3,0,1]: lane ^ 2
+        return (b0 ? v2[1] : v2[0]) + dpp(b0 ? v2[0] : v2[1], std::integral_constant<int, 0xB1>{});                                               // quad_perm [1,0,3,2]: lane ^ 1
     };
     // BatchNorm + ReLU of columns 8g+4h..+3 of tile rt's resident values -> operand split -> planes of buffer buf
     // Four plane buffers in the layers without aggregation (two of them in the ring area, free there): the tiles go in pairs —
@@ -499,9 +555,10 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             // slice 4
             M(2 * g + 1, 1, 0);
             if constexpr (g < 3) xf[0][1] = *reinterpret_cast<const gr_h8 *>(xa + GR_PLANE + 32 * (2 * g + 2));
-            if constexpr (NEXT) { if constexpr (GR_MIX) { v01 = gr_rem2(v01, p01); v23 = gr_rem2(v23, p23); } else { v01 = gr_sub2(v01, e01); v23 = gr_sub2(v23, e23); }
+            if constexpr (NEXT) { if constexpr (GR_MIX == 2) { q01 = gr_rem16(v01, p01); q23 = gr_rem16(v23, p23); }
+                                  else if constexpr (GR_MIX == 1) { v01 = gr_rem2(v01, p01); v23 = gr_rem2(v23, p23); } else { v01 = gr_sub2(v01, e01); v23 = gr_sub2(v23, e23); }
                                   if (!(GR_ABL & 8)) *reinterpret_cast<uint2 *>(dst) = make_uint2(__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23));
-                                  q01 = __builtin_convertvector(v01, gr_h2); q23 = __builtin_convertvector(v23, gr_h2); }
+                                  if constexpr (GR_MIX != 2) { q01 = __builtin_convertvector(v01, gr_h2); q23 = __builtin_convertvector(v23, gr_h2); } }
             GR_FENCE();
             // slice 5
             M(2 * g + 1, 0, 0);
@@ -548,83 +605,72 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // (its matrix instructions were written as text: no compiler-inserted wait before the reads)
             stats_all(zs[(GR_NT - 1 - GR_NRES) & 1]);
         }
+#if GR_FOLD_DPP
+        (void)fold_stats;
+        const float colsum = fold_stats_dpp();                    // lane n of a half wave: value n of its 32 (see above)
+        const int kind = n >> 4, scol = 32 * wave + 8 * ((n & 15) >> 2) + 4 * h + (n & 3);
+        constexpr int PAIR = 16;                                  // the lane holding the other kind of the same column
+#else
         const float colsum = fold_stats();                        // (GR_VRES 0: tile 17's sums were taken when it was stored)
+        const int kind = tid & 1, scol = tid >> 1;
+        constexpr int PAIR = 1;
+#endif
+        const int sidx = 2 * scol + kind;                         // this thread's (column, sum | sumsq) word pair
         if (k == 1) GR_STAMP_AT(2);
-        // thread tid holds this workgroup's (column tid >> 1, sum | sumsq): two integer atomics, fire and forget
+        // one integer atomic, fire and forget
         const unsigned grp = blockIdx.x & 7u;
-        unsigned long long *part = A.stats + (((size_t)k * 8 + grp) * 256 + tid) * 2;
         {
-            const int kind = tid & 1;
             float x = colsum;
-            if (!(__builtin_fabsf(x) * (kind ? A.wsinv[k] * A.wsinv[k] : A.wsinv[k]) < GR_FIX_LIMIT)) {
+            if (!(__builtin_fabsf(x) * (kind ? A.wsinv[k] * A.wsinv[k] : A.wsinv[k]) < __builtin_ldexpf(1.0f, 51 - A.ffrac[k]))) {
                 // not a number (an operand beyond the f16 range upstream: (inf | -inf) pieces) or beyond the fixed-point range: the host
                 // repeats the forward on the f32-instruction kernels; the contribution still goes out so that nobody waits for it
-                if (A.range_flag) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (A.range_flag && !timed_out) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (after a time-out the values mean nothing)
                 x = 0.f;
             }
-            unsigned long long lo, hi;
-            gr_fix_encode(x, kind ? 2 * A.wexp[k] : A.wexp[k], lo, hi);
-            (void)__hip_atomic_fetch_add(&part[0], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            (void)__hip_atomic_fetch_add(&part[1], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (void)__hip_atomic_fetch_add(A.stats + ((size_t)k * 8 + grp) * 256 + sidx, gr_fix_encode(x, kind ? 2 * A.wexp[k] : A.wexp[k], A.ffrac[k]),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (k == 1) GR_STAMP_AT(3);
-        // requests that do not depend on the other workgroups go out behind them: the next Linear's weight fragments
-        // and this BatchNorm's affine parameters
+        // requests that do not depend on the other workgroups go out behind it: this BatchNorm's affine parameters and the next
+        // Linear's weight fragments
+        const float ga = A.gamma[k][scol], be = A.beta[k][scol];
         if constexpr (k < 5) load_weights(k + 1);
-        const float ga = A.gamma[k][tid >> 1], be = A.beta[k][tid >> 1];
         GR_STAMP_AT(5 + 4 * k);
+        // every thread collects its own (column, kind) from the 8 dispatch groups: a word is complete when it carries its group's size
+        // in the count field
+        const unsigned long long *w0 = A.stats + (size_t)k * 8 * 256 + sidx;
+        unsigned long long vw[8], want[8], ssum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) want[j] = (unsigned long long)((nblk >> 3) + ((unsigned)j < (nblk & 7u) ? 1u : 0u));
         {
-            // every thread collects its own (column, kind) from the 8 dispatch groups: 16 words, complete when each carries its
-            // group's size in the count field
-            const unsigned long long *w0 = A.stats + ((size_t)k * 8 * 256 + tid) * 2;
-            unsigned long long want[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) want[j] = (unsigned long long)((nblk >> 3) + ((unsigned)j < (nblk & 7u) ? 1u : 0u));
             const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-            unsigned long long slo = 0, shi = 0;
-            if (A.poll_mode == 1) {                                // one word per group first: lanes 0..7 of every wave (no LDS hand-off)
-                const unsigned long long *sw = A.stats + (((size_t)k * 8 + (lane & 7)) * 256 + 255) * 2 + 1;
-                const unsigned long long sneed = (unsigned long long)((nblk >> 3) + ((unsigned)(lane & 7) < (nblk & 7u) ? 1u : 0u));
-                for (;;) {
-                    const unsigned long long v = __hip_atomic_load(sw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__builtin_amdgcn_read_exec() == __builtin_amdgcn_ballot_w64((v >> 58) >= sneed)) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) break;
-                }
-            }
             for (;;) {
-                unsigned long long vl[8], vh[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    vl[j] = __hip_atomic_load(w0 + (size_t)j * 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    vh[j] = __hip_atomic_load(w0 + (size_t)j * 512 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                for (int j = 0; j < 8; j++) vw[j] = __hip_atomic_load(w0 + (size_t)j * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bool done = true;
-                slo = 0; shi = 0;
+                ssum = 0;
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
-                    done = done && (vl[j] >> 58) == want[j] && (vh[j] >> 58) == want[j];
-                    slo += vl[j] & GR_FIX_PAYLOAD; shi += vh[j] & GR_FIX_PAYLOAD;
-                }
+                for (int j = 0; j < 8; j++) { done = done && (vw[j] >> 58) == want[j]; ssum += vw[j] & GR_FIX_PAYLOAD; }
                 if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;                  // (wave-uniform exit: the pair exchange below is cross-lane)
                 if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) {                 // 4 ms at 100 MHz: not all workgroups are resident
                     __hip_atomic_store(A.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (host-mapped word: the host polls it without synchronising)
+                    timed_out = true;
                     break;
                 }
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(2);
             }
             GR_STAMP_AT(6 + 4 * k);
-            const double tot = gr_fix_decode(slo, shi, nblk);      // the true-z (sum | sumsq) of this thread's column over all rows
-            const double oth = __shfl_xor(tot, 1);
-            if (!(tid & 1)) {
+            const double tot = gr_fix_decode(ssum, nblk, A.ffrac[k]);   // the true-z (sum | sumsq) of this thread's column over all rows
+            const double oth = __shfl_xor(tot, PAIR);
+            if (!kind) {
                 const double mean = tot * A.inv_rows;
                 double var = oth * A.inv_rows - mean * mean;       // biased variance (training-mode BN)
                 if (var < 0) var = 0;
                 const float rstd = 1.0f / sqrtf((float)(var + BN_EPS));
                 const float s = rstd * ga;
                 // the accumulators hold z * wscale (power of two, exact): statistics of z, scale applied to the stored value
-                s_bn[tid >> 1] = s * A.wsinv[k];
-                s_bn[HD + (tid >> 1)] = be - (float)mean * s;
+                s_bn[scol] = s * A.wsinv[k];
+                s_bn[HD + scol] = be - (float)mean * s;
             }
         }
         LDS_BARRIER();
@@ -846,7 +892,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                     GR_FENCE();
                     // slice 5
                     M(2 * g + 1, 0, 0);
-                    if constexpr (NEXT) { if constexpr (GR_MIX) { v01 = gr_rem2(v01, p01); v23 = gr_rem2(v23, p23); } else { v01 = gr_sub2(v01, e01); v23 = gr_sub2(v23, e23); } q01 = __builtin_convertvector(v01, gr_h2); q23 = __builtin_convertvector(v23, gr_h2);
+                    if constexpr (NEXT) { if constexpr (GR_MIX == 2) { q01 = gr_rem16(v01, p01); q23 = gr_rem16(v23, p23); }
+                                          else { if constexpr (GR_MIX) { v01 = gr_rem2(v01, p01); v23 = gr_rem2(v23, p23); } else { v01 = gr_sub2(v01, e01); v23 = gr_sub2(v23, e23); } q01 = __builtin_convertvector(v01, gr_h2); q23 = __builtin_convertvector(v23, gr_h2); }
                                           *reinterpret_cast<uint2 *>(dst + 16 * g) = make_uint2(__builtin_bit_cast(unsigned, p01), __builtin_bit_cast(unsigned, p23));
                                           *reinterpret_cast<uint2 *>(dst + 16 * g + GR_PLANE) = make_uint2(__builtin_bit_cast(unsigned, q01), __builtin_bit_cast(unsigned, q23)); }
                     GR_FENCE();

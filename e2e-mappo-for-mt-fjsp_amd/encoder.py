@@ -198,6 +198,13 @@ class Encoder:
         capi.check(self.L.mtfjsp_encoder_resident_failures(self.h, C.byref(n)), self.h, enc=True)
         return int(n.value)
 
+    def peek_nodes(self):
+        """diagnostic: the machine path's node rows [B*M,128] as the GAT passes left them (host array)"""
+        import numpy as np
+        out = np.empty((self.B * self.M, 128), dtype=np.float32)
+        capi.check(self.L.mtfjsp_encoder_peek_nodes_host(self.h, out.ctypes.data, out.size), self.h, enc=True)
+        return out
+
     def range_fallbacks(self):
         """-> (times the handle left the f16 split products because an activation exceeded their range, product mode in force)"""
         n, m = C.c_int64(0), C.c_int32(0)

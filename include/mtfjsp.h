@@ -342,6 +342,9 @@ int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_out);
  * the forward.  mtfjsp_encoder_set_product_mode(0) returns to the split products.  *count_out = number of such switches,
  * *product_mode_out (may be NULL) = the product mode now in force. */
 int mtfjsp_encoder_range_fallbacks(mtfjsp_encoder_t e, int64_t *count_out, int32_t *product_mode_out);
+/* diagnostic (tools/first_launch): the first `count` floats of the machine path's node buffer [B*M,128] — the output of the three
+ * GAT passes of ac:409-420 before the BatchNorm of ac:434 — copied to host memory after synchronising the stream */
+int mtfjsp_encoder_peek_nodes_host(mtfjsp_encoder_t e, float *out_host, int64_t count);
 /* number of grid-barrier time-outs reported on this handle so far */
 int mtfjsp_encoder_resident_failures(mtfjsp_encoder_t e, int64_t *count_out);
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);

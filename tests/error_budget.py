@@ -1,0 +1,73 @@
+"""Observed-error ledger of the encoder parity tests (round-3 review, item 7).
+
+The blanket tolerances of the encoder tests (1e-4 of a tensor's scale, 1e-3 on critic values) are 30-100x what the kernels deliver:
+a regression of the split products by an order of magnitude would pass them.  Every comparison made through `check()` therefore
+  * records the error it OBSERVED, normalised by the tensor's scale, under (case, tensor) — the ledger of a test run is written to
+    gpurun_out/encoder_errors_observed.json when the interpreter exits (the builder copies a GPU run's ledger to
+    profiles/r04_encoder_errors.json and commits it);
+  * asserts it against 5x the committed figure for that (case, tensor) when profiles/r04_encoder_errors.json holds one (never looser
+    than the blanket tolerance, never tighter than a few f32 ulps of the scale), and against the blanket tolerance otherwise.
+Test infrastructure only; nothing in the product imports it.
+"""
+import atexit
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUDGET_FILE = os.path.join(ROOT, "profiles", "r04_encoder_errors.json")
+OBSERVED_FILE = os.path.join(ROOT, "gpurun_out", "encoder_errors_observed.json")
+MARGIN = 5.0
+FLOOR = 1e-6            # normalised: ~8 ulps of an f32 at the tensor's scale — below this a recorded figure is round-off noise
+
+_observed = {}
+try:
+    _budget = json.load(open(BUDGET_FILE))["normalised_max_error"]
+except (OSError, ValueError, KeyError):
+    _budget = {}
+
+
+def _flush():
+    if not _observed:
+        return
+    try:
+        os.makedirs(os.path.dirname(OBSERVED_FILE), exist_ok=True)
+        try:
+            old = json.load(open(OBSERVED_FILE))["normalised_max_error"]
+        except (OSError, ValueError, KeyError):
+            old = {}
+        for case, d in _observed.items():
+            o = old.setdefault(case, {})
+            for k, v in d.items():
+                o[k] = max(float(o.get(k, 0.0)), v)
+        json.dump({"what": "max |HIP - expected| / scale per (case, tensor) observed by tests/error_budget.check in GPU test runs; "
+                           "scale = max(1, max |expected|) for embeddings, 1 for probabilities, 1 + |expected| elementwise for critic values",
+                   "normalised_max_error": old}, open(OBSERVED_FILE, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+
+
+atexit.register(_flush)
+
+
+def bound(case, tensor, blanket):
+    rec = _budget.get(case, {}).get(tensor)
+    if rec is None:
+        return blanket
+    return min(blanket, max(MARGIN * float(rec), FLOOR))
+
+
+def check(case, tensor, got, want, blanket, scale=None, relative=False):
+    """max |got - want| / scale (relative=True: elementwise / (1 + |want|), the critic-value form) recorded under (case, tensor)
+    and asserted against bound(); -> the normalised error"""
+    got = np.asarray(got, dtype=np.float64); want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (case, tensor, got.shape, want.shape)
+    assert np.isfinite(got).all(), (case, tensor, "not finite")
+    d = np.abs(got - want)
+    err = float((d / (1.0 + np.abs(want))).max()) if relative else float(d.max()) / (float(scale) if scale else 1.0)
+    c = _observed.setdefault(case, {})
+    c[tensor] = max(c.get(tensor, 0.0), err)
+    b = bound(case, tensor, blanket)
+    assert err <= b, f"{case} / {tensor}: normalised error {err:.3e} > {b:.3e} (blanket {blanket:.1e}, committed {_budget.get(case, {}).get(tensor)})"
+    return err

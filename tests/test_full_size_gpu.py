@@ -9,6 +9,8 @@ from importlib import import_module
 import numpy as np
 import pytest
 
+from error_budget import check as budget
+
 pytestmark = pytest.mark.gpu
 
 
@@ -230,12 +232,14 @@ def test_encoder_headline_partition_vs_oracle(size, gin):
     cand, mask = env.candidate.cpu().numpy(), env.job_mask.cpu().numpy()
     o = eo.job_actor_forward(ja, tf, col, val, cand, mask, hm.cpu().numpy(), B, T)
     scale = max(1.0, float(np.abs(o["h_nodes"]).max()))
-    np.testing.assert_allclose(h_nodes.cpu().numpy(), o["h_nodes"], rtol=0, atol=1e-4 * scale)
-    np.testing.assert_allclose(h_o.cpu().numpy(), o["h_pooled"], rtol=0, atol=1e-4 * scale)
-    np.testing.assert_allclose(prob.cpu().numpy(), o["prob"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(job_v.cpu().numpy(), o["job_v"], rtol=1e-3, atol=1e-3)
+    case = f"whole_batch_oracle:{J}x{M}x{E}x{B}:{gin}"             # (observed errors are recorded and held to 5x the committed ones: tests/error_budget.py)
+    budget(case, "h_nodes", h_nodes.cpu().numpy(), o["h_nodes"], 1e-4, scale)
+    budget(case, "h_pooled_o", h_o.cpu().numpy(), o["h_pooled"], 1e-4, scale)
+    budget(case, "job_prob", prob.cpu().numpy(), o["prob"], 1e-4)
+    budget(case, "job_v", job_v.cpu().numpy(), o["job_v"], 1e-3, relative=True)
     o64 = eo.job_actor_forward(ja, tf, col, val, cand, mask, hm.cpu().numpy(), B, T, dtype=torch.float64)
-    err_hip = float(np.abs(h_nodes.cpu().numpy() - o64["h_nodes"]).max()); err_f32 = float(np.abs(o["h_nodes"] - o64["h_nodes"]).max())
+    err_hip = budget(case, "h_nodes_vs_binary64", h_nodes.cpu().numpy(), o64["h_nodes"], 1e-4, scale) * scale
+    err_f32 = float(np.abs(o["h_nodes"] - o64["h_nodes"]).max())
     print(f"{size} {gin}: h_nodes vs binary64: HIP {err_hip:.3g}, f32 oracle {err_f32:.3g}, scale {scale:.3g}")
     assert err_hip <= max(2 * err_f32, 1e-4 * scale)
     e.check()
@@ -304,21 +308,22 @@ def test_encoder_config2_full_size_vs_oracle(size):
     col = env.ell_col.cpu().numpy().reshape(B, T, 2); val = env.ell_val.cpu().numpy().reshape(B, T, 2)
     o = eo.job_actor_forward(ja, tf, col, val, env.candidate.cpu().numpy(), env.job_mask.cpu().numpy(), hm.cpu().numpy(), B, T)
     scale = max(1.0, float(np.abs(o["h_nodes"]).max()))
-    np.testing.assert_allclose(h_nodes.cpu().numpy(), o["h_nodes"], rtol=0, atol=1e-4 * scale)
-    np.testing.assert_allclose(h_o.cpu().numpy(), o["h_pooled"], rtol=0, atol=1e-4 * scale)
-    np.testing.assert_allclose(prob.cpu().numpy(), o["prob"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(job_v.cpu().numpy(), o["job_v"], rtol=1e-3, atol=1e-3)
+    case = f"whole_batch_oracle:{J}x{M}x{E}x{B}:default"
+    budget(case, "h_nodes", h_nodes.cpu().numpy(), o["h_nodes"], 1e-4, scale)
+    budget(case, "h_pooled_o", h_o.cpu().numpy(), o["h_pooled"], 1e-4, scale)
+    budget(case, "job_prob", prob.cpu().numpy(), o["prob"], 1e-4)
+    budget(case, "job_v", job_v.cpu().numpy(), o["job_v"], 1e-3, relative=True)
     task = torch.as_tensor(env.candidate.cpu().numpy()[np.arange(B), o["prob"].argmax(1)].astype(np.int32)).cuda()
     env.observe_mfea1(task)
     mprob, h_m, mach_v = e.machine_actor_forward(env.m_fea1, env.m_fea2, torch.as_tensor(o["h_pooled"]).cuda(), env.mmask)
     torch.cuda.synchronize()
     mo = eo.machine_actor_forward(ma, env.m_fea1.cpu().numpy(), env.m_fea2.cpu().numpy(), o["h_pooled"], env.mmask.cpu().numpy(), B, M)
-    np.testing.assert_allclose(mprob.cpu().numpy(), mo["prob"], rtol=0, atol=1e-4)
-    np.testing.assert_allclose(mach_v.cpu().numpy(), mo["mach_v"], rtol=1e-3, atol=1e-3)
+    budget(case, "mch_prob", mprob.cpu().numpy(), mo["prob"], 1e-4)
+    budget(case, "mach_v", mach_v.cpu().numpy(), mo["mach_v"], 1e-3, relative=True)
     # graph embedding after three GAT passes + BatchNorm over B*M rows: 1e-4 of the tensor's scale against the f32 oracle,
     # and no further from a binary64 evaluation of the same network than that f32 evaluation is itself (x2)
     mscale = max(1.0, float(np.abs(mo["h_pooled"]).max()))
-    np.testing.assert_allclose(h_m.cpu().numpy(), mo["h_pooled"], rtol=0, atol=1e-4 * mscale)
+    budget(case, "h_pooled_m", h_m.cpu().numpy(), mo["h_pooled"], 1e-4, mscale)
     m64 = eo.machine_actor_forward(ma, env.m_fea1.cpu().numpy(), env.m_fea2.cpu().numpy(), o["h_pooled"], env.mmask.cpu().numpy(), B, M,
                                    dtype=torch.float64)
     err_hip = float(np.abs(h_m.cpu().numpy() - m64["h_pooled"]).max()); err_f32 = float(np.abs(mo["h_pooled"] - m64["h_pooled"]).max())

@@ -380,7 +380,7 @@ def _lockstep_worker(rank, world, port, q, mode):
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
         kw = dict(collect=True) if mode == "advantage" else dict(collect="full", weights=enc_mod.random_init_weights(7, with_critic=True))
-        ro = rollout.Rollout(6, 6, 2, 256, policy="actor", obs_dtype="f32", buffer_episodes=1, rank=rank, world=world, **kw)
+        ro = rollout.Rollout(6, 6, 2, 256, policy="actor", obs_dtype="f32", buffer_episodes=1, rank=rank, world=world, time_handoff=True, **kw)
         for _ in range(4 * ro.S):                                # four buffers' worth of step() calls on every rank
             ro.step()
         torch.cuda.synchronize()
