@@ -95,6 +95,21 @@ __device__ __forceinline__ float fast_tanh(float x)
     return 1.0f - __fdividef(2.0f, e + 1.0f);
 }
 
+// A vector instruction must not read the result of a matrix instruction before the matrix pipe has written it back, and gfx950 does NOT
+// interlock that: tools/ubench/mfma_raw.hip reads stale registers up to 6 wait states behind v_mfma_f32_16x16x32_f16 (5 when the
+// fillers are single-width vector instructions, where ~15-45 % of the reads are still stale: a marginal regime that depends on how the
+// SIMD's two waves interleave) and up to 10 behind v_mfma_f32_32x32x16_f16.  hipcc's hazard recogniser inserts the required s_nops with
+// NO margin, counting every vector instruction in between as one wait state.  Round 3's "first launch of the function-form GAT kernel
+// miscomputes a few row tiles" was this: that schedule read one accumulator of the last pass through v_pk_mul_f32 exactly 8 counted
+// wait states (6 vector instructions + s_nop 1) behind its matrix instruction; the stale values sat in lanes 48..63 — the rows of
+// the last write-back pass — of the accumulator read first, a handful of tiles per launch, on every launch (profiles/r04_first_launch_*).
+// MFMA_SETTLE puts four real wait states behind the last matrix instruction of a chain and ties the accumulators to them, so that
+// every schedule — textual body or function, this compiler or the next — has the margin.
+#define MFMA_SETTLE1(a) asm volatile("s_nop 3" : "+v"(a))
+#define MFMA_SETTLE2(a, b) asm volatile("s_nop 3" : "+v"(a), "+v"(b))
+#define MFMA_SETTLE3(a, b, c) asm volatile("s_nop 3" : "+v"(a), "+v"(b), "+v"(c))
+#define MFMA_SETTLE8(a) asm volatile("s_nop 3" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]), "+v"((a)[4]), "+v"((a)[5]), "+v"((a)[6]), "+v"((a)[7]))
+
 // sum over the 16 lanes of a DPP row, result in every lane: xor 1, xor 2 (quad permutes), half-row mirror, row mirror —
 // four VALU instructions with DPP operands instead of four dependent ds_bpermute round trips
 __device__ __forceinline__ float row_sum16(float x)
@@ -190,6 +205,7 @@ __device__ __forceinline__ void mfma_tile16(const float *ap, const float *bp, co
         for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1[c], acc[c], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     }
+    MFMA_SETTLE8(acc);
 }
 // per-wave f64 column sums (lane (m,q), block c) -> one f64 atomic per column per workgroup (into one of STAT_REP replicas);
 // s_red may alias the LDS tiles: the first barrier makes sure every wave is done with them
@@ -446,6 +462,7 @@ __global__ __launch_bounds__(512) void k_gemm16p(GemmArgs A)
             for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s & 1], bv[s & 1][c], acc[c], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        MFMA_SETTLE8(acc);
         asm volatile("" ::: "memory");
         if (have_next) tile_to_lds();
 #pragma unroll
@@ -920,6 +937,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                             MH(0, 1); MH(1, 0); MH(0, 0);
                         }
                     }
+                    MFMA_SETTLE2(acc[0], acc[1]);
 #pragma unroll
                     for (int c = 0; c < 2; c++) acc[c] = acc[c] * wsinv + biasv[c];
                     const int ptile = FULL || tb + t < last ? PT(tb + t) : 0;
@@ -1318,6 +1336,7 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32((t0p)[4 * s_], bw[s_], acc0, 0, 0, 0);                   \
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32((t1p)[4 * s_], bw[s_], acc1, 0, 0, 0);                   \
         }                                                                                                        \
+        MFMA_SETTLE2(acc0, acc1);                                                                                \
     } while (0)
     const int sr = tid >> 5, sc4 = (tid & 31) * 4;                  // staging: thread -> (row sr of 16, 4 columns)
     const int aoff = m * LDA16 + q;                                 // A operand: tile[row m][k = 4s+q]
@@ -1403,6 +1422,7 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
                 ac = __builtin_amdgcn_mfma_f32_16x16x4f32(a_p, wC[s], ac, 0, 0, 0);
                 au2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a_o, wB[s], au2, 0, 0, 0);
             }
+            MFMA_SETTLE3(au, ac, au2);
             WCOL(wA, A.Wc1i);                                       // requested now, used in phase B
             WCOL(wB, A.W0i);                                        // Wa
             WCOL(wC, A.W1i);                                        // phase C
@@ -1448,6 +1468,7 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
                 const float *pc = s_c1 + aoff;
 #pragma unroll
                 for (int s = 0; s < 32; s++) a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pc[4 * s], wA[s], a0, 0, 0, 0);
+                MFMA_SETTLE1(a0);
 #pragma unroll
                 for (int i = 0; i < 4; i++) s_c2[(4 * q + i) * LDA16 + col] = fast_tanh(a0[i] + bc1c);
             }

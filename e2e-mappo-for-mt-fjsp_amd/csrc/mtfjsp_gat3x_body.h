@@ -1,8 +1,8 @@
 // mtfjsp_gat3x_body.h — the statements of k_gat3x (csrc/mtfjsp_encoder.hip), to be included inside a kernel that has `A` (GatArgs) and
 // `smem` (the dynamic LDS base) in scope: once in k_gat3x itself and once, behind the job actor's heads, in k_headsx_gat3x.
-// Textual inclusion on purpose: as a __forceinline__ device function called from a wrapper kernel the same statements came out with
-// a different instruction schedule whose FIRST launch in a process produced a few wrong row tiles (later launches were right;
-// tests/test_first_launch_gpu.py keeps watch) — the stand-alone form never did.
+// (Round 3 kept these statements as text because the same statements as a __forceinline__ function miscomputed a few row tiles; round 4
+// found the cause — a vector read of a matrix result with no margin behind the write-back, MFMA_SETTLE in mtfjsp_encoder.hip — and
+// both forms are built and tested: -DMTFJSP_BODY_FUNCS, tests/test_first_launch_gpu.py.)
     unsigned char *s_wf = smem;                                   // 8*2*4*64*16 B
     float *s_a = reinterpret_cast<float *>(smem + 8 * 2 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
     double *s_red = reinterpret_cast<double *>(s_a);              // (after the last tile)
@@ -140,6 +140,7 @@
 #pragma unroll
                     for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[0][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
                 }
+                MFMA_SETTLE8(acc);                                            // (margin behind the matrix pipe's write-back: see the macro)
 #pragma unroll
                 for (int c = 0; c < 8; c++) acc[c] *= wsinv;                  // the weight image is scaled by a power of two
             }

@@ -76,6 +76,9 @@
 #define GR_MIX 2                          // 1: the low operand piece as fma(f16 high piece, -1, x) = v_fma_mix_f32 (no separate f16 -> f32 conversion); same bits
 #endif                                    // 2: ... and rounded to f16 by the same instruction (v_fma_mixlo_f16 / v_fma_mixhi_f16: the remainder is exact in f32,
                                           //    so this is the one rounding the separate conversion performed): a packed conversion less per value pair; same bits
+#ifndef GR_SETTLE
+#define GR_SETTLE 1                       // two extra wait states between a tile's last matrix instruction and the first vector read of its result
+#endif
 #ifndef GR_FOLD_DPP
 #define GR_FOLD_DPP 1                     // 1: the per-lane column sums of a layer are folded over the 32 row lanes in registers (DPP reduce-scatter); 0: through LDS
 #endif
@@ -97,7 +100,7 @@ struct GinResArgs {
     unsigned long long *stats;            // this forward's accumulators (zero on entry): [6 layers][8 groups][128 columns][sum | sumsq], see gr_fix_encode
     unsigned long long *stats_next;       // the set of the next forward: zeroed here
     int wexp[6];                          // log2 of each weight image's scale (wsinv = 2^-wexp)
-    int ffrac[6];                         // fractional bits of each layer's fixed-point statistics (gr_fix_encode): 20, and 8 for the first Linear, whose
+    int ffrac[6];                         // fractional bits of each layer's fixed-point statistics (gr_fix_encode): 20, and 12 for the first Linear, whose
                                           // outputs inherit the range of the raw features (start / finish times in the thousands)
     unsigned long long *bar;              // barrier words (monotonic counters, never reset)
     unsigned long long epoch;             // launches on `bar` so far
@@ -191,7 +194,7 @@ __device__ __forceinline__ float gr_sum32(float x)
 
 // ---- BatchNorm column sums across the grid WITHOUT a separate barrier: every 64-bit accumulator word carries its own arrival count.
 // A workgroup's f32 column sum x (of the true z: the power-of-two scale of the weight image is divided out of the exponent) goes
-// out as ONE integer atomic add of (1 << 58) | (trunc(x * 2^frac) + 2^51), frac = 20: after n contributions a word holds n
+// out as ONE integer atomic add of (1 << 58) | (round(x * 2^frac) + 2^51), frac = 20: after n contributions a word holds n
 // in its top 6 bits and, below, the exact sum of the fixed-point values (n <= 63 workgroups per dispatch group, |x| < 2^31).  A
 // reader that finds the expected count in a word HAS that word's complete sum: no data atomics to wait for before signalling, no
 // counter atomics, no release flag, no second read.  Integer sums are exact and order-independent: the statistics (and with them
@@ -200,9 +203,9 @@ __device__ __forceinline__ float gr_sum32(float x)
 // orders of magnitude under the BatchNorm epsilon (1e-5) the variance is added to.  Range: a workgroup's sum of squares must stay
 // below 2^31 (|z| < 1900 rms over its 576 rows); beyond it — or for a NaN — the contribution is flagged (range word) and the host
 // repeats the forward on the streaming f32-instruction kernels, exactly as for an operand beyond the f16 range.  The first Linear's
-// outputs inherit the range of the raw features (times in the thousands): its words carry 8 fractional bits (range 2^43).
+// outputs inherit the range of the raw features (times in the thousands): its words carry 12 fractional bits (range 2^39).
 #define GR_FIX_FRAC_DEFAULT 20
-#define GR_FIX_FRAC_FIRST 8
+#define GR_FIX_FRAC_FIRST 12
 #define GR_FIX_BIAS (1ull << 51)
 #define GR_FIX_ONE (1ull << 58)
 #define GR_FIX_PAYLOAD (GR_FIX_ONE - 1ull)
@@ -210,12 +213,12 @@ __device__ __forceinline__ unsigned long long gr_fix_encode(float x, int exp2, i
 {
     // integer arithmetic only (an f64 form — ldexp, floor, conversion to a 64-bit integer — took 0.8 us of every boundary):
     // x = (-1)^s * mant * 2^(e - 150)  ->  V = (-1)^s * (mant << sh), sh = e - 150 + FRAC - exp2 <= 27 by the caller's range check
-    // (mant < 2^24: |V| < 2^51); for sh < 0 the bits below 2^-FRAC are dropped (truncation toward zero)
+    // (mant < 2^24: |V| < 2^51); for sh < 0 the magnitude is rounded to the nearest multiple of 2^-frac
     const unsigned u = __builtin_bit_cast(unsigned, x);
     const int e = (int)((u >> 23) & 255u);
     const unsigned long long mant = (unsigned long long)((u & 0x7fffffu) | (e ? 0x800000u : 0u));
     const int sh = (e ? e : 1) - 150 + frac - exp2;
-    long long v = sh >= 0 ? (long long)(mant << (sh > 27 ? 27 : sh)) : (sh > -24 ? (long long)(mant >> (-sh)) : 0ll);
+    long long v = sh >= 0 ? (long long)(mant << (sh > 39 ? 39 : sh)) : (sh > -25 ? (long long)((mant + (1ull << (-sh - 1))) >> (-sh)) : 0ll);   // (round half up)
     if (u >> 31) v = -v;
     return GR_FIX_ONE | (unsigned long long)(v + (long long)GR_FIX_BIAS);
 }
@@ -572,6 +575,9 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
             GR_FENCE();
         }
+        // margin behind the matrix pipe's write-back (MFMA_SETTLE in mtfjsp_encoder.hip): hipcc copies the finished tile out of the
+        // accumulation file right here, at exactly the distance its hazard table asks for
+        if constexpr (!VT && GR_SETTLE) { asm volatile("s_nop 1"); GR_FENCE(); }          // (no operands: nothing for the register allocator to reconcile)
     };
     // first Linear: tile RT's 16-wide operand sits at byte offset 32*(RT & 7) of buffer 0's rows
     auto consume_tile0 = [&](auto Tc) __attribute__((always_inline)) {
@@ -903,6 +909,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                     zstore(std::integral_constant<int, RT - GR_NRES>{}, a);
                     GR_FENCE();
                 }
+                if constexpr (!VT && GR_SETTLE) { asm volatile("s_nop 1"); GR_FENCE(); }          // (no operands: nothing for the register allocator to reconcile)
             };
             write_h(std::integral_constant<int, 0>{}); write_h(std::integral_constant<int, 1>{}); write_h(std::integral_constant<int, 2>{});
             write_h(std::integral_constant<int, 3>{});

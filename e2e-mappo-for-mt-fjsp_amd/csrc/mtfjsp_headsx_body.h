@@ -147,6 +147,7 @@
                 for (int p = 0; p < 2; p++) xv[ks][p] = *reinterpret_cast<const h16x8 *>(tp + xoff + p * X6_PLANE + 64 * ks);
 #pragma unroll
             for (int ks = 0; ks < 4; ks++) X6_STEP(aA, aB, wv, xv[ks], ks);
+            MFMA_SETTLE2(aA, aB);                                   // (margin behind the matrix pipe's write-back: see the macro)
             return aA + aB;
         };
         // a lane's 4 values of row m -> the two planes of a tile

@@ -17,3 +17,26 @@ for r, x in enumerate(b):
         print("   machine row %6d  workgroup %4d  tile-in-workgroup %2d (wave %d, round %d)  tile rows %2d,%2d  lane q=%d  columns off: %3d  first %s  blocks(c) %s  m %s" % (
             row, tile // 12, tile % 12, (tile % 12) % 8, (tile % 12) // 8, (2 * row) % 16, (2 * row) % 16 + 1, ((2 * row) % 16) // 4, len(cols), cols[:8].tolist(),
             sorted(set((cols // 16).tolist())), sorted(set((cols % 16).tolist()))[:16]))
+
+# values of the first few differing rows: expected | got | ratio (a pattern — stale, scaled, zero — names the instruction)
+x = b[0]
+d = np.abs(x - ref)
+rows = np.nonzero(d.max(1) > 1e-5 * scale)[0][:4]
+np.set_printoptions(precision=5, linewidth=220, suppress=True)
+for row in rows:
+    cols = np.nonzero(d[row] > 1e-5 * scale)[0]
+    print("row", row, "columns", cols[0], "..", cols[-1])
+    print("  expected", ref[row, cols])
+    print("  got     ", x[row, cols])
+    print("  got/exp ", x[row, cols] / ref[row, cols])
+    nb = [c for c in (cols[0] - 16, cols[-1] + 1) if 0 <= c < 128]
+    for c0 in nb:
+        print("  neighbour block", c0, "expected", ref[row, c0:c0 + 16][:6], "got", x[row, c0:c0 + 16][:6])
+    # is the wrong block equal to some other row's expected block (a stale / misplaced accumulator)?
+    blk = x[row, cols[0]:cols[0] + 16]
+    cand = np.abs(ref[:, cols[0]:cols[0] + 16] - blk).max(1)
+    print("  closest expected row for this block:", int(cand.argmin()), "max |diff| %.3e" % cand.min(), "(this row: %d)" % row)
+    for cb in range(8):
+        c2 = np.abs(ref[row - 8:row + 8, 16 * cb:16 * cb + 16] - blk).max(1)
+        if c2.min() < 1e-4:
+            print("  == expected block", cb, "of row", row - 8 + int(c2.argmin()))
