@@ -97,14 +97,11 @@ __device__ __forceinline__ float fast_tanh(float x)
 
 // A vector instruction must not read the result of a matrix instruction before the matrix pipe has written it back, and gfx950 does NOT
 // interlock that: tools/ubench/mfma_raw.hip reads stale registers up to 6 wait states behind v_mfma_f32_16x16x32_f16 (5 when the
-// fillers are single-width vector instructions, where ~15-45 % of the reads are still stale: a marginal regime that depends on how the
+// fillers are single-width vector instructions, where 15-45 % of the reads are still stale: a marginal regime that depends on how the
 // SIMD's two waves interleave) and up to 10 behind v_mfma_f32_32x32x16_f16.  hipcc's hazard recogniser inserts the required s_nops with
-// NO margin, counting every vector instruction in between as one wait state.  Round 3's "first launch of the function-form GAT kernel
-// miscomputes a few row tiles" was this: that schedule read one accumulator of the last pass through v_pk_mul_f32 exactly 8 counted
-// wait states (6 vector instructions + s_nop 1) behind its matrix instruction; the stale values sat in lanes 48..63 — the rows of
-// the last write-back pass — of the accumulator read first, a handful of tiles per launch, on every launch (profiles/r04_first_launch_*).
-// MFMA_SETTLE puts four real wait states behind the last matrix instruction of a chain and ties the accumulators to them, so that
-// every schedule — textual body or function, this compiler or the next — has the margin.
+// NO margin, counting every instruction in between as one wait state.  (This was the first suspect of the round-4 bisection of the
+// function-form GAT miscomputation; the culprit turned out to be another one — mtfjsp_gat3x_body.h — but the margin is cheap.)
+// MFMA_SETTLE puts four real wait states behind the last matrix instruction of a chain and ties the accumulators to them.
 #define MFMA_SETTLE1(a) asm volatile("s_nop 3" : "+v"(a))
 #define MFMA_SETTLE2(a, b) asm volatile("s_nop 3" : "+v"(a), "+v"(b))
 #define MFMA_SETTLE3(a, b, c) asm volatile("s_nop 3" : "+v"(a), "+v"(b), "+v"(c))
@@ -1630,15 +1627,7 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
 #include "mtfjsp_headsx_body.h"
     }
 #endif
-#ifdef MTFJSP_DBG_VMWAIT        // bisection aid: every global store of the heads part acknowledged and visible device-wide
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __threadfence();
-#endif
     __syncthreads();
-#ifdef MTFJSP_DBG_POISON        // bisection aid: whatever the GAT part reads from LDS without having written it is a NaN
-    for (int i = threadIdx.x; i < MTFJSP_DBG_POISON / 4; i += 512) reinterpret_cast<unsigned *>(smem)[i] = 0x7fc00000u;
-    __syncthreads();
-#endif
 #if MTFJSP_BODY_FUNCS & 1
     gat3x_body(GA, smem);
 #else

@@ -1,8 +1,8 @@
 // mtfjsp_gat3x_body.h — the statements of k_gat3x (csrc/mtfjsp_encoder.hip), to be included inside a kernel that has `A` (GatArgs) and
 // `smem` (the dynamic LDS base) in scope: once in k_gat3x itself and once, behind the job actor's heads, in k_headsx_gat3x.
 // (Round 3 kept these statements as text because the same statements as a __forceinline__ function miscomputed a few row tiles; round 4
-// found the cause — a vector read of a matrix result with no margin behind the write-back, MFMA_SETTLE in mtfjsp_encoder.hip — and
-// both forms are built and tested: -DMTFJSP_BODY_FUNCS, tests/test_first_launch_gpu.py.)
+// found the cause — a packed-f32 instruction form that is unreliable next to matrix instructions, see the attention mixture below —
+// and both forms are built, linted and tested: -DMTFJSP_BODY_FUNCS, tools/isa_lint.py, tests/test_first_launch_gpu.py.)
     unsigned char *s_wf = smem;                                   // 8*2*4*64*16 B
     float *s_a = reinterpret_cast<float *>(smem + 8 * 2 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
     double *s_red = reinterpret_cast<double *>(s_a);              // (after the last tile)
@@ -82,9 +82,6 @@
                 o[x] = a;
             }
             *reinterpret_cast<float4 *>(my_a + gx_off(r, c4)) = make_float4(o[0], o[1], o[2], o[3]);
-#if defined(MTFJSP_DBG_DSNOP) && (MTFJSP_DBG_DSNOP & 1)      // bisection aid: distance between an LDS store and the next write to its data registers
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (t_n1 < last) fpre = fetch_feat(t_n1);
@@ -157,28 +154,35 @@
                 const float mx = fmaxf(e00, e01);
                 const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
                 const float inv = 1.0f / (x0 + x1);
-                const float al0 = x0 * inv, al1 = x1 * inv;
+                // The attention mixture al0 z0 + al1 z1 as an explicit two-wide product (z0, z1) * (al0, al1) followed by a horizontal add:
+                // (z0, z1) are neighbouring accumulator registers, so the packed multiply needs no operand swizzle.  Left as scalar code,
+                // hipcc's SLP vectoriser paired products of DIFFERENT column blocks — (z1 of block a) * al1 with (z0 of block b) * al0 — and
+                // emitted v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0] (source 1 with its halves swapped).  On gfx950 that form (any packed
+                // f32 instruction whose low result reads the HIGH half of source 1 and the low half of source 0) is not reliable when the
+                // SIMD's other wave is executing matrix instructions: lanes 48..63 of about 0.3 % of the executions come out wrong
+                // (tools/ubench/valu_after_mfma.hip, profiles/r04_ubench_valu_after_mfma.txt).  That — not the first launch — was round 3's
+                // "function form miscomputes a few row tiles"; tools/isa_lint.py now refuses a build that contains the form.
+                const f32x2 alv = {x0 * inv, x1 * inv};
                 const int r = 4 * q + i;
                 if (pass < 2) {
 #pragma unroll
                     for (int c = 0; c < 8; c++) {
-                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
-                        float n0 = al0 * z0 + al1 * z1, n1 = z1;
+                        const float z1 = acc[c][i + 1];
+                        const f32x2 pz = f32x2{acc[c][i], z1} * alv;
+                        float n0 = pz[0] + pz[1], n1 = z1;
                         n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;               // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
                         n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
                         my_a[gx_off(r, c * 16 + m)] = n0;
                         my_a[gx_off(r + 1, c * 16 + m)] = n1;
-#if defined(MTFJSP_DBG_DSNOP) && (MTFJSP_DBG_DSNOP & 2)
-                        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
                     }
                 } else {
                     const bool valid = row0 + r < N;
                     float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + m;
 #pragma unroll
                     for (int c = 0; c < 8; c++) {
-                        const float z0 = acc[c][i], z1 = acc[c][i + 1];
-                        float mv = (al0 * z0 + al1 * z1 + z1) * 0.5f;        // mean over the 2 nodes (ac:420)
+                        const float z1 = acc[c][i + 1];
+                        const f32x2 pz = f32x2{acc[c][i], z1} * alv;
+                        float mv = (pz[0] + pz[1] + z1) * 0.5f;              // mean over the 2 nodes (ac:420)
                         nd[c * 16] = mv;
                         if (!valid) mv = 0.f;
                         st_sum[c] += mv; st_sq[c] = __builtin_fmaf(mv, mv, st_sq[c]);

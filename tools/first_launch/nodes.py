@@ -30,4 +30,5 @@ for r in range(reps):                                    # the GAT launch alone,
     e.machine_actor_forward(env.m_fea1, env.m_fea2, e.h_pooled_o, env.mmask)
     outs.append(e.peek_nodes())
 np.save(sys.argv[2], np.stack(outs))
+np.savez(sys.argv[2] + ".inputs.npz", mfea1=env.m_fea1.cpu().numpy(), mfea2=env.m_fea2.cpu().numpy())
 print("saved", sys.argv[2], np.stack(outs).shape)
