@@ -60,7 +60,7 @@ def same_footprint_copy(env, B, J, M):
     return out
 
 
-PMC_FILE = "r03_pmc_traffic.json"
+PMC_FILE = "r04_pmc_traffic.json"
 
 
 def pmc_traffic(family):

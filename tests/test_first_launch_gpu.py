@@ -76,13 +76,14 @@ for it in range(decisions):
     tf = env.tasks_fea.cpu().numpy(); col = env.ell_col.cpu().numpy().reshape(B, J * M, 2); val = env.ell_val.cpu().numpy().reshape(B, J * M, 2)
     cand, mask = env.candidate.cpu().numpy(), env.job_mask.cpu().numpy()
     hm = e.h_pooled_m.cpu().numpy().copy() if ro.actor.have_hm else None
+    mf2 = env.m_fea2.cpu().numpy().copy()                    # (the machine actor's input: with the step fused into its launch, env.m_fea2 is the NEXT state's afterwards)
     stepped = ro.actor.act(env, it, ro.task, ro.mach, ro.job, env_step=() if os.environ.get("MTFJSP_FUSED_ENV") else None)
     torch.cuda.synchronize()
     o = eo.job_actor_forward(w[0], tf, col, val, cand, mask, hm, B, J * M)
     top2 = np.sort(o["prob"], 1)[:, -2:]
     clear = top2[:, 1] - top2[:, 0] > 2e-4
     assert np.array_equal(ro.job.cpu().numpy()[clear], o["prob"].argmax(1)[clear])
-    mo = eo.machine_actor_forward(w[1], env.m_fea1.cpu().numpy(), env.m_fea2.cpu().numpy(), e.h_pooled_o.cpu().numpy(), env.mmask.cpu().numpy(), B, M)
+    mo = eo.machine_actor_forward(w[1], env.m_fea1.cpu().numpy(), mf2, e.h_pooled_o.cpu().numpy(), env.mmask.cpu().numpy(), B, M)
     worst = max(worst, float(np.abs(e.job_prob.cpu().numpy() - o["prob"]).max()), float(np.abs(e.mch_prob.cpu().numpy() - mo["prob"]).max()),
                 float(np.abs(e.h_pooled_m.cpu().numpy() - mo["h_pooled"]).max()) / max(1.0, float(np.abs(mo["h_pooled"]).max())))
     if not stepped:
