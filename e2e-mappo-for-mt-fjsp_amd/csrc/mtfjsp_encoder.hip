@@ -1622,18 +1622,30 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
 #if MTFJSP_BODY_FUNCS & 2
     headsx_body(HA, smem);
 #else
+    // the GAT part's 64 KB weight image is requested while the heads part runs its softmax and selection (round 4: staging it was
+    // 3.3 us of the GAT part, most of it the latency of the first request) and committed to LDS behind the barrier
+    float4 gat_pf[8];
+#define HEADS_TAIL_HOOK() do { const float4 *pf_ = reinterpret_cast<const float4 *>(GA.Wx6); _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) gat_pf[i_] = pf_[i_ * 512 + threadIdx.x]; } while (0)
     {
         const HeadArgs &A = HA;
 #include "mtfjsp_headsx_body.h"
     }
+#undef HEADS_TAIL_HOOK
 #endif
     __syncthreads();
 #if MTFJSP_BODY_FUNCS & 1
     gat3x_body(GA, smem);
-#else
+#elif MTFJSP_BODY_FUNCS & 2
     {
         const GatArgs &A = GA;
 #include "mtfjsp_gat3x_body.h"
+    }
+#else
+    {
+        const GatArgs &A = GA;
+#define GAT_PREFETCHED gat_pf
+#include "mtfjsp_gat3x_body.h"
+#undef GAT_PREFETCHED
     }
 #endif
 }
@@ -1798,6 +1810,10 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
     }
 }
 
+// (Round 4 tried ONE WAVE per instance instead — lane = (row parity, 4 columns), a ring of 16 row-pair requests that runs across
+// instance boundaries, the two parities folded with one cross-lane move, the candidate rows picked out of the stream, no barriers:
+// 121.7 / 131.1 us against 115.5 / 107.2 us for this kernel at J10M10 x 8192 / J20M20 x 2048 on the same box — the ring's slots are
+// consumed in issue order with a wait each, and a wave has a sixteenth of a block's requests in flight.  Not kept.)
 // broadcast a [128] vector to [B,128] (first step: learned `_input` instead of h_m_prev, ac:229-233)
 __global__ void k_bcast128(int B, const float *v, float *out)
 {

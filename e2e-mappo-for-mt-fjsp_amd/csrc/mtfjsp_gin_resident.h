@@ -328,7 +328,6 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if (tid == 0) s_flag[1] = 0u;
         if (tid < 5 * (GR_NT / GR_GRP)) s_cnt[tid] = 0u;
         for (int i = tid; i < 2 * GR_TILE / 16; i += 256) reinterpret_cast<float4 *>(s_planes)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < 3 * GR_PLANE / 16; i += 256) reinterpret_cast<float4 *>(reinterpret_cast<unsigned char *>(s_ring) + 32768)[i] = make_float4(0.f, 0.f, 0.f, 0.f);   // (first Linear's second plane buffer)
         if (A.candidate) {                                        // row -> candidate slot (ac:197-207 gathers h of one row per job)
             __syncthreads();
 #pragma unroll
@@ -581,13 +580,9 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if constexpr (!VT && GR_SETTLE) { asm volatile("s_nop 1"); GR_FENCE(); }          // (no operands: nothing for the register allocator to reconcile)
     };
     // first Linear: tile RT's 16-wide operand sits at byte offset 32*(RT & 7) of buffer 0's rows
-    // (two plane buffers: chunk C of 8 tiles sits in buffer C & 1 — buffer 1 is a piece of the ring area behind the staged features —
-    // so that the operands of chunk C + 1 are produced between the matrix instructions of chunk C)
-    unsigned char *const l0buf1 = reinterpret_cast<unsigned char *>(s_ring) + 32768;
-    static_assert(GR_ROWS * 12 * 4 <= 32768 && 32768 + 3 * GR_PLANE <= GR_RING_BYTES, "first Linear: features + second plane buffer in the ring area");
     auto consume_tile0 = [&](auto Tc) __attribute__((always_inline)) {
         constexpr int RT = decltype(Tc)::value;
-        const unsigned char *xa = (((RT >> 3) & 1) ? l0buf1 + n * GR_ROWB + 16 * h : xa0) + 32 * (RT & 7);
+        const unsigned char *xa = xa0 + 32 * (RT & 7);
         bf16x8 x[3];
 #pragma unroll
         for (int p = 0; p < 3; p++) x[p] = *reinterpret_cast<const bf16x8 *>(xa + p * GR_PLANE);
@@ -612,10 +607,6 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     auto layer_boundary = [&](auto Kc) __attribute__((always_inline)) {
         constexpr int k = decltype(Kc)::value;
         GR_STAMP_AT(4 + 4 * k);
-        // requests that depend on nothing of this boundary go out first: the next Linear's weight fragments (the layer's own are dead)
-        // — their address processing (about 0.5 us per workgroup in the in-order memory pipeline) then runs under the fold below
-        // instead of between the statistics' atomics and the first poll
-        if constexpr (k < 5) load_weights(k + 1);
         if constexpr (GR_VRES && GR_NT > GR_NRES) {               // the last tile's sums (it has no successor to take them beside)
             asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");     // (its matrix instructions were written as text: no compiler-inserted wait before the reads)
             stats_all(zs[(GR_NT - 1 - GR_NRES) & 1]);
@@ -646,7 +637,11 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (k == 1) GR_STAMP_AT(3);
-        const float ga = A.gamma[k][scol], be = A.beta[k][scol];  // (this BatchNorm's affine parameters: needed after the poll)
+        // requests that do not depend on the other workgroups go out behind it: this BatchNorm's affine parameters and the next
+        // Linear's weight fragments.  (Measured, round 4: with the weight requests at the TOP of the boundary — under the fold — the
+        // statistics' atomics queue behind 64 KB of loads in the in-order memory pipeline and every boundary gets 0.4 to 1.9 us longer.)
+        const float ga = A.gamma[k][scol], be = A.beta[k][scol];
+        if constexpr (k < 5) load_weights(k + 1);
         GR_STAMP_AT(5 + 4 * k);
         // every thread collects its own (column, kind) from the 8 dispatch groups: a word is complete when it carries its group's size
         // in the count field
@@ -720,30 +715,26 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             if (row >= nrows) { v[0] = 0.f; v[1] = 0.f; }
             uint2 p0, p1, p2;
             split3x4(v, p0, p1, p2);                              // elements 2, 3 are padding
-            unsigned char *d = (((rt >> 3) & 1) ? l0buf1 : s_planes) + r * GR_ROWB + 32 * (rt & 7) + 4 * fk;
+            unsigned char *d = s_planes + r * GR_ROWB + 32 * (rt & 7) + 4 * fk;
             if (fk < 6) {
                 *reinterpret_cast<unsigned *>(d) = p0.x;
                 *reinterpret_cast<unsigned *>(d + GR_PLANE) = p1.x;
                 *reinterpret_cast<unsigned *>(d + 2 * GR_PLANE) = p2.x;
             }
         };
-#pragma unroll
-        for (int i = 0; i < (GR_NT < 8 ? GR_NT : 8); i++) produce0(i);
-        LDS_BARRIER();
-        __builtin_amdgcn_sched_barrier(0);
+        // (producing chunk C + 1's operands between chunk C's matrix instructions — a second plane buffer — was measured in round 4: 6.4 us
+        // for this Linear against 6.5 us; not kept)
         gr_static_for<(GR_NT + 7) / 8>([&](auto Cc) __attribute__((always_inline)) {
             constexpr int C = decltype(Cc)::value;
             constexpr int NTC = GR_NT - 8 * C < 8 ? GR_NT - 8 * C : 8;
-            constexpr int NNX = GR_NT - 8 * (C + 1) < 0 ? 0 : (GR_NT - 8 * (C + 1) < 8 ? GR_NT - 8 * (C + 1) : 8);      // tiles of the next chunk
-            gr_static_for<NTC>([&](auto Ic) __attribute__((always_inline)) {
-                constexpr int I = decltype(Ic)::value, RT = 8 * C + I;
-                consume_tile0(std::integral_constant<int, RT>{});
-                if constexpr (I < NNX) { produce0(8 * (C + 1) + I); __builtin_amdgcn_sched_barrier(0); }
-            });
-            if constexpr (NNX > NTC) {
 #pragma unroll
-                for (int i = NTC; i < NNX; i++) produce0(8 * (C + 1) + i);
-            }
+            for (int i = 0; i < NTC; i++) produce0(8 * C + i);
+            LDS_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+            gr_static_for<NTC>([&](auto Ic) __attribute__((always_inline)) {
+                constexpr int RT = 8 * C + decltype(Ic)::value;
+                consume_tile0(std::integral_constant<int, RT>{});
+            });
             LDS_BARRIER();
             __builtin_amdgcn_sched_barrier(0);
         });
