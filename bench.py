@@ -552,12 +552,50 @@ def main():
         }
         if full_handoff is not None:
             out["handoff_full"] = full_handoff
+        # the two latency chains beside the dominant kernel (round-3 review: "no roofline at all"): matrix time and LDS traffic bound
+        heads = {}
+        for fam in ("heads", "heads_gat3", "gat3"):
+            if fam in ktimes and ktimes[fam]["launches"]:
+                try:
+                    heads[fam] = ro.roofline(fam, ktimes[fam])
+                except Exception as ex:
+                    heads[fam] = {"error": repr(ex)}
+        if heads:
+            out["roofline_heads"] = heads
+        full_rate = None
+        if world == 1 and policy == "actor" and args.trajectory == "advantage" and not args.no_config_legs:
+            # the same rollout with the complete device trajectory buffer (every field of the reference's ReplayBuffer):
+            # its cost under the driver's clock, as an extra key (`value` stays the advantage-inputs trajectory BASELINE's metric names)
+            try:
+                del ro.traj
+            except AttributeError:
+                pass
+            ro2 = rollout_mod.Rollout(J, M, E, B, device=local_rank, policy=policy, obs_dtype=args.obs, instance_seed=0, rank=rank, world=world, collect="full")
+            for _ in range(2 * T):
+                ro2.step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            nfull = 10 * T
+            for _ in range(nfull):
+                ro2.step()
+            torch.cuda.synchronize()
+            dtf = time.perf_counter() - t0
+            full_rate = {"value": B * nfull / dtf, "unit": "env-steps/s", "ms_per_step": dtf / nfull * 1e3, "steps_timed": nfull,
+                         "what": "--trajectory full: the device-resident TrajectoryBuffer records every field of the reference's ReplayBuffer per step"}
+            del ro2
+            torch.cuda.empty_cache()
+            out["trajectory_full"] = full_rate
         if world == 1 and not args.no_env_sweep:
             del ro
             torch.cuda.empty_cache()
             sweep = [env_kernel_large_batch(J, M, E, local_rank, B=b, episodes=1 if b >= 65536 else 2) for b in (4096, 16384, 65536, 262144)]
             out["roofline_env_step_batch_sweep"] = sweep
             out["roofline_env_step_large_batch"] = sweep[-1]
+            if B == sweep[0]["instances"]:
+                # SURVEY 8(d)'s denominator for the step kernel as it runs INSIDE the rollout (the sweep's figure is the kernel alone)
+                c16 = sweep[0]["same_footprint_copy"]["access_16B"]["avg_launch_us"]
+                out["roofline_env_step"]["same_footprint_copy_us"] = c16
+                out["roofline_env_step"]["frac_of_same_footprint_copy"] = c16 / out["roofline_env_step"]["avg_launch_us"]
         if world == 1 and headline and policy == "actor" and not args.no_config_legs:
             legs = {}
             for name, (cj, cm, ce, cb) in (("J10M10E2_x8192", (10, 10, 2, 8192)), ("J20M20E4_x2048", (20, 20, 4, 2048))):

@@ -1622,30 +1622,20 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
 #if MTFJSP_BODY_FUNCS & 2
     headsx_body(HA, smem);
 #else
-    // the GAT part's 64 KB weight image is requested while the heads part runs its softmax and selection (round 4: staging it was
-    // 3.3 us of the GAT part, most of it the latency of the first request) and committed to LDS behind the barrier
-    float4 gat_pf[8];
-#define HEADS_TAIL_HOOK() do { const float4 *pf_ = reinterpret_cast<const float4 *>(GA.Wx6); _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) gat_pf[i_] = pf_[i_ * 512 + threadIdx.x]; } while (0)
+    // (requesting the GAT part's 64 KB weight image under the heads part's softmax — eight float4 per thread held across the barrier —
+    // was measured in round 4: 48.7 us against 46.2 us per launch; not kept)
     {
         const HeadArgs &A = HA;
 #include "mtfjsp_headsx_body.h"
     }
-#undef HEADS_TAIL_HOOK
 #endif
     __syncthreads();
 #if MTFJSP_BODY_FUNCS & 1
     gat3x_body(GA, smem);
-#elif MTFJSP_BODY_FUNCS & 2
-    {
-        const GatArgs &A = GA;
-#include "mtfjsp_gat3x_body.h"
-    }
 #else
     {
         const GatArgs &A = GA;
-#define GAT_PREFETCHED gat_pf
 #include "mtfjsp_gat3x_body.h"
-#undef GAT_PREFETCHED
     }
 #endif
 }

@@ -18,17 +18,11 @@
     {   // stage the weight fragments: 65536 B = 8 x 16 B per thread, coalesced
         const float4 *src = reinterpret_cast<const float4 *>(A.Wx6);
         float4 *dst = reinterpret_cast<float4 *>(s_wf);
-#ifdef GAT_PREFETCHED                                               // (k_headsx_gat3x: requested under the heads' softmax, HEADS_TAIL_HOOK)
-        (void)src;
-#pragma unroll
-        for (int i = 0; i < 8; i++) dst[i * 512 + tid] = GAT_PREFETCHED[i];
-#else
         float4 v[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) v[i] = src[i * 512 + tid];
 #pragma unroll
         for (int i = 0; i < 8; i++) dst[i * 512 + tid] = v[i];
-#endif
     }
     const float wsinv = A.w_sinv;
     float *my_a = s_a + wave * 16 * HD;

@@ -252,9 +252,6 @@
             STAMP(4);
         }
         // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance; optional action selection
-#ifdef HEADS_TAIL_HOOK
-        HEADS_TAIL_HOOK();                                          // (k_headsx_gat3x: the GAT part's weight image is requested here, under the softmax)
-#endif
         {
             const int r0 = tid >> 4, l = tid & 15;
             if (r0 < ng) {

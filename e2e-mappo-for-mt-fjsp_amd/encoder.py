@@ -361,6 +361,33 @@ class ActorPair:
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_bytes_per_launch": nbytes,
                     "algorithmic_flops_per_launch": flops, "f32_equivalent_TFLOPs": flops / avg_s / 1e12,
                     "f16_matrix_TFLOPs": 3 * flops / avg_s / 1e12}
+        if name in ("heads", "heads_gat3", "gat3"):
+            # Latency chains: one workgroup per CU runs a dependent sequence of small products separated by workgroup barriers.  Two
+            # bounds are priced: the matrix time of the executed f16 piece products at the dense 16-bit peak, and the LDS traffic of
+            # the operand reads at the chip's ds_read_b128 rate (every wave re-reads every activation tile / the GAT weight image).
+            R = J if name != "gat3" else 0
+            heads_flops = lambda rows_per_inst: 2.0 * B * H * H * (2 * rows_per_inst + 4)          # Wa x, W1 s1 per scorer row; Wb, Wc, Wc0, Wc1 per instance
+            gat_flops = 2.0 * (2 * B * M) * H * H * 2 + 2.0 * (2 * B * M) * 8 * H             # two 128-deep passes + the K = 8 first pass
+            if name == "heads":
+                rows = (J + M) / 2.0                                                           # job and machine heads launches are averaged in this family
+                flops = heads_flops(rows)
+                lds = B * (rows + 2) * H * 2 * 2 * 8 * 2                                       # planes (2 x f16) of every tile read by all 8 waves, twice (phases B, C)
+            elif name == "heads_gat3":
+                flops = heads_flops(J) + gat_flops
+                lds = B * (J + 2) * H * 2 * 2 * 8 * 2 + (2 * B * M / 16.0) * 2 * 65536           # + the 64 KB weight image streamed per tile and pass
+            else:
+                flops = gat_flops
+                lds = (2 * B * M / 16.0) * 2 * 65536
+            executed = 3.0 * flops
+            t_mfma = executed / 2.5e15
+            t_lds = lds / 150e12                                                               # ~150 TB/s aggregate ds_read_b128 (MI355X_MICROARCH.md, LDS)
+            return {"kernel": {"heads": "k_headsx (both heads of an actor for 16 instances per workgroup)", "heads_gat3": "k_headsx_gat3x (job heads + the machine path's three GAT passes)",
+                               "gat3": "k_gat3x (three GAT passes, stand-alone)"}[name],
+                    "bound": "latency (dependent phases of one workgroup per CU); priced against the matrix peak and the LDS read rate",
+                    "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_flops_per_launch": flops, "executed_matrix_flops_per_launch": executed,
+                    "matrix_time_us_at_2.5_PFLOPs": t_mfma * 1e6, "frac_of_matrix_peak": t_mfma / avg_s,
+                    "lds_operand_bytes_per_launch": lds, "lds_time_us_at_150_TBps": t_lds * 1e6, "frac_of_lds_read_rate": t_lds / avg_s,
+                    "achieved": executed / avg_s / 1e12, "peak": 2500.0, "unit": "TFLOP/s", "frac": t_mfma / avg_s, "traffic": None}
         if name == "gin_resident":
             # k_gin_res: the six Linear products of one forward in one launch.  Algorithmic work = the f32 products of the
             # reference (2 * rows * (12*128 + 5*128*128)); executed on the f16 matrix cores as 3 piece products each (the first
