@@ -50,6 +50,7 @@ PROTOTYPES = {
     "mtfjsp_alloc_obs": (_I, [_VP, C.POINTER(Obs)]),
     "mtfjsp_bind_obs": (_I, [_VP, C.POINTER(Obs)]),
     "mtfjsp_snapshot_obs": (_I, [_VP, C.POINTER(Obs)]),
+    "mtfjsp_snapshot_obs2": (_I, [_VP, C.POINTER(Obs), C.POINTER(Obs), _VP]),
     "mtfjsp_generate_instances": (_I, [_VP, _U64, _U64, _VP]),
     "mtfjsp_read_instances_host": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_load_instances": (_I, [_VP, _VP, _VP, _VP, _VP]),

@@ -1576,20 +1576,26 @@ __global__ void k_scaler(int B, int full, double *scal, const uint8_t *mask)
 // observation snapshot into a trajectory slot (device-resident replacement of ReplayBuffer.store_operation's
 // per-step copies, replaybuffer.py:82-139): up to 8 (src, dst, bytes) segments in ONE launch; 16-byte lanes for the bulk,
 // bytes for a ragged tail.  Pointers are 16-byte aligned when bytes % 16 == 0 slots are used (checked on the host).
-struct SnapSeg { const unsigned char *src; unsigned char *dst; unsigned long long bytes; };
-struct SnapArgs { SnapSeg seg[8]; int n; };
+struct SnapSeg { const unsigned char *src; unsigned char *dst, *dst2; unsigned long long bytes; };
+struct SnapArgs { SnapSeg seg[8]; int n; const double *info; float *reward; int B; };
 __global__ __launch_bounds__(256) void k_snapshot(SnapArgs A)
 {
     const size_t gt = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
     for (int i = 0; i < A.n; i++) {
         const SnapSeg g = A.seg[i];
-        const bool al = (((size_t)g.src | (size_t)g.dst) & 15) == 0;
+        const bool al = (((size_t)g.src | (size_t)g.dst | (size_t)g.dst2) & 15) == 0;
         const size_t n16 = al ? g.bytes >> 4 : 0;
         const uint4 *s4 = reinterpret_cast<const uint4 *>(g.src);
-        uint4 *d4 = reinterpret_cast<uint4 *>(g.dst);
-        for (size_t k = gt; k < n16; k += stride) d4[k] = s4[k];
-        for (size_t k = (n16 << 4) + gt; k < g.bytes; k += stride) g.dst[k] = g.src[k];
+        uint4 *d4 = reinterpret_cast<uint4 *>(g.dst), *e4 = reinterpret_cast<uint4 *>(g.dst2);
+        if (g.dst2) {                                                       // one read, two destinations (s' of step k = s of step k+1)
+            for (size_t k = gt; k < n16; k += stride) { const uint4 v = s4[k]; d4[k] = v; e4[k] = v; }
+            for (size_t k = (n16 << 4) + gt; k < g.bytes; k += stride) { const unsigned char v = g.src[k]; g.dst[k] = v; g.dst2[k] = v; }
+        } else {
+            for (size_t k = gt; k < n16; k += stride) d4[k] = s4[k];
+            for (size_t k = (n16 << 4) + gt; k < g.bytes; k += stride) g.dst[k] = g.src[k];
+        }
     }
+    if (A.reward) for (size_t b = gt; b < (size_t)A.B; b += stride) A.reward[b] = (float)A.info[b * 6];   // info[:,0] as f32 (pe:255-262)
 }
 
 // On-device instance generator (distribution of instance/generate_allsize_mofjsp_dataset.py:133-296, values of
@@ -1812,36 +1818,51 @@ extern "C" int mtfjsp_bind_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *o)
 
 // = the observation part of ReplayBuffer.store_operation (replaybuffer.py:82-139): copy the CURRENT bound observation
 // (tasks_fea, ELL adjacency, m_fea2, candidate, job_mask; info/raw/status when dst has them) into caller buffers of the
-// same layout, one launch on the handle's stream.  dst fields left NULL are skipped.
-extern "C" int mtfjsp_snapshot_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *dst)
+// same layout, one launch on the handle's stream.  dst fields left NULL are skipped.  With dst2 the same launch writes a
+// second copy (the reference's buffer keeps s' of step k and s of step k+1 separately: replaybuffer.py:97-118); with
+// reward_out it also stores the scalar reward info[:,0] as f32 [B] (replaybuffer.py:106).
+static int snapshot_impl(mtfjsp_env *h, const mtfjsp_obs_t *dst, const mtfjsp_obs_t *dst2, float *reward_out)
 {
-    if (!h || !dst) return MTFJSP_ERR_ARG;
     if (!h->obs_bound) { h->err = "no observation buffers bound (mtfjsp_alloc_obs / mtfjsp_bind_obs)"; return MTFJSP_ERR_STATE; }
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const size_t B = h->cfg.batch, T = h->T, M = h->cfg.n_machine, J = h->cfg.n_job;
     const size_t es = h->cfg.obs_dtype == MTFJSP_OBS_F32 ? 4 : 8;
     SnapArgs a{};
     size_t total = 0;
-    auto add = [&](const void *src, void *d, size_t bytes) {
+    auto add = [&](const void *src, void *d, void *d2, size_t bytes) {
+        if (!d) { d = d2; d2 = nullptr; }
         if (!d || !src) return;
-        a.seg[a.n].src = (const unsigned char *)src; a.seg[a.n].dst = (unsigned char *)d; a.seg[a.n].bytes = bytes; a.n++;
+        a.seg[a.n].src = (const unsigned char *)src; a.seg[a.n].dst = (unsigned char *)d; a.seg[a.n].dst2 = (unsigned char *)d2; a.seg[a.n].bytes = bytes; a.n++;
         total += bytes;
     };
-    add(h->obs.tasks_fea, dst->tasks_fea, B * T * 12 * es);
-    add(h->obs.ell_col, dst->ell_col, B * T * 2 * 4);
-    add(h->obs.ell_val, dst->ell_val, B * T * 2 * 4);
-    add(h->obs.m_fea2, dst->m_fea2, B * M * 8 * es);
-    add(h->obs.candidate, dst->candidate, B * J * 4);
-    add(h->obs.job_mask, dst->job_mask, B * J);
-    add(h->obs.info, dst->info, B * 6 * 8);
-    add(h->obs.raw, dst->raw, B * 5 * 8);
-    if (a.n == 0) return MTFJSP_OK;
+#define SNAP2(f) (dst2 ? (void *)dst2->f : nullptr)
+    add(h->obs.tasks_fea, dst->tasks_fea, SNAP2(tasks_fea), B * T * 12 * es);
+    add(h->obs.ell_col, dst->ell_col, SNAP2(ell_col), B * T * 2 * 4);
+    add(h->obs.ell_val, dst->ell_val, SNAP2(ell_val), B * T * 2 * 4);
+    add(h->obs.m_fea2, dst->m_fea2, SNAP2(m_fea2), B * M * 8 * es);
+    add(h->obs.candidate, dst->candidate, SNAP2(candidate), B * J * 4);
+    add(h->obs.job_mask, dst->job_mask, SNAP2(job_mask), B * J);
+    add(h->obs.info, dst->info, SNAP2(info), B * 6 * 8);
+    add(h->obs.raw, dst->raw, SNAP2(raw), B * 5 * 8);
+#undef SNAP2
+    if (reward_out) { a.info = h->obs.info; a.reward = reward_out; a.B = (int)B; }
+    if (a.n == 0 && !reward_out) return MTFJSP_OK;
     size_t blocks = (total / 16 + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_snapshot, dim3((unsigned)blocks), dim3(256), 0, h->stream, a);
     HIPCHK(h, hipGetLastError());
     return MTFJSP_OK;
+}
+extern "C" int mtfjsp_snapshot_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *dst)
+{
+    if (!h || !dst) return MTFJSP_ERR_ARG;
+    return snapshot_impl(h, dst, nullptr, nullptr);
+}
+extern "C" int mtfjsp_snapshot_obs2(mtfjsp_handle_t h, const mtfjsp_obs_t *dst, const mtfjsp_obs_t *dst2, float *reward_out)
+{
+    if (!h || !dst) return MTFJSP_ERR_ARG;
+    return snapshot_impl(h, dst, dst2, reward_out);
 }
 
 static int load_common(mtfjsp_env *h, const double *t, const double *p, const double *tt, const int32_t *shop, hipMemcpyKind kind)
@@ -2090,7 +2111,17 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
             unsigned long long t0 = ~0ull;
             for (int w = 0; w < ng; w++) t0 = hst[(size_t)w * 8] < t0 ? hst[(size_t)w * 8] : t0;
             for (int w = 0; w < ng; w++) for (int i = 0; i < 8; i++) r[i] += (double)(hst[(size_t)w * 8 + i] - t0) / 100.0 / ng;
-            printf("STAMP k_env_grp16 B=%d (us since the first workgroup's start, wave 0): entry %.2f  first-hop data %.2f  decision %.2f  per-task costs done %.2f  wave done %.2f  barrier %.2f  tail issued %.2f  stores drained %.2f\n",
+#ifdef MTFJSP_STAMP_WAVES
+            if (P.B == 4096) {
+                double e[16] = {0}, f[16] = {0}, c[16] = {0}, dn[16] = {0};
+                for (int w = 0; w < ng; w++) for (int g = 0; g < 16; g++) {
+                    e[g] += (double)(hst[2048 + (size_t)w * 64 + g * 4] - t0) / 100.0 / ng; f[g] += (double)(hst[2048 + (size_t)w * 64 + g * 4 + 1] - t0) / 100.0 / ng;
+                    c[g] += (double)(hst[2048 + (size_t)w * 64 + g * 4 + 2] - t0) / 100.0 / ng; dn[g] += (double)(hst[2048 + (size_t)w * 64 + g * 4 + 3] - t0) / 100.0 / ng;
+                }
+                for (int g = 0; g < 16; g++) printf("STAMPW wave %2d: entry %.2f first-hop %.2f costs %.2f done %.2f\n", g, e[g], f[g], c[g], dn[g]);
+            }
+#endif
+            printf("STAMP k_env_grp16 B=%d (us since the first workgroup's start, wave 0): entry %.2f  first-hop data %.2f  decision %.2f  per-task costs done %.2f  wave done %.2f  barrier %.2f  scalar-part wave done %.2f  ELL/mask wave done %.2f\n",
                    P.B, r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
         } else
         printf("STAMP k_env B=%d: load %.0f  schedule %.0f  estimate+terms %.0f  lane0-costs %.0f  scaler+info %.0f  observation %.0f  mask %.0f+writeback-issue  drain %.0f  (cycles/wave)\n",

@@ -321,10 +321,27 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
     const int b = b0 + g;
     if (g >= EG || b >= P.B) return;
     const int J = P.J, M = P.M, T = P.T;
-    const double *sc = A.scl(g);
-    const int status = A.in(g)[I_STATUS];
-    if (!A.in(g)[I_VALID]) {                                                    // rejected action: nothing changed; observations persist
-        const bool all_done = sc[S_NSCHED] == (double)T;
+    // Every fixed-slot input of the scalar part is requested here in ONE batch of LDS reads: this wave runs alone after the
+    // group's barrier, so a read per dependent step is all latency (the per-use form had twelve serial LDS round trips, about
+    // 0.7 us of the 1.8 us this part took).  The first chunk of the job maxima and of the idle terms rides in the same batch.
+    const int *in = A.in(g);
+    const double *sc = A.scl(g), *un = A.un(g), *so = A.sorted(g), *jm = A.jmx(g);
+    const int valid = in[I_VALID], status = in[I_STATUS], nsched = in[I_NSCHED], m = in[I_M];
+    const double mk_prev = sc[S_MK_PREV], e1_prev = sc[S_E1_PREV], tr_prev = sc[S_TR_PREV], id_prev = sc[S_ID_PREV];
+    const double tr_this0 = sc[S_TR_THIS], n0 = sc[S_N], ns0 = sc[S_NSCHED];
+    const double sR0 = sc[S_R + ch], sM0 = sc[S_MEAN + ch], S0 = sc[S_S + ch];
+    const double u_r0 = un[U_R0], new_tr = un[U_NEWTR], d = un[U_D], pk = un[U_PK], fttail = un[U_FTTAIL];
+    double xt[7];
+#pragma unroll
+    for (int i = 0; i < 7; i++) xt[i] = un[U_TAIL + i];
+    const double mf_ch = A.mf(g)[ch], mf_4 = A.mf(g)[4];
+    double xj[8], xs[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xj[k] = jm[k < J ? k : J - 1];
+#pragma unroll
+    for (int k = 0; k < 8; k++) xs[k] = so[k];
+    if (!valid) {                                                               // rejected action: nothing changed; observations persist
+        const bool all_done = ns0 == (double)T;
         P.obs.info[(size_t)b * 6 + ch] = (ch == 1 && all_done) ? 1.0 : 0.0;
         if (ch < 2) P.obs.info[(size_t)b * 6 + 4 + ch] = 0.0;
         if (P.obs.raw) { P.obs.raw[(size_t)b * 5 + ch] = 0.0; if (ch == 0) P.obs.raw[(size_t)b * 5 + 4] = 0.0; }
@@ -333,51 +350,40 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
         if (ch == 1) P.obs.status[b] = status;
         return;
     }
-    const int nsched = A.in(g)[I_NSCHED], m = A.in(g)[I_M];
-    // (loops in chunks whose LDS reads go out together: this wave runs alone, a read per dependent step would be all latency;
-    // indices past the end are clamped — max / min are idempotent — or hit zero-filled slots)
-    double mk = A.jmx(g)[0];                                                    // env:894 np.amax
-    for (int j0 = 0; j0 < J; j0 += 4) {
+    // (indices past the end are clamped — max / min are idempotent — or hit zero-filled slots)
+    double mk = xj[0];                                                          // env:894 np.amax
+#pragma unroll
+    for (int k = 1; k < 8; k++) mk = fmax(mk, xj[k]);
+    for (int j0 = 8; j0 < J; j0 += 4) {
         double x[4];
 #pragma unroll
-        for (int k = 0; k < 4; k++) x[k] = A.jmx(g)[j0 + k < J ? j0 + k : J - 1];
+        for (int k = 0; k < 4; k++) x[k] = jm[j0 + k < J ? j0 + k : J - 1];
 #pragma unroll
         for (int k = 0; k < 4; k++) mk = fmax(mk, x[k]);
     }
-    double e1 = A.un(g)[U_R0];                                                  // env:896 np.sum: pairwise part, then the ragged tail in order
+    double e1 = u_r0;                                                           // env:896 np.sum: pairwise part, then the ragged tail in order
     bool big = false;
     if constexpr (ACC::kBigT) big = T > 128;                                    // (more than one leaf block: the instance's wave walked numpy's recursion, U_R0 is the total)
     if (!big) {
         const int nt = T < 8 ? T : (T & 7);
-        double x[7];
 #pragma unroll
-        for (int i = 0; i < 7; i++) x[i] = A.un(g)[U_TAIL + i];
-#pragma unroll
-        for (int i = 0; i < 7; i++) if (i < nt) e1 += x[i];
+        for (int i = 0; i < 7; i++) if (i < nt) e1 += xt[i];
     }
     e1 = 0.0 + e1;
     // dg:144-170, strictly left to right.  Slots >= nsched hold +0.0 and the running sum starts at +0.0, so it is never -0.0 and
     // adding them changes nothing: the loop stops at nsched; the next chunk's reads are in flight under the 8 dependent adds
     double idle = 0.0;
-    {
-        const double *so = A.sorted(g);
-        double x[8];
+    for (int i0 = 0; i0 < nsched; i0 += 8) {
+        double y[8];
+        const bool more = i0 + 8 < nsched;
 #pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = so[k];
-        for (int i0 = 0; i0 < nsched; i0 += 8) {
-            double y[8];
-            const bool more = i0 + 8 < nsched;
+        for (int k = 0; k < 8; k++) y[k] = more ? so[i0 + 8 + k] : 0.0;
 #pragma unroll
-            for (int k = 0; k < 8; k++) y[k] = more ? so[i0 + 8 + k] : 0.0;
+        for (int k = 0; k < 8; k++) idle = idle + xs[k];
 #pragma unroll
-            for (int k = 0; k < 8; k++) idle = idle + x[k];
-#pragma unroll
-            for (int k = 0; k < 8; k++) x[k] = y[k];
-        }
+        for (int k = 0; k < 8; k++) xs[k] = y[k];
     }
-    const double new_tr = A.un(g)[U_NEWTR], d = A.un(g)[U_D], pk = A.un(g)[U_PK];
-    const double trans_this = sc[S_TR_THIS] + new_tr;
-    const double mk_prev = sc[S_MK_PREV], e1_prev = sc[S_E1_PREV], tr_prev = sc[S_TR_PREV], id_prev = sc[S_ID_PREV];
+    const double trans_this = tr_this0 + new_tr;
     const double r_t = 1.0 * mk_prev - mk;                                      // env:1066
     double r_pt = 1.0 * e1_prev - e1;
     r_pt = r_pt / (double)T;                                                    // env:1073-1076
@@ -388,11 +394,10 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
     const bool done = nsched == T;                                              // env:797-800
     double *s = P.scal + (size_t)b * SCAL_N;
     {   // reward scaling of channel ch (pt:54-124)
-        const double n = sc[S_N] + 1.0;
+        const double n = n0 + 1.0;
         const double x = ch == 0 ? r_t : ch == 1 ? r_idle : ch == 2 ? r_pt : r_tt;
-        const double sR0 = sc[S_R + ch], sM0 = sc[S_MEAN + ch];
         const double R = P.gamma * sR0 + x;
-        double mean, S = sc[S_S + ch], sd;
+        double mean, S = S0, sd;
         if (n == 1.0) { mean = R; sd = fabs(R); }
         else { mean = sM0 + (R - sM0) / n; S = S + (R - sM0) * (R - mean); sd = sqrt(S / n); }
         const double scaled = x / (sd + 1e-8);
@@ -414,8 +419,8 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
         if (ch == 1) P.obs.status[b] = status;
     }
     {   // machine features of the acting machine (env:2315-2340): columns 0..3 on the four lanes, column 4 with lane 0
-        double mfr = A.mf(g)[ch];
-        if (ch == 0) mfr = A.un(g)[U_FTTAIL];
+        double mfr = mf_ch;
+        if (ch == 0) mfr = fttail;
         else if (ch == 1) mfr += (pk * d) / (double)T;
         else if (ch == 2) mfr += new_tr;
         else mfr += idle - id_prev;
@@ -423,7 +428,7 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
         P.mfea[o + ch] = mfr;
         reinterpret_cast<OBS *>(P.obs.m_fea2)[o + ch] = (OBS)mfr;
         if (ch == 0) {
-            const double c4 = A.mf(g)[4] + 1;
+            const double c4 = mf_4 + 1;
             P.mfea[o + 4] = c4;
             reinterpret_cast<OBS *>(P.obs.m_fea2)[o + 4] = (OBS)c4;
         }
@@ -539,6 +544,14 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
     rt[0] = __builtin_amdgcn_s_memrealtime();
 #endif
     if (b0 + grp < P.B) env_grp_wave<OBS, NS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp], s_mp[grp], s_sdf[grp], s_ttl[grp], rt);
+#ifdef MTFJSP_STAMP_WAVES                      // diagnostic: every wave's entry / first-hop / end of its instance's work (slots 16.. of the group's 128)
+    if (P.stamps && lane == 0 && EG == 16) {
+        P.stamps[2048 + (size_t)blockIdx.x * 64 + grp * 4] = rt[0];
+        P.stamps[2048 + (size_t)blockIdx.x * 64 + grp * 4 + 1] = rt[1];
+        P.stamps[2048 + (size_t)blockIdx.x * 64 + grp * 4 + 2] = rt[3];
+        P.stamps[2048 + (size_t)blockIdx.x * 64 + grp * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     __syncthreads();
 #ifdef MTFJSP_STAMP
     rt[5] = __builtin_amdgcn_s_memrealtime();
@@ -555,9 +568,9 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 #ifdef MTFJSP_STAMP
     if (grp == 0) {
         rt[6] = __builtin_amdgcn_s_memrealtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        rt[7] = __builtin_amdgcn_s_memrealtime();
-        if (P.stamps && lane == 0) for (int i = 0; i < 8; i++) P.stamps[(size_t)blockIdx.x * 8 + i] = rt[i];
+        if (P.stamps && lane == 0) for (int i = 0; i < 7; i++) P.stamps[(size_t)blockIdx.x * 8 + i] = rt[i];
+    } else if (grp == 1) {                     // slot 7: the ELL / job-mask wave's end
+        if (P.stamps && lane == 0) P.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
     (void)rt;

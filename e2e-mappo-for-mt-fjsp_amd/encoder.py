@@ -256,7 +256,8 @@ class ActorPair:
         self.enc.load_weights(w[0], w[1], w[2] if len(w) > 2 else None)   # (job actor, machine actor[, global critic])
         self.has_critic = len(w) > 2
         self.greedy, self.seed = greedy, seed
-        self._mf_ctx, self._mf_env = None, None
+        self._mf_ctx, self._mf_env, self._mf_own = None, None, None
+        self.last_mfea1 = self.last_mmask = None
         self.n_env_fused = 0                                     # decisions whose environment step rode in the machine heads' launch
         self.fuse_env = bool(os.environ.get("MTFJSP_FUSED_ENV")) # (the library reads the same switch when the handle is created; off by default: DESIGN.md §9)
         self.fused = not os.environ.get("MTFJSP_NO_FUSED_SELECT")   # action selection inside the heads kernels (same stream either way)
@@ -269,11 +270,15 @@ class ActorPair:
         self.have_hm = False                                    # run:280 h_mch_pooled = None
 
     def act(self, env, counter, task_idx, mach_idx, job_idx, jv_out=None, mv_out=None, job_logp=None, mach_logp=None,
-            after_mfea1=None, force=None, env_step=None):
+            after_mfea1=None, force=None, env_step=None, mfea1_out=None, mmask_out=None):
         """one joint decision for every instance; the optional outputs let a trajectory buffer receive action indices,
         log-probabilities and critic values in place (no copies).  force = (task [B], machine [B][, job [B]]) int32 tensors:
         replay these decisions instead of the selected ones (teacher forcing; the forwards and their outputs are unchanged,
-        the recorded log-probabilities stay those of the actors' own selections)."""
+        the recorded log-probabilities stay those of the actors' own selections).
+        mfea1_out / mmask_out ([B,M,6] observation dtype / [B,M] bytes): when the job heads' launch produces m_fea1 and the machine
+        mask of the selected tasks itself, it writes them THERE (a trajectory slot) instead of env.m_fea1 / env.mmask, and the
+        machine actor reads them from there; decisions that go through env.observe_mfea1 (forced actions, unfused selection)
+        keep env's buffers and `after_mfea1(env)` is the caller's hook to copy them."""
         e = self.enc
         jl = job_logp if job_logp is not None else self.job_logp
         ml = mach_logp if mach_logp is not None else self.mch_logp
@@ -284,6 +289,10 @@ class ActorPair:
             if fuse_mfea1:
                 if self._mf_env is not env:
                     self._mf_ctx, self._mf_env = env.mfea1_context(), env
+                    self._mf_own = (self._mf_ctx.m_fea1_out, self._mf_ctx.mmask_out)
+                redirect = mfea1_out is not None and mmask_out is not None
+                self._mf_ctx.m_fea1_out = mfea1_out.data_ptr() if redirect else self._mf_own[0]
+                self._mf_ctx.mmask_out = mmask_out.data_ptr() if redirect else self._mf_own[1]
                 e.arm_mfea1(self._mf_ctx)
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
         else:
@@ -293,10 +302,16 @@ class ActorPair:
             task_idx.copy_(force[0])
             if len(force) > 2:
                 job_idx.copy_(force[2])
+        mf1, mmk = env.m_fea1, env.mmask
         if not fuse_mfea1:
             env.observe_mfea1(task_idx)                         # -> env.m_fea1, env.mmask (else: written by the heads kernel)
-        if after_mfea1 is not None:
+            if after_mfea1 is not None:
+                after_mfea1(env)
+        elif mfea1_out is not None and mmask_out is not None:
+            mf1, mmk = mfea1_out, mmask_out                     # the heads kernel wrote them into the caller's buffers
+        elif after_mfea1 is not None:
             after_mfea1(env)
+        self.last_mfea1, self.last_mmask = mf1, mmk             # (terminal_values: the machine actor's inputs of the last decision)
         stepped = False
         if self.fused:
             e.arm_selection(1, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
@@ -305,10 +320,10 @@ class ActorPair:
                 params = env.step_params(task_idx, mach_idx, *env_step)
                 if params is not None:
                     e.arm_env_step(params)
-            e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
+            e.machine_actor_forward(mf1, env.m_fea2, h_o, mmk, v_out=mv_out)
             stepped = self.fuse_env and env_step is not None and force is None and e.env_step_fused()
         else:
-            mprob, _, _ = e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
+            mprob, _, _ = e.machine_actor_forward(mf1, env.m_fea2, h_o, mmk, v_out=mv_out)
             e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
         if force is not None:
             mach_idx.copy_(force[1])
@@ -325,7 +340,9 @@ class ActorPair:
         e = self.enc
         hm = e.h_pooled_m if self.have_hm else None
         _, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, prev_job_mask, hm, v_out=jv_out)
-        e.machine_actor_forward(env.m_fea1, env.m_fea2, h_o, env.mmask, v_out=mv_out)
+        mf1 = self.last_mfea1 if self.last_mfea1 is not None else env.m_fea1
+        mmk = self.last_mmask if self.last_mmask is not None else env.mmask
+        e.machine_actor_forward(mf1, env.m_fea2, h_o, mmk, v_out=mv_out)
 
     def timing_begin(self):
         self.enc.timing_begin()

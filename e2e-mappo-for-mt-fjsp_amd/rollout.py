@@ -94,6 +94,7 @@ class Rollout:
         self.n_dropped_buffers = 0         # buffers every rank dropped together because one of them reported a failure (world > 1)
         self.tainted = False               # this rank's current buffer contains invalid steps and will be dropped at its boundary
         self._new_episode = False
+        self._pre_slot = -1                # trajectory slot whose pre-decision observation the previous step's snapshot already wrote
         self.exact_bn = False
         self.global_handoff, self.time_handoff = global_handoff, time_handoff
         self.last_full = None
@@ -214,17 +215,22 @@ class Rollout:
             if self.buf_pos == self.S:
                 self.finish_buffer()
         elif self.full:
+            # Per step: the four launches of the decision + ONE snapshot launch.  The kernels write actions, log-probabilities,
+            # critic values, rewards, m_fea1 and the machine mask straight into the slot; the snapshot after the step copies the
+            # observation into this slot's s' fields, the NEXT slot's s fields (same observation inside an episode) and the scalar
+            # reward.  Only an episode's first step takes its own pre-decision snapshot.
             tb = self.traj
             sl = tb.slot()
-            tb.snapshot(env, "pre")
+            if self._pre_slot != tb.count_operation or self.t_in_ep == 0:
+                tb.snapshot(env, "pre")
             if not self.actor.act(env, self.nsteps, self.task, sl["mach_idx"], sl["job_idx"], sl["job_v"], sl["mach_v"],
                                   job_logp=sl["job_logp"], mach_logp=sl["mach_logp"], after_mfea1=tb.after_decision, force=force,
-                                  env_step=(sl["r4"], sl["done"])):
+                                  env_step=(sl["r4"], sl["done"]), mfea1_out=sl["m_fea1"], mmask_out=sl["mmask"]):
                 env.step_record(self.task, sl["mach_idx"], sl["r4"], sl["done"])
             if last:           # value of the terminal state (run:455-475) with the mask the last decision was taken under
                 jv_t, mv_t = tb.terminal_slot()
                 self.actor.terminal_values(env, tb.mask_operation[tb.count_operation], jv_t, mv_t)
-            tb.after_step(env)
+            self._pre_slot = tb.count_operation + 1 if tb.after_step(env, next_pre=not last) else -1
             self.buf_pos += 1
             if self.buf_pos == self.S:
                 self.finish_buffer()

@@ -13,9 +13,11 @@ reference's `[n, B, T, T]` float tensor for a minibatch.
 Two ways to fill it:
   * `store_operation(...)` — the reference's call (replaybuffer.py:82-139), any mix of numpy / torch inputs,
     dense adjacencies accepted (converted to ELL);
-  * `slot()` / `snapshot(env, 'pre'|'post')` / `after_decision()` / `after_step()` — the path of the device rollout:
-    the kernels write actions, log-probabilities, critic values and rewards straight into the slot views, and ONE
-    launch (`mtfjsp_snapshot_obs`) copies the environment's current observation into the slot.
+  * `slot()` / `snapshot(env, 'pre')` / `after_step(env, next_pre=...)` — the path of the device rollout: the kernels write
+    actions, log-probabilities, critic values, rewards, m_fea1 and the machine mask straight into the slot views, and ONE
+    launch per step (`mtfjsp_snapshot_obs2`) copies the environment's post-step observation into the slot's s' fields, into the
+    NEXT slot's s fields (the same observation inside an episode) and the scalar reward into `r_operation`.
+    (`after_decision()` is the copying fallback for decisions whose m_fea1 comes from `observe_mfea1`, i.e. forced actions.)
 """
 import ctypes as C
 
@@ -241,12 +243,7 @@ class TrajectoryBuffer:
         if self.count_operation >= self.total_step:
             raise IndexError("trajectory buffer is full: call reset() after the update")
 
-    def snapshot(self, env, which):
-        """copy the environment's CURRENT observation into slot `count_operation`: which='pre' (state the decision is
-        taken in: adj, fea, candidate, mask, mch_fea2) or 'post' (adj_, fea_, candidate_, mask_, mch_fea2_).
-        One kernel launch (mtfjsp_snapshot_obs)."""
-        self._check_env(env)
-        k = self.count_operation
+    def _obs_ptrs(self, k, which):
         if which == "pre":
             dst = (self.tasks_fea[k], self.ell_col[k], self.ell_val[k], self.machine_fea2[k], self.candidate[k],
                    self.mask_operation[k])
@@ -254,12 +251,20 @@ class TrajectoryBuffer:
             dst = (self.tasks_fea_[k], self.ell_col_[k], self.ell_val_[k], self.machine_fea2_[k], self.candidate_[k],
                    self.mask_operation_[k])
         tf, ec, ev, mf, cand, mask = [d.data_ptr() for d in dst]
-        obs = capi.Obs(tf, ec, ev, mf, 0, 0, cand, mask, 0)
+        return capi.Obs(tf, ec, ev, mf, 0, 0, cand, mask, 0)
+
+    def snapshot(self, env, which):
+        """copy the environment's CURRENT observation into slot `count_operation`: which='pre' (state the decision is
+        taken in: adj, fea, candidate, mask, mch_fea2) or 'post' (adj_, fea_, candidate_, mask_, mch_fea2_).
+        One kernel launch (mtfjsp_snapshot_obs)."""
+        self._check_env(env)
+        obs = self._obs_ptrs(self.count_operation, which)
         capi.check(env.L.mtfjsp_snapshot_obs(env.h, C.byref(obs)), env.h)
 
     def slot(self):
         """views of the current slot the rollout kernels write straight into (no copies): job index / log-prob, machine
-        index / log-prob (int32 / f32 [B]), critic values [B,2] x 2, scaled reward components [4,B], done [B]"""
+        index / log-prob (int32 / f32 [B]), critic values [B,2] x 2, scaled reward components [4,B], done [B], m_fea1 [B,M,6]
+        (observation dtype) and the machine mask [B,1,M] (as bytes)"""
         k = self.count_operation
         if self.alias_v_next:
             e, t = divmod(k, self.total_task)
@@ -267,7 +272,8 @@ class TrajectoryBuffer:
         else:
             jv, mv = self.job_v[k], self.machine_v[k]
         return dict(job_idx=self.a_operation[k], job_logp=self.a_logprob_operation[k], mach_idx=self.a[k],
-                    mach_logp=self.a_logprob[k], job_v=jv, mach_v=mv, r4=self.r4[k], done=self.done_operation[k])
+                    mach_logp=self.a_logprob[k], job_v=jv, mach_v=mv, r4=self.r4[k], done=self.done_operation[k],
+                    m_fea1=self.machine_fea1[k], mmask=self.mask_machine_[k].view(torch.uint8))
 
     def terminal_slot(self):
         """(job_v_, machine_v_) [B,2] views of the CURRENT slot's episode that receive the value of the terminal state from
@@ -288,11 +294,16 @@ class TrajectoryBuffer:
         self.machine_fea1[k].copy_(env.m_fea1.reshape(self.B, self.M, 6))
         self.mask_machine_[k].copy_(env.mmask.reshape(self.B, 1, self.M))
 
-    def after_step(self, env):
-        """scalar reward (info[:,0], pe:255-262) and the post-decision observation; advances the slot"""
+    def after_step(self, env, next_pre=False):
+        """scalar reward (info[:,0], pe:255-262) and the post-decision observation, in ONE launch; advances the slot.
+        next_pre: the same launch also fills the NEXT slot's pre-decision fields (inside an episode s of step k+1 is s' of
+        step k), so the next step needs no snapshot(env, 'pre')."""
         self._check_env(env)
         k = self.count_operation
-        self.r_operation[k].copy_(env.info[:, 0])
-        self.snapshot(env, "post")
+        post = self._obs_ptrs(k, "post")
+        nxt = self._obs_ptrs(k + 1, "pre") if next_pre and k + 1 < self.total_step else None
+        capi.check(env.L.mtfjsp_snapshot_obs2(env.h, C.byref(post), C.byref(nxt) if nxt is not None else None,
+                                              self.r_operation[k].data_ptr()), env.h)
         self.count_operation += 1
         self.count_operation_ = self.count_operation
+        return nxt is not None

@@ -108,6 +108,11 @@ int mtfjsp_bind_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *obs);
  * Fields of dst left NULL are skipped (status is never copied).  The adjacency stays ELL: the reference's dense
  * [steps,B,T,T] f64 buffer is 7.6 GB per copy at B=4096 J6M6. */
 int mtfjsp_snapshot_obs(mtfjsp_handle_t h, const mtfjsp_obs_t *dst);
+/* The same launch with a second destination and the scalar reward: the reference's buffer stores s' of step k (adj_, fea_, ...:
+ * replaybuffer.py:108-118) and s of step k+1 (replaybuffer.py:97-104) separately although they are the same observation inside an
+ * episode, and the reward as f32 [B] (replaybuffer.py:106 <- info[:,0], pe:255-262).  dst2 (may be NULL) receives a second copy of
+ * every field it has; reward_out (may be NULL) receives (float)info[b][0]. */
+int mtfjsp_snapshot_obs2(mtfjsp_handle_t h, const mtfjsp_obs_t *dst, const mtfjsp_obs_t *dst2, float *reward_out);
 
 /* ------------------------------------------------------------------ instances */
 /* = Parallel_env.get_batch (pe:39-66): t,p [B,T,M] (negative = machine infeasible), tt [B,M,M],

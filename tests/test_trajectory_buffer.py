@@ -123,16 +123,15 @@ def test_device_rollout_fills_the_buffer_consistently():
     a = rollout.Rollout(J, M, 2, B, policy="actor", obs_dtype="f32", collect="full", buffer_episodes=2)
     b = rollout.Rollout(J, M, 2, B, policy="actor", obs_dtype="f32", collect=True, buffer_episodes=2)
     S = 2 * T
-    pre, post, acts = [], [], []
+    pre, post, acts, dec = [], [], [], []
     for s in range(S - 1):                                   # stop one step short of the hand-off (which resets the counters)
-        if b.t_in_ep == 0:
-            pass
         b_env = b.env
         # the twin's pre-state is only defined after its reset, which happens inside step(); clone post-state instead
         a.step(); b.step()
         post.append((b_env.tasks_fea.clone(), b_env.ell_col.clone(), b_env.ell_val.clone(), b_env.m_fea2.clone(),
                      b_env.candidate.clone(), b_env.job_mask.clone(), b_env.info.clone()))
         acts.append((b.job.clone(), b.mach.clone(), b.task.clone()))
+        dec.append((b_env.m_fea1.clone(), b_env.mmask.clone()))   # the twin's heads kernel writes them into the environment's buffers
     torch.cuda.synchronize()
     tb = a.traj
     assert tb.count_operation == S - 1
@@ -145,9 +144,14 @@ def test_device_rollout_fills_the_buffer_consistently():
         assert torch.equal(tb.mk[s], info[:, 2].float()) and torch.equal(tb.it[s], info[:, 3].float())
         assert torch.equal(tb.pt[s], info[:, 4].float()) and torch.equal(tb.tt[s], info[:, 5].float())
         assert torch.equal(tb.a_operation[s], acts[s][0]) and torch.equal(tb.a[s], acts[s][1])
+        # m_fea1 / machine mask: written by the job heads' launch straight into the slot (no copy) and read from there by the machine actor
+        assert torch.equal(tb.machine_fea1[s], dec[s][0].reshape(B, M, 6)) and torch.equal(tb.mask_machine_[s], dec[s][1].bool().reshape(B, 1, M))
         if (s + 1) % T != 0 and s + 1 < S - 1:               # inside an episode: s' of step s is s of step s+1
             assert torch.equal(tb.tasks_fea[s + 1], tb.tasks_fea_[s]) and torch.equal(tb.ell_col[s + 1], tb.ell_col_[s])
             assert torch.equal(tb.candidate[s + 1], tb.candidate_[s]) and torch.equal(tb.machine_fea2[s + 1], tb.machine_fea2_[s])
+            assert torch.equal(tb.ell_val[s + 1], tb.ell_val_[s]) and torch.equal(tb.mask_operation[s + 1], tb.mask_operation_[s])
+    # an episode's first slot holds the observation after the reset (its own snapshot): not the previous episode's terminal state
+    assert not torch.equal(tb.tasks_fea[T], tb.tasks_fea_[T - 1]) and torch.equal(tb.tasks_fea[T][:, 3], torch.zeros_like(tb.tasks_fea[T][:, 3]))
     # chosen machine is feasible under the stored machine mask; stored job is selectable under the stored job mask
     idx = torch.arange(B, device="cuda")
     for s in (0, 17, T, S - 2):

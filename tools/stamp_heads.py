@@ -9,4 +9,4 @@ from importlib import import_module
 b = import_module("e2e-mappo-for-mt-fjsp_amd._build")
 lib = b.build_variant("stamp", ["-DMTFJSP_STAMP"] + sys.argv[1:])
 env = dict(os.environ, MTFJSP_LIB=lib, MTFJSP_STAMP_PRINT="1")
-subprocess.call([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "72", "--warmup", "36", "--min-seconds", "0.01", "--no-cpu-baseline", "--no-env-sweep"], env=env)
+subprocess.call([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "72", "--warmup", "36", "--min-seconds", "0.01", "--no-cpu-baseline", "--no-env-sweep", "--no-config-legs"], env=env)
