@@ -1378,7 +1378,7 @@ __global__ __launch_bounds__(ENV_LDS_GMAX * WAVE) void k_env_step_grp(EnvParams 
     __syncthreads();
     if (grp == 0) {
         const EnvGrpLdsAcc acc{smem, LL};
-        env_grp_tail<OBS>(P, b0, lane, G, acc);
+        env_grp_tail<OBS, false>(P, b0, lane, G, acc);
 #ifdef MTFJSP_STAMP
         if (P.stamps && lane == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); P.stamps[(size_t)b0 * 8 + 7] = __builtin_amdgcn_s_memrealtime(); }
 #endif

@@ -315,7 +315,7 @@ struct EnvGrpRegAcc {
 };
 // the per-instance scalar part for the instances of the group: lane = (instance g = lane >> 2, reward channel ch = lane & 3)
 template <typename OBS, typename ACC>
-__device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A)
+__device__ __forceinline__ void env_grp_tail_batched(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A)
 {
     const int g = lane >> 2, ch = lane & 3;
     const int b = b0 + g;
@@ -433,6 +433,132 @@ __device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, c
             reinterpret_cast<OBS *>(P.obs.m_fea2)[o + 4] = (OBS)c4;
         }
     }
+}
+
+// the same scalar part with every LDS input read where it is used: 30-odd fewer live registers.  The kernels that run several
+// workgroups per CU (k_env_grp4 at 64 registers, k_env_grp4x2, k_env_step_grp) use this form — the batched one spilled k_env_grp4
+// to scratch and cost it 26 % at 262 144 instances (342 -> 430 us), for 0.2 us gained where one workgroup per CU runs alone
+template <typename OBS, typename ACC>
+__device__ __forceinline__ void env_grp_tail_seq(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A)
+{
+    const int g = lane >> 2, ch = lane & 3;
+    const int b = b0 + g;
+    if (g >= EG || b >= P.B) return;
+    const int J = P.J, M = P.M, T = P.T;
+    const double *sc = A.scl(g);
+    const int status = A.in(g)[I_STATUS];
+    if (!A.in(g)[I_VALID]) {                                                    // rejected action: nothing changed; observations persist
+        const bool all_done = sc[S_NSCHED] == (double)T;
+        P.obs.info[(size_t)b * 6 + ch] = (ch == 1 && all_done) ? 1.0 : 0.0;
+        if (ch < 2) P.obs.info[(size_t)b * 6 + 4 + ch] = 0.0;
+        if (P.obs.raw) { P.obs.raw[(size_t)b * 5 + ch] = 0.0; if (ch == 0) P.obs.raw[(size_t)b * 5 + 4] = 0.0; }
+        if (P.rec_r4) P.rec_r4[(size_t)ch * P.B + b] = 0.f;
+        if (P.rec_done && ch == 0) P.rec_done[b] = all_done ? 1.f : 0.f;
+        if (ch == 1) P.obs.status[b] = status;
+        return;
+    }
+    const int nsched = A.in(g)[I_NSCHED], m = A.in(g)[I_M];
+    // (loops in chunks whose LDS reads go out together: this wave runs alone, a read per dependent step would be all latency;
+    // indices past the end are clamped — max / min are idempotent — or hit zero-filled slots)
+    double mk = A.jmx(g)[0];                                                    // env:894 np.amax
+    for (int j0 = 0; j0 < J; j0 += 4) {
+        double x[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) x[k] = A.jmx(g)[j0 + k < J ? j0 + k : J - 1];
+#pragma unroll
+        for (int k = 0; k < 4; k++) mk = fmax(mk, x[k]);
+    }
+    double e1 = A.un(g)[U_R0];                                                  // env:896 np.sum: pairwise part, then the ragged tail in order
+    bool big = false;
+    if constexpr (ACC::kBigT) big = T > 128;                                    // (more than one leaf block: the instance's wave walked numpy's recursion, U_R0 is the total)
+    if (!big) {
+        const int nt = T < 8 ? T : (T & 7);
+        double x[7];
+#pragma unroll
+        for (int i = 0; i < 7; i++) x[i] = A.un(g)[U_TAIL + i];
+#pragma unroll
+        for (int i = 0; i < 7; i++) if (i < nt) e1 += x[i];
+    }
+    e1 = 0.0 + e1;
+    // dg:144-170, strictly left to right.  Slots >= nsched hold +0.0 and the running sum starts at +0.0, so it is never -0.0 and
+    // adding them changes nothing: the loop stops at nsched; the next chunk's reads are in flight under the 8 dependent adds
+    double idle = 0.0;
+    {
+        const double *so = A.sorted(g);
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = so[k];
+        for (int i0 = 0; i0 < nsched; i0 += 8) {
+            double y[8];
+            const bool more = i0 + 8 < nsched;
+#pragma unroll
+            for (int k = 0; k < 8; k++) y[k] = more ? so[i0 + 8 + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) idle = idle + x[k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[k] = y[k];
+        }
+    }
+    const double new_tr = A.un(g)[U_NEWTR], d = A.un(g)[U_D], pk = A.un(g)[U_PK];
+    const double trans_this = sc[S_TR_THIS] + new_tr;
+    const double mk_prev = sc[S_MK_PREV], e1_prev = sc[S_E1_PREV], tr_prev = sc[S_TR_PREV], id_prev = sc[S_ID_PREV];
+    const double r_t = 1.0 * mk_prev - mk;                                      // env:1066
+    double r_pt = 1.0 * e1_prev - e1;
+    r_pt = r_pt / (double)T;                                                    // env:1073-1076
+    const double r_tt = 1.0 * tr_prev - trans_this;                             // env:1083
+    const double r_idle = 1.0 * id_prev - idle;                                 // env:1088
+    const double tot_n = P.w_mk * r_t + P.w_ec * (r_pt + 1 * r_idle) + P.w_tt * r_tt * 1;                  // env:1164
+    const double tot = P.divisor == 1.0 ? tot_n : tot_n / P.divisor;            // x / 1.0 == x exactly
+    const bool done = nsched == T;                                              // env:797-800
+    double *s = P.scal + (size_t)b * SCAL_N;
+    {   // reward scaling of channel ch (pt:54-124)
+        const double n = sc[S_N] + 1.0;
+        const double x = ch == 0 ? r_t : ch == 1 ? r_idle : ch == 2 ? r_pt : r_tt;
+        const double sR0 = sc[S_R + ch], sM0 = sc[S_MEAN + ch];
+        const double R = P.gamma * sR0 + x;
+        double mean, S = sc[S_S + ch], sd;
+        if (n == 1.0) { mean = R; sd = fabs(R); }
+        else { mean = sM0 + (R - sM0) / n; S = S + (R - sM0) * (R - mean); sd = sqrt(S / n); }
+        const double scaled = x / (sd + 1e-8);
+        s[S_R + ch] = R; s[S_MEAN + ch] = mean; s[S_S + ch] = S; s[S_STD + ch] = sd;
+        P.obs.info[(size_t)b * 6 + 2 + ch] = scaled;
+        if (P.rec_r4) P.rec_r4[(size_t)ch * P.B + b] = (float)scaled;
+        if (ch == 0) {
+            s[S_N] = n; s[S_NSCHED] = (double)nsched;
+            s[S_MK_PREV] = mk; s[S_E1_PREV] = e1; s[S_TR_PREV] = trans_this; s[S_ID_PREV] = idle;    // env:932-936
+            s[S_TR_THIS] = done ? 0.0 : trans_this;                              // env:950-960
+            P.obs.info[(size_t)b * 6 + 0] = tot;
+            P.obs.info[(size_t)b * 6 + 1] = done ? 1.0 : 0.0;
+            if (P.rec_done) P.rec_done[b] = done ? 1.f : 0.f;
+        }
+        if (P.obs.raw) {
+            P.obs.raw[(size_t)b * 5 + 1 + ch] = x;                            // raw: total, makespan, idle, energy, transport
+            if (ch == 0) P.obs.raw[(size_t)b * 5] = tot;
+        }
+        if (ch == 1) P.obs.status[b] = status;
+    }
+    {   // machine features of the acting machine (env:2315-2340): columns 0..3 on the four lanes, column 4 with lane 0
+        double mfr = A.mf(g)[ch];
+        if (ch == 0) mfr = A.un(g)[U_FTTAIL];
+        else if (ch == 1) mfr += (pk * d) / (double)T;
+        else if (ch == 2) mfr += new_tr;
+        else mfr += idle - id_prev;
+        const size_t o = ((size_t)b * M + m) * 8;
+        P.mfea[o + ch] = mfr;
+        reinterpret_cast<OBS *>(P.obs.m_fea2)[o + ch] = (OBS)mfr;
+        if (ch == 0) {
+            const double c4 = A.mf(g)[4] + 1;
+            P.mfea[o + 4] = c4;
+            reinterpret_cast<OBS *>(P.obs.m_fea2)[o + 4] = (OBS)c4;
+        }
+    }
+}
+
+template <typename OBS, bool BATCHED, typename ACC>
+__device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A)
+{
+    if constexpr (BATCHED) env_grp_tail_batched<OBS>(P, b0, lane, EG, A);
+    else env_grp_tail_seq<OBS>(P, b0, lane, EG, A);
 }
 
 // job mask (ppo:202-316) of the group's instances: lane = (instance, jobs ch, ch + 4, ...)
@@ -559,7 +685,7 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
     // two scalar-part waves (on different SIMDs): rewards / scaler / machine row | ELL rows + job mask
     if (grp == 0) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
-        env_grp_tail<OBS>(P, b0, lane, EG, acc);
+        env_grp_tail<OBS, EG == EG_SMALL>(P, b0, lane, EG, acc);
     } else if (grp == 1) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
         env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl);
@@ -613,7 +739,7 @@ __device__ __forceinline__ void env_grp_body_dyn(const EnvParams &P, unsigned ch
     __syncthreads();
     if (w == 0) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
-        env_grp_tail<OBS>(P, b0, lane, EG, acc);
+        env_grp_tail<OBS, false>(P, b0, lane, EG, acc);
     } else if (w == 1) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
         env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl);
