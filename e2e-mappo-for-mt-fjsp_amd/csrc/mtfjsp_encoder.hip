@@ -935,6 +935,9 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                         }
                     }
                     MFMA_SETTLE2(acc[0], acc[1]);
+#ifdef MTFJSP_STAMP_TILE                       // diagnostic split of the consumer's tile: 5 = fragments + products, 1 = epilogue up to the LDS write + sums, 6 = LDS read-back + stores issued
+                    STAMP(5);
+#endif
 #pragma unroll
                     for (int c = 0; c < 2; c++) acc[c] = acc[c] * wsinv + biasv[c];
                     const int ptile = FULL || tb + t < last ? PT(tb + t) : 0;
@@ -952,12 +955,18 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 #pragma unroll
                         for (int i = 0; i < 4; i++) { const float x = ok ? v[i] : 0.f; ts[c][i] += x; tq[c][i] = __builtin_fmaf(x, x, tq[c][i]); }
                     }
+#ifdef MTFJSP_STAMP_TILE
+                    STAMP(1);
+#endif
 #pragma unroll
                     for (int i = 0; i < 2; i++) {
                         const int r8 = 8 * i + (lane >> 3);
                         const float4 v = *reinterpret_cast<const float4 *>(trb + r8 * 144 + 16 * (lane & 7));
                         *reinterpret_cast<float4 *>(A.out + ((size_t)ptile * 16 + r8) * HD + 32 * cg + 4 * (lane & 7)) = v;
                     }
+#ifdef MTFJSP_STAMP_TILE
+                    STAMP(6);
+#endif
                 }
             };
             if (tb + 4 <= last && ((A.rev ? PT(tb) : tb + 3) + 1) * 16 <= A.N) tiles4(std::true_type{});

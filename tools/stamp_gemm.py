@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import mtfjsp_amd  # noqa
 from importlib import import_module
 b = import_module("e2e-mappo-for-mt-fjsp_amd._build")
-lib = b.build_variant("stamp", ["-DMTFJSP_STAMP"])
+lib = b.build_variant("stamp" + "".join(x.replace("-D", "_") for x in sys.argv[3:]), ["-DMTFJSP_STAMP"] + sys.argv[3:])
 env = dict(os.environ, MTFJSP_LIB=lib, MTFJSP_STAMP_PRINT="1")
 size, batch = (sys.argv[1:] + ["10x10x2", "8192"])[:2]
 subprocess.call([sys.executable, os.path.join(ROOT, "bench.py"), "--size", size, "--batch", batch, "--steps", "20", "--warmup", "5", "--min-warmup-seconds", "0",
