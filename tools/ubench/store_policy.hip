@@ -33,6 +33,13 @@ __global__ __launch_bounds__(256) void k_copy(const u4 *__restrict__ src, u4 *__
     if (acc == 0x9e3779b9u) *sink = acc;
 }
 __global__ void k_empty(unsigned *sink) { if (threadIdx.x == 9999) *sink = 1; }
+// a kernel that just takes `ticks` of the 100 MHz clock in every wave (a long kernel whose own work does not touch memory)
+__global__ void k_spin(unsigned *sink, unsigned ticks)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+    if (threadIdx.x == 9999) *sink = 1;
+}
 __global__ __launch_bounds__(256) void k_read(const u4 *__restrict__ src, size_t nr, unsigned *sink)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -62,6 +69,29 @@ static int timed(const char *what, F launch, int reps)
     return 0;
 }
 
+// the same train as ONE hipGraph (stream capture of `n` dependent launches), launched `reps` times
+template <typename F>
+static int timed_graph(const char *what, F launch, int n, int reps)
+{
+    hipStream_t st; CHK(hipStreamCreate(&st));
+    hipGraph_t g; hipGraphExec_t ge;
+    CHK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int i = 0; i < n; i++) launch(i, st);
+    CHK(hipStreamEndCapture(st, &g));
+    CHK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; i++) CHK(hipGraphLaunch(ge, st));
+    CHK(hipStreamSynchronize(st));
+    CHK(hipEventRecord(e0, st));
+    for (int i = 0; i < reps; i++) CHK(hipGraphLaunch(ge, st));
+    CHK(hipEventRecord(e1, st));
+    CHK(hipStreamSynchronize(st));
+    float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+    printf("%-44s hipGraph of %d dependent launches x %d: %6.2f us per launch\n", what, n, reps, ms / reps / n * 1e3);
+    (void)hipGraphExecDestroy(ge); (void)hipGraphDestroy(g); (void)hipStreamDestroy(st);
+    return 0;
+}
+
 int main()
 {
     const size_t rb = 11337728, wb = 14528512;           // 4096 x (64 T + 100 M + 176), 4096 x (72 T + 56 M + 307) with T = 36, M = 6
@@ -71,6 +101,16 @@ int main()
     CHK(hipMemset(a, 1, wb + 64)); CHK(hipMemset(b, 2, wb + 64));
     const int reps = 100;
     timed("empty kernel (256 x 256)", [&](int) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, 0, sink); }, reps);
+    timed_graph("empty kernel (256 x 256)", [&](int, hipStream_t st) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, sink); }, 100, 20);
+    for (unsigned us : {20u, 100u}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "spin %u us (256 x 256)", us);
+        timed(nm, [&](int) { hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, 0, sink, us * 100); }, reps);
+        timed_graph(nm, [&](int, hipStream_t st) { hipLaunchKernelGGL(k_spin, dim3(256), dim3(256), 0, st, sink, us * 100); }, 100, 10);
+    }
+    timed_graph("empty kernel, graphs of FOUR launches", [&](int, hipStream_t st) { hipLaunchKernelGGL(k_empty, dim3(256), dim3(256), 0, st, sink); }, 4, 500);
+    timed_graph("copy, graphs of FOUR launches", [&](int i, hipStream_t st) { hipLaunchKernelGGL(k_copy<0>, dim3(2048), dim3(256), 0, st, (i & 1) ? b : a, (i & 1) ? a : b, nr, nw, sink); }, 4, 500);
+    timed_graph("copy, plain stores, grid 2048", [&](int i, hipStream_t st) { hipLaunchKernelGGL(k_copy<0>, dim3(2048), dim3(256), 0, st, (i & 1) ? b : a, (i & 1) ? a : b, nr, nw, sink); }, 100, 20);
     for (int grid : {1024, 2048, 4096}) {
         char nm[96];
         snprintf(nm, sizeof nm, "read only, grid %d", grid);
