@@ -166,3 +166,50 @@ def test_device_rollout_fills_the_buffer_consistently():
     # the hand-off still works on the buffer's own storage (GAE + normalisation), and resets the counters
     a.step()
     assert tb.count_operation == 0 and a.last_adv is not None
+
+
+@pytest.mark.gpu
+def test_two_destination_snapshot_copies_exactly_the_fields_each_destination_has():
+    """mtfjsp_snapshot_obs2 (include/mtfjsp.h): one launch, every non-NULL field of dst and of dst2 receives the bound observation,
+    reward_out receives (float)info[:,0]; NULL fields / a NULL dst2 / a NULL reward_out are skipped; an odd batch exercises the
+    byte tails of the 16-byte copy loops."""
+    import ctypes as C
+    import mtfjsp_amd  # noqa: F401
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    capi = import_module("e2e-mappo-for-mt-fjsp_amd.capi")
+    B, J, M = 37, 5, 3
+    T = J * M
+    ro = rollout.Rollout(J, M, 3, B, policy="random", obs_dtype="f32")
+    for _ in range(7):
+        ro.step()
+    env = ro.env
+    dev = env.tasks_fea.device
+    like = lambda x: torch.full_like(x, 77) if x.dtype != torch.bool else torch.ones_like(x)
+    a = dict(tf=like(env.tasks_fea), ec=like(env.ell_col), ev=like(env.ell_val), mf=like(env.m_fea2), cand=like(env.candidate), mask=like(env.job_mask),
+             info=like(env.info))
+    b = dict(tf=like(env.tasks_fea), cand=like(env.candidate), mask=like(env.job_mask), mf=like(env.m_fea2))
+    rew = torch.full((B,), -5.0, dtype=torch.float32, device=dev)
+    p = lambda t: t.data_ptr()
+    oa = capi.Obs(p(a["tf"]), p(a["ec"]), p(a["ev"]), p(a["mf"]), p(a["info"]), 0, p(a["cand"]), p(a["mask"]), 0)
+    ob = capi.Obs(p(b["tf"]), 0, 0, p(b["mf"]), 0, 0, p(b["cand"]), p(b["mask"]), 0)          # dst2 without the adjacency and info
+    capi.check(env.L.mtfjsp_snapshot_obs2(env.h, C.byref(oa), C.byref(ob), rew.data_ptr()), env.h)
+    torch.cuda.synchronize()
+    for k, src in (("tf", env.tasks_fea), ("ec", env.ell_col), ("ev", env.ell_val), ("mf", env.m_fea2), ("cand", env.candidate), ("mask", env.job_mask),
+                   ("info", env.info)):
+        assert torch.equal(a[k], src), k
+    for k, src in (("tf", env.tasks_fea), ("mf", env.m_fea2), ("cand", env.candidate), ("mask", env.job_mask)):
+        assert torch.equal(b[k], src), k
+    assert torch.equal(rew, env.info[:, 0].float())
+    # a field only dst2 has is still copied; no dst2 and no reward: the plain snapshot
+    c_tf, d_ec = like(env.tasks_fea), like(env.ell_col)
+    oc = capi.Obs(p(c_tf), 0, 0, 0, 0, 0, 0, 0, 0)
+    od = capi.Obs(0, p(d_ec), 0, 0, 0, 0, 0, 0, 0)
+    capi.check(env.L.mtfjsp_snapshot_obs2(env.h, C.byref(oc), C.byref(od), None), env.h)
+    torch.cuda.synchronize()
+    assert torch.equal(c_tf, env.tasks_fea) and torch.equal(d_ec, env.ell_col)
+    e_tf = like(env.tasks_fea)
+    oe = capi.Obs(p(e_tf), 0, 0, 0, 0, 0, 0, 0, 0)
+    capi.check(env.L.mtfjsp_snapshot_obs2(env.h, C.byref(oe), None, None), env.h)
+    torch.cuda.synchronize()
+    assert torch.equal(e_tf, env.tasks_fea)
+    assert env.L.mtfjsp_snapshot_obs2(env.h, None, None, None) == capi.ERR_ARG
