@@ -1812,7 +1812,9 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
 // (Round 4 tried ONE WAVE per instance instead — lane = (row parity, 4 columns), a ring of 16 row-pair requests that runs across
 // instance boundaries, the two parities folded with one cross-lane move, the candidate rows picked out of the stream, no barriers:
 // 121.7 / 131.1 us against 115.5 / 107.2 us for this kernel at J10M10 x 8192 / J20M20 x 2048 on the same box — the ring's slots are
-// consumed in issue order with a wait each, and a wave has a sixteenth of a block's requests in flight.  Not kept.)
+// consumed in issue order with a wait each, and a wave has a sixteenth of a block's requests in flight.  Not kept.  Capping the block
+// kernel at 128 registers so that all four of a CU's blocks are resident at once — it takes 253 uncapped — changed nothing: 115.7 / 108.1
+// against 115.4 / 107.9 us.)
 // broadcast a [128] vector to [B,128] (first step: learned `_input` instead of h_m_prev, ac:229-233)
 __global__ void k_bcast128(int B, const float *v, float *out)
 {
