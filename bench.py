@@ -63,12 +63,13 @@ def same_footprint_copy(env, B, J, M):
 PMC_FILE = "r04_pmc_traffic.json"
 
 
-def pmc_traffic(family):
+def pmc_traffic(family, shape=None):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json: FETCH_SIZE and
     WRITE_SIZE collected in separate passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  PMC
     collection cannot run inside the timed process, so bench.py reports the last committed measurement (B=4096 J6M6E2)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"][family]
+        d = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+        d = d["sizes"][shape][family] if shape else d["kernels"][family]      # shape: "J10M10E2_B8192" ... (tools/pmc_sizes.sh passes)
         return d["traffic_bytes"]
     except Exception:
         return None
@@ -141,10 +142,17 @@ def config_leg(rollout_mod, J, M, E, B, device, steps=240, warm=120):
     ke = kt["env_step"]
     sec_env = ke["ms_total"] / max(ke["launches"], 1) * 1e-3
     alg = B * env_bytes(J, M)
+    shape = f"J{J}M{M}E{E}_B{B}"
+    roof = ro.roofline(dom, kt[dom]) if dom != "env_step" else None
+    if roof is not None:
+        roof["traffic"] = pmc_traffic(dom, shape)
+        roof["traffic_source"] = (f"profiles/{PMC_FILE} sizes.{shape} (rocprofv3 --pmc passes of `bench.py --size {J}x{M}x{E} --batch {B}`, tools/pmc_sizes.sh; "
+                                  "not re-measured inside this run)") if roof["traffic"] is not None else None
     out = {"workload": f"J{J}M{M}E{E}, {B} parallel instances (on-device generator, all distinct), full rollout step",
            "value": B * steps / dt, "unit": "env-steps/s", "ms_per_step": dt / steps * 1e3, "steps_timed": steps,
-           "roofline": ro.roofline(dom, kt[dom]) if dom != "env_step" else None,
+           "roofline": roof,
            "roofline_env_step": {"kernel": ro.env_kernel_name(), "bound": "hbm", "achieved": alg / sec_env / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "traffic": pmc_traffic("env_step", shape),
                                  "frac": alg / sec_env / 1e9 / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": alg / sec_env / 1e9 / HBM_MEASURED_GBPS,
                                  "avg_launch_us": sec_env * 1e6, "algorithmic_bytes_per_launch": alg, "env_steps_per_s": B / sec_env},
            "kernel_times_us_per_launch": {k: v["ms_total"] / max(v["launches"], 1) * 1e3 for k, v in kt.items()}}
