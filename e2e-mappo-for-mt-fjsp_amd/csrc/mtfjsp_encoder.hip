@@ -1734,6 +1734,9 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
 // ---------------------------------------------------------------------------------------------
 // After the last GIN BatchNorm: h = relu(bn(z)); graph mean pool (gcn:192) and candidate gather (ac:197-207).
 // One 128-thread block per instance, thread = column.
+#ifndef POOL_INFLIGHT
+#define POOL_INFLIGHT 8                        // rows in flight per thread; 13 / 16 measured the same (114 / 108 us at J10M10 x 8192 / J20M20 x 2048), 25 slower (133 / 117)
+#endif
 __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, int nt, int rpr, int S, int B, int T, int J, const float *z, const double *stats, double inv_rows,
                                                         const float *gamma, const float *beta, const int *cand,
                                                         float *h_pooled, float *cand_feat, float *h_nodes)
@@ -1768,10 +1771,10 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
     }
     for (int b = rpr ? i_hi - 1 - l : blockIdx.x; rpr ? l < n_g : b < B; rpr ? (l += lstep, b = i_hi - 1 - l) : (b += gridDim.x)) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int v0 = rg; v0 < T; v0 += 64) {                                      // eight rows in flight per thread (same summation order)
-            float4 x[8];
+        for (int v0 = rg; v0 < T; v0 += 8 * POOL_INFLIGHT) {                       // POOL_INFLIGHT rows in flight per thread (same summation order)
+            float4 x[POOL_INFLIGHT];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < POOL_INFLIGHT; u++) {
                 const int v = v0 + 8 * u;
                 x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (v < T) {
@@ -1781,7 +1784,7 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < POOL_INFLIGHT; u++) {
                 const int v = v0 + 8 * u;
                 if (v < T) {
                     float hv[4] = {bn_relu(x[u].x, mean[0], rstd[0], g[0], be[0]), bn_relu(x[u].y, mean[1], rstd[1], g[1], be[1]),
