@@ -1737,15 +1737,26 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
 #ifndef POOL_INFLIGHT
 #define POOL_INFLIGHT 8                        // rows in flight per thread; 13 / 16 measured the same (114 / 108 us at J10M10 x 8192 / J20M20 x 2048), 25 slower (133 / 117)
 #endif
-__global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, int nt, int rpr, int S, int B, int T, int J, const float *z, const double *stats, double inv_rows,
+// NT (non-temporal row loads) is a template parameter: as a run-time flag — `nt ? __builtin_nontemporal_load(p) : *p` — the two arms
+// were merged into ONE plain load (rounds 3 and 4 shipped that: no `nt` load in the kernel's ISA), and a just-written 419 MB matrix
+// reads at 3.6-3.8 TB/s with plain loads against 5.2-6.3 TB/s with non-temporal ones (tools/ubench/read_after_write.hip).
+//
+// A 256-thread block takes the instances of its sequence one after the other; thread = (row group rg = tid / 32 of 8, 4 columns).
+// The rows are streamed in batches of 64 (8 per thread, 16-byte loads) through ONE software pipeline that runs across the instance
+// boundaries: two batches are always in flight, so the memory pipe does not drain while an instance's 8 partial sums are folded
+// through LDS (double-buffered: one barrier per instance).  The candidate rows (ac:197-207) are picked out of the stream — row v of
+// job v / M is written to cand_feat when cand[b][v / M] == v — instead of being read a second time behind a dependent index load.
+// The summation order per thread (rows rg, rg+8, ... ascending) and of the fold (row groups 0..7) is the earlier kernel's: same bits.
+#ifndef POOL_INFLIGHT
+#define POOL_INFLIGHT 8                        // rows per batch and thread (two batches in flight)
+#endif
+template <int NT>
+__global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, int rpr, int S, int B, int T, int J, const float *z, const double *stats, double inv_rows,
                                                         const float *gamma, const float *beta, const int *cand,
                                                         float *h_pooled, float *cand_feat, float *h_nodes)
 {
-    // a 256-thread block takes instances blockIdx.x, + gridDim.x, ... (the BatchNorm scale/shift of its 4 columns is computed once per
-    // block, not once per instance: 64 dependent loads that were a third of a block's life at T = 100); thread = (row group
-    // rg = tid/32 of 8, 4 columns); rows rg, rg+8, ... are streamed with 16-byte loads, eight in flight per thread, the 8 partial
-    // sums are folded through LDS.
-    __shared__ float s_part[8][HD];
+    constexpr int NB = POOL_INFLIGHT, RB = 8 * NB;            // rows per batch
+    __shared__ float s_part[2][8][HD];
     const int tid = threadIdx.x, rg = tid >> 5, c4 = (tid & 31) * 4;
     float mean[4], rstd[4], g[4], be[4];
     for (int q = 0; q < 4; q++) {
@@ -1758,66 +1769,86 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
         if (var < 0) var = 0;
         mean[q] = (float)mean_d; rstd[q] = 1.0f / sqrtf((float)(var + BN_EPS)); g[q] = gamma[c]; be[q] = beta[c];
     }
-    // instance order: rpr == 0: blockIdx.x, + gridDim.x, ...; else (matrix beyond the memory-side cache) the instances of the row
-    // range [g rpr, (g+1) rpr) that ONE workgroup of the last product wrote front to back are taken from the back — what is still
-    // cached first — by the S blocks (g, s), s = blockIdx.x / ranges
-    int i_hi = 0, n_g = 0, l = 0, lstep = 1;
+    // instance sequence b(i), i < n_inst: rpr == 0: blockIdx.x, + gridDim.x, ...; else (matrix beyond the memory-side cache) the instances
+    // of the row range [g rpr, (g+1) rpr) that ONE workgroup of the last product wrote front to back are taken from the back — what is
+    // still cached first — by the S blocks (g, s), s = blockIdx.x / ranges
+    int i_hi = 0, sub = 0, n_inst;
     if (rpr) {
-        const int nranges = gridDim.x / S, g = blockIdx.x % nranges, sub = blockIdx.x / nranges;
-        const long long r0 = (long long)g * rpr, r1 = r0 + rpr;
+        const int nranges = gridDim.x / S, gg = blockIdx.x % nranges;
+        sub = blockIdx.x / nranges;
+        const long long r0 = (long long)gg * rpr, r1 = r0 + rpr;
         const int i_lo = (int)((r0 + T - 1) / T);
         i_hi = (int)((r1 + T - 1) / T); if (i_hi > B) i_hi = B;
-        n_g = i_hi - i_lo; l = sub; lstep = S;
-    }
-    for (int b = rpr ? i_hi - 1 - l : blockIdx.x; rpr ? l < n_g : b < B; rpr ? (l += lstep, b = i_hi - 1 - l) : (b += gridDim.x)) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int v0 = rg; v0 < T; v0 += 8 * POOL_INFLIGHT) {                       // POOL_INFLIGHT rows in flight per thread (same summation order)
-            float4 x[POOL_INFLIGHT];
+        const int n_g = i_hi - i_lo;
+        n_inst = n_g > sub ? (n_g - sub + S - 1) / S : 0;
+    } else n_inst = B > (int)blockIdx.x ? (B - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    auto inst = [&](int i) __attribute__((always_inline)) { return rpr ? i_hi - 1 - (sub + i * S) : (int)blockIdx.x + i * (int)gridDim.x; };
+    const int nb = (T + RB - 1) / RB;                         // batches per instance
+    const int nq = n_inst * nb;                               // batches of this block
+    const int M = J > 0 ? T / J : 1;
+    const unsigned invM = (unsigned)((0x100000000ull + (unsigned)M - 1) / (unsigned)M);   // v / M = umulhi(v, invM) for v < 65536
+    // straight-line requests (a load behind an `if` would make every later wait drain the queue): rows beyond the instance / batches
+    // beyond the sequence are clamped to a valid row and discarded where they are used
+    auto request = [&](int q, f32x4 (&x)[NB], int (&cv)[NB]) __attribute__((always_inline)) {
+        const int qq = q < nq ? q : (nq > 0 ? nq - 1 : 0);
+        const int i = qq / nb, k = qq - i * nb;
+        const int b = nq > 0 ? inst(i) : 0;
 #pragma unroll
-            for (int u = 0; u < POOL_INFLIGHT; u++) {
-                const int v = v0 + 8 * u;
-                x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (v < T) {
-                    const f32x4 *src = reinterpret_cast<const f32x4 *>(z + ((size_t)b * T + v) * HD + c4);
-                    const f32x4 t = nt ? __builtin_nontemporal_load(src) : *src;       // (GemmArgs::nt)
-                    x[u] = make_float4(t[0], t[1], t[2], t[3]);
-                }
-            }
+        for (int u = 0; u < NB; u++) {
+            int v = k * RB + rg + 8 * u;
+            v = v < T ? v : T - 1;
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(z + ((size_t)b * T + v) * HD + c4);
+            x[u] = NT ? __builtin_nontemporal_load(src) : *src;
+            cv[u] = J > 0 ? cand[(size_t)b * J + (int)__umulhi((unsigned)v, invM)] : -1;
+        }
+    };
+    f32x4 xa[NB], xb[NB];
+    int ca[NB], cb[NB];
+    request(0, xa, ca);
+    request(1, xb, cb);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    auto consume = [&](int q, const f32x4 (&x)[NB], const int (&cv)[NB]) __attribute__((always_inline)) {
+        const int i = q / nb, k = q - i * nb;
+        const int b = inst(i);
 #pragma unroll
-            for (int u = 0; u < POOL_INFLIGHT; u++) {
-                const int v = v0 + 8 * u;
-                if (v < T) {
-                    float hv[4] = {bn_relu(x[u].x, mean[0], rstd[0], g[0], be[0]), bn_relu(x[u].y, mean[1], rstd[1], g[1], be[1]),
-                                   bn_relu(x[u].z, mean[2], rstd[2], g[2], be[2]), bn_relu(x[u].w, mean[3], rstd[3], g[3], be[3])};
-                    for (int q = 0; q < 4; q++) acc[q] += hv[q];
-                    if (h_nodes) *reinterpret_cast<float4 *>(h_nodes + ((size_t)b * T + v) * HD + c4) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-                }
+        for (int u = 0; u < NB; u++) {
+            const int v = k * RB + rg + 8 * u;
+            if (v < T) {
+                const float hv[4] = {bn_relu(x[u][0], mean[0], rstd[0], g[0], be[0]), bn_relu(x[u][1], mean[1], rstd[1], g[1], be[1]),
+                                     bn_relu(x[u][2], mean[2], rstd[2], g[2], be[2]), bn_relu(x[u][3], mean[3], rstd[3], g[3], be[3])};
+                for (int qq = 0; qq < 4; qq++) acc[qq] += hv[qq];
+                if (h_nodes) *reinterpret_cast<float4 *>(h_nodes + ((size_t)b * T + v) * HD + c4) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+                if (cv[u] == v)                                                         // candidate gather (ac:197-207); J = 0: cv = -1
+                    *reinterpret_cast<float4 *>(cand_feat + ((size_t)b * J + (int)__umulhi((unsigned)v, invM)) * HD + c4) = make_float4(hv[0], hv[1], hv[2], hv[3]);
             }
         }
-        for (int q = 0; q < 4; q++) s_part[rg][c4 + q] = acc[q];
-        for (int jj = rg; jj < J; jj += 8) {                                       // candidate gather (ac:197-207); J = 0: skipped
-            const int v = cand[b * J + jj];
-            const float4 x = *reinterpret_cast<const float4 *>(z + ((size_t)b * T + v) * HD + c4);
-            *reinterpret_cast<float4 *>(cand_feat + ((size_t)b * J + jj) * HD + c4) =
-                make_float4(bn_relu(x.x, mean[0], rstd[0], g[0], be[0]), bn_relu(x.y, mean[1], rstd[1], g[1], be[1]),
-                            bn_relu(x.z, mean[2], rstd[2], g[2], be[2]), bn_relu(x.w, mean[3], rstd[3], g[3], be[3]));
+        if (k == nb - 1) {                                                              // the instance is complete: fold the 8 row groups
+            float *sp = &s_part[i & 1][0][0];
+            *reinterpret_cast<float4 *>(sp + rg * HD + c4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            for (int qq = 0; qq < 4; qq++) acc[qq] = 0.f;
+            __syncthreads();                                                            // (buffer i & 1 is written again two instances later, behind the next barrier)
+            if (tid < HD) {
+                float t = 0.f;
+                for (int r = 0; r < 8; r++) t += sp[r * HD + tid];
+                h_pooled[(size_t)b * HD + tid] = t * (1.0f / (float)T);                 // sparse mm with 1/T entries (gcn:192)
+            }
         }
-        __syncthreads();
-        if (tid < HD) {
-            float t = 0.f;
-            for (int r = 0; r < 8; r++) t += s_part[r][tid];
-            h_pooled[(size_t)b * HD + tid] = t * (1.0f / (float)T);                // sparse mm with 1/T entries (gcn:192)
-        }
-        __syncthreads();                                                           // s_part is reused by the next instance
+    };
+    for (int q = 0; q < nq; q += 2) {
+        consume(q, xa, ca);
+        request(q + 2, xa, ca);
+        if (q + 1 < nq) consume(q + 1, xb, cb);
+        request(q + 3, xb, cb);
     }
 }
 
-// (Round 4 tried ONE WAVE per instance instead — lane = (row parity, 4 columns), a ring of 16 row-pair requests that runs across
-// instance boundaries, the two parities folded with one cross-lane move, the candidate rows picked out of the stream, no barriers:
-// 121.7 / 131.1 us against 115.5 / 107.2 us for this kernel at J10M10 x 8192 / J20M20 x 2048 on the same box — the ring's slots are
-// consumed in issue order with a wait each, and a wave has a sixteenth of a block's requests in flight.  Not kept.  Capping the block
-// kernel at 128 registers so that all four of a CU's blocks are resident at once — it takes 253 uncapped — changed nothing: 115.7 / 108.1
-// against 115.4 / 107.9 us.)
+// (Measured on the way, J10M10 x 8192 / J20M20 x 2048, us per launch, all on one box unless said otherwise: the earlier kernel — one
+// instance at a time, two barriers, candidate rows re-read behind their index, plain loads by accident — 116 / 108; the same with
+// real non-temporal loads 105 / 105; this kernel 108 / 101 on that box and 86-92 / 86 on faster ones (the launch is bimodal from run to
+// run, 92 or 107 on the same box: placement of the 419 MB matrix); without the candidate index loads 103 / 99; 4 or 8 rows per batch
+// the same, 13 slower; plain instance order instead of back-to-front per writer range 8-20 slower.  A bare non-temporal read of the
+// matrix in this order takes 69-76 us there (tools/ubench/read_after_write.hip).  Round 4's earlier attempts: ONE WAVE per instance,
+// 122 / 131 against 116 / 107; a register cap for four resident blocks per CU, no change — both still with the accidental plain loads.)
 // broadcast a [128] vector to [B,128] (first step: learned `_input` instead of h_m_prev, ac:229-233)
 __global__ void k_bcast128(int B, const float *v, float *out)
 {
@@ -2844,8 +2875,12 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         // (the last product's partition: launch_gemm's grid and k_gemm_x6's tiles per workgroup)
         const int ntiles = (N + 15) / 16, ggrid = std::min((ntiles + 7) / 8, e->num_cu), rpr = so && e->pool_s > 0 ? ((ntiles + ggrid - 1) / ggrid) * 16 : 0;
         const int pool_grid = rpr ? ggrid * e->pool_s : (B < e->num_cu * 8 ? B : e->num_cu * 8);
-        hipLaunchKernelGGL(k_job_pool_gather, dim3(pool_grid), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, (so && (e->stream_nt & 4)) ? 1 : 0, rpr, e->pool_s, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
-                           W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, cand_feat, h_nodes);
+        if (so && (e->stream_nt & 4))
+            hipLaunchKernelGGL(k_job_pool_gather<1>, dim3(pool_grid), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, rpr, e->pool_s, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
+                               W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, cand_feat, h_nodes);
+        else
+            hipLaunchKernelGGL(k_job_pool_gather<0>, dim3(pool_grid), dim3(256), 0, e->stream, split_products_in_use(e) ? e->range_flag : nullptr, rpr, e->pool_s, B, T, candidate ? J : 0, e->zB, st + 5 * STAT_REP * 256, invN,
+                               W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), candidate, h_pooled, cand_feat, h_nodes);
     }
     HIPCHK(e, hipGetLastError());
     return MTFJSP_OK;

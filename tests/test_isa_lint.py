@@ -31,5 +31,21 @@ _Z7k_gat3x7GatArgs:
 def test_kernels_contain_no_unreliable_packed_f32_swizzle(flags):
     if not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("hipcc not available")
-    bad = isa_lint.lint_sources(flags)
+    stream_bad = []
+    bad = isa_lint.lint_sources(flags, streaming=stream_bad)
     assert not bad, "\n".join(f"{s}: {k}: {i}" for s, k, _, i in bad)
+    # rule 2: the read-once kernels really carry their non-temporal loads (a run-time flag is silently merged into a plain load)
+    assert not stream_bad, "\n".join(f"{k}: {w} (found {n})" for k, w, n in stream_bad)
+
+
+def test_streaming_rule_on_samples():
+    asm = """
+_Z17k_job_pool_gatherILi1EEvPjiiiiiPKfPKddS2_S2_PKiPfS7_S7_:
+\tglobal_load_dwordx4 v[12:15], v[4:5], off
+_Z17k_job_pool_gatherILi0EEvPjiiiiiPKfPKddS2_S2_PKiPfS7_S7_:
+\tglobal_load_dwordx4 v[12:15], v[4:5], off nt
+_Z9k_gemm_x6ILi1EEv8GemmArgs:
+\tglobal_load_dwordx4 v[12:15], v[4:5], off nt
+"""
+    bad = isa_lint.lint_streaming(asm)
+    assert sorted(b[0][:28] for b in bad) == ["_Z17k_job_pool_gatherILi0EEv", "_Z17k_job_pool_gatherILi1EEv", "_Z9k_gemm_x6ILi2EE"]

@@ -8,6 +8,12 @@ while reading the low half of source 0 (`op_sel:[0,1...]`): with a second wave o
 hipcc's SLP vectoriser produces the form when it pairs scalar products whose second operands sit in a register pair in the opposite
 order.  Every other op_sel combination measured (source 0 swapped, both swapped, low-twice, source-0 / source-2 high-twice) is clean.
 
+Rule 2 — the kernels that read a matrix ONCE must do it with non-temporal loads (`global_load_dwordx4 ... nt`): a 419 MB matrix
+just written by the previous launch reads at 3.6 TB/s with plain loads and at 5.0-5.2 TB/s with non-temporal ones
+(tools/ubench/read_after_write.hip).  A run-time `nt ? __builtin_nontemporal_load(p) : *p` is merged by the optimiser into ONE
+plain load — k_job_pool_gather shipped like that for two rounds — so the expectation is checked on the ISA: STREAMING lists the
+kernels (mangled-name prefixes) and whether their ISA must / must not contain such loads.
+
     python tools/isa_lint.py [extra hipcc flags ...]      exit code 1 and a listing when a rule fires
 """
 import os
@@ -48,19 +54,66 @@ def lint_asm(text):
     return bad
 
 
-def lint_sources(extra_flags=()):
+NT_LOAD = re.compile(r"^\s*global_load_dwordx4\b.*\bnt\b")
+# (mangled-name prefix, must contain non-temporal 16-byte loads?)
+STREAMING = [("_Z17k_job_pool_gatherILi1EE", True), ("_Z17k_job_pool_gatherILi0EE", False),
+             ("_Z9k_gemm_x6ILi1EE", True), ("_Z9k_gemm_x6ILi2EE", True)]
+
+
+def nt_load_counts(text):
+    """-> {kernel: number of non-temporal 16-byte global loads in its ISA}"""
+    counts, kernel = {}, None
+    for line in text.splitlines():
+        m = re.match(r"^(_Z\w+|k_\w+):", line)
+        if m:
+            kernel = m.group(1)
+            counts.setdefault(kernel, 0)
+        elif kernel and NT_LOAD.match(line):
+            counts[kernel] += 1
+    return counts
+
+
+def lint_streaming(text):
+    """-> list of (kernel prefix, expectation, count) for the STREAMING kernels whose ISA disagrees with the expectation"""
+    counts = nt_load_counts(text)
+    bad = []
+    for prefix, want in STREAMING:
+        ks = [k for k in counts if k.startswith(prefix)]
+        for k in ks:
+            if (counts[k] > 0) != want:
+                bad.append((k, "non-temporal loads expected" if want else "no non-temporal loads expected", counts[k]))
+        if not ks:
+            bad.append((prefix, "kernel not found in the assembly", 0))
+    return bad
+
+
+def compile_asm(extra_flags=()):
+    """-> [(source file, gfx950 assembly text)]"""
     out = []
     with tempfile.TemporaryDirectory() as tmp:
         for src in SOURCES:
             asm = os.path.join(tmp, src + ".s")
             subprocess.check_call([hipcc()] + FLAGS + list(extra_flags) + [os.path.join(CSRC, src), "-o", asm], stderr=subprocess.DEVNULL)
-            out += [(src,) + b for b in lint_asm(open(asm).read())]
+            out.append((src, open(asm).read()))
+    return out
+
+
+def lint_sources(extra_flags=(), streaming=None):
+    """rule 1 over every source; with `streaming` (a list) rule 2's findings for mtfjsp_encoder.hip are appended to it"""
+    out = []
+    for src, text in compile_asm(extra_flags):
+        out += [(src,) + b for b in lint_asm(text)]
+        if streaming is not None and src == "mtfjsp_encoder.hip":
+            streaming += lint_streaming(text)
     return out
 
 
 if __name__ == "__main__":
-    bad = lint_sources(sys.argv[1:])
+    stream_bad = []
+    bad = lint_sources(sys.argv[1:], streaming=stream_bad)
     for src, kernel, n, ins in bad:
         print(f"{src}: {kernel}: line {n}: {ins}")
-    print(f"isa_lint: {len(bad)} unreliable packed-f32 operand swizzle(s)" + (" with " + " ".join(sys.argv[1:]) if sys.argv[1:] else ""))
-    sys.exit(1 if bad else 0)
+    for kernel, what, n in stream_bad:
+        print(f"mtfjsp_encoder.hip: {kernel}: {what} (found {n})")
+    print(f"isa_lint: {len(bad)} unreliable packed-f32 operand swizzle(s), {len(stream_bad)} streaming-load mismatch(es)" + (" with " + " ".join(sys.argv[1:]) if sys.argv[1:] else ""))
+    sys.exit(1 if bad or stream_bad else 0)

@@ -1,0 +1,105 @@
+// read_after_write.hip — how fast can a kernel READ a 419 MB matrix that the previous kernel has just WRITTEN?
+// (k_job_pool_gather reads the last GIN product's 819 200 x 128 f32 output once: 108-116 us = 3.6-3.9 TB/s, and neither more blocks per
+// CU nor more loads in flight per thread change that.  Is that the memory system's rate for this situation, or the kernel's?)
+// Writer: 256 workgroups, each filling its own contiguous range front to back (the product's partition), plain stores.
+// Readers (16-byte loads, 8 in flight per thread, xor-reduced so that nothing is written):
+//   A  grid-stride over the whole matrix, ascending            B  the same, non-temporal loads
+//   C  each of 1024 blocks takes a quarter of a writer's range, from the BACK of the range (what the pool kernel does), plain
+//   D  the same, non-temporal                                   E  as C but ascending inside the range
+// Also the reader alone on a matrix that was written long ago (after a 1 GB flush of the memory-side cache): the cold rate.
+//   hipcc --offload-arch=gfx950 -O3 -o read_after_write read_after_write.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void k_write(u4 *dst, size_t n16, unsigned v)
+{
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 512) dst[i] = u4{v, v, v, v};
+}
+// a writer like the GIN product: reads another matrix of the same size (non-temporal) while it writes this one
+__global__ __launch_bounds__(512) void k_copy_write(const u4 *src, u4 *dst, size_t n16)
+{
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 512) dst[i] = __builtin_nontemporal_load(src + i);
+}
+template <int NT>
+__device__ __forceinline__ u4 ld(const u4 *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <int NT>
+__global__ __launch_bounds__(256) void k_read_stride(const u4 *src, size_t n16, unsigned *sink)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    u4 acc = {0, 0, 0, 0};
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 7 * stride < n16; i += 8 * stride) {
+        u4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = ld<NT>(src + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc ^= x[u];
+    }
+    for (; i < n16; i += stride) acc ^= ld<NT>(src + i);
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) *sink = 1;
+}
+// block (g, s): quarter s of writer range g; BACK: from the end of the range towards its start
+template <int NT, int BACK>
+__global__ __launch_bounds__(256) void k_read_ranges(const u4 *src, size_t n16, int nranges, unsigned *sink)
+{
+    const int g = blockIdx.x % nranges, s = blockIdx.x / nranges, S = gridDim.x / nranges;
+    const size_t per = (n16 + nranges - 1) / nranges, lo = g * per, hi = lo + per < n16 ? lo + per : n16;
+    // chunks of 256 x 8 x 16 B = 32 KB, dealt to the S blocks of the range in turn
+    const size_t chunk = 256 * 8, nch = (hi - lo + chunk - 1) / chunk;
+    u4 acc = {0, 0, 0, 0};
+    for (size_t c = s; c < nch; c += S) {
+        const size_t cc = BACK ? nch - 1 - c : c;
+        const size_t base = lo + cc * chunk + threadIdx.x;
+        u4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const size_t i = base + u * 256; x[u] = i < hi ? ld<NT>(src + i) : u4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc ^= x[u];
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9e3779b9u) *sink = 1;
+}
+
+int main()
+{
+    const size_t bytes = (size_t)819200 * 512, n16 = bytes / 16;
+    u4 *m, *flush; unsigned *sink;
+    CHK(hipMalloc((void **)&m, bytes)); CHK(hipMalloc((void **)&flush, (size_t)1 << 30)); CHK(hipMalloc((void **)&sink, 4));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    u4 *m2; CHK(hipMalloc((void **)&m2, bytes)); CHK(hipMemset(m2, 3, bytes));
+    auto run = [&](const char *what, int mode, int after_write) -> int {
+        double tot = 0; const int reps = 10;
+        for (int r = 0; r < reps + 2; r++) {
+            if (after_write == 2) hipLaunchKernelGGL(k_copy_write, dim3(256), dim3(512), 0, 0, m2, m, n16);
+            else if (after_write) hipLaunchKernelGGL(k_write, dim3(256), dim3(512), 0, 0, m, n16, (unsigned)r);
+            else hipLaunchKernelGGL(k_write, dim3(256), dim3(512), 0, 0, flush, ((size_t)1 << 30) / 16, (unsigned)r);   // pushes the matrix out of the memory-side cache
+            CHK(hipEventRecord(e0, 0));
+            switch (mode) {
+            case 0: hipLaunchKernelGGL(k_read_stride<0>, dim3(2048), dim3(256), 0, 0, m, n16, sink); break;
+            case 1: hipLaunchKernelGGL(k_read_stride<1>, dim3(2048), dim3(256), 0, 0, m, n16, sink); break;
+            case 2: hipLaunchKernelGGL((k_read_ranges<0, 1>), dim3(1024), dim3(256), 0, 0, m, n16, 256, sink); break;
+            case 3: hipLaunchKernelGGL((k_read_ranges<1, 1>), dim3(1024), dim3(256), 0, 0, m, n16, 256, sink); break;
+            case 4: hipLaunchKernelGGL((k_read_ranges<0, 0>), dim3(1024), dim3(256), 0, 0, m, n16, 256, sink); break;
+            case 5: hipLaunchKernelGGL((k_read_ranges<1, 0>), dim3(1024), dim3(256), 0, 0, m, n16, 256, sink); break;
+            }
+            CHK(hipEventRecord(e1, 0));
+            CHK(hipDeviceSynchronize());
+            float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) tot += ms;
+        }
+        printf("%-72s %-28s %7.1f us  (%.2f TB/s)\n", what, after_write == 2 ? "after a read+write product" : after_write ? "right after its writer" : "written long ago (flushed)", tot / reps * 1e3, bytes / (tot / reps * 1e-3) / 1e12);
+        return 0;
+    };
+    for (int aw = 2; aw >= 0; aw--) {
+        run("A grid-stride ascending, plain loads", 0, aw);
+        run("B grid-stride ascending, non-temporal loads", 1, aw);
+        run("C quarter of a writer's range per block, from the BACK, plain", 2, aw);
+        run("D quarter of a writer's range per block, from the BACK, non-temporal", 3, aw);
+        run("E quarter of a writer's range per block, ascending, plain", 4, aw);
+        run("F quarter of a writer's range per block, ascending, non-temporal", 5, aw);
+    }
+    return 0;
+}
