@@ -18,6 +18,11 @@ __global__ __launch_bounds__(512) void k_write(u4 *dst, size_t n16, unsigned v)
     const size_t per = (n16 + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = lo + per < n16 ? lo + per : n16;
     for (size_t i = lo + threadIdx.x; i < hi; i += 512) dst[i] = u4{v, v, v, v};
 }
+__global__ __launch_bounds__(256) void k_write_stride(u4 *dst, size_t n16, unsigned v)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += stride) dst[i] = u4{v, v, v, v};
+}
 // a writer like the GIN product: reads another matrix of the same size (non-temporal) while it writes this one
 __global__ __launch_bounds__(512) void k_copy_write(const u4 *src, u4 *dst, size_t n16)
 {
@@ -93,6 +98,29 @@ int main()
         printf("%-72s %-28s %7.1f us  (%.2f TB/s)\n", what, after_write == 2 ? "after a read+write product" : after_write ? "right after its writer" : "written long ago (flushed)", tot / reps * 1e3, bytes / (tot / reps * 1e-3) / 1e12);
         return 0;
     };
+    // the writers alone (what the first GIN product does: a write-only 419 MB stream)
+    {
+        auto wr = [&](const char *what, int mode) -> int {
+            double tot = 0; const int reps = 10;
+            for (int r = 0; r < reps + 2; r++) {
+                CHK(hipEventRecord(e0, 0));
+                if (mode == 0) hipLaunchKernelGGL(k_write, dim3(256), dim3(512), 0, 0, m, n16, (unsigned)r);
+                else if (mode == 1) hipLaunchKernelGGL(k_write, dim3(1024), dim3(512), 0, 0, m, n16, (unsigned)r);
+                else if (mode == 2) hipLaunchKernelGGL(k_write_stride, dim3(2048), dim3(256), 0, 0, m, n16, (unsigned)r);
+                else hipLaunchKernelGGL(k_write, dim3(256), dim3(512), 0, 0, (r & 1) ? m2 : m, n16, (unsigned)r);
+                CHK(hipEventRecord(e1, 0));
+                CHK(hipDeviceSynchronize());
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (r >= 2) tot += ms;
+            }
+            printf("%-72s %-28s %7.1f us  (%.2f TB/s)\n", what, "write only", tot / reps * 1e3, bytes / (tot / reps * 1e-3) / 1e12);
+            return 0;
+        };
+        wr("W 256 workgroups, each its contiguous range front to back (same matrix again)", 0);
+        wr("W 1024 workgroups, each its contiguous range", 1);
+        wr("W grid-stride, 2048 blocks", 2);
+        wr("W 256 workgroups, contiguous ranges, two matrices alternately", 3);
+    }
     for (int aw = 2; aw >= 0; aw--) {
         run("A grid-stride ascending, plain loads", 0, aw);
         run("B grid-stride ascending, non-temporal loads", 1, aw);
