@@ -252,6 +252,9 @@
             STAMP(4);
         }
         // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance; optional action selection
+        // (Round 4 requested gather_from[row] and the job predecessor's machine of EVERY scorer row at the top of the kernel, so that the
+        // selection below would not fetch them behind one another — index, link, then the task's rows: the job heads' launch did not
+        // change (46.2 against 46.0 us) and the machine heads, which only paid for the extra requests, lost 0.4 us: not kept.)
         {
             const int r0 = tid >> 4, l = tid & 15;
             if (r0 < ng) {
