@@ -30,16 +30,36 @@ def normalise(advs, group=None, eps=1e-5, timed=False):
     return (out, info) if timed else out
 
 
+def _pairs(r4, job_v, job_v_, machine_v, machine_v_):
+    """(reward, value, next value) views per local-critic channel in the order mk, pt, tt, it (r4 is mk, idle, pt, tt: pe:255-262)"""
+    return [(r4[:, 0], job_v[..., 0], job_v_[..., 0]), (r4[:, 2], machine_v[..., 0], machine_v_[..., 0]),
+            (r4[:, 3], machine_v[..., 1], machine_v_[..., 1]), (r4[:, 1], job_v[..., 1], job_v_[..., 1])]
+
+
+def _device_handoff(env, packed, K, values, group, timed, want_full):
+    """packed [K_total,S,B] (first K: raw advantages) -> all-gather (one collective) -> HIP normalisation (mtfjsp_normalize_advantages):
+    (norm [K,S,B], targets [K,S,B], full [K_total,S,B_total] or None, gather info).  No torch kernel runs on this path."""
+    Kt, S, B = packed.shape
+    G, info = D.all_gather_packed(packed, group=group, timed=timed)
+    world, rank = info["world"], info["rank"]
+    norm = torch.empty(K, S, B, dtype=torch.float32, device=packed.device)
+    targets = torch.empty_like(norm)
+    full = torch.empty(Kt, S, world * B, dtype=torch.float32, device=packed.device) if (want_full and world > 1) else None
+    env.normalize_advantages(G, K, world, rank, values, norm, targets, full)
+    return norm, targets, full, info
+
+
 def local_advantages(env, r4, job_v, job_v_, machine_v, machine_v_, done, gamma, lam, group=None, timed=False):
     """r4 [S,4,B] in the step kernel's order (mk, idle, pt, tt; pe:255-262); job_v* [S,B,2] = (mk, it), machine_v* [S,B,2] =
-    (pt, tt); done [S,B].  -> (advantages[4], value_targets[4], raw[4], gather_info) in the order mk, pt, tt, it."""
-    pairs = [(r4[:, 0], job_v[..., 0], job_v_[..., 0]), (r4[:, 2], machine_v[..., 0], machine_v_[..., 0]),
-             (r4[:, 3], machine_v[..., 1], machine_v_[..., 1]), (r4[:, 1], job_v[..., 1], job_v_[..., 1])]
-    raw = [env.gae(r, v, v_, done, gamma, lam) for r, v, v_ in pairs]
-    res = normalise(raw, group=group, timed=timed)
-    norm, info = res if timed else (res, None)
-    targets = [a + p[1] for a, p in zip(norm, pairs)]
-    return norm, targets, raw, info
+    (pt, tt); done [S,B].  -> (advantages[4], value_targets[4], raw[4], gather_info) in the order mk, pt, tt, it.
+    The four GAE scans write into ONE packed buffer, which is what the all-gather sends and the normalisation kernel reads."""
+    pairs = _pairs(r4, job_v, job_v_, machine_v, machine_v_)
+    S, B = done.shape
+    packed = torch.empty(4, S, B, dtype=torch.float32, device=done.device)
+    for k, (r, v, v_) in enumerate(pairs):
+        env.gae(r, v, v_, done, gamma, lam, out=packed[k])
+    norm, targets, _, info = _device_handoff(env, packed, 4, [p[1] for p in pairs], group, timed, False)
+    return list(norm.unbind(0)), list(targets.unbind(0)), list(packed.unbind(0)), (info if timed else None)
 
 
 def sample_global_values(enc, traj):
@@ -71,28 +91,30 @@ def full_handoff(env, r4, job_v, job_v_, machine_v, machine_v_, multi_v, multi_v
                  gather_values=True):
     """The complete rollout -> update hand-off of ppo:628-703 in ONE collective: the four global-critic advantages
     (separate_cal_4_reward_GAE, ppo:491-536) and the four local-critic advantages (cal_local_job_machine_reward_GAE, ppo:437-489)
-    are computed per shard (`mtfjsp_gae` reverse scans) and exchanged as one packed buffer — with gather_values the eight value
-    tensors their targets are built from ride along, so that every rank ends with what the reference's single process holds:
-    16 tensors x [S, B_total] f32 (SURVEY §8e sizes the exchange so: 47 MB per rank at 8 x 4096 J6M6 instances); a data-parallel
-    trainer that only consumes its own columns sets gather_values=False (8 tensors).  Normalisation (adv - mean) / (std + 1e-5)
-    per tensor over ALL shards' columns (ppo:485,532), value target = normalised advantage + value at act time (ppo:668-671,689).
-    Channel order mk, pt, tt, it everywhere.
+    are computed per shard (`mtfjsp_gae` reverse scans, straight into the packed buffer) and exchanged as one packed buffer — with
+    gather_values the eight value tensors their targets are built from ride along (`mtfjsp_pack_views`), so that every rank ends with
+    what the reference's single process holds: 16 tensors x [S, B_total] f32 (SURVEY §8e sizes the exchange so: 47 MB per rank at
+    8 x 4096 J6M6 instances); a data-parallel trainer that only consumes its own columns sets gather_values=False (8 tensors).
+    Normalisation (adv - mean) / (std + 1e-5) per tensor over ALL shards' columns (ppo:485,532), value target = normalised advantage
+    + value at act time (ppo:668-671,689): `mtfjsp_normalize_advantages`.  Channel order mk, pt, tt, it everywhere.
     -> dict(global_adv[4], global_targets[4], local_adv[4], local_targets[4], raw_global[4], raw_local[4], gather=info,
-            full_adv / full_values: the gathered [S,B_total] tensors when more than one rank took part)"""
+            full_adv / full_values: the gathered [S,B_total] tensors (views of this rank's own when only one rank took part))"""
     order = (0, 2, 3, 1)                                   # mk, pt, tt, it inside r4's (mk, idle, pt, tt)
-    raw_g = [env.gae(r4[:, order[i]], multi_v[..., i], multi_v_[..., i], done, gamma, lam) for i in range(4)]
-    pairs = [(r4[:, 0], job_v[..., 0], job_v_[..., 0]), (r4[:, 2], machine_v[..., 0], machine_v_[..., 0]),
-             (r4[:, 3], machine_v[..., 1], machine_v_[..., 1]), (r4[:, 1], job_v[..., 1], job_v_[..., 1])]
-    raw_l = [env.gae(r, v, v_, done, gamma, lam) for r, v, v_ in pairs]
+    pairs = _pairs(r4, job_v, job_v_, machine_v, machine_v_)
+    S, B = done.shape
+    Kt = 16 if gather_values else 8
+    packed = torch.empty(Kt, S, B, dtype=torch.float32, device=done.device)
+    for i in range(4):
+        env.gae(r4[:, order[i]], multi_v[..., i], multi_v_[..., i], done, gamma, lam, out=packed[i])
+    for k, (r, v, v_) in enumerate(pairs):
+        env.gae(r, v, v_, done, gamma, lam, out=packed[4 + k])
     vals = [multi_v[..., i] for i in range(4)] + [p[1] for p in pairs]
-    packed = raw_g + raw_l + (vals if gather_values else [])
-    res = D.all_gather_advantages(packed, group=group, timed=timed)
-    full, info = res if timed else (res, None)
-    norm = []
-    for a_full, a_loc in zip(full[:8], raw_g + raw_l):
-        mean, std = a_full.mean(), a_full.std()
-        norm.append((a_loc - mean) / (std + 1e-5))
-    out = dict(global_adv=norm[:4], local_adv=norm[4:], raw_global=raw_g, raw_local=raw_l,
-               global_targets=[norm[i] + vals[i] for i in range(4)], local_targets=[norm[4 + i] + vals[4 + i] for i in range(4)],
-               gather=info, full_adv=full[:8], full_values=full[8:] if gather_values else None)
+    if gather_values:
+        env.pack_views(vals, packed[8:])
+    norm, targets, full, info = _device_handoff(env, packed, 8, vals, group, timed, True)
+    src = full if full is not None else packed              # one rank: the gathered tensors ARE this rank's
+    out = dict(global_adv=list(norm[:4].unbind(0)), local_adv=list(norm[4:].unbind(0)),
+               raw_global=list(packed[:4].unbind(0)), raw_local=list(packed[4:8].unbind(0)),
+               global_targets=list(targets[:4].unbind(0)), local_targets=list(targets[4:].unbind(0)),
+               gather=(info if timed else None), full_adv=list(src[:8].unbind(0)), full_values=list(src[8:].unbind(0)) if gather_values else None)
     return out

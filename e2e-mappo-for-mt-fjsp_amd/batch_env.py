@@ -174,6 +174,37 @@ class DeviceBatchEnv:
                                      v_next.data_ptr(), v_next.stride(0), v_next.stride(1), done.data_ptr(), gamma, lam, out.data_ptr()), self.h)
         return out
 
+    @staticmethod
+    def _view_table(views):
+        """K f32 [S,B] views (any element strides) -> (pointer array, stride_s array, stride_b array) for the C ABI"""
+        K = len(views)
+        ptrs = (C.c_void_p * K)(*[(v.data_ptr() if v is not None else None) for v in views])
+        ss = (C.c_int64 * K)(*[(v.stride(0) if v is not None else 0) for v in views])
+        sb = (C.c_int64 * K)(*[(v.stride(1) if v is not None else 0) for v in views])
+        return ptrs, ss, sb
+
+    def pack_views(self, views, out):
+        """K strided f32 [S,B] views -> out[k] (out: contiguous [K,S,B] or a contiguous slice of a larger packed buffer); one launch"""
+        K, S = len(views), views[0].shape[0]
+        assert out.is_contiguous() and tuple(out.shape) == (K, S, self.B) and all(v.dtype == torch.float32 for v in views)
+        ptrs, ss, sb = self._view_table(views)
+        capi.check(self.L.mtfjsp_pack_views(self.h, K, S, ptrs, ss, sb, out.data_ptr()), self.h)
+        return out
+
+    def normalize_advantages(self, gathered, K, world, rank, values, norm_out, targets_out=None, full_out=None, eps=1e-5):
+        """(adv - mean) / (std + eps) of ppo:485,532 for the first K tensors of gathered [world, K_total, S, B] (statistics over all
+        shards' columns), value targets = normalised advantage + values[k] ([S,B] views), optional reference layout
+        full_out [K_total, S, world*B]; two launches, no torch kernels (include/mtfjsp.h)"""
+        Kt, S = gathered.shape[-3], gathered.shape[-2]
+        assert gathered.is_contiguous() and gathered.dtype == torch.float32 and gathered.numel() == world * Kt * S * self.B
+        assert norm_out.is_contiguous() and (targets_out is None or targets_out.is_contiguous()) and (full_out is None or full_out.is_contiguous())
+        ptrs = ss = sb = None
+        if targets_out is not None:
+            ptrs, ss, sb = self._view_table(list(values) + [None] * (K - len(values)))
+        capi.check(self.L.mtfjsp_normalize_advantages(self.h, K, Kt, world, rank, S, gathered.data_ptr(), eps, ptrs, ss, sb, norm_out.data_ptr(),
+                                                      targets_out.data_ptr() if targets_out is not None else None,
+                                                      full_out.data_ptr() if full_out is not None else None), self.h)
+
     def observe_mfea1(self, task_idx, mmask=None):
         if not torch.is_tensor(task_idx):
             task_idx = torch.as_tensor(np.ascontiguousarray(task_idx, np.int32), device=self.device)

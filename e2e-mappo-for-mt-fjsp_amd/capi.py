@@ -67,6 +67,8 @@ PROTOTYPES = {
     "mtfjsp_step_params_bytes": (C.c_int32, []),
     "mtfjsp_step_params": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, C.c_int32]),
     "mtfjsp_gae": (_I, [_VP, C.c_int32, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int64, _VP, C.c_int64, C.c_int64, _VP, C.c_float, C.c_float, _VP]),
+    "mtfjsp_normalize_advantages": (_I, [_VP, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _VP, C.c_float, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "mtfjsp_pack_views": (_I, [_VP, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP]),
     "mtfjsp_observe_mfea1": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "mtfjsp_random_actions": (_I, [_VP, _U64, _U64, _VP, _VP, _VP]),
     "mtfjsp_export_dense_adj": (_I, [_VP, _VP]),
@@ -91,6 +93,7 @@ PROTOTYPES = {
     "mtfjsp_encoder_set_bn_mode": (_I, [_VP, C.c_int32]),
     "mtfjsp_encoder_set_product_mode": (_I, [_VP, C.c_int32]),
     "mtfjsp_encoder_set_stats_reduce": (_I, [_VP, C.c_void_p, _VP, C.c_int64]),
+    "mtfjsp_encoder_set_deferred_poll": (_I, [_VP, C.c_int32]),
     "mtfjsp_get_mfea1_context": (_I, [_VP, _VP, _VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_mfea1": (_I, [_VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_env_step": (_I, [_VP, _VP, C.c_int32]),

@@ -1832,6 +1832,18 @@ __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, i
                 for (int r = 0; r < 8; r++) t += sp[r * HD + tid];
                 h_pooled[(size_t)b * HD + tid] = t * (1.0f / (float)T);                 // sparse mm with 1/T entries (gcn:192)
             }
+            // The stream above picks candidate j's row out of job j's block of rows [j M, (j+1) M) — where the environment's candidates
+            // always lie (ppo:306-309: the next operation of job j).  A caller-made candidate outside its job's block (the other
+            // forward paths accept any row < T) takes a dependent gather here instead of leaving a stale row: never on the rollout path.
+            for (int j = rg; j < J; j += 8) {
+                const int c = cand[(size_t)b * J + j];
+                if (c >= 0 && c < T && (int)__umulhi((unsigned)c, invM) != j) {
+                    const f32x4 xv = *reinterpret_cast<const f32x4 *>(z + ((size_t)b * T + c) * HD + c4);
+                    *reinterpret_cast<float4 *>(cand_feat + ((size_t)b * J + j) * HD + c4) =
+                        make_float4(bn_relu(xv[0], mean[0], rstd[0], g[0], be[0]), bn_relu(xv[1], mean[1], rstd[1], g[1], be[1]),
+                                    bn_relu(xv[2], mean[2], rstd[2], g[2], be[2]), bn_relu(xv[3], mean[3], rstd[3], g[3], be[3]));
+                }
+            }
         }
     };
     for (int q = 0; q < nq; q += 2) {
@@ -2236,6 +2248,7 @@ struct mtfjsp_encoder {
     bool gin_stats_clean = false;           // slots 0..5 are zero (the job-actor heads kernel zeroes them after their last reader)
     bool gat_stats_clean[2] = {false, false};
     int bn_mode = 0;                        // 0: BatchNorm statistics over the whole device batch; 1: per instance (validate.py semantics)
+    bool defer_poll = false;                // forward entries do not poll the asynchronous failure words: only mtfjsp_encoder_check reports them (mtfjsp_encoder_set_deferred_poll)
     mtfjsp_stats_reduce_fn reduce_fn = nullptr; void *reduce_user = nullptr;   // exact multi-shard BatchNorm: sums of every BN summed over the shards
     double reduce_scale = 1.0;              // global rows / local rows
     // which products run with the f32 matrix instruction instead of the exact bf16 split (A/B reference; bits: 1 GIN products,
@@ -2253,6 +2266,7 @@ struct mtfjsp_encoder {
     bool res_eligible = false;              // the shape can use the single-launch kernel (res_ok: and the census passed / no failure since)
     long long res_failures = 0, res_launches = 0;
     long long res_fail_at = getenv("MTFJSP_GIN_RES_FAIL_AT") ? atoll(getenv("MTFJSP_GIN_RES_FAIL_AT")) : 0;   // diagnostic: this launch's barriers time out
+    long long range_fail_at = getenv("MTFJSP_RANGE_FAIL_AT") ? atoll(getenv("MTFJSP_RANGE_FAIL_AT")) : 0, job_forwards = 0;   // diagnostic: the n-th job-actor forward raises the range word (as a NaN output would)
     float *res_zspill = nullptr;            // [grid][4][2][1024] f32: the two row tiles per workgroup that do not fit the registers
     unsigned long long res_epoch = 0;
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
@@ -2455,7 +2469,8 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
         if (!getenv("MTFJSP_NO_RESIDENT_GIN") && T >= GR_MINT && T <= GR_MAXT) {
             const int ipc = (B + e->num_cu - 1) / e->num_cu;
             const int grid = (B + ipc - 1) / ipc;
-            if (ipc * T <= GR_ROWS && ipc <= GR_MAXIPC && grid <= e->num_cu && ipc * cfg->n_job <= GR_MAXCAND &&
+            // (grid + 7) / 8 <= 63: a count-carrying statistics word holds the arrivals of one dispatch group in 6 bits (gr_fix_encode)
+            if (ipc * T <= GR_ROWS && ipc <= GR_MAXIPC && grid <= e->num_cu && (grid + 7) / 8 <= 63 && ipc * cfg->n_job <= GR_MAXCAND &&
                 hipFuncSetAttribute((const void *)k_gin_res, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gin_res_lds_bytes()) == hipSuccess) {
                 int rc = dalloc(e, &e->res_stats, (size_t)2 * GR_STATS_SET) | dalloc(e, &e->res_bar, (size_t)17 * 16) |
                          dalloc(e, &e->res_zspill, (size_t)grid * 4 * (GR_NT - GR_NRES) * 1024);
@@ -2841,6 +2856,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         else
             hipLaunchKernelGGL((k_gin0<double>), dim3(pgrid), dim3(256), 0, e->stream, N, T, (const double *)tasks_fea, ell_col, ell_val,
                                W(P + "mlps.0.linears.0.weight"), W(P + "mlps.0.linears.0.bias"), e->zA, st + 0 * STAT_REP * 256);
+        if ((rrc = reduce_stats(e, st + 0 * STAT_REP * 256))) return rrc;      // (the same number of reductions per forward in every product mode)
     }
     // the launches alternate the direction in which a workgroup walks its rows (GemmArgs::rev): each starts on the part of its
     // input that is still in the memory-side cache.  The aggregation product walks FORWARD (a row's job predecessor is the row
@@ -3144,6 +3160,15 @@ extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instan
     e->prefused.valid = false;
     return MTFJSP_OK;
 }
+// deferred = 1: the forward entries stop polling the asynchronous failure words; failures surface at mtfjsp_encoder_check only.  For
+// callers whose forwards contain collectives (exact multi-shard BatchNorm): every rank must issue the same sequence of forwards, so a
+// rank-local failure may only be acted upon at a point all ranks agree on (rollout.py: once per step, after a synchronised check).
+extern "C" int mtfjsp_encoder_set_deferred_poll(mtfjsp_encoder_t e, int32_t deferred)
+{
+    if (!e || deferred < 0 || deferred > 1) return MTFJSP_ERR_ARG;
+    e->defer_poll = deferred != 0;
+    return MTFJSP_OK;
+}
 
 static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic, const GatArgs *fused_gat = nullptr,
                          const EnvParams *env_tail = nullptr)
@@ -3215,7 +3240,8 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     int rc = mtfjsp_encoder_weights_ready(e);
     if (rc) return rc;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
-    if ((rc = res_poll_failure(e))) return rc;
+    if (!e->defer_poll && (rc = res_poll_failure(e))) return rc;
+    if (++e->job_forwards == e->range_fail_at && e->res_fail_host) e->res_fail_host[1] = 1u;   // (diagnostic, MTFJSP_RANGE_FAIL_AT)
     const int B = e->cfg.batch, J = e->cfg.n_job;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
@@ -3304,7 +3330,7 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
     int rc = mtfjsp_encoder_weights_ready(e);
     if (rc) return rc;
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
-    if ((rc = res_poll_failure(e))) return rc;
+    if (!e->defer_poll && (rc = res_poll_failure(e))) return rc;
     const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
@@ -3376,7 +3402,7 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
     // this forward's GAT passes overwrite e->node and move on to another statistics slot: GAT passes the job actor's heads launch
     // ran ahead for a coming machine-actor forward (k_headsx_gat3x) are gone, that forward has to redo them
     e->prefused.valid = false;
-    { const int prc = res_poll_failure(e); if (prc) return prc; }
+    if (!e->defer_poll) { const int prc = res_poll_failure(e); if (prc) return prc; }
     const int B = e->cfg.batch;
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WT = [&](const std::string &k) { return e->wt.at(k); };

@@ -1691,6 +1691,7 @@ struct mtfjsp_env {
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    double *adv_partial = nullptr;     // mtfjsp_normalize_advantages: per-block partial sums [16][ADV_NB][2]
     size_t ev_used = 0;
 };
 
@@ -1845,7 +1846,10 @@ static int snapshot_impl(mtfjsp_env *h, const mtfjsp_obs_t *dst, const mtfjsp_ob
     add(h->obs.info, dst->info, SNAP2(info), B * 6 * 8);
     add(h->obs.raw, dst->raw, SNAP2(raw), B * 5 * 8);
 #undef SNAP2
-    if (reward_out) { a.info = h->obs.info; a.reward = reward_out; a.B = (int)B; }
+    if (reward_out) {
+        if (!h->obs.info) { h->err = "mtfjsp_snapshot_obs2: reward_out needs the bound observation to hold the step information (obs.info)"; return MTFJSP_ERR_STATE; }
+        a.info = h->obs.info; a.reward = reward_out; a.B = (int)B;
+    }
     if (a.n == 0 && !reward_out) return MTFJSP_OK;
     size_t blocks = (total / 16 + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -2343,6 +2347,130 @@ extern "C" int mtfjsp_gae(mtfjsp_handle_t h, int32_t S, const float *r, int64_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Global advantage normalisation of the rollout -> update hand-off (ppo:485,532: `(adv - adv.mean()) / (adv.std() + 1e-5)` over the
+// whole [S, B_total] tensor, torch's unbiased std) on the gathered buffer G [world][K][n] (n = S * B_local; what one
+// all_gather_into_tensor of the packed [K,S,B_local] advantages leaves on every rank): statistics per tensor k over all shards, this
+// rank's block normalised, value targets = normalised advantage + value at act time (ppo:668-671,689), and — optionally — the
+// reference's single-process layout [K][S][B_total] (rank-major column blocks).  Deterministic: per-block f64 partial sums in a
+// fixed order (no atomics), so two runs over the same numbers give the same bits.
+#define ADV_NB 128
+struct AdvNormArgs {
+    int K, Kt, world, rank, B_local; long n;        // K tensors are normalised, Kt >= K travel in G; n = S * B_local
+    const float *G; float eps;
+    const float *val[16]; long val_ss[16], val_sb[16];   // value at act time of tensor k as an [S,B_local] view (NULL: no target)
+    float *norm, *targets, *full;                   // [K][n], [K][n] or NULL, [Kt][S][world * B_local] or NULL
+    double *partial;                                // [K][ADV_NB][2]
+};
+__global__ __launch_bounds__(256) void k_adv_stats(AdvNormArgs A)
+{
+    __shared__ double s_red[2][256];
+    const int k = blockIdx.y, j = blockIdx.x, tid = threadIdx.x;
+    const long n_all = (long)A.world * A.n;
+    double su = 0.0, sq = 0.0;
+    for (long i = (long)j * 256 + tid; i < n_all; i += (long)ADV_NB * 256) {
+        const long w = i / A.n, r = i - w * A.n;
+        const double x = (double)A.G[((size_t)w * A.Kt + k) * A.n + r];
+        su += x; sq += x * x;
+    }
+    s_red[0][tid] = su; s_red[1][tid] = sq;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { s_red[0][tid] += s_red[0][tid + o]; s_red[1][tid] += s_red[1][tid + o]; }
+        __syncthreads();
+    }
+    if (tid == 0) { A.partial[((size_t)k * ADV_NB + j) * 2] = s_red[0][0]; A.partial[((size_t)k * ADV_NB + j) * 2 + 1] = s_red[1][0]; }
+}
+__global__ __launch_bounds__(256) void k_adv_norm(AdvNormArgs A)
+{
+    __shared__ double s_red[2][ADV_NB];
+    __shared__ float s_ms[2];
+    const int k = blockIdx.y, tid = threadIdx.x;
+    const bool normed = k < A.K;                    // (block-uniform)
+    if (normed) {
+        if (tid < ADV_NB) { s_red[0][tid] = A.partial[((size_t)k * ADV_NB + tid) * 2]; s_red[1][tid] = A.partial[((size_t)k * ADV_NB + tid) * 2 + 1]; }
+        __syncthreads();
+        for (int o = ADV_NB / 2; o > 0; o >>= 1) {
+            if (tid < o) { s_red[0][tid] += s_red[0][tid + o]; s_red[1][tid] += s_red[1][tid + o]; }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double cnt = (double)A.world * (double)A.n;
+            const double mean = s_red[0][0] / cnt;
+            double var = cnt > 1.0 ? (s_red[1][0] - cnt * mean * mean) / (cnt - 1.0) : 0.0;      // unbiased, as torch.std
+            if (var < 0) var = 0;
+            s_ms[0] = (float)mean; s_ms[1] = (float)sqrt(var);
+        }
+        __syncthreads();
+    } else if (!A.full) return;
+    const float mean = normed ? s_ms[0] : 0.f, inv = normed ? 1.0f / (s_ms[1] + A.eps) : 0.f;
+    const long n_all = (long)A.world * A.n;
+    const long Bt = (long)A.world * A.B_local;
+    for (long i = (long)blockIdx.x * 256 + tid; i < n_all; i += (long)gridDim.x * 256) {
+        const long w = i / A.n, r = i - w * A.n;
+        const float x = A.G[((size_t)w * A.Kt + k) * A.n + r];
+        const long sidx = r / A.B_local, b = r - sidx * A.B_local;
+        if (A.full) A.full[(size_t)k * A.n * A.world + sidx * Bt + w * A.B_local + b] = x;
+        if (normed && w == A.rank) {
+            const float a = (x - mean) * inv;
+            A.norm[(size_t)k * A.n + r] = a;
+            if (A.targets && A.val[k]) A.targets[(size_t)k * A.n + r] = a + A.val[k][sidx * A.val_ss[k] + b * A.val_sb[k]];
+        }
+    }
+}
+extern "C" int mtfjsp_normalize_advantages(mtfjsp_handle_t h, int32_t K, int32_t K_total, int32_t world, int32_t rank, int32_t S, const float *gathered, float eps,
+                                           const float *const *values, const int64_t *value_stride_s, const int64_t *value_stride_b,
+                                           float *norm_out, float *targets_out, float *full_out)
+{
+    if (!h || K < 1 || K > 16 || K_total < K || K_total > 16 || world < 1 || rank < 0 || rank >= world || S < 1 || !gathered || !norm_out) return MTFJSP_ERR_ARG;
+    if (targets_out && (!values || !value_stride_s || !value_stride_b)) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    if (!h->adv_partial) {
+        HIPCHK(h, hipMalloc((void **)&h->adv_partial, (size_t)16 * ADV_NB * 2 * sizeof(double)));
+        h->owned.push_back(h->adv_partial);
+    }
+    AdvNormArgs a{};
+    a.K = K; a.Kt = K_total; a.world = world; a.rank = rank; a.B_local = h->cfg.batch; a.n = (long)S * h->cfg.batch; a.G = gathered; a.eps = eps;
+    for (int k = 0; k < K; k++) {
+        a.val[k] = values ? values[k] : nullptr;
+        a.val_ss[k] = value_stride_s ? (long)value_stride_s[k] : 0; a.val_sb[k] = value_stride_b ? (long)value_stride_b[k] : 0;
+    }
+    a.norm = norm_out; a.targets = targets_out; a.full = full_out; a.partial = h->adv_partial;
+    hipLaunchKernelGGL(k_adv_stats, dim3(ADV_NB, K), dim3(256), 0, h->stream, a);
+    const long n_all = (long)world * a.n;
+    int gx = (int)((n_all + 256 * 8 - 1) / (256 * 8));
+    gx = gx < 1 ? 1 : gx > 1024 ? 1024 : gx;
+    hipLaunchKernelGGL(k_adv_norm, dim3(gx, K_total), dim3(256), 0, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+// out[k][s][b] = src_k[s * ss_k + b * sb_k]: K strided [S,B] f32 views into one packed buffer (the value tensors that ride in the
+// hand-off's all-gather beside the advantages), one launch
+struct PackArgs { int K, S, B; const float *src[16]; long ss[16], sb[16]; float *out; };
+__global__ __launch_bounds__(256) void k_pack_views(PackArgs A)
+{
+    const int k = blockIdx.y;
+    const long n = (long)A.S * A.B;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long s = i / A.B, b = i - s * A.B;
+        A.out[(size_t)k * n + i] = A.src[k][s * A.ss[k] + b * A.sb[k]];
+    }
+}
+extern "C" int mtfjsp_pack_views(mtfjsp_handle_t h, int32_t K, int32_t S, const float *const *src, const int64_t *stride_s, const int64_t *stride_b, float *out)
+{
+    if (!h || K < 1 || K > 16 || S < 1 || !src || !stride_s || !stride_b || !out) return MTFJSP_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    PackArgs a{};
+    a.K = K; a.S = S; a.B = h->cfg.batch; a.out = out;
+    for (int k = 0; k < K; k++) { if (!src[k]) return MTFJSP_ERR_ARG; a.src[k] = src[k]; a.ss[k] = (long)stride_s[k]; a.sb[k] = (long)stride_b[k]; }
+    const long n = (long)S * a.B;
+    int gx = (int)((n + 256 * 4 - 1) / (256 * 4));
+    gx = gx < 1 ? 1 : gx > 1024 ? 1024 : gx;
+    hipLaunchKernelGGL(k_pack_views, dim3(gx, K), dim3(256), 0, h->stream, a);
+    HIPCHK(h, hipGetLastError());
+    return MTFJSP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Measurement only ("fraction = achieved / measured copy bandwidth of a same-footprint streaming kernel"): a launch
 // that reads `read_bytes` and writes `write_bytes` with W-byte accesses, perfectly coalesced, nothing else — the denominator the
 // step kernel's achieved bytes/s are compared with at the same batch.  Word i of the read stream is copied to word i of the write
@@ -2370,11 +2498,17 @@ extern "C" int mtfjsp_footprint_copy(mtfjsp_handle_t h, size_t read_bytes, size_
     if (!h || (access_bytes != 4 && access_bytes != 8 && access_bytes != 16) || grid < 1 || reps < 1 || !avg_us_out) return MTFJSP_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const size_t nr = read_bytes / access_bytes, nw = write_bytes / access_bytes;
-    void *src = nullptr, *dst = nullptr; unsigned *sink = nullptr;
-    HIPCHK(h, hipMalloc(&src, nr * access_bytes + 16)); HIPCHK(h, hipMalloc(&dst, nw * access_bytes + 16)); HIPCHK(h, hipMalloc((void **)&sink, 4));
-    HIPCHK(h, hipMemsetAsync(src, 1, nr * access_bytes + 16, h->stream));
-    std::vector<hipEvent_t> ev(2 * (size_t)reps);
-    for (auto &e : ev) HIPCHK(h, hipEventCreate(&e));
+    // every exit path frees what was allocated (bench.py calls this a dozen times per batch size)
+    struct Scratch {
+        void *src = nullptr, *dst = nullptr; unsigned *sink = nullptr; std::vector<hipEvent_t> ev;
+        ~Scratch() { for (auto &e : ev) if (e) (void)hipEventDestroy(e); (void)hipFree(src); (void)hipFree(dst); (void)hipFree(sink); }
+    } S;
+    HIPCHK(h, hipMalloc(&S.src, nr * access_bytes + 16)); HIPCHK(h, hipMalloc(&S.dst, nw * access_bytes + 16)); HIPCHK(h, hipMalloc((void **)&S.sink, 4));
+    HIPCHK(h, hipMemsetAsync(S.src, 1, nr * access_bytes + 16, h->stream));
+    S.ev.assign(2 * (size_t)reps, nullptr);
+    for (auto &e : S.ev) HIPCHK(h, hipEventCreate(&e));
+    void *src = S.src, *dst = S.dst; unsigned *sink = S.sink;
+    std::vector<hipEvent_t> &ev = S.ev;
     auto launch = [&]() {
         if (access_bytes == 16) hipLaunchKernelGGL(k_footprint_copy<fp_u4>, dim3(grid), dim3(256), 0, h->stream, (const fp_u4 *)src, (fp_u4 *)dst, nr, nw, sink);
         else if (access_bytes == 8) hipLaunchKernelGGL(k_footprint_copy<fp_u2>, dim3(grid), dim3(256), 0, h->stream, (const fp_u2 *)src, (fp_u2 *)dst, nr, nw, sink);
@@ -2393,11 +2527,9 @@ extern "C" int mtfjsp_footprint_copy(mtfjsp_handle_t h, size_t read_bytes, size_
         HIPCHK(h, hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
         tot += ms; mn = ms < mn ? ms : mn;
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    (void)hipFree(src); (void)hipFree(dst); (void)hipFree(sink);
+    HIPCHK(h, hipGetLastError());
     *avg_us_out = tot / reps * 1e3;
     if (min_us_out) *min_us_out = mn * 1e3;
-    HIPCHK(h, hipGetLastError());
     return MTFJSP_OK;
 }
 

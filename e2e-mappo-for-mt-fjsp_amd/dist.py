@@ -5,30 +5,42 @@ advantage normalisation `(adv - mean) / (std + 1e-5)` of ppo:485,532 (RCCL over 
 gloo in the CPU tests).  GAE itself (ppo:438-536) is a reverse scan over the S stored steps and is per-instance,
 so it runs on each shard locally.
 """
-import os
+import warnings
 
 import torch
 import torch.distributed as dist
 
+# Test switch (tests/test_rollout_handoff.py): treat an initialised ONE-rank group as a collective to run, so that the RCCL branches
+# execute on a single GPU (a world-size-1 all-gather is a copy, but it goes through the same calls).  A module attribute the tests set
+# explicitly — never read from the environment, so nothing that leaks into a production run changes single-rank behaviour.
+COLLECT_ON_ONE_RANK = False
+_warned_fallback = False
+
 
 def active(group=None):
-    """is there a collective to run?  A process group with more than one rank — or, for the tests that drive the RCCL branches on
-    a single GPU, any initialised group when MTFJSP_DIST_ALWAYS_COLLECT is set (a world-size-1 all-gather is a copy, but it goes
-    through the same calls)."""
+    """is there a collective to run?  A process group with more than one rank (or the test switch above)."""
     if not (dist.is_available() and dist.is_initialized()):
         return False
-    return dist.get_world_size(group) > 1 or bool(os.environ.get("MTFJSP_DIST_ALWAYS_COLLECT"))
+    return dist.get_world_size(group) > 1 or COLLECT_ON_ONE_RANK
 
 
 def device_collectives(group=None):
     """can `group` run collectives on device tensors (RCCL: backend "nccl", also as the cuda half of "cpu:gloo,cuda:nccl" or of a
     group created without a backend name)?  Decided by capability, not by the configured name; gloo-only groups go through host
-    copies."""
+    copies.  A query that raises is reported once (the host-copy path is correct but slow: it must not be taken silently)."""
+    global _warned_fallback
     try:
-        return "nccl" in str(dist.get_backend(group)).lower() or \
-            "nccl" in str((group or dist.group.WORLD)._get_backend(torch.device("cuda")).name()).lower()
-    except Exception:
+        if "nccl" in str(dist.get_backend(group)).lower():
+            return True
+    except Exception as ex:
+        if not _warned_fallback:
+            _warned_fallback = True
+            warnings.warn(f"mtfjsp dist: backend query failed ({ex!r}); collectives go through host copies")
         return False
+    try:
+        return "nccl" in str((group or dist.group.WORLD)._get_backend(torch.device("cuda")).name()).lower()
+    except Exception:
+        return False                                      # (a group without a cuda backend: gloo-only — the expected answer, not an error)
 
 
 def agree_any(flag, group=None):
@@ -113,6 +125,34 @@ def all_gather_advantages(tensors, group=None, timed=False):
     full = torch.cat(list(out.unbind(0)), dim=2)          # [K,S,B_total]
     res = list(full.unbind(0))
     return (res, info) if timed else res
+
+
+def all_gather_packed(packed, group=None, timed=False):
+    """ONE collective for a packed [K,S,B_local] device buffer -> ([world,K,S,B_local] on every rank, info); with no process group
+    active the packed buffer itself comes back as [1,K,S,B_local] (no copy).  info = {"world", "rank", "bytes_per_rank", "ms"};
+    ms (timed=True) from device events around the collective."""
+    info = {"world": 1, "rank": 0, "bytes_per_rank": packed.numel() * packed.element_size(), "ms": None}
+    assert packed.is_contiguous()
+    if not active(group):
+        return packed.unsqueeze(0), info
+    world = dist.get_world_size(group)
+    info["world"], info["rank"] = world, dist.get_rank(group)
+    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    ev = None
+    if timed and packed.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    if packed.is_cuda and not device_collectives(group):          # CPU-only group (gloo in the two-process tests): through host copies
+        oc = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(oc.view(-1), packed.cpu().view(-1), group=group)
+        out.copy_(oc)
+    else:
+        dist.all_gather_into_tensor(out.view(-1), packed.view(-1), group=group)
+    if ev is not None:
+        ev[1].record()
+        ev[1].synchronize()
+        info["ms"] = ev[0].elapsed_time(ev[1])
+    return out, info
 
 
 def normalize_advantages_global(adv_local, group=None, eps=1e-5):

@@ -124,6 +124,7 @@ class Rollout:
             if exact_bn and world > 1:
                 from . import dist as _dist
                 self.actor.enc.set_stats_reduce(_dist.bn_stats_allreduce(), world * batch)
+                self.actor.enc.set_deferred_poll(True)     # failures are acted upon once per step, by all ranks together (step())
                 self.exact_bn = True
 
     def describe(self):
@@ -165,7 +166,15 @@ class Rollout:
         Single process: the buffer restarts at once.  With a process group (`_lockstep`): the hand-off at the end of a buffer is
         a collective, so every rank must reach it after the same number of step() calls — the failing rank keeps its position in
         the buffer, marks the buffer as tainted, restarts its episode and runs the rest of the buffer without recording; at the
-        buffer boundary the ranks agree (one MAX all-reduce of a flag, finish_buffer) and ALL of them drop the buffer."""
+        buffer boundary the ranks agree (one MAX all-reduce of a flag, finish_buffer) and ALL of them drop the buffer.
+        With exact_bn the forwards themselves contain collectives (the BatchNorm all-reduces), so the ranks must issue the SAME
+        forwards at every step: the forward entries do not poll for failures at all (Encoder.set_deferred_poll); once per step,
+        after draining the device, every rank checks its failure words and the ranks agree — if any failed, ALL restart their
+        episode and taint the buffer together, and their forward sequences stay identical."""
+        if self.exact_bn and self._lockstep:
+            self._agree_on_failure_and_restart_together()
+            self._step(force)
+            return
         try:
             self._step(force)
         except capi.MtfjspError as ex:
@@ -173,6 +182,27 @@ class Rollout:
                 raise
             self._restart_after_failure()
             self._step(force)
+
+    def _failed_since_last_check(self):
+        """synchronise and read the encoder's asynchronous failure words -> True when a forward enqueued since the last check is
+        invalid (capi.ERR_RETRY; the handle has switched kernels); any other error propagates"""
+        try:
+            self.actor.enc.check()
+        except capi.MtfjspError as ex:
+            if ex.code != capi.ERR_RETRY:
+                raise
+            return True
+        return False
+
+    def _agree_on_failure_and_restart_together(self):
+        from . import dist as _dist
+        torch.cuda.synchronize()
+        failed = self._failed_since_last_check()
+        if _dist.agree_any(failed):
+            self.n_resident_failures += int(failed)
+            self.t_in_ep = 0                               # every rank: fresh episode, rest of the buffer unrecorded, dropped at its boundary
+            self.tainted = True
+            self.actor.begin_episode()
 
     @property
     def _lockstep(self):
@@ -203,11 +233,6 @@ class Rollout:
             if self.full:
                 self.traj.begin_episode(w3)
         last = self.t_in_ep == self.T - 1
-        if self.exact_bn:
-            # the BatchNorm all-reduces make the ranks' forwards collective: every rank must notice an asynchronous failure flag
-            # at the SAME step, so the device is drained before the forward entry polls it (this mode synchronises after each of
-            # its seven all-reduces anyway)
-            torch.cuda.synchronize()
         if self.tainted:
             # rest of a buffer that will be dropped (see step()): decisions and env steps without recording
             self.actor.act(env, self.nsteps, self.task, self.mach, self.job, force=force, env_step=()) or env.step(self.task, self.mach)
@@ -276,19 +301,10 @@ class Rollout:
         mv4 = mv4_ = None
         whole = self.full and self.actor.has_critic and self.global_handoff
         if self._lockstep:
-            failed = self.tainted
-            try:
-                self.actor.enc.check()
-                if whole and not failed:
-                    mv4, mv4_ = A.sample_global_values(self.actor.enc, self.traj)
-                    self.actor.enc.check()                  # (the 2 S critic forwards may have failed asynchronously as well)
-            except capi.MtfjspError as ex:
-                if ex.code != capi.ERR_RETRY:
-                    raise
-                if not failed:
-                    self.n_resident_failures += 1
-                failed = True
-            if _dist.agree_any(failed):
+            # The ranks agree BEFORE any rank-conditional work that may contain collectives: the global critic's 2 S forwards of the
+            # whole hand-off run either on every rank or on none (with exact_bn each of them all-reduces its BatchNorm sums), and
+            # the ranks agree once more on what those forwards reported before anybody enters the all-gather.
+            def drop(failed):
                 self.n_dropped_buffers += 1
                 self.buf_pos = 0
                 if self.full:
@@ -296,7 +312,22 @@ class Rollout:
                 if failed:                                  # this rank's episode is not aligned with the buffer any more (or invalid)
                     self._new_episode = True
                 self.tainted = False
-                return
+            failed = self._failed_since_last_check()
+            self.n_resident_failures += int(failed and not self.tainted)
+            failed = failed or self.tainted
+            if _dist.agree_any(failed):
+                return drop(failed)
+            if whole:
+                try:
+                    mv4, mv4_ = A.sample_global_values(self.actor.enc, self.traj)
+                    failed = self._failed_since_last_check()
+                except capi.MtfjspError as ex:               # (a forward entry of the sampling polled the failure itself: no exact_bn, no collectives inside)
+                    if ex.code != capi.ERR_RETRY:
+                        raise
+                    failed = True
+                self.n_resident_failures += int(failed)
+                if _dist.agree_any(failed):
+                    return drop(failed)
         else:
             self.actor.enc.check()
         # v of step t = slot t, v_ of step t = slot t+1 of its episode; the terminal step's v_ is the post-terminal forward

@@ -41,7 +41,7 @@ typedef enum {
     MTFJSP_ERR_STATE = -2,    /* call order (e.g. step before load_instances/reset) */
     MTFJSP_ERR_HIP = -3,      /* HIP runtime error (no device, launch failure, OOM) */
     MTFJSP_ERR_ACTION = -4,   /* *_host step: at least one action was invalid */
-    MTFJSP_ERR_RETRY = -5     /* encoder: an earlier forward on the single-launch GIN kernel failed asynchronously (grid-barrier time-out);
+    MTFJSP_ERR_RETRY = -5     /* encoder: an earlier forward on the single-launch GIN kernel failed asynchronously (time-out of a grid-wide statistics exchange);
                                * everything enqueued on the handle since then is invalid, the handle has switched to the streaming
                                * launches — repeat the work (see mtfjsp_encoder_check) */
 } mtfjsp_status;
@@ -205,6 +205,20 @@ int mtfjsp_copy_to_host(mtfjsp_handle_t h, void *dst_host, const void *src_dev, 
  * done and adv are [S,B] contiguous.  The result is NOT normalised (that needs the all-gather across GPUs). */
 int mtfjsp_gae(mtfjsp_handle_t h, int32_t S, const float *r, int64_t r_ss, int64_t r_sb, const float *v, int64_t v_ss, int64_t v_sb,
                const float *v_next, int64_t n_ss, int64_t n_sb, const float *done, float gamma, float lambda, float *adv);
+/* Global advantage normalisation of the hand-off (ppo:485,532): `(adv - adv.mean()) / (adv.std() + 1e-5)` with torch's unbiased
+ * std, per tensor over ALL shards' columns.  gathered = [world][K_total][S][B] f32 — what ONE all-gather of the packed
+ * [K_total,S,B] buffer leaves on every rank (world = 1: the packed buffer itself); the first K <= K_total <= 16 tensors are
+ * advantages to normalise, the others (the value tensors of the whole hand-off, ppo:628-703) only ride along.  norm_out [K][S][B]
+ * receives this rank's normalised advantages; targets_out (may be NULL) [K][S][B] = normalised advantage + value at act time
+ * (ppo:668-671,689) with values[k] an f32 [S,B] view given by element strides (NULL entries are skipped); full_out (may be NULL)
+ * [K_total][S][world*B] receives every gathered tensor in the reference's single-process layout (rank-major column blocks).
+ * Two launches on the handle's stream; f64 statistics from per-block partial sums in a fixed order: bit-reproducible. */
+int mtfjsp_normalize_advantages(mtfjsp_handle_t h, int32_t K, int32_t K_total, int32_t world, int32_t rank, int32_t S, const float *gathered, float eps,
+                                const float *const *values, const int64_t *value_stride_s, const int64_t *value_stride_b,
+                                float *norm_out, float *targets_out, float *full_out);
+/* K strided f32 [S,B] views -> one packed [K][S][B] buffer in one launch (the value tensors that ride in the hand-off's all-gather
+ * beside the advantages; the reference stacks them with torch.cat, ppo:657-703) */
+int mtfjsp_pack_views(mtfjsp_handle_t h, int32_t K, int32_t S, const float *const *src, const int64_t *stride_s, const int64_t *stride_b, float *out);
 
 /* kernel timing hook for bench.py: HIP events recorded on the handle's stream around every step launch
  * between begin/end; returns accumulated milliseconds and launch count. */
@@ -239,7 +253,10 @@ int mtfjsp_encoder_weights_ready(mtfjsp_encoder_t e);     /* 0 when every requir
 /* = Operation_Actor_JointAction_selfCritic.forward (ac:104-296) without the sampling:
  * GIN encoder (gcn:109-197, training-mode BatchNorm over all B*T rows), candidate scorer, masked softmax,
  * local critic.  h_m_prev may be NULL (first step: learned `_input`, ac:229-233).
- * Outputs (f32): prob [B,J], h_pooled [B,H], job_v [B,2]; h_nodes [B*T,H] optional (NULL = keep internal). */
+ * Outputs (f32): prob [B,J], h_pooled [B,H], job_v [B,2]; h_nodes [B*T,H] optional (NULL = keep internal).
+ * candidate [B,J]: any task row in [0, T) per job (ac:197-207 gathers by index).  The environment's candidates lie in their job's
+ * own block of rows, candidate[b][j] in [j M, (j+1) M) (ppo:306-309), which the streaming pool/gather kernel of the large shapes
+ * exploits (it picks them out of the row stream); a candidate outside its block takes a dependent gather there — same result. */
 int mtfjsp_job_actor_forward(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col,
                              const float *ell_val, const int32_t *candidate, const uint8_t *job_mask,
                              const float *h_m_prev, float *prob, float *h_pooled, float *job_v, float *h_nodes);
@@ -289,6 +306,13 @@ int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance);
  * statistics (the default) are what DESIGN.md §7 describes: each GPU behaves like a reference run with env_batch = its shard. */
 typedef int (*mtfjsp_stats_reduce_fn)(void *user, double *sums, int32_t count);
 int mtfjsp_encoder_set_stats_reduce(mtfjsp_encoder_t e, mtfjsp_stats_reduce_fn fn, void *user, int64_t global_batch);
+/* deferred = 1: the forward entries stop polling the asynchronous failure words (see mtfjsp_encoder_check); a failure then
+ * surfaces only at mtfjsp_encoder_check.  For callers whose forwards contain collectives (the reduction callback above): every
+ * shard must issue the same sequence of forwards, so a shard-local MTFJSP_ERR_RETRY may only be acted upon at a point all shards
+ * agree on — rollout.py checks once per step and lets the shards agree through one MAX all-reduce (the reference has no
+ * counterpart: its update samples the critics in one process, ppo:422-435).  Default 0.
+ * Diagnostic: MTFJSP_RANGE_FAIL_AT=n raises the range word at the n-th job-actor forward of a handle (tests). */
+int mtfjsp_encoder_set_deferred_poll(mtfjsp_encoder_t e, int32_t deferred);
 /* How the [rows,128]x[128,128] products of the actor forwards (Linear layers of gcn:95-153 / ac:205-293, the GAT weight of
  * gat:82) are formed.  0 (default): on the 16-bit matrix cores with f32 accumulation, from f32 operands split into two f16
  * pieces (relative representation error <= 2^-22; weights pre-scaled by a power of two) and the three significant piece
@@ -296,7 +320,7 @@ int mtfjsp_encoder_set_stats_reduce(mtfjsp_encoder_t e, mtfjsp_stats_reduce_fn f
  * the bounds); the 12 -> 128 first Linear, whose inputs are raw features, uses an exact three-piece bf16 split instead.
  * Bits select the f32 matrix instruction instead, as the A/B reference: 1 = GIN products, 2 = GAT passes, 4 = actor/critic
  * heads, 8 = first GIN Linear (12 -> 128) on the vector ALU.  Bit 16 is not a numerics choice: it runs the GIN encoder as six
- * streaming launches (k_gemm_x6) even where the single-launch register-resident kernel (k_gin_res; in-kernel grid barriers for
+ * streaming launches (k_gemm_x6) even where the single-launch register-resident kernel (k_gin_res; in-kernel grid-wide statistics exchanges for
  * the batch statistics) is eligible (16 <= T <= 65, <= 576 node rows per CU, census launch passed in mtfjsp_encoder_create);
  * MTFJSP_NO_RESIDENT_GIN=1 in the environment does the same for every handle. */
 int mtfjsp_encoder_set_product_mode(mtfjsp_encoder_t e, int32_t f32_instruction_mask);
@@ -326,7 +350,8 @@ int mtfjsp_hostgen_infeasible(uint32_t *key, int32_t *pos, int64_t samples, int3
 int mtfjsp_hostgen_transport(uint32_t *key, int32_t *pos, int64_t samples, int32_t M, const int64_t *shop_of_machine,
                              double in_lo, double in_hi, double out_hi, int64_t first, int64_t count, double *tt);
 /* Synchronises the encoder's stream and reports asynchronous failures of the forwards enqueued so far.  The single-launch GIN
- * kernel synchronises its workgroups with in-kernel grid barriers whose spins are bounded (4 ms); it needs all of its workgroups
+ * kernel exchanges its BatchNorm statistics between its workgroups inside the launch (count-carrying integer atomics; the waits
+ * for the other workgroups' contributions are bounded at 4 ms); it needs all of its workgroups
  * resident at once (one per CU), which another process or another stream using the same GPU can prevent — not a hang but a
  * time-out.  The kernel then sets a host-mapped word that EVERY job-actor / global-critic forward polls on entry (a plain host
  * read, no synchronisation) and that this call reads after synchronising: the first call to see it returns MTFJSP_ERR_RETRY,
@@ -350,7 +375,7 @@ int mtfjsp_encoder_range_fallbacks(mtfjsp_encoder_t e, int64_t *count_out, int32
 /* diagnostic (tools/first_launch): the first `count` floats of the machine path's node buffer [B*M,128] — the output of the three
  * GAT passes of ac:409-420 before the BatchNorm of ac:434 — copied to host memory after synchronising the stream */
 int mtfjsp_encoder_peek_nodes_host(mtfjsp_encoder_t e, float *out_host, int64_t count);
-/* number of grid-barrier time-outs reported on this handle so far */
+/* number of statistics-exchange time-outs of the single-launch kernels reported on this handle so far */
 int mtfjsp_encoder_resident_failures(mtfjsp_encoder_t e, int64_t *count_out);
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
 int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);

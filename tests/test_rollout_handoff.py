@@ -367,11 +367,15 @@ def test_grid_barrier_timeout_is_reported_and_the_rollout_recovers(monkeypatch):
 
 def _lockstep_worker(rank, world, port, q, mode):
     """two ranks on cuda:0 over gloo; rank 0's single-launch GIN kernel is told to time out at its 7th launch (rank 1 runs the
-    streaming launches: two resident grids cannot share one GPU)"""
+    streaming launches: two resident grids cannot share one GPU).  mode "exact_bn_full": both ranks all-reduce every BatchNorm's
+    sums (streaming launches on both), the whole hand-off with the global critic, and rank 0's 7th job-actor forward raises the
+    RANGE word — the one failure a rank can see alone in that mode (a NaN in the BatchNorm sums reaches every rank through the
+    all-reduce; a NaN in a scorer output does not)."""
     import torch.distributed as td
+    exact = mode == "exact_bn_full"
     if rank == 0:
-        os.environ["MTFJSP_GIN_RES_FAIL_AT"] = "7"
-    else:
+        os.environ["MTFJSP_RANGE_FAIL_AT" if exact else "MTFJSP_GIN_RES_FAIL_AT"] = "7"
+    elif not exact:
         os.environ["MTFJSP_NO_RESIDENT_GIN"] = "1"
     _mods()
     rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
@@ -380,12 +384,16 @@ def _lockstep_worker(rank, world, port, q, mode):
     td.init_process_group("gloo", rank=rank, world_size=world)
     try:
         kw = dict(collect=True) if mode == "advantage" else dict(collect="full", weights=enc_mod.random_init_weights(7, with_critic=True))
-        ro = rollout.Rollout(6, 6, 2, 256, policy="actor", obs_dtype="f32", buffer_episodes=1, rank=rank, world=world, time_handoff=True, **kw)
+        ro = rollout.Rollout(6, 6, 2, 64 if exact else 256, policy="actor", obs_dtype="f32", buffer_episodes=1, rank=rank, world=world,
+                             time_handoff=True, exact_bn=exact, **kw)
+        assert ro.exact_bn == exact
         for _ in range(4 * ro.S):                                # four buffers' worth of step() calls on every rank
             ro.step()
         torch.cuda.synchronize()
         ro.check_finished_cleanly()
         ok = bool(torch.isfinite(ro.last_adv[0][0]).all()) and ro.last_gather["world"] == 2
+        if exact:                                                # the failing rank left the split products, the other one did not
+            ok = ok and (ro.actor.enc.range_fallbacks()[0] == (1 if rank == 0 else 0))
         q.put((rank, ro.n_handoffs, ro.n_dropped_buffers, ro.n_resident_failures, ro.buf_pos, ro.t_in_ep, ok))
         td.barrier()
     finally:
@@ -393,11 +401,14 @@ def _lockstep_worker(rank, world, port, q, mode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["advantage", "full"])
+@pytest.mark.parametrize("mode", ["advantage", "full", "exact_bn_full"])
 def test_a_failure_on_one_rank_drops_the_buffer_on_every_rank(mode):
     """the hand-off is a collective, so a rank that restarts after MTFJSP_ERR_RETRY must not fall out of step
     with the others.  Rank 0 reports a grid-barrier time-out in its first buffer: BOTH ranks drop that buffer at its boundary
-    (agreed through one MAX all-reduce), both run the same number of all-gathers afterwards, nobody hangs."""
+    (agreed through one MAX all-reduce), both run the same number of all-gathers afterwards, nobody hangs.
+    ADVICE r4 (medium), mode "exact_bn_full": with all-reduced BatchNorm statistics every forward is a collective, so the ranks
+    agree on a failure once per step and restart TOGETHER; the global critic's 2 S forwards of the hand-off run on every rank or on
+    none.  A mismatch shows as a hang (the 600 s time-out below) or as mixed statistics (non-finite advantages)."""
     import torch.multiprocessing as tmp_mp
     ctx = tmp_mp.get_context("spawn")
     q = ctx.Queue()
@@ -418,8 +429,8 @@ def test_a_failure_on_one_rank_drops_the_buffer_on_every_rank(mode):
 def _nccl_world1_worker(port, q):
     """a world-size-1 RCCL group on cuda:0: every collective of the data path goes through its device-tensor branch"""
     import torch.distributed as td
-    os.environ["MTFJSP_DIST_ALWAYS_COLLECT"] = "1"
     D = _mods()
+    D.COLLECT_ON_ONE_RANK = True
     rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
     enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -468,8 +479,7 @@ def _nccl_world1_worker(port, q):
 
 def _nccl_exact_bn_worker(port, q):
     import torch.distributed as td
-    os.environ["MTFJSP_DIST_ALWAYS_COLLECT"] = "1"
-    _mods()
+    _mods().COLLECT_ON_ONE_RANK = True
     rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""The step kernel and SURVEY 8(d)'s same-footprint copy kernel in ONE process, for `rocprofv3 --kernel-trace`:
+kernel-only durations of both (no HIP events, no host pairing) at one batch size.  tools/footprint_kernel_only.sh runs it
+under the profiler at 4 096 ... 262 144 instances and reduces the per-dispatch trace to profiles/r05_footprint_kernel_only.json.
+
+  python3 tools/footprint_kernel_only.py --batch 4096          (under rocprofv3: program directly after `--`)
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mtfjsp_amd  # noqa
+from importlib import import_module
+
+be = import_module("e2e-mappo-for-mt-fjsp_amd.batch_env")
+
+GRIDS = (256, 512, 1024, 2048, 4096, 8192)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--size", default="6x6x2")
+    ap.add_argument("--episodes", type=int, default=3)
+    a = ap.parse_args()
+    J, M, E = [int(x) for x in a.size.split("x")]
+    T, B = J * M, a.batch
+    env = be.DeviceBatchEnv(J, M, E, B, obs_dtype="f32")
+    env.generate_instances(seed=123)
+    env.scaler_init()
+    w3 = torch.full((B, 3), 1.0 / 3, dtype=torch.float64, device=env.device)
+    act, mch = torch.zeros(B, dtype=torch.int32, device=env.device), torch.zeros(B, dtype=torch.int32, device=env.device)
+    r, w = 64 * T + 100 * M + 176, 72 * T + 56 * M + 307          # read / written bytes per env-step (bench.env_bytes_rw)
+    # interleaved rounds (cdna_hip_programming.md rule 24): an episode of steps, then the copy at every grid, repeated
+    for ep in range(a.episodes):
+        env.reset(w3)
+        for s in range(T):
+            env.random_actions(7, ep * T + s, act, mch)
+            env.step(act, mch)
+        for acc in (16, 8):
+            for grid in GRIDS:
+                env.footprint_copy(B * r, B * w, access_bytes=acc, grid=grid, reps=20)
+    torch.cuda.synchronize()
+    assert bool(env.info[:, 1].all()) and int((env.status & 0x100).sum()) == 0
+    print(f"done B={B} read={B * r} written={B * w}")
+
+
+if __name__ == "__main__":
+    main()
