@@ -562,7 +562,7 @@ def main():
             out["handoff_full"] = full_handoff
         # the two latency chains beside the dominant kernel (round-3 review: "no roofline at all"): matrix time and LDS traffic bound
         heads = {}
-        for fam in ("heads", "heads_gat3", "gat3"):
+        for fam in ("heads", "heads_gat3", "heads_gat3_heads", "gat3"):
             if fam in ktimes and ktimes[fam]["launches"]:
                 try:
                     heads[fam] = ro.roofline(fam, ktimes[fam])

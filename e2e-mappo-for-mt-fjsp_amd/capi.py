@@ -96,6 +96,8 @@ PROTOTYPES = {
     "mtfjsp_encoder_set_deferred_poll": (_I, [_VP, C.c_int32]),
     "mtfjsp_get_mfea1_context": (_I, [_VP, _VP, _VP, C.POINTER(Mfea1Ctx)]),
     "mtfjsp_encoder_arm_mfea1": (_I, [_VP, C.POINTER(Mfea1Ctx)]),
+    "mtfjsp_encoder_arm_machine_heads": (_I, [_VP, _VP, _VP, _VP]),
+    "mtfjsp_encoder_fused_launches": (_I, [_VP, C.POINTER(C.c_int64)]),
     "mtfjsp_encoder_arm_env_step": (_I, [_VP, _VP, C.c_int32]),
     "mtfjsp_encoder_env_step_fused": (_I, [_VP]),
     "mtfjsp_encoder_arm_selection": (_I, [_VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),

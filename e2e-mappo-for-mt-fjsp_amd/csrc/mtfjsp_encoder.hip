@@ -1204,6 +1204,18 @@ __device__ __forceinline__ int gx_off(int row, int col) { return row * HD + ((((
 #ifndef MTFJSP_BODY_FUNCS
 #define MTFJSP_BODY_FUNCS 0   // diagnostic builds: bit 0 = the GAT statements, bit 1 = the heads statements as __forceinline__ functions
 #endif
+// Grid-wide exchange of the machine nodes' BatchNorm sums INSIDE a launch (k_headsx_gat3x_headsx below): the body files take these
+// switches from the kernel that includes them — GAT_XCHG: the GAT statements publish their column sums as count-carrying fixed-point
+// words instead of f64 atomics; HX_XCHG: the heads statements collect them from those words instead of reading finished sums.
+#define GAT_XCHG 0
+#define HX_XCHG 0
+struct XchgArgs {
+    unsigned long long *words;       // this forward's words (zero on entry): [fine | wide][8 dispatch groups][sum | sumsq][128 columns]
+    unsigned long long *words_next;  // the next forward's set: zeroed by this launch
+    unsigned nblk;                   // workgroups of the launch (all co-resident: the host checked the grid against the census)
+    unsigned *fail, *range_flag;     // host-mapped words: a wait timed out / a contribution was not a number
+};
+#define XW_SET (2 * 8 * 256)
 #if MTFJSP_BODY_FUNCS & 1
 __device__ __forceinline__ void gat3x_body(const GatArgs &A, unsigned char *smem)
 {
@@ -1648,6 +1660,43 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
     }
 #endif
 }
+// Round 5: the machine actor's heads in the SAME launch as well — three launches per rollout step instead of four.  What separates
+// the GAT passes from the machine heads is one BatchNorm over all B*M machine nodes (ac:434): a grid-wide dependency, but a small one
+// (256 column sums).  It is exchanged the way k_gin_res exchanges its statistics (count-carrying integer atomics, no barrier, ~3 us)
+// with everything the machine heads request on their own — weights, vectors, their node rows (written by this very workgroup), the
+// job actor's pooled embedding — in flight before the wait; the launch boundary, its cold first phase (3.9 us of requests with
+// nothing to overlap) and a second dispatch ramp go.  Needs the whole grid co-resident (one workgroup per CU: the host enables it
+// only where the single-launch GIN kernel's census passed) and bounds its wait like that kernel (time-out -> MTFJSP_ERR_RETRY).
+#if !MTFJSP_BODY_FUNCS
+__global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArgs GA, HeadArgs HM, XchgArgs XG)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    const XchgArgs &XA = XG;
+    for (int i = blockIdx.x * 512 + threadIdx.x; i < XW_SET; i += (int)gridDim.x * 512) XA.words_next[i] = 0ull;
+    {
+        const HeadArgs &A = HA;
+#include "mtfjsp_headsx_body.h"
+    }
+    __syncthreads();                                               // m_fea1 / the machine mask of this workgroup's instances are written
+    {
+        const GatArgs &A = GA;
+#undef GAT_XCHG
+#define GAT_XCHG 1
+#include "mtfjsp_gat3x_body.h"
+#undef GAT_XCHG
+#define GAT_XCHG 0
+    }
+    LDS_BARRIER();                                                 // (not __syncthreads(): that would wait for the statistics' atomics to be acknowledged)
+    {
+        const HeadArgs &A = HM;
+#undef HX_XCHG
+#define HX_XCHG 1
+#include "mtfjsp_headsx_body.h"
+#undef HX_XCHG
+#define HX_XCHG 0
+    }
+}
+#endif
 // The machine actor's heads and the environment step of the same 16 instances in ONE launch (round-2 review, item 3): the heads end
 // with the machine selection of exactly the instances k_env_grp16 would give this blockIdx, and nothing else the step reads is written
 // by this launch.  __syncthreads() orders the selected indices' stores before the step's loads (same workgroup, same CU); the step's
@@ -2270,8 +2319,16 @@ struct mtfjsp_encoder {
     float *res_zspill = nullptr;            // [grid][4][2][1024] f32: the two row tiles per workgroup that do not fit the registers
     unsigned long long res_epoch = 0;
     int gat_slot = 0;                       // the machine-path slot of the NEXT forward; the other one is zeroed by that forward's heads kernel
-    struct { bool valid = false; const void *f1 = nullptr, *f2 = nullptr; int slot = 0; } prefused;   // the GAT passes of the coming machine forward already ran inside the job actor's heads launch (k_headsx_gat3x)
+    struct { bool valid = false; const void *f1 = nullptr, *f2 = nullptr; int slot = 0;
+             bool heads = false; const float *h_pooled_o = nullptr; const uint8_t *mmask = nullptr; float *prob = nullptr, *h_pooled = nullptr, *machine_v = nullptr;
+           } prefused;   // the GAT passes of the coming machine forward already ran inside the job actor's heads launch (k_headsx_gat3x); heads: the WHOLE machine forward did (k_headsx_gat3x_headsx)
     bool fuse_gat = !getenv("MTFJSP_NO_FUSED_GAT");
+    bool fuse_mheads = !getenv("MTFJSP_NO_FUSED_MHEADS");       // the machine heads in the job heads + GAT launch behind an in-launch exchange of the node statistics (three launches per rollout step)
+    struct { bool armed = false; float *prob = nullptr, *h_pooled = nullptr, *machine_v = nullptr; } mh;   // mtfjsp_encoder_arm_machine_heads
+    unsigned long long *xw = nullptr;       // [2 sets][XW_SET] count-carrying words of that exchange; forward n uses set n & 1 and zeroes the other
+    unsigned long long xw_epoch = 0;
+    long long fused3_launches = 0;
+    long long fused3_fail_at = getenv("MTFJSP_FUSED3_FAIL_AT") ? atoll(getenv("MTFJSP_FUSED3_FAIL_AT")) : 0;   // diagnostic: this three-in-one launch waits for a workgroup that does not exist
     bool heads_hg8 = !getenv("MTFJSP_NO_HEADS_HG8");
     bool heads10 = !getenv("MTFJSP_NO_HEADS10");              // k_headsx10 (ten tiles per chunk) for groups of 7..10 tiles
     // the environment step as the tail of the machine heads' launch (mtfjsp_encoder_arm_env_step).  OFF unless MTFJSP_FUSED_ENV is set:
@@ -2382,10 +2439,12 @@ static int res_poll_failure(mtfjsp_encoder *e)
         e->res_ok = false; e->res_failures++;
         e->res_fail_host[0] = 0u; e->res_fail_host[1] = 0u;
         (void)hipMemset(e->res_bar, 0, (size_t)17 * 16 * 8); e->res_epoch = 0;
-        (void)hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8);
+        if (e->res_stats) (void)hipMemset(e->res_stats, 0, (size_t)2 * GR_STATS_SET * 8);
+        if (e->xw) (void)hipMemset(e->xw, 0, (size_t)2 * XW_SET * 8);
+        e->xw_epoch = 0; e->prefused.valid = false; e->prefused.heads = false;
         e->gin_stats_clean = false; e->gat_stats_clean[0] = e->gat_stats_clean[1] = false;   // (the heads launches behind it may have summed NaNs)
-        e->err = "single-launch GIN kernel: the grid-wide statistics timed out (its workgroups were not co-resident); every output enqueued since that "
-                 "launch is invalid and must be recomputed; the handle now uses the streaming launches";
+        e->err = "single-launch GIN kernel / fused heads launch: a grid-wide statistics exchange timed out (the workgroups were not co-resident); every output "
+                 "enqueued since that launch is invalid and must be recomputed; the handle now uses the streaming launches";
         return MTFJSP_ERR_RETRY;
     }
     if (e->res_fail_host[1]) {
@@ -2441,6 +2500,8 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     rc |= dalloc_rows(&e->node, B * M);
     rc |= dalloc(e, &e->stats, 8 * STAT_REP * 256);
     rc |= res_alloc_fail_word(e);
+    rc |= dalloc(e, &e->xw, (size_t)2 * XW_SET);
+    if (!rc && hipMemset(e->xw, 0, (size_t)2 * XW_SET * 8) != hipSuccess) rc = 1;
     if (!rc && hipMemset(e->stats, 0, 8 * STAT_REP * 256 * sizeof(double)) == hipSuccess) { e->gin_stats_clean = true; e->gat_stats_clean[0] = e->gat_stats_clean[1] = true; }
     if (rc) { g_enc_err = e->err; mtfjsp_encoder_destroy(e); return MTFJSP_ERR_HIP; }
     const int lds16 = (int)gemm16_lds_bytes();
@@ -2464,6 +2525,12 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_headsx_envstep<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(headsx_lds_bytes() > EnvGrpDynLds<1>::bytes ? headsx_lds_bytes() : EnvGrpDynLds<1>::bytes));
     (void)hipFuncSetAttribute((const void *)k_headsx_gat3x, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes()));
+#if !MTFJSP_BODY_FUNCS
+    if (hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes())) != hipSuccess) e->fuse_mheads = false;
+#else
+    e->fuse_mheads = false;
+#endif
     {   // resident GIN kernel: whole instances per workgroup, at most 576 rows, one workgroup per CU
         const int T = e->T, B = cfg->batch;
         if (!getenv("MTFJSP_NO_RESIDENT_GIN") && T >= GR_MINT && T <= GR_MAXT) {
@@ -2996,9 +3063,12 @@ static int fused_projection(mtfjsp_encoder *e, const std::string &pre, int which
 static int gat3x_args(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, int slot, GatArgs *out)
 {
     const int R = e->cfg.batch * e->cfg.n_machine;
-    double *st = e->stats + (6 + slot) * STAT_REP * 256;
-    if (!e->gat_stats_clean[slot]) HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
-    e->gat_stats_clean[slot] = false;
+    double *st = nullptr;                                                  // slot < 0: the launch exchanges the sums itself (k_headsx_gat3x_headsx)
+    if (slot >= 0) {
+        st = e->stats + (6 + slot) * STAT_REP * 256;
+        if (!e->gat_stats_clean[slot]) HIPCHK(e, hipMemsetAsync(st, 0, STAT_REP * 256 * sizeof(double), e->stream));
+        e->gat_stats_clean[slot] = false;
+    }
     GatArgs a{};
     a.R = R; a.f1 = m_fea1; a.f2 = m_fea2; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
     int frc = fused_projection(e, pre, 1, &a.W1);
@@ -3020,6 +3090,15 @@ static bool gat_fusable(const mtfjsp_encoder *e)
     const int hgrid = e->cfg.batch / HG, gtiles = (2 * e->cfg.batch * e->cfg.n_machine + 15) / 16, ggrid = (gtiles + 7) / 8 < e->num_cu ? (gtiles + 7) / 8 : e->num_cu;
     return e->fuse_gat && !e->bn_mode && !e->reduce_fn && !(e->f32_products & (2 | 4)) && e->cfg.batch % HG == 0 && hgrid <= e->num_cu && hgrid >= ggrid &&
            e->w.count("machine_actor.gat_layer.W") && e->wx6.count("machine_actor.gat_layer.W");
+}
+// ... and the machine actor's heads as well (k_headsx_gat3x_headsx)?  The in-launch exchange needs every workgroup resident at once:
+// one per CU, on a device where the census of the single-launch GIN kernel found all of them available; a count field of the exchange
+// words holds the arrivals of one dispatch group in 6 bits.
+static bool mheads_fusable(const mtfjsp_encoder *e)
+{
+    const int hgrid = e->cfg.batch / HG;
+    return e->fuse_mheads && e->res_ok && gat_fusable(e) && hgrid <= e->num_cu && (hgrid + 7) / 8 <= 63 && e->xw &&
+           e->wx6.count("machine_actor.m_policy.linears.0.weight") && e->wx6.count("machine_actor.machine_critic.linears.0.weight");
 }
 static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, float *h_pooled, int *slot_out = nullptr)
 {
@@ -3170,19 +3249,34 @@ extern "C" int mtfjsp_encoder_set_deferred_poll(mtfjsp_encoder_t e, int32_t defe
     return MTFJSP_OK;
 }
 
-static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic, const GatArgs *fused_gat = nullptr,
-                         const EnvParams *env_tail = nullptr)
+static void set_head_images(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic)
 {
-    if (e->f32_products & 4) { hipLaunchKernelGGL(k_heads, dim3((ha.B + HG - 1) / HG), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
-    ha.hg = (!fused_gat && !env_tail && e->heads_hg8 && 2 * ((ha.B + HG - 1) / HG) <= e->num_cu) ? HG / 2 : HG;
-    const int grid = (ha.B + ha.hg - 1) / ha.hg;
     ha.range_flag = e->range_flag;
     ha.W0x = e->wx6.at(policy + ".linears.0.weight"); ha.W1x = e->wx6.at(policy + ".linears.1.weight");
     ha.Wc0x = e->wx6.at(critic + ".linears.0.weight"); ha.Wc1x = e->wx6.at(critic + ".linears.1.weight");
     ha.sW0 = e->wx6_sinv.at(policy + ".linears.0.weight"); ha.sW1 = e->wx6_sinv.at(policy + ".linears.1.weight");
     ha.sWc0 = e->wx6_sinv.at(critic + ".linears.0.weight"); ha.sWc1 = e->wx6_sinv.at(critic + ".linears.1.weight");
+}
+static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &policy, const std::string &critic, const GatArgs *fused_gat = nullptr,
+                         const EnvParams *env_tail = nullptr, const HeadArgs *fused_mheads = nullptr)
+{
+    if (e->f32_products & 4) { hipLaunchKernelGGL(k_heads, dim3((ha.B + HG - 1) / HG), dim3(512), heads_lds_bytes(), e->stream, ha); return; }
+    ha.hg = (!fused_gat && !env_tail && e->heads_hg8 && 2 * ((ha.B + HG - 1) / HG) <= e->num_cu) ? HG / 2 : HG;
+    const int grid = (ha.B + ha.hg - 1) / ha.hg;
+    set_head_images(e, ha, policy, critic);
     if (fused_gat) {                                                // + the machine path's GAT passes of the same 16 instances
         const size_t lds = headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes();
+#if !MTFJSP_BODY_FUNCS
+        if (fused_mheads) {                                         // + the machine actor's heads behind the in-launch exchange of the node statistics
+            XchgArgs xg{};
+            const int set = (int)(e->xw_epoch++ & 1);
+            xg.words = e->xw + (size_t)set * XW_SET; xg.words_next = e->xw + (size_t)(set ^ 1) * XW_SET;
+            xg.nblk = (unsigned)grid; xg.fail = e->res_fail; xg.range_flag = e->range_flag;
+            if (++e->fused3_launches == e->fused3_fail_at) xg.nblk += 8;      // (diagnostic) every group's count stays one short: the time-out path
+            hipLaunchKernelGGL(k_headsx_gat3x_headsx, dim3(grid), dim3(512), lds, e->stream, ha, *fused_gat, *fused_mheads, xg);
+            return;
+        }
+#endif
         hipLaunchKernelGGL(k_headsx_gat3x, dim3(grid), dim3(512), lds, e->stream, ha, *fused_gat);
         return;
     }
@@ -3222,6 +3316,19 @@ extern "C" int mtfjsp_encoder_arm_mfea1(mtfjsp_encoder_t e, const mtfjsp_mfea1_c
     return MTFJSP_OK;
 }
 
+extern "C" int mtfjsp_encoder_arm_machine_heads(mtfjsp_encoder_t e, float *prob, float *h_pooled, float *machine_v)
+{
+    if (!e || !prob || !h_pooled || !machine_v) return MTFJSP_ERR_ARG;
+    e->mh.armed = true; e->mh.prob = prob; e->mh.h_pooled = h_pooled; e->mh.machine_v = machine_v;
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_encoder_fused_launches(mtfjsp_encoder_t e, int64_t *three_in_one_out)
+{
+    if (!e || !three_in_one_out) return MTFJSP_ERR_ARG;
+    *three_in_one_out = e->fused3_launches;
+    return MTFJSP_OK;
+}
+
 extern "C" int mtfjsp_encoder_arm_env_step(mtfjsp_encoder_t e, const void *params, int32_t bytes)
 {
     if (!e || !params) return MTFJSP_ERR_ARG;
@@ -3232,6 +3339,7 @@ extern "C" int mtfjsp_encoder_arm_env_step(mtfjsp_encoder_t e, const void *param
 }
 extern "C" int mtfjsp_encoder_env_step_fused(mtfjsp_encoder_t e) { return e && e->env_step.done ? 1 : 0; }
 
+static HeadArgs machine_head_args(mtfjsp_encoder *e, const float *h_pooled_o, const uint8_t *mmask, float *prob, float *machine_v);
 static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, const int32_t *ell_col, const float *ell_val,
                                   const int32_t *candidate, const uint8_t *job_mask, const float *h_m_prev,
                                   float *prob, float *h_pooled, float *job_v, float *h_nodes)
@@ -3263,7 +3371,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         hm = e->hm_b;
     }
     {
-        Timed t(e, (e->mf_armed && e->mf_ctx.m_fea2 && gat_fusable(e)) ? "heads_gat3" : "heads");
+        Timed t(e, (e->mf_armed && e->mf_ctx.m_fea2 && gat_fusable(e)) ? ((e->mh.armed && e->fs[1].armed && mheads_fusable(e)) ? "heads_gat3_heads" : "heads_gat3") : "heads");
         HeadArgs ha{};
         ha.B = B; ha.R = J; ha.X = e->cand_feat; ha.pooled = h_pooled; ha.other = hm;
         ha.W0i = WI("job_actor.o_policy.linears.0.weight"); ha.b0 = W("job_actor.o_policy.linears.0.bias");
@@ -3295,17 +3403,35 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         if (!d_st) (void)hipMalloc((void **)&d_st, 4096 * 8 * 8);
         ha.stamps = d_st;
 #endif
-        e->prefused.valid = false;
+        e->prefused.valid = false; e->prefused.heads = false;
         GatArgs ga{};
+        HeadArgs hm_args{};
         const bool with_gat = ha.mf_on && ha.mf.m_fea2 && gat_fusable(e);
-        if (with_gat) {                                                  // the machine forward that follows finds its GAT passes done
+        // the whole machine forward in this launch: armed outputs (mtfjsp_encoder_arm_machine_heads) and an armed machine selection
+        const bool with_mheads = with_gat && e->mh.armed && e->fs[1].armed && mheads_fusable(e);
+        e->mh.armed = false;
+        if (with_gat && !with_mheads) {                                  // the machine forward that follows finds its GAT passes done
             const int slot = e->gat_slot;
             e->gat_slot ^= 1;
             const int grc = gat3x_args(e, "machine_actor.", ha.mf.m_fea1_out, ha.mf.m_fea2, slot, &ga);
             if (grc) return grc;
             e->prefused.valid = true; e->prefused.f1 = ha.mf.m_fea1_out; e->prefused.f2 = ha.mf.m_fea2; e->prefused.slot = slot;
         }
-        launch_heads(e, ha, "job_actor.o_policy", "job_actor.job_critic", with_gat ? &ga : nullptr);
+        if (with_mheads) {                                               // ... finds itself done (same pointers) and returns at once
+            const int grc = gat3x_args(e, "machine_actor.", ha.mf.m_fea1_out, ha.mf.m_fea2, -1, &ga);
+            if (grc) return grc;
+            hm_args = machine_head_args(e, h_pooled, ha.mf.mmask_out, e->mh.prob, e->mh.machine_v);
+            hm_args.pooled = nullptr; hm_args.pooled_out = e->mh.h_pooled;
+            hm_args.xbn_stats = e->stats;                                // (non-NULL = "normalise X here"; the sums come from the in-launch exchange, these are not read)
+            hm_args.xbn_gamma = W("machine_actor.bn.weight"); hm_args.xbn_beta = W("machine_actor.bn.bias");
+            hm_args.xbn_inv_rows = 1.0 / ((double)B * (double)e->cfg.n_machine);
+            hm_args.hg = HG;
+            arm_sampling(e, 1, hm_args);
+            set_head_images(e, hm_args, "machine_actor.m_policy", "machine_actor.machine_critic");
+            e->prefused.heads = true; e->prefused.f1 = ha.mf.m_fea1_out; e->prefused.f2 = ha.mf.m_fea2; e->prefused.h_pooled_o = h_pooled;
+            e->prefused.mmask = ha.mf.mmask_out; e->prefused.prob = e->mh.prob; e->prefused.h_pooled = e->mh.h_pooled; e->prefused.machine_v = e->mh.machine_v;
+        }
+        launch_heads(e, ha, "job_actor.o_policy", "job_actor.job_critic", with_gat ? &ga : nullptr, nullptr, with_mheads ? &hm_args : nullptr);
 #ifdef MTFJSP_STAMP
         static int printed = 0;
         if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
@@ -3323,6 +3449,22 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     return MTFJSP_OK;
 }
 
+// scorer / critic weights and in/out pointers of the machine actor's heads (ac:444-495); the caller adds the BatchNorm source
+static HeadArgs machine_head_args(mtfjsp_encoder *e, const float *h_pooled_o, const uint8_t *mmask, float *prob, float *machine_v)
+{
+    auto W = [&](const std::string &k) { return e->w.at(k); };
+    auto WI = [&](const std::string &k) { return e->wimg.at(k); };
+    HeadArgs ha{};
+    ha.B = e->cfg.batch; ha.R = e->cfg.n_machine; ha.X = e->node; ha.other = h_pooled_o;
+    ha.W0i = WI("machine_actor.m_policy.linears.0.weight"); ha.b0 = W("machine_actor.m_policy.linears.0.bias");
+    ha.W1i = WI("machine_actor.m_policy.linears.1.weight"); ha.b1 = W("machine_actor.m_policy.linears.1.bias");
+    ha.w2 = W("machine_actor.m_policy.linears.2.weight"); ha.b2 = W("machine_actor.m_policy.linears.2.bias");
+    ha.Wc0i = WI("machine_actor.machine_critic.linears.0.weight"); ha.bc0 = W("machine_actor.machine_critic.linears.0.bias");
+    ha.Wc1i = WI("machine_actor.machine_critic.linears.1.weight"); ha.bc1 = W("machine_actor.machine_critic.linears.1.bias");
+    ha.wc2 = W("machine_actor.machine_critic.linears.2.weight"); ha.bc2 = W("machine_actor.machine_critic.linears.2.bias");
+    ha.mask = mmask; ha.scale = 10.0f; ha.prob = prob; ha.value = machine_v;
+    return ha;
+}
 static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, const void *m_fea2, const float *h_pooled_o,
                                       const uint8_t *mmask, float *prob, float *h_pooled, float *machine_v)
 {
@@ -3335,14 +3477,22 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
     auto W = [&](const std::string &k) { return e->w.at(k); };
     auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     int slot = 0;
+    if (e->prefused.heads && !e->bn_mode && m_fea1 == e->prefused.f1 && m_fea2 == e->prefused.f2 && h_pooled_o == e->prefused.h_pooled_o &&
+        mmask == e->prefused.mmask && prob == e->prefused.prob && h_pooled == e->prefused.h_pooled && machine_v == e->prefused.machine_v) {
+        // k_headsx_gat3x_headsx ran this whole forward (and its armed selection) inside the job actor's heads launch
+        e->prefused.heads = false; e->prefused.valid = false;
+        e->env_step.armed = false; e->env_step.done = false;
+        e->fs[1].armed = false;                                       // (a selection armed again for this call has been made already)
+        return MTFJSP_OK;
+    }
+    e->prefused.heads = false;
     if (e->prefused.valid && !e->bn_mode && m_fea1 == e->prefused.f1 && m_fea2 == e->prefused.f2) slot = e->prefused.slot;   // k_headsx_gat3x did it
     else rc = e->bn_mode ? run_gat_inst(e, "machine_actor.", m_fea1, m_fea2, h_pooled) : run_gat(e, "machine_actor.", m_fea1, m_fea2, nullptr, &slot);
     e->prefused.valid = false;
     if (rc) return rc;
     {
         Timed t(e, "heads");
-        HeadArgs ha{};
-        ha.B = B; ha.R = M; ha.X = e->node; ha.other = h_pooled_o;
+        HeadArgs ha = machine_head_args(e, h_pooled_o, mmask, prob, machine_v);
         if (e->bn_mode) ha.pooled = h_pooled;                     // k_gat_inst already normalised and pooled the nodes per instance
         else {
             ha.pooled = nullptr;
@@ -3356,13 +3506,6 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
             }
         }
         arm_sampling(e, 1, ha);
-        ha.W0i = WI("machine_actor.m_policy.linears.0.weight"); ha.b0 = W("machine_actor.m_policy.linears.0.bias");
-        ha.W1i = WI("machine_actor.m_policy.linears.1.weight"); ha.b1 = W("machine_actor.m_policy.linears.1.bias");
-        ha.w2 = W("machine_actor.m_policy.linears.2.weight"); ha.b2 = W("machine_actor.m_policy.linears.2.bias");
-        ha.Wc0i = WI("machine_actor.machine_critic.linears.0.weight"); ha.bc0 = W("machine_actor.machine_critic.linears.0.bias");
-        ha.Wc1i = WI("machine_actor.machine_critic.linears.1.weight"); ha.bc1 = W("machine_actor.machine_critic.linears.1.bias");
-        ha.wc2 = W("machine_actor.machine_critic.linears.2.weight"); ha.bc2 = W("machine_actor.machine_critic.linears.2.bias");
-        ha.mask = mmask; ha.scale = 10.0f; ha.prob = prob; ha.value = machine_v;
         // an armed environment step (mtfjsp_encoder_arm_env_step) rides in this launch when the selection made here is the one it
         // reads, the shapes agree and the launch is the split-product heads kernel; otherwise the caller steps the environment itself
         const EnvParams &EP = e->env_step.P;

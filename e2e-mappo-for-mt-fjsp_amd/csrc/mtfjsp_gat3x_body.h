@@ -209,7 +209,25 @@
     if (tid < 256) {
         double v = 0;
         for (int w = 0; w < 8; w++) v += s_red[w * 256 + tid];
+#if GAT_XCHG
+        // k_headsx_gat3x_headsx: the machine heads follow in THIS launch, behind one grid-wide exchange of these sums.  The protocol is
+        // k_gin_res' (mtfjsp_gin_resident.h: count-carrying 64-bit words, one integer atomic per value, no barrier): the contribution
+        // travels as fixed point with 20 fractional bits (|v| < 2^31: an absolute resolution far below what the BatchNorm epsilon
+        // hides) — or, beyond that range, in a second set of words with 6 fractional bits (|v| < 2^45: relative resolution 2^-37),
+        // so that no magnitude a finite f32 forward produces needs a fallback.  A word of either set carries its arrival count.
+        {
+            const double av = __builtin_fabs(v);
+            int cls = 0;
+            long long fx = 0;
+            if (av < 2147483648.0) fx = __builtin_llrint(v * 1048576.0);
+            else if (av < 35184372088832.0) { cls = 1; fx = __builtin_llrint(v * 64.0); }
+            else if (XA.range_flag) __hip_atomic_store(XA.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // not a number (an operand beyond the f16 range upstream) or absurd: the host repeats the forward
+            (void)__hip_atomic_fetch_add(XA.words + ((size_t)(cls * 8 + (blockIdx.x & 7)) * 256) + tid, GR_FIX_ONE | (unsigned long long)(fx + (long long)GR_FIX_BIAS),
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#else
         atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], v);
+#endif
     }
     GAT_RT(4);
 #undef GAT_RT

@@ -36,8 +36,10 @@
     double bsu[STAT_REP], bsq[STAT_REP];
     float bga = 0.f, bbe = 0.f;
     if (A.xbn_stats) {
+#if !HX_XCHG
 #pragma unroll
         for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.xbn_stats[r * 256 + tc]; bsq[r] = A.xbn_stats[r * 256 + HD + tc]; }
+#endif
         bga = A.xbn_gamma[tc]; bbe = A.xbn_beta[tc];
     }
     {   // one workgroup per group of 16 instances (a persistent loop here makes the compiler hoist ~200 loop-invariant
@@ -78,11 +80,58 @@
         if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
         if (A.zero_stats2 && blockIdx.x == 0) for (int i = tid; i < A.zero_count2; i += 512) A.zero_stats2[i] = 0.0;
         if (A.xbn_stats) {
+#if HX_XCHG
+            // The statistics of X are this launch's own: every workgroup has added its (sum | sum of squares) per column to the
+            // count-carrying words of its dispatch group (the end of mtfjsp_gat3x_body.h) and now collects the eight groups' words —
+            // a word that carries its group's size in the count field is complete (mtfjsp_gin_resident.h).  Everything this kernel
+            // requests that does not depend on other workgroups is already in flight.  Thread t < 256 takes value t (sum of column t,
+            // or sum of squares of column t - 128): 8 loads per poll.  The words of the wide-range set are empty unless a
+            // contribution left the fine set's range: they are looked at from the fourth poll on.
+            double *s_xch = reinterpret_cast<double *>(s_c2);       // (free until phase B)
+            if (tid < 2 * HD) {
+                (void)bsu; (void)bsq;
+                const unsigned long long *w0 = XA.words + tid;      // [set fine | wide][group 8][sum | sumsq][column 128]
+                const unsigned nblk = XA.nblk;
+                unsigned long long sf = 0, sc = 0;
+                unsigned nf = 0, nc = 0;
+                const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                for (int it = 0;; it++) {
+                    unsigned long long vf[8], vc[8];
+                    const bool wide = it >= 3;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) vf[j] = __hip_atomic_load(w0 + j * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) vc[j] = wide ? __hip_atomic_load(w0 + (8 + j) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                    bool done = true;
+                    sf = sc = 0; nf = nc = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const unsigned want = (nblk >> 3) + ((unsigned)j < (nblk & 7u) ? 1u : 0u);
+                        const unsigned c0 = (unsigned)(vf[j] >> 58), d0 = (unsigned)(vc[j] >> 58);
+                        nf += c0; sf += vf[j] & GR_FIX_PAYLOAD; nc += d0; sc += vc[j] & GR_FIX_PAYLOAD;
+                        done = done && c0 + d0 == want;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;                   // (waves 0..3 poll, each until all of its values are in)
+                    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) {                 // 4 ms at 100 MHz: not all workgroups are resident
+                        if (XA.fail) __hip_atomic_store(XA.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (host-mapped: the next forward entry / mtfjsp_encoder_check reports it)
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                s_xch[tid] = __builtin_ldexp((double)((long long)sf - (long long)nf * (long long)GR_FIX_BIAS), -20) +
+                             __builtin_ldexp((double)((long long)sc - (long long)nc * (long long)GR_FIX_BIAS), -6);
+            }
+            LDS_BARRIER();
+#endif
             if (tid < HD) {                                         // stage_bn() from the registers requested above; s_u is free until phase A
                 double su = 0, sq = 0;
+#if HX_XCHG
+                su = s_xch[tid]; sq = s_xch[HD + tid];
+#else
 #pragma unroll
                 for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
                 if (A.range_flag && (su != su || sq != sq)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
                 const double mean = su * A.xbn_inv_rows;
                 double var = sq * A.xbn_inv_rows - mean * mean;
                 if (var < 0) var = 0;

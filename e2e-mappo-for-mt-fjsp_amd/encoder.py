@@ -16,7 +16,7 @@ from . import capi
 
 H = 128
 FAMILIES = ["gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg", "job_pool_gather", "heads", "head_gemm", "gat3", "mach_bn_pool",
-            "sample", "small", "gin_inst", "gat_inst", "gin_resident", "heads_gat3"]
+            "sample", "small", "gin_inst", "gat_inst", "gin_resident", "heads_gat3", "heads_gat3_heads"]
 
 
 def available():
@@ -228,6 +228,18 @@ class Encoder:
         """the next job actor forward (with an armed selection) also writes m_fea1 / the machine mask of the selected tasks"""
         capi.check(self.L.mtfjsp_encoder_arm_mfea1(self.h, C.byref(ctx)), self.h, enc=True)
 
+    def arm_machine_heads(self, prob, h_pooled, machine_v):
+        """the next job actor forward (selection + mfea1 with m_fea2 armed, machine selection armed too) also runs the WHOLE machine
+        actor forward into these outputs where the shape allows it (include/mtfjsp.h); the machine_actor_forward that follows with
+        the same tensors returns at once"""
+        capi.check(self.L.mtfjsp_encoder_arm_machine_heads(self.h, prob.data_ptr(), h_pooled.data_ptr(), machine_v.data_ptr()), self.h, enc=True)
+
+    def fused_launches(self):
+        """forwards that took the three-in-one launch (job heads + GAT passes + machine heads) so far"""
+        n = C.c_int64(0)
+        capi.check(self.L.mtfjsp_encoder_fused_launches(self.h, C.byref(n)), self.h, enc=True)
+        return int(n.value)
+
     def arm_env_step(self, params):
         """the next machine actor forward (with an armed selection into the `mach_idx` of DeviceBatchEnv.step_params) also runs that
         environment step in its heads launch; env_step_fused() tells afterwards whether it did"""
@@ -266,6 +278,7 @@ class ActorPair:
         self.n_env_fused = 0                                     # decisions whose environment step rode in the machine heads' launch
         self.fuse_env = bool(os.environ.get("MTFJSP_FUSED_ENV")) # (the library reads the same switch when the handle is created; off by default: DESIGN.md §9)
         self.fused = not os.environ.get("MTFJSP_NO_FUSED_SELECT")   # action selection inside the heads kernels (same stream either way)
+        self.fuse_mheads = not os.environ.get("MTFJSP_NO_FUSED_MHEADS")   # the machine forward inside the job heads' launch where the library allows it
         dev = self.enc.device
         self.job_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
         self.mch_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
@@ -289,6 +302,7 @@ class ActorPair:
         ml = mach_logp if mach_logp is not None else self.mch_logp
         hm = e.h_pooled_m if self.have_hm else None
         fuse_mfea1 = self.fused and force is None
+        armed_m = False
         if self.fused:
             e.arm_selection(0, self.greedy, self.seed, 2 * counter, job_idx, jl, env.candidate, task_idx)
             if fuse_mfea1:
@@ -299,6 +313,12 @@ class ActorPair:
                 self._mf_ctx.m_fea1_out = mfea1_out.data_ptr() if redirect else self._mf_own[0]
                 self._mf_ctx.mmask_out = mmask_out.data_ptr() if redirect else self._mf_own[1]
                 e.arm_mfea1(self._mf_ctx)
+                if self.fuse_mheads and not (self.fuse_env and env_step is not None):
+                    # the whole machine forward may ride in the job heads' launch (three launches per step): its selection and outputs
+                    # are armed now; the machine_actor_forward call below then finds itself done
+                    e.arm_selection(1, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
+                    e.arm_machine_heads(e.mch_prob, e.h_pooled_m, mv_out if mv_out is not None else e.mach_v)
+                    armed_m = True
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
         else:
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
@@ -319,7 +339,8 @@ class ActorPair:
         self.last_mfea1, self.last_mmask = mf1, mmk             # (terminal_values: the machine actor's inputs of the last decision)
         stepped = False
         if self.fused:
-            e.arm_selection(1, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
+            if not armed_m:
+                e.arm_selection(1, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
             if self.fuse_env and env_step is not None and force is None:
                 # env_step = () or (r4_out, done_out): let the environment step of this decision ride in the machine heads' launch
                 params = env.step_params(task_idx, mach_idx, *env_step)
@@ -383,7 +404,7 @@ class ActorPair:
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_bytes_per_launch": nbytes,
                     "algorithmic_flops_per_launch": flops, "f32_equivalent_TFLOPs": flops / avg_s / 1e12,
                     "f16_matrix_TFLOPs": 3 * flops / avg_s / 1e12}
-        if name in ("heads", "heads_gat3", "gat3"):
+        if name in ("heads", "heads_gat3", "heads_gat3_heads", "gat3"):
             # Latency chains: one workgroup per CU runs a dependent sequence of small products separated by workgroup barriers.  Two
             # bounds are priced: the matrix time of the executed f16 piece products at the dense 16-bit peak, and the LDS traffic of
             # the operand reads at the chip's ds_read_b128 rate (every wave re-reads every activation tile / the GAT weight image).
@@ -397,6 +418,9 @@ class ActorPair:
             elif name == "heads_gat3":
                 flops = heads_flops(J) + gat_flops
                 lds = B * (J + 2) * H * 2 * 2 * 8 * 2 + (2 * B * M / 16.0) * 2 * 65536           # + the 64 KB weight image streamed per tile and pass
+            elif name == "heads_gat3_heads":                                                   # job heads + GAT passes + machine heads in one launch
+                flops = heads_flops(J) + gat_flops + heads_flops(M)
+                lds = B * (J + M + 4) * H * 2 * 2 * 8 * 2 + (2 * B * M / 16.0) * 2 * 65536
             else:
                 flops = gat_flops
                 lds = (2 * B * M / 16.0) * 2 * 65536
@@ -404,6 +428,7 @@ class ActorPair:
             t_mfma = executed / 2.5e15
             t_lds = lds / 150e12                                                               # ~150 TB/s aggregate ds_read_b128 (MI355X_MICROARCH.md, LDS)
             return {"kernel": {"heads": "k_headsx (both heads of an actor for 16 instances per workgroup)", "heads_gat3": "k_headsx_gat3x (job heads + the machine path's three GAT passes)",
+                               "heads_gat3_heads": "k_headsx_gat3x_headsx (job heads + the machine path's three GAT passes + in-launch exchange of the node statistics + machine heads)",
                                "gat3": "k_gat3x (three GAT passes, stand-alone)"}[name],
                     "bound": "latency (dependent phases of one workgroup per CU); priced against the matrix peak and the LDS read rate",
                     "avg_launch_us": avg_s * 1e6, "launches": kd["launches"], "algorithmic_flops_per_launch": flops, "executed_matrix_flops_per_launch": executed,

@@ -230,7 +230,7 @@ class Rollout:
             env.reset(w3)                                                  # pe:87 / run:229
             if self.actor is not None:
                 self.actor.begin_episode()
-            if self.full:
+            if self.full and not self.tainted:             # (a tainted buffer records nothing: its slots are not episode-aligned any more)
                 self.traj.begin_episode(w3)
         last = self.t_in_ep == self.T - 1
         if self.tainted:

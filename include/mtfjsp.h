@@ -292,6 +292,18 @@ typedef struct {
                                          * — the mtfjsp_machine_actor_forward that follows with exactly these two pointers skips them */
 } mtfjsp_mfea1_ctx_t;
 int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask_out, mtfjsp_mfea1_ctx_t *ctx);
+/* The WHOLE machine actor forward (ac:359-498) inside the job actor's heads launch: three launches per rollout step.  With these
+ * outputs armed (prob [B,M], h_pooled [B,H], machine_v [B,2]; one-shot), a machine selection armed (mtfjsp_encoder_arm_selection,
+ * which = 1) and an mfea1 context with m_fea2 (above), the NEXT mtfjsp_job_actor_forward — where the shape allows it: one workgroup
+ * of 16 instances per CU, all co-resident (the single-launch GIN kernel's census), split products — also runs the machine path's
+ * GAT passes, exchanges the BatchNorm sums of the B*M machine nodes (ac:434) between its workgroups inside the launch
+ * (count-carrying integer atomics as in the single-launch GIN kernel; the wait is bounded, a time-out surfaces as
+ * MTFJSP_ERR_RETRY) and the machine heads with their selection.  The mtfjsp_machine_actor_forward that follows with exactly the
+ * pointers involved (m_fea1_out, m_fea2, that job forward's h_pooled, mmask_out, these outputs) finds itself done and returns at
+ * once; with any other argument it recomputes.  Where the shape does not allow it nothing changes.  MTFJSP_NO_FUSED_MHEADS=1: off.
+ * mtfjsp_encoder_fused_launches: how many forwards took the three-in-one launch so far (tests, bench). */
+int mtfjsp_encoder_arm_machine_heads(mtfjsp_encoder_t e, float *prob, float *h_pooled, float *machine_v);
+int mtfjsp_encoder_fused_launches(mtfjsp_encoder_t e, int64_t *three_in_one_out);
 /* BatchNorm statistics of the two actor forwards (every BatchNorm in the reference is in training mode):
  * per_instance = 0 (default): over all rows of the device batch = one reference run with env_batch = B (training rollout);
  * per_instance = 1: over the rows of ONE instance = B independent reference runs with env_batch = 1, i.e. the greedy
