@@ -1213,9 +1213,16 @@ struct XchgArgs {
     unsigned long long *words;       // this forward's words (zero on entry): [fine | wide][8 dispatch groups][sum | sumsq][128 columns]
     unsigned long long *words_next;  // the next forward's set: zeroed by this launch
     unsigned nblk;                   // workgroups of the launch (all co-resident: the host checked the grid against the census)
+    double fine_limit;               // contributions below this magnitude travel in the fine words (2^31; lower only in tests: MTFJSP_XCHG_FINE_LIMIT)
     unsigned *fail, *range_flag;     // host-mapped words: a wait timed out / a contribution was not a number
+    unsigned long long *stamps;      // diagnostic build only (-DMTFJSP_STAMP3): [workgroups][8 waves][8] s_memrealtime
 };
 #define XW_SET (2 * 8 * 256)
+#ifdef MTFJSP_STAMP3
+#define X3_RT(i) do { if (XA.stamps && (threadIdx.x & 63) == 0) { __builtin_amdgcn_sched_barrier(0); XA.stamps[((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define X3_RT(i) do { } while (0)
+#endif
 #if MTFJSP_BODY_FUNCS & 1
 __device__ __forceinline__ void gat3x_body(const GatArgs &A, unsigned char *smem)
 {
@@ -1672,11 +1679,13 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const XchgArgs &XA = XG;
+    X3_RT(0);
     for (int i = blockIdx.x * 512 + threadIdx.x; i < XW_SET; i += (int)gridDim.x * 512) XA.words_next[i] = 0ull;
     {
         const HeadArgs &A = HA;
 #include "mtfjsp_headsx_body.h"
     }
+    X3_RT(1);
     __syncthreads();                                               // m_fea1 / the machine mask of this workgroup's instances are written
     {
         const GatArgs &A = GA;
@@ -1686,6 +1695,7 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #undef GAT_XCHG
 #define GAT_XCHG 0
     }
+    X3_RT(3);
     LDS_BARRIER();                                                 // (not __syncthreads(): that would wait for the statistics' atomics to be acknowledged)
     {
         const HeadArgs &A = HM;
@@ -1695,6 +1705,7 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #undef HX_XCHG
 #define HX_XCHG 0
     }
+    X3_RT(7);
 }
 #endif
 // The machine actor's heads and the environment step of the same 16 instances in ONE launch (round-2 review, item 3): the heads end
@@ -2328,6 +2339,7 @@ struct mtfjsp_encoder {
     unsigned long long *xw = nullptr;       // [2 sets][XW_SET] count-carrying words of that exchange; forward n uses set n & 1 and zeroes the other
     unsigned long long xw_epoch = 0;
     long long fused3_launches = 0;
+    double xchg_fine_limit = getenv("MTFJSP_XCHG_FINE_LIMIT") ? atof(getenv("MTFJSP_XCHG_FINE_LIMIT")) : 2147483648.0;   // diagnostic: a lower limit sends ordinary contributions through the wide-range words
     long long fused3_fail_at = getenv("MTFJSP_FUSED3_FAIL_AT") ? atoll(getenv("MTFJSP_FUSED3_FAIL_AT")) : 0;   // diagnostic: this three-in-one launch waits for a workgroup that does not exist
     bool heads_hg8 = !getenv("MTFJSP_NO_HEADS_HG8");
     bool heads10 = !getenv("MTFJSP_NO_HEADS10");              // k_headsx10 (ten tiles per chunk) for groups of 7..10 tiles
@@ -3097,7 +3109,7 @@ static bool gat_fusable(const mtfjsp_encoder *e)
 static bool mheads_fusable(const mtfjsp_encoder *e)
 {
     const int hgrid = e->cfg.batch / HG;
-    return e->fuse_mheads && e->res_ok && gat_fusable(e) && hgrid <= e->num_cu && (hgrid + 7) / 8 <= 63 && e->xw &&
+    return e->fuse_mheads && e->res_ok && gat_fusable(e) && hgrid <= e->num_cu && (hgrid + 7) / 8 <= 63 && e->xw && e->cfg.n_machine <= 8 &&   // (<= 8: the pool rows are requested ahead of the exchange, mtfjsp_headsx_body.h)
            e->wx6.count("machine_actor.m_policy.linears.0.weight") && e->wx6.count("machine_actor.machine_critic.linears.0.weight");
 }
 static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1, const void *m_fea2, float *h_pooled, int *slot_out = nullptr)
@@ -3272,8 +3284,31 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
             const int set = (int)(e->xw_epoch++ & 1);
             xg.words = e->xw + (size_t)set * XW_SET; xg.words_next = e->xw + (size_t)(set ^ 1) * XW_SET;
             xg.nblk = (unsigned)grid; xg.fail = e->res_fail; xg.range_flag = e->range_flag;
+            xg.fine_limit = e->xchg_fine_limit > 0 && e->xchg_fine_limit <= 2147483648.0 ? e->xchg_fine_limit : 2147483648.0;
             if (++e->fused3_launches == e->fused3_fail_at) xg.nblk += 8;      // (diagnostic) every group's count stays one short: the time-out path
+#ifdef MTFJSP_STAMP3
+            static unsigned long long *d_st3 = nullptr;
+            if (!d_st3) { (void)hipMalloc((void **)&d_st3, (size_t)1024 * 64 * 8); (void)hipMemset(d_st3, 0, (size_t)1024 * 64 * 8); }
+            xg.stamps = d_st3;
+#endif
             hipLaunchKernelGGL(k_headsx_gat3x_headsx, dim3(grid), dim3(512), lds, e->stream, ha, *fused_gat, *fused_mheads, xg);
+#ifdef MTFJSP_STAMP3
+            if (e->fused3_launches % 50 == 20 && getenv("MTFJSP_STAMP_PRINT")) {
+                (void)hipStreamSynchronize(e->stream);
+                std::vector<unsigned long long> h((size_t)grid * 64);
+                (void)hipMemcpy(h.data(), d_st3, h.size() * 8, hipMemcpyDeviceToHost);
+                unsigned long long t0 = ~0ull;
+                for (int w = 0; w < grid * 8; w++) t0 = h[(size_t)w * 8] < t0 ? h[(size_t)w * 8] : t0;
+                printf("STAMP3 (us since the first wave's start; mean / max over %d waves): ", grid * 8);
+                const char *nm[8] = {"start", "job heads done", "gat tiles done", "gat stats out", "poll done", "bn staged", "mheads products done", "end"};
+                for (int i = 0; i < 8; i++) {
+                    double m = 0, mx = 0; int n = 0;
+                    for (int w = 0; w < grid * 8; w++) { if (!h[(size_t)w * 8 + i]) continue; const double v = (double)(h[(size_t)w * 8 + i] - t0) / 100.0; m += v; mx = v > mx ? v : mx; n++; }
+                    printf(" [%s] %.2f/%.2f", nm[i], n ? m / n : 0.0, mx);
+                }
+                printf("\n");
+            }
+#endif
             return;
         }
 #endif

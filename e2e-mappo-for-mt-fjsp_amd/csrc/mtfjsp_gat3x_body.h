@@ -198,6 +198,9 @@
 #endif
     }
     // column sums: fold the 4 row quarters, then the 8 waves through LDS
+#if GAT_XCHG
+    X3_RT(2);
+#endif
     __syncthreads();                                              // every tile is done: s_red aliases them
     for (int c = 0; c < 8; c++) {
         double a = (double)st_sum[c], b = (double)st_sq[c];
@@ -219,7 +222,7 @@
             const double av = __builtin_fabs(v);
             int cls = 0;
             long long fx = 0;
-            if (av < 2147483648.0) fx = __builtin_llrint(v * 1048576.0);
+            if (av < XA.fine_limit) fx = __builtin_llrint(v * 1048576.0);
             else if (av < 35184372088832.0) { cls = 1; fx = __builtin_llrint(v * 64.0); }
             else if (XA.range_flag) __hip_atomic_store(XA.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // not a number (an operand beyond the f16 range upstream) or absurd: the host repeats the forward
             (void)__hip_atomic_fetch_add(XA.words + ((size_t)(cls * 8 + (blockIdx.x & 7)) * 256) + tid, GR_FIX_ONE | (unsigned long long)(fx + (long long)GR_FIX_BIAS),

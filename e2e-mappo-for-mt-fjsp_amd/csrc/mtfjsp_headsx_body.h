@@ -53,6 +53,28 @@
             const int il = (int)__umulhi((unsigned)grow, invR);
             return A.X + ((size_t)(g0 + il) * A.xT + A.xgather[(size_t)g0 * R + grow]) * HD + sc4;
         };
+#if HX_XCHG
+        // Behind the in-launch exchange nothing may wait for memory that could have been requested before it.  X is this workgroup's
+        // own (its GAT passes wrote it), the BatchNorm in front of the pool has no ReLU (ac:434-444), so the pooled embedding is
+        // scale * (raw row mean) + shift: the raw mean of this thread's instance and the other actor's embedding are formed now.
+        // R <= 8 (host: mheads_fusable); rows beyond R are clamped and weighted 0 — no request behind a branch.
+        float4 praw = make_float4(0.f, 0.f, 0.f, 0.f), xo_pre;
+        {
+            const int ic = sr < ng ? sr : ng - 1;
+            const float *src = A.X + (size_t)(g0 + ic) * R * HD + sc4;
+            float4 rv[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) rv[r] = *reinterpret_cast<const float4 *>(src + (size_t)(r < R ? r : R - 1) * HD);
+            xo_pre = *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + ic) * HD + sc4);
+            const float ir = 1.0f / (float)R;
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const float wgt = r < R ? ir : 0.f;
+                praw.x = fmaf(rv[r].x, wgt, praw.x); praw.y = fmaf(rv[r].y, wgt, praw.y); praw.z = fmaf(rv[r].z, wgt, praw.z); praw.w = fmaf(rv[r].w, wgt, praw.w);
+            }
+            asm volatile("" : "+v"(praw.x), "+v"(praw.y), "+v"(praw.z), "+v"(praw.w));   // (formed here: the 8 row registers are free before the weight requests go out)
+        }
+#endif
         float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
         {   // (rows beyond the group's are clamped to its last one here and zeroed by xnorm() where they are used)
             int gi[HCH];
@@ -118,6 +140,7 @@
                     }
                     __builtin_amdgcn_s_sleep(2);
                 }
+                X3_RT(4);
                 s_xch[tid] = __builtin_ldexp((double)((long long)sf - (long long)nf * (long long)GR_FIX_BIAS), -20) +
                              __builtin_ldexp((double)((long long)sc - (long long)nc * (long long)GR_FIX_BIAS), -6);
             }
@@ -144,11 +167,20 @@
             xs0 = s_u[sc4]; xs1 = s_u[sc4 + 1]; xs2 = s_u[sc4 + 2]; xs3 = s_u[sc4 + 3];
             xh0 = s_u[HD + sc4]; xh1 = s_u[HD + sc4 + 1]; xh2 = s_u[HD + sc4 + 2]; xh3 = s_u[HD + sc4 + 3];
             LDS_BARRIER();
+#if HX_XCHG
+            X3_RT(5);
+#endif
         }
         STAMP(6);
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 xp = z;
+#if HX_XCHG
+            if (sr < ng) {
+                xp = make_float4(fmaf(praw.x, xs0, xh0), fmaf(praw.y, xs1, xh1), fmaf(praw.z, xs2, xh2), fmaf(praw.w, xs3, xh3));
+                *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
+            }
+#else
             if (A.xbn_stats) {                                      // pooled = mean over the instance's normalised rows (ac:444 / gcn:192)
                 if (sr < ng) {
                     const int nr = A.xgather ? A.xT : R;
@@ -166,8 +198,13 @@
                     *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
                 }
             } else if (sr < ng) xp = *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4);
+#endif
             STAMP(7);
+#if HX_XCHG
+            const float4 xo = sr < ng ? xo_pre : z;
+#else
             const float4 xo = sr < ng ? *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + sr) * HD + sc4) : z;
+#endif
             {
                 const float vp[4] = {xp.x, xp.y, xp.z, xp.w}, vo[4] = {xo.x, xo.y, xo.z, xo.w};
                 uint2 a0, a1, b0, b1;
@@ -300,6 +337,9 @@
             LDS_BARRIER();                                          // planes / s_part are reused by the next chunk
             STAMP(4);
         }
+#if HX_XCHG
+        X3_RT(6);
+#endif
         // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance; optional action selection
         // (Round 4 requested gather_from[row] and the job predecessor's machine of EVERY scorer row at the top of the kernel, so that the
         // selection below would not fetch them behind one another — index, link, then the task's rows: the job heads' launch did not

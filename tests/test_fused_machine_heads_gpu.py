@@ -73,10 +73,16 @@ def test_three_in_one_launch_equals_the_separate_launches_and_the_oracle(steps_b
     assert float(np.abs(fused[2].cpu().numpy() - mo["mach_v"]).max()) <= 1e-3 * max(1.0, float(np.abs(mo["mach_v"]).max()))
 
 
-def test_contributions_beyond_the_fine_range_use_the_wide_words():
-    """input projections scaled until a workgroup's sum of squares leaves the fine words' range (2^31) while every activation
-    stays inside the f16 range of the split products: the wide-range words carry those contributions — no fallback, same results"""
-    ro, ja, ma = _rollout(scale_fcl=25.0)
+@pytest.mark.parametrize("limit", ["100", "5000"])
+def test_contributions_beyond_the_fine_range_use_the_wide_words(monkeypatch, limit):
+    """A contribution beyond the fine words' range (2^31: a workgroup's sum of squares of 96 node rows with |z| rms > 4 700 — the f16
+    range of the split products leaves little room above that) travels in the wide-range words.  MTFJSP_XCHG_FINE_LIMIT lowers the
+    limit so that ordinary contributions take that way — every sum of squares and most sums at 100, about half of the sums of squares
+    at 5000 (both sets in use for one column): the counts of the two sets add up, the decoded totals agree with the separate
+    launches' f64 sums, nothing falls back.  (With the limit lowered the wide words' 6 fractional bits are coarse for these small
+    magnitudes — at the real limit they resolve 2^-37 of a contribution — hence the looser tolerance: a protocol error would be O(1).)"""
+    monkeypatch.setenv("MTFJSP_XCHG_FINE_LIMIT", limit)
+    ro, ja, ma = _rollout()
     for _ in range(9):
         ro.step()
     env, e = ro.env, ro.actor.enc
@@ -84,14 +90,15 @@ def test_contributions_beyond_the_fine_range_use_the_wide_words():
     fused = [x.clone() for x in (e.mch_prob, e.h_pooled_m, e.mach_v)]
     node = torch.as_tensor(e.peek_nodes())
     per_wg = (node.double() ** 2).reshape(B // 16, 16 * M, 128).sum(1)              # a workgroup's sum of squares per column
-    assert float(per_wg.max()) > 2.0 ** 31 and float(node.abs().max()) < 65504.0, (float(per_wg.max()), float(node.abs().max()))
+    frac_wide = float((per_wg >= float(limit)).double().mean())
+    assert (frac_wide > 0.99) if limit == "100" else (0.2 < frac_wide < 0.8), frac_wide
     mprob, h_m, mach_v = e.machine_actor_forward(env.m_fea1, env.m_fea2, e.h_pooled_o, env.mmask)
     torch.cuda.synchronize()
     assert e.range_fallbacks()[0] == 0 and e.check()
     scale = max(1.0, float(h_m.abs().max()))
-    assert float((fused[0] - mprob).abs().max()) <= 2e-6
-    assert float((fused[1] - h_m).abs().max()) <= 2e-6 * scale
-    assert float((fused[2] - mach_v).abs().max()) <= 2e-5 * max(1.0, float(mach_v.abs().max()))
+    assert float((fused[0] - mprob).abs().max()) <= 2e-4
+    assert float((fused[1] - h_m).abs().max()) <= 2e-4 * scale
+    assert float((fused[2] - mach_v).abs().max()) <= 2e-3 * max(1.0, float(mach_v.abs().max()))
 
 
 def test_exchange_timeout_is_reported_and_the_rollout_recovers(monkeypatch):
@@ -102,10 +109,12 @@ def test_exchange_timeout_is_reported_and_the_rollout_recovers(monkeypatch):
     capi = import_module("e2e-mappo-for-mt-fjsp_amd.capi")
     ro, _, _ = _rollout(seed=5)
     e = ro.actor.enc
-    for _ in range(30):
+    for _ in range(12):                                           # (the host runs ahead of the device: the 4 ms wait of launch 5 ends long after these are enqueued)
         ro.step()
     torch.cuda.synchronize()
-    assert ro.n_resident_failures == 1 and e.resident_failures() == 1
+    ro.step()                                                     # this forward entry sees the failure word: restart on the separate launches
+    torch.cuda.synchronize()
+    assert ro.n_resident_failures == 1 and e.resident_failures() == 1 and ro.t_in_ep == 1
     n3 = e.fused_launches()
     for _ in range(10):                                           # (no check() yet: the handle stays on the separate launches)
         ro.step()
