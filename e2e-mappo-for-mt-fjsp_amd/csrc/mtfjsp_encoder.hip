@@ -951,18 +951,22 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 #pragma unroll
                     for (int c = 0; c < 2; c++) {
                         const f32x4 v = acc[c];
-                        *reinterpret_cast<float4 *>(trb + m * 144 + 16 * (4 * c + q)) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (A.out) *reinterpret_cast<float4 *>(trb + m * 144 + 16 * (4 * c + q)) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
                         for (int i = 0; i < 4; i++) { const float x = ok ? v[i] : 0.f; ts[c][i] += x; tq[c][i] = __builtin_fmaf(x, x, tq[c][i]); }
                     }
 #ifdef MTFJSP_STAMP_TILE
                     STAMP(1);
 #endif
+                    // (out == NULL: the statistics-only pass in front of k_gemm_x6f, mtfjsp_gemm_pair.h — the product is formed, only its
+                    // BatchNorm column sums leave the chip)
+                    if (A.out) {
 #pragma unroll
                     for (int i = 0; i < 2; i++) {
                         const int r8 = 8 * i + (lane >> 3);
                         const float4 v = *reinterpret_cast<const float4 *>(trb + r8 * 144 + 16 * (lane & 7));
                         *reinterpret_cast<float4 *>(A.out + ((size_t)ptile * 16 + r8) * HD + 32 * cg + 4 * (lane & 7)) = v;
+                    }
                     }
 #ifdef MTFJSP_STAMP_TILE
                     STAMP(6);
@@ -1001,6 +1005,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 }
 static size_t gemm_x6_lds_bytes() { return (size_t)X6_TR_OFF + 4 * 2 * X6_TRB; }
 
+#include "mtfjsp_gemm_pair.h"
 #include "mtfjsp_gin_resident.h"
 // the grouped environment step as a device function (k_headsx_envstep below)
 #define MTFJSP_ENV_GRP_NO_KERNELS
@@ -2349,6 +2354,13 @@ struct mtfjsp_encoder {
     // rounds where k_env_grp16's 16 waves take them in one: the second round costs more than the launch boundary saves
     bool fuse_env = getenv("MTFJSP_FUSED_ENV") != nullptr;
     struct { bool armed = false, done = false; EnvParams P; } env_step;          // groups of 8 instances in k_headsx when groups of 16 fill at most half the CUs
+    // streaming GIN launches: the two inner Linears of an MLP in one launch behind a statistics-only pass (mtfjsp_gemm_pair.h).
+    // MTFJSP_FUSE_PAIR=1: always; -1: where the activation matrix exceeds the 256 MB memory-side cache; 0 (default): never —
+    // measured (round 5, J10M10 x 8192 / J20M20 x 2048): statistics-only pass 102 us + pair launch 203 us against 2 x 148 us for the two
+    // launches: a consumer wave runs BOTH products of a step's four tiles back to back (8 tile products, ~10 k cycles per step) and
+    // is the critical path; the 25 % of HBM traffic saved does not show because these launches are bound by the SIMDs' instruction
+    // issue (~100 us per launch even with no output at all), not by memory
+    int fuse_pair = getenv("MTFJSP_FUSE_PAIR") ? atoi(getenv("MTFJSP_FUSE_PAIR")) : 0;
     int stream_order = getenv("MTFJSP_NO_STREAM_ORDER") ? 0 : 1;   // streaming GIN launches: alternating row direction + non-temporal input reads (A/B switch)
     int pool_s = getenv("MTFJSP_POOL_S") ? atoi(getenv("MTFJSP_POOL_S")) : 4;      // k_job_pool_gather: blocks per row range of the last product (0: plain instance order)
     int stream_nt = getenv("MTFJSP_STREAM_NT") ? atoi(getenv("MTFJSP_STREAM_NT")) : 5;   // which readers use non-temporal loads: 1 BatchNorm+ReLU products, 2 aggregation product, 4 pool / gather
@@ -2527,6 +2539,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_GIN0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
+    if (hipFuncSetAttribute((const void *)k_gemm_x6f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6f_lds_bytes()) != hipSuccess) e->fuse_pair = 0;
     (void)hipFuncSetAttribute((const void *)k_gin_inst<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gin_inst<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gat_inst, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
@@ -2950,10 +2963,47 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_bn_relu");
         if (!rrc) rrc = reduce_stats(e, st + sout * STAT_REP * 256);
     };
+    // Two Linears per launch (mtfjsp_gemm_pair.h): pass 1 = the first product with no output (its BatchNorm sums only, slot `smid`),
+    // pass 2 = k_gemm_x6f: in -> bn(sin) -> lin1 -> bn(smid) -> lin2 -> out with the sums of slot `sout`.  Split products only.
+    const bool pair = !(e->f32_products & 1) && (e->fuse_pair > 0 || (e->fuse_pair < 0 && (size_t)N * HD * 4 > ((size_t)256 << 20)));
+    auto bn_gemm_pair = [&](const float *in, float *out, int sin, const std::string &bn1, const std::string &lin1, int smid,
+                            const std::string &bn2, const std::string &lin2, int sout, int rev) {
+        {   // pass 1: statistics of z_b
+            GemmArgs a = gemm_args(in, N, WT(P + lin1 + ".weight"), W(P + lin1 + ".bias"), nullptr);
+            a.rev = so ? rev : 0; a.nt = so && (e->stream_nt & 1);
+            a.pro_stats = st + sin * STAT_REP * 256; a.pro_gamma = W(P + bn1 + ".weight"); a.pro_beta = W(P + bn1 + ".bias"); a.pro_inv_rows = invN;
+            a.epi_stats = st + smid * STAT_REP * 256;
+            a.Wx6 = e->wx6.at(P + lin1 + ".weight"); a.w_sinv = e->wx6_sinv.at(P + lin1 + ".weight");
+            launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_stats_only");
+            if (!rrc) rrc = reduce_stats(e, st + smid * STAT_REP * 256);
+        }
+        {   // pass 2
+            Timed t(e, "gin_gemm_pair");
+            Gemm2Args g{};
+            g.a = gemm_args(in, N, WT(P + lin1 + ".weight"), W(P + lin1 + ".bias"), out);
+            g.a.rev = so ? rev ^ 1 : 0; g.a.nt = so && (e->stream_nt & 1);   // (opposite direction: it starts on what pass 1 read last)
+            g.a.pro_stats = st + sin * STAT_REP * 256; g.a.pro_gamma = W(P + bn1 + ".weight"); g.a.pro_beta = W(P + bn1 + ".bias"); g.a.pro_inv_rows = invN;
+            g.a.epi_stats = st + sout * STAT_REP * 256;
+            g.a.Wx6 = e->wx6.at(P + lin1 + ".weight"); g.a.w_sinv = e->wx6_sinv.at(P + lin1 + ".weight");
+            g.a.range_flag = e->range_flag;
+            g.Wx6b = e->wx6.at(P + lin2 + ".weight"); g.w_sinvb = e->wx6_sinv.at(P + lin2 + ".weight"); g.biasb = W(P + lin2 + ".bias");
+            g.mid_stats = st + smid * STAT_REP * 256; g.mid_gamma = W(P + bn2 + ".weight"); g.mid_beta = W(P + bn2 + ".bias"); g.mid_inv_rows = invN;
+            const int ntiles = (N + 15) / 16;
+            int grid = (ntiles + 7) / 8;
+            if (grid > e->num_cu) grid = e->num_cu;
+            hipLaunchKernelGGL(k_gemm_x6f, dim3(grid), dim3(512), gemm_x6f_lds_bytes(), e->stream, g);
+        }
+        if (!rrc) rrc = reduce_stats(e, st + sout * STAT_REP * 256);
+    };
+    if (pair) bn_gemm_pair(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1, "mlps.0.batch_norms.1", "mlps.0.linears.2", 2, 0);
+    else {
     bn_gemm(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1, 0);
     bn_gemm(e->zB, e->zA, 1, "mlps.0.batch_norms.1", "mlps.0.linears.2", 2, 1);
+    }
+    const float *z2 = pair ? e->zB : e->zA;                        // where the first MLP's output is
+    float *z3 = pair ? e->zA : e->zB;
     {   // layer 1 / linear 0: aggregation of h = relu(bn_outer0(z)) over the ELL adjacency
-        GemmArgs a = gemm_args(e->zA, N, WT(P + "mlps.1.linears.0.weight"), W(P + "mlps.1.linears.0.bias"), e->zB);
+        GemmArgs a = gemm_args(z2, N, WT(P + "mlps.1.linears.0.weight"), W(P + "mlps.1.linears.0.bias"), z3);
         a.pro_stats = st + 2 * STAT_REP * 256; a.pro_gamma = W(P + "batch_norms.0.weight"); a.pro_beta = W(P + "batch_norms.0.bias"); a.pro_inv_rows = invN;
         a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
         a.rev = 0; a.nt = so && (e->stream_nt & 2);
@@ -2962,8 +3012,11 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         launch_gemm<PRO_AGG, EPI_STATS>(e, a, "gin_gemm_agg");
         if (!rrc) rrc = reduce_stats(e, st + 3 * STAT_REP * 256);
     }
+    if (pair) bn_gemm_pair(z3, e->zB, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5, 1);
+    else {
     bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4, 1);
     bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5, 0);
+    }
     if (rrc) return rrc;
     if (h_pooled) {                                               // h_pooled == NULL: the consumer (k_heads) normalises, pools and gathers itself
         Timed t(e, "job_pool_gather");
@@ -3307,6 +3360,15 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
                     printf(" [%s] %.2f/%.2f", nm[i], n ? m / n : 0.0, mx);
                 }
                 printf("\n");
+                for (int i = 1; i <= 3; i++) {                          // per wave index: who finishes when
+                    printf("STAMP3 [%s] by wave:", nm[i]);
+                    for (int wv = 0; wv < 8; wv++) {
+                        double m = 0; int n = 0;
+                        for (int b = 0; b < grid; b++) { const unsigned long long x = h[((size_t)b * 8 + wv) * 8 + i]; if (x) { m += (double)(x - t0) / 100.0; n++; } }
+                        printf(" %.2f", n ? m / n : 0.0);
+                    }
+                    printf("\n");
+                }
             }
 #endif
             return;
