@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         constexpr bool VT = GR_VRES && RT >= GR_NRES;                    // this tile lives in vector registers
         f32x16 atmp;
         f32x16 &a = RT < GR_NRES ? acc[RT < GR_NRES ? RT : 0] : VT ? zs[RT >= GR_NRES ? (RT - GR_NRES) & 1 : 0] : atmp;     // (its previous-layer values went into the planes one tile ago)
-        if constexpr (!VT) a = f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // (the tile's first matrix instruction takes a literal zero as its accumulator: no 16 writes into the accumulation file)
         // the spilled tiles' old values: requested a tile before the slices that turn them into planes
         if constexpr (RT + GR_LOOK + 1 >= GR_NRES && RT + GR_LOOK + 1 < GR_NT) zload(std::integral_constant<int, RT + GR_LOOK + 1 - GR_NRES>{});
         gr_static_for<4>([&](auto Pc) __attribute__((always_inline)) {
@@ -531,6 +531,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             auto M = [&](int ks, int wp, int xp) __attribute__((always_inline)) {
                 if (GR_ABL & 2) return;
                 if constexpr (VT) mfma_v(a, wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], ks == 0 && wp == 0 && xp == 1);
+                else if (ks == 0 && wp == 0 && xp == 1)
+                    a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], x0[xp], f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 else a = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[wp][ks], (ks & 1) ? x1[xp] : x0[xp], a, 0, 0, 0);
             };
             // slice 0
