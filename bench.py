@@ -60,11 +60,25 @@ def same_footprint_copy(env, B, J, M):
     return out
 
 
-PMC_FILE = "r04_pmc_traffic.json"
+PMC_FILE = "r05_pmc_traffic.json"
+FOOTPRINT_FILE = "r05_footprint_kernel_only.json"
+
+
+def footprint_kernel_only(B):
+    """The same-footprint fraction of the step kernel on KERNEL-ONLY durations: rocprofv3 --kernel-trace of the step kernel and of the
+    SURVEY 8(d) copy kernel in one process (tools/footprint_kernel_only.sh; committed under profiles/).  The fraction measured inside
+    this run (frac_of_same_footprint_copy) pairs two HIP-event timings, each of which carries ~2.3 us of event cost: it flatters the
+    step kernel at small batches.  The profiler cannot run inside the timed process, so the committed measurement is reported."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", FOOTPRINT_FILE)))["batches"][str(B)]
+        return {"frac": d["frac_of_same_footprint_copy_kernel_only"], "step_kernel_us": d["step_ns_avg"] / 1e3, "copy_kernel_us": d["copy_16B"]["ns_avg"] / 1e3,
+                "copy_grid": d["copy_16B"]["grid"], "source": f"profiles/{FOOTPRINT_FILE} (rocprofv3 --kernel-trace, End - Start per dispatch; not re-measured inside this run)"}
+    except Exception:
+        return None
 
 
 def pmc_traffic(family, shape=None):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/r03_pmc_traffic.json: FETCH_SIZE and
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/<PMC_FILE>: FETCH_SIZE and
     WRITE_SIZE collected in separate passes of this same command, gfx950 FETCH_SIZE x2 correction applied).  PMC
     collection cannot run inside the timed process, so bench.py reports the last committed measurement (B=4096 J6M6E2)."""
     try:
@@ -103,7 +117,9 @@ def env_kernel_large_batch(J, M, E, device, B=262144, episodes=2):
     torch.cuda.empty_cache()
     kname = (("k_env_grp16" if B <= 8192 else "k_env_grp4") if (T <= 64 and M * M <= 64) else
              ("k_env_grp16x2" if B <= 4096 else "k_env_grp4x2") if (T <= 128 and M * M <= 128 and M <= 16) else "k_env_step_grp")
+    ko = footprint_kernel_only(B)
     return {"kernel": kname, "instances": B, "bound": "hbm", "achieved": ach,
+            "frac_of_same_footprint_copy_kernel_only": ko["frac"] if ko else None, "kernel_only": ko,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBPS,
             "avg_launch_us": sec * 1e6, "launches": n, "env_steps_per_s": B / sec,
             # SURVEY §8(d)'s own denominator: the same bytes through a plain streaming launch at the same batch
@@ -604,6 +620,10 @@ def main():
                 c16 = sweep[0]["same_footprint_copy"]["access_16B"]["avg_launch_us"]
                 out["roofline_env_step"]["same_footprint_copy_us"] = c16
                 out["roofline_env_step"]["frac_of_same_footprint_copy"] = c16 / out["roofline_env_step"]["avg_launch_us"]
+                ko = footprint_kernel_only(B)
+                if ko:                                             # the figure to quote: both durations kernel-only (see footprint_kernel_only)
+                    out["roofline_env_step"]["frac_of_same_footprint_copy_kernel_only"] = ko["frac"]
+                    out["roofline_env_step"]["kernel_only"] = ko
         if world == 1 and headline and policy == "actor" and not args.no_config_legs:
             legs = {}
             for name, (cj, cm, ce, cb) in (("J10M10E2_x8192", (10, 10, 2, 8192)), ("J20M20E4_x2048", (20, 20, 4, 2048))):
