@@ -367,6 +367,11 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         if (zero) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(c) : "v"(a), "v"(b));
         else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
     };
+    // The per-tile "is this lane's row valid" masks and the scale / shift addresses selected by them are the same expressions in every
+    // layer: left alone, hipcc forms all 18 tiles' once and keeps them for five layers — through scratch memory (128 reloads, 47
+    // stores per wave) and SGPR spill lanes (~570 v_readlane / v_writelane).  nrows_l is the same number made opaque at the top of each
+    // layer (and so is the lane's row index n_l), so each layer forms its own (an or, a compare, two selects and two adds per tile).
+    int nrows_l = nrows, n_l = n;
     bool timed_out = false;                                       // a statistics wait of this launch gave up: everything after it is garbage
     gr_h8 wf[2][8];
     bf16x8 w0f[3];                                                // (first Linear only)
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     auto produce_quarter = [&](auto Tc, auto Gc, unsigned char *pbuf) __attribute__((always_inline)) {
         constexpr int rt = decltype(Tc)::value, g = decltype(Gc)::value;
         unsigned char *dst = pbuf + n * GR_ROWB + (32 * wave + 8 * g + 4 * h) * 2;
-        const float *bn = rt * 32 + n < nrows ? s_bn : s_zero;    // rows >= nrows: scale = shift = 0 -> zero planes
+        const float *bn = rt * 32 + n_l < nrows_l ? s_bn : s_zero;  // rows >= nrows: scale = shift = 0 -> zero planes
         const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);        // scale | shift of these 4 columns
         const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
         const f32x16 &a = GR_TILEVAL(rt);
@@ -505,7 +510,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         constexpr bool STATS = RT > 0 && (GR_VRES || RT - 1 < GR_NRES) && !(GR_ABL & 4);     // (a spilled tile's sums are taken when it is stored)
         const unsigned char *xa = plane_buf(RT % (2 * GR_LOOK)) + n * GR_ROWB + 16 * h;
         unsigned char *pnext = plane_buf(PT % (2 * GR_LOOK));
-        const float *bn = PT * 32 + n < nrows ? s_bn : s_zero;            // rows >= nrows: scale = shift = 0 -> zero planes
+        const float *bn = PT * 32 + n_l < nrows_l ? s_bn : s_zero;          // rows >= nrows: scale = shift = 0 -> zero planes
         gr_h8 xf[2][2];
 #pragma unroll
         for (int p = 0; p < 2; p++) xf[0][p] = *reinterpret_cast<const gr_h8 *>(xa + p * GR_PLANE);
@@ -748,6 +753,9 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     // allocator resolves through scratch memory)
     gr_static_for<5>([&](auto Lc) __attribute__((always_inline)) {
         constexpr int layer = decltype(Lc)::value + 1;
+#ifndef GR_KEEP_MASKS                     // (A/B: -DGR_KEEP_MASKS is the code before this change)
+        asm volatile("" : "+s"(nrows_l), "+v"(n_l));
+#endif
         if constexpr (layer != 3) {
             gr_static_for<GR_LOOK>([&](auto Ic) __attribute__((always_inline)) { produce_tile(Ic, plane_buf(decltype(Ic)::value)); });
             LDS_BARRIER();
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                 float *base = s_ring + ((rt % GR_RING) * 32 + n) * HD;
                 gr_static_for<4>([&](auto Gc) __attribute__((always_inline)) {
                     constexpr int g = decltype(Gc)::value;
-                    const float *bn = rt * 32 + n < nrows ? s_bn : s_zero;
+                    const float *bn = rt * 32 + n_l < nrows_l ? s_bn : s_zero;
                     const float4 s4 = *reinterpret_cast<const float4 *>(bn + 32 * wave + 8 * g + 4 * h);
                     const float4 h4 = *reinterpret_cast<const float4 *>(bn + HD + 32 * wave + 8 * g + 4 * h);
                     const f32x16 &a = GR_TILEVAL(rt);
@@ -801,7 +809,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             struct AggRow { const float *po, *px, *py; float w0, w1, inv; int s0, s1, s2; };
             auto agg_row = [&](int RT) __attribute__((always_inline)) {
                 AggRow r;
-                const int row = RT * 32 + n;
+                const int row = RT * 32 + n_l;
                 const unsigned cp = s_ellc[row];
                 const unsigned r0 = cp & 0xffffu, r1 = cp >> 16;
                 r.w0 = s_ellv0[row]; r.w1 = s_ellv1[row];
@@ -841,7 +849,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                 for (int p = 0; p < 2; p++) xf[0][p] = *reinterpret_cast<const gr_h8 *>(xa + p * GR_PLANE);
                 AggRow r = agg_row(NEXT ? RT + 1 : RT);
                 unsigned char *dst = s_planes + ((RT + 1) & 1) * GR_TILE + n * GR_ROWB + (32 * wave + 4 * h) * 2;
-                const float *bnw = WT * 32 + n < nrows ? s_bn : s_zero;
+                const float *bnw = WT * 32 + n_l < nrows_l ? s_bn : s_zero;
                 float *hbase = s_ring + ((WT % GR_RING) * 32 + n) * HD;
                 float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = s4;
                 if constexpr (WH) {
@@ -958,8 +966,11 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         const int c = lane & 31;
         int left = ((16 * h) / T + 1) * T - 16 * h;                   // rows of the instance of this lane's first row (16h of tile 0) still ahead
         int slot[GR_NT];                                              // candidate slot of this lane's row in every tile (-1: none)
+#ifndef GR_KEEP_MASKS
+        asm volatile("" : "+v"(n_l));                                 // (the row indices of this phase are formed here, not kept from the layers)
+#endif
 #pragma unroll
-        for (int rt = 0; rt < GR_NT; rt++) slot[rt] = (GR_ABL & 32) ? -1 : s_rowcand[rt * 32 + n];
+        for (int rt = 0; rt < GR_NT; rt++) slot[rt] = (GR_ABL & 32) ? -1 : s_rowcand[rt * 32 + n_l];
         LDS_BARRIER();                                                // the plane buffers are no longer read
         // gcn:192 for one tile: rows 16h .. 16h+15 of column c from the transposition buffer, split at the instance boundary
         auto pool_tile = [&](int rt) __attribute__((always_inline)) {
@@ -1001,8 +1012,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 #pragma unroll
                 for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(d + 8 * g) = v[g];
             }
-            if (A.h_nodes && rt * 32 + n < nrows) {
-                float *d = A.h_nodes + (grow0 + rt * 32 + n) * HD + 32 * wave + 4 * h;
+            if (A.h_nodes && rt * 32 + n_l < nrows) {
+                float *d = A.h_nodes + (grow0 + rt * 32 + n_l) * HD + 32 * wave + 4 * h;
 #pragma unroll
                 for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(d + 8 * g) = v[g];
             }
