@@ -196,7 +196,8 @@ class Rollout:
 
     def _agree_on_failure_and_restart_together(self):
         from . import dist as _dist
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():                      # (always, in the product; the CPU control-flow test drives this with stubs)
+            torch.cuda.synchronize()
         failed = self._failed_since_last_check()
         if _dist.agree_any(failed):
             self.n_resident_failures += int(failed)
