@@ -1029,6 +1029,8 @@ struct GatArgs {
     int feat_f64;
     const float *W1, *W2;   // (m_fea_1_fcl.weight^T . gat W)^T [128,6], (m_fea_2_fcl.weight^T . gat W)^T [128,8]: input projection and
                             // the first pass' h W fused on the host (one 14 x 128 x 128 product per weight load)
+    const float *Wq;        // the two of them as the f32 matrix instruction's B operands (k_gat3x): [c 8][lane 64][ks 4] = W_cat[4 ks + (lane >> 4)][16 c + (lane & 15)],
+                            // W_cat = [W1^T (6 rows) ; 0 0 ; W2^T (8 rows)] (16 x 128)
     const float *Wt;        // gat_layer.W [in,out]
     const void *Wx6;        // the same (scaled by a power of two) as f16 x 2-plane operand fragments [c 8][plane 2][ks 4][lane 64][8] (k_gat3x)
     float w_sinv;           // 1 / that scale
@@ -1214,6 +1216,7 @@ __device__ __forceinline__ int gx_off(int row, int col) { return row * HD + ((((
 // words instead of f64 atomics; HX_XCHG: the heads statements collect them from those words instead of reading finished sums.
 #define GAT_XCHG 0
 #define HX_XCHG 0
+#define GAT_PRESTAGED 0
 struct XchgArgs {
     unsigned long long *words;       // this forward's words (zero on entry): [fine | wide][8 dispatch groups][sum | sumsq][128 columns]
     unsigned long long *words_next;  // the next forward's set: zeroed by this launch
@@ -1228,6 +1231,8 @@ struct XchgArgs {
 #else
 #define X3_RT(i) do { } while (0)
 #endif
+#define H3S_RT(i) do { } while (0)
+#define H3_RT(i) do { } while (0)                                  // (the heads statements' phase boundaries; live only inside k_headsx_gat3x_headsx of the -DMTFJSP_STAMP3 build)
 #if MTFJSP_BODY_FUNCS & 1
 __device__ __forceinline__ void gat3x_body(const GatArgs &A, unsigned char *smem)
 {
@@ -1679,6 +1684,41 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
 // job actor's pooled embedding — in flight before the wait; the launch boundary, its cold first phase (3.9 us of requests with
 // nothing to overlap) and a second dispatch ramp go.  Needs the whole grid co-resident (one workgroup per CU: the host enables it
 // only where the single-launch GIN kernel's census passed) and bounds its wait like that kernel (time-out -> MTFJSP_ERR_RETRY).
+// What the GAT statements need in LDS before their first tile — the 64 KB of weight fragments (s_wf), the projection's operand image
+// and the attention vectors — copied by the 256 threads of waves 4-7 while waves 0-3 run the job selection (HX_IDLE_HOOK in
+// mtfjsp_headsx_body.h): [0, 64 KB) lies in the scorer's dead planes, the images beyond everything the heads part uses.
+#define GAT_IMG_OFF (128 * 1024)                                  // behind s_wf (64 KB) and s_a (64 KB)
+#define GAT_IMG_BYTES (8 * 64 * 4 * 4 + 256 * 4)
+#define GAT_F1_OFF (GAT_IMG_OFF + GAT_IMG_BYTES)                  // m_fea1 of the workgroup's 16 x M machines as f32 [16 M][6] (M <= 8), written by the job selection
+#define GAT_F2_OFF (GAT_F1_OFF + 16 * 8 * 6 * 4)                  // m_fea2 likewise [16 M][8], copied here
+#define GAT_PRE_END (GAT_F2_OFF + 16 * 8 * 8 * 4)
+__device__ __forceinline__ void gat_prestage(const GatArgs &G, unsigned char *smem, int t, int M)
+{
+    // every request first, none behind a branch (indices clamped, values zeroed where they are stored); then the stores in request order
+    const float4 *src = reinterpret_cast<const float4 *>(G.Wx6);
+    float4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = src[i * 256 + t];
+    const float4 q0 = reinterpret_cast<const float4 *>(G.Wq)[t], q1 = reinterpret_cast<const float4 *>(G.Wq)[256 + t];
+    const float ga = G.gat_a[t];
+    const size_t base = (size_t)blockIdx.x * 16 * M * 8, total = (size_t)G.R * 8;   // this workgroup's m_fea2 rows
+    float x[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const size_t idx = base + (size_t)(i * 256 + t), ic = idx < total ? idx : total - 1;
+        x[i] = G.feat_f64 ? (float)reinterpret_cast<const double *>(G.f2)[ic] : reinterpret_cast<const float *>(G.f2)[ic];
+        if (!(i * 256 + t < 16 * M * 8 && idx < total)) x[i] = 0.f;
+    }
+    float4 *dst = reinterpret_cast<float4 *>(smem);
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst[i * 256 + t] = v[i];
+    float4 *img = reinterpret_cast<float4 *>(smem + GAT_IMG_OFF);
+    img[t] = q0; img[256 + t] = q1;
+    reinterpret_cast<float *>(smem + GAT_IMG_OFF + 8192)[t] = ga;
+    float *d = reinterpret_cast<float *>(smem + GAT_F2_OFF);
+#pragma unroll
+    for (int i = 0; i < 4; i++) d[i * 256 + t] = x[i];
+}
 #if !MTFJSP_BODY_FUNCS
 __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArgs GA, HeadArgs HM, XchgArgs XG)
 {
@@ -1686,22 +1726,41 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
     const XchgArgs &XA = XG;
     X3_RT(0);
     for (int i = blockIdx.x * 512 + threadIdx.x; i < XW_SET; i += (int)gridDim.x * 512) XA.words_next[i] = 0ull;
+#ifdef MTFJSP_STAMP3
+#undef H3_RT
+#define H3_RT(i) do { if (XA.stamps && (threadIdx.x & 63) == 0) { __builtin_amdgcn_sched_barrier(0); XA.stamps[(size_t)H3_BASE * 64 + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define H3_BASE 512
+#undef H3S_RT
+#define H3S_RT(i) do { if (XA.stamps && (threadIdx.x & 63) == 0) { __builtin_amdgcn_sched_barrier(0); XA.stamps[(size_t)(H3_BASE + 256) * 64 + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#endif
     {
         const HeadArgs &A = HA;
+#define HX_IDLE_HOOK gat_prestage(GA, smem, tid - 256, A.mf.M);
+#define HX_MF1_LDS reinterpret_cast<float *>(smem + GAT_F1_OFF)
 #include "mtfjsp_headsx_body.h"
+#undef HX_IDLE_HOOK
+#undef HX_MF1_LDS
     }
     X3_RT(1);
-    __syncthreads();                                               // m_fea1 / the machine mask of this workgroup's instances are written
+    __syncthreads();                                               // m_fea1 / the machine mask of this workgroup's instances are written; the GAT part's LDS images are staged
     {
         const GatArgs &A = GA;
 #undef GAT_XCHG
 #define GAT_XCHG 1
+#undef GAT_PRESTAGED
+#define GAT_PRESTAGED 1
 #include "mtfjsp_gat3x_body.h"
+#undef GAT_PRESTAGED
+#define GAT_PRESTAGED 0
 #undef GAT_XCHG
 #define GAT_XCHG 0
     }
     X3_RT(3);
     LDS_BARRIER();                                                 // (not __syncthreads(): that would wait for the statistics' atomics to be acknowledged)
+#ifdef MTFJSP_STAMP3
+#undef H3_BASE
+#define H3_BASE 1024
+#endif
     {
         const HeadArgs &A = HM;
 #undef HX_XCHG
@@ -1710,6 +1769,12 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #undef HX_XCHG
 #define HX_XCHG 0
     }
+#ifdef MTFJSP_STAMP3
+#undef H3_RT
+#define H3_RT(i) do { } while (0)
+#undef H3S_RT
+#define H3S_RT(i) do { } while (0)
+#endif
     X3_RT(7);
 }
 #endif
@@ -1729,6 +1794,7 @@ __global__ __launch_bounds__(512) void k_headsx_envstep(HeadArgs HA, EnvParams E
     env_grp_body_dyn<OBS, 1, 8>(EP, smem);
 }
 static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
+static size_t fused3_lds_bytes() { const size_t g = GAT_PRE_END; return headsx_lds_bytes() > g ? headsx_lds_bytes() : g; }   // k_headsx_gat3x_headsx: + the prestaged GAT images and feature rows (GAT_PRE_END)
 // The same kernel with TEN scorer tiles per chunk: a group of 16 instances with 7..10 candidates / machines each (J10M10: R = 10)
 // goes through the product phases once instead of twice (6 + 4 tiles, each chunk with its own staging, four barriers and latency chain)
 #undef HCH
@@ -2552,7 +2618,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
                               (int)(headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes()));
 #if !MTFJSP_BODY_FUNCS
     if (hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes())) != hipSuccess) e->fuse_mheads = false;
+                            (int)fused3_lds_bytes()) != hipSuccess) e->fuse_mheads = false;
 #else
     e->fuse_mheads = false;
 #endif
@@ -2684,7 +2750,7 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
         key.find("m_fea_2_fcl.weight") != std::string::npos) {
         e->hostw[key].assign(data, data + numel);
         const std::string prefix = key.substr(0, key.find('.') + 1);
-        e->wfused.erase(prefix + "1"); e->wfused.erase(prefix + "2");   // rebuilt at the next forward (buffers stay owned)
+        e->wfused.erase(prefix + "1"); e->wfused.erase(prefix + "2"); e->wfused.erase(prefix + "q");   // rebuilt at the next forward (buffers stay owned)
     }
     if (numel == (int64_t)HD * 12 && key.find("mlps.0.linears.0.weight") != std::string::npos) {
         // k_gemm_x6<PRO_GIN0>: the 12 -> 128 first Linear as ONE k-step of 32 (k >= 12 zero), exact 3-way bf16 split:
@@ -3100,11 +3166,8 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
 // Machine path shared by the machine actor and the global critic (ac:383-444): input projections + 3x the same GATLayer
 // + node mean (in-place GEMM passes), then BatchNorm over all B*M rows and the mean over M.  Uses accumulator slot 6.
 // (m_fea_k_fcl.weight^T . gat_layer.W)^T on the host, cached per prefix until one of the three weights is loaded again
-static int fused_projection(mtfjsp_encoder *e, const std::string &pre, int which, const float **out)
+static std::vector<float> fused_projection_host(mtfjsp_encoder *e, const std::string &pre, int which)
 {
-    const std::string key = pre + (which == 1 ? "1" : "2");
-    auto it = e->wfused.find(key);
-    if (it != e->wfused.end()) { *out = it->second; return MTFJSP_OK; }
     const int K = which == 1 ? 6 : 8;
     const std::vector<float> &P = e->hostw.at(pre + (which == 1 ? "m_fea_1_fcl.weight" : "m_fea_2_fcl.weight"));   // [128,K]
     const std::vector<float> &W = e->hostw.at(pre + "gat_layer.W");                                                  // [128(in),128(out)]
@@ -3115,9 +3178,38 @@ static int fused_projection(mtfjsp_encoder *e, const std::string &pre, int which
             for (int i = 0; i < HD; i++) a += (double)P[(size_t)i * K + k] * (double)W[(size_t)i * HD + n];
             f[(size_t)n * K + k] = (float)a;
         }
+    return f;
+}
+static int fused_projection(mtfjsp_encoder *e, const std::string &pre, int which, const float **out)
+{
+    const std::string key = pre + (which == 1 ? "1" : "2");
+    auto it = e->wfused.find(key);
+    if (it != e->wfused.end()) { *out = it->second; return MTFJSP_OK; }
+    const std::vector<float> f = fused_projection_host(e, pre, which);
     float *d = nullptr;
     if (dalloc(e, &d, f.size())) return MTFJSP_ERR_HIP;
     HIPCHK(e, hipMemcpy(d, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+    e->wfused[key] = d;
+    *out = d;
+    return MTFJSP_OK;
+}
+// both fused projections as the B operands of v_mfma_f32_16x16x4_f32 (GatArgs::Wq), cached like them
+static int fused_projection_image(mtfjsp_encoder *e, const std::string &pre, const float **out)
+{
+    const std::string key = pre + "q";
+    auto it = e->wfused.find(key);
+    if (it != e->wfused.end()) { *out = it->second; return MTFJSP_OK; }
+    const std::vector<float> f1 = fused_projection_host(e, pre, 1), f2 = fused_projection_host(e, pre, 2);
+    std::vector<float> img((size_t)8 * 64 * 4);
+    for (int c = 0; c < 8; c++)
+        for (int lane = 0; lane < 64; lane++)
+            for (int ks = 0; ks < 4; ks++) {
+                const int kk = 4 * ks + (lane >> 4), col = 16 * c + (lane & 15);
+                img[((size_t)c * 64 + lane) * 4 + ks] = kk < 6 ? f1[(size_t)col * 6 + kk] : kk < 8 ? 0.f : f2[(size_t)col * 8 + (kk - 8)];
+            }
+    float *d = nullptr;
+    if (dalloc(e, &d, img.size())) return MTFJSP_ERR_HIP;
+    HIPCHK(e, hipMemcpy(d, img.data(), img.size() * 4, hipMemcpyHostToDevice));
     e->wfused[key] = d;
     *out = d;
     return MTFJSP_OK;
@@ -3138,6 +3230,7 @@ static int gat3x_args(mtfjsp_encoder *e, const std::string &pre, const void *m_f
     a.R = R; a.f1 = m_fea1; a.f2 = m_fea2; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
     int frc = fused_projection(e, pre, 1, &a.W1);
     if (!frc) frc = fused_projection(e, pre, 2, &a.W2);
+    if (!frc) frc = fused_projection_image(e, pre, &a.Wq);
     if (frc) return frc;
     a.Wt = e->wt.at(pre + "gat_layer.W"); a.gat_a = e->w.at(pre + "gat_layer.a"); a.node = e->node; a.epi_stats = st;
     a.Wx6 = e->wx6.at(pre + "gat_layer.W"); a.w_sinv = e->wx6_sinv.at(pre + "gat_layer.W");
@@ -3182,6 +3275,7 @@ static int run_gat(mtfjsp_encoder *e, const std::string &pre, const void *m_fea1
         a.R = R; a.f1 = m_fea1; a.f2 = m_fea2; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64;
         int frc = fused_projection(e, pre, 1, &a.W1);
         if (!frc) frc = fused_projection(e, pre, 2, &a.W2);
+        if (!frc) frc = fused_projection_image(e, pre, &a.Wq);
         if (frc) return frc;
         a.Wt = WT(pre + "gat_layer.W"); a.gat_a = W(pre + "gat_layer.a"); a.node = e->node; a.epi_stats = st;
         const int ntiles = (2 * R + 15) / 16;
@@ -3341,15 +3435,17 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
             if (++e->fused3_launches == e->fused3_fail_at) xg.nblk += 8;      // (diagnostic) every group's count stays one short: the time-out path
 #ifdef MTFJSP_STAMP3
             static unsigned long long *d_st3 = nullptr;
-            if (!d_st3) { (void)hipMalloc((void **)&d_st3, (size_t)1024 * 64 * 8); (void)hipMemset(d_st3, 0, (size_t)1024 * 64 * 8); }
+            if (!d_st3) { (void)hipMalloc((void **)&d_st3, (size_t)2048 * 64 * 8); (void)hipMemset(d_st3, 0, (size_t)2048 * 64 * 8); }
             xg.stamps = d_st3;
 #endif
-            hipLaunchKernelGGL(k_headsx_gat3x_headsx, dim3(grid), dim3(512), lds, e->stream, ha, *fused_gat, *fused_mheads, xg);
+            hipLaunchKernelGGL(k_headsx_gat3x_headsx, dim3(grid), dim3(512), fused3_lds_bytes(), e->stream, ha, *fused_gat, *fused_mheads, xg);
 #ifdef MTFJSP_STAMP3
             if (e->fused3_launches % 50 == 20 && getenv("MTFJSP_STAMP_PRINT")) {
                 (void)hipStreamSynchronize(e->stream);
                 std::vector<unsigned long long> h((size_t)grid * 64);
                 (void)hipMemcpy(h.data(), d_st3, h.size() * 8, hipMemcpyDeviceToHost);
+                std::vector<unsigned long long> h2((size_t)grid * 64);
+                (void)hipMemcpy(h2.data(), d_st3 + (size_t)256 * 64, h2.size() * 8, hipMemcpyDeviceToHost);
                 unsigned long long t0 = ~0ull;
                 for (int w = 0; w < grid * 8; w++) t0 = h[(size_t)w * 8] < t0 ? h[(size_t)w * 8] : t0;
                 printf("STAMP3 (us since the first wave's start; mean / max over %d waves): ", grid * 8);
@@ -3365,6 +3461,41 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
                     for (int wv = 0; wv < 8; wv++) {
                         double m = 0; int n = 0;
                         for (int b = 0; b < grid; b++) { const unsigned long long x = h[((size_t)b * 8 + wv) * 8 + i]; if (x) { m += (double)(x - t0) / 100.0; n++; } }
+                        printf(" %.2f", n ? m / n : 0.0);
+                    }
+                    printf("\n");
+                }
+                for (int part = 0; part < 2; part++) {                  // the heads statements' phase boundaries (H3_RT): job part, machine part
+                    std::vector<unsigned long long> h3((size_t)grid * 64);
+                    (void)hipMemcpy(h3.data(), d_st3 + (size_t)(part ? 1024 : 512) * 64, h3.size() * 8, hipMemcpyDeviceToHost);
+                    const char *hn[8] = {"requests waited for (6)", "weights + pool (7)", "stage done (0)", "phase A (1)", "X planes (2)", "phase B + s1 (3)", "phase C + scores (4)", "softmax + selection (5)"};
+                    const int order[8] = {6, 7, 0, 1, 2, 3, 4, 5};
+                    printf("STAMP3 %s heads, mean over waves 0-3 / 4-7:", part ? "machine" : "job");
+                    for (int oi = 0; oi < 8; oi++) {
+                        double m[2] = {0, 0}; int n[2] = {0, 0};
+                        for (int w = 0; w < grid * 8; w++) { const unsigned long long x = h3[(size_t)w * 8 + order[oi]]; if (x) { m[(w & 7) >> 2] += (double)(x - t0) / 100.0; n[(w & 7) >> 2]++; } }
+                        printf(" [%s] %.2f/%.2f", hn[oi], n[0] ? m[0] / n[0] : 0.0, n[1] ? m[1] / n[1] : 0.0);
+                    }
+                    printf("\n");
+                }
+                for (int part = 0; part < 2; part++) {                  // ... and inside phases B, C and the selection (H3S_RT)
+                    std::vector<unsigned long long> h3((size_t)grid * 64);
+                    (void)hipMemcpy(h3.data(), d_st3 + (size_t)((part ? 1024 : 512) + 256) * 64, h3.size() * 8, hipMemcpyDeviceToHost);
+                    const char *hn[8] = {"B products", "c2", "barrier", "s1 planes", "C products + partial scores", "value head", "barrier + scores", "probabilities"};
+                    printf("STAMP3 %s heads detail, mean over waves 0-3 / 4-7:", part ? "machine" : "job");
+                    for (int oi = 0; oi < 8; oi++) {
+                        double m[2] = {0, 0}; int n[2] = {0, 0};
+                        for (int w = 0; w < grid * 8; w++) { const unsigned long long x = h3[(size_t)w * 8 + oi]; if (x) { m[(w & 7) >> 2] += (double)(x - t0) / 100.0; n[(w & 7) >> 2]++; } }
+                        printf(" [%s] %.2f/%.2f", hn[oi], n[0] ? m[0] / n[0] : 0.0, n[1] ? m[1] / n[1] : 0.0);
+                    }
+                    printf("\n");
+                }
+                const char *gn[7] = {"gat entry", "staged", "projection", "pass 1", "pass 2", "pass 3 = first tile", "second tile"};
+                for (int i = 0; i < 7; i++) {                           // inside the GAT statements (mtfjsp_gat3x_body.h: G3_RT)
+                    printf("STAMP3 gat [%s] by wave:", gn[i]);
+                    for (int wv = 0; wv < 8; wv++) {
+                        double m = 0; int n = 0;
+                        for (int b = 0; b < grid; b++) { const unsigned long long x = h2[((size_t)b * 8 + wv) * 8 + i]; if (x) { m += (double)(x - t0) / 100.0; n++; } }
                         printf(" %.2f", n ? m / n : 0.0);
                     }
                     printf("\n");
@@ -3572,7 +3703,6 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
     if (!e->defer_poll && (rc = res_poll_failure(e))) return rc;
     const int B = e->cfg.batch, M = e->cfg.n_machine, R = B * M;
     auto W = [&](const std::string &k) { return e->w.at(k); };
-    auto WI = [&](const std::string &k) { return e->wimg.at(k); };
     int slot = 0;
     if (e->prefused.heads && !e->bn_mode && m_fea1 == e->prefused.f1 && m_fea2 == e->prefused.f2 && h_pooled_o == e->prefused.h_pooled_o &&
         mmask == e->prefused.mmask && prob == e->prefused.prob && h_pooled == e->prefused.h_pooled && machine_v == e->prefused.machine_v) {

@@ -3,18 +3,27 @@
 // (Round 3 kept these statements as text because the same statements as a __forceinline__ function miscomputed a few row tiles; round 4
 // found the cause — a packed-f32 instruction form that is unreliable next to matrix instructions, see the attention mixture below —
 // and both forms are built, linted and tested: -DMTFJSP_BODY_FUNCS, tools/isa_lint.py, tests/test_first_launch_gpu.py.)
+#ifndef GAT_ABL
+#define GAT_ABL 0                                                 // diagnostic timing ablations (wrong results): 1 the weight fragments are read from LDS once per pass, 2 no ELU
+#endif                                                            // exponentials, 4 no activation writes to LDS, 8 no split matrix products, 16 no row reductions
     unsigned char *s_wf = smem;                                   // 8*2*4*64*16 B
     float *s_a = reinterpret_cast<float *>(smem + 8 * 2 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
     double *s_red = reinterpret_cast<double *>(s_a);              // (after the last tile)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int j = lane & 31, h = lane >> 5, c4 = j * 4;
     const int m = lane & 15, q = lane >> 4;
 #ifdef MTFJSP_STAMP
 #define GAT_RT(i) do { if (A.stamps && lane == 0) { __builtin_amdgcn_sched_barrier(0); A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define GAT_RT(i) do { } while (0)
 #endif
+#if GAT_XCHG && defined(MTFJSP_STAMP3)
+#define G3_RT(i) do { if (XA.stamps && lane == 0) { __builtin_amdgcn_sched_barrier(0); XA.stamps[(size_t)256 * 64 + ((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define G3_RT(i) do { } while (0)
+#endif
     GAT_RT(0);
+    G3_RT(0);
+#if !GAT_PRESTAGED
     {   // stage the weight fragments: 65536 B = 8 x 16 B per thread, coalesced
         const float4 *src = reinterpret_cast<const float4 *>(A.Wx6);
         float4 *dst = reinterpret_cast<float4 *>(s_wf);
@@ -24,6 +33,7 @@
 #pragma unroll
         for (int i = 0; i < 8; i++) dst[i * 512 + tid] = v[i];
     }
+#endif
     const float wsinv = A.w_sinv;
     float *my_a = s_a + wave * 16 * HD;
     float *my_f = my_a + 15 * HD;                                 // the tile's feature words live in its last row until that row is written (p = 7)
@@ -34,11 +44,45 @@
     const int last = first + per < ntiles ? first + per : ntiles;
     float st_sum[8], st_sq[8];                                    // per lane: <= 2 machines x (tiles per wave) values — f32 partial sums, f64 from the fold on
     for (int c = 0; c < 8; c++) { st_sum[c] = 0.f; st_sq[c] = 0.f; }
-    float wp[4][8];                                               // this lane's 4 output columns of W1 (h = 0) or W2 (h = 1)
-    for (int x = 0; x < 4; x++)
-        for (int k = 0; k < 8; k++) wp[x][k] = h == 0 ? (k < 6 ? A.W1[(c4 + x) * 6 + k] : 0.f) : A.W2[(c4 + x) * 8 + k];
+    // input projection (+ the first pass' h W, folded on the host) on the f32 matrix instruction (round 5: it was 128 two-wide FMAs per
+    // lane and tile on vector units that bound this kernel, and its result had to travel through LDS into the accumulator layout):
+    // rows alternate node 0 (m_fea1, 6 words) / node 1 (m_fea2, 8 words), so a tile row is x_cat = [f1 | 0 0 | 0 x 8] or [0 x 8 | f2]
+    // against W_cat = [W1 ; 0 0 ; W2] (K = 16 = four 16x16x4 steps per column block).  B operand: lane (m, q) holds W_cat[4 ks + q][16 c + m]
+    // (GatArgs::Wq, formed on the host).
+    // (GAT_PRESTAGED — k_headsx_gat3x_headsx: the fragments above, this operand image and the attention vectors were copied into LDS by the
+    // waves that idle during the job selection, gat_prestage() in mtfjsp_encoder.hip; here they are a few LDS reads behind the barrier
+    // that ended the heads part — it was 6.4 us of requests and waits on every workgroup's critical path.)
+    float wq[8][4];
     float asrc[8], adst[8];
+#if GAT_PRESTAGED
+    {
+        const float4 *img = reinterpret_cast<const float4 *>(smem + GAT_IMG_OFF);
+        const float *ga = reinterpret_cast<const float *>(smem + GAT_IMG_OFF + 8192);
+#pragma unroll
+        for (int c = 0; c < 8; c++) { const float4 w4 = img[c * 64 + lane]; wq[c][0] = w4.x; wq[c][1] = w4.y; wq[c][2] = w4.z; wq[c][3] = w4.w; }
+#pragma unroll
+        for (int c = 0; c < 8; c++) { asrc[c] = ga[c * 16 + m]; adst[c] = ga[HD + c * 16 + m]; }
+    }
+#else
+#pragma unroll
+    for (int c = 0; c < 8; c++) { const float4 w4 = reinterpret_cast<const float4 *>(A.Wq)[c * 64 + lane]; wq[c][0] = w4.x; wq[c][1] = w4.y; wq[c][2] = w4.z; wq[c][3] = w4.w; }
     for (int c = 0; c < 8; c++) { asrc[c] = A.gat_a[c * 16 + m]; adst[c] = A.gat_a[HD + c * 16 + m]; }
+#endif
+#if GAT_PRESTAGED
+    // the feature words of this workgroup's own machines are in LDS: m_fea1 rows from the job selection that ran in this launch
+    // (HX_MF1_LDS), m_fea2 rows from gat_prestage() — no request to memory behind the barrier that ended the heads part
+    auto fetch_feat = [&](int tile) __attribute__((always_inline)) -> float4 {
+        const int r = tile * 16 + (lane >> 1), k0 = (lane & 1) * 4;
+        float x[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane < 32 && r < N) {
+            const int ul = (r >> 1) - first * 8, node = r & 1, width = node ? 8 : 6;
+            const float *src = reinterpret_cast<const float *>(smem + (node ? GAT_F2_OFF : GAT_F1_OFF)) + ul * width + k0;
+            for (int k = 0; k < 4; k++)
+                if (k0 + k < width) x[k] = src[k];
+        }
+        return make_float4(x[0], x[1], x[2], x[3]);
+    };
+#else
     auto fetch_feat = [&](int tile) __attribute__((always_inline)) -> float4 {   // lane L < 32: 4 of the 128 feature words of a tile
         const int r = tile * 16 + (lane >> 1), k0 = (lane & 1) * 4;
         float x[4] = {0.f, 0.f, 0.f, 0.f};
@@ -53,11 +97,16 @@
         }
         return make_float4(x[0], x[1], x[2], x[3]);
     };
+#endif
     int t_cur = first + wave, t_n1 = t_cur + 8;
     float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t_cur < last) fpre = fetch_feat(t_cur);
+#if !GAT_PRESTAGED
     __syncthreads();                                              // weight fragments are staged
+#endif
     GAT_RT(1);
+    G3_RT(1);
+    int g3_tile = 0;
 #ifdef MTFJSP_STAMP
     int gat_rt_i = 2;
 #endif
@@ -68,20 +117,12 @@
         // weight, so these rows ARE z of the first pass
         if (lane < 32) *reinterpret_cast<float4 *>(my_f + lane * 4) = fpre;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int p = 0; p < 8; p++) {
-            const int r = 2 * p + h;
-            const float4 fa = *reinterpret_cast<const float4 *>(my_f + r * 8), fb = *reinterpret_cast<const float4 *>(my_f + r * 8 + 4);
-            const float ff[8] = {fa.x, fa.y, fa.z, fa.w, fb.x, fb.y, fb.z, fb.w};
-            float o[4];
-#pragma unroll
-            for (int x = 0; x < 4; x++) {
-                float a = 0.f;
-#pragma unroll
-                for (int k = 0; k < 8; k++) a = fmaf(ff[k], wp[x][k], a);
-                o[x] = a;
-            }
-            *reinterpret_cast<float4 *>(my_a + gx_off(r, c4)) = make_float4(o[0], o[1], o[2], o[3]);
+        // A operand of the projection: lane (m, q) holds x_cat[row m][4 ks + q] — its two feature words f[m][q], f[m][4 + q] on the side of its node
+        float xa[4];
+        {
+            const float fa = my_f[m * 8 + q], fb = my_f[m * 8 + 4 + q];
+            const bool node1 = (m & 1) != 0;
+            xa[0] = node1 ? 0.f : fa; xa[1] = node1 ? 0.f : fb; xa[2] = node1 ? fa : 0.f; xa[3] = node1 ? fb : 0.f;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (t_n1 < last) fpre = fetch_feat(t_n1);
@@ -90,10 +131,13 @@
             f32x4 acc[8];
             if (pass == 0) {
 #pragma unroll
-                for (int c = 0; c < 8; c++)
+                for (int c = 0; c < 8; c++) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int i = 0; i < 4; i++) acc[c][i] = my_a[gx_off(4 * q + i, c * 16 + m)];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[ks], wq[c][ks], acc[c], 0, 0, 0);
+                MFMA_SETTLE8(acc);
+                if (g3_tile == 0) G3_RT(2);
             } else {
                 // the tile in operand layout: row m, k = 32ks + 8q .. +7, split into two f16 planes.  The values are ELU outputs of
                 // attention mixtures — unbounded in principle: one beyond the f16 range becomes (inf | -inf) pieces, their products
@@ -122,14 +166,15 @@
 #pragma unroll
                 for (int u = 0; u < 16; u++) {
                     const int cp = u >> 2, ks = u & 3;
-                    if (u + 1 < 16) {
+                    if (u + 1 < 16 && !(GAT_ABL & 1)) {
                         const int cn = (u + 1) >> 2, kn = (u + 1) & 3;
 #pragma unroll
                         for (int cc = 0; cc < 2; cc++)
 #pragma unroll
                             for (int p = 0; p < 2; p++) wr[(u + 1) & 1][cc][p] = *reinterpret_cast<const h16x8 *>(wl + (((2 * cn + cc) * 2 + p) * 4 + kn) * 1024);
                     }
-                    const h16x8 (*w)[2] = wr[u & 1];
+                    const h16x8 (*w)[2] = wr[(GAT_ABL & 1) ? 0 : (u & 1)];
+                    if (GAT_ABL & 8) continue;
 #pragma unroll
                     for (int cc = 0; cc < 2; cc++) acc[2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[1][ks], w[cc][0], acc[2 * cp + cc], 0, 0, 0);
 #pragma unroll
@@ -141,16 +186,36 @@
 #pragma unroll
                 for (int c = 0; c < 8; c++) acc[c] *= wsinv;                  // the weight image is scaled by a power of two
             }
+            // attention logits of the lane's two machines u = 0, 1: tile rows 4q + 2u (node 0), + 1 (node 1) = accumulator elements 2u, 2u + 1.
+            // Round 5: the six dot products of both machines are formed together — adst against the element pairs (0,1), (2,3) as two-wide FMAs,
+            // asrc against elements 0 and 2 — and reduced over the 16 lanes of the row one DPP add per value and step (it was 36 + 24
+            // instructions per machine; the vector units bound this kernel).
+            float s_u[2], d0_u[2], d1_u[2];
+            {
+                f32x2 dA = {0.f, 0.f}, dB = {0.f, 0.f};
+                float sA = 0.f, sB = 0.f;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {                                     // the lane's two machines: tile rows 4q+2u (node 0), +1 (node 1)
+                for (int c = 0; c < 8; c++) {
+                    const f32x2 ad = {adst[c], adst[c]};
+                    dA = gr_fma2(f32x2{acc[c][0], acc[c][1]}, ad, dA);
+                    dB = gr_fma2(f32x2{acc[c][2], acc[c][3]}, ad, dB);
+                    sA = __builtin_fmaf(asrc[c], acc[c][0], sA);
+                    sB = __builtin_fmaf(asrc[c], acc[c][2], sB);
+                }
+                float r0 = dA[0], r1 = dA[1], r2 = dB[0], r3 = dB[1];
+                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(sA), "+v"(sB));   // (scalars from here on: a packed add has no DPP operand)
+                if (GAT_ABL & 16) { s_u[0] = sA; s_u[1] = sB; d0_u[0] = r0; d1_u[0] = r1; d0_u[1] = r2; d1_u[1] = r3; }
+                else {
+                    s_u[0] = row_sum16(sA); s_u[1] = row_sum16(sB);
+                    d0_u[0] = row_sum16(r0); d1_u[0] = row_sum16(r1); d0_u[1] = row_sum16(r2); d1_u[1] = row_sum16(r3);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
                 const int i = 2 * u;
-                float s0 = 0.f, d0 = 0.f, d1 = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; c++) { const float z0 = acc[c][i], z1 = acc[c][i + 1]; s0 += asrc[c] * z0; d0 += adst[c] * z0; d1 += adst[c] * z1; }
-                s0 = row_sum16(s0); d0 = row_sum16(d0); d1 = row_sum16(d1);
-                float e00 = s0 + d0, e01 = s0 + d1;
-                e00 = e00 > 0.f ? e00 : 0.2f * e00;
-                e01 = e01 > 0.f ? e01 : 0.2f * e01;
+                float e00 = s_u[u] + d0_u[u], e01 = s_u[u] + d1_u[u];
+                e00 = fmaxf(e00, 0.2f * e00);                                 // LeakyReLU(0.2) (a NaN stays a NaN: both operands are)
+                e01 = fmaxf(e01, 0.2f * e01);
                 const float mx = fmaxf(e00, e01);
                 const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
                 const float inv = 1.0f / (x0 + x1);
@@ -169,11 +234,16 @@
                     for (int c = 0; c < 8; c++) {
                         const float z1 = acc[c][i + 1];
                         const f32x2 pz = f32x2{acc[c][i], z1} * alv;
-                        float n0 = pz[0] + pz[1], n1 = z1;
-                        n0 = n0 > 0.f ? n0 : __expf(n0) - 1.0f;               // ELU after passes 1 and 2 (ac:409-413); |err| < 2e-7
-                        n1 = n1 > 0.f ? n1 : __expf(n1) - 1.0f;
-                        my_a[gx_off(r, c * 16 + m)] = n0;
-                        my_a[gx_off(r + 1, c * 16 + m)] = n1;
+                        // ELU after passes 1 and 2 (ac:409-413) of the pair (mixture, node 1's own row): x > 0 ? x : exp(x) - 1 with the two
+                        // multiplications by log2(e) and the two "- 1" as two-wide instructions; |err| < 2e-7; the select (not a max) keeps a NaN
+                        float n0 = pz[0] + pz[1];
+                        asm volatile("" : "+v"(n0));                          // (a plain add: left to itself hipcc adds the halves with a swizzled packed add — the unreliable form above)
+                        const f32x2 nv = {n0, z1};
+                        const f32x2 tl = nv * f32x2{1.44269504088896340736f, 1.44269504088896340736f};
+                        const f32x2 em = ((GAT_ABL & 2) ? tl : f32x2{__builtin_amdgcn_exp2f(tl[0]), __builtin_amdgcn_exp2f(tl[1])}) + f32x2{-1.0f, -1.0f};
+                        if (GAT_ABL & 4) { asm volatile("" :: "v"(nv[0] > 0.f ? nv[0] : em[0]), "v"(nv[1] > 0.f ? nv[1] : em[1])); continue; }
+                        my_a[gx_off(r, c * 16 + m)] = nv[0] > 0.f ? nv[0] : em[0];
+                        my_a[gx_off(r + 1, c * 16 + m)] = nv[1] > 0.f ? nv[1] : em[1];
                     }
                 } else {
                     const bool valid = row0 + r < N;
@@ -190,8 +260,10 @@
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tile is complete before the next pass reads it
+            if (g3_tile == 0) { if (pass == 0) G3_RT(3); else if (pass == 1) G3_RT(4); else G3_RT(5); } else if (pass == 2) G3_RT(6);
         }
         t_cur = t_n1; t_n1 += 8;
+        g3_tile++;
 #ifdef MTFJSP_STAMP
         if (gat_rt_i == 2) GAT_RT(2); else if (gat_rt_i == 3) GAT_RT(3);
         gat_rt_i++;
@@ -234,3 +306,4 @@
     }
     GAT_RT(4);
 #undef GAT_RT
+#undef G3_RT

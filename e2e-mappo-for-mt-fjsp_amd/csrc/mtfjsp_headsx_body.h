@@ -171,7 +171,7 @@
             X3_RT(5);
 #endif
         }
-        STAMP(6);
+        STAMP(6); H3_RT(6);
         {
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 xp = z;
@@ -199,7 +199,7 @@
                 }
             } else if (sr < ng) xp = *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4);
 #endif
-            STAMP(7);
+            STAMP(7); H3_RT(7);
 #if HX_XCHG
             const float4 xo = sr < ng ? xo_pre : z;
 #else
@@ -216,7 +216,7 @@
         }
         for (int i = tid; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
         LDS_BARRIER();
-        STAMP(0);
+        STAMP(0); H3_RT(0);
         auto xnorm = [&](float4 v, bool valid) __attribute__((always_inline)) {
             if (!valid) return make_float4(0.f, 0.f, 0.f, 0.f);
             float y0 = fmaf(v.x, xs0, xh0), y1 = fmaf(v.y, xs1, xh1), y2 = fmaf(v.z, xs2, xh2), y3 = fmaf(v.w, xs3, xh3);
@@ -255,7 +255,7 @@
             const float c1v[4] = {fast_tanh(fmaf(ac[0], sWc0, bc0v.x)), fast_tanh(fmaf(ac[1], sWc0, bc0v.y)), fast_tanh(fmaf(ac[2], sWc0, bc0v.z)), fast_tanh(fmaf(ac[3], sWc0, bc0v.w))};
             put_planes(s_c1p, c1v);
         }
-        STAMP(1);
+        STAMP(1); H3_RT(1);
         const int ntl = (nrows + 15) >> 4;                          // 16-row tiles of this group (R for a full group of 16 instances)
         for (int tb = 0; tb < ntl; tb += HCH) {
             const int nt = (ntl - tb) < HCH ? (ntl - tb) : HCH;
@@ -274,18 +274,21 @@
                 *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1;
             }
             LDS_BARRIER();                                          // X planes, u and c1 are complete
-            STAMP(2);
+            STAMP(2); H3_RT(2);
             // ---- phase B: Wa x for every tile of the chunk (accumulators held); first chunk: c2 = tanh(Wc1 c1 + bc1)
             f32x4 accb[HCH];
 #pragma unroll
             for (int t = 0; t < HCH; t++) accb[t] = t < nt ? tile_x6(s_xs + t * X2_TILE, wB) : zero4;
+            H3S_RT(0);
             if (tb == 0) {
                 const f32x4 a0 = tile_x6(s_c1p, wA);
                 const float4 bc1v = *reinterpret_cast<const float4 *>(s_vec + 2 * HD + col4);
                 *reinterpret_cast<float4 *>(s_c2 + m * HX_CLDA + col4) =
                     make_float4(fast_tanh(fmaf(a0[0], sWc1, bc1v.x)), fast_tanh(fmaf(a0[1], sWc1, bc1v.y)), fast_tanh(fmaf(a0[2], sWc1, bc1v.z)), fast_tanh(fmaf(a0[3], sWc1, bc1v.w)));
             }
+            H3S_RT(1);
             LDS_BARRIER();                                          // every wave is done with the X planes: s1 overwrites them
+            H3S_RT(2);
             // s1 = tanh(Wa x + u[instance]) -> planes
 #pragma unroll
             for (int t = 0; t < HCH; t++) {
@@ -297,13 +300,14 @@
                     put_planes(s_xs + t * X2_TILE, sv);
                 }
             }
+            H3S_RT(3);
             LDS_BARRIER();                                          // s1 planes and c2 are complete
-            STAMP(3);
+            STAMP(3); H3_RT(3);
             // ---- phase C: s2 = tanh(W1 s1 + b1) ; partial scores of this wave's 16 columns
             {
                 const float4 b1v = *reinterpret_cast<const float4 *>(s_vec + 3 * HD + col4), w2v = *reinterpret_cast<const float4 *>(s_vec + 4 * HD + col4);
 #pragma unroll 1
-                for (int t = 0; t < HCH; t++) {                     // (rolled: this kernel runs once per workgroup from a cold instruction cache)
+                for (int t = 0; t < HCH; t++) {                     // (rolled; round 5 measured unroll 2 and 6, and two / three tile products interleaved per wave: no change)
                     if (t < nt) {
                         const f32x4 a0 = tile_x6(s_xs + t * X2_TILE, wC);
                         float v = fast_tanh(fmaf(a0[0], sW1, b1v.x)) * w2v.x;
@@ -316,6 +320,7 @@
                     }
                 }
             }
+            H3S_RT(4);
             if (tb == 0) {   // value head: 32 threads per instance row, 4 columns each, both outputs
                 const int r = tid >> 5, part = tid & 31;
                 float p0 = 0.f, p1 = 0.f;
@@ -327,6 +332,7 @@
                     if (A.range_flag && (v0 != v0 || v1 != v1)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
+            H3S_RT(5);
             LDS_BARRIER();
             if (tid < nt * 16) {
                 const int grow = tb * 16 + tid;
@@ -334,11 +340,18 @@
                 for (int w = 0; w < 8; w++) v += s_part[w * (HCH * 16) + tid];
                 if (grow < nrows) s_score[grow] = v * A.scale;
             }
+            H3S_RT(6);
             LDS_BARRIER();                                          // planes / s_part are reused by the next chunk
-            STAMP(4);
+            STAMP(4); H3_RT(4);
         }
 #if HX_XCHG
         X3_RT(6);
+#endif
+#ifdef HX_IDLE_HOOK
+        // the selection below keeps waves 0-3 (16 lanes per instance) busy for ~4 us while waves 4-7 have nothing to do, and the scorer's
+        // planes (the first 78 KB of LDS) are dead: the including kernel may give the idle waves work that touches neither s_score,
+        // s_mask nor s_part (k_headsx_gat3x_headsx: the GAT part's weight staging)
+        if (tid >= 256) { HX_IDLE_HOOK }
 #endif
         // ---- masked softmax per instance (ac:266-278 / ac:487-491): 16 lanes per instance; optional action selection
         // (Round 4 requested gather_from[row] and the job predecessor's machine of EVERY scorer row at the top of the kernel, so that the
@@ -359,6 +372,7 @@
                     if (A.range_flag && pr != pr) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     s_score[r0 * R + r] = pr;                           // lanes of one wave: visible to lane l == 0 below
                 }
+                H3S_RT(7);
                 if (A.sample_mode) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (l == 0) {
@@ -399,12 +413,18 @@
                                 od[0] = f0; od[1] = f1; od[2] = x; od[3] = f3; od[4] = f4; od[5] = f5;
                             }
                             A.mf.mmask_out[(size_t)b * M_ + mm] = mk;
+#ifdef HX_MF1_LDS
+                            {   // the GAT statements that follow in this launch take the row from LDS (as f32: what they would make of it)
+                                float *lf = (HX_MF1_LDS) + ((size_t)r0 * M_ + mm) * 6;
+                                lf[0] = (float)f0; lf[1] = (float)f1; lf[2] = (float)x; lf[3] = (float)f3; lf[4] = (float)f4; lf[5] = (float)f5;
+                            }
+#endif
                         }
                     }
                 }
             }
         }
-        STAMP(5);
+        STAMP(5); H3_RT(5);
     }
 #ifdef MTFJSP_STAMP
     if (A.stamps && lane == 0) for (int i = 0; i < 8; i++) A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + i] = ph[i];
