@@ -1232,6 +1232,7 @@ struct XchgArgs {
 #define X3_RT(i) do { } while (0)
 #endif
 #define H3S_RT(i) do { } while (0)
+#define H3T_RT(i) do { } while (0)
 #define H3_RT(i) do { } while (0)                                  // (the heads statements' phase boundaries; live only inside k_headsx_gat3x_headsx of the -DMTFJSP_STAMP3 build)
 #if MTFJSP_BODY_FUNCS & 1
 __device__ __forceinline__ void gat3x_body(const GatArgs &A, unsigned char *smem)
@@ -1272,6 +1273,38 @@ __device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t 
         c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
+}
+// the uniform number of instance b's draw (the part of pick_action that does not depend on the probabilities: k_headsx forms it early)
+__device__ __forceinline__ float pick_uniform(int b, uint64_t seed, uint64_t counter)
+{
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)counter, (uint32_t)(counter >> 32), 0x73616d70u};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    return (float)(c[0] >> 8) * (1.0f / 16777216.0f);      // [0,1)
+}
+// pick_action with the uniform number given (the same comparisons in the same order)
+__device__ __forceinline__ int pick_action_u(const float *p, int n, int greedy, float u)
+{
+    int pick = 0;
+    if (greedy) {
+        float best = p[0];
+        for (int i = 1; i < n; i++) if (p[i] > best) { best = p[i]; pick = i; }
+    } else {
+        float tot = 0.f;
+        for (int i = 0; i < n; i++) tot += p[i];
+        float acc = 0.f;
+        const float thr = u * tot;
+        pick = -1;
+        int last = 0;
+        for (int i = 0; i < n; i++) {
+            if (p[i] > 0.f) {
+                last = i;
+                acc += p[i];
+                if (pick < 0 && thr < acc) pick = i;
+            }
+        }
+        if (pick < 0) pick = last;
+    }
+    return pick;
 }
 __device__ __forceinline__ int pick_action(const float *p, int n, int b, int greedy, uint64_t seed, uint64_t counter)
 {
@@ -1730,6 +1763,8 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #undef H3_RT
 #define H3_RT(i) do { if (XA.stamps && (threadIdx.x & 63) == 0) { __builtin_amdgcn_sched_barrier(0); XA.stamps[(size_t)H3_BASE * 64 + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define H3_BASE 512
+#undef H3T_RT
+#define H3T_RT(i) do { if (XA.stamps && (threadIdx.x & 63) == 0) { __builtin_amdgcn_sched_barrier(0); XA.stamps[(size_t)(H3_BASE == 512 ? 1536 : 1792) * 64 + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #undef H3S_RT
 #define H3S_RT(i) do { if (XA.stamps && (threadIdx.x & 63) == 0) { __builtin_amdgcn_sched_barrier(0); XA.stamps[(size_t)(H3_BASE + 256) * 64 + ((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #endif
@@ -1774,6 +1809,8 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #define H3_RT(i) do { } while (0)
 #undef H3S_RT
 #define H3S_RT(i) do { } while (0)
+#undef H3T_RT
+#define H3T_RT(i) do { } while (0)
 #endif
     X3_RT(7);
 }
@@ -1793,7 +1830,7 @@ __global__ __launch_bounds__(512) void k_headsx_envstep(HeadArgs HA, EnvParams E
     __syncthreads();
     env_grp_body_dyn<OBS, 1, 8>(EP, smem);
 }
-static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
+static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64 + 2 * 512 * 4; }
 static size_t fused3_lds_bytes() { const size_t g = GAT_PRE_END; return headsx_lds_bytes() > g ? headsx_lds_bytes() : g; }   // k_headsx_gat3x_headsx: + the prestaged GAT images and feature rows (GAT_PRE_END)
 // The same kernel with TEN scorer tiles per chunk: a group of 16 instances with 7..10 candidates / machines each (J10M10: R = 10)
 // goes through the product phases once instead of twice (6 + 4 tiles, each chunk with its own staging, four barriers and latency chain)
@@ -1804,7 +1841,7 @@ __global__ __launch_bounds__(512) void k_headsx10(HeadArgs A)
     extern __shared__ __align__(16) unsigned char smem[];
 #include "mtfjsp_headsx_body.h"
 }
-static size_t headsx10_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64; }
+static size_t headsx10_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64 + 2 * 512 * 4; }
 #undef HCH
 #define HCH 6
 
@@ -3490,8 +3527,20 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
                     }
                     printf("\n");
                 }
-                const char *gn[7] = {"gat entry", "staged", "projection", "pass 1", "pass 2", "pass 3 = first tile", "second tile"};
-                for (int i = 0; i < 7; i++) {                           // inside the GAT statements (mtfjsp_gat3x_body.h: G3_RT)
+                for (int part = 0; part < 2; part++) {                  // ... and inside the selection (H3T_RT; waves 0-3)
+                    std::vector<unsigned long long> h3((size_t)grid * 64);
+                    (void)hipMemcpy(h3.data(), d_st3 + (size_t)(part ? 1792 : 1536) * 64, h3.size() * 8, hipMemcpyDeviceToHost);
+                    const char *hn[5] = {"picked, index handed over", "predecessor's machine", "t / p / transport requested", "t / p arrived", "means arrived"};
+                    printf("STAMP3 %s selection, mean over waves 0-3:", part ? "machine" : "job");
+                    for (int oi = 0; oi < 5; oi++) {
+                        double m = 0; int n = 0;
+                        for (int w = 0; w < grid * 8; w++) { const unsigned long long x = h3[(size_t)w * 8 + oi]; if (x) { m += (double)(x - t0) / 100.0; n++; } }
+                        printf(" [%s] %.2f", hn[oi], n ? m / n : 0.0);
+                    }
+                    printf("\n");
+                }
+                const char *gn[8] = {"gat entry", "staged", "projection", "pass 1", "pass 2", "pass 3 = first tile", "second tile", "all tiles done (barrier)"};
+                for (int i = 0; i < 8; i++) {                           // inside the GAT statements (mtfjsp_gat3x_body.h: G3_RT)
                     printf("STAMP3 gat [%s] by wave:", gn[i]);
                     for (int wv = 0; wv < 8; wv++) {
                         double m = 0; int n = 0;

@@ -8,7 +8,6 @@
 #endif                                                            // exponentials, 4 no activation writes to LDS, 8 no split matrix products, 16 no row reductions
     unsigned char *s_wf = smem;                                   // 8*2*4*64*16 B
     float *s_a = reinterpret_cast<float *>(smem + 8 * 2 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
-    double *s_red = reinterpret_cast<double *>(s_a);              // (after the last tile)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int m = lane & 15, q = lane >> 4;
 #ifdef MTFJSP_STAMP
@@ -273,17 +272,19 @@
 #if GAT_XCHG
     X3_RT(2);
 #endif
-    __syncthreads();                                              // every tile is done: s_red aliases them
-    for (int c = 0; c < 8; c++) {
-        double a = (double)st_sum[c], b = (double)st_sq[c];
-        a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-        b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-        if (q == 0) { s_red[wave * 256 + c * 16 + m] = a; s_red[wave * 256 + HD + c * 16 + m] = b; }
-    }
-    __syncthreads();
+    // (round 5: every lane parks its 16 f32 partial sums in its wave's own tile buffer — free once the wave's last tile is done, so nothing
+    // waits for the other waves first — and thread t < 256 adds up the 4 row quarters x 8 waves of its value in f64, in a fixed order; it
+    // was 64 ds_bpermute round trips of f64 halves per wave between two workgroup barriers: 2.1 us from the last tile to the atomics)
+    for (int c = 0; c < 8; c++) { my_a[c * 64 + lane] = st_sum[c]; my_a[(8 + c) * 64 + lane] = st_sq[c]; }
+    __syncthreads();                                              // (also: this workgroup's node rows are in memory before its machine heads read them)
+    G3_RT(7);
     if (tid < 256) {
         double v = 0;
-        for (int w = 0; w < 8; w++) v += s_red[w * 256 + tid];
+        {
+            const float *wf = s_a + ((tid >> 7) * 8 + ((tid & 127) >> 4)) * 64 + (tid & 15);
+            for (int w = 0; w < 8; w++)
+                for (int qq = 0; qq < 4; qq++) v += (double)wf[w * 16 * HD + qq * 16];
+        }
 #if GAT_XCHG
         // k_headsx_gat3x_headsx: the machine heads follow in THIS launch, behind one grid-wide exchange of these sums.  The protocol is
         // k_gin_res' (mtfjsp_gin_resident.h: count-carrying 64-bit words, one integer atomic per value, no barrier): the contribution

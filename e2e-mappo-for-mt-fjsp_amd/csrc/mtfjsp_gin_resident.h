@@ -306,24 +306,56 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             const int i = tid + 256 * k;
             cand_pre[k] = (A.candidate && i < ninst * A.J) ? A.candidate[(size_t)inst0 * A.J + i] : -1;
         }
+        // Every request of the prologue goes out before the first of them is waited for (round 5: as `for (i = tid; i < n; i += 256)` loops
+        // with a run-time bound the feature and adjacency copies were compiled into load -> s_waitcnt vmcnt(0) -> LDS store per iteration:
+        // ten dependent round trips, ~2.5 of the prologue's 4.1 us).  Indices are clamped into the workgroup's rows, not branched around.
         float *s_feat = s_ring;                                   // [nrows][12]
-        if (A.feat_f64) {
-            const double *src = reinterpret_cast<const double *>(A.tfea) + grow0 * 12;
-            for (int i = tid; i < nrows * 12; i += 256) s_feat[i] = (float)src[i];
-        } else {
-            const float4 *src = reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(A.tfea) + grow0 * 12);
-            for (int i = tid; i < nrows * 3; i += 256) reinterpret_cast<float4 *>(s_feat)[i] = src[i];
+        constexpr int NF4 = (GR_ROWS * 3 + 255) / 256, NER = (GR_ROWS + 255) / 256;
+        f32x4 fpre[NF4];
+        {   // (unconditional; f64 features: the same bytes lie inside the buffer and are overwritten below)
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(A.tfea) + grow0 * 12);
+            const int last = nrows * 3 - 1;
+#pragma unroll
+            for (int k = 0; k < NF4; k++) { const int i = tid + 256 * k; fpre[k] = src[i < last ? i : last]; }
         }
-        for (int r = tid; r < GR_ROWS; r += 256) {
-            unsigned cp = 0xffffffffu; float v0 = 0.f, v1 = 0.f;
-            if (r < nrows) {
-                const int2 cc = *reinterpret_cast<const int2 *>(A.ell_col + (grow0 + r) * 2);
-                const float2 vv = *reinterpret_cast<const float2 *>(A.ell_val + (grow0 + r) * 2);
-                const int base = (r / T) * T;
-                const unsigned r0 = cc.x >= 0 ? (unsigned)(base + cc.x) : 0xffffu, r1 = cc.y >= 0 ? (unsigned)(base + cc.y) : 0xffffu;
-                cp = r0 | (r1 << 16); v0 = cc.x >= 0 ? vv.x : 0.f; v1 = cc.y >= 0 ? vv.y : 0.f;
+        int2 ecc[NER]; float2 evv[NER];
+#pragma unroll
+        for (int k = 0; k < NER; k++) {
+            const int r = tid + 256 * k, rc = r < nrows ? r : nrows - 1;
+            ecc[k] = *reinterpret_cast<const int2 *>(A.ell_col + (grow0 + rc) * 2);
+            evv[k] = *reinterpret_cast<const float2 *>(A.ell_val + (grow0 + rc) * 2);
+        }
+        // (stored unconditionally too: a store behind `if (i < nrows * 3)` or behind `if (!A.feat_f64)` pulls its request down to itself or sends
+        // the seven registers through scratch memory; words beyond the workgroup's rows are copies nobody uses)
+#pragma unroll
+        for (int k = 0; k < NF4; k++) reinterpret_cast<f32x4 *>(s_feat)[tid + 256 * k] = fpre[k];
+        if (A.feat_f64) {                                         // f64 observations: converted here, over what the lines above left
+            const double *src = reinterpret_cast<const double *>(A.tfea) + grow0 * 12;
+            const int n12 = nrows * 12;
+            __syncthreads();
+#pragma unroll 1
+            for (int i0 = 0; i0 < n12; i0 += 256 * 9) {            // 9 requests in flight per thread
+                double d[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) { const int i = i0 + tid + 256 * k; d[k] = src[i < n12 ? i : n12 - 1]; }
+#pragma unroll
+                for (int k = 0; k < 9; k++) { const int i = i0 + tid + 256 * k; if (i < n12) s_feat[i] = (float)d[k]; }
             }
-            s_ellc[r] = cp; s_ellv0[r] = v0; s_ellv1[r] = v1; s_rowcand[r] = -1;
+        }
+#pragma unroll
+        for (int k = 0; k < NER; k++) {
+            const int r = tid + 256 * k;
+            if (r < GR_ROWS) {
+                unsigned cp = 0xffffffffu; float v0 = 0.f, v1 = 0.f;
+                if (r < nrows) {
+                    const int2 cc = ecc[k];
+                    const float2 vv = evv[k];
+                    const int base = (r / T) * T;
+                    const unsigned r0 = cc.x >= 0 ? (unsigned)(base + cc.x) : 0xffffu, r1 = cc.y >= 0 ? (unsigned)(base + cc.y) : 0xffffu;
+                    cp = r0 | (r1 << 16); v0 = cc.x >= 0 ? vv.x : 0.f; v1 = cc.y >= 0 ? vv.y : 0.f;
+                }
+                s_ellc[r] = cp; s_ellv0[r] = v0; s_ellv1[r] = v1; s_rowcand[r] = -1;
+            }
         }
         if (tid == 0) s_flag[1] = 0u;
         if (tid < 5 * (GR_NT / GR_GRP)) s_cnt[tid] = 0u;

@@ -11,6 +11,8 @@
     float *s_wc2 = s_score + HG * 64;                              // 2 * 128
     float *s_vec = s_wc2 + 2 * HD;                                 // b0 | bc0 | bc1 | b1 | w2
     unsigned char *s_mask = reinterpret_cast<unsigned char *>(s_vec + 5 * HD);   // HG * 64
+    int *s_gf = reinterpret_cast<int *>(s_mask + HG * 64);         // [512] gather_from of the first 512 scorer rows (the selection's task per row)
+    int *s_pm = s_gf + 512;                                        // [512] machine of that task's job predecessor (m_fea1)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int m = lane & 15, q = lane >> 4;
     const int col4 = 16 * wave + 4 * q;                            // this lane's 4 output columns
@@ -75,6 +77,13 @@
             asm volatile("" : "+v"(praw.x), "+v"(praw.y), "+v"(praw.z), "+v"(praw.w));   // (formed here: the 8 row registers are free before the weight requests go out)
         }
 #endif
+        const unsigned char r_mask = A.mask[(size_t)g0 * R + (tid < nrows ? tid : nrows - 1)];   // the group's action mask (rows beyond 512: fetched where they are stored)
+        // The selection at the end walks a chain of dependent requests — the picked row's task (gather_from), that task's job predecessor's
+        // machine (link), then the task's rows — behind one another, ~0.6 us each on every workgroup's critical path.  The first two links
+        // are walked for EVERY scorer row instead, up here where requests are free: index now, predecessor's machine behind the first
+        // barrier, both parked in LDS (rows beyond 512: the old way).  Pointers are chosen, not branched around (a request behind an `if`
+        // makes the later waits drain everything): without gather_from / m_fea1 some valid word of X is fetched and ignored.
+        const int r_gf = (A.gather_from ? A.gather_from + (size_t)g0 * R : reinterpret_cast<const int *>(A.X))[tid < nrows ? tid : nrows - 1];
         float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
         {   // (rows beyond the group's are clamped to its last one here and zeroed by xnorm() where they are used)
             int gi[HCH];
@@ -96,7 +105,9 @@
         WCOLX(wA, A.W0x, 1);                                        // Wb
         WCOLX(wB, A.W0x, 2);                                        // Wc
         WCOLX(wC, A.Wc0x, 0);
-        // (everything is in flight: now the stores that only needed the first few words)
+        // (everything is in flight) the uniform number of this thread's instance's draw (pick_action): ten Philox rounds that need no memory
+        const float u_pre = A.sample_mode == 1 ? pick_uniform(g0 + (tid >> 4), A.seed, A.counter) : 0.f;
+        // now the stores that only needed the first few words
         if (tid < 2 * HD) s_wc2[tid] = r_wc2;
         if (tid < HD) { s_vec[tid] = r_v0; s_vec[HD + tid] = r_v1; s_vec[2 * HD + tid] = r_v2; s_vec[3 * HD + tid] = r_v3; s_vec[4 * HD + tid] = r_v4; }
         if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
@@ -214,7 +225,17 @@
                 *reinterpret_cast<uint2 *>(dq) = b0; *reinterpret_cast<uint2 *>(dq + X6_PLANE) = b1;
             }
         }
-        for (int i = tid; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
+        if (tid < nrows) s_mask[tid] = r_mask;                      // (requested with the first phase's other loads)
+        short r_lk;
+        {   // second link of the selection's chain: the machine of the job predecessor of row tid's task
+            const int T_ = A.mf_on ? A.mf.T : 1, il = (int)__umulhi((unsigned)(tid < nrows ? tid : 0), invR);
+            int a = A.gather_from ? r_gf : 0;
+            if (a < 0 || a >= T_) a = 0;
+            const size_t row = (size_t)(g0 + il) * T_ + a;
+            r_lk = (A.mf_on ? reinterpret_cast<const short *>(A.mf.link) : reinterpret_cast<const short *>(A.X))[(A.mf_on && row > 0 ? row - 1 : 0) * 4];
+            s_gf[tid] = r_gf;
+        }
+        for (int i = tid + 512; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
         LDS_BARRIER();
         STAMP(0); H3_RT(0);
         auto xnorm = [&](float4 v, bool valid) __attribute__((always_inline)) {
@@ -255,6 +276,7 @@
             const float c1v[4] = {fast_tanh(fmaf(ac[0], sWc0, bc0v.x)), fast_tanh(fmaf(ac[1], sWc0, bc0v.y)), fast_tanh(fmaf(ac[2], sWc0, bc0v.z)), fast_tanh(fmaf(ac[3], sWc0, bc0v.w))};
             put_planes(s_c1p, c1v);
         }
+        s_pm[tid] = (int)r_lk;
         STAMP(1); H3_RT(1);
         const int ntl = (nrows + 15) >> 4;                          // 16-row tiles of this group (R for a full group of 16 instances)
         for (int tb = 0; tb < ntl; tb += HCH) {
@@ -377,13 +399,16 @@
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (l == 0) {
                         const int b = g0 + r0;
-                        const int pick = pick_action(s_score + r0 * R, R, b, A.sample_mode == 2, A.seed, A.counter);
+                        const int pick = pick_action_u(s_score + r0 * R, R, A.sample_mode == 2, u_pre);
                         A.idx_out[b] = pick;
                         if (A.logp_out) A.logp_out[b] = logf(s_score[r0 * R + pick]);
-                        const int gsel = A.gather_from ? A.gather_from[(size_t)b * R + pick] : pick;
+                        const int prow = r0 * R + pick;
+                        const int gsel = !A.gather_from ? pick : prow < 512 ? s_gf[prow] : A.gather_from[(size_t)b * R + pick];
                         if (A.gather_from && A.gathered_out) A.gathered_out[b] = gsel;
                         s_part[r0] = __int_as_float(gsel);                     // hand the selected task to the instance's 16 lanes (s_part is free now)
+                        s_part[HG + r0] = __int_as_float(prow);
                     }
+                    H3T_RT(0);
                     if (A.mf_on) {
                         // = k_mfea1 (pe:152-214) for the task just selected: the 16 lanes of the instance take the machines
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -393,16 +418,21 @@
                         const size_t row = (size_t)b * T_ + a;
                         int pm = 0;
                         if (a % M_ != 0) {
-                            pm = reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
+                            const int prow = __float_as_int(s_part[HG + r0]);
+                            pm = prow < 512 ? s_pm[prow] : (int)reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
                             if (pm < 0) pm += M_;                                             // python negative index (pe:206)
                         }
+                        H3T_RT(1);
                         for (int mm = l; mm < M_; mm += 16) {
                             const double tv = A.mf.t[row * M_ + mm], pv = A.mf.p[row * M_ + mm];
+                            H3T_RT(2);
                             const double ptv = tv * fabs(pv);
                             const unsigned char mk = (unsigned char)!(tv >= 0);              // run:258-259 ~(t >= 0)
                             const double x = (a % M_ != 0) ? A.mf.tt[((size_t)b * M_ + pm) * M_ + mm] : 0.0;
+                            H3T_RT(3);
                             const double f0 = tv > 0 ? tv : A.mf.mean3[row * 3 + 0], f1 = ptv > 0 ? ptv : A.mf.mean3[row * 3 + 1];
                             const double f4 = pv > 0 ? pv : A.mf.mean3[row * 3 + 2];
+                            H3T_RT(4);
                             const size_t o = ((size_t)b * M_ + mm) * 6;
                             const double f3 = (double)(1 - (int)mk), f5 = (double)(A.mf.shop[(size_t)b * M_ + mm] + 1);
                             if (A.mf.obs_f32) {

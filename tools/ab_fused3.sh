@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 for rep in 1 2; do
   for flags in "$@"; do
     echo "== flags: [$flags] (run $rep)" >> gpurun_out/ab_fused3.txt
-    python tools/stamp_fused3.py $flags 2>&1 | grep "STAMP3" | head -15 | grep -E "STAMP3 \(|heads" >> gpurun_out/ab_fused3.txt
+    python tools/stamp_fused3.py $flags 2>&1 | grep "STAMP3" | head -24 >> gpurun_out/ab_fused3.txt
   done
 done
 cat gpurun_out/ab_fused3.txt
