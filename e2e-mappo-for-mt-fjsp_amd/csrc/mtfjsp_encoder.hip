@@ -1752,6 +1752,9 @@ __device__ __forceinline__ void gat_prestage(const GatArgs &G, unsigned char *sm
 #pragma unroll
     for (int i = 0; i < 4; i++) d[i * 256 + t] = x[i];
 }
+// (Requesting one word of every line gat_prestage() reads at the top of the launch, so that they wait in this XCD's L2 — they were last
+// read a rollout step ago — shortened it by 2 us and lengthened the first phase of the job heads by 0.5 us: the launch ended 0.7-1.2 us
+// later in alternating runs on one box, because the selection on waves 0-3, not this copy, ends the heads part.  Not kept.)
 #if !MTFJSP_BODY_FUNCS
 __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArgs GA, HeadArgs HM, XchgArgs XG)
 {

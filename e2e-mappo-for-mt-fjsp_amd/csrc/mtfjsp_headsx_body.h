@@ -381,7 +381,61 @@
         // change (46.2 against 46.0 us) and the machine heads, which only paid for the extra requests, lost 0.4 us: not kept.)
         {
             const int r0 = tid >> 4, l = tid & 15;
+            // R <= 16 (round 5): lane l of the instance's 16 holds row l, and everything that went through LDS or a ds_bpermute per
+            // step — the two butterflies of the softmax, the sequential scans of the draw by ONE lane, the hand-over of the picked
+            // index — stays in registers: DPP partners within the row, the same additions in the same order (the same bits).
+            const bool rowwise = R <= 16;
+            float pr_l = 0.f;                                       // this lane's probability (rowwise)
+            int pick_l = 0;
+            if (r0 < ng && rowwise) {
+                auto dpp = [&](float x, auto Ctrl) __attribute__((always_inline)) {
+                    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(Ctrl)::value, 0xF, 0xF, true));
+                };
+                // partner lane ^ 8, ^ 4, ^ 2, ^ 1 (the order of __shfl_xor's butterfly): row rotations by 8 and by 4 / 12, quad permutes
+                auto x8 = [&](float x) __attribute__((always_inline)) { return dpp(x, std::integral_constant<int, 0x128>{}); };
+                auto x4 = [&](float x) __attribute__((always_inline)) {
+                    const float up = dpp(x, std::integral_constant<int, 0x12C>{}), dn = dpp(x, std::integral_constant<int, 0x124>{});   // row_ror:12 = lane + 4, row_ror:4 = lane - 4
+                    return (l & 4) ? dn : up;
+                };
+                auto x2 = [&](float x) __attribute__((always_inline)) { return dpp(x, std::integral_constant<int, 0x4E>{}); };
+                auto x1 = [&](float x) __attribute__((always_inline)) { return dpp(x, std::integral_constant<int, 0xB1>{}); };
+                const bool on = l < R && !s_mask[r0 * R + (l < R ? l : 0)];
+                const float sc = s_score[r0 * R + (l < R ? l : 0)];
+                float mx = on ? sc : -INFINITY;
+                mx = fmaxf(mx, x8(mx)); mx = fmaxf(mx, x4(mx)); mx = fmaxf(mx, x2(mx)); mx = fmaxf(mx, x1(mx));
+                const float ex = on ? __expf(sc - mx) : 0.f;
+                float sum = ex;
+                sum += x8(sum); sum += x4(sum); sum += x2(sum); sum += x1(sum);
+                pr_l = on ? ex / sum : 0.f;
+                if (l < R) {
+                    A.prob[(size_t)(g0 + r0) * R + l] = pr_l;
+                    if (A.range_flag && pr_l != pr_l) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+                H3S_RT(7);
+                if (A.sample_mode) {
+                    // pick_action_u's scans as a chain along the row: lane k takes lane k-1's running sum (row_shr:1) + its own p
+                    float run = pr_l;
+#pragma unroll 1
+                    for (int k = 1; k < R; k++) {
+                        const float prev = dpp(run, std::integral_constant<int, 0x111>{});
+                        if (l == k) run = prev + pr_l;
+                    }
+                    const float tot = __shfl(run, (lane & 48) + R - 1);            // (adding the masked rows' zeros is exact: the last row's sum is the total)
+                    const float thr = u_pre * tot;
+                    const bool pos = l < R && pr_l > 0.f;
+                    const unsigned hit = (unsigned)(__builtin_amdgcn_ballot_w64(pos && thr < run) >> (lane & 48)) & 0xffffu;
+                    const unsigned any = (unsigned)(__builtin_amdgcn_ballot_w64(pos) >> (lane & 48)) & 0xffffu;
+                    pick_l = hit ? __builtin_ctz(hit) : any ? 31 - __builtin_clz(any) : 0;
+                    if (A.sample_mode == 2) {                                       // greedy: the first row holding the maximum
+                        float best = l < R ? pr_l : -INFINITY;
+                        best = fmaxf(best, x8(best)); best = fmaxf(best, x4(best)); best = fmaxf(best, x2(best)); best = fmaxf(best, x1(best));
+                        const unsigned eq = (unsigned)(__builtin_amdgcn_ballot_w64(l < R && pr_l == best) >> (lane & 48)) & 0xffffu;
+                        pick_l = eq ? __builtin_ctz(eq) : 0;
+                    }
+                }
+            }
             if (r0 < ng) {
+              if (!rowwise) {
                 float mx = -INFINITY;
                 for (int r = l; r < R; r += 16) if (!s_mask[r0 * R + r]) mx = fmaxf(mx, s_score[r0 * R + r]);
                 for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
@@ -394,14 +448,15 @@
                     if (A.range_flag && pr != pr) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     s_score[r0 * R + r] = pr;                           // lanes of one wave: visible to lane l == 0 below
                 }
-                H3S_RT(7);
+              }
                 if (A.sample_mode) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    const float p_pick = rowwise ? __shfl(pr_l, (lane & 48) + pick_l) : 0.f;
                     if (l == 0) {
                         const int b = g0 + r0;
-                        const int pick = pick_action_u(s_score + r0 * R, R, A.sample_mode == 2, u_pre);
+                        const int pick = rowwise ? pick_l : pick_action_u(s_score + r0 * R, R, A.sample_mode == 2, u_pre);
                         A.idx_out[b] = pick;
-                        if (A.logp_out) A.logp_out[b] = logf(s_score[r0 * R + pick]);
+                        if (A.logp_out) A.logp_out[b] = logf(rowwise ? p_pick : s_score[r0 * R + pick]);
                         const int prow = r0 * R + pick;
                         const int gsel = !A.gather_from ? pick : prow < 512 ? s_gf[prow] : A.gather_from[(size_t)b * R + pick];
                         if (A.gather_from && A.gathered_out) A.gathered_out[b] = gsel;
@@ -411,15 +466,20 @@
                     H3T_RT(0);
                     if (A.mf_on) {
                         // = k_mfea1 (pe:152-214) for the task just selected: the 16 lanes of the instance take the machines
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         const int b = g0 + r0, T_ = A.mf.T, M_ = A.mf.M;
-                        int a = __float_as_int(s_part[r0]);
+                        int a, prow_m;
+                        if (rowwise) {                                          // every lane of the row knows the pick: no hand-over through LDS
+                            prow_m = r0 * R + pick_l;
+                            a = !A.gather_from ? pick_l : prow_m < 512 ? s_gf[prow_m] : A.gather_from[(size_t)b * R + pick_l];
+                        } else {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            a = __float_as_int(s_part[r0]); prow_m = __float_as_int(s_part[HG + r0]);
+                        }
                         if (a < 0 || a >= T_) a = 0;
                         const size_t row = (size_t)b * T_ + a;
                         int pm = 0;
                         if (a % M_ != 0) {
-                            const int prow = __float_as_int(s_part[HG + r0]);
-                            pm = prow < 512 ? s_pm[prow] : (int)reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
+                            pm = prow_m < 512 ? s_pm[prow_m] : (int)reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
                             if (pm < 0) pm += M_;                                             // python negative index (pe:206)
                         }
                         H3T_RT(1);
