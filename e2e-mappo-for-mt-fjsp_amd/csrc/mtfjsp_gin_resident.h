@@ -987,6 +987,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         float *s_part = reinterpret_cast<float *>(s_planes);      // [2 * GR_NT chunks][2 segments][128] = 36 KB: the plane buffers and the first 2 KB of the ring area
         static_assert(2 * GR_NT * 2 * HD * 4 <= 2 * GR_TILE + 4096, "partial pool sums: plane buffers + 4 KB");
         float *tb = s_ring + 1024 + wave * (2 * 32 * 36);         // transposition buffers: ring area past those 4 KB
+        float *s_wtab = s_ring + 1024 + 4 * (2 * 32 * 36);        // [17][16]: row j = 1 for the first j of a chunk's 16 rows, 0 for the others (pool_tile)
+        for (int i = tid; i < 17 * 16; i += 256) s_wtab[i] = (i & 15) < (i >> 4) ? 1.0f : 0.0f;
         float4 S[4], Hs[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -1005,23 +1007,33 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         for (int rt = 0; rt < GR_NT; rt++) slot[rt] = (GR_ABL & 32) ? -1 : s_rowcand[rt * 32 + n_l];
         LDS_BARRIER();                                                // the plane buffers are no longer read
         // gcn:192 for one tile: rows 16h .. 16h+15 of column c from the transposition buffer, split at the instance boundary
-        auto pool_tile = [&](int rt) __attribute__((always_inline)) {
+        // pool_load: the requests (a chunk's 16 values of column c, its weights) — issued a tile's BatchNorm + ReLU ahead of pool_math, which
+        // would otherwise meet an LDS round trip with nothing to cover it (one wave per SIMD)
+        float x[16];
+        float4 w0, w1, w2, w3;
+        auto pool_load = [&](int rt) __attribute__((always_inline)) {
             const float *rb = tb + (rt & 1) * (32 * 36) + (16 * h) * 36 + c;
-            float x[16];
 #pragma unroll
             for (int i = 0; i < 16; i++) x[i] = rb[i * 36];
-            // the chunk's total by a pairwise tree, the part in front of the instance boundary by masked FMAs, the rest as their difference
-            // (round 3 accumulated both parts with masked FMAs: 16 more vector instructions per tile)
-            const float fb = (float)left;
-            float sa0 = 0.f, sa1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                const float wa = __builtin_amdgcn_fmed3f(fb - (float)i, 0.f, 1.f), wb_ = __builtin_amdgcn_fmed3f(fb - (float)(i + 1), 0.f, 1.f);   // 1 while i < left
-                sa0 = __builtin_fmaf(x[i], wa, sa0);
-                sa1 = __builtin_fmaf(x[i + 1], wb_, sa1);
-            }
-            const float tot = (((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]))) + (((x[8] + x[9]) + (x[10] + x[11])) + ((x[12] + x[13]) + (x[14] + x[15])));
-            const float sa = sa0 + sa1;
+            const float4 *wt = reinterpret_cast<const float4 *>(s_wtab + (left < 16 ? left : 16) * 16);
+            w0 = wt[0]; w1 = wt[1]; w2 = wt[2]; w3 = wt[3];
+        };
+        auto pool_math = [&](int rt) __attribute__((always_inline)) {
+            // the chunk's total by a pairwise tree of two-wide adds, the part in front of the instance boundary by two-wide FMAs against the
+            // 0 / 1 weights of row `left` of s_wtab (round 5: the weights were formed per value — a subtraction, a clamp and an FMA each, 48
+            // vector instructions per tile where the vector unit is what this phase waits for), the rest as their difference
+            f32x2 sa2 = gr_fma2(f32x2{x[0], x[1]}, f32x2{w0.x, w0.y}, f32x2{0.f, 0.f});
+            sa2 = gr_fma2(f32x2{x[2], x[3]}, f32x2{w0.z, w0.w}, sa2);
+            sa2 = gr_fma2(f32x2{x[4], x[5]}, f32x2{w1.x, w1.y}, sa2);
+            sa2 = gr_fma2(f32x2{x[6], x[7]}, f32x2{w1.z, w1.w}, sa2);
+            sa2 = gr_fma2(f32x2{x[8], x[9]}, f32x2{w2.x, w2.y}, sa2);
+            sa2 = gr_fma2(f32x2{x[10], x[11]}, f32x2{w2.z, w2.w}, sa2);
+            sa2 = gr_fma2(f32x2{x[12], x[13]}, f32x2{w3.x, w3.y}, sa2);
+            sa2 = gr_fma2(f32x2{x[14], x[15]}, f32x2{w3.z, w3.w}, sa2);
+            const f32x2 t2 = gr_add2(gr_add2(gr_add2(f32x2{x[0], x[1]}, f32x2{x[2], x[3]}), gr_add2(f32x2{x[4], x[5]}, f32x2{x[6], x[7]})),
+                                     gr_add2(gr_add2(f32x2{x[8], x[9]}, f32x2{x[10], x[11]}), gr_add2(f32x2{x[12], x[13]}, f32x2{x[14], x[15]})));
+            const float tot = t2[0] + t2[1];
+            const float sa = sa2[0] + sa2[1];
             float *pp = s_part + ((2 * rt + h) * 2) * HD + 32 * wave + c;
             pp[0] = left >= 16 ? tot : sa; pp[HD] = left >= 16 ? 0.f : tot - sa;
             left -= 32;                                               // on to this lane's rows of the next tile (T >= 16: at most two instances further)
@@ -1031,11 +1043,14 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         gr_static_for<GR_NT>([&](auto Tc) __attribute__((always_inline)) {
             constexpr int rt = decltype(Tc)::value;
             const f32x16 &a = GR_TILEVAL(rt);
+            if constexpr (rt > 0) { if (!(GR_ABL & 16)) pool_load(rt - 1); }     // one tile behind: its writes have landed (the other buffer)
             float4 v[4];
 #pragma unroll
-            for (int g = 0; g < 4; g++)
-                v[g] = make_float4(bn_relu_ss(a[4 * g], S[g].x, Hs[g].x), bn_relu_ss(a[4 * g + 1], S[g].y, Hs[g].y),
-                                   bn_relu_ss(a[4 * g + 2], S[g].z, Hs[g].z), bn_relu_ss(a[4 * g + 3], S[g].w, Hs[g].w));
+            for (int g = 0; g < 4; g++) {
+                const f32x2 lo = __builtin_elementwise_max(gr_fma2(f32x2{a[4 * g], a[4 * g + 1]}, f32x2{S[g].x, S[g].y}, f32x2{Hs[g].x, Hs[g].y}), f32x2{0.f, 0.f});
+                const f32x2 hi = __builtin_elementwise_max(gr_fma2(f32x2{a[4 * g + 2], a[4 * g + 3]}, f32x2{S[g].z, S[g].w}, f32x2{Hs[g].z, Hs[g].w}), f32x2{0.f, 0.f});
+                v[g] = make_float4(lo[0], lo[1], hi[0], hi[1]);                  // = bn_relu_ss: max(fma(a, scale, shift), 0)
+            }
             float *wb = tb + (rt & 1) * (32 * 36);
 #pragma unroll
             for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(wb + n * 36 + 8 * g + 4 * h) = v[g];
@@ -1049,10 +1064,10 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 #pragma unroll
                 for (int g = 0; g < 4; g++) *reinterpret_cast<float4 *>(d + 8 * g) = v[g];
             }
-            if constexpr (rt > 0) { if (!(GR_ABL & 16)) pool_tile(rt - 1); }     // one tile behind: its writes have landed
+            if constexpr (rt > 0) { if (!(GR_ABL & 16)) pool_math(rt - 1); }
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (!(GR_ABL & 16)) pool_tile(GR_NT - 1);
+        if (!(GR_ABL & 16)) { pool_load(GR_NT - 1); pool_math(GR_NT - 1); }
         LDS_BARRIER();
         const float invT = 1.0f / (float)T;
         for (int item = tid; item < ninst * HD; item += 256) {
