@@ -78,6 +78,12 @@
         }
 #endif
         const unsigned char r_mask = A.mask[(size_t)g0 * R + (tid < nrows ? tid : nrows - 1)];   // the group's action mask (rows beyond 512: fetched where they are stored)
+#if !HX_XCHG
+        // the two embedding rows of this thread's instance (the stage below used to request them where it needed them: a memory round trip
+        // on every workgroup's critical path, round 5); without `pooled` (it is formed here from X) some valid row is fetched and ignored
+        const float4 xp_top = *reinterpret_cast<const float4 *>((A.pooled ? A.pooled : A.other) + (size_t)(g0 + (sr < ng ? sr : ng - 1)) * HD + sc4);
+        const float4 xo_top = *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + (sr < ng ? sr : ng - 1)) * HD + sc4);
+#endif
         // The selection at the end walks a chain of dependent requests — the picked row's task (gather_from), that task's job predecessor's
         // machine (link), then the task's rows — behind one another, ~0.6 us each on every workgroup's critical path.  The first two links
         // are walked for EVERY scorer row instead, up here where requests are free: index now, predecessor's machine behind the first
@@ -208,13 +214,13 @@
                     xp = make_float4(a0 * ir, a1 * ir, a2 * ir, a3 * ir);
                     *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
                 }
-            } else if (sr < ng) xp = *reinterpret_cast<const float4 *>(A.pooled + (size_t)(g0 + sr) * HD + sc4);
+            } else if (sr < ng) xp = xp_top;
 #endif
             STAMP(7); H3_RT(7);
 #if HX_XCHG
             const float4 xo = sr < ng ? xo_pre : z;
 #else
-            const float4 xo = sr < ng ? *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + sr) * HD + sc4) : z;
+            const float4 xo = sr < ng ? xo_top : z;
 #endif
             {
                 const float vp[4] = {xp.x, xp.y, xp.z, xp.w}, vo[4] = {xo.x, xo.y, xo.z, xo.w};
