@@ -88,11 +88,14 @@ struct GemmArgs {
     } while (0)
 
 // tanh(x) = 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units: |error| < 3e-7 absolute (the scorer/critic heads are
-// checked against the reference at 1e-4); saturates correctly for |x| large.
+// checked against the reference at 1e-4); saturates correctly for |x| large, a NaN stays a NaN.  Five instructions: multiply, v_exp_f32, add,
+// v_rcp_f32 (1 ulp), FMA.  (Until round 5 the quotient was written __fdividef(2, e + 1), which hipcc expands into the full IEEE division —
+// two v_div_scale, v_rcp, four FMAs, v_div_fmas, v_div_fixup: 16 instructions per tanh, ~60 tanh per wave and heads part, a third of
+// the heads' vector instructions.)
 __device__ __forceinline__ float fast_tanh(float x)
 {
-    const float e = __expf(2.0f * x);
-    return 1.0f - __fdividef(2.0f, e + 1.0f);
+    const float e = __builtin_amdgcn_exp2f(x * 2.885390081777926815f);        // exp(2x) = 2^(2 x log2 e)
+    return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
 // A vector instruction must not read the result of a matrix instruction before the matrix pipe has written it back, and gfx950 does NOT
@@ -2413,6 +2416,7 @@ struct mtfjsp_encoder {
     float *zA = nullptr, *zB = nullptr;     // [B*T,128] ping-pong
     float *cand_feat = nullptr;             // [B*max(J,M),128]
     float *u = nullptr, *c1 = nullptr, *c2 = nullptr, *hm_b = nullptr, *pooled_int = nullptr;   // [B,128]
+    bool hm_b_valid = false;                // hm_b holds the broadcast of the current job_actor._input (rebuilt when that weight is loaded again)
     float *node = nullptr;                  // [B*M,128]
     double *stats = nullptr;                // [8][STAT_REP][256]: slots 0..5 GIN layers, 6/7 machine path (alternating)
     bool gin_slot5_dirty = false;           // slots 0..4 zeroed by the job heads, slot 5 still holds sums (zeroed by the machine heads)
@@ -2786,6 +2790,7 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
     if (it != e->w.end()) d = it->second;
     else { if (dalloc(e, &d, (size_t)numel)) return MTFJSP_ERR_HIP; e->w[key] = d; }
     HIPCHK(e, hipMemcpy(d, data, (size_t)numel * 4, hipMemcpyHostToDevice));
+    if (key == "job_actor._input") e->hm_b_valid = false;
     if ((key.size() >= 11 && key.compare(key.size() - 11, 11, "gat_layer.W") == 0) || key.find("m_fea_1_fcl.weight") != std::string::npos ||
         key.find("m_fea_2_fcl.weight") != std::string::npos) {
         e->hostw[key].assign(data, data + numel);
@@ -3645,9 +3650,12 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
     if (rc) return rc;
     // ---- heads (ac:205-293): score = L2 tanh(L1 tanh(Wa cand + Wb pooled + Wc hm + b0))
     const float *hm = h_m_prev;
-    if (!hm) {
-        Timed t(e, "small");
-        hipLaunchKernelGGL(k_bcast128, dim3((B * HD + 255) / 256), dim3(256), 0, e->stream, B, W("job_actor._input"), e->hm_b);
+    if (!hm) {                                                     // first decision of an episode: the learned `_input` row for every instance (a constant
+        if (!e->hm_b_valid) {                                      // of the weights: broadcast once per weight load, not once per episode)
+            Timed t(e, "small");
+            hipLaunchKernelGGL(k_bcast128, dim3((B * HD + 255) / 256), dim3(256), 0, e->stream, B, W("job_actor._input"), e->hm_b);
+            e->hm_b_valid = true;
+        }
         hm = e->hm_b;
     }
     {
