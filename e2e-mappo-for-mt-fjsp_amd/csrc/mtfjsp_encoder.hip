@@ -2405,6 +2405,7 @@ struct mtfjsp_encoder {
     std::map<std::string, float *> wt;      // transposed [in,out] copies of the 128-wide Linear weights (split per 128-block of `in`)
     std::map<std::string, std::vector<float>> hostw;   // host copies of gat_layer.W / m_fea_*_fcl.weight (inputs of the fused projections)
     std::map<std::string, float *> wfused;  // per prefix + "1"/"2": (m_fea_k_fcl.weight^T . gat_layer.W)^T, [128,6] / [128,8]
+    std::map<std::string, size_t> wx6_bytes;   // size of each wx6 image
     std::map<std::string, void *> wx6;      // 128x128 Linear weights as 2 f16 planes (scaled) in k_gemm_x6's register-image order; GAT W / first Linear: 3 bf16 planes
     std::map<std::string, void *> wx32;     // GIN Linear weights as operand-piece planes in k_gin_res's (32x32x16) register-image order
     std::map<std::string, float> wx32_sinv; // ... 1 / the power-of-two scale folded into that image
@@ -2463,6 +2464,7 @@ struct mtfjsp_encoder {
     // 220.4 against 217.6 us per step, three alternating runs on one box — because the heads' 8 waves take the 16 instances in two
     // rounds where k_env_grp16's 16 waves take them in one: the second round costs more than the launch boundary saves
     bool fuse_env = getenv("MTFJSP_FUSED_ENV") != nullptr;
+    bool warm_heads = !getenv("MTFJSP_NO_WARM_HEADS");          // k_gin_res requests the heads launch's weight lines in its last phase
     struct { bool armed = false, done = false; EnvParams P; } env_step;          // groups of 8 instances in k_headsx when groups of 16 fill at most half the CUs
     // streaming GIN launches: the two inner Linears of an MLP in one launch behind a statistics-only pass (mtfjsp_gemm_pair.h).
     // MTFJSP_FUSE_PAIR=1: always; -1: where the activation matrix exceeds the 256 MB memory-side cache; 0 (default): never —
@@ -2820,6 +2822,7 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
         if (kt != e->wx6.end()) dx = kt->second;
         else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx6[key] = dx; }
         HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
+            e->wx6_bytes[key] = im.size() * 2;
     }
     if (key.find("feature_extract.mlps.") != std::string::npos && key.size() > 7 && key.compare(key.size() - 7, 7, ".weight") == 0 &&
         key.find("linears") != std::string::npos) {
@@ -2859,6 +2862,7 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
         if (kt != e->wx32.end()) dx = kt->second;
         else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx32[key] = dx; }
         HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
+            e->wx6_bytes[key] = im.size() * 2;
         e->wx32_sinv[key] = 1.0f / scale;
     }
     // 128-wide Linear weights [out=128, in=128*k] and gat W [in,out]: keep GEMM-ready [in-block][k][n] copies
@@ -2920,6 +2924,7 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
             if (kt != e->wx6.end()) dx = kt->second;
             else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx6[key] = dx; }
             HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
+            e->wx6_bytes[key] = im.size() * 2;
         }
         if (!is_gat_w) {
             // k_gemm_x6 / k_headsx: 2-way f16 split (round to nearest) of the weight scaled by a power of two, per 128-wide input block
@@ -2948,6 +2953,7 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
             if (kt != e->wx6.end()) dx = kt->second;
             else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx6[key] = dx; }
             HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
+            e->wx6_bytes[key] = im.size() * 2;
         }
     }
     return MTFJSP_OK;
@@ -3176,6 +3182,19 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
     a.bar = e->res_bar; a.epoch = e->res_epoch++; a.fail = e->res_fail; a.range_flag = e->range_flag;
     a.candidate = candidate; a.pooled = h_pooled; a.cand_feat = cand_feat; a.h_nodes = h_nodes; a.zspill = e->res_zspill;
     a.inv_rows = 1.0 / ((double)B * (double)T);
+    if (pre == "job_actor." && e->warm_heads) {
+        // what the heads launch behind this one reads first — the weight images of both actors' heads and of the GAT passes, last read a
+        // rollout step ago and evicted from the XCDs' L2 since — is requested (one word per 128-byte line, dropped) in this kernel's last phase
+        const char *keys[9] = {"job_actor.o_policy.linears.0.weight", "job_actor.job_critic.linears.0.weight", "job_actor.o_policy.linears.1.weight",
+                               "job_actor.job_critic.linears.1.weight", "machine_actor.gat_layer.W", "machine_actor.m_policy.linears.0.weight",
+                               "machine_actor.machine_critic.linears.0.weight", "machine_actor.m_policy.linears.1.weight", "machine_actor.machine_critic.linears.1.weight"};
+        for (const char *k : keys) {
+            auto it = e->wx6.find(k);
+            auto bt = e->wx6_bytes.find(k);
+            if (it == e->wx6.end() || bt == e->wx6_bytes.end() || a.nwarm >= GR_MAXWARM) continue;
+            a.warm[a.nwarm] = it->second; a.warm_lines[a.nwarm] = (unsigned)(bt->second / 128); a.nwarm++;
+        }
+    }
     if (++e->res_launches == e->res_fail_at) a.expect_extra = 1u;      // (diagnostic) this launch's barriers never complete
 #ifdef GR_STAMP
     static unsigned long long *d_st = nullptr;

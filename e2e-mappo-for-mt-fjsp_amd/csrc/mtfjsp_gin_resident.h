@@ -68,6 +68,7 @@
 #define GR_PLANE (32 * GR_ROWB)
 #define GR_TILE (2 * GR_PLANE)                // a tile buffer: the (high | low) f16 planes of 32 rows
 #define GR_MAXCAND 384
+#define GR_MAXWARM 10
 #define GR_MAXT 65                        // rows per instance: the in-edge sources of a tile lie within two tiles of it
 #define GR_MINT 16                        // ... and a 16-row run spans at most two instances (pooling)
 #define GR_MAXIPC 64                      // instances per workgroup (u8 instance ids; pool accumulators in the ring area)
@@ -115,6 +116,9 @@ struct GinResArgs {
     int barrier_only;                     // census launch: barriers only
     unsigned expect_extra;                // diagnostic (MTFJSP_GIN_RES_FAIL_AT): the barriers wait for this many workgroups that do not exist -> time-out path
     unsigned long long *stamps;           // diagnostic build only (-DGR_STAMP): [blocks][64] s_memrealtime at the phase boundaries
+    const void *warm[GR_MAXWARM];         // buffers the NEXT launch reads first: one word of every 128-byte line is requested in the last phase, so that
+    unsigned warm_lines[GR_MAXWARM];      // the lines wait in this XCD's L2 (workgroups blockIdx % 8 share an XCD; each requests its share)
+    int nwarm;
 };
 #define GR_STATS_PART (6 * 8 * HD * 2)                            // 64-bit words: per layer, per dispatch group: (sum, sumsq) per column
 #define GR_STATS_SET GR_STATS_PART
@@ -989,6 +993,21 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         float *tb = s_ring + 1024 + wave * (2 * 32 * 36);         // transposition buffers: ring area past those 4 KB
         float *s_wtab = s_ring + 1024 + 4 * (2 * 32 * 36);        // [17][16]: row j = 1 for the first j of a chunk's 16 rows, 0 for the others (pool_tile)
         for (int i = tid; i < 17 * 16; i += 256) s_wtab[i] = (i & 15) < (i >> 4) ? 1.0f : 0.0f;
+        // ONE request per thread on behalf of the next launch (GinResArgs::warm): thread (blockIdx / 8) * 256 + tid of this XCD's workgroups
+        // takes that line of the concatenated buffers (lines beyond the XCD's thread count are not requested); the word is dropped behind
+        // the last tile, where it has long arrived — no wait of this phase can be held up by it
+        unsigned warm_word = 0;
+        if (A.nwarm > 0) {
+            unsigned l = (blockIdx.x >> 3) * 256u + (unsigned)tid;
+            const unsigned char *wp = reinterpret_cast<const unsigned char *>(A.warm[0]);
+            bool found = false;
+            for (int w = 0; w < A.nwarm; w++) {
+                const unsigned nl = A.warm_lines[w];
+                if (!found && l < nl) { wp = reinterpret_cast<const unsigned char *>(A.warm[w]) + (size_t)l * 128; found = true; }
+                if (!found) l -= nl;
+            }
+            warm_word = *reinterpret_cast<const unsigned *>(wp);
+        }
         float4 S[4], Hs[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -1068,6 +1087,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
             __builtin_amdgcn_sched_barrier(0);
         });
         if (!(GR_ABL & 16)) { pool_load(GR_NT - 1); pool_math(GR_NT - 1); }
+        asm volatile("" :: "v"(warm_word));
         LDS_BARRIER();
         const float invT = 1.0f / (float)T;
         for (int item = tid; item < ninst * HD; item += 256) {
