@@ -3194,6 +3194,8 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
             if (it == e->wx6.end() || bt == e->wx6_bytes.end() || a.nwarm >= GR_MAXWARM) continue;
             a.warm[a.nwarm] = it->second; a.warm_lines[a.nwarm] = (unsigned)(bt->second / 128); a.nwarm++;
         }
+        auto q = e->wfused.find("machine_actor.q");               // the GAT projection's operand image (8 KB), once it has been formed
+        if (q != e->wfused.end() && a.nwarm < GR_MAXWARM) { a.warm[a.nwarm] = q->second; a.warm_lines[a.nwarm] = 64; a.nwarm++; }
     }
     if (++e->res_launches == e->res_fail_at) a.expect_extra = 1u;      // (diagnostic) this launch's barriers never complete
 #ifdef GR_STAMP

@@ -301,6 +301,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 
     // ---------------------------------------------------------------- prologue: features + adjacency to LDS, zero the planes
     GR_STAMP_AT(32);
+    f32x4 w0pre[3];                                               // the first Linear's weight image (requested in the prologue)
     for (int i = blockIdx.x * 256 + tid; i < GR_STATS_SET; i += (int)gridDim.x * 256) A.stats_next[i] = 0ull;
     {
         // (the candidate indices are requested with everything else: their use below would otherwise be a second memory round trip)
@@ -361,11 +362,19 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
                 s_ellc[r] = cp; s_ellv0[r] = v0; s_ellv1[r] = v1; s_rowcand[r] = -1;
             }
         }
+        {   // the first Linear's weight image: last read a rollout step ago (memory-side cache by now), needed ~2 us from here.  Behind the
+            // prologue's other requests and their waits: loads return in order, and those (written by the environment step a moment ago) come from L2
+            const f32x4 *wi = reinterpret_cast<const f32x4 *>(A.Wx32[0]) + (size_t)wave * (3 * 64) + lane;
+            __builtin_amdgcn_sched_barrier(0);                    // (hipcc would slip them in front of the last adjacency request)
+#pragma unroll
+            for (int p = 0; p < 3; p++) w0pre[p] = wi[p * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if (tid == 0) s_flag[1] = 0u;
         if (tid < 5 * (GR_NT / GR_GRP)) s_cnt[tid] = 0u;
         for (int i = tid; i < 2 * GR_TILE / 16; i += 256) reinterpret_cast<float4 *>(s_planes)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (A.candidate) {                                        // row -> candidate slot (ac:197-207 gathers h of one row per job)
-            __syncthreads();
+            LDS_BARRIER();                                        // (s_rowcand is LDS; __syncthreads() would also wait for the weight request above)
 #pragma unroll
             for (int k = 0; k < (GR_MAXCAND + 255) / 256; k++) {
                 const int i = tid + 256 * k, c = cand_pre[k];
@@ -729,11 +738,8 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 
     // ---------------------------------------------------------------- layer 0 / Linear 0: aggregated raw features (12 -> 128)
     GR_STAMP_AT(0);
-    {
-        const float4 *wi = reinterpret_cast<const float4 *>(A.Wx32[0]) + (size_t)wave * (3 * 64) + lane;
 #pragma unroll
-        for (int p = 0; p < 3; p++) w0f[p] = __builtin_bit_cast(bf16x8, wi[p * 64]);
-    }
+    for (int p = 0; p < 3; p++) w0f[p] = __builtin_bit_cast(bf16x8, w0pre[p]);
     LDS_BARRIER();
     GR_STAMP_AT(1);
     {
