@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 J, M, E, B = 6, 6, 2, 4096
 
 
-def _rollout(seed=77, scale_fcl=1.0, **kw):
+def _rollout(seed=77, scale_fcl=1.0, shape=None, obs_dtype="f32", **kw):
     import mtfjsp_amd  # noqa: F401
     enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
     rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
@@ -29,7 +29,8 @@ def _rollout(seed=77, scale_fcl=1.0, **kw):
     if scale_fcl != 1.0:
         ma["m_fea_1_fcl.weight"] = (ma["m_fea_1_fcl.weight"] * scale_fcl).astype(np.float32)
         ma["m_fea_2_fcl.weight"] = (ma["m_fea_2_fcl.weight"] * scale_fcl).astype(np.float32)
-    ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=(ja, ma), collect=False, **kw)
+    j, m = shape or (J, M)
+    ro = rollout.Rollout(j, m, E, B, policy="actor", obs_dtype=obs_dtype, weights=(ja, ma), collect=False, **kw)
     return ro, ja, ma
 
 
@@ -71,6 +72,32 @@ def test_three_in_one_launch_equals_the_separate_launches_and_the_oracle(steps_b
     assert float(np.abs(fused[0].cpu().numpy() - mo["prob"]).max()) <= 1e-4
     assert float(np.abs(fused[1].cpu().numpy() - mo["h_pooled"]).max()) <= 1e-4 * mscale
     assert float(np.abs(fused[2].cpu().numpy() - mo["mach_v"]).max()) <= 1e-3 * max(1.0, float(np.abs(mo["mach_v"]).max()))
+
+
+@pytest.mark.parametrize("shape,obs_dtype", [((6, 6), "f64"), ((4, 8), "f32"), ((4, 8), "f64")])
+def test_three_in_one_launch_with_f64_observations_and_eight_machines(shape, obs_dtype):
+    """The inputs the GAT part finds staged in LDS (m_fea2 rows copied and converted by the idle waves, m_fea1 rows left there by the job
+    selection) for the other observation dtype and for the widest machine count the launch takes (M = 8: 128 machine rows per workgroup)."""
+    from oracle import encoder_oracle as eo
+    ro, ja, ma = _rollout(shape=shape, obs_dtype=obs_dtype)
+    j, m = shape
+    for _ in range(3):
+        ro.step()
+    env, e = ro.env, ro.actor.enc
+    assert e.check()
+    assert _one_decision(ro) == 1
+    fused = [x.clone() for x in (e.mch_prob, e.h_pooled_m, e.mach_v, ro.mach)]
+    e.arm_selection(1, ro.actor.greedy, ro.actor.seed, 2 * ro.nsteps + 1, ro.mach, ro.actor.mch_logp)
+    mprob, h_m, mach_v = e.machine_actor_forward(env.m_fea1, env.m_fea2, e.h_pooled_o, env.mmask)
+    torch.cuda.synchronize()
+    scale = max(1.0, float(h_m.abs().max()))
+    assert float((fused[0] - mprob).abs().max()) <= 2e-6
+    assert float((fused[1] - h_m).abs().max()) <= 2e-6 * scale
+    assert float((fused[3] == ro.mach).float().mean()) >= 0.999
+    mo = eo.machine_actor_forward(ma, env.m_fea1.cpu().numpy().astype(np.float32), env.m_fea2.cpu().numpy().astype(np.float32), e.h_pooled_o.cpu().numpy(),
+                                  env.mmask.cpu().numpy(), B, m)
+    assert float(np.abs(fused[0].cpu().numpy() - mo["prob"]).max()) <= 1e-4
+    assert float(np.abs(fused[1].cpu().numpy() - mo["h_pooled"]).max()) <= 1e-4 * max(1.0, float(np.abs(mo["h_pooled"]).max()))
 
 
 @pytest.mark.parametrize("limit", ["100", "5000"])
