@@ -1220,6 +1220,11 @@ __device__ __forceinline__ int gx_off(int row, int col) { return row * HD + ((((
 #define GAT_XCHG 0
 #define HX_XCHG 0
 #define GAT_PRESTAGED 0
+#define BODY_TID threadIdx.x              // (k_headsx_gat3x_headsx gives each of its three parts an opaque copy: left alone, hipcc keeps the thread-index
+                                          // expressions common to the parts alive across all of them — through scratch memory where registers run out)
+#ifndef GAT_PAIRED
+#define GAT_PAIRED 1                        // the three-in-one launch takes a wave's two GAT tiles together (mtfjsp_gat3x_body.h); 0: one after the other
+#endif
 struct XchgArgs {
     unsigned long long *words;       // this forward's words (zero on entry): [fine | wide][8 dispatch groups][sum | sumsq][128 columns]
     unsigned long long *words_next;  // the next forward's set: zeroed by this launch
@@ -1784,6 +1789,10 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
     }
     X3_RT(1);
     __syncthreads();                                               // m_fea1 / the machine mask of this workgroup's instances are written; the GAT part's LDS images are staged
+    int tid_part = threadIdx.x;
+    asm volatile("" : "+v"(tid_part));
+#undef BODY_TID
+#define BODY_TID tid_part
     {
         const GatArgs &A = GA;
 #undef GAT_XCHG
@@ -1797,6 +1806,8 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #define GAT_XCHG 0
     }
     X3_RT(3);
+    tid_part = threadIdx.x;
+    asm volatile("" : "+v"(tid_part));
     LDS_BARRIER();                                                 // (not __syncthreads(): that would wait for the statistics' atomics to be acknowledged)
 #ifdef MTFJSP_STAMP3
 #undef H3_BASE
@@ -1818,6 +1829,8 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #undef H3T_RT
 #define H3T_RT(i) do { } while (0)
 #endif
+#undef BODY_TID
+#define BODY_TID threadIdx.x
     X3_RT(7);
 }
 #endif
@@ -1837,7 +1850,7 @@ __global__ __launch_bounds__(512) void k_headsx_envstep(HeadArgs HA, EnvParams E
     env_grp_body_dyn<OBS, 1, 8>(EP, smem);
 }
 static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64 + 2 * 512 * 4; }
-static size_t fused3_lds_bytes() { const size_t g = GAT_PRE_END; return headsx_lds_bytes() > g ? headsx_lds_bytes() : g; }   // k_headsx_gat3x_headsx: + the prestaged GAT images and feature rows (GAT_PRE_END)
+static size_t fused3_lds_bytes() { const size_t g = GAT_PAIRED ? (size_t)(8 * 2 * 4 * 64 * 16 + 12 * 16 * HD * 4) : (size_t)GAT_PRE_END; return headsx_lds_bytes() > g ? headsx_lds_bytes() : g; }   // k_headsx_gat3x_headsx: + the prestaged GAT images and feature rows (GAT_PRE_END)
 // The same kernel with TEN scorer tiles per chunk: a group of 16 instances with 7..10 candidates / machines each (J10M10: R = 10)
 // goes through the product phases once instead of twice (6 + 4 tiles, each chunk with its own staging, four barriers and latency chain)
 #undef HCH

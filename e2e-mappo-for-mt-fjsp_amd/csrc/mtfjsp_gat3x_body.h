@@ -8,7 +8,7 @@
 #endif                                                            // exponentials, 4 no activation writes to LDS, 8 no split matrix products, 16 no row reductions
     unsigned char *s_wf = smem;                                   // 8*2*4*64*16 B
     float *s_a = reinterpret_cast<float *>(smem + 8 * 2 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tid = BODY_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int m = lane & 15, q = lane >> 4;
 #ifdef MTFJSP_STAMP
 #define GAT_RT(i) do { if (A.stamps && lane == 0) { __builtin_amdgcn_sched_barrier(0); A.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
@@ -97,6 +97,203 @@
         return make_float4(x[0], x[1], x[2], x[3]);
     };
 #endif
+    // the attention of one tile behind a pass' products (accumulators `acc` = z, rows 4q + i of the tile at `row0`): logits, softmax over the two
+    // nodes, mixture, ELU and the tile rewritten in `my_a` for the next pass — or, behind the third pass, the node mean and its statistics
+    auto attend = [&](f32x4 (&acc)[8], float *my_a, const int row0, const int pass) __attribute__((always_inline)) {
+    // attention logits of the lane's two machines u = 0, 1: tile rows 4q + 2u (node 0), + 1 (node 1) = accumulator elements 2u, 2u + 1.
+    // Round 5: the six dot products of both machines are formed together — adst against the element pairs (0,1), (2,3) as two-wide FMAs,
+    // asrc against elements 0 and 2 — and reduced over the 16 lanes of the row one DPP add per value and step (it was 36 + 24
+    // instructions per machine; the vector units bound this kernel).
+    float s_u[2], d0_u[2], d1_u[2];
+    {
+        f32x2 dA = {0.f, 0.f}, dB = {0.f, 0.f};
+        float sA = 0.f, sB = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            const f32x2 ad = {adst[c], adst[c]};
+            dA = gr_fma2(f32x2{acc[c][0], acc[c][1]}, ad, dA);
+            dB = gr_fma2(f32x2{acc[c][2], acc[c][3]}, ad, dB);
+            sA = __builtin_fmaf(asrc[c], acc[c][0], sA);
+            sB = __builtin_fmaf(asrc[c], acc[c][2], sB);
+        }
+        float r0 = dA[0], r1 = dA[1], r2 = dB[0], r3 = dB[1];
+        asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(sA), "+v"(sB));   // (scalars from here on: a packed add has no DPP operand)
+        if (GAT_ABL & 16) { s_u[0] = sA; s_u[1] = sB; d0_u[0] = r0; d1_u[0] = r1; d0_u[1] = r2; d1_u[1] = r3; }
+        else {
+            s_u[0] = row_sum16(sA); s_u[1] = row_sum16(sB);
+            d0_u[0] = row_sum16(r0); d1_u[0] = row_sum16(r1); d0_u[1] = row_sum16(r2); d1_u[1] = row_sum16(r3);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int i = 2 * u;
+        float e00 = s_u[u] + d0_u[u], e01 = s_u[u] + d1_u[u];
+        e00 = fmaxf(e00, 0.2f * e00);                                 // LeakyReLU(0.2) (a NaN stays a NaN: both operands are)
+        e01 = fmaxf(e01, 0.2f * e01);
+        const float mx = fmaxf(e00, e01);
+        const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
+        const float inv = 1.0f / (x0 + x1);
+        // The attention mixture al0 z0 + al1 z1 as an explicit two-wide product (z0, z1) * (al0, al1) followed by a horizontal add:
+        // (z0, z1) are neighbouring accumulator registers, so the packed multiply needs no operand swizzle.  Left as scalar code,
+        // hipcc's SLP vectoriser paired products of DIFFERENT column blocks — (z1 of block a) * al1 with (z0 of block b) * al0 — and
+        // emitted v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0] (source 1 with its halves swapped).  On gfx950 that form (any packed
+        // f32 instruction whose low result reads the HIGH half of source 1 and the low half of source 0) is not reliable when the
+        // SIMD's other wave is executing matrix instructions: lanes 48..63 of about 0.3 % of the executions come out wrong
+        // (tools/ubench/valu_after_mfma.hip, profiles/r04_ubench_valu_after_mfma.txt).  That — not the first launch — was round 3's
+        // "function form miscomputes a few row tiles"; tools/isa_lint.py now refuses a build that contains the form.
+        const f32x2 alv = {x0 * inv, x1 * inv};
+        const int r = 4 * q + i;
+        if (pass < 2) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float z1 = acc[c][i + 1];
+                const f32x2 pz = f32x2{acc[c][i], z1} * alv;
+                // ELU after passes 1 and 2 (ac:409-413) of the pair (mixture, node 1's own row): x > 0 ? x : exp(x) - 1 with the two
+                // multiplications by log2(e) and the two "- 1" as two-wide instructions; |err| < 2e-7; the select (not a max) keeps a NaN
+                float n0 = pz[0] + pz[1];
+                asm volatile("" : "+v"(n0));                          // (a plain add: left to itself hipcc adds the halves with a swizzled packed add — the unreliable form above)
+                const f32x2 nv = {n0, z1};
+                const f32x2 tl = nv * f32x2{1.44269504088896340736f, 1.44269504088896340736f};
+                const f32x2 em = ((GAT_ABL & 2) ? tl : f32x2{__builtin_amdgcn_exp2f(tl[0]), __builtin_amdgcn_exp2f(tl[1])}) + f32x2{-1.0f, -1.0f};
+                if (GAT_ABL & 4) { asm volatile("" :: "v"(nv[0] > 0.f ? nv[0] : em[0]), "v"(nv[1] > 0.f ? nv[1] : em[1])); continue; }
+                my_a[gx_off(r, c * 16 + m)] = nv[0] > 0.f ? nv[0] : em[0];
+                my_a[gx_off(r + 1, c * 16 + m)] = nv[1] > 0.f ? nv[1] : em[1];
+            }
+        } else {
+            const bool valid = row0 + r < N;
+            float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + m;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float z1 = acc[c][i + 1];
+                const f32x2 pz = f32x2{acc[c][i], z1} * alv;
+                float mv = (pz[0] + pz[1] + z1) * 0.5f;              // mean over the 2 nodes (ac:420)
+                nd[c * 16] = mv;
+                if (!valid) mv = 0.f;
+                st_sum[c] += mv; st_sq[c] = __builtin_fmaf(mv, mv, st_sq[c]);
+            }
+        }
+    }
+    };
+    const unsigned char *wl = s_wf + lane * 16;                   // fragment (c, p, ks): wl + ((c*2 + p)*4 + ks) * 1024
+#if GAT_PRESTAGED && GAT_PAIRED
+    // PAIRED tiles (round 5, k_headsx_gat3x_headsx with 9..12 tiles per workgroup = M = 5, 6): every tile has its own buffer (12 x 8 KB + the 64 KB of
+    // fragments = all of LDS), a wave with two tiles (w and w + 8) takes them TOGETHER — each weight fragment read from LDS feeds the matrix
+    // instructions of both tiles (the tiles are bound by those reads: profiles/r05_ablate_gat.txt) and no wave is left alone with a second tile
+    // while the others idle.  The staged images and feature rows lie where tile buffers 8, 9 are: they are read into registers first, then one
+    // barrier releases the buffers.  Per accumulator the products arrive in the same order as in the loop below: the same bits.
+    const bool paired = per > 8 && per <= 12;
+    if (paired) {
+        auto run = [&](auto NTc) __attribute__((always_inline)) {
+            constexpr int NT = decltype(NTc)::value;
+            float *buf[NT]; int row0[NT];
+            float xa[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const int lt = wave + 8 * t;
+                buf[t] = s_a + lt * 16 * HD; row0[t] = (first + lt) * 16;
+                const int r = row0[t] + m, ul = 8 * lt + (m >> 1);
+                const bool node1 = (m & 1) != 0, in = r < N;
+                const float *src = reinterpret_cast<const float *>(smem + (node1 ? GAT_F2_OFF : GAT_F1_OFF)) + ul * (node1 ? 8 : 6);
+                const float fa = in ? src[q] : 0.f, fb = (in && (node1 || q < 2)) ? src[4 + q] : 0.f;
+                xa[t][0] = node1 ? 0.f : fa; xa[t][1] = node1 ? 0.f : fb; xa[t][2] = node1 ? fa : 0.f; xa[t][3] = node1 ? fb : 0.f;
+            }
+            LDS_BARRIER();                                        // every wave holds what it needs of the staged images / rows: tile buffers 8, 9 may be written
+            f32x4 acc[NT][8];
+            {   // first pass (outside the loop: the projection's 32 operand registers are free afterwards)
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++)
+#pragma unroll
+                        for (int t = 0; t < NT; t++) acc[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[t][ks], wq[c][ks], acc[t][c], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; t++) MFMA_SETTLE8(acc[t]);
+#pragma unroll
+                for (int t = 0; t < NT; t++) attend(acc[t], buf[t], row0[t], 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+#pragma unroll 1
+            for (int pass = 1; pass < 3; pass++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int c = 0; c < 8; c++) acc[t][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                {
+                    // k-steps outermost: a step's operand pieces of both tiles (two 16-byte reads and a split each, requested a step ahead), then the
+                    // four units (column-block pair) of that step, each unit's 4 weight fragments requested one unit ahead
+                    float4 xl[NT], xh[NT];
+                    h16x8 xf[NT][2];
+                    auto xload = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int t = 0; t < NT; t++) {
+                            xl[t] = *reinterpret_cast<const float4 *>(buf[t] + gx_off(m, 32 * ks + 8 * q));
+                            xh[t] = *reinterpret_cast<const float4 *>(buf[t] + gx_off(m, 32 * ks + 8 * q + 4));
+                        }
+                    };
+                    auto xsplit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                        for (int t = 0; t < NT; t++) {
+                            const float v0[4] = {xl[t].x, xl[t].y, xl[t].z, xl[t].w}, v1[4] = {xh[t].x, xh[t].y, xh[t].z, xh[t].w};
+                            uint2 a0, a1, b0, b1;
+                            split2x4(v0, a0, a1); split2x4(v1, b0, b1);
+                            xf[t][0] = __builtin_bit_cast(h16x8, make_uint4(a0.x, a0.y, b0.x, b0.y));
+                            xf[t][1] = __builtin_bit_cast(h16x8, make_uint4(a1.x, a1.y, b1.x, b1.y));
+                        }
+                    };
+                    xload(0);
+                    h16x8 wr[2][2][2];
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                        for (int p = 0; p < 2; p++) wr[0][cc][p] = *reinterpret_cast<const h16x8 *>(wl + ((cc * 2 + p) * 4) * 1024);
+                    xsplit();
+#pragma unroll
+                    for (int u = 0; u < 16; u++) {
+                        const int ks = u >> 2, cp = u & 3;
+                        if (u + 1 < 16) {
+                            const int kn = (u + 1) >> 2, cn = (u + 1) & 3;
+#pragma unroll
+                            for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                                for (int p = 0; p < 2; p++) wr[(u + 1) & 1][cc][p] = *reinterpret_cast<const h16x8 *>(wl + (((2 * cn + cc) * 2 + p) * 4 + kn) * 1024);
+                        }
+                        if (cp == 0 && ks + 1 < 4) xload(ks + 1);
+                        const h16x8 (*w)[2] = wr[u & 1];
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+#pragma unroll
+                            for (int cc = 0; cc < 2; cc++) acc[t][2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[t][1], w[cc][0], acc[t][2 * cp + cc], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+#pragma unroll
+                            for (int cc = 0; cc < 2; cc++) acc[t][2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[t][0], w[cc][1], acc[t][2 * cp + cc], 0, 0, 0);
+#pragma unroll
+                        for (int t = 0; t < NT; t++)
+#pragma unroll
+                            for (int cc = 0; cc < 2; cc++) acc[t][2 * cp + cc] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xf[t][0], w[cc][0], acc[t][2 * cp + cc], 0, 0, 0);
+                        if (cp == 3 && ks + 1 < 4) xsplit();
+                    }
+#pragma unroll
+                    for (int t = 0; t < NT; t++) {
+                        MFMA_SETTLE8(acc[t]);
+#pragma unroll
+                        for (int c = 0; c < 8; c++) acc[t][c] *= wsinv;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < NT; t++) attend(acc[t], buf[t], row0[t], pass);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tiles are complete before the next pass reads them
+            }
+        };
+        if (wave + 8 < per) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 1>{});
+    } else
+#endif
+    {
     int t_cur = first + wave, t_n1 = t_cur + 8;
     float4 fpre = make_float4(0.f, 0.f, 0.f, 0.f);
     if (t_cur < last) fpre = fetch_feat(t_cur);
@@ -109,7 +306,6 @@
 #ifdef MTFJSP_STAMP
     int gat_rt_i = 2;
 #endif
-    const unsigned char *wl = s_wf + lane * 16;                   // fragment (c, p, ks): wl + ((c*2 + p)*4 + ks) * 1024
     while (t_cur < last) {
         const int row0 = t_cur * 16;
         // ---- input rows: tile rows 2p+h are node h of machine (row0/2 + p); W1/W2 arrive pre-multiplied with the GAT
@@ -185,79 +381,7 @@
 #pragma unroll
                 for (int c = 0; c < 8; c++) acc[c] *= wsinv;                  // the weight image is scaled by a power of two
             }
-            // attention logits of the lane's two machines u = 0, 1: tile rows 4q + 2u (node 0), + 1 (node 1) = accumulator elements 2u, 2u + 1.
-            // Round 5: the six dot products of both machines are formed together — adst against the element pairs (0,1), (2,3) as two-wide FMAs,
-            // asrc against elements 0 and 2 — and reduced over the 16 lanes of the row one DPP add per value and step (it was 36 + 24
-            // instructions per machine; the vector units bound this kernel).
-            float s_u[2], d0_u[2], d1_u[2];
-            {
-                f32x2 dA = {0.f, 0.f}, dB = {0.f, 0.f};
-                float sA = 0.f, sB = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const f32x2 ad = {adst[c], adst[c]};
-                    dA = gr_fma2(f32x2{acc[c][0], acc[c][1]}, ad, dA);
-                    dB = gr_fma2(f32x2{acc[c][2], acc[c][3]}, ad, dB);
-                    sA = __builtin_fmaf(asrc[c], acc[c][0], sA);
-                    sB = __builtin_fmaf(asrc[c], acc[c][2], sB);
-                }
-                float r0 = dA[0], r1 = dA[1], r2 = dB[0], r3 = dB[1];
-                asm volatile("" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(sA), "+v"(sB));   // (scalars from here on: a packed add has no DPP operand)
-                if (GAT_ABL & 16) { s_u[0] = sA; s_u[1] = sB; d0_u[0] = r0; d1_u[0] = r1; d0_u[1] = r2; d1_u[1] = r3; }
-                else {
-                    s_u[0] = row_sum16(sA); s_u[1] = row_sum16(sB);
-                    d0_u[0] = row_sum16(r0); d1_u[0] = row_sum16(r1); d0_u[1] = row_sum16(r2); d1_u[1] = row_sum16(r3);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int i = 2 * u;
-                float e00 = s_u[u] + d0_u[u], e01 = s_u[u] + d1_u[u];
-                e00 = fmaxf(e00, 0.2f * e00);                                 // LeakyReLU(0.2) (a NaN stays a NaN: both operands are)
-                e01 = fmaxf(e01, 0.2f * e01);
-                const float mx = fmaxf(e00, e01);
-                const float x0 = __expf(e00 - mx), x1 = __expf(e01 - mx);
-                const float inv = 1.0f / (x0 + x1);
-                // The attention mixture al0 z0 + al1 z1 as an explicit two-wide product (z0, z1) * (al0, al1) followed by a horizontal add:
-                // (z0, z1) are neighbouring accumulator registers, so the packed multiply needs no operand swizzle.  Left as scalar code,
-                // hipcc's SLP vectoriser paired products of DIFFERENT column blocks — (z1 of block a) * al1 with (z0 of block b) * al0 — and
-                // emitted v_pk_mul_f32 ... op_sel:[0,1] op_sel_hi:[1,0] (source 1 with its halves swapped).  On gfx950 that form (any packed
-                // f32 instruction whose low result reads the HIGH half of source 1 and the low half of source 0) is not reliable when the
-                // SIMD's other wave is executing matrix instructions: lanes 48..63 of about 0.3 % of the executions come out wrong
-                // (tools/ubench/valu_after_mfma.hip, profiles/r04_ubench_valu_after_mfma.txt).  That — not the first launch — was round 3's
-                // "function form miscomputes a few row tiles"; tools/isa_lint.py now refuses a build that contains the form.
-                const f32x2 alv = {x0 * inv, x1 * inv};
-                const int r = 4 * q + i;
-                if (pass < 2) {
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        const float z1 = acc[c][i + 1];
-                        const f32x2 pz = f32x2{acc[c][i], z1} * alv;
-                        // ELU after passes 1 and 2 (ac:409-413) of the pair (mixture, node 1's own row): x > 0 ? x : exp(x) - 1 with the two
-                        // multiplications by log2(e) and the two "- 1" as two-wide instructions; |err| < 2e-7; the select (not a max) keeps a NaN
-                        float n0 = pz[0] + pz[1];
-                        asm volatile("" : "+v"(n0));                          // (a plain add: left to itself hipcc adds the halves with a swizzled packed add — the unreliable form above)
-                        const f32x2 nv = {n0, z1};
-                        const f32x2 tl = nv * f32x2{1.44269504088896340736f, 1.44269504088896340736f};
-                        const f32x2 em = ((GAT_ABL & 2) ? tl : f32x2{__builtin_amdgcn_exp2f(tl[0]), __builtin_amdgcn_exp2f(tl[1])}) + f32x2{-1.0f, -1.0f};
-                        if (GAT_ABL & 4) { asm volatile("" :: "v"(nv[0] > 0.f ? nv[0] : em[0]), "v"(nv[1] > 0.f ? nv[1] : em[1])); continue; }
-                        my_a[gx_off(r, c * 16 + m)] = nv[0] > 0.f ? nv[0] : em[0];
-                        my_a[gx_off(r + 1, c * 16 + m)] = nv[1] > 0.f ? nv[1] : em[1];
-                    }
-                } else {
-                    const bool valid = row0 + r < N;
-                    float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + m;
-#pragma unroll
-                    for (int c = 0; c < 8; c++) {
-                        const float z1 = acc[c][i + 1];
-                        const f32x2 pz = f32x2{acc[c][i], z1} * alv;
-                        float mv = (pz[0] + pz[1] + z1) * 0.5f;              // mean over the 2 nodes (ac:420)
-                        nd[c * 16] = mv;
-                        if (!valid) mv = 0.f;
-                        st_sum[c] += mv; st_sq[c] = __builtin_fmaf(mv, mv, st_sq[c]);
-                    }
-                }
-            }
+            attend(acc, my_a, row0, pass);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the rewritten tile is complete before the next pass reads it
             if (g3_tile == 0) { if (pass == 0) G3_RT(3); else if (pass == 1) G3_RT(4); else G3_RT(5); } else if (pass == 2) G3_RT(6);
         }
@@ -267,6 +391,7 @@
         if (gat_rt_i == 2) GAT_RT(2); else if (gat_rt_i == 3) GAT_RT(3);
         gat_rt_i++;
 #endif
+    }
     }
     // column sums: fold the 4 row quarters, then the 8 waves through LDS
 #if GAT_XCHG

@@ -13,7 +13,7 @@
     unsigned char *s_mask = reinterpret_cast<unsigned char *>(s_vec + 5 * HD);   // HG * 64
     int *s_gf = reinterpret_cast<int *>(s_mask + HG * 64);         // [512] gather_from of the first 512 scorer rows (the selection's task per row)
     int *s_pm = s_gf + 512;                                        // [512] machine of that task's job predecessor (m_fea1)
-    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int tid = BODY_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int m = lane & 15, q = lane >> 4;
     const int col4 = 16 * wave + 4 * q;                            // this lane's 4 output columns
 #ifdef MTFJSP_STAMP
