@@ -1372,6 +1372,7 @@ struct HeadArgs {
 };
 #define HG 16                            // instances per group
 #define HCH 6                            // scorer tiles per chunk (even; X tiles and s1 tiles are separate LDS buffers)
+#define HX_NPART 32                      // k_headsx: partial scores per (wave, row quarter) — 32 — or per wave with a cross-lane reduction per tile — 8 (HCH 10: LDS)
 
 __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
 {
@@ -1849,20 +1850,24 @@ __global__ __launch_bounds__(512) void k_headsx_envstep(HeadArgs HA, EnvParams E
     __syncthreads();
     env_grp_body_dyn<OBS, 1, 8>(EP, smem);
 }
-static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64 + 2 * 512 * 4; }
+static size_t headsx_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + HX_NPART * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64 + 2 * 512 * 4; }
 static size_t fused3_lds_bytes() { const size_t g = GAT_PAIRED ? (size_t)(8 * 2 * 4 * 64 * 16 + 12 * 16 * HD * 4) : (size_t)GAT_PRE_END; return headsx_lds_bytes() > g ? headsx_lds_bytes() : g; }   // k_headsx_gat3x_headsx: + the prestaged GAT images and feature rows (GAT_PRE_END)
 // The same kernel with TEN scorer tiles per chunk: a group of 16 instances with 7..10 candidates / machines each (J10M10: R = 10)
 // goes through the product phases once instead of twice (6 + 4 tiles, each chunk with its own staging, four barriers and latency chain)
 #undef HCH
 #define HCH 10
+#undef HX_NPART
+#define HX_NPART 8
 __global__ __launch_bounds__(512) void k_headsx10(HeadArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
 #include "mtfjsp_headsx_body.h"
 }
-static size_t headsx10_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + 8 * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64 + 2 * 512 * 4; }
+static size_t headsx10_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_t)(16 * HX_CLDA + HG * HD + HX_NPART * HCH * 16 + HG * 64 + 2 * HD + 5 * HD) * 4 + HG * 64 + 2 * 512 * 4; }
 #undef HCH
 #define HCH 6
+#undef HX_NPART
+#define HX_NPART 32
 
 // ---------------------------------------------------------------------------------------------
 // GIN layer 0, first Linear (12 -> 128) fused with the neighbour aggregation of the raw task features

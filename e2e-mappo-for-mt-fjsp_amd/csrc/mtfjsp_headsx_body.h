@@ -6,8 +6,8 @@
     unsigned char *s_c1p = s_op + X2_TILE;                         // c1 planes
     float *s_c2 = reinterpret_cast<float *>(s_c1p + X2_TILE);      // [16][HX_CLDA] f32
     float *s_u = s_c2 + 16 * HX_CLDA;                              // [16][128]
-    float *s_part = s_u + HG * HD;                                 // 8 waves * (HCH*16) rows
-    float *s_score = s_part + 8 * HCH * 16;                        // HG * 64
+    float *s_part = s_u + HG * HD;                                 // HX_NPART (wave[, row quarter]) partial scores of HCH*16 rows
+    float *s_score = s_part + HX_NPART * HCH * 16;                 // HG * 64
     float *s_wc2 = s_score + HG * 64;                              // 2 * 128
     float *s_vec = s_wc2 + 2 * HD;                                 // b0 | bc0 | bc1 | b1 | w2
     unsigned char *s_mask = reinterpret_cast<unsigned char *>(s_vec + 5 * HD);   // HG * 64
@@ -342,18 +342,29 @@
                         v = fmaf(fast_tanh(fmaf(a0[1], sW1, b1v.y)), w2v.y, v);
                         v = fmaf(fast_tanh(fmaf(a0[2], sW1, b1v.z)), w2v.z, v);
                         v = fmaf(fast_tanh(fmaf(a0[3], sW1, b1v.w)), w2v.w, v);
+#if HX_NPART == 32
+                        s_part[(wave * 4 + q) * (HCH * 16) + t * 16 + m] = v;    // (the four row quarters are added with the waves below: it was two ds_bpermute round trips per tile)
+#else
                         v += __shfl_xor(v, 16);
                         v += __shfl_xor(v, 32);
                         if (q == 0) s_part[wave * (HCH * 16) + t * 16 + m] = v;
+#endif
                     }
                 }
             }
             H3S_RT(4);
-            if (tb == 0) {   // value head: 32 threads per instance row, 4 columns each, both outputs
-                const int r = tid >> 5, part = tid & 31;
+            if (tb == 0 && tid < 256) {   // value head: the 16 lanes of a DPP row per instance row, 8 columns each, both outputs (round 5: it was 32 lanes per row and
+                                          // five ds_bpermute steps per output, one after the other)
+                const int r = tid >> 4, part = tid & 15;
                 float p0 = 0.f, p1 = 0.f;
-                for (int k = 0; k < 4; k++) { const float x = s_c2[r * HX_CLDA + part * 4 + k]; p0 = fmaf(x, s_wc2[part * 4 + k], p0); p1 = fmaf(x, s_wc2[HD + part * 4 + k], p1); }
-                for (int o = 16; o > 0; o >>= 1) { p0 += __shfl_xor(p0, o); p1 += __shfl_xor(p1, o); }
+                const float4 xa_ = *reinterpret_cast<const float4 *>(s_c2 + r * HX_CLDA + part * 8), xb_ = *reinterpret_cast<const float4 *>(s_c2 + r * HX_CLDA + part * 8 + 4);
+                const float4 wa0 = *reinterpret_cast<const float4 *>(s_wc2 + part * 8), wb0 = *reinterpret_cast<const float4 *>(s_wc2 + part * 8 + 4);
+                const float4 wa1 = *reinterpret_cast<const float4 *>(s_wc2 + HD + part * 8), wb1 = *reinterpret_cast<const float4 *>(s_wc2 + HD + part * 8 + 4);
+                const float xs[8] = {xa_.x, xa_.y, xa_.z, xa_.w, xb_.x, xb_.y, xb_.z, xb_.w};
+                const float w0s[8] = {wa0.x, wa0.y, wa0.z, wa0.w, wb0.x, wb0.y, wb0.z, wb0.w}, w1s[8] = {wa1.x, wa1.y, wa1.z, wa1.w, wb1.x, wb1.y, wb1.z, wb1.w};
+#pragma unroll
+                for (int k = 0; k < 8; k++) { p0 = fmaf(xs[k], w0s[k], p0); p1 = fmaf(xs[k], w1s[k], p1); }
+                p0 = row_sum16(p0); p1 = row_sum16(p1);
                 if (part == 0 && r < ng) {
                     const float v0 = p0 + A.bc2[0], v1 = p1 + A.bc2[1];
                     A.value[(size_t)(g0 + r) * 2] = v0; A.value[(size_t)(g0 + r) * 2 + 1] = v1;
@@ -365,7 +376,8 @@
             if (tid < nt * 16) {
                 const int grow = tb * 16 + tid;
                 float v = b2;
-                for (int w = 0; w < 8; w++) v += s_part[w * (HCH * 16) + tid];
+#pragma unroll
+                for (int w = 0; w < HX_NPART; w++) v += s_part[w * (HCH * 16) + tid];
                 if (grow < nrows) s_score[grow] = v * A.scale;
             }
             H3S_RT(6);
