@@ -503,16 +503,20 @@
                         H3T_RT(1);
                         for (int mm = l; mm < M_; mm += 16) {
                             const double tv = A.mf.t[row * M_ + mm], pv = A.mf.p[row * M_ + mm];
+                            // (requested with them, not where a comparison on tv / pv selects them: that was a second round trip behind the first)
+                            const double mean0 = A.mf.mean3[row * 3 + 0], mean1 = A.mf.mean3[row * 3 + 1], mean2 = A.mf.mean3[row * 3 + 2];
+                            const int shop_m = A.mf.shop[(size_t)b * M_ + mm];
+                            const double tt_pm = A.mf.tt[((size_t)b * M_ + pm) * M_ + mm];   // (pm = 0 where the task has no job predecessor: a valid row, value unused)
                             H3T_RT(2);
                             const double ptv = tv * fabs(pv);
                             const unsigned char mk = (unsigned char)!(tv >= 0);              // run:258-259 ~(t >= 0)
-                            const double x = (a % M_ != 0) ? A.mf.tt[((size_t)b * M_ + pm) * M_ + mm] : 0.0;
+                            const double x = (a % M_ != 0) ? tt_pm : 0.0;
                             H3T_RT(3);
-                            const double f0 = tv > 0 ? tv : A.mf.mean3[row * 3 + 0], f1 = ptv > 0 ? ptv : A.mf.mean3[row * 3 + 1];
-                            const double f4 = pv > 0 ? pv : A.mf.mean3[row * 3 + 2];
+                            const double f0 = tv > 0 ? tv : mean0, f1 = ptv > 0 ? ptv : mean1;
+                            const double f4 = pv > 0 ? pv : mean2;
                             H3T_RT(4);
                             const size_t o = ((size_t)b * M_ + mm) * 6;
-                            const double f3 = (double)(1 - (int)mk), f5 = (double)(A.mf.shop[(size_t)b * M_ + mm] + 1);
+                            const double f3 = (double)(1 - (int)mk), f5 = (double)(shop_m + 1);
                             if (A.mf.obs_f32) {
                                 float *of = reinterpret_cast<float *>(A.mf.m_fea1_out) + o;
                                 of[0] = (float)f0; of[1] = (float)f1; of[2] = (float)x; of[3] = (float)f3; of[4] = (float)f4; of[5] = (float)f5;
