@@ -29,8 +29,8 @@ def _rollout(seed=77, scale_fcl=1.0, shape=None, obs_dtype="f32", **kw):
     if scale_fcl != 1.0:
         ma["m_fea_1_fcl.weight"] = (ma["m_fea_1_fcl.weight"] * scale_fcl).astype(np.float32)
         ma["m_fea_2_fcl.weight"] = (ma["m_fea_2_fcl.weight"] * scale_fcl).astype(np.float32)
-    j, m = shape or (J, M)
-    ro = rollout.Rollout(j, m, E, B, policy="actor", obs_dtype=obs_dtype, weights=(ja, ma), collect=False, **kw)
+    j, m, e = (tuple(shape) + (E,))[:3] if shape else (J, M, E)
+    ro = rollout.Rollout(j, m, e, B, policy="actor", obs_dtype=obs_dtype, weights=(ja, ma), collect=False, **kw)
     return ro, ja, ma
 
 
@@ -74,13 +74,14 @@ def test_three_in_one_launch_equals_the_separate_launches_and_the_oracle(steps_b
     assert float(np.abs(fused[2].cpu().numpy() - mo["mach_v"]).max()) <= 1e-3 * max(1.0, float(np.abs(mo["mach_v"]).max()))
 
 
-@pytest.mark.parametrize("shape,obs_dtype", [((6, 6), "f64"), ((4, 8), "f32"), ((4, 8), "f64")])
+@pytest.mark.parametrize("shape,obs_dtype", [((6, 6), "f64"), ((4, 8), "f32"), ((4, 8), "f64"), ((7, 5, 1), "f32"), ((8, 4), "f32")])
 def test_three_in_one_launch_with_f64_observations_and_eight_machines(shape, obs_dtype):
     """The inputs the GAT part finds staged in LDS (m_fea2 rows copied and converted by the idle waves, m_fea1 rows left there by the job
-    selection) for the other observation dtype and for the widest machine count the launch takes (M = 8: 128 machine rows per workgroup)."""
+    selection) for the other observation dtype and for the widest machine count the launch takes (M = 8: 128 machine rows per workgroup);
+    M = 5: ten GAT tiles per workgroup (two waves take a pair, six a single tile); M = 4: eight (the one-tile-at-a-time loop)."""
     from oracle import encoder_oracle as eo
     ro, ja, ma = _rollout(shape=shape, obs_dtype=obs_dtype)
-    j, m = shape
+    j, m = shape[:2]
     for _ in range(3):
         ro.step()
     env, e = ro.env, ro.actor.enc
