@@ -1734,23 +1734,27 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x(HeadArgs HA, GatArgs GA)
 #define GAT_F1_OFF (GAT_IMG_OFF + GAT_IMG_BYTES)                  // m_fea1 of the workgroup's 16 x M machines as f32 [16 M][6] (M <= 8), written by the job selection
 #define GAT_F2_OFF (GAT_F1_OFF + 16 * 8 * 6 * 4)                  // m_fea2 likewise [16 M][8], copied here
 #define GAT_PRE_END (GAT_F2_OFF + 16 * 8 * 8 * 4)
-__device__ __forceinline__ void gat_prestage(const GatArgs &G, unsigned char *smem, int t, int M)
+// this workgroup's m_fea2 rows (written by the environment step a rollout step ago: the memory-side cache by now) are requested at the top of
+// the launch — the last of the first phase's requests, by every thread (waves 0-3 drop theirs) — and wait in four registers
+__device__ __forceinline__ void gat_f2_load(const GatArgs &G, int t, int M, float (&x)[4])
 {
-    // every request first, none behind a branch (indices clamped, values zeroed where they are stored); then the stores in request order
-    const float4 *src = reinterpret_cast<const float4 *>(G.Wx6);
-    float4 v[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = src[i * 256 + t];
-    const float4 q0 = reinterpret_cast<const float4 *>(G.Wq)[t], q1 = reinterpret_cast<const float4 *>(G.Wq)[256 + t];
-    const float ga = G.gat_a[t];
-    const size_t base = (size_t)blockIdx.x * 16 * M * 8, total = (size_t)G.R * 8;   // this workgroup's m_fea2 rows
-    float x[4];
+    const size_t base = (size_t)blockIdx.x * 16 * M * 8, total = (size_t)G.R * 8;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const size_t idx = base + (size_t)(i * 256 + t), ic = idx < total ? idx : total - 1;
         x[i] = G.feat_f64 ? (float)reinterpret_cast<const double *>(G.f2)[ic] : reinterpret_cast<const float *>(G.f2)[ic];
         if (!(i * 256 + t < 16 * M * 8 && idx < total)) x[i] = 0.f;
     }
+}
+__device__ __forceinline__ void gat_prestage(const GatArgs &G, unsigned char *smem, int t, const float (&x)[4])
+{
+    // every request first, none behind a branch; then the stores in request order
+    const float4 *src = reinterpret_cast<const float4 *>(G.Wx6);
+    float4 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = src[i * 256 + t];
+    const float4 q0 = reinterpret_cast<const float4 *>(G.Wq)[t], q1 = reinterpret_cast<const float4 *>(G.Wq)[256 + t];
+    const float ga = G.gat_a[t];
     float4 *dst = reinterpret_cast<float4 *>(smem);
 #pragma unroll
     for (int i = 0; i < 16; i++) dst[i * 256 + t] = v[i];
@@ -1782,10 +1786,16 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #endif
     {
         const HeadArgs &A = HA;
-#define HX_IDLE_HOOK gat_prestage(GA, smem, tid - 256, A.mf.M);
+#ifndef GAT_F2_LATE
+#define HX_TOP_HOOK float gf2[4]; gat_f2_load(GA, tid & 255, A.mf.M, gf2);
+#define HX_IDLE_HOOK gat_prestage(GA, smem, tid - 256, gf2);
+#else                                                              // (diagnostic builds: the rows requested where they are stored, as before)
+#define HX_IDLE_HOOK float gf2[4]; gat_f2_load(GA, tid - 256, A.mf.M, gf2); gat_prestage(GA, smem, tid - 256, gf2);
+#endif
 #define HX_MF1_LDS reinterpret_cast<float *>(smem + GAT_F1_OFF)
 #include "mtfjsp_headsx_body.h"
 #undef HX_IDLE_HOOK
+#undef HX_TOP_HOOK
 #undef HX_MF1_LDS
     }
     X3_RT(1);

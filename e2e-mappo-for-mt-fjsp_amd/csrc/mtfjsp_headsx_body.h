@@ -111,6 +111,9 @@
         WCOLX(wA, A.W0x, 1);                                        // Wb
         WCOLX(wB, A.W0x, 2);                                        // Wc
         WCOLX(wC, A.Wc0x, 0);
+#ifdef HX_TOP_HOOK
+        HX_TOP_HOOK                                                 // (requests of the including kernel that a later part consumes: behind this phase's own)
+#endif
         // (everything is in flight) the uniform number of this thread's instance's draw (pick_action): ten Philox rounds that need no memory
         const float u_pre = A.sample_mode == 1 ? pick_uniform(g0 + (tid >> 4), A.seed, A.counter) : 0.f;
         // now the stores that only needed the first few words
