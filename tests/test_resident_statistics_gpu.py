@@ -114,3 +114,21 @@ def test_two_runs_give_the_same_bits():
     torch.cuda.synchronize()
     assert torch.equal(ro.actor.enc.mch_prob, ro2.actor.enc.mch_prob) and torch.equal(ro.actor.enc.h_pooled_m, ro2.actor.enc.h_pooled_m)
     assert torch.equal(ro.mach, ro2.mach) and torch.equal(ro.task, ro2.task)
+
+
+def test_the_requests_on_behalf_of_the_heads_launch_change_no_bit(monkeypatch):
+    """k_gin_res requests (and drops) one word of every line of the heads launch's weight images in its last phase
+    (GinResArgs::warm, MTFJSP_NO_WARM_HEADS=1 switches that off when a handle is created): a rollout with and one without them
+    take the same decisions and produce the same bits."""
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    ja, ma = enc_mod.random_init_weights(seed=5)
+    ro_a = _mid_episode((ja, ma), steps=9, seed=11)
+    monkeypatch.setenv("MTFJSP_NO_WARM_HEADS", "1")
+    ro_b = _mid_episode((ja, ma), steps=9, seed=11)
+    monkeypatch.delenv("MTFJSP_NO_WARM_HEADS")
+    for r in (ro_a, ro_b):
+        r.actor.act(r.env, r.nsteps, r.task, r.mach, r.job)
+    torch.cuda.synchronize()
+    assert torch.equal(ro_a.task, ro_b.task) and torch.equal(ro_a.mach, ro_b.mach)
+    assert torch.equal(ro_a.actor.enc.mch_prob, ro_b.actor.enc.mch_prob) and torch.equal(ro_a.actor.enc.h_pooled_m, ro_b.actor.enc.h_pooled_m)
+    assert torch.equal(ro_a.env.tasks_fea, ro_b.env.tasks_fea)
