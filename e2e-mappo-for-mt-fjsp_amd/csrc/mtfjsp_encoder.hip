@@ -3587,8 +3587,10 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
                 for (int part = 0; part < 2; part++) {                  // ... and inside the selection (H3T_RT; waves 0-3)
                     std::vector<unsigned long long> h3((size_t)grid * 64);
                     (void)hipMemcpy(h3.data(), d_st3 + (size_t)(part ? 1792 : 1536) * 64, h3.size() * 8, hipMemcpyDeviceToHost);
-                    const char *hn[5] = {"picked, index handed over", "predecessor's machine", "t / p / transport requested", "t / p arrived", "means arrived"};
-                    printf("STAMP3 %s selection, mean over waves 0-3:", part ? "machine" : "job");
+                    const char *hj[5] = {"picked, index handed over", "predecessor's machine", "t / p / transport requested", "t / p arrived", "means arrived"};
+                    const char *hm[5] = {"picked", "poll loop entered", "first poll back", "second poll back", "third poll back"};
+                    const char **hn = part ? hm : hj;
+                    printf("STAMP3 %s, mean over waves 0-3:", part ? "machine exchange / selection" : "job selection");
                     for (int oi = 0; oi < 5; oi++) {
                         double m = 0; int n = 0;
                         for (int w = 0; w < grid * 8; w++) { const unsigned long long x = h3[(size_t)w * 8 + oi]; if (x) { m += (double)(x - t0) / 100.0; n++; } }

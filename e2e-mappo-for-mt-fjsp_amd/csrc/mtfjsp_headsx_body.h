@@ -137,6 +137,7 @@
                 unsigned long long sf = 0, sc = 0;
                 unsigned nf = 0, nc = 0;
                 const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+                H3T_RT(1);
                 for (int it = 0;; it++) {
                     unsigned long long vf[8], vc[8];
                     const bool wide = it >= 3;
@@ -153,6 +154,7 @@
                         nf += c0; sf += vf[j] & GR_FIX_PAYLOAD; nc += d0; sc += vc[j] & GR_FIX_PAYLOAD;
                         done = done && c0 + d0 == want;
                     }
+                    if (it == 0) H3T_RT(2); else if (it == 1) H3T_RT(3); else if (it == 2) H3T_RT(4);
                     if (__builtin_amdgcn_ballot_w64(!done) == 0ull) break;                   // (waves 0..3 poll, each until all of its values are in)
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) {                 // 4 ms at 100 MHz: not all workgroups are resident
                         if (XA.fail) __hip_atomic_store(XA.fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (host-mapped: the next forward entry / mtfjsp_encoder_check reports it)
