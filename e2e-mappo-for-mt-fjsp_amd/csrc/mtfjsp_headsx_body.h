@@ -60,14 +60,17 @@
         // own (its GAT passes wrote it), the BatchNorm in front of the pool has no ReLU (ac:434-444), so the pooled embedding is
         // scale * (raw row mean) + shift: the raw mean of this thread's instance and the other actor's embedding are formed now.
         // R <= 8 (host: mheads_fusable); rows beyond R are clamped and weighted 0 — no request behind a branch.
+        // R <= HCH (round 5, end): the scorer's X rows are staged by INSTANCE — thread (sr, 4 columns) takes rows sr R + t — so the rows it
+        // stages are the rows it pools: no second set of requests, and no wait for them in front of the exchange (by_inst).
+        const bool by_inst = R <= HCH;
         float4 praw = make_float4(0.f, 0.f, 0.f, 0.f), xo_pre;
-        {
+        xo_pre = *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + (sr < ng ? sr : ng - 1)) * HD + sc4);
+        if (!by_inst) {
             const int ic = sr < ng ? sr : ng - 1;
             const float *src = A.X + (size_t)(g0 + ic) * R * HD + sc4;
             float4 rv[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) rv[r] = *reinterpret_cast<const float4 *>(src + (size_t)(r < R ? r : R - 1) * HD);
-            xo_pre = *reinterpret_cast<const float4 *>(A.other + (size_t)(g0 + ic) * HD + sc4);
             const float ir = 1.0f / (float)R;
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -76,6 +79,8 @@
             }
             asm volatile("" : "+v"(praw.x), "+v"(praw.y), "+v"(praw.z), "+v"(praw.w));   // (formed here: the 8 row registers are free before the weight requests go out)
         }
+#else
+        const bool by_inst = false;
 #endif
         const unsigned char r_mask = A.mask[(size_t)g0 * R + (tid < nrows ? tid : nrows - 1)];   // the group's action mask (rows beyond 512: fetched where they are stored)
 #if !HX_XCHG
@@ -95,12 +100,12 @@
             int gi[HCH];
 #pragma unroll
             for (int t = 0; t < HCH; t++) {
-                const int grow = t * 16 + sr, gc = grow < nrows ? grow : nrows - 1;
+                const int grow = by_inst ? sr * R + t : t * 16 + sr, gc = (grow < nrows && (!by_inst || t < R)) ? grow : nrows - 1;
                 gi[t] = A.xgather ? A.xgather[(size_t)g0 * R + gc] : gc;
             }
 #pragma unroll
             for (int t = 0; t < HCH; t++) {
-                const int grow = t * 16 + sr, gc = grow < nrows ? grow : nrows - 1;
+                const int grow = by_inst ? sr * R + t : t * 16 + sr, gc = (grow < nrows && (!by_inst || t < R)) ? grow : nrows - 1;
                 const int il = (int)__umulhi((unsigned)gc, invR);
                 const float *src = A.xgather ? A.X + ((size_t)(g0 + il) * A.xT + gi[t]) * HD + sc4 : A.X + ((size_t)g0 * R + gc) * HD + sc4;
                 xr[t] = *reinterpret_cast<const float4 *>(src);
@@ -198,6 +203,14 @@
             const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
             float4 xp = z;
 #if HX_XCHG
+            if (by_inst) {                                          // the raw mean of the instance's R rows = of the rows this thread stages
+                const float ir = 1.0f / (float)R;
+#pragma unroll
+                for (int t = 0; t < HCH; t++) {
+                    const float wgt = t < R ? ir : 0.f;
+                    praw.x = fmaf(xr[t].x, wgt, praw.x); praw.y = fmaf(xr[t].y, wgt, praw.y); praw.z = fmaf(xr[t].z, wgt, praw.z); praw.w = fmaf(xr[t].w, wgt, praw.w);
+                }
+            }
             if (sr < ng) {
                 xp = make_float4(fmaf(praw.x, xs0, xh0), fmaf(praw.y, xs1, xh1), fmaf(praw.z, xs2, xh2), fmaf(praw.w, xs3, xh3));
                 *reinterpret_cast<float4 *>(A.pooled_out + (size_t)(g0 + sr) * HD + sc4) = xp;
@@ -299,12 +312,13 @@
                     const int grow = (tb + t) * 16 + sr;
                     xr[t] = (tb + t < ntl && grow < nrows) ? *reinterpret_cast<const float4 *>(xrow(grow)) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                const float4 xv4 = xnorm(xr[t], (tb + t) * 16 + sr < nrows);
+                const int srow = by_inst ? sr * R + t : (tb + t) * 16 + sr;   // (by_inst: one chunk, tb = 0)
+                const float4 xv4 = xnorm(xr[t], srow < nrows);
                 const float v[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
                 uint2 p0, p1;
                 split2x4(v, p0, p1);
-                unsigned char *d = s_xs + t * X2_TILE + sr * X6_ROWB + (tid & 31) * 8;
-                *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1;
+                unsigned char *d = by_inst ? s_xs + (srow >> 4) * X2_TILE + (srow & 15) * X6_ROWB + (tid & 31) * 8 : s_xs + t * X2_TILE + sr * X6_ROWB + (tid & 31) * 8;
+                if (!by_inst || t < R) { *reinterpret_cast<uint2 *>(d) = p0; *reinterpret_cast<uint2 *>(d + X6_PLANE) = p1; }
             }
             LDS_BARRIER();                                          // X planes, u and c1 are complete
             STAMP(2); H3_RT(2);
