@@ -95,6 +95,12 @@
         // barrier, both parked in LDS (rows beyond 512: the old way).  Pointers are chosen, not branched around (a request behind an `if`
         // makes the later waits drain everything): without gather_from / m_fea1 some valid word of X is fetched and ignored.
         const int r_gf = (A.gather_from ? A.gather_from + (size_t)g0 * R : reinterpret_cast<const int *>(A.X))[tid < nrows ? tid : nrows - 1];
+        h16x8 wA[2][4], wB[2][4], wC[2][4];
+        const float sW0 = A.sW0, sW1 = A.sW1, sWc0 = A.sWc0, sWc1 = A.sWc1;   // 1 / scale of the weight images
+        WCOLX(wA, A.W0x, 1);                                        // Wb
+        WCOLX(wB, A.W0x, 2);                                        // Wc
+        WCOLX(wC, A.Wc0x, 0);
+        // (the X rows behind the weights: phase A needs the weights first and covers the rows' arrival)
         float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
         {   // (rows beyond the group's are clamped to its last one here and zeroed by xnorm() where they are used)
             int gi[HCH];
@@ -111,11 +117,6 @@
                 xr[t] = *reinterpret_cast<const float4 *>(src);
             }
         }
-        h16x8 wA[2][4], wB[2][4], wC[2][4];
-        const float sW0 = A.sW0, sW1 = A.sW1, sWc0 = A.sWc0, sWc1 = A.sWc1;   // 1 / scale of the weight images
-        WCOLX(wA, A.W0x, 1);                                        // Wb
-        WCOLX(wB, A.W0x, 2);                                        // Wc
-        WCOLX(wC, A.Wc0x, 0);
 #ifdef HX_TOP_HOOK
         HX_TOP_HOOK                                                 // (requests of the including kernel that a later part consumes: behind this phase's own)
 #endif
