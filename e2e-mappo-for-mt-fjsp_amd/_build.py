@@ -44,10 +44,21 @@ def build_variant(tag, extra_flags, verbose=False):
     """diagnostic builds (never used by the product path): libmtfjsp_<tag>.so, selected with MTFJSP_LIB=<path>"""
     out = os.path.join(PKG, f"libmtfjsp_{tag}.so")
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    # a variant built in the build container ships with the snapshot: rebuilt only when a source or a flag changed (content hash —
+    # file times do not survive the copy)
+    import hashlib
+    hsh = hashlib.sha256(" ".join(FLAGS + list(extra_flags)).encode())
+    for d in sorted(srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))] + [os.path.join(PKG, "..", "include", "mtfjsp.h")]):
+        hsh.update(open(d, "rb").read())
+    stamp = out + ".srchash"
+    if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == hsh.hexdigest() and not os.environ.get("MTFJSP_REBUILD_VARIANTS"):
+        return out
     cmd = [hipcc()] + FLAGS + list(extra_flags) + srcs + ["-o", out]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(hsh.hexdigest())
     return out
 
 

@@ -1615,7 +1615,7 @@ __global__ __launch_bounds__(512) void k_heads(HeadArgs A)
                         const size_t row = (size_t)b * T_ + a;
                         int pm = 0;
                         if (a % M_ != 0) {
-                            pm = reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
+                            pm = reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 8 + 4];   // machine of the job predecessor
                             if (pm < 0) pm += M_;                                             // python negative index (pe:206)
                         }
                         for (int mm = l; mm < M_; mm += 16) {

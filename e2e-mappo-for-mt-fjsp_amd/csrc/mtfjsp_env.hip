@@ -158,8 +158,10 @@ __global__ __launch_bounds__(WAVE) void k_env_reset(EnvParams P)
             reinterpret_cast<int2 *>(P.obs.ell_col)[bT + v] = make_int2(c != 0 ? v - 1 : -1, -1);   // job edge weight 1 (env:617-644)
             reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(c != 0 ? 1.f : 0.f, 0.f);
             Link l; l.mach = -1; l.prev = -1; l.pos = 0; l.pad = -1;                               // pad = route successor
-            P.link[bT + v] = l;
-            P.st[bT + v] = 0.0; P.ft[bT + v] = 0.0; P.dur[bT + v] = 0.0; P.psel[bT + v] = 0.0; P.pte[bT + v] = s_pte[v];
+            TaskPL y; y.pte = s_pte[v]; y.link = l;
+            P.pl[bT + v] = y;
+            TaskSD x; x.st = 0.0; x.dur = 0.0;
+            P.sd[bT + v] = x;
         }
         WSYNC();
         const int n16 = rows * 12 * (int)sizeof(OBS) / 16;
@@ -173,11 +175,12 @@ __global__ __launch_bounds__(WAVE) void k_env_reset(EnvParams P)
     for (int j = lane; j < J; j += WAVE) {
         double fm = s_fte[j * M];
         for (int c = 1; c < M; c++) fm = fmax(fm, s_fte[j * M + c]);
-        P.jmax[(size_t)b * J + j] = fm; P.jrow[(size_t)b * J + j] = 0.0; P.jcnt[(size_t)b * J + j] = 0;
+        JobR r; r.jmax = fm; r.jrow = 0.0;
+        P.jr[(size_t)b * J + j] = r;
         P.obs.candidate[(size_t)b * J + j] = j * M;                         // ppo:90-98 pool = first op of every job
         P.obs.job_mask[(size_t)b * J + j] = 0;
     }
-    for (int i = lane; i < M; i += WAVE) { MRec r; r.head = -1; r.tail = -1; r.len = 0; r.pad = 0; P.mrec[(size_t)b * M + i] = r; }
+    for (int i = lane; i < P.MJ; i += WAVE) { MJRec r; r.head = -1; r.tail = -1; r.len = 0; r.cnt = 0; P.mj[(size_t)b * P.MJ + i] = r; }
     for (int i = lane; i < M * 8; i += WAVE) {
         const int f = i & 7;
         const double x = f == 5 ? w30 : f == 6 ? w31 : f == 7 ? w32 : 0.0;  // env:2343-2354
@@ -192,11 +195,12 @@ __global__ __launch_bounds__(WAVE) void k_env_reset(EnvParams P)
         else if (lane == S_W3) x = w30;
         else if (lane == S_W3 + 1) x = w31;
         else if (lane == S_W3 + 2) x = w32;
+        else if (lane == S_LASTM) x = -1.0;
         P.scal[(size_t)b * SCAL_N + lane] = x;
     }
     if (lane < 6) P.obs.info[(size_t)b * 6 + lane] = 0.0;
     if (lane < 5 && P.obs.raw) P.obs.raw[(size_t)b * 5 + lane] = 0.0;
-    if (lane == 6) { P.obs.status[b] = 0; P.lastm[b] = -1; }
+    if (lane == 6) P.obs.status[b] = 0;
 }
 static size_t env_reset_lds_bytes(int T, bool f32) { return (size_t)3 * T * 8 + (size_t)(T < WAVE ? T : WAVE) * 12 * (f32 ? 4 : 8) + 16; }
 
@@ -253,16 +257,17 @@ __global__ __launch_bounds__(WAVE, 4) void k_env_step(EnvParams P)
     const size_t bT = (size_t)b * T;
     // ---- bulk state first (independent of the action), the action-dependent second hop right behind it
     for (int v = lane; v < T; v += WAVE) {
-        s_st[v] = P.st[bT + v]; s_ft[v] = P.ft[bT + v]; s_dur[v] = P.dur[bT + v]; s_pte[v] = P.pte[bT + v];
-        const Link l = P.link[bT + v];
+        const TaskSD x = P.sd[bT + v]; const TaskPL y = P.pl[bT + v];
+        s_st[v] = x.st; s_dur[v] = x.dur; s_ft[v] = x.st + x.dur; s_pte[v] = y.pte;      // ft == st + dur (env:356)
+        const Link l = y.link;
         s_mach[v] = l.mach; s_prev[v] = l.prev; s_pos[v] = l.pos;
     }
     for (int i = lane; i < Tp; i += WAVE) s_term[i] = 0.0;
     for (int i = lane; i < M * M; i += WAVE) s_tt[i] = P.tt[(size_t)b * M * M + i];
-    for (int i = lane; i < M; i += WAVE) { const MRec r = P.mrec[(size_t)b * M + i]; s_head[i] = r.head; s_tail[i] = r.tail; s_len[i] = r.len; }
-    for (int i = lane; i < J; i += WAVE) { s_cnt[i] = (int)P.jcnt[(size_t)b * J + i]; s_jmax[i] = P.jmax[(size_t)b * J + i]; s_jrow[i] = P.jrow[(size_t)b * J + i]; }
+    for (int i = lane; i < P.MJ; i += WAVE) { const MJRec r = P.mj[(size_t)b * P.MJ + i]; if (i < M) { s_head[i] = r.head; s_tail[i] = r.tail; s_len[i] = r.len; } if (i < J) s_cnt[i] = r.cnt; }
+    for (int i = lane; i < J; i += WAVE) { const JobR r = P.jr[(size_t)b * J + i]; s_jmax[i] = r.jmax; s_jrow[i] = r.jrow; }
     if (lane < SCAL_N) s_sc[lane] = P.scal[(size_t)b * SCAL_N + lane];
-    const int lastm = P.lastm[b];
+    const int lastm = (int)P.scal[(size_t)b * SCAL_N + S_LASTM];
     int a = P.task_idx[b], m = P.mach_idx[b];
     bool valid = a >= 0 && a < T && m >= 0 && m < M;
     if (!valid) { a = 0; m = 0; }
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(WAVE, 4) void k_env_step(EnvParams P)
             reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(a_job, a_mch);
             if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + v) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
         }
-        if (lane == 6) P.lastm[b] = merged_now;
+        if (lane == 6) { s_sc[S_LASTM] = (double)merged_now; s_sc[S_TRLAST] = new_tr; }    // (written back with the scalar row below)
     }
     if (lane < 8) reinterpret_cast<OBS *>(P.obs.m_fea2)[((size_t)b * M + m) * 8 + lane] = (OBS)s_mfr[lane];
     STAMP(5);
@@ -567,13 +572,14 @@ __global__ __launch_bounds__(WAVE, 4) void k_env_step(EnvParams P)
         if (lane == 0) P.obs.candidate[(size_t)b * J + ja] = ja * M + (s_cnt[ja] < M ? s_cnt[ja] : M - 1);
     }
     // ---- write back the state that changed
+    WSYNC();
     for (int v = lane; v < T; v += WAVE) {
         Link l; l.mach = (short)s_mach[v]; l.prev = (short)s_prev[v]; l.pos = (short)s_pos[v]; l.pad = 0;
-        P.link[bT + v] = l;
+        P.pl[bT + v].link = l;
     }
-    if (lane == 0) { P.st[bT + a] = st_k; P.ft[bT + a] = ft_k; P.dur[bT + a] = d; P.psel[bT + a] = pk; P.pte[bT + a] = d * pk; }
-    if (lane == 1) { P.jcnt[(size_t)b * J + ja] = (short)s_cnt[ja]; P.jmax[(size_t)b * J + ja] = s_jmax[ja]; P.jrow[(size_t)b * J + ja] = s_jrow[ja]; }
-    if (lane == 2) { MRec r; r.head = (short)s_head[m]; r.tail = (short)s_tail[m]; r.len = (short)s_len[m]; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+    if (lane == 0) { TaskSD x; x.st = st_k; x.dur = d; P.sd[bT + a] = x; P.pl[bT + a].pte = d * pk; }
+    if (lane == 1) { JobR r; r.jmax = s_jmax[ja]; r.jrow = s_jrow[ja]; P.jr[(size_t)b * J + ja] = r; P.mj[(size_t)b * P.MJ + ja].cnt = (short)s_cnt[ja]; }
+    if (lane == 2) { MJRec *r = &P.mj[(size_t)b * P.MJ + m]; r->head = (short)s_head[m]; r->tail = (short)s_tail[m]; r->len = (short)s_len[m]; }
     if (lane >= 8 && lane < 16) P.mfea[((size_t)b * M + m) * 8 + lane - 8] = s_mfr[lane - 8];
     if (lane < SCAL_N) P.scal[(size_t)b * SCAL_N + lane] = s_sc[lane];
 #ifdef MTFJSP_STAMP
@@ -619,17 +625,18 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
     int mach = -1, prev = -1, next = -1, pos = 0;
     double st = 0.0, ft = 0.0, dur = 0.0, pte = 0.0;
     if (isT) {
-        const Link l = P.link[bT + v];
+        const TaskSD x = P.sd[bT + v]; const TaskPL y = P.pl[bT + v];
+        const Link l = y.link;
         mach = l.mach; prev = l.prev; pos = l.pos; next = l.pad;
-        st = P.st[bT + v]; ft = P.ft[bT + v]; dur = P.dur[bT + v]; pte = P.pte[bT + v];
+        st = x.st; dur = x.dur; ft = x.st + x.dur; pte = y.pte;                  // ft == st + dur (env:356)
     }
     const double ttv = lane < M * M ? P.tt[(size_t)b * M * M + lane] : 0.0;
     int head_ = -1, tail_ = -1, len_ = 0;
-    if (lane < M) { const MRec r = P.mrec[(size_t)b * M + lane]; head_ = r.head; tail_ = r.tail; len_ = r.len; }
     int cnt_ = 0; double jmax_ = -INFINITY, jrow_ = 0.0;
-    if (lane < J) { cnt_ = (int)P.jcnt[(size_t)b * J + lane]; jmax_ = P.jmax[(size_t)b * J + lane]; jrow_ = P.jrow[(size_t)b * J + lane]; }
+    if (lane < P.MJ) { const MJRec r = P.mj[(size_t)b * P.MJ + lane]; if (lane < M) { head_ = r.head; tail_ = r.tail; len_ = r.len; } if (lane < J) cnt_ = r.cnt; }
+    if (lane < J) { const JobR r = P.jr[(size_t)b * J + lane]; jmax_ = r.jmax; jrow_ = r.jrow; }
     const double sc = lane < SCAL_N ? P.scal[(size_t)b * SCAL_N + lane] : 0.0;
-    const int lastm = uni(P.lastm[b]);
+    const int lastm = (int)rl_d(sc, S_LASTM);
     int a = uni(P.task_idx[b]), m = uni(P.mach_idx[b]);
     bool valid = a >= 0 && a < T && m >= 0 && m < M;
     if (!valid) { a = 0; m = 0; }
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
             reinterpret_cast<float2 *>(P.obs.ell_val)[bT + vv] = make_float2(a_job, a_mch);
             if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + vv) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
         }
-        if (lane == 6) P.lastm[b] = merged_now;
+        if (lane == 6) { P.scal[(size_t)b * SCAL_N + S_LASTM] = (double)merged_now; P.scal[(size_t)b * SCAL_N + S_TRLAST] = new_tr; }
     }
 
     // =========================================================================================
@@ -921,17 +928,18 @@ __global__ __launch_bounds__(WAVE) void k_env_reg(EnvParams P)
             P.obs.job_mask[(size_t)b * J + lane] = mk_;
             if (lane == ja) {
                 P.obs.candidate[(size_t)b * J + ja] = ja * M + (cnt_ < M ? cnt_ : M - 1);
-                P.jcnt[(size_t)b * J + ja] = (short)cnt_; P.jmax[(size_t)b * J + ja] = jmax_; P.jrow[(size_t)b * J + ja] = jrow_;
+                JobR r; r.jmax = jmax_; r.jrow = jrow_;
+                P.jr[(size_t)b * J + ja] = r;
             }
         }
     }
     // ---- write back the state that changed
     if (isT) {
-        Link l; l.mach = (short)mach; l.prev = (short)prev; l.pos = (short)pos; l.pad = (short)next;
-        P.link[bT + v] = l;
-        if (v == a) { P.st[bT + a] = st; P.ft[bT + a] = ft; P.dur[bT + a] = dur; P.psel[bT + a] = pk; P.pte[bT + a] = pte; }
+        TaskPL y; y.pte = pte; y.link.mach = (short)mach; y.link.prev = (short)prev; y.link.pos = (short)pos; y.link.pad = (short)next;
+        P.pl[bT + v] = y;
+        if (v == a) { TaskSD x; x.st = st; x.dur = dur; P.sd[bT + a] = x; }
     }
-    if (lane == m) { MRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+    if (lane == m || lane == ja) { MJRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.cnt = (short)cnt_; P.mj[(size_t)b * P.MJ + lane] = r; }
 #undef DIVM
 }
 
@@ -1035,18 +1043,18 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
     // ---- the action first; then the bulk state with every request of up to 8 task slots per lane in flight before the first
     // LDS write (a plain loop pays one memory round trip per 64 tasks); the action-dependent requests go out behind the bulk
     // requests and before any of them is waited for (loads return in order: the action's two words are there first)
-    const int lastm = P.lastm[b];
+    const int lastm = (int)P.scal[(size_t)b * SCAL_N + S_LASTM];
     int a = P.task_idx[b], m = P.mach_idx[b];
     const double *ttb = P.tt + (size_t)b * M * M;
     bool valid = false;
     int ja = 0, op = 0;
     double d = 0.0, pk = 0.0, x_mind = 0.0, x_ttc = 0.0, x_mfr = 0.0;
     for (int v0 = 0; v0 < T; v0 += 8 * WAVE) {
-        double x_st[8], x_ft[8], x_pte[8]; Link x_l[8];
+        TaskSD x_sd[8]; TaskPL x_pl[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int v = v0 + k * WAVE + lane;
-            if (v < T) { x_st[k] = P.st[bT + v]; x_ft[k] = P.ft[bT + v]; x_pte[k] = P.pte[bT + v]; x_l[k] = P.link[bT + v]; }
+            if (v < T) { x_sd[k] = P.sd[bT + v]; x_pl[k] = P.pl[bT + v]; }
         }
         if (v0 == 0) {
             valid = a >= 0 && a < T && m >= 0 && m < M;
@@ -1054,21 +1062,21 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
             ja = DIVM(a); op = a - ja * M;
             d = P.t[(bT + a) * M + m];
             pk = P.p[(bT + a) * M + m];
-            if (lane < M) { x_mind = P.cst[bT + ja * M + lane].x; x_ttc = ttb[lane * M + m]; }
+            if (lane < M) { x_mind = P.cst[bT + ja * M + lane].x; x_ttc = P.ttT[((size_t)b * M + m) * M + lane]; }
             if (lane < 8) x_mfr = P.mfea[((size_t)b * M + m) * 8 + lane];
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const int v = v0 + k * WAVE + lane;
-            if (v < T) { s_st[v] = x_st[k]; s_ft[v] = x_ft[k]; s_pte[v] = x_pte[k]; s_mach[v] = x_l[k].mach; s_prev[v] = x_l[k].prev; s_pos[v] = x_l[k].pos; }
+            if (v < T) { s_st[v] = x_sd[k].st; s_ft[v] = x_sd[k].st + x_sd[k].dur; s_pte[v] = x_pl[k].pte; s_mach[v] = x_pl[k].link.mach; s_prev[v] = x_pl[k].link.prev; s_pos[v] = x_pl[k].link.pos; }   // ft == st + dur (env:356)
         }
     }
     for (int i = lane; i < Tp; i += WAVE) s_term[i] = 0.0;
-    for (int i = lane; i < M; i += WAVE) { const MRec r = P.mrec[(size_t)b * M + i]; s_head[i] = r.head; s_tail[i] = r.tail; s_len[i] = r.len; }
-    for (int i = lane; i < J; i += WAVE) { s_cnt[i] = (int)P.jcnt[(size_t)b * J + i]; s_jmax[i] = P.jmax[(size_t)b * J + i]; s_jrow[i] = P.jrow[(size_t)b * J + i]; }
+    for (int i = lane; i < P.MJ; i += WAVE) { const MJRec r = P.mj[(size_t)b * P.MJ + i]; if (i < M) { s_head[i] = r.head; s_tail[i] = r.tail; s_len[i] = r.len; } if (i < J) s_cnt[i] = r.cnt; }
+    for (int i = lane; i < J; i += WAVE) { const JobR r = P.jr[(size_t)b * J + i]; s_jmax[i] = r.jmax; s_jrow[i] = r.jrow; }
     if (lane < SCAL_N) s_sc[lane] = P.scal[(size_t)b * SCAL_N + lane];
     if (lane < M) { s_mind[lane] = x_mind; s_ttc[lane] = x_ttc; }
-    for (int i = WAVE + lane; i < M; i += WAVE) { s_mind[i] = P.cst[bT + ja * M + i].x; s_ttc[i] = ttb[i * M + m]; }
+    for (int i = WAVE + lane; i < M; i += WAVE) { s_mind[i] = P.cst[bT + ja * M + i].x; s_ttc[i] = P.ttT[((size_t)b * M + m) * M + i]; }
     if (lane < 8) s_mfr[lane] = x_mfr;
     WSYNC();
 
@@ -1171,7 +1179,7 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
     int e_mv = -1, e_pr = -1, e_mu = -1, e_opv = 0, e_jv = 0;
     double e_nd = 1.0, e_dp = 0.0, e_tt1 = 0.0, e_tt2 = 0.0, e_gap1 = 0.0, e_gap2 = 0.0;
     if (ev >= 0) {
-        auto durg = [&](int x) __attribute__((always_inline)) { return x == a ? d : P.dur[bT + x]; };
+        auto durg = [&](int x) __attribute__((always_inline)) { return x == a ? d : P.sd[bT + x].dur; };
         auto ttg = [&](int r, int c) __attribute__((always_inline)) { return c == m ? s_ttc[r] : ttb[r * M + c]; };
         e_mv = s_mach[ev];
         e_jv = DIVM(ev); e_opv = ev - e_jv * M;
@@ -1337,7 +1345,7 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
         reinterpret_cast<float2 *>(P.obs.ell_val)[bT + v] = make_float2(a_job, a_mch);
         if (lane == 2) reinterpret_cast<OBS *>(P.obs.tasks_fea)[(bT + v) * 12 + 4] = (OBS)(1 + ((pr >= 0 && !merged) ? 1 : 0));
     }
-    if (lane == 6) P.lastm[b] = merged_now;
+    if (lane == 6) { P.scal[(size_t)b * SCAL_N + S_LASTM] = (double)merged_now; P.scal[(size_t)b * SCAL_N + S_TRLAST] = (op == 0) ? 0.0 : s_ttc[s_mach[a - 1]]; }
 
     ESW_RT(5);
     // ---- candidate of the acting job (ppo:202-316; the mask is the scalar part's)
@@ -1356,12 +1364,12 @@ __device__ __forceinline__ void env_step_wave(const EnvParams &P, const int b, c
         for (int k = 0; k < 8; k++)
             if (mc[k] == m && ps[k] >= ipos) {
                 Link l; l.mach = mc[k]; l.prev = pr[k]; l.pos = ps[k]; l.pad = 0;
-                P.link[bT + v0 + k * WAVE + lane] = l;
+                P.pl[bT + v0 + k * WAVE + lane].link = l;
             }
     }
-    if (lane == 0) { P.st[bT + a] = st_k; P.ft[bT + a] = ft_k; P.dur[bT + a] = d; P.psel[bT + a] = pk; P.pte[bT + a] = d * pk; }
-    if (lane == 1) { P.jcnt[(size_t)b * J + ja] = (short)s_cnt[ja]; P.jmax[(size_t)b * J + ja] = s_jmax[ja]; P.jrow[(size_t)b * J + ja] = s_jrow[ja]; }
-    if (lane == 2) { MRec r; r.head = (short)s_head[m]; r.tail = (short)s_tail[m]; r.len = (short)s_len[m]; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+    if (lane == 0) { TaskSD x; x.st = st_k; x.dur = d; P.sd[bT + a] = x; P.pl[bT + a].pte = d * pk; }
+    if (lane == 1) { JobR r; r.jmax = s_jmax[ja]; r.jrow = s_jrow[ja]; P.jr[(size_t)b * J + ja] = r; P.mj[(size_t)b * P.MJ + ja].cnt = (short)s_cnt[ja]; }
+    if (lane == 2) { MJRec *r = &P.mj[(size_t)b * P.MJ + m]; r->head = (short)s_head[m]; r->tail = (short)s_tail[m]; r->len = (short)s_len[m]; }
     ESW_RT(6);
 #undef ESW_RT
 #undef DIVM
@@ -1417,10 +1425,19 @@ __global__ void k_prepare(int B, int T, int M, const double *t, const double *p,
     mean3[(size_t)i * 3 + 2] = np_sum(bp, np_) / (double)np_;
 }
 
+// ttT[b][m][x] = tt[b][x][m]: thread = (b, m, x)
+__global__ void k_transpose_tt(int B, int M, const double *tt, double *ttT)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * M * M) return;
+    const int b = i / (M * M), r = i - b * M * M, m = r / M, x = r - m * M;
+    ttT[i] = tt[((size_t)b * M + x) * M + m];
+}
+
 // m_fea1 (pe:152-214): thread = (b, machine)
 template <typename OBS>
 __global__ void k_mfea1(int B, int T, int M, const double *t, const double *p, const double *tt, const double *mean3,
-                        const int *shop, const Link *link, const int *task_idx, const uint8_t *mmask_in, OBS *out,
+                        const int *shop, const TaskPL *pl, const int *task_idx, const uint8_t *mmask_in, OBS *out,
                         uint8_t *mmask_out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1434,7 +1451,7 @@ __global__ void k_mfea1(int B, int T, int M, const double *t, const double *p, c
     const uint8_t mk = mmask_in ? mmask_in[i] : (uint8_t)!(tv >= 0);          // run:258-259 ~(t >= 0)
     double x = 0.0;
     if (a % M != 0) {
-        int pm = link[row - 1].mach;                                          // == tasks_fea[a-1][5] - 1 (pe:206)
+        int pm = pl[row - 1].link.mach;                                       // == tasks_fea[a-1][5] - 1 (pe:206)
         if (pm < 0) pm += M;                                                  // python negative index on an unscheduled predecessor
         x = tt[((size_t)b * M + pm) * M + m];
     }
@@ -1463,12 +1480,12 @@ __global__ void k_dense_adj(int B, int T, const int *ell_col, const float *ell_v
 }
 
 // env.valid_action_mask (env:2535-2575): thread = (b, task)
-__global__ void k_valid_mask(int B, int T, int M, const Link *link, uint8_t *out)
+__global__ void k_valid_mask(int B, int T, int M, const TaskPL *pl, uint8_t *out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * T) return;
     const int v = i % T;
-    bool ok = link[i].mach < 0 && (v % M == 0 || link[i - 1].mach >= 0);
+    bool ok = pl[i].link.mach < 0 && (v % M == 0 || pl[i - 1].link.mach >= 0);
     out[i] = ok;
 }
 
@@ -1672,14 +1689,12 @@ struct mtfjsp_env {
     double *t = nullptr, *p = nullptr, *tt = nullptr, *mean3 = nullptr;
     double2 *cst = nullptr;
     int *shop = nullptr;
-    double *st = nullptr, *ft = nullptr, *dur = nullptr, *psel = nullptr, *mfea = nullptr, *scal = nullptr;
+    double *ttT = nullptr;             // tt transposed per instance (the step kernels read one row of it behind the action)
+    TaskSD *sd = nullptr; TaskPL *pl = nullptr; JobR *jr = nullptr; MJRec *mj = nullptr;   // dynamic state records (mtfjsp_env_dev.h)
+    int MJ = 0;
+    double *mfea = nullptr, *scal = nullptr;
     size_t lds_max = 64 * 1024;        // hipDeviceAttributeMaxSharedMemoryPerBlock of the handle's device (160 KiB on gfx950)
     bool grp_lds_ok = true;            // the grouped LDS step kernel may be launched with lds_max bytes
-    Link *link = nullptr;
-    MRec *mrec = nullptr;
-    short *jcnt = nullptr;
-    double *pte = nullptr, *jmax = nullptr, *jrow = nullptr;
-    int *lastm = nullptr;
     int *d_task = nullptr, *d_mach = nullptr;
     double *d_w3 = nullptr;
     short *pw_tab = nullptr;           // pw_table(T) on the device
@@ -1743,10 +1758,10 @@ extern "C" int mtfjsp_create(const mtfjsp_config_t *cfg, mtfjsp_handle_t *out)
     int rc = 0;
     rc |= dalloc(h, &h->t, B * T * M); rc |= dalloc(h, &h->p, B * T * M); rc |= dalloc(h, &h->tt, B * M * M);
     rc |= dalloc(h, &h->mean3, B * T * 3); rc |= dalloc(h, &h->cst, B * T); rc |= dalloc(h, &h->shop, B * M);
-    rc |= dalloc(h, &h->st, B * T); rc |= dalloc(h, &h->ft, B * T); rc |= dalloc(h, &h->dur, B * T); rc |= dalloc(h, &h->psel, B * T);
+    h->MJ = cfg->n_job > cfg->n_machine ? cfg->n_job : cfg->n_machine;
+    rc |= dalloc(h, &h->ttT, B * M * M);
+    rc |= dalloc(h, &h->sd, B * T); rc |= dalloc(h, &h->pl, B * T); rc |= dalloc(h, &h->jr, B * (size_t)cfg->n_job); rc |= dalloc(h, &h->mj, B * (size_t)h->MJ);
     rc |= dalloc(h, &h->mfea, B * M * 8); rc |= dalloc(h, &h->scal, B * SCAL_N);
-    rc |= dalloc(h, &h->link, B * T); rc |= dalloc(h, &h->mrec, B * M); rc |= dalloc(h, &h->jcnt, B * (size_t)cfg->n_job);
-    rc |= dalloc(h, &h->pte, B * T); rc |= dalloc(h, &h->jmax, B * (size_t)cfg->n_job); rc |= dalloc(h, &h->jrow, B * (size_t)cfg->n_job); rc |= dalloc(h, &h->lastm, B);
     rc |= dalloc(h, &h->d_task, B); rc |= dalloc(h, &h->d_mach, B); rc |= dalloc(h, &h->d_w3, B * 3);
     if (rc) { g_create_err = h->err; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
     if (hipMemset(h->scal, 0, B * SCAL_N * sizeof(double)) != hipSuccess) { g_create_err = "memset failed"; mtfjsp_destroy(h); return MTFJSP_ERR_HIP; }
@@ -1879,6 +1894,7 @@ static int load_common(mtfjsp_env *h, const double *t, const double *p, const do
     HIPCHK(h, hipMemcpyAsync(h->shop, shop, B * M * 4, kind, h->stream));
     const int n = (int)(B * T);
     hipLaunchKernelGGL(k_prepare, dim3((n + 127) / 128), dim3(128), 0, h->stream, (int)B, (int)T, (int)M, h->t, h->p, h->cst, h->mean3);
+    hipLaunchKernelGGL(k_transpose_tt, dim3((unsigned)((B * M * M + 127) / 128)), dim3(128), 0, h->stream, (int)B, (int)M, h->tt, h->ttT);
     HIPCHK(h, hipGetLastError());
     if (kind == hipMemcpyHostToDevice) HIPCHK(h, hipStreamSynchronize(h->stream));
     h->loaded = true; h->was_reset = false;
@@ -1908,6 +1924,7 @@ extern "C" int mtfjsp_generate_instances(mtfjsp_handle_t h, uint64_t seed, uint6
     const int n = B * (T > M * M ? T : M * M);
     hipLaunchKernelGGL(k_generate, dim3((n + 127) / 128), dim3(128), 0, h->stream, B, T, M, E, seed, first_instance, S, h->t, h->p, h->tt, h->shop);
     hipLaunchKernelGGL(k_prepare, dim3((B * T + 127) / 128), dim3(128), 0, h->stream, B, T, M, h->t, h->p, h->cst, h->mean3);
+    hipLaunchKernelGGL(k_transpose_tt, dim3((B * M * M + 127) / 128), dim3(128), 0, h->stream, B, M, h->tt, h->ttT);
     HIPCHK(h, hipGetLastError());
     h->loaded = true; h->was_reset = false;
     return MTFJSP_OK;
@@ -1954,7 +1971,7 @@ static EnvParams make_params(mtfjsp_env *h)
     P.left_shift = h->cfg.left_shift; P.obs_f32 = h->cfg.obs_dtype == MTFJSP_OBS_F32;
     P.w_mk = h->cfg.w_mk; P.w_ec = h->cfg.w_ec; P.w_tt = h->cfg.w_tt; P.divisor = h->cfg.scaling_divisor; P.gamma = h->cfg.gamma;
     P.t = h->t; P.p = h->p; P.tt = h->tt; P.cst = h->cst;
-    P.st = h->st; P.ft = h->ft; P.dur = h->dur; P.psel = h->psel; P.link = h->link; P.mrec = h->mrec; P.jcnt = h->jcnt; P.pte = h->pte; P.jmax = h->jmax; P.jrow = h->jrow; P.lastm = h->lastm; P.mfea = h->mfea; P.scal = h->scal;
+    P.ttT = h->ttT; P.sd = h->sd; P.pl = h->pl; P.jr = h->jr; P.mj = h->mj; P.MJ = h->MJ; P.mfea = h->mfea; P.scal = h->scal;
     P.inv_M = (unsigned)((0x100000000ull + (unsigned long long)P.M - 1) / (unsigned long long)P.M);
     P.obs = h->obs;
     P.pw_tab = h->pw_tab; P.pw_nleaf = h->pw_nleaf;
@@ -2123,6 +2140,9 @@ static int step_impl(mtfjsp_handle_t h, const int32_t *task_idx, const int32_t *
                     c[g] += (double)(hst[2048 + (size_t)w * 64 + g * 4 + 2] - t0) / 100.0 / ng; dn[g] += (double)(hst[2048 + (size_t)w * 64 + g * 4 + 3] - t0) / 100.0 / ng;
                 }
                 for (int g = 0; g < 16; g++) printf("STAMPW wave %2d: entry %.2f first-hop %.2f costs %.2f done %.2f\n", g, e[g], f[g], c[g], dn[g]);
+                double t2[4] = {0};
+                for (int w = 0; w < ng; w++) for (int i = 0; i < 4; i++) t2[i] += (double)(hst[2048 + 256 * 64 + (size_t)w * 4 + i] - t0) / 100.0 / ng;
+                printf("STAMPT scalar-part wave: inputs read %.2f  idle sum done %.2f  rewards + scaling done %.2f  machine row done %.2f\n", t2[0], t2[1], t2[2], t2[3]);
             }
 #endif
             printf("STAMP k_env_grp16 B=%d (us since the first workgroup's start, wave 0): entry %.2f  first-hop data %.2f  decision %.2f  per-task costs done %.2f  wave done %.2f  barrier %.2f  scalar-part wave done %.2f  ELL/mask wave done %.2f\n",
@@ -2165,9 +2185,9 @@ extern "C" int mtfjsp_observe_mfea1(mtfjsp_handle_t h, const int32_t *task_idx, 
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int B = h->cfg.batch, M = h->cfg.n_machine, n = B * M;
     if (h->cfg.obs_dtype == MTFJSP_OBS_F32)
-        hipLaunchKernelGGL((k_mfea1<float>), dim3((n + 255) / 256), dim3(256), 0, h->stream, B, h->T, M, h->t, h->p, h->tt, h->mean3, h->shop, h->link, task_idx, mmask_in, (float *)out, mmask_out);
+        hipLaunchKernelGGL((k_mfea1<float>), dim3((n + 255) / 256), dim3(256), 0, h->stream, B, h->T, M, h->t, h->p, h->tt, h->mean3, h->shop, h->pl, task_idx, mmask_in, (float *)out, mmask_out);
     else
-        hipLaunchKernelGGL((k_mfea1<double>), dim3((n + 255) / 256), dim3(256), 0, h->stream, B, h->T, M, h->t, h->p, h->tt, h->mean3, h->shop, h->link, task_idx, mmask_in, (double *)out, mmask_out);
+        hipLaunchKernelGGL((k_mfea1<double>), dim3((n + 255) / 256), dim3(256), 0, h->stream, B, h->T, M, h->t, h->p, h->tt, h->mean3, h->shop, h->pl, task_idx, mmask_in, (double *)out, mmask_out);
     HIPCHK(h, hipGetLastError());
     return MTFJSP_OK;
 }
@@ -2177,7 +2197,7 @@ extern "C" int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uin
     if (!h || !m_fea1_out || !mmask_out || !ctx) return MTFJSP_ERR_ARG;
     int rc = check_ready(h, false);
     if (rc) return rc;
-    ctx->t = h->t; ctx->p = h->p; ctx->tt = h->tt; ctx->mean3 = h->mean3; ctx->shop = h->shop; ctx->link = h->link;
+    ctx->t = h->t; ctx->p = h->p; ctx->tt = h->tt; ctx->mean3 = h->mean3; ctx->shop = h->shop; ctx->link = h->pl;
     ctx->m_fea1_out = m_fea1_out; ctx->mmask_out = mmask_out;
     ctx->T = h->T; ctx->M = h->cfg.n_machine; ctx->obs_f32 = h->cfg.obs_dtype == MTFJSP_OBS_F32;
     ctx->m_fea2 = h->obs_bound ? h->obs.m_fea2 : nullptr;
@@ -2241,7 +2261,7 @@ extern "C" int mtfjsp_valid_action_mask(mtfjsp_handle_t h, uint8_t *out)
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const int n = h->cfg.batch * h->T;
-    hipLaunchKernelGGL(k_valid_mask, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->cfg.batch, h->T, h->cfg.n_machine, h->link, out);
+    hipLaunchKernelGGL(k_valid_mask, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->cfg.batch, h->T, h->cfg.n_machine, h->pl, out);
     HIPCHK(h, hipGetLastError());
     return MTFJSP_OK;
 }
@@ -2262,9 +2282,11 @@ extern "C" int mtfjsp_read_state_host(mtfjsp_handle_t h, int which, void *out)
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     const size_t B = h->cfg.batch, T = h->T, M = h->cfg.n_machine;
-    std::vector<Link> link(B * T);
-    HIPCHK(h, hipMemcpyAsync(link.data(), h->link, B * T * sizeof(Link), hipMemcpyDeviceToHost, h->stream));
+    std::vector<TaskPL> pl(B * T);
+    HIPCHK(h, hipMemcpyAsync(pl.data(), h->pl, B * T * sizeof(TaskPL), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    std::vector<Link> link(B * T);
+    for (size_t i = 0; i < B * T; i++) link[i] = pl[i].link;
     switch (which) {
     case MTFJSP_STATE_MACHINE: {
         int32_t *o = (int32_t *)out;
@@ -2274,9 +2296,10 @@ extern "C" int mtfjsp_read_state_host(mtfjsp_handle_t h, int which, void *out)
     case MTFJSP_STATE_START:
     case MTFJSP_STATE_FINISH: {
         double *o = (double *)out;
-        rc = mtfjsp_copy_to_host(h, o, which == MTFJSP_STATE_START ? h->st : h->ft, B * T * 8);
+        std::vector<TaskSD> sd(B * T);
+        rc = mtfjsp_copy_to_host(h, sd.data(), h->sd, B * T * sizeof(TaskSD));
         if (rc) return rc;
-        for (size_t i = 0; i < B * T; i++) if (link[i].mach < 0) o[i] = NAN;
+        for (size_t i = 0; i < B * T; i++) o[i] = link[i].mach < 0 ? NAN : which == MTFJSP_STATE_START ? sd[i].st : sd[i].st + sd[i].dur;   // ft == st + dur (env:356)
         return MTFJSP_OK;
     }
     case MTFJSP_STATE_ROUTES: {

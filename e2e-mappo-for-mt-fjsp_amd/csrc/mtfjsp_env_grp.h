@@ -55,35 +55,65 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     };
     const size_t bT = (size_t)b * T;
     int v[NS]; bool isT[NS];
-    // ---- bulk state (independent of the action)
+    // ---- Loads.  Round 6: the loads used to sit behind `if (lane < ...)` branches; hipcc turned every branch into "request, wait
+    // for EVERYTHING outstanding, continue" — three dependent round trips (bulk state | per-job rows, scalars and the action |
+    // the rows the action selects) where the data dependencies ask for one and a short second.  Now: the action first (scalar
+    // loads), every action-independent row in ONE batch with clamped indices and no branch (lanes past the end re-read the last
+    // element: same line, no traffic), and the rows the action selects as soon as the action is there, behind the batch.
+    // State records (mtfjsp_env_dev.h): a lane's share of the batch is FIVE loads, three of them 16 bytes wide (round 5: eleven
+    // 8-byte loads from eleven arrays, 2.1 KB per instance; now 1.5 KB — no finish times, no transport matrix).
+    int a = uni(P.task_idx[b]), m = uni(P.mach_idx[b]);
+    __builtin_amdgcn_sched_barrier(0);          // (the action's requests stay ahead of the batch)
     int mach[NS], prev[NS], next[NS], pos[NS];
-    double st[NS], ft[NS], dur[NS], pte[NS], ttv[NS];
+    double st[NS], ft[NS], dur[NS], pte[NS];
+    TaskSD sd_[NS]; TaskPL pl_[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         v[s] = lane + 64 * s; isT[s] = v[s] < T;
-        mach[s] = -1; prev[s] = -1; next[s] = -1; pos[s] = 0; st[s] = 0.0; ft[s] = 0.0; dur[s] = 0.0; pte[s] = 0.0;
-        if (isT[s]) {
-            const Link l = P.link[bT + v[s]];
-            mach[s] = l.mach; prev[s] = l.prev; pos[s] = l.pos; next[s] = l.pad;
-            st[s] = P.st[bT + v[s]]; ft[s] = P.ft[bT + v[s]]; dur[s] = P.dur[bT + v[s]]; pte[s] = P.pte[bT + v[s]];
-        }
-        ttv[s] = v[s] < M * M ? P.tt[(size_t)b * M * M + v[s]] : 0.0;
+        const size_t o = bT + (isT[s] ? v[s] : T - 1);
+        sd_[s] = P.sd[o]; pl_[s] = P.pl[o];
     }
-    int head_ = -1, tail_ = -1, len_ = 0;
-    if (lane < M) { const MRec r = P.mrec[(size_t)b * M + lane]; head_ = r.head; tail_ = r.tail; len_ = r.len; }
-    int cnt_ = 0; double jmax_ = -INFINITY, jrow_ = 0.0;
-    if (lane < J) { cnt_ = (int)P.jcnt[(size_t)b * J + lane]; jmax_ = P.jmax[(size_t)b * J + lane]; jrow_ = P.jrow[(size_t)b * J + lane]; }
-    const double sc = lane < SCAL_N ? P.scal[(size_t)b * SCAL_N + lane] : 0.0;
-    const int lastm = uni(P.lastm[b]);
-    int a = uni(P.task_idx[b]), m = uni(P.mach_idx[b]);
+    const MJRec r_ = P.mj[(size_t)b * P.MJ + (lane < P.MJ ? lane : P.MJ - 1)];
+    const JobR jr_ = P.jr[(size_t)b * J + (lane < J ? lane : J - 1)];
+    const double sc = P.scal[(size_t)b * SCAL_N + (lane < SCAL_N ? lane : SCAL_N - 1)];
+    // (the second hop's per-lane source array is known before the action: only a 32-bit offset waits for it)
+    const bool h_mf = lane < 8, h_md = lane >= 16 && lane < 16 + M, h_tt = lane >= 40 && lane < 40 + M;
+    const char *src0 = reinterpret_cast<const char *>(lane == 33 ? P.p + bT * M : P.t + bT * M);
+    if (h_mf) src0 = reinterpret_cast<const char *>(P.mfea + (size_t)b * M * 8 + lane);
+    if (h_md) src0 = reinterpret_cast<const char *>(&P.cst[bT + (lane - 16)].x);
+    if (h_tt) src0 = reinterpret_cast<const char *>(P.ttT + (size_t)b * M * M + (lane - 40));
+    const unsigned k_mf = h_mf ? ~0u : 0u, k_md = h_md ? ~0u : 0u, k_tt = h_tt ? ~0u : 0u, k_t = ~(k_mf | k_md | k_tt);   // (selects as masks: the ternary chain became four nested branches)
+    __builtin_amdgcn_sched_barrier(0);          // every request of the batch goes out before the wait for the action
     bool valid = a >= 0 && a < T && m >= 0 && m < M;
     if (!valid) { a = 0; m = 0; }
     const int ja = DIVM(a), op = a - ja * M;
-    // ---- second hop (depends on the action)
-    const double d = P.t[(bT + a) * M + m];
-    const double pk = P.p[(bT + a) * M + m];
-    const double md = lane < M ? P.cst[bT + ja * M + lane].x : 0.0;
-    const double mfr = lane < 8 ? P.mfea[((size_t)b * M + m) * 8 + lane] : 0.0;
+    // ---- second hop (depends on the action): ONE vector load with a per-lane source — lanes 0..7 the acting machine's feature row,
+    // lanes 16..16+M-1 the acting job's minimal durations, lane 32 t[a, m], lane 33 p[a, m], lanes 40..40+M-1 column m of the
+    // transport times (a row of the transposed copy: the step never needs another column — its own decision, the job edge of a, the
+    // route edges of a and of its successor all end on machine m; the one entry of another column, for the merged edge that
+    // reverts, is the previous step's job-edge transport time and waits in S_TRLAST); every other lane re-reads t[a, m].
+    // As four loads, the two uniform ones became scalar loads that hipcc sank into the branch of their first use, BEHIND the
+    // waits for the batch: a third dependent round trip.  The lane reads below are convergent and keep the request up here.
+    double d, pk, md, mfr, ttc;
+    {
+        const unsigned off = (k_mf & ((unsigned)m * 64u)) | (k_md & ((unsigned)(ja * M) * 16u)) | (k_tt & ((unsigned)(m * M) * 8u)) | (k_t & ((unsigned)(a * M + m) * 8u));
+        const double x2 = *reinterpret_cast<const double *>(src0 + off);
+        d = rl_d(x2, 32); pk = rl_d(x2, 33);
+        md = x2; mfr = x2; ttc = x2;
+    }
+#define MD_AT(c) rl_d(md, 16 + (c))
+#define TTC_AT(x) rl_d(ttc, 40 + (x))           /* tt[x, m], uniform x */
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+        const Link l = pl_[s].link;
+        mach[s] = isT[s] ? l.mach : -1; prev[s] = isT[s] ? l.prev : -1; pos[s] = isT[s] ? l.pos : 0; next[s] = isT[s] ? l.pad : -1;
+        st[s] = isT[s] ? sd_[s].st : 0.0; dur[s] = isT[s] ? sd_[s].dur : 0.0; pte[s] = isT[s] ? pl_[s].pte : 0.0;
+        ft[s] = st[s] + dur[s];                                                 // env:356: the addition that made the stored finish time
+    }
+    int head_ = lane < M ? r_.head : -1, tail_ = lane < M ? r_.tail : -1, len_ = lane < M ? r_.len : 0;
+    int cnt_ = lane < J ? r_.cnt : 0;
+    double jmax_ = lane < J ? jr_.jmax : -INFINITY, jrow_ = lane < J ? jr_.jrow : 0.0;
+    const int lastm = (int)rl_d(sc, S_LASTM);
     int jv[NS], opv[NS];
 #pragma unroll
     for (int s = 0; s < NS; s++) { jv[s] = DIVM(v[s]); opv[s] = v[s] - jv[s] * M; }
@@ -99,18 +129,18 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
         else if (op != 0) { mach_p = RLI(mach, a - 1); if (mach_p < 0) valid = false; }    // env:1520
     }
     const int len = rl_i(len_, m), head = rl_i(head_, m), tail = rl_i(tail_, m);
-    const double ttmm = RLD(ttv, m * M + m);
+    const double ttmm = TTC_AT(m);
     RT(1);
     if (valid) {
         if (d < 0.0) status |= MTFJSP_ST_INFEASIBLE;                            // pe:246-248
-        const double arr_k = op == 0 ? 0.0 : RLD(ft, a - 1) + RLD(ttv, mach_p * M + m);     // dg:46-66
+        const double arr_k = op == 0 ? 0.0 : RLD(ft, a - 1) + TTC_AT(mach_p);     // dg:46-66
         bool do_append = false;
         if (len == 0) { path = MTFJSP_PATH_EMPTY; st_k = arr_k; ipos = 0; }                 // env:1684
         else if (!P.left_shift) do_append = true;                                               // env:1680
         else {
             const double lb_ft = arr_k + d;
             const int jh = DIVM(head);
-            const double arr_f = (head == jh * M) ? 0.0 : RLD(ft, head - 1) + RLD(ttv, RLI(mach, head - 1) * M + m);
+            const double arr_f = (head == jh * M) ? 0.0 : RLD(ft, head - 1) + TTC_AT(RLI(mach, head - 1));
             if (lb_ft <= arr_f) { path = MTFJSP_PATH_FRONT; st_k = arr_k; ipos = 0; Nk = head; }   // env:1548
             else if (len == 1) do_append = true;                                                 // env:1577
             else {
@@ -119,9 +149,17 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
 #pragma unroll
                 for (int s = 0; s < NS; s++) {
                     const int pi = prev[s] >= 0 ? prev[s] : 0, vi = v[s] > 0 ? v[s] - 1 : 0;
-                    const double ftP = SHD(ft, pi), ftj = SHD(ft, vi);
-                    const int mj = SHI(mach, vi);
-                    const double ttj = SHD(ttv, (mj >= 0 ? mj : 0) * M + m);
+                    double ftP, ftj, ttj;
+                    if constexpr (NS == 1) {                                    // the job predecessor is the lane below: two DPP moves; the two gathers that remain are ONE LDS round trip (they were two)
+                        ftj = dpp_d<0x138>(ft[0]);
+                        const int mj = dpp_i<0x138>(mach[0]);
+                        ftP = SHD(ft, pi);
+                        ttj = __shfl(ttc, 40 + (mj >= 0 ? mj : 0));
+                    } else {
+                        ftP = SHD(ft, pi); ftj = SHD(ft, vi);
+                        const int mj = SHI(mach, vi);
+                        ttj = __shfl(ttc, 40 + (mj >= 0 ? mj : 0));
+                    }
                     const double jarr = (opv[s] == 0) ? 0.0 : ftj + ttj;
                     const double x = (DIVM(pi) == jv[s]) ? ttmm : 0.0;
                     const double nst = fmax(jarr, ftP + x);
@@ -183,13 +221,13 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
 #pragma unroll
     for (int s = 0; s < NS; s++) if (v[s] == a) { my_ste[s] = st_k; my_fte[s] = ft_k; }
     if (ft_k == 0.0) {                                                          // env:1977: a zero finish time is treated as "not set"
-        accp = (op ? RLD(ft, a - 1) : 0.0) + rl_d(md, op);
+        accp = (op ? RLD(ft, a - 1) : 0.0) + MD_AT(op);
 #pragma unroll
         for (int s = 0; s < NS; s++) if (v[s] == a) my_fte[s] = accp;
         jmax_new = op == 0 ? accp : fmax(row_prev, accp);
     }
     for (int c = op + 1; c < M; c++) {
-        const double fte_c = accp + rl_d(md, c);
+        const double fte_c = accp + MD_AT(c);
 #pragma unroll
         for (int s = 0; s < NS; s++) if (v[s] == ja * M + c) { my_ste[s] = accp; my_fte[s] = fte_c; }
         accp = fte_c;
@@ -204,8 +242,23 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
         const int nb = T < 8 ? 0 : T - (T & 7);
         if (nb) {
             double r = pte[0];
-            for (int i = 8; i < nb; i += 8) r += SHD(pte, (lane & 7) + i);
-            r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
+            if constexpr (NS == 1) {                                            // the same additions in the same order without LDS round trips (there were six)
+                const double x8 = dpp_d<0x108>(pte[0]), x16 = up16_d(pte[0]), x24 = dpp_d<0x108>(x16);
+                if (nb > 8) r += x8;
+                if (nb > 16) r += x16;
+                if (nb > 24) r += x24;
+                if (nb > 32) {
+                    const double y = up32_d(pte[0]), y8 = dpp_d<0x108>(y), y16 = up16_d(y), y24 = dpp_d<0x108>(y16);
+                    r += y;
+                    if (nb > 40) r += y8;
+                    if (nb > 48) r += y16;
+                    if (nb > 56) r += y24;
+                }
+                r += dpp_d<0xB1>(r); r += dpp_d<0x4E>(r); r += dpp_d<0x141>(r);     // fp addition commutes: both partners hold the same sum
+            } else {
+                for (int i = 8; i < nb; i += 8) r += SHD(pte, (lane & 7) + i);
+                r += __shfl_xor(r, 1); r += __shfl_xor(r, 2); r += __shfl_xor(r, 4);
+            }
             if (lane == 0) s_un[U_R0] = r;
         } else if (lane == 0) s_un[U_R0] = 0.0;
 #pragma unroll
@@ -236,8 +289,8 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
             ubase += __builtin_popcountll(um);
         }
     }
+    const double new_tr = (op == 0) ? 0.0 : TTC_AT(mach_p);                       // env:872-876
     {
-        const double new_tr = (op == 0) ? 0.0 : RLD(ttv, mach_p * M + m);       // env:872-876
         const double ft_tail = RLD(ft, rl_i(tail_, m));                         // env:2315-2340, column 0 of the acting machine's row
         if (lane == 0) {
             s_un[U_NEWTR] = new_tr; s_un[U_D] = d; s_un[U_PK] = pk; s_un[U_FTTAIL] = ft_tail;
@@ -274,36 +327,49 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
 #pragma unroll
         for (int s = 0; s < NS; s++) {
             if (isT[s]) { s_mp[v[s]] = mach[s]; s_mp[NL + v[s]] = prev[s]; s_sdf[v[s]] = st[s]; s_sdf[NL + v[s]] = dur[s]; s_sdf[2 * NL + v[s]] = ft[s]; }
-            if (v[s] < M * M) s_ttl[v[s]] = ttv[s];
         }
+        if (lane >= 40 && lane < 40 + M) s_ttl[lane - 40] = ttc;                // column m of the transport times
         if (lane == 0) { s_in[I_A] = a; s_in[I_NK] = Nk; s_in[I_LASTM] = lastm; s_in[I_MERGED] = merged_now; }
-        if (lane == 6) P.lastm[b] = merged_now;
+        if (lane == 6) { P.scal[(size_t)b * SCAL_N + S_LASTM] = (double)merged_now; P.scal[(size_t)b * SCAL_N + S_TRLAST] = new_tr; }
     }
     // ---- candidate of the acting job (ppo:202-316; the mask is the scalar part's) and the state that changed
     if (lane == ja) {
         P.obs.candidate[(size_t)b * J + ja] = ja * M + (cnt_ < M ? cnt_ : M - 1);
-        P.jcnt[(size_t)b * J + ja] = (short)cnt_; P.jmax[(size_t)b * J + ja] = jmax_; P.jrow[(size_t)b * J + ja] = jrow_;
+        JobR r; r.jmax = jmax_; r.jrow = jrow_;
+        P.jr[(size_t)b * J + ja] = r;
     }
 #pragma unroll
-    for (int s = 0; s < NS; s++)
-        if (isT[s]) {
-            Link l; l.mach = (short)mach[s]; l.prev = (short)prev[s]; l.pos = (short)pos[s]; l.pad = (short)next[s];
-            P.link[bT + v[s]] = l;
-            if (v[s] == a) { P.st[bT + a] = st[s]; P.ft[bT + a] = ft[s]; P.dur[bT + a] = dur[s]; P.psel[bT + a] = pk; P.pte[bT + a] = pte[s]; }
+    for (int s = 0; s < NS; s++) {
+        // only the records this decision changed: the acting task, its route neighbours, the tasks of machine m whose rank moved up
+        const bool chg = isT[s] && (v[s] == a || v[s] == Pk || v[s] == Nk || (mach[s] == m && pos[s] > ipos));
+        if (chg) {
+            TaskPL y; y.pte = pte[s]; y.link.mach = (short)mach[s]; y.link.prev = (short)prev[s]; y.link.pos = (short)pos[s]; y.link.pad = (short)next[s];
+            P.pl[bT + v[s]] = y;
         }
-    if (lane == m) { MRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.pad = 0; P.mrec[(size_t)b * M + m] = r; }
+        if (v[s] == a) { TaskSD x; x.st = st[s]; x.dur = dur[s]; P.sd[bT + a] = x; }
+    }
+    if (lane == m || lane == ja) { MJRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.cnt = (short)cnt_; P.mj[(size_t)b * P.MJ + lane] = r; }
     RT(4);
+#undef MD_AT
+#undef TTC_AT
 #undef DIVM
 #undef RT
 }
 
+// Row pitches of the group's per-instance LDS arrays.  The scalar-part waves read them with lane = (instance, channel): the eight
+// instances of a 32-lane group read the same slot of eight rows at once, and with power-of-two pitches (round 5: 64 doubles, 8, 16,
+// 128 ints ...) all eight reads fell on one bank — every ds_read of the scalar part took eight LDS cycles instead of one.  Pitches
+// of 2 (doubles: 4) banks modulo 64 put the eight rows on different banks.
+template <int NL>
+struct EgPitch { static constexpr int SORTED = NL + 2, JOB = 66, CN = 65, MF = 9, UN = 17, MP = 2 * NL + 1, SDF = 3 * NL + 1, TTL = NL + 1; };
 // where the per-instance inputs of the scalar part live: k_env_grp* keeps them in fixed-size arrays, k_env_step_grp in the
 // instance's own LDS region
 template <int NL>
 struct EnvGrpRegAcc {
     static constexpr bool kBigT = false;                         // T <= 128: the pairwise energy sum is one leaf block
-    const double (*s_sorted)[NL], (*s_jmx)[64], (*s_jrw)[64]; const int (*s_cn)[64];
-    const double (*s_scl)[SCAL_N], (*s_mf)[8], (*s_un)[16]; const int (*s_in)[12];
+    using PT = EgPitch<NL>;
+    const double (*s_sorted)[PT::SORTED], (*s_jmx)[PT::JOB], (*s_jrw)[PT::JOB]; const int (*s_cn)[PT::CN];
+    const double (*s_scl)[SCAL_N], (*s_mf)[PT::MF], (*s_un)[PT::UN]; const int (*s_in)[12];
     __device__ __forceinline__ const double *sorted(int g) const { return s_sorted[g]; }
     __device__ __forceinline__ const double *jmx(int g) const { return s_jmx[g]; }
     __device__ __forceinline__ const double *jrw(int g) const { return s_jrw[g]; }
@@ -315,8 +381,13 @@ struct EnvGrpRegAcc {
 };
 // the per-instance scalar part for the instances of the group: lane = (instance g = lane >> 2, reward channel ch = lane & 3)
 template <typename OBS, typename ACC>
-__device__ __forceinline__ void env_grp_tail_batched(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A)
+__device__ __forceinline__ void env_grp_tail_batched(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A, unsigned long long *rt2 = nullptr)
 {
+#ifdef MTFJSP_STAMP
+#define RT2(i) do { __builtin_amdgcn_sched_barrier(0); if (rt2) rt2[i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define RT2(i) do { } while (0)
+#endif
     const int g = lane >> 2, ch = lane & 3;
     const int b = b0 + g;
     if (g >= EG || b >= P.B) return;
@@ -340,6 +411,7 @@ __device__ __forceinline__ void env_grp_tail_batched(const EnvParams &P, const i
     for (int k = 0; k < 8; k++) xj[k] = jm[k < J ? k : J - 1];
 #pragma unroll
     for (int k = 0; k < 8; k++) xs[k] = so[k];
+    RT2(0);
     if (!valid) {                                                               // rejected action: nothing changed; observations persist
         const bool all_done = ns0 == (double)T;
         P.obs.info[(size_t)b * 6 + ch] = (ch == 1 && all_done) ? 1.0 : 0.0;
@@ -372,17 +444,27 @@ __device__ __forceinline__ void env_grp_tail_batched(const EnvParams &P, const i
     e1 = 0.0 + e1;
     // dg:144-170, strictly left to right.  Slots >= nsched hold +0.0 and the running sum starts at +0.0, so it is never -0.0 and
     // adding them changes nothing: the loop stops at nsched; the next chunk's reads are in flight under the 8 dependent adds
+    // Round 6: two register sets in turn (the chunk loop copied the prefetched chunk into the working set — 16 moves and 8 selects
+    // per 8 additions; the loop took 0.5-0.65 us of this wave's 1.5).  Every slot below NL is written by the instance's wave (+0.0
+    // past nsched), so a chunk past the end may be read and added.
     double idle = 0.0;
-    for (int i0 = 0; i0 < nsched; i0 += 8) {
-        double y[8];
-        const bool more = i0 + 8 < nsched;
+    {
+        constexpr int NLr = (int)(sizeof(*A.s_sorted) / sizeof(double)) - 2;    // slots per row (EgPitch::SORTED = NL + 2)
+        double ys[8];
+        for (int i0 = 0; i0 < nsched; i0 += 16) {
+            const int i1 = i0 + 8 < NLr ? i0 + 8 : NLr - 8, i2 = i0 + 16 < NLr ? i0 + 16 : NLr - 8;
 #pragma unroll
-        for (int k = 0; k < 8; k++) y[k] = more ? so[i0 + 8 + k] : 0.0;
+            for (int k = 0; k < 8; k++) ys[k] = so[i1 + k];
 #pragma unroll
-        for (int k = 0; k < 8; k++) idle = idle + xs[k];
+            for (int k = 0; k < 8; k++) idle = idle + xs[k];
+            if (i0 + 8 >= nsched) break;
 #pragma unroll
-        for (int k = 0; k < 8; k++) xs[k] = y[k];
+            for (int k = 0; k < 8; k++) xs[k] = so[i2 + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) idle = idle + ys[k];
+        }
     }
+    RT2(1);
     const double trans_this = tr_this0 + new_tr;
     const double r_t = 1.0 * mk_prev - mk;                                      // env:1066
     double r_pt = 1.0 * e1_prev - e1;
@@ -418,6 +500,7 @@ __device__ __forceinline__ void env_grp_tail_batched(const EnvParams &P, const i
         }
         if (ch == 1) P.obs.status[b] = status;
     }
+    RT2(2);
     {   // machine features of the acting machine (env:2315-2340): columns 0..3 on the four lanes, column 4 with lane 0
         double mfr = mf_ch;
         if (ch == 0) mfr = fttail;
@@ -433,6 +516,8 @@ __device__ __forceinline__ void env_grp_tail_batched(const EnvParams &P, const i
             reinterpret_cast<OBS *>(P.obs.m_fea2)[o + 4] = (OBS)c4;
         }
     }
+    RT2(3);
+#undef RT2
 }
 
 // the same scalar part with every LDS input read where it is used: 30-odd fewer live registers.  The kernels that run several
@@ -555,9 +640,9 @@ __device__ __forceinline__ void env_grp_tail_seq(const EnvParams &P, const int b
 }
 
 template <typename OBS, bool BATCHED, typename ACC>
-__device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A)
+__device__ __forceinline__ void env_grp_tail(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A, unsigned long long *rt2 = nullptr)
 {
-    if constexpr (BATCHED) env_grp_tail_batched<OBS>(P, b0, lane, EG, A);
+    if constexpr (BATCHED) env_grp_tail_batched<OBS>(P, b0, lane, EG, A, rt2);
     else env_grp_tail_seq<OBS>(P, b0, lane, EG, A);
 }
 
@@ -595,7 +680,8 @@ __device__ __forceinline__ void env_grp_mask(const EnvParams &P, const int b0, c
 // 1607-1675, 1703-1765, 2019, 2060-2062) — k_env_reg's arithmetic with the gathers going to the instance's LDS arrays.
 template <typename OBS, int NL>
 __device__ __forceinline__ void env_grp_ell(const EnvParams &P, const int b0, const int lane, const int EG, const int (*s_in)[12],
-                                            const int (*s_mp)[2 * NL], const double (*s_sdf)[3 * NL], const double (*s_ttl)[NL])
+                                            const int (*s_mp)[EgPitch<NL>::MP], const double (*s_sdf)[EgPitch<NL>::SDF], const double (*s_ttl)[EgPitch<NL>::TTL],
+                                            const double (*s_scl)[SCAL_N])
 {
     const int g = lane >> 2, r = lane & 3;
     const int b = b0 + g;
@@ -609,7 +695,7 @@ __device__ __forceinline__ void env_grp_ell(const EnvParams &P, const int b0, co
     const int vv = r == 0 ? a : r == 1 ? ((op + 1 < M) ? a + 1 : -1) : r == 2 ? Nk : lastm;
     if (vv < 0) return;
     const int *mach = s_mp[g], *prev = s_mp[g] + NL;
-    const double *st = s_sdf[g], *dur = s_sdf[g] + NL, *ft = s_sdf[g] + 2 * NL, *tt = s_ttl[g];
+    const double *st = s_sdf[g], *dur = s_sdf[g] + NL, *ft = s_sdf[g] + 2 * NL, *ttc = s_ttl[g];      // ttc[x] = tt[x, m]
     const int mv = mach[vv], pr = prev[vv];
     const double st_v = st[vv];
     const int jvv = DIVM(vv), opvv = vv - jvv * M;
@@ -619,8 +705,11 @@ __device__ __forceinline__ void env_grp_ell(const EnvParams &P, const int b0, co
     const int pri = pr >= 0 ? pr : 0;
     const int mpr = mach[pri];
     const double dur_p = dur[pri], ft_p = ft[pri];
-    const double tt_uv = tt[(mu >= 0 ? mu : 0) * M + (mv >= 0 ? mv : 0)];
-    const double tt_pv = tt[(mpr >= 0 ? mpr : 0) * M + (mv >= 0 ? mv : 0)];
+    // rows 0 and 2 (a, its new route successor) sit on machine m: column m.  Row 1 (the job successor) is unscheduled: no transport
+    // term.  Row 3 (the merged edge of the previous step that reverts): tt[mach(lastm - 1), mach(lastm)] was that step's job-edge
+    // transport time (S_TRLAST); when a lands between the merged pair, row 3 is row 2's node on machine m and both forms agree.
+    const double tt_uv = r == 3 ? s_scl[g][S_TRLAST] : ttc[mu >= 0 ? mu : 0];
+    const double tt_pv = ttc[mpr >= 0 ? mpr : 0];
     const bool s = mv >= 0;
     const bool merged = pr >= 0 && opvv != 0 && pr == vv - 1;
     int c_job = -1, c_mch = -1;
@@ -652,16 +741,17 @@ template <typename OBS, int EG, int NS>
 __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 {
     constexpr int NL = 64 * NS;                // task slots per instance
-    __shared__ double s_sorted[EG][NL];        // idle terms in (machine, route position) rank order
-    __shared__ double s_jmx[EG][64], s_jrw[EG][64];
-    __shared__ int s_cn[EG][64];
+    using PT = EgPitch<NL>;
+    __shared__ double s_sorted[EG][PT::SORTED];    // idle terms in (machine, route position) rank order
+    __shared__ double s_jmx[EG][PT::JOB], s_jrw[EG][PT::JOB];
+    __shared__ int s_cn[EG][PT::CN];
     __shared__ double s_scl[EG][SCAL_N];
-    __shared__ double s_mf[EG][8];
-    __shared__ double s_un[EG][16];
+    __shared__ double s_mf[EG][PT::MF];
+    __shared__ double s_un[EG][PT::UN];
     __shared__ int s_in[EG][12];
-    __shared__ int s_mp[EG][2 * NL];           // machine | route predecessor per task (after the step)
-    __shared__ double s_sdf[EG][3 * NL];       // start | duration | finish per task
-    __shared__ double s_ttl[EG][NL];           // transport times
+    __shared__ int s_mp[EG][PT::MP];           // machine | route predecessor per task (after the step)
+    __shared__ double s_sdf[EG][PT::SDF];      // start | duration | finish per task
+    __shared__ double s_ttl[EG][PT::TTL];      // transport times
     const int grp = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b0 = blockIdx.x * EG;
     const int lane = threadIdx.x & 63;
@@ -685,10 +775,16 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
     // two scalar-part waves (on different SIMDs): rewards / scaler / machine row | ELL rows + job mask
     if (grp == 0) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
+#ifdef MTFJSP_STAMP_WAVES
+        unsigned long long rt2[4] = {0, 0, 0, 0};
+        env_grp_tail<OBS, EG == EG_SMALL>(P, b0, lane, EG, acc, rt2);
+        if (P.stamps && lane == 0 && EG == 16) for (int i = 0; i < 4; i++) P.stamps[2048 + 256 * 64 + (size_t)blockIdx.x * 4 + i] = rt2[i];
+#else
         env_grp_tail<OBS, EG == EG_SMALL>(P, b0, lane, EG, acc);
+#endif
     } else if (grp == 1) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
-        env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl);
+        env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl, s_scl);
         env_grp_mask(P, b0, lane, EG, acc);
     }
 #ifdef MTFJSP_STAMP
@@ -708,27 +804,30 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 template <int NS>
 struct EnvGrpDynLds {
     static constexpr int NL = 64 * NS, EG = EG_SMALL;
-    static constexpr size_t o_sorted = 0, o_jmx = o_sorted + sizeof(double) * EG * NL, o_jrw = o_jmx + sizeof(double) * EG * 64,
-                            o_cn = o_jrw + sizeof(double) * EG * 64, o_scl = o_cn + sizeof(int) * EG * 64, o_mf = o_scl + sizeof(double) * EG * SCAL_N,
-                            o_un = o_mf + sizeof(double) * EG * 8, o_in = o_un + sizeof(double) * EG * 16, o_mp = o_in + sizeof(int) * EG * 12,
-                            o_sdf = o_mp + sizeof(int) * EG * 2 * NL, o_ttl = o_sdf + sizeof(double) * EG * 3 * NL, bytes = o_ttl + sizeof(double) * EG * NL;
+    using PT = EgPitch<NL>;
+    static constexpr size_t o_sorted = 0, o_jmx = o_sorted + sizeof(double) * EG * PT::SORTED, o_jrw = o_jmx + sizeof(double) * EG * PT::JOB,
+                            o_scl = o_jrw + sizeof(double) * EG * PT::JOB, o_mf = o_scl + sizeof(double) * EG * SCAL_N,
+                            o_un = o_mf + sizeof(double) * EG * PT::MF, o_sdf = o_un + sizeof(double) * EG * PT::UN, o_ttl = o_sdf + sizeof(double) * EG * PT::SDF,
+                            o_cn = o_ttl + sizeof(double) * EG * PT::TTL, o_in = o_cn + sizeof(int) * EG * PT::CN, o_mp = o_in + sizeof(int) * EG * 12,
+                            bytes = (o_mp + sizeof(int) * EG * PT::MP + 15) / 16 * 16;
 };
 template <typename OBS, int NS, int NW>
 __device__ __forceinline__ void env_grp_body_dyn(const EnvParams &P, unsigned char *smem)
 {
     using L = EnvGrpDynLds<NS>;
+    using PT = typename L::PT;
     constexpr int NL = L::NL, EG = L::EG;
-    auto s_sorted = reinterpret_cast<double (*)[NL]>(smem + L::o_sorted);
-    auto s_jmx = reinterpret_cast<double (*)[64]>(smem + L::o_jmx);
-    auto s_jrw = reinterpret_cast<double (*)[64]>(smem + L::o_jrw);
-    auto s_cn = reinterpret_cast<int (*)[64]>(smem + L::o_cn);
+    auto s_sorted = reinterpret_cast<double (*)[PT::SORTED]>(smem + L::o_sorted);
+    auto s_jmx = reinterpret_cast<double (*)[PT::JOB]>(smem + L::o_jmx);
+    auto s_jrw = reinterpret_cast<double (*)[PT::JOB]>(smem + L::o_jrw);
+    auto s_cn = reinterpret_cast<int (*)[PT::CN]>(smem + L::o_cn);
     auto s_scl = reinterpret_cast<double (*)[SCAL_N]>(smem + L::o_scl);
-    auto s_mf = reinterpret_cast<double (*)[8]>(smem + L::o_mf);
-    auto s_un = reinterpret_cast<double (*)[16]>(smem + L::o_un);
+    auto s_mf = reinterpret_cast<double (*)[PT::MF]>(smem + L::o_mf);
+    auto s_un = reinterpret_cast<double (*)[PT::UN]>(smem + L::o_un);
     auto s_in = reinterpret_cast<int (*)[12]>(smem + L::o_in);
-    auto s_mp = reinterpret_cast<int (*)[2 * NL]>(smem + L::o_mp);
-    auto s_sdf = reinterpret_cast<double (*)[3 * NL]>(smem + L::o_sdf);
-    auto s_ttl = reinterpret_cast<double (*)[NL]>(smem + L::o_ttl);
+    auto s_mp = reinterpret_cast<int (*)[PT::MP]>(smem + L::o_mp);
+    auto s_sdf = reinterpret_cast<double (*)[PT::SDF]>(smem + L::o_sdf);
+    auto s_ttl = reinterpret_cast<double (*)[PT::TTL]>(smem + L::o_ttl);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b0 = blockIdx.x * EG;
     const int lane = threadIdx.x & 63;
@@ -742,7 +841,7 @@ __device__ __forceinline__ void env_grp_body_dyn(const EnvParams &P, unsigned ch
         env_grp_tail<OBS, false>(P, b0, lane, EG, acc);
     } else if (w == 1) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
-        env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl);
+        env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl, s_scl);
         env_grp_mask(P, b0, lane, EG, acc);
     }
     (void)rt;

@@ -257,7 +257,7 @@
             int a = A.gather_from ? r_gf : 0;
             if (a < 0 || a >= T_) a = 0;
             const size_t row = (size_t)(g0 + il) * T_ + a;
-            r_lk = (A.mf_on ? reinterpret_cast<const short *>(A.mf.link) : reinterpret_cast<const short *>(A.X))[(A.mf_on && row > 0 ? row - 1 : 0) * 4];
+            r_lk = (A.mf_on ? reinterpret_cast<const short *>(A.mf.link) : reinterpret_cast<const short *>(A.X))[(A.mf_on && row > 0 ? row - 1 : 0) * 8 + 4];
             s_gf[tid] = r_gf;
         }
         for (int i = tid + 512; i < nrows; i += 512) s_mask[i] = A.mask[(size_t)g0 * R + i];
@@ -517,7 +517,7 @@
                         const size_t row = (size_t)b * T_ + a;
                         int pm = 0;
                         if (a % M_ != 0) {
-                            pm = prow_m < 512 ? s_pm[prow_m] : (int)reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 4];   // machine of the job predecessor
+                            pm = prow_m < 512 ? s_pm[prow_m] : (int)reinterpret_cast<const short *>(A.mf.link)[(row - 1) * 8 + 4];   // machine of the job predecessor
                             if (pm < 0) pm += M_;                                             // python negative index (pe:206)
                         }
                         H3T_RT(1);

@@ -283,7 +283,7 @@ int mtfjsp_sample_categorical(mtfjsp_encoder_t e, const float *prob, int32_t n, 
 typedef struct {
     const double *t, *p, *tt, *mean3;   /* [B,T,M], [B,T,M], [B,M,M], [B,T,3] */
     const int32_t *shop;                /* [B,M] */
-    const void *link;                   /* [B,T] 8-byte task records {i16 machine, prev, pos, next} */
+    const void *link;                   /* [B,T] 16-byte task records {f64 energy estimate; i16 machine, prev, pos, next}: the machine of task v is the i16 at byte 16 v + 8 */
     void *m_fea1_out;                   /* [B,M,6] obs dtype */
     uint8_t *mmask_out;                 /* [B,M] */
     int32_t T, M, obs_f32;
