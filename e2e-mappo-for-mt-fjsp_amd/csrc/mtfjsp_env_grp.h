@@ -18,18 +18,21 @@
 // 16 instances and 4 waves per SIMD (no spills) while all waves of the batch are resident at once (<= 8192 instances: 14.4 us at
 // 4096 against 16.1 us for k_env_reg); 4 instances and 8 waves per SIMD for chip-filling batches, where occupancy and short
 // barrier waits matter more than the amortisation (262 144 instances: 335 us = 0.78 of the copy rate against 442 us = 0.59).
+#ifndef EG_ABL
+#define EG_ABL 0           // timing ablations of the diagnostic builds (tools/ablate_env.sh): wrong results, never in the product
+#endif
 #define EG_SMALL 16
 #define EG_LARGE 4
 #define EG_SMALL_MAX_B 8192
-enum { U_R0 = 0, U_NEWTR, U_D, U_PK, U_FTTAIL, U_TAIL = 8 };     // s_un slots (8..15: ragged tail of the pairwise energy sum)
-enum { I_VALID = 0, I_STATUS, I_NSCHED, I_M, I_JA, I_A, I_NK, I_LASTM, I_MERGED };   // s_in slots (12 per instance)
+enum { U_R0 = 0, U_NEWTR, U_D, U_PK, U_FTTAIL, U_STK, U_TAIL = 8 };     // s_un slots (8..15: ragged tail of the pairwise energy sum)
+enum { I_VALID = 0, I_STATUS, I_NSCHED, I_M, I_JA, I_A, I_NK, I_LASTM, I_MERGED, I_F4A };   // s_in slots (12 per instance)
 
 // NS task slots per lane: NS = 1 for T <= 64 (lane = task), NS = 2 for T <= 128 (lane holds tasks lane and lane + 64, and two
 // transport-time entries: M*M <= 128).  Gathers with a uniform index pick the slot with a scalar condition and read one lane;
 // gathers with a per-lane index read both slots' lanes and select.  The per-task LDS arrays have 64*NS entries.
 template <typename OBS, int NS>
 __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, const int lane, double *s_sorted, double *s_jmx, double *s_jrw,
-                                             int *s_cn, double *s_scl, double *s_mf, double *s_un, int *s_in, int *s_mp /*[2][64 NS] mach | prev*/,
+                                             int *s_cn, double *s_scl, double *s_mf, double *s_un, int *s_in, MJRec *s_mj2 /*[2] records m | ja*/, double *s_row /*[3][16] ste | fte | pte of the acting job's ops*/, int *s_mp /*[2][64 NS] mach | prev*/,
                                              double *s_sdf /*[3][64 NS] st | dur | ft*/, double *s_ttl /*[64 NS]*/, unsigned long long *rt)
 {
 #ifdef MTFJSP_STAMP
@@ -226,6 +229,7 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
         for (int s = 0; s < NS; s++) if (v[s] == a) my_fte[s] = accp;
         jmax_new = op == 0 ? accp : fmax(row_prev, accp);
     }
+    if (!(EG_ABL & 8))
     for (int c = op + 1; c < M; c++) {
         const double fte_c = accp + MD_AT(c);
 #pragma unroll
@@ -239,7 +243,7 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     // a[k+8] + ... (in that order), then its fixed tree ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) as an xor butterfly (fp addition
     // commutes); the ragged tail is added by the scalar part, in order
     {
-        const int nb = T < 8 ? 0 : T - (T & 7);
+        const int nb = (EG_ABL & 8) ? 0 : T < 8 ? 0 : T - (T & 7);
         if (nb) {
             double r = pte[0];
             if constexpr (NS == 1) {                                            // the same additions in the same order without LDS round trips (there were six)
@@ -267,7 +271,7 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     // idle time (dg:144-170): one term per scheduled task, summed strictly left to right in (machine, route position)
     // order: every scheduled task's lane computes its rank in that order = (tasks on lower machines) + (its route position) and
     // drops its term at that index; the scalar part adds terms in order.
-    {
+    if (!(EG_ABL & 4)) {
         int incl = lane < M ? len_ : 0;                                         // M <= 16: four DPP row shifts with zero fill
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true);   // row_shr:1
         incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);   // row_shr:2
@@ -293,7 +297,7 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     {
         const double ft_tail = RLD(ft, rl_i(tail_, m));                         // env:2315-2340, column 0 of the acting machine's row
         if (lane == 0) {
-            s_un[U_NEWTR] = new_tr; s_un[U_D] = d; s_un[U_PK] = pk; s_un[U_FTTAIL] = ft_tail;
+            s_un[U_NEWTR] = new_tr; s_un[U_D] = d; s_un[U_PK] = pk; s_un[U_FTTAIL] = ft_tail; s_un[U_STK] = st_k;
             s_in[I_VALID] = 1; s_in[I_STATUS] = status; s_in[I_NSCHED] = nsched; s_in[I_M] = m; s_in[I_JA] = ja;
         }
         if (lane < 8) s_mf[lane] = mfr;
@@ -304,40 +308,32 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
     // C. the observation rows that changed
     const double w30 = rl_d(sc, S_W3), w31 = rl_d(sc, S_W3 + 1), w32 = rl_d(sc, S_W3 + 2);
     const bool merged_a = Pk >= 0 && op != 0 && Pk == a - 1;
+    // (the rows themselves — tasks a .. end of job, env:2245-2277 — are formed and stored by scalar-part waves for the whole group:
+    // env_grp_rows; a lane of the acting job leaves its three per-task values)
 #pragma unroll
     for (int s = 0; s < NS; s++)
-        if (isT[s] && jv[s] == ja && opv[s] >= op) {                            // feature rows a .. end of job (env:2245-2277)
-            const bool isa = v[s] == a;
-            OBS f[12];
-            f[0] = (OBS)my_ste[s]; f[1] = (OBS)my_fte[s]; f[2] = (OBS)pte[s];
-            f[3] = (OBS)(isa ? 1.0 : 0.0);
-            f[4] = (OBS)(isa ? (1 + ((Pk >= 0 && !merged_a) ? 1 : 0)) : 1);
-            f[5] = (OBS)(isa ? m + 1 : 0);
-            f[6] = (OBS)(isa ? d : 0.0);
-            f[7] = (OBS)(isa ? pk : 0.0);
-            f[8] = (OBS)(ja + 1);
-            f[9] = (OBS)w30; f[10] = (OBS)w31; f[11] = (OBS)w32;
-            uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + (bT + v[s]) * 12);
-            const uint4 *src = reinterpret_cast<const uint4 *>(f);
-            for (int i = 0; i < (int)(12 * sizeof(OBS) / 16); i++) dst[i] = src[i];
-        }
+        if (isT[s] && jv[s] == ja && opv[s] >= op) { s_row[opv[s]] = my_ste[s]; s_row[16 + opv[s]] = my_fte[s]; s_row[32 + opv[s]] = pte[s]; }
     {   // the in-edge (ELL) rows that changed — of a, its job successor, its new route successor and the node whose merged edge
         // reverts — are computed by the group's second scalar wave (env_grp_ell: 4 lanes per instance); it gathers from these
         const int merged_now = merged_a ? a : -1;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            if (isT[s]) { s_mp[v[s]] = mach[s]; s_mp[NL + v[s]] = prev[s]; s_sdf[v[s]] = st[s]; s_sdf[NL + v[s]] = dur[s]; s_sdf[2 * NL + v[s]] = ft[s]; }
+            if (!(EG_ABL & 16) && isT[s]) { s_mp[v[s]] = mach[s]; s_mp[NL + v[s]] = prev[s]; s_sdf[v[s]] = st[s]; s_sdf[NL + v[s]] = dur[s]; s_sdf[2 * NL + v[s]] = ft[s]; }
         }
         if (lane >= 40 && lane < 40 + M) s_ttl[lane - 40] = ttc;                // column m of the transport times
-        if (lane == 0) { s_in[I_A] = a; s_in[I_NK] = Nk; s_in[I_LASTM] = lastm; s_in[I_MERGED] = merged_now; }
-        if (lane == 6) { P.scal[(size_t)b * SCAL_N + S_LASTM] = (double)merged_now; P.scal[(size_t)b * SCAL_N + S_TRLAST] = new_tr; }
+        if (lane == 0) { s_in[I_A] = a; s_in[I_NK] = Nk; s_in[I_LASTM] = lastm; s_in[I_MERGED] = merged_now; s_in[I_F4A] = 1 + ((Pk >= 0 && !merged_a) ? 1 : 0); }
     }
-    // ---- candidate of the acting job (ppo:202-316; the mask is the scalar part's) and the state that changed
-    if (lane == ja) {
-        P.obs.candidate[(size_t)b * J + ja] = ja * M + (cnt_ < M ? cnt_ : M - 1);
-        JobR r; r.jmax = jmax_; r.jrow = jrow_;
-        P.jr[(size_t)b * J + ja] = r;
+    // ---- the state that changed.  Round 6: the one-lane stores of an instance (start / duration of a, the job's record, the two
+    // records of machine m and job ja, the merged-edge words, the candidate) each cost this wave a branch, a 64-bit address and a
+    // store instruction for ONE lane — without them the group reached its barrier 1.2 us earlier (profiles/r06_ablate_env.txt).  They
+    // are now stored for ALL instances of the group by three instructions of a scalar-part wave (env_grp_state); only the task
+    // records, whose lanes are tasks, are stored here.
+    {
+        MJRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.cnt = (short)cnt_;
+        if (lane == m) s_mj2[0] = r;
+        if (lane == ja) s_mj2[1] = r;
     }
+    if (!(EG_ABL & 1))
 #pragma unroll
     for (int s = 0; s < NS; s++) {
         // only the records this decision changed: the acting task, its route neighbours, the tasks of machine m whose rank moved up
@@ -346,9 +342,7 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
             TaskPL y; y.pte = pte[s]; y.link.mach = (short)mach[s]; y.link.prev = (short)prev[s]; y.link.pos = (short)pos[s]; y.link.pad = (short)next[s];
             P.pl[bT + v[s]] = y;
         }
-        if (v[s] == a) { TaskSD x; x.st = st[s]; x.dur = dur[s]; P.sd[bT + a] = x; }
     }
-    if (lane == m || lane == ja) { MJRec r; r.head = (short)head_; r.tail = (short)tail_; r.len = (short)len_; r.cnt = (short)cnt_; P.mj[(size_t)b * P.MJ + lane] = r; }
     RT(4);
 #undef MD_AT
 #undef TTC_AT
@@ -675,6 +669,64 @@ __device__ __forceinline__ void env_grp_mask(const EnvParams &P, const int b0, c
     }
 }
 
+// The per-instance state words a decision changes, for the group's instances: lane = (instance g, item): 0 start / duration of the
+// acting task, 1 the acting job's record, 2 the merged-edge words of the scalar row; then the records of machine m and of job ja, the
+// acting job's candidate (ppo:202-316).  Three store instructions for the group.
+template <typename ACC>
+__device__ __forceinline__ void env_grp_state(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A, const MJRec (*s_mj2)[2])
+{
+    const int g = lane >> 2, it = lane & 3;
+    const int b = b0 + g;
+    if (g >= EG || b >= P.B || !A.in(g)[I_VALID]) return;
+    const int J = P.J, M = P.M;
+    const int a = A.in(g)[I_A], ja = A.in(g)[I_JA], m = A.in(g)[I_M], merged_now = A.in(g)[I_MERGED];
+    const double stk = A.un(g)[U_STK], d = A.un(g)[U_D], new_tr = A.un(g)[U_NEWTR], jmx = A.jmx(g)[ja], jrw = A.jrw(g)[ja];
+    const int cnt = A.cn(g)[ja];
+    const MJRec r0 = s_mj2[g][0], r1 = s_mj2[g][1];
+    if (it < 3) {
+        double2 x; double2 *dst;
+        if (it == 0) { x = make_double2(stk, d); dst = reinterpret_cast<double2 *>(&P.sd[(size_t)b * P.T + a]); }
+        else if (it == 1) { x = make_double2(jmx, jrw); dst = reinterpret_cast<double2 *>(&P.jr[(size_t)b * J + ja]); }
+        else { x = make_double2(new_tr, (double)merged_now); dst = reinterpret_cast<double2 *>(P.scal + (size_t)b * SCAL_N + S_TRLAST); }
+        *dst = x;
+    }
+    if (it < 2) P.mj[(size_t)b * P.MJ + (it == 0 ? m : ja)] = it == 0 ? r0 : r1;
+    if (it == 0) P.obs.candidate[(size_t)b * J + ja] = ja * M + (cnt < M ? cnt : M - 1);
+}
+
+// The feature rows a decision changes (tasks a .. end of its job, env:2245-2277), for the group's instances: lane = (instance, op of
+// the acting job), 8 (M <= 8) or 4 instances per pass; passes are dealt to the waves w0, w0 + nw, ...  Round 5 stored them from the
+// instances' own waves: three 16-byte stores of at most M lanes each per instance, 48 store instructions per group instead of 6.
+template <typename OBS, typename ACC>
+__device__ __forceinline__ void env_grp_rows(const EnvParams &P, const int b0, const int lane, const int EG, const ACC &A, const double (*s_row)[48], const int w0, const int nw)
+{
+    const int M = P.M, T = P.T;
+    const int sh = M <= 8 ? 3 : 4, ipp = 64 >> sh;
+    for (int g0 = w0 * ipp; g0 < EG; g0 += nw * ipp) {
+        const int g = g0 + (lane >> sh), c = lane & ((1 << sh) - 1);
+        const int b = b0 + g;
+        if (g >= EG || b >= P.B || c >= M || !A.in(g)[I_VALID]) continue;
+        const int a = A.in(g)[I_A], ja = A.in(g)[I_JA], m = A.in(g)[I_M], f4a = A.in(g)[I_F4A];
+        const int op = a - ja * M;
+        if (c < op) continue;
+        const double ste = s_row[g][c], fte = s_row[g][16 + c], pte = s_row[g][32 + c];
+        const double d = A.un(g)[U_D], pk = A.un(g)[U_PK], w30 = A.scl(g)[S_W3], w31 = A.scl(g)[S_W3 + 1], w32 = A.scl(g)[S_W3 + 2];
+        const bool isa = c == op;
+        OBS f[12];
+        f[0] = (OBS)ste; f[1] = (OBS)fte; f[2] = (OBS)pte;
+        f[3] = (OBS)(isa ? 1.0 : 0.0);
+        f[4] = (OBS)(isa ? f4a : 1);
+        f[5] = (OBS)(isa ? m + 1 : 0);
+        f[6] = (OBS)(isa ? d : 0.0);
+        f[7] = (OBS)(isa ? pk : 0.0);
+        f[8] = (OBS)(ja + 1);
+        f[9] = (OBS)w30; f[10] = (OBS)w31; f[11] = (OBS)w32;
+        uint4 *dst = reinterpret_cast<uint4 *>(reinterpret_cast<OBS *>(P.obs.tasks_fea) + ((size_t)b * T + ja * M + c) * 12);
+        const uint4 *src = reinterpret_cast<const uint4 *>(f);
+        for (int i = 0; i < (int)(12 * sizeof(OBS) / 16); i++) dst[i] = src[i];
+    }
+}
+
 // The <= 4 in-edge (ELL) rows a decision changes, for the group's instances: lane = (instance g, row r): r = 0 the acting
 // task a, 1 its job successor, 2 its new route successor, 3 the node whose merged job+machine edge reverts (env:1384-1422,
 // 1607-1675, 1703-1765, 2019, 2060-2062) — k_env_reg's arithmetic with the gathers going to the instance's LDS arrays.
@@ -749,6 +801,8 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
     __shared__ double s_mf[EG][PT::MF];
     __shared__ double s_un[EG][PT::UN];
     __shared__ int s_in[EG][12];
+    __shared__ MJRec s_mj2[EG][2];             // the records of machine m and of job ja (after the step)
+    __shared__ double s_row[EG][48];           // estimated start | estimated finish | energy of the acting job's ops
     __shared__ int s_mp[EG][PT::MP];           // machine | route predecessor per task (after the step)
     __shared__ double s_sdf[EG][PT::SDF];      // start | duration | finish per task
     __shared__ double s_ttl[EG][PT::TTL];      // transport times
@@ -759,7 +813,7 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 #ifdef MTFJSP_STAMP
     rt[0] = __builtin_amdgcn_s_memrealtime();
 #endif
-    if (b0 + grp < P.B) env_grp_wave<OBS, NS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp], s_mp[grp], s_sdf[grp], s_ttl[grp], rt);
+    if (b0 + grp < P.B) env_grp_wave<OBS, NS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp], s_mj2[grp], s_row[grp], s_mp[grp], s_sdf[grp], s_ttl[grp], rt);
 #ifdef MTFJSP_STAMP_WAVES                      // diagnostic: every wave's entry / first-hop / end of its instance's work (slots 16.. of the group's 128)
     if (P.stamps && lane == 0 && EG == 16) {
         P.stamps[2048 + (size_t)blockIdx.x * 64 + grp * 4] = rt[0];
@@ -772,7 +826,7 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 #ifdef MTFJSP_STAMP
     rt[5] = __builtin_amdgcn_s_memrealtime();
 #endif
-    // two scalar-part waves (on different SIMDs): rewards / scaler / machine row | ELL rows + job mask
+    // three scalar-part waves (on different SIMDs): rewards / scaler / machine row | ELL rows | job mask + state words
     if (grp == 0) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
 #ifdef MTFJSP_STAMP_WAVES
@@ -785,7 +839,13 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
     } else if (grp == 1) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
         env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl, s_scl);
+    } else if (grp == 2) {
+        const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
         env_grp_mask(P, b0, lane, EG, acc);
+        env_grp_state(P, b0, lane, EG, acc, s_mj2);
+    } else if (grp >= 3) {
+        const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
+        env_grp_rows<OBS>(P, b0, lane, EG, acc, s_row, grp - 3, EG - 3);
     }
 #ifdef MTFJSP_STAMP
     if (grp == 0) {
@@ -809,7 +869,8 @@ struct EnvGrpDynLds {
                             o_scl = o_jrw + sizeof(double) * EG * PT::JOB, o_mf = o_scl + sizeof(double) * EG * SCAL_N,
                             o_un = o_mf + sizeof(double) * EG * PT::MF, o_sdf = o_un + sizeof(double) * EG * PT::UN, o_ttl = o_sdf + sizeof(double) * EG * PT::SDF,
                             o_cn = o_ttl + sizeof(double) * EG * PT::TTL, o_in = o_cn + sizeof(int) * EG * PT::CN, o_mp = o_in + sizeof(int) * EG * 12,
-                            bytes = (o_mp + sizeof(int) * EG * PT::MP + 15) / 16 * 16;
+                            o_mj2 = (o_mp + sizeof(int) * EG * PT::MP + 7) / 8 * 8, o_row = o_mj2 + sizeof(MJRec) * EG * 2,
+                            bytes = (o_row + sizeof(double) * EG * 48 + 15) / 16 * 16;
 };
 template <typename OBS, int NS, int NW>
 __device__ __forceinline__ void env_grp_body_dyn(const EnvParams &P, unsigned char *smem)
@@ -828,13 +889,15 @@ __device__ __forceinline__ void env_grp_body_dyn(const EnvParams &P, unsigned ch
     auto s_mp = reinterpret_cast<int (*)[PT::MP]>(smem + L::o_mp);
     auto s_sdf = reinterpret_cast<double (*)[PT::SDF]>(smem + L::o_sdf);
     auto s_ttl = reinterpret_cast<double (*)[PT::TTL]>(smem + L::o_ttl);
+    auto s_mj2 = reinterpret_cast<MJRec (*)[2]>(smem + L::o_mj2);
+    auto s_row = reinterpret_cast<double (*)[48]>(smem + L::o_row);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b0 = blockIdx.x * EG;
     const int lane = threadIdx.x & 63;
     unsigned long long rt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll 1
     for (int g = w; g < EG; g += NW)
-        if (b0 + g < P.B) env_grp_wave<OBS, NS>(P, b0 + g, lane, s_sorted[g], s_jmx[g], s_jrw[g], s_cn[g], s_scl[g], s_mf[g], s_un[g], s_in[g], s_mp[g], s_sdf[g], s_ttl[g], rt);
+        if (b0 + g < P.B) env_grp_wave<OBS, NS>(P, b0 + g, lane, s_sorted[g], s_jmx[g], s_jrw[g], s_cn[g], s_scl[g], s_mf[g], s_un[g], s_in[g], s_mj2[g], s_row[g], s_mp[g], s_sdf[g], s_ttl[g], rt);
     __syncthreads();
     if (w == 0) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
@@ -842,8 +905,15 @@ __device__ __forceinline__ void env_grp_body_dyn(const EnvParams &P, unsigned ch
     } else if (w == 1) {
         const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
         env_grp_ell<OBS, NL>(P, b0, lane, EG, s_in, s_mp, s_sdf, s_ttl, s_scl);
+    } else if (w == 2) {
+        const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
         env_grp_mask(P, b0, lane, EG, acc);
+        env_grp_state(P, b0, lane, EG, acc, s_mj2);
+    } else {
+        const EnvGrpRegAcc<NL> acc{s_sorted, s_jmx, s_jrw, s_cn, s_scl, s_mf, s_un, s_in};
+        env_grp_rows<OBS>(P, b0, lane, EG, acc, s_row, w - 3, NW - 3);
     }
+    static_assert(NW >= 4, "four scalar-part waves");
     (void)rt;
 }
 #ifndef MTFJSP_ENV_GRP_NO_KERNELS

@@ -24,7 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--size", default="6x6x2")
-    ap.add_argument("--episodes", type=int, default=3)
+    ap.add_argument("--episodes", type=int, default=5)
     a = ap.parse_args()
     J, M, E = [int(x) for x in a.size.split("x")]
     T, B = J * M, a.batch
@@ -34,15 +34,29 @@ def main():
     w3 = torch.full((B, 3), 1.0 / 3, dtype=torch.float64, device=env.device)
     act, mch = torch.zeros(B, dtype=torch.int32, device=env.device), torch.zeros(B, dtype=torch.int32, device=env.device)
     r, w = 64 * T + 100 * M + 176, 72 * T + 56 * M + 307          # read / written bytes per env-step (bench.env_bytes_rw)
-    # interleaved rounds (cdna_hip_programming.md rule 24): an episode of steps, then the copy at every grid, repeated
+    # interleaved rounds (cdna_hip_programming.md rule 24): an episode of steps, then the copy at every grid, repeated.  Episodes
+    # alternate between two launch patterns, because a dispatch's trace duration depends on how it is queued (round 6: in the
+    # rollout's pattern — action kernel and step kernel queued back to back — the trace durations of BOTH kernels, the 16-workgroup
+    # action kernel included, jump by about 2.5 us from one launch to the next; the copy launches, each between two HIP event
+    # records, do not):
+    #   episode 0            warm-up (not counted);
+    #   odd episodes         the rollout's pattern;
+    #   even episodes >= 2   every step launch between two HIP event records (mtfjsp_timing_begin): the copy launches' pattern.
+    # tools/footprint_reduce.py compares like with like: steps and copies that were both launched between event records.
     for ep in range(a.episodes):
         env.reset(w3)
+        if ep >= 2 and ep % 2 == 0:
+            env.timing_begin()
         for s in range(T):
             env.random_actions(7, ep * T + s, act, mch)
             env.step(act, mch)
+        if ep >= 2 and ep % 2 == 0:
+            env.timing_end()
         for acc in (16, 8):
             for grid in GRIDS:
                 env.footprint_copy(B * r, B * w, access_bytes=acc, grid=grid, reps=20)
+        # (each footprint_copy call queues 10 warm-up launches back to back, then its timed launches with events between them: the
+        # trace holds copies of both kinds)
     torch.cuda.synchronize()
     assert bool(env.info[:, 1].all()) and int((env.status & 0x100).sum()) == 0
     print(f"done B={B} read={B * r} written={B * w}")

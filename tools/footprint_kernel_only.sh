@@ -5,7 +5,7 @@ set -u
 tag=${1:-r05}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-$OLDPWD}"
 mkdir -p gpurun_out
-for B in 4096 16384 65536 262144; do
+for B in ${FP_SIZES:-4096 16384 65536 262144}; do
   rocprofv3 --kernel-trace --output-format csv -d gpurun_out/fp_${tag}_${B} -- python3 tools/footprint_kernel_only.py --batch $B > gpurun_out/fp_${tag}_${B}.log 2>&1
 done
 python3 tools/footprint_reduce.py "$tag"
