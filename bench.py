@@ -60,19 +60,29 @@ def same_footprint_copy(env, B, J, M):
     return out
 
 
-PMC_FILE = "r05_pmc_traffic.json"
-FOOTPRINT_FILE = "r05_footprint_kernel_only.json"
+PMC_FILE = "r06_pmc_traffic.json" if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_pmc_traffic.json")) else "r05_pmc_traffic.json"
+FOOTPRINT_FILE = "r06_footprint_kernel_only.json"
 
 
-def footprint_kernel_only(B):
+def footprint_kernel_only(B, J, M, E, kernel):
     """The same-footprint fraction of the step kernel on KERNEL-ONLY durations: rocprofv3 --kernel-trace of the step kernel and of the
-    SURVEY 8(d) copy kernel in one process (tools/footprint_kernel_only.sh; committed under profiles/).  The fraction measured inside
-    this run (frac_of_same_footprint_copy) pairs two HIP-event timings, each of which carries ~2.3 us of event cost: it flatters the
-    step kernel at small batches.  The profiler cannot run inside the timed process, so the committed measurement is reported."""
+    SURVEY 8(d) copy kernel in one process (tools/footprint_kernel_only.sh; committed under profiles/), both launched the same way
+    (between two HIP event records).  The fraction measured inside this run (frac_of_same_footprint_copy) pairs two HIP-event timings,
+    each of which carries ~2.3 us of event cost: it flatters the step kernel at small batches.  The profiler cannot run inside the
+    timed process, so the committed measurement is reported — for the size and the step kernel it was MEASURED on only (advisor r5:
+    the file used to be looked up by batch alone, and a J10M10 run quoted the J6M6 kernel's fraction)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", FOOTPRINT_FILE)))["batches"][str(B)]
-        return {"frac": d["frac_of_same_footprint_copy_kernel_only"], "step_kernel_us": d["step_ns_avg"] / 1e3, "copy_kernel_us": d["copy_16B"]["ns_avg"] / 1e3,
-                "copy_grid": d["copy_16B"]["grid"], "source": f"profiles/{FOOTPRINT_FILE} (rocprofv3 --kernel-trace, End - Start per dispatch; not re-measured inside this run)"}
+        f = json.load(open(os.path.join(ROOT, "profiles", FOOTPRINT_FILE)))
+        d = f["batches"][str(B)]
+        if f.get("size") != f"{J}x{M}x{E}" or kernel not in d["step_kernel"]:
+            return None
+        return {"frac": d["frac_of_same_footprint_copy_kernel_only"], "step_kernel": d["step_kernel"], "size": f["size"],
+                "step_kernel_us": d["step_idle"]["ns_avg"] / 1e3, "copy_kernel_us": d["copy_16B_idle"]["ns_avg"] / 1e3, "copy_grid": d["copy_16B_idle"]["grid"],
+                "step_kernel_us_in_the_rollouts_launch_pattern": (d.get("step_b2b") or {}).get("ns_avg", 0) / 1e3 or None,
+                "frac_round5_method": d.get("frac_round5_method"),
+                "source": f"profiles/{FOOTPRINT_FILE} (rocprofv3 --kernel-trace, End - Start per dispatch, step and copy launches both between HIP event "
+                          "records; frac_round5_method = the copy between events over the step in the rollout's back-to-back pattern, round 5's quotient; "
+                          "not re-measured inside this run)"}
     except Exception:
         return None
 
@@ -117,7 +127,7 @@ def env_kernel_large_batch(J, M, E, device, B=262144, episodes=2):
     torch.cuda.empty_cache()
     kname = (("k_env_grp16" if B <= 8192 else "k_env_grp4") if (T <= 64 and M * M <= 64) else
              ("k_env_grp16x2" if B <= 4096 else "k_env_grp4x2") if (T <= 128 and M * M <= 128 and M <= 16) else "k_env_step_grp")
-    ko = footprint_kernel_only(B)
+    ko = footprint_kernel_only(B, J, M, E, kname)
     return {"kernel": kname, "instances": B, "bound": "hbm", "achieved": ach,
             "frac_of_same_footprint_copy_kernel_only": ko["frac"] if ko else None, "kernel_only": ko,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS, "frac_of_measured_copy_bw": ach / HBM_MEASURED_GBPS,
@@ -390,6 +400,10 @@ def main():
     ap.add_argument("--no-env-sweep", action="store_true", help="skip the step-kernel batch sweep (N=1 only)")
     ap.add_argument("--no-config-legs", action="store_true", help="skip the short legs of BASELINE configs 2 and 4's shard (N=1, headline size only)")
     ap.add_argument("--no-full-handoff", action="store_true", help="skip the untimed full hand-off leg (N>1)")
+    ap.add_argument("--weights", default="random", choices=["random", "top1"],
+                    help="actor weights: seeded random initialisation (default; throughput does not depend on the values unless a range "
+                         "fallback trips, which encoder_status reports) or the reference's shipped J6M6E2 `top1` checkpoint (its tensors "
+                         "as arrays in tests/golden/encoder_j6m6e2_top1.npz)")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -434,9 +448,15 @@ def main():
     if policy == "auto":
         policy = "actor" if rollout_mod.actor_available() else "random"
     # Instance_Dataset(samples = world*B, seed = 0), shard `rank` owns rows [rank*B, (rank+1)*B) — all distinct
+    weights = None
+    if args.weights == "top1":
+        if (J, M, E) != (6, 6, 2):
+            raise SystemExit("--weights top1: the shipped checkpoint is a J6M6E2 model")
+        gz = np.load(os.path.join(ROOT, "tests", "golden", "encoder_j6m6e2_top1.npz"))
+        weights = ({k[len("w_ja."):]: gz[k] for k in gz.files if k.startswith("w_ja.")}, {k[len("w_ma."):]: gz[k] for k in gz.files if k.startswith("w_ma.")})
     ro = rollout_mod.Rollout(J, M, E, B, device=local_rank, policy=policy, obs_dtype=args.obs,
                              instance_seed=0, rank=rank, world=world, collect="full" if args.trajectory == "full" else True,
-                             time_handoff=True)
+                             time_handoff=True, weights=weights)
 
     def sync():
         torch.cuda.synchronize()
@@ -487,8 +507,15 @@ def main():
     for _ in range(blocks * args.steps):
         ro.step()
     sync()
-    elapsed = agree_max(time.perf_counter() - t0)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = agree_max(elapsed_local)
     steps_timed = blocks * args.steps
+    per_rank_ms = None
+    if dist is not None:                                # every rank's own time for the same timed region (the line's value uses the MAX)
+        tl = torch.tensor([elapsed_local / steps_timed * 1e3], dtype=torch.float64, device="cpu" if one_device else "cuda")
+        allt = [torch.zeros_like(tl) for _ in range(world)]
+        dist.all_gather(allt, tl)
+        per_rank_ms = [float(x.item()) for x in allt]
     handoffs = ro.n_handoffs - handoffs0
     # the advantage all-gather of the rollout -> update hand-off (the only collective of the data path) fires once per
     # S = buffer_episodes*T steps; when the timed region was shorter than that (N > 1), run the steps up to the next hand-off
@@ -556,6 +583,9 @@ def main():
             if headline:
                 roof["traffic"] = pmc_traffic(dom)
                 roof["traffic_source"] = traffic_note if roof["traffic"] is not None else None
+                if roof["traffic"] is not None:            # the HBM side of the same launch on the bytes it really moved (its `frac` is the matrix-core one)
+                    roof["achieved_GBps_on_pmc_traffic"] = roof["traffic"] / avg_s / 1e9
+                    roof["frac_hbm_on_pmc_traffic"] = roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBPS
         # the north-star kernel is always reported as well (extra key)
         ke = ktimes["env_step"]
         roof_env = env_roof(ke["ms_total"] / max(ke["launches"], 1) * 1e-3, ro.env_kernel_name())
@@ -573,7 +603,11 @@ def main():
                         "what": "local-critic GAE (4 reverse scans) + ONE packed all-gather of the 4 advantage tensors [4,S,B] f32 + global normalisation"},
             "kernel_times_ms": {k: v for k, v in ktimes.items()}, "kernel_times_steps": prof_steps,
             "encoder_status": enc_status,
+            "weights": "seeded random initialisation (encoder.random_init_weights)" if weights is None else "the reference's shipped J6M6E2 top1 checkpoint (tests/golden/encoder_j6m6e2_top1.npz)",
         }
+        if per_rank_ms is not None:                        # N > 1: what each rank took for the timed region, so that a first real scaling run can be read
+            out["per_rank_ms_per_step"] = per_rank_ms
+            out["handoff"]["allgather_GBps_per_rank"] = ((gather or {}).get("bytes_per_rank") or 0) * (world - 1) / max((gather or {}).get("ms") or 1e30, 1e-9) / 1e6 if gather else None
         if full_handoff is not None:
             out["handoff_full"] = full_handoff
         # the two latency chains beside the dominant kernel (round-3 review: "no roofline at all"): matrix time and LDS traffic bound
@@ -620,7 +654,7 @@ def main():
                 c16 = sweep[0]["same_footprint_copy"]["access_16B"]["avg_launch_us"]
                 out["roofline_env_step"]["same_footprint_copy_us"] = c16
                 out["roofline_env_step"]["frac_of_same_footprint_copy"] = c16 / out["roofline_env_step"]["avg_launch_us"]
-                ko = footprint_kernel_only(B)
+                ko = footprint_kernel_only(B, J, M, E, out["roofline_env_step"]["kernel"])
                 if ko:                                             # the figure to quote: both durations kernel-only (see footprint_kernel_only)
                     out["roofline_env_step"]["frac_of_same_footprint_copy_kernel_only"] = ko["frac"]
                     out["roofline_env_step"]["kernel_only"] = ko
@@ -633,6 +667,13 @@ def main():
                     legs[name] = {"error": repr(ex)}
             out["configs"] = legs
         if cpu_leg is not None:
+            # like for like: the CPU figure is the ENVIRONMENT alone; so is gpu_env_only (the step kernel's own rate, HIP events around the
+            # launch, inside the rollout).  `value` of the line is the FULL rollout step (both actor forwards included) — not the pair to compare.
+            if "error" not in cpu_leg:
+                cpu_leg["gpu_env_only_env_steps_per_s"] = roof_env["env_steps_per_s"]
+                cpu_leg["gpu_env_only_over_cpu"] = roof_env["env_steps_per_s"] / cpu_leg["value"]
+                cpu_leg["gpu_full_rollout_env_steps_per_s"] = value
+                cpu_leg["compare"] = "value (CPU, environment only) with gpu_env_only_env_steps_per_s; gpu_full_rollout_env_steps_per_s is the line's `value` and includes both actor forwards"
             out["cpu_baseline"] = cpu_leg
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -1769,7 +1769,13 @@ __device__ __forceinline__ void gat_prestage(const GatArgs &G, unsigned char *sm
 // read a rollout step ago — shortened it by 2 us and lengthened the first phase of the job heads by 0.5 us: the launch ended 0.7-1.2 us
 // later in alternating runs on one box, because the selection on waves 0-3, not this copy, ends the heads part.  Not kept.)
 #if !MTFJSP_BODY_FUNCS
-__global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArgs GA, HeadArgs HM, XchgArgs XG)
+// ENV (round 6): 0 = the three parts; 1 / 2 = + the environment step of the workgroup's 16 instances as the launch's tail (f32 / f64
+// observations; mtfjsp_env_grp.h's own code with the instances dealt to the 8 waves: bit-identical to k_env_grp16).  Two launches per
+// rollout step.  Round 3's k_headsx_envstep lost to the separate launch because the tail's first loads were cold (the state was last
+// touched a rollout step ago); here one word of every line of the workgroup's state records is requested in front of the machine
+// heads' part, 13 us ahead of the tail, and waits in this XCD's L2.
+template <int ENV>
+__global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArgs GA, HeadArgs HM, XchgArgs XG, EnvParams EP)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const XchgArgs &XA = XG;
@@ -1819,6 +1825,19 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
     X3_RT(3);
     tid_part = threadIdx.x;
     asm volatile("" : "+v"(tid_part));
+    unsigned env_warm = 0;
+    if (ENV) {                                                     // one word per 128-byte line of this workgroup's state records (task records 2 x 16 T x 16 B, job / machine records, scalar rows)
+        const int b0 = blockIdx.x * EG_SMALL, nb = EP.B - b0 < EG_SMALL ? EP.B - b0 : EG_SMALL;
+        const unsigned l_sd = (unsigned)(nb * EP.T * 16 + 127) / 128, l_jr = (unsigned)(nb * EP.J * 16 + 127) / 128, l_mj = (unsigned)(nb * EP.MJ * 8 + 127) / 128, l_sc = (unsigned)(nb * SCAL_N * 8 + 127) / 128;
+        unsigned l = (unsigned)tid_part;
+        const unsigned char *wp = reinterpret_cast<const unsigned char *>(EP.scal + (size_t)b0 * SCAL_N);
+        if (l < l_sd) wp = reinterpret_cast<const unsigned char *>(EP.sd + (size_t)b0 * EP.T) + (size_t)l * 128;
+        else if ((l -= l_sd) < l_sd) wp = reinterpret_cast<const unsigned char *>(EP.pl + (size_t)b0 * EP.T) + (size_t)l * 128;
+        else if ((l -= l_sd) < l_jr) wp = reinterpret_cast<const unsigned char *>(EP.jr + (size_t)b0 * EP.J) + (size_t)l * 128;
+        else if ((l -= l_jr) < l_mj) wp = reinterpret_cast<const unsigned char *>(EP.mj + (size_t)b0 * EP.MJ) + (size_t)l * 128;
+        else if ((l -= l_mj) < l_sc) wp += (size_t)l * 128;
+        env_warm = *reinterpret_cast<const unsigned *>(wp);
+    }
     LDS_BARRIER();                                                 // (not __syncthreads(): that would wait for the statistics' atomics to be acknowledged)
 #ifdef MTFJSP_STAMP3
 #undef H3_BASE
@@ -1843,6 +1862,11 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #undef BODY_TID
 #define BODY_TID threadIdx.x
     X3_RT(7);
+    if (ENV) {
+        asm volatile("" :: "v"(env_warm));
+        __syncthreads();                                           // the machine selection of this workgroup's instances is stored; the heads' LDS is free
+        if (ENV == 1) env_grp_body_dyn<float, 1, 8>(EP, smem); else env_grp_body_dyn<double, 1, 8>(EP, smem);
+    }
 }
 #endif
 // The machine actor's heads and the environment step of the same 16 instances in ONE launch (round-2 review, item 3): the heads end
@@ -2434,6 +2458,7 @@ struct mtfjsp_encoder {
     std::map<std::string, std::vector<float>> hostw;   // host copies of gat_layer.W / m_fea_*_fcl.weight (inputs of the fused projections)
     std::map<std::string, float *> wfused;  // per prefix + "1"/"2": (m_fea_k_fcl.weight^T . gat_layer.W)^T, [128,6] / [128,8]
     std::map<std::string, size_t> wx6_bytes;   // size of each wx6 image
+    std::map<std::string, size_t> wx32_bytes;  // size of each wx32 image (a GIN Linear has both: one map keyed by name held whichever was uploaded last)
     std::map<std::string, void *> wx6;      // 128x128 Linear weights as 2 f16 planes (scaled) in k_gemm_x6's register-image order; GAT W / first Linear: 3 bf16 planes
     std::map<std::string, void *> wx32;     // GIN Linear weights as operand-piece planes in k_gin_res's (32x32x16) register-image order
     std::map<std::string, float> wx32_sinv; // ... 1 / the power-of-two scale folded into that image
@@ -2492,6 +2517,12 @@ struct mtfjsp_encoder {
     // 220.4 against 217.6 us per step, three alternating runs on one box — because the heads' 8 waves take the 16 instances in two
     // rounds where k_env_grp16's 16 waves take them in one: the second round costs more than the launch boundary saves
     bool fuse_env = getenv("MTFJSP_FUSED_ENV") != nullptr;
+    // Round 6: the step as the tail of the THREE-in-one launch (k_headsx_gat3x_headsx<1|2>) with its state lines requested 13 us ahead:
+    // two launches per rollout step, bit-identical (tests/test_fused_env_step_gpu.py).  OFF unless MTFJSP_FUSED_ENV3 is set: measured
+    // SLOWER again — 0.1772-0.1786 against 0.1750-0.1751 ms per step, three alternating runs on one box (tools/ab_bench_env3.sh,
+    // profiles/r06_ab_env3.txt): the launch's 8 waves take the 16 instances in two rounds behind one another, which costs about 3 us
+    // more than the launch boundary and the separate kernel's dispatch ramp together, warm state lines or not.
+    bool fuse_env3 = getenv("MTFJSP_FUSED_ENV3") != nullptr;
     bool warm_heads = !getenv("MTFJSP_NO_WARM_HEADS");          // k_gin_res requests the heads launch's weight lines in its last phase
     struct { bool armed = false, done = false; EnvParams P; } env_step;          // groups of 8 instances in k_headsx when groups of 16 fill at most half the CUs
     // streaming GIN launches: the two inner Linears of an MLP in one launch behind a statistics-only pass (mtfjsp_gemm_pair.h).
@@ -2507,6 +2538,7 @@ struct mtfjsp_encoder {
     mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
     struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
                          const int32_t *gather_from = nullptr; int32_t *gathered = nullptr; } fs[2];   // [0] job actor, [1] machine actor
+    FusedSample fs1_consumed;               // the machine selection the last three-in-one launch consumed (restored when the machine forward that follows is NOT the one it ran)
     // timing
     bool timing = false;
     std::map<std::string, std::vector<std::pair<hipEvent_t, hipEvent_t>>> ev;
@@ -2691,7 +2723,9 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_headsx_gat3x, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes()));
 #if !MTFJSP_BODY_FUNCS
-    if (hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
+    if (hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)fused3_lds_bytes()) != hipSuccess) e->fuse_mheads = false;
 #else
     e->fuse_mheads = false;
@@ -2890,7 +2924,7 @@ extern "C" int mtfjsp_encoder_load_weight_host(mtfjsp_encoder_t e, const char *n
         if (kt != e->wx32.end()) dx = kt->second;
         else { float *tmp = nullptr; if (dalloc(e, &tmp, im.size() / 2)) return MTFJSP_ERR_HIP; dx = tmp; e->wx32[key] = dx; }
         HIPCHK(e, hipMemcpy(dx, im.data(), im.size() * 2, hipMemcpyHostToDevice));
-            e->wx6_bytes[key] = im.size() * 2;
+        e->wx32_bytes[key] = im.size() * 2;
         e->wx32_sinv[key] = 1.0f / scale;
     }
     // 128-wide Linear weights [out=128, in=128*k] and gat W [in,out]: keep GEMM-ready [in-block][k][n] copies
@@ -3466,7 +3500,7 @@ extern "C" int mtfjsp_encoder_set_product_mode(mtfjsp_encoder_t e, int32_t f32_i
 {
     if (!e || f32_instruction_mask < 0 || f32_instruction_mask > 31) return MTFJSP_ERR_ARG;
     e->f32_products = f32_instruction_mask;
-    e->prefused.valid = false;                       // (GAT passes done ahead by another kernel family are not reused across a mode change)
+    e->prefused.valid = false; e->prefused.heads = false;   // (work done ahead by another kernel family is not reused across a mode change)
     return MTFJSP_OK;
 }
 // exact multi-shard BatchNorm: after the launch that completes a BatchNorm's column sums, hand them to the caller's reduction
@@ -3481,7 +3515,7 @@ extern "C" int mtfjsp_encoder_set_stats_reduce(mtfjsp_encoder_t e, mtfjsp_stats_
 {
     if (!e || (fn && global_batch < e->cfg.batch)) return MTFJSP_ERR_ARG;
     e->reduce_fn = fn; e->reduce_user = user;
-    e->prefused.valid = false;
+    e->prefused.valid = false; e->prefused.heads = false;
     e->reduce_scale = fn ? (double)global_batch / (double)e->cfg.batch : 1.0;
     return MTFJSP_OK;
 }
@@ -3489,7 +3523,7 @@ extern "C" int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instan
 {
     if (!e || per_instance < 0 || per_instance > 1) return MTFJSP_ERR_ARG;
     e->bn_mode = per_instance;
-    e->prefused.valid = false;
+    e->prefused.valid = false; e->prefused.heads = false;
     return MTFJSP_OK;
 }
 // deferred = 1: the forward entries stop polling the asynchronous failure words; failures surface at mtfjsp_encoder_check only.  For
@@ -3532,7 +3566,9 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
             if (!d_st3) { (void)hipMalloc((void **)&d_st3, (size_t)2048 * 64 * 8); (void)hipMemset(d_st3, 0, (size_t)2048 * 64 * 8); }
             xg.stamps = d_st3;
 #endif
-            hipLaunchKernelGGL(k_headsx_gat3x_headsx, dim3(grid), dim3(512), fused3_lds_bytes(), e->stream, ha, *fused_gat, *fused_mheads, xg);
+            if (env_tail && env_tail->obs_f32) hipLaunchKernelGGL(k_headsx_gat3x_headsx<1>, dim3(grid), dim3(512), fused3_lds_bytes(), e->stream, ha, *fused_gat, *fused_mheads, xg, *env_tail);
+            else if (env_tail) hipLaunchKernelGGL(k_headsx_gat3x_headsx<2>, dim3(grid), dim3(512), fused3_lds_bytes(), e->stream, ha, *fused_gat, *fused_mheads, xg, *env_tail);
+            else hipLaunchKernelGGL(k_headsx_gat3x_headsx<0>, dim3(grid), dim3(512), fused3_lds_bytes(), e->stream, ha, *fused_gat, *fused_mheads, xg, EnvParams{});
 #ifdef MTFJSP_STAMP3
             if (e->fused3_launches % 50 == 20 && getenv("MTFJSP_STAMP_PRINT")) {
                 (void)hipStreamSynchronize(e->stream);
@@ -3765,12 +3801,20 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
             hm_args.xbn_gamma = W("machine_actor.bn.weight"); hm_args.xbn_beta = W("machine_actor.bn.bias");
             hm_args.xbn_inv_rows = 1.0 / ((double)B * (double)e->cfg.n_machine);
             hm_args.hg = HG;
+            e->fs1_consumed = e->fs[1]; e->fs1_consumed.armed = true;
             arm_sampling(e, 1, hm_args);
             set_head_images(e, hm_args, "machine_actor.m_policy", "machine_actor.machine_critic");
             e->prefused.heads = true; e->prefused.f1 = ha.mf.m_fea1_out; e->prefused.f2 = ha.mf.m_fea2; e->prefused.h_pooled_o = h_pooled;
             e->prefused.mmask = ha.mf.mmask_out; e->prefused.prob = e->mh.prob; e->prefused.h_pooled = e->mh.h_pooled; e->prefused.machine_v = e->mh.machine_v;
         }
-        launch_heads(e, ha, "job_actor.o_policy", "job_actor.job_critic", with_gat ? &ga : nullptr, nullptr, with_mheads ? &hm_args : nullptr);
+        // an environment step armed BEFORE this forward (mtfjsp_encoder_arm_env_step) rides in the three-in-one launch when the machine
+        // selection made there is the one it reads and the shapes agree (round 6: two launches per rollout step)
+        const EnvParams &EP = e->env_step.P;
+        const bool env_tail = with_mheads && e->env_step.armed && e->fuse_env3 && !e->timing && hm_args.sample_mode && ha.sample_mode &&
+                              (const void *)hm_args.idx_out == (const void *)EP.mach_idx && (const void *)ha.gathered_out == (const void *)EP.task_idx &&
+                              EP.B == B && EP.M == e->cfg.n_machine && EP.T <= 64 && EP.M * EP.M <= 64 && EP.J <= 64 && fused3_lds_bytes() >= EnvGrpDynLds<1>::bytes;
+        if (e->env_step.armed && with_mheads) { e->env_step.armed = false; e->env_step.done = env_tail; }
+        launch_heads(e, ha, "job_actor.o_policy", "job_actor.job_critic", with_gat ? &ga : nullptr, env_tail ? &EP : nullptr, with_mheads ? &hm_args : nullptr);
 #ifdef MTFJSP_STAMP
         static int printed = 0;
         if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
@@ -3817,12 +3861,19 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
     int slot = 0;
     if (e->prefused.heads && !e->bn_mode && m_fea1 == e->prefused.f1 && m_fea2 == e->prefused.f2 && h_pooled_o == e->prefused.h_pooled_o &&
         mmask == e->prefused.mmask && prob == e->prefused.prob && h_pooled == e->prefused.h_pooled && machine_v == e->prefused.machine_v) {
-        // k_headsx_gat3x_headsx ran this whole forward (and its armed selection) inside the job actor's heads launch
+        // k_headsx_gat3x_headsx ran this whole forward (and its armed selection) inside the job actor's heads launch.  The match is by
+        // POINTER: a caller that rewrites m_fea1 / the mask in place between the two forwards must not arm the machine heads
+        // (include/mtfjsp.h, mtfjsp_encoder_arm_machine_heads).  A time-out of that launch's exchange is reported HERE, at the machine
+        // forward of the same step, as the separate launch would (advisor r5) — unless the caller polls once per step itself.
+        if (!e->defer_poll && (rc = res_poll_failure(e))) { e->prefused.heads = false; e->prefused.valid = false; return rc; }
         e->prefused.heads = false; e->prefused.valid = false;
-        e->env_step.armed = false; e->env_step.done = false;
+        e->fs1_consumed = mtfjsp_encoder::FusedSample{};
+        e->env_step.armed = false;                                    // (env_step.done: set by the job forward whose launch ran this forward — and the armed step, if it could)
         e->fs[1].armed = false;                                       // (a selection armed again for this call has been made already)
         return MTFJSP_OK;
     }
+    if (e->prefused.heads && e->fs1_consumed.idx && !e->fs[1].armed) e->fs[1] = e->fs1_consumed;   // other pointers: this forward is computed here and selects again with the selection the fused launch consumed
+    e->fs1_consumed = mtfjsp_encoder::FusedSample{};
     e->prefused.heads = false;
     if (e->prefused.valid && !e->bn_mode && m_fea1 == e->prefused.f1 && m_fea2 == e->prefused.f2) slot = e->prefused.slot;   // k_headsx_gat3x did it
     else rc = e->bn_mode ? run_gat_inst(e, "machine_actor.", m_fea1, m_fea2, h_pooled) : run_gat(e, "machine_actor.", m_fea1, m_fea2, nullptr, &slot);
@@ -3881,8 +3932,9 @@ static int global_critic_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea,
         if (!e->w.count(k)) { e->err = std::string("missing weight: ") + k; return MTFJSP_ERR_STATE; }
     HIPCHK(e, hipSetDevice(e->cfg.device_id));
     // this forward's GAT passes overwrite e->node and move on to another statistics slot: GAT passes the job actor's heads launch
-    // ran ahead for a coming machine-actor forward (k_headsx_gat3x) are gone, that forward has to redo them
-    e->prefused.valid = false;
+    // ran ahead for a coming machine-actor forward (k_headsx_gat3x) are gone, that forward has to redo them — and so is a whole
+    // machine forward done ahead (k_headsx_gat3x_headsx): its node rows are overwritten
+    e->prefused.valid = false; e->prefused.heads = false;
     if (!e->defer_poll) { const int prc = res_poll_failure(e); if (prc) return prc; }
     const int B = e->cfg.batch;
     auto W = [&](const std::string &k) { return e->w.at(k); };

@@ -279,6 +279,7 @@ class ActorPair:
         self.fuse_env = bool(os.environ.get("MTFJSP_FUSED_ENV")) # (the library reads the same switch when the handle is created; off by default: DESIGN.md §9)
         self.fused = not os.environ.get("MTFJSP_NO_FUSED_SELECT")   # action selection inside the heads kernels (same stream either way)
         self.fuse_mheads = not os.environ.get("MTFJSP_NO_FUSED_MHEADS")   # the machine forward inside the job heads' launch where the library allows it
+        self.fuse_env3 = bool(os.environ.get("MTFJSP_FUSED_ENV3"))        # ... and the environment step as that launch's tail (two launches per step; off by default: measured slower)
         dev = self.enc.device
         self.job_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
         self.mch_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
@@ -302,7 +303,7 @@ class ActorPair:
         ml = mach_logp if mach_logp is not None else self.mch_logp
         hm = e.h_pooled_m if self.have_hm else None
         fuse_mfea1 = self.fused and force is None
-        armed_m = False
+        armed_m = armed_e = False
         if self.fused:
             e.arm_selection(0, self.greedy, self.seed, 2 * counter, job_idx, jl, env.candidate, task_idx)
             if fuse_mfea1:
@@ -319,6 +320,13 @@ class ActorPair:
                     e.arm_selection(1, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)
                     e.arm_machine_heads(e.mch_prob, e.h_pooled_m, mv_out if mv_out is not None else e.mach_v)
                     armed_m = True
+                    if self.fuse_env3 and env_step is not None:
+                        # env_step = () or (r4_out, done_out): the step of this decision as the tail of that launch (the library takes it
+                        # where the three-in-one launch runs and the step is the 16-instance register kernel; env_step_fused() tells)
+                        params = env.step_params(task_idx, mach_idx, *env_step)
+                        if params is not None:
+                            e.arm_env_step(params)
+                            armed_e = True
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
         else:
             prob, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm, v_out=jv_out)
@@ -347,7 +355,7 @@ class ActorPair:
                 if params is not None:
                     e.arm_env_step(params)
             e.machine_actor_forward(mf1, env.m_fea2, h_o, mmk, v_out=mv_out)
-            stepped = self.fuse_env and env_step is not None and force is None and e.env_step_fused()
+            stepped = (armed_e or (self.fuse_env and env_step is not None and force is None)) and e.env_step_fused()
         else:
             mprob, _, _ = e.machine_actor_forward(mf1, env.m_fea2, h_o, mmk, v_out=mv_out)
             e.sample(mprob, self.greedy, self.seed, 2 * counter + 1, mach_idx, ml)

@@ -13,8 +13,13 @@ Differences that are deliberate (documented in DESIGN.md §6):
   * `paral_env_DG[i].render()` prints a console Gantt chart (the reference's default "gantt_console" visualisation,
     Run.py:651-653, validate.py:286); window / rgb-array rendering is outside the accelerated hot path;
   * `paral_env_DG[i].step([task, machine])` (gym-style, env:716-974) steps instance i alone through the same kernel (the other
-    instances of the batch receive a rejected no-op); entries of the reference's 14-tuple that no caller of the hot path
-    reads (flat gym observation, ft_s / it_s lists, the 3-column tasks_fea) are None.
+    instances of the batch receive a rejected no-op) and returns the reference's 14-tuple; the ONE entry left None is `state`
+    (entry 0 of step's and reset's tuples: the flat normalised [T, T + M + 1] legacy observation of env:2073-2140, which no caller
+    in Run.py / validate.py / ppo_algorithm.py reads).  ft_s (finish times of the scheduled tasks, env:2146-2151), it_s (idle time
+    each decision added, env:2150) and the 3-column tasks_fea (env:2215-2241) are filled, bit-equal to the reference's;
+    `observation_space` / `action_space` (env:434-467, the defaults Parallel_env constructs its environments with: task actions,
+    normalised flat float32 observation) are gym / gymnasium spaces when either package is importable and objects with the same
+    `shape`, `n`, `low`, `high`, `dtype` attributes otherwise.
 `DisjunctiveGraphJspEnv_singleStep` below is the same surface as a stand-alone one-instance environment for callers that
 build their own env (trainer/validate.py:108-127).
 """
@@ -25,6 +30,47 @@ import torch
 from . import capi
 from .batch_env import DeviceBatchEnv
 from .instances import random_weights
+
+
+class _Space:
+    """what callers read of a gym space (shape / n / low / high / dtype / contains / sample) when neither gym nor gymnasium is installed"""
+
+    def __init__(self, n=None, shape=None, low=0.0, high=1.0, dtype=np.float32):
+        self.n, self.low, self.high, self.dtype = n, low, high, np.dtype(dtype if n is None else np.int64)
+        self.shape = () if n is not None else tuple(shape)
+
+    def contains(self, x):
+        if self.n is not None:
+            return isinstance(x, (int, np.integer)) and 0 <= int(x) < self.n
+        x = np.asarray(x)
+        return x.shape == self.shape and bool((x >= self.low).all() and (x <= self.high).all())
+
+    def sample(self):
+        return int(np.random.randint(self.n)) if self.n is not None else np.random.uniform(self.low, self.high, self.shape).astype(self.dtype)
+
+    def __repr__(self):
+        return f"Discrete({self.n})" if self.n is not None else f"Box({self.low}, {self.high}, {self.shape}, {self.dtype})"
+
+
+def _spaces(T, M):
+    """(observation_space, action_space) of env:434-467 with the constructor defaults (action_mode 'task', normalised flat float32)"""
+    shape = (T * (T + M + 1),)
+    for mod in ("gymnasium", "gym"):
+        try:
+            sp = __import__(mod).spaces
+            return sp.Box(low=0.0, high=1.0, shape=shape, dtype=np.float32), sp.Discrete(T)
+        except Exception:
+            continue
+    return _Space(shape=shape), _Space(n=T)
+
+
+def _tuple_extras(tfea, finish, it_s):
+    """ft_s (env:2146-2151), it_s (env:2150), the 3-column tasks_fea (env:2215-2241) of one instance from its [T,12] feature rows
+    (col 1 estimated / real finish, col 2 energy, col 3 scheduled), its finish times (NaN = unscheduled) and the idle-time record"""
+    sched = tfea[:, 3] == 1
+    ft_s = np.where(sched, np.nan_to_num(finish, nan=0.0), 0.0)
+    old = np.stack([tfea[:, 1], np.where(sched, tfea[:, 2], 0.0), tfea[:, 3]], axis=1)
+    return ft_s, np.array(it_s, dtype=np.int64), old
 
 
 class _NodeView:
@@ -64,6 +110,7 @@ class _EnvProxy:
     def __init__(self, parent, i):
         self._parent, self._i, self._env = parent, i, parent._dev
         self.G = _GraphView(self)
+        self.observation_space, self.action_space = parent._spaces
 
     @property
     def reward_random_weight(self):
@@ -153,6 +200,10 @@ class Parallel_env(object):
         self._w3 = np.zeros((self.batch_size, 3))
         self._cache = {}
         self._scaler_pending = np.zeros(self.batch_size, bool)
+        # env.it_s: the idle time each decision added (env:2150), cleared by reset — an INTEGER array in the reference (reset's
+        # _state_array turns the list of zeros into an int64 array; every later assignment truncates toward zero), and so here
+        self._it_s = np.zeros((self.batch_size, self.ntasks), np.int64)
+        self._spaces = _spaces(self.ntasks, self.nmachines)
 
     # -- host mirrors of device state, refreshed lazily once per step
     def _mirror(self, which):
@@ -204,6 +255,7 @@ class Parallel_env(object):
         self._w3 = random_weights(self.batch_size, kind="01", config_weights=self._w_cfg)   # pe:130 calls env.reset() with its default type "01" (env:1183)
         self._dev.reset(self._w3)
         self._cache = {}
+        self._it_s[:] = 0
         self.paral_env_DG = [_EnvProxy(self, i) for i in range(self.batch_size)]
         return self._host_obs()
 
@@ -233,6 +285,8 @@ class Parallel_env(object):
             print("!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!!")
             print(f"============= 'DGFJSPEnv_paral_step' occur error: chose Minus: t={self.ability_instance[l][0][a[l]][m[l]]}, p= {self.ability_instance[l][1][a[l]][m[l]]}")
         info = self._dev.info.cpu().numpy()
+        ok = (status & capi.ST_INVALID) == 0
+        self._it_s[np.flatnonzero(ok), a[ok]] = -self._dev.raw.cpu().numpy()[ok, 2]     # idle_this - idle_prev = -(r_idle) exactly (env:1088, 2150)
         self.oenv_info = [[info[i, 0], bool(info[i, 1]), info[i, 2], info[i, 3], info[i, 4], info[i, 5]]
                           for i in range(self.batch_size)]
         adj, mfea2, tfea = self._host_obs()
@@ -260,8 +314,10 @@ class Parallel_env(object):
         adj = self._dense_adj_row(i)
         tfea = self._dev.tasks_fea.view(B, T, 12)[i].cpu().numpy().copy()
         mfea = self._dev.m_fea2[i].cpu().numpy().copy()
-        return (None, float(raw[0]), done, {}, float(raw[1]), float(raw[2]), float(raw[3]), float(raw[4]), None, None,
-                adj, None, mfea, tfea)
+        self._it_s[i, a] = -float(raw[2])                           # env:2150
+        ft_s, it_s, tfea3 = _tuple_extras(tfea, self._mirror(capi.STATE_FINISH)[i], self._it_s[i])
+        return (None, float(raw[0]), done, {}, float(raw[1]), float(raw[2]), float(raw[3]), float(raw[4]), ft_s, it_s,
+                adj, tfea3, mfea, tfea)
 
     def _dense_adj_row(self, i):
         """dense adj_wrk [T,T] of ONE instance from its 2 T ELL entries (row = destination, self loop 1; env:2019-2073) — not the
@@ -306,19 +362,22 @@ class DisjunctiveGraphJspEnv_singleStep:
         self._pe.get_batch({"t": t[None], "p": p[None], "transT": np.asarray(ability_tr_mm, np.float64)[None], "edge": np.asarray(edge)[None]})
         self._pe.init_RewardScaling_sameBATCH(4)
         self.n_jobs, self.n_machines, self.total_tasks_without_dummies = J, M, J * M
+        self.observation_space, self.action_space = self._pe._spaces
         self._proxy = None
 
     def reset(self, Random_weight_type="01"):
         """-> the 9-tuple of env._state_array (env:2515): (state, ft_s, it_s, adj_wrk, tasks_fea, machines_fea, tasks_fea_1101,
-        ft_estimated [T], pt_estimated [T]); entries no hot-path caller reads are None"""
+        ft_estimated [T], pt_estimated [T]); `state` (the flat legacy observation, read by no caller) is None"""
         pe = self._pe
         pe._w3 = random_weights(1, kind=Random_weight_type, config_weights=pe._w_cfg)
         pe._dev.reset(pe._w3)
         pe._cache = {}
+        pe._it_s[:] = 0
         pe.paral_env_DG = [_EnvProxy(pe, 0)]
         self._proxy = pe.paral_env_DG[0]
         adj, mfea2, tfea = pe._host_obs()
-        return (None, None, None, adj[0], None, mfea2[0], tfea, tfea[:, 1].copy(), tfea[:, 2].copy())
+        ft_s, it_s, tfea3 = _tuple_extras(tfea, np.full(tfea.shape[0], np.nan), pe._it_s[0])
+        return (None, ft_s, it_s, adj[0], tfea3, mfea2[0], tfea, tfea[:, 1].copy(), tfea[:, 2].copy())
 
     def step(self, joint_action):
         return self._proxy.step(joint_action)

@@ -171,7 +171,10 @@ class Rollout:
         forwards at every step: the forward entries do not poll for failures at all (Encoder.set_deferred_poll); once per step,
         after draining the device, every rank checks its failure words and the ranks agree — if any failed, ALL restart their
         episode and taint the buffer together, and their forward sequences stay identical."""
-        if self.exact_bn and self._lockstep:
+        if self.exact_bn:
+            # (exact_bn implies an active group with world > 1 and a deferred poll, with or without a trajectory record: a throughput
+            # run over several ranks — collect=False — all-reduces BatchNorm sums too, and a range failure on one rank must still
+            # switch every rank's kernels before NaN sums spread through the reduction: advisor r5)
             self._agree_on_failure_and_restart_together()
             self._step(force)
             return
@@ -202,7 +205,7 @@ class Rollout:
         if _dist.agree_any(failed):
             self.n_resident_failures += int(failed)
             self.t_in_ep = 0                               # every rank: fresh episode, rest of the buffer unrecorded, dropped at its boundary
-            self.tainted = True
+            self.tainted = self.collect                    # (without a trajectory record there is no buffer to drop)
             self.actor.begin_episode()
 
     @property

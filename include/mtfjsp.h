@@ -300,7 +300,11 @@ int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask
  * (count-carrying integer atomics as in the single-launch GIN kernel; the wait is bounded, a time-out surfaces as
  * MTFJSP_ERR_RETRY) and the machine heads with their selection.  The mtfjsp_machine_actor_forward that follows with exactly the
  * pointers involved (m_fea1_out, m_fea2, that job forward's h_pooled, mmask_out, these outputs) finds itself done and returns at
- * once; with any other argument it recomputes.  Where the shape does not allow it nothing changes.  MTFJSP_NO_FUSED_MHEADS=1: off.
+ * once; with any other argument it recomputes (and selects again with the machine selection the launch consumed).  The match is by
+ * POINTER IDENTITY, as for m_fea2: a caller that rewrites m_fea1 / the machine mask IN PLACE between the two forwards (a forced task
+ * through mtfjsp_observe_mfea1 into the same buffers) must not arm the machine heads for that step.  The mode setters
+ * (set_bn_mode, set_stats_reduce, set_product_mode) and mtfjsp_global_critic_forward discard a forward done ahead.
+ * Where the shape does not allow it nothing changes.  MTFJSP_NO_FUSED_MHEADS=1: off.
  * mtfjsp_encoder_fused_launches: how many forwards took the three-in-one launch so far (tests, bench). */
 int mtfjsp_encoder_arm_machine_heads(mtfjsp_encoder_t e, float *prob, float *h_pooled, float *machine_v);
 int mtfjsp_encoder_fused_launches(mtfjsp_encoder_t e, int64_t *three_in_one_out);

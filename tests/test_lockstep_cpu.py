@@ -108,7 +108,7 @@ class StubEnv:
                 targets[k] = norm[k] + values[k]
 
 
-def _worker(rank, world, port, tmp, exact, fail_rank, fail_at, defer=True, timeout_s=60):
+def _worker(rank, world, port, tmp, exact, fail_rank, fail_at, defer=True, timeout_s=60, collect=True):
     rollout, capi, D = _mods()
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
@@ -130,7 +130,7 @@ def _worker(rank, world, port, tmp, exact, fail_rank, fail_at, defer=True, timeo
         ro.w3_mode, ro.w3_pool = "fixed", torch.zeros(1, B, 3, dtype=torch.float64)
         ro.task = torch.zeros(B, dtype=torch.int32); ro.mach = torch.zeros(B, dtype=torch.int32); ro.job = torch.zeros(B, dtype=torch.int32)
         ro.seed, ro.t_in_ep, ro.episode, ro.nsteps = 1, 0, 0, 0
-        ro.collect, ro.full, ro.S, ro.buffer_episodes, ro.gamma, ro.lam = True, False, eps * T, eps, 0.99, 0.98
+        ro.collect, ro.full, ro.S, ro.buffer_episodes, ro.gamma, ro.lam = collect, False, eps * T, eps, 0.99, 0.98
         ro.buf_pos, ro.last_adv, ro.last_gather, ro.n_handoffs, ro.n_resident_failures, ro.n_dropped_buffers = 0, None, None, 0, 0, 0
         ro.tainted, ro._new_episode, ro._pre_slot, ro.exact_bn = False, False, -1, exact
         ro.global_handoff, ro.time_handoff, ro.last_full, ro.traj = True, True, None, None
@@ -165,6 +165,22 @@ def test_a_failure_on_one_rank_keeps_the_ranks_collectives_aligned(tmp_path, exa
     assert r0["finite"] and r1["finite"] and r0["world"] == r1["world"] == 2
     if exact:                                                                # the forwards ARE collectives: identical sequences on both ranks
         assert r0["allreduce"] == r1["allreduce"] == r0["forwards"] == r1["forwards"]
+
+
+def test_exact_bn_without_a_trajectory_record_still_agrees_on_failures_every_step(tmp_path):
+    """advisor r5: a throughput run over several ranks (collect=False) with exact_bn all-reduces BatchNorm sums in every forward and
+    polls nothing at the forward entries (deferred poll) — so the once-per-step agree-and-restart must run there too, or a range
+    failure on one rank never switches kernels and NaN sums reach every rank.  Both ranks restart their episode at the same step and
+    issue identical forward / all-reduce sequences."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path), True, 0, 11, True, 60, False), nprocs=2, join=True)
+    r0, r1 = eval(open(tmp_path / "r0").read()), eval(open(tmp_path / "r1").read())
+    assert r0["failures"] == 1 and r1["failures"] == 0
+    assert r0["agree"] == r1["agree"] == 4 * 2 * T                           # one agreement per step() call on both ranks
+    assert r0["t"] == r1["t"] and r0["t"] != (4 * 2 * T) % T                 # ... and both restarted their episode at the failing step
+    assert r0["allreduce"] == r1["allreduce"] == r0["forwards"] == r1["forwards"]
+    assert r0["handoffs"] == r1["handoffs"] == 0 and r0["dropped"] == r1["dropped"] == 0
 
 
 def test_negative_control_entry_polls_under_exact_bn_do_misalign(tmp_path):

@@ -123,9 +123,15 @@ def test_gym_style_single_env_replays_reference_trace(capsys):
     env = pe.DisjunctiveGraphJspEnv_singleStep(jps_instance=[g["t"][0], g["p"][0]], reward_function_parameters={"scaling_divisor": 1},
                                                default_visualisations=["gantt_console", "graph_console"], reward_function='wrk',
                                                ability_tr_mm=g["tt"][0], perform_left_shift_if_possible=True, configs=cfg, edge=g["edge"][0])
+    gs = load("gymstep_j6m6e2")                          # the reference's own single env replaying this instance (oracle/ref_harness/gen_golden_gymstep.py)
+    assert tuple(env.observation_space.shape) == tuple(gs["obs_shape"]) and env.action_space.n == int(gs["act_n"])       # env:434-467
+    assert float(np.min(env.observation_space.low)) == float(gs["obs_low"]) and float(np.max(env.observation_space.high)) == float(gs["obs_high"])
+    assert str(np.dtype(env.observation_space.dtype)) == str(gs["obs_dtype"])
     random.seed(1)                                      # gen_golden.py: w_seed=1; instance 0 takes the first three draws
     out = env.reset()
     assert len(out) == 9 and np.array_equal(env.reward_random_weight, g["w3"][0][0])
+    assert np.array_equal(out[1], gs["reset_ft_s"]) and np.array_equal(out[2], gs["reset_it_s"]) and np.array_equal(out[4], gs["reset_tfea3"])
+    assert out[2].dtype == gs["reset_it_s"].dtype
     assert np.array_equal(out[3], g["adj0"][0][0]) and np.array_equal(out[6], g["tfea0"][0][:T]) and np.array_equal(out[5], g["mfea2_0"][0][0])
     assert np.array_equal(out[7], g["tfea0"][0][:T, 1]) and np.array_equal(out[8], g["tfea0"][0][:T, 2])
     for step in range(T):
@@ -137,6 +143,9 @@ def test_gym_style_single_env_replays_reference_trace(capsys):
         assert res[1] == raw[0] and res[2] == bool(g["info"][0, step][0, 1]) and tuple(res[4:8]) == tuple(raw[1:5])
         assert np.array_equal(res[10], g["adj"][0, step][0]) and np.array_equal(res[12], g["mfea2"][0, step][0])
         assert np.array_equal(res[13], g["tfea"][0, step][:T])
+        # the entries the batched trace does not hold: ft_s, it_s (an int64 record: the reference truncates), the 3-column tasks_fea
+        assert np.array_equal(res[8], gs["ft_s"][step]) and np.array_equal(res[9], gs["it_s"][step]) and res[9].dtype == gs["it_s"].dtype
+        assert np.array_equal(res[11], gs["tfea3"][step])
         assert env.G.nodes[a + 1]['finish_time'] == g["ft"][0, step][0, a]
     assert res[2] is True
     prev = g["prev"][0, T - 1][0]

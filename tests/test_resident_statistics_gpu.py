@@ -95,6 +95,22 @@ def test_shipped_checkpoint_at_the_headline_batch_stays_inside_the_range_and_on_
     budget(case, "job_v", job_v.cpu().numpy(), o["job_v"], 1e-3, relative=True)
 
 
+def test_shipped_checkpoint_over_five_episodes_of_the_headline_rollout_never_leaves_the_fast_kernels():
+    """review r5 item 6: the range / overflow fallbacks of the split products and of the fixed-point statistics, and the three-in-one
+    launch's exchange, over a whole timed-region-like run with the only TRAINED weights — not one observation"""
+    from oracle import encoder_oracle as eo
+    g = np.load(os.path.join(GOLDEN, "encoder_j6m6e2_top1.npz"))
+    ja, ma = eo.split_weights(g)
+    steps = 5 * T
+    ro = _mid_episode((ja, ma), steps=steps, seed=5)
+    enc = ro.actor.enc
+    assert enc.check()                                             # no asynchronous failure word raised
+    assert enc.range_fallbacks()[0] == 0 and ro.n_resident_failures == 0
+    assert enc.fused_launches() == steps, (enc.fused_launches(), steps)      # every decision took the three-in-one launch
+    assert bool(ro.env.info[:, 1].all())                           # ... and the fifth episode ended on every instance
+    assert bool(torch.isfinite(enc.mch_prob).all()) and bool(torch.isfinite(ro.env.info).all())
+
+
 def test_two_runs_give_the_same_bits():
     enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
     ja, ma = enc_mod.random_init_weights(seed=4)

@@ -12,7 +12,8 @@ made.  Like is compared with like:
 import csv, collections, glob, json, re, sys
 tag = sys.argv[1]
 prefix = sys.argv[2] if len(sys.argv) > 2 else "fp"
-out = {"what": "rocprofv3 --kernel-trace durations (End - Start per dispatch, ns) of the step kernel and of the SURVEY 8(d) same-footprint copy kernel in one "
+size = sys.argv[3] if len(sys.argv) > 3 else "6x6x2"                # what tools/footprint_kernel_only.py ran (--size)
+out = {"size": size, "what": "rocprofv3 --kernel-trace durations (End - Start per dispatch, ns) of the step kernel and of the SURVEY 8(d) same-footprint copy kernel in one "
                "process (tools/footprint_kernel_only.py), by the gap in front of the dispatch: idle (>= 1 us) | b2b (< 0.2 us); copy: best grid per class",
        "batches": {}}
 
