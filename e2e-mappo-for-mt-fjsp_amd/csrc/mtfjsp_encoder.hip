@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <map>
 #include <stdexcept>
 #include <string>
@@ -3285,6 +3286,19 @@ static int run_gin_resident(mtfjsp_encoder *e, const std::string &pre, const voi
             printf(" [%d] %.1f/%.1f", i, m / e->res_grid, mx);
         }
         printf("\n");
+        {   // the clock inside the kernel: shader cycles (s_memtime) per 10 ns tick (s_memrealtime) over a span, median over the workgroups
+            auto clk = [&](int a, int b) {
+                std::vector<double> v;
+                for (int blk = 0; blk < e->res_grid; blk++) {
+                    const double dr = (double)(h[(size_t)blk * 64 + b] - h[(size_t)blk * 64 + a]), dc = (double)(h[(size_t)blk * 64 + 33 + b] - h[(size_t)blk * 64 + 33 + a]);
+                    if (dr > 0) v.push_back(dc / dr * 0.1);                    // GHz
+                }
+                std::sort(v.begin(), v.end());
+                return v.empty() ? 0.0 : v[v.size() / 2];
+            };
+            printf("GR_CLOCK launch %d (GHz, median over %d workgroups): five layers [7 -> 24] %.3f | layer 1 [7 -> 8] %.3f  layer 2 [11 -> 12] %.3f  layer 3 [15 -> 16] %.3f  "
+                   "layer 4 [19 -> 20] %.3f  layer 5 [23 -> 24] %.3f | whole kernel [0 -> 30] %.3f\n", printed, e->res_grid, clk(7, 24), clk(7, 8), clk(11, 12), clk(15, 16), clk(19, 20), clk(23, 24), clk(0, 30));
+        }
     }
 #endif
     HIPCHK(e, hipGetLastError());

@@ -283,10 +283,11 @@ __device__ __forceinline__ void env_grp_wave(const EnvParams &P, const int b, co
         int ubase = nsched;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-            const double ftPr = SHD(ft, prev[s] >= 0 ? prev[s] : 0);
+            const int below = __shfl(before, mach[s] >= 0 ? mach[s] : 0);       // executed by ALL lanes: the source lanes must be active
+            const double ftPr = SHD(ft, prev[s] >= 0 ? prev[s] : 0);            // (the three gathers go out together: one LDS round trip)
+            __builtin_amdgcn_sched_barrier(0);
             const double term = prev[s] < 0 ? st[s] : st[s] - ftPr;
             const bool sch = isT[s] && mach[s] >= 0;
-            const int below = __shfl(before, mach[s] >= 0 ? mach[s] : 0);       // executed by ALL lanes: the source lanes must be active
             const unsigned long long um = __ballot(isT[s] && mach[s] < 0);
             const int uidx = ubase + __builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
             s_sorted[sch ? below + pos[s] : isT[s] ? uidx : v[s]] = sch ? term : 0.0;
@@ -813,6 +814,8 @@ __device__ __forceinline__ void env_grp_body(const EnvParams &P)
 #ifdef MTFJSP_STAMP
     rt[0] = __builtin_amdgcn_s_memrealtime();
 #endif
+    // (issue priority by quartet — s_setprio 1..3 for the waves whose data arrives later — was measured in round 6: it reverses the order in
+    // which the quartets' loads are served as well, the barrier moved from 4.65 to 4.97 us: not kept)
     if (b0 + grp < P.B) env_grp_wave<OBS, NS>(P, b0 + grp, lane, s_sorted[grp], s_jmx[grp], s_jrw[grp], s_cn[grp], s_scl[grp], s_mf[grp], s_un[grp], s_in[grp], s_mj2[grp], s_row[grp], s_mp[grp], s_sdf[grp], s_ttl[grp], rt);
 #ifdef MTFJSP_STAMP_WAVES                      // diagnostic: every wave's entry / first-hop / end of its instance's work (slots 16.. of the group's 128)
     if (P.stamps && lane == 0 && EG == 16) {

@@ -123,7 +123,10 @@ struct GinResArgs {
 #define GR_STATS_PART (6 * 8 * HD * 2)                            // 64-bit words: per layer, per dispatch group: (sum, sumsq) per column
 #define GR_STATS_SET GR_STATS_PART
 #ifdef GR_STAMP
-#define GR_STAMP_AT(i) do { if (tid == 0 && A.stamps) A.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// slot i: s_memrealtime (100 MHz); slot 33 + i (i <= 30): s_memtime (shader clock) at the same point — the clock the chip holds inside the
+// kernel is d(s_memtime) / d(s_memrealtime) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6; round-5 review item 2)
+#define GR_STAMP_AT(i) do { if (tid == 0 && A.stamps) { A.stamps[(size_t)blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+                                                         if ((i) <= 30) A.stamps[(size_t)blockIdx.x * 64 + 33 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define GR_STAMP_AT(i) do { } while (0)
 #endif
