@@ -129,6 +129,15 @@ class DeviceBatchEnv:
             assert w3.shape == (self.B, 3)
             capi.check(self.L.mtfjsp_reset_host(self.h, w3.ctypes.data), self.h)
 
+    def reset_episode(self, seed, episode, out=None, reset_returns=True):
+        """scaler_reset_returns() + draw_reward_weights(seed, episode) + reset(those weights) in ONE launch -> the weights [B,3] f64"""
+        if out is None:
+            out = torch.empty(self.B, 3, dtype=torch.float64, device=self.device)
+        assert out.is_cuda and out.dtype == torch.float64 and out.is_contiguous()
+        self._w3 = out
+        capi.check(self.L.mtfjsp_reset_episode(self.h, int(seed), int(episode), out.data_ptr(), 1 if reset_returns else 0), self.h)
+        return out
+
     def draw_reward_weights(self, seed, episode, out=None):
         """reward weights of one episode drawn on the device (env:1253-1259 type "01", Philox keyed by (seed, episode, b)) -> [B,3] f64"""
         if out is None:

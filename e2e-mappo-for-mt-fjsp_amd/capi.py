@@ -60,6 +60,7 @@ PROTOTYPES = {
     "mtfjsp_scaler_reset_returns_masked_host": (_I, [_VP, _VP]),
     "mtfjsp_reset": (_I, [_VP, _VP]),
     "mtfjsp_draw_reward_weights": (_I, [_VP, _U64, _U64, _VP]),
+    "mtfjsp_reset_episode": (_I, [_VP, _U64, _U64, _VP, C.c_int32]),
     "mtfjsp_reset_host": (_I, [_VP, _VP]),
     "mtfjsp_step": (_I, [_VP, _VP, _VP]),
     "mtfjsp_step_host": (_I, [_VP, _VP, _VP]),
@@ -99,6 +100,7 @@ PROTOTYPES = {
     "mtfjsp_encoder_arm_machine_heads": (_I, [_VP, _VP, _VP, _VP]),
     "mtfjsp_encoder_fused_launches": (_I, [_VP, C.POINTER(C.c_int64)]),
     "mtfjsp_encoder_arm_env_step": (_I, [_VP, _VP, C.c_int32]),
+    "mtfjsp_encoder_arm_values_only": (_I, [_VP]),
     "mtfjsp_encoder_env_step_fused": (_I, [_VP]),
     "mtfjsp_encoder_arm_selection": (_I, [_VP, C.c_int32, C.c_int32, _U64, _U64, _VP, _VP, _VP, _VP]),
     "mtfjsp_hostgen_infeasible": (_I, [_VP, C.POINTER(C.c_int32), C.c_int64, _I, _I, C.c_int64, C.c_int64, _VP]),

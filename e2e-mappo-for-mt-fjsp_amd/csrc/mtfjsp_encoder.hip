@@ -1903,6 +1903,18 @@ static size_t headsx10_lds_bytes() { return (size_t)(HCH + 3) * X2_TILE + (size_
 #define HCH 6
 #undef HX_NPART
 #define HX_NPART 32
+// The critic values alone (round 6): the post-terminal forward pair of an episode (Run.py:455-475) keeps only job_v and mach_v, so its
+// two heads launches run the pooled / other staging, phase A, c2 and the value head — the same statements, the same bits — and none of
+// the scorer (X rows, phases B and C on them, scores, softmax, selection).  mtfjsp_encoder_arm_values_only.
+#undef HX_VALUES_ONLY
+#define HX_VALUES_ONLY 1
+__global__ __launch_bounds__(512) void k_headsx_values(HeadArgs A)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+#include "mtfjsp_headsx_body.h"
+}
+#undef HX_VALUES_ONLY
+#define HX_VALUES_ONLY 0
 
 // ---------------------------------------------------------------------------------------------
 // GIN layer 0, first Linear (12 -> 128) fused with the neighbour aggregation of the raw task features
@@ -2539,6 +2551,8 @@ struct mtfjsp_encoder {
     mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
     struct FusedSample { bool armed = false; int greedy = 0; uint64_t seed = 0, counter = 0; int32_t *idx = nullptr; float *logp = nullptr;
                          const int32_t *gather_from = nullptr; int32_t *gathered = nullptr; } fs[2];   // [0] job actor, [1] machine actor
+    int values_only = 0;                    // mtfjsp_encoder_arm_values_only: the next (job, machine) forward pair produces the critic values only
+    bool vo_now = false;                    // (the forward in progress is such a forward)
     FusedSample fs1_consumed;               // the machine selection the last three-in-one launch consumed (restored when the machine forward that follows is NOT the one it ran)
     // timing
     bool timing = false;
@@ -2724,6 +2738,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_headsx_gat3x, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)(headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes()));
 #if !MTFJSP_BODY_FUNCS
+    (void)hipFuncSetAttribute((const void *)k_headsx_values, hipFuncAttributeMaxDynamicSharedMemorySize, (int)headsx_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
     if (hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -3672,6 +3687,7 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
         else hipLaunchKernelGGL(k_headsx_envstep<double>, dim3(grid), dim3(512), lds, e->stream, ha, *env_tail);
         return;
     }
+    if (e->vo_now) { hipLaunchKernelGGL(k_headsx_values, dim3(grid), dim3(512), headsx_lds_bytes(), e->stream, ha); return; }
     const int ntl = (ha.hg * ha.R + 15) / 16;                       // tiles of a full group
     if (e->heads10 && ntl > 6 && ntl <= 10) { hipLaunchKernelGGL(k_headsx10, dim3(grid), dim3(512), headsx10_lds_bytes(), e->stream, ha); return; }
     hipLaunchKernelGGL(k_headsx, dim3(grid), dim3(512), headsx_lds_bytes(), e->stream, ha);
@@ -3706,6 +3722,12 @@ extern "C" int mtfjsp_encoder_arm_machine_heads(mtfjsp_encoder_t e, float *prob,
 {
     if (!e || !prob || !h_pooled || !machine_v) return MTFJSP_ERR_ARG;
     e->mh.armed = true; e->mh.prob = prob; e->mh.h_pooled = h_pooled; e->mh.machine_v = machine_v;
+    return MTFJSP_OK;
+}
+extern "C" int mtfjsp_encoder_arm_values_only(mtfjsp_encoder_t e)
+{
+    if (!e) return MTFJSP_ERR_ARG;
+    e->values_only = 2;                                             // the next job forward and the next machine forward
     return MTFJSP_OK;
 }
 extern "C" int mtfjsp_encoder_fused_launches(mtfjsp_encoder_t e, int64_t *three_in_one_out)
@@ -3795,7 +3817,10 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
         e->prefused.valid = false; e->prefused.heads = false;
         GatArgs ga{};
         HeadArgs hm_args{};
-        const bool with_gat = ha.mf_on && ha.mf.m_fea2 && gat_fusable(e);
+        // values only (armed pair): nothing rides in this launch, no selection, no m_fea1
+        e->vo_now = e->values_only > 0 && !ha.sample_mode && !ha.mf_on && !(e->f32_products & 4) && !e->bn_mode;
+        if (e->values_only > 0) e->values_only--;
+        const bool with_gat = !e->vo_now && ha.mf_on && ha.mf.m_fea2 && gat_fusable(e);
         // the whole machine forward in this launch: armed outputs (mtfjsp_encoder_arm_machine_heads) and an armed machine selection
         const bool with_mheads = with_gat && e->mh.armed && e->fs[1].armed && mheads_fusable(e);
         e->mh.armed = false;
@@ -3829,6 +3854,7 @@ static int job_actor_forward_impl(mtfjsp_encoder_t e, const void *tasks_fea, con
                               EP.B == B && EP.M == e->cfg.n_machine && EP.T <= 64 && EP.M * EP.M <= 64 && EP.J <= 64 && fused3_lds_bytes() >= EnvGrpDynLds<1>::bytes;
         if (e->env_step.armed && with_mheads) { e->env_step.armed = false; e->env_step.done = env_tail; }
         launch_heads(e, ha, "job_actor.o_policy", "job_actor.job_critic", with_gat ? &ga : nullptr, env_tail ? &EP : nullptr, with_mheads ? &hm_args : nullptr);
+        e->vo_now = false;
 #ifdef MTFJSP_STAMP
         static int printed = 0;
         if (printed++ < 3 && getenv("MTFJSP_STAMP_PRINT")) {
@@ -3909,13 +3935,16 @@ static int machine_actor_forward_impl(mtfjsp_encoder_t e, const void *m_fea1, co
             }
         }
         arm_sampling(e, 1, ha);
+        e->vo_now = e->values_only > 0 && !ha.sample_mode && !(e->f32_products & 4) && !e->bn_mode;
+        if (e->values_only > 0) e->values_only--;
         // an armed environment step (mtfjsp_encoder_arm_env_step) rides in this launch when the selection made here is the one it
         // reads, the shapes agree and the launch is the split-product heads kernel; otherwise the caller steps the environment itself
         const EnvParams &EP = e->env_step.P;
         const bool env_tail = e->env_step.armed && e->fuse_env && !e->timing && !e->bn_mode && !(e->f32_products & 4) && ha.sample_mode &&
                               (const void *)ha.idx_out == (const void *)EP.mach_idx && EP.B == B && EP.M == M && EP.T <= 64 && EP.M * EP.M <= 64 && EP.J <= 64;
         e->env_step.armed = false; e->env_step.done = env_tail;
-        launch_heads(e, ha, "machine_actor.m_policy", "machine_actor.machine_critic", nullptr, env_tail ? &EP : nullptr);
+        launch_heads(e, ha, "machine_actor.m_policy", "machine_actor.machine_critic", nullptr, (env_tail && !e->vo_now) ? &EP : nullptr);
+        e->vo_now = false;
     }
     HIPCHK(e, hipGetLastError());
     return MTFJSP_OK;

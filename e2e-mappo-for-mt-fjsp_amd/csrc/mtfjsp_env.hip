@@ -122,6 +122,32 @@ __device__ __forceinline__ int wave_scan_incl(int x)
     return x;
 }
 
+// Philox4x32-10 (counter-based; Salmon et al. 2011)
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1)
+{
+    for (int r = 0; r < 10; r++) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// env.generate_random_weights("01") (env:1253-1259) of instance b: three uniforms in [0,1), normalised by their sum (numpy's sum of three =
+// left-to-right adds).  53-bit uniforms like python's random.random(): (a >> 5, b >> 6) -> (a*2^26 + b) / 2^53.
+__device__ __forceinline__ void draw_w3(int b, uint64_t seed, uint64_t episode, double (&w)[3])
+{
+    double u[3];
+    for (int i = 0; i < 3; i += 2) {
+        uint32_t c[4] = {(uint32_t)b, (uint32_t)episode, (uint32_t)(episode >> 32), 0x77337733u + (uint32_t)i};
+        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+        u[i] = ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) * (1.0 / 9007199254740992.0);
+        if (i + 1 < 3) u[i + 1] = ((double)(c[2] >> 5) * 67108864.0 + (double)(c[3] >> 6)) * (1.0 / 9007199254740992.0);
+    }
+    const double sum = (u[0] + u[1]) + u[2];
+    w[0] = u[0] / sum; w[1] = u[1] / sum; w[2] = u[2] / sum;
+}
+
 // =================================================================================================
 // k_env_reset — env.reset() of every instance (env:1183-1245 + load_instance env:397-714): all tasks unscheduled,
 // estimated times from the per-job prefix sums of min_dur, full observation written once (the step kernels then
@@ -139,7 +165,13 @@ __global__ __launch_bounds__(WAVE) void k_env_reset(EnvParams P)
     OBS *s_stage = reinterpret_cast<OBS *>(s_fte + T);          // min(T,64) rows x 12
     const size_t bT = (size_t)b * T;
     for (int v = lane; v < T; v += WAVE) { const double2 c = P.cst[bT + v]; s_mind[v] = c.x; s_pte[v] = c.y; }
-    const double w30 = P.w3[b * 3], w31 = P.w3[b * 3 + 1], w32 = P.w3[b * 3 + 2];
+    double w30, w31, w32;
+    if (P.draw) {                                               // (every lane of the instance's wave: the same three numbers)
+        double w[3];
+        draw_w3(b, P.draw_seed, P.draw_episode, w);
+        w30 = w[0]; w31 = w[1]; w32 = w[2];
+        if (lane < 3 && P.w3_out) P.w3_out[(size_t)b * 3 + lane] = lane == 0 ? w30 : lane == 1 ? w31 : w32;
+    } else { w30 = P.w3[b * 3]; w31 = P.w3[b * 3 + 1]; w32 = P.w3[b * 3 + 2]; }
     WSYNC();
     double mkmax = -INFINITY;
     for (int c0 = 0; c0 < T; c0 += WAVE) {
@@ -189,7 +221,7 @@ __global__ __launch_bounds__(WAVE) void k_env_reset(EnvParams P)
     }
     if (lane < SCAL_N) {
         double x = 0.0;
-        if (lane >= S_R && lane <= S_N) x = P.scal[(size_t)b * SCAL_N + lane];   // the scaler survives resets (pe:70-85)
+        if (lane >= S_R && lane <= S_N && !(P.reset_returns && lane < S_R + 4)) x = P.scal[(size_t)b * SCAL_N + lane];   // the scaler survives resets (pe:70-85); its returns R are zeroed per episode (pt:123) when asked
         else if (lane == S_MK_PREV) x = mk;
         else if (lane == S_E1_PREV) x = e1;
         else if (lane == S_W3) x = w30;
@@ -1489,17 +1521,6 @@ __global__ void k_valid_mask(int B, int T, int M, const TaskPL *pl, uint8_t *out
     out[i] = ok;
 }
 
-// Philox4x32-10 (counter-based; Salmon et al. 2011)
-__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1)
-{
-    for (int r = 0; r < 10; r++) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-}
 // uniform random valid action per instance: thread = instance
 __global__ void k_random_actions(int B, int J, int M, int T, const double *t, const int *cand, const uint8_t *jmask,
                                  uint64_t seed, uint64_t counter, int *task_idx, int *mach_idx, int *job_idx)
@@ -1536,15 +1557,9 @@ __global__ void k_draw_w3(int B, uint64_t seed, uint64_t episode, double *w3)
 {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
-    double u[3];
-    for (int i = 0; i < 3; i += 2) {
-        uint32_t c[4] = {(uint32_t)b, (uint32_t)episode, (uint32_t)(episode >> 32), 0x77337733u + (uint32_t)i};
-        philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-        u[i] = ((double)(c[0] >> 5) * 67108864.0 + (double)(c[1] >> 6)) * (1.0 / 9007199254740992.0);
-        if (i + 1 < 3) u[i + 1] = ((double)(c[2] >> 5) * 67108864.0 + (double)(c[3] >> 6)) * (1.0 / 9007199254740992.0);
-    }
-    const double sum = (u[0] + u[1]) + u[2];
-    w3[(size_t)b * 3 + 0] = u[0] / sum; w3[(size_t)b * 3 + 1] = u[1] / sum; w3[(size_t)b * 3 + 2] = u[2] / sum;
+    double w[3];
+    draw_w3(b, seed, episode, w);
+    w3[(size_t)b * 3 + 0] = w[0]; w3[(size_t)b * 3 + 1] = w[1]; w3[(size_t)b * 3 + 2] = w[2];
 }
 
 // GAE reverse scan (ppo:444-457 / 500-510): thread = instance, coalesced over b at every step.  The recurrence is serial in s but its
@@ -1994,6 +2009,23 @@ extern "C" int mtfjsp_reset(mtfjsp_handle_t h, const double *w3)
     HIPCHK(h, hipSetDevice(h->cfg.device_id));
     EnvParams P = make_params(h);
     P.w3 = w3;
+    const size_t lds = env_reset_lds_bytes(P.T, P.obs_f32);
+    if (P.obs_f32) hipLaunchKernelGGL((k_env_reset<float>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
+    else hipLaunchKernelGGL((k_env_reset<double>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
+    HIPCHK(h, hipGetLastError());
+    h->was_reset = true;
+    return MTFJSP_OK;
+}
+// reset of an EPISODE in one launch: scaler_reset_returns + draw_reward_weights + reset (run:283-284, env:1253-1259, pe:87) — what the
+// accelerated rollout issued as three launches per episode
+extern "C" int mtfjsp_reset_episode(mtfjsp_handle_t h, uint64_t seed, uint64_t episode, double *w3_out, int32_t reset_returns)
+{
+    if (!h || !w3_out) return MTFJSP_ERR_ARG;
+    int rc = check_ready(h, false);
+    if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->cfg.device_id));
+    EnvParams P = make_params(h);
+    P.w3 = nullptr; P.draw = 1; P.draw_seed = seed; P.draw_episode = episode; P.w3_out = w3_out; P.reset_returns = reset_returns ? 1 : 0;
     const size_t lds = env_reset_lds_bytes(P.T, P.obs_f32);
     if (P.obs_f32) hipLaunchKernelGGL((k_env_reset<float>), dim3(P.B), dim3(WAVE), lds, h->stream, P);
     else hipLaunchKernelGGL((k_env_reset<double>), dim3(P.B), dim3(WAVE), lds, h->stream, P);

@@ -51,6 +51,12 @@ struct EnvParams {
     // inputs
     const int *task_idx, *mach_idx;    // [B]
     const double *w3;                  // [B,3] (reset)
+    // reset of an EPISODE in one launch (mtfjsp_reset_episode): draw = 1: the reward weights are drawn here (k_draw_w3's Philox stream for
+    // (draw_seed, draw_episode, instance): same bits) and written to w3_out; reset_returns = 1: the discounted returns R of the reward
+    // scaler are zeroed as well (pt:123, run:283-284)
+    int draw, reset_returns;
+    unsigned long long draw_seed, draw_episode;
+    double *w3_out;
     // outputs
     mtfjsp_obs_t obs;
     unsigned long long *stamps;        // diagnostic build only

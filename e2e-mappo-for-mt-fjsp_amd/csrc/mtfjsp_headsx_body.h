@@ -1,5 +1,8 @@
 // mtfjsp_headsx_body.h — the statements of k_headsx (csrc/mtfjsp_encoder.hip), included inside a kernel with `A` (HeadArgs) and `smem`
 // in scope: k_headsx and k_headsx_gat3x (see mtfjsp_gat3x_body.h for why this is textual).
+#ifndef HX_VALUES_ONLY
+#define HX_VALUES_ONLY 0                   // 1 (k_headsx_values): the critic values only — no scorer rows, no probabilities, no selection (the post-terminal forward pair keeps nothing else: Run.py:455-475)
+#endif
     unsigned char *s_xs = smem;                                    // HCH tiles of 2 planes: X rows, then s1
     unsigned char *s_pp = s_xs + HCH * X2_TILE;                    // pooled planes
     unsigned char *s_op = s_pp + X2_TILE;                          // other planes
@@ -102,7 +105,8 @@
         WCOLX(wC, A.Wc0x, 0);
         // (the X rows behind the weights: phase A needs the weights first and covers the rows' arrival)
         float4 xr[HCH];                                             // X rows of the first chunk: requested now, committed after phase A
-        {   // (rows beyond the group's are clamped to its last one here and zeroed by xnorm() where they are used)
+        if (HX_VALUES_ONLY) { for (int t = 0; t < HCH; t++) xr[t] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        else {   // (rows beyond the group's are clamped to its last one here and zeroed by xnorm() where they are used)
             int gi[HCH];
 #pragma unroll
             for (int t = 0; t < HCH; t++) {
@@ -303,6 +307,35 @@
         }
         s_pm[tid] = (int)r_lk;
         STAMP(1); H3_RT(1);
+#if HX_VALUES_ONLY
+        {   // c2 = tanh(Wc1 c1 + bc1), then the value head: the statements of the full kernel's first chunk (phase B's second half, the
+            // head behind phase C), nothing of the scorer
+            LDS_BARRIER();                                          // c1 planes are complete
+            const f32x4 a0 = tile_x6(s_c1p, wA);
+            const float4 bc1v = *reinterpret_cast<const float4 *>(s_vec + 2 * HD + col4);
+            *reinterpret_cast<float4 *>(s_c2 + m * HX_CLDA + col4) =
+                make_float4(fast_tanh(fmaf(a0[0], sWc1, bc1v.x)), fast_tanh(fmaf(a0[1], sWc1, bc1v.y)), fast_tanh(fmaf(a0[2], sWc1, bc1v.z)), fast_tanh(fmaf(a0[3], sWc1, bc1v.w)));
+            LDS_BARRIER();                                          // c2 is complete
+            if (tid < 256) {
+                const int r = tid >> 4, part = tid & 15;
+                float p0 = 0.f, p1 = 0.f;
+                const float4 xa_ = *reinterpret_cast<const float4 *>(s_c2 + r * HX_CLDA + part * 8), xb_ = *reinterpret_cast<const float4 *>(s_c2 + r * HX_CLDA + part * 8 + 4);
+                const float4 wa0 = *reinterpret_cast<const float4 *>(s_wc2 + part * 8), wb0 = *reinterpret_cast<const float4 *>(s_wc2 + part * 8 + 4);
+                const float4 wa1 = *reinterpret_cast<const float4 *>(s_wc2 + HD + part * 8), wb1 = *reinterpret_cast<const float4 *>(s_wc2 + HD + part * 8 + 4);
+                const float xs[8] = {xa_.x, xa_.y, xa_.z, xa_.w, xb_.x, xb_.y, xb_.z, xb_.w};
+                const float w0s[8] = {wa0.x, wa0.y, wa0.z, wa0.w, wb0.x, wb0.y, wb0.z, wb0.w}, w1s[8] = {wa1.x, wa1.y, wa1.z, wa1.w, wb1.x, wb1.y, wb1.z, wb1.w};
+#pragma unroll
+                for (int k = 0; k < 8; k++) { p0 = fmaf(xs[k], w0s[k], p0); p1 = fmaf(xs[k], w1s[k], p1); }
+                p0 = row_sum16(p0); p1 = row_sum16(p1);
+                if (part == 0 && r < ng) {
+                    const float v0 = p0 + A.bc2[0], v1 = p1 + A.bc2[1];
+                    A.value[(size_t)(g0 + r) * 2] = v0; A.value[(size_t)(g0 + r) * 2 + 1] = v1;
+                    if (A.range_flag && (v0 != v0 || v1 != v1)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+            (void)xnorm; (void)b2; (void)invR; (void)xoff;
+        }
+#else
         const int ntl = (nrows + 15) >> 4;                          // 16-row tiles of this group (R for a full group of 16 instances)
         for (int tb = 0; tb < ntl; tb += HCH) {
             const int nt = (ntl - tb) < HCH ? (ntl - tb) : HCH;
@@ -556,6 +589,7 @@
                 }
             }
         }
+#endif                                                              // !HX_VALUES_ONLY
         STAMP(5); H3_RT(5);
     }
 #ifdef MTFJSP_STAMP

@@ -245,6 +245,10 @@ class Encoder:
         environment step in its heads launch; env_step_fused() tells afterwards whether it did"""
         capi.check(self.L.mtfjsp_encoder_arm_env_step(self.h, params, len(params)), self.h, enc=True)
 
+    def arm_values_only(self):
+        """the next job forward and the next machine forward produce the critic values (and pooled embeddings) only: no scorer, prob untouched"""
+        capi.check(self.L.mtfjsp_encoder_arm_values_only(self.h), self.h, enc=True)
+
     def env_step_fused(self):
         return bool(self.L.mtfjsp_encoder_env_step_fused(self.h))
 
@@ -279,6 +283,7 @@ class ActorPair:
         self.fuse_env = bool(os.environ.get("MTFJSP_FUSED_ENV")) # (the library reads the same switch when the handle is created; off by default: DESIGN.md §9)
         self.fused = not os.environ.get("MTFJSP_NO_FUSED_SELECT")   # action selection inside the heads kernels (same stream either way)
         self.fuse_mheads = not os.environ.get("MTFJSP_NO_FUSED_MHEADS")   # the machine forward inside the job heads' launch where the library allows it
+        self.values_only_terminal = not os.environ.get("MTFJSP_NO_VALUES_ONLY")   # the post-terminal forward pair without its scorers
         self.fuse_env3 = bool(os.environ.get("MTFJSP_FUSED_ENV3"))        # ... and the environment step as that launch's tail (two launches per step; off by default: measured slower)
         dev = self.enc.device
         self.job_logp = torch.zeros(batch, dtype=torch.float32, device=dev)
@@ -373,6 +378,8 @@ class ActorPair:
         (replaybuffer.py:131-139), which every advantage of the episode depends on (ppo:473,523 have no (1-done) factor)."""
         e = self.enc
         hm = e.h_pooled_m if self.have_hm else None
+        if self.values_only_terminal:
+            e.arm_values_only()                                  # (round 6) the pair keeps nothing but the two values: no scorer in its heads launches
         _, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, prev_job_mask, hm, v_out=jv_out)
         mf1 = self.last_mfea1 if self.last_mfea1 is not None else env.m_fea1
         mmk = self.last_mmask if self.last_mmask is not None else env.mmask

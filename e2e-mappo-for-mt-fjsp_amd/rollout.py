@@ -229,9 +229,14 @@ class Rollout:
         the sampled ones (teacher forcing for the parity tests; the forwards and everything recorded are unchanged)."""
         env = self.env
         if self.t_in_ep == 0:
-            w3 = self._episode_w3()
-            env.scaler_reset_returns()                                     # run:283-284
-            env.reset(w3)                                                  # pe:87 / run:229
+            if self.w3_mode == "device" and hasattr(env, "reset_episode") and not os.environ.get("MTFJSP_NO_RESET_EPISODE"):
+                # one launch: RewardScaling.reset() of every instance (run:283-284), the episode's reward weights (env:1253-1259), reset (pe:87)
+                n = self.w3_pool.shape[0]
+                w3 = env.reset_episode(self.seed, self.episode, out=self.w3_pool[self.episode % n])
+            else:
+                w3 = self._episode_w3()
+                env.scaler_reset_returns()                                 # run:283-284
+                env.reset(w3)                                              # pe:87 / run:229
             if self.actor is not None:
                 self.actor.begin_episode()
             if self.full and not self.tainted:             # (a tainted buffer records nothing: its slots are not episode-aligned any more)

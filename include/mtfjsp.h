@@ -144,6 +144,11 @@ int mtfjsp_reset(mtfjsp_handle_t h, const double *w3);
  * uniforms normalised by their sum, Philox stream keyed by (seed, episode, instance) — distributional parity, for rollouts
  * that must not wait for the host; parity runs draw the weights with python `random` and pass them to mtfjsp_reset. */
 int mtfjsp_draw_reward_weights(mtfjsp_handle_t h, uint64_t seed, uint64_t episode, double *w3_out);
+/* One episode's start in ONE launch (the accelerated rollout issued three per episode): mtfjsp_draw_reward_weights(seed, episode) into
+ * w3_out [B,3] (kept: the trajectory record and the next episode's observations carry the weights), mtfjsp_reset with them, and — with
+ * reset_returns != 0 — mtfjsp_scaler_reset_returns (run:283-284: RewardScaling.reset() of every instance, pt:123).  Bit-identical to
+ * the three calls. */
+int mtfjsp_reset_episode(mtfjsp_handle_t h, uint64_t seed, uint64_t episode, double *w3_out, int32_t reset_returns);
 int mtfjsp_reset_host(mtfjsp_handle_t h, const double *w3_host);
 
 /* = DGFJSPEnv_paral_step (pe:217-268): env.step (env:716-974) + RewardScaling (pe:255-260), fused with
@@ -308,6 +313,12 @@ int mtfjsp_get_mfea1_context(mtfjsp_handle_t h, void *m_fea1_out, uint8_t *mmask
  * mtfjsp_encoder_fused_launches: how many forwards took the three-in-one launch so far (tests, bench). */
 int mtfjsp_encoder_arm_machine_heads(mtfjsp_encoder_t e, float *prob, float *h_pooled, float *machine_v);
 int mtfjsp_encoder_fused_launches(mtfjsp_encoder_t e, int64_t *three_in_one_out);
+/* The post-terminal forward pair of an episode (Run.py:455-475: job actor on the terminal observation, machine actor on the last
+ * decision's m_fea1) keeps only the two local critics' values (replaybuffer.py:131-139).  Armed with this call, the NEXT
+ * mtfjsp_job_actor_forward and the NEXT mtfjsp_machine_actor_forward write job_v / machine_v and the pooled embeddings as always —
+ * bit-identical — and skip the scorer: prob (and any selection output) is left untouched.  One-shot; ignored (full forward) for a
+ * forward with an armed selection / m_fea1 context, with per-instance BatchNorm or with the f32-instruction heads. */
+int mtfjsp_encoder_arm_values_only(mtfjsp_encoder_t e);
 /* BatchNorm statistics of the two actor forwards (every BatchNorm in the reference is in training mode):
  * per_instance = 0 (default): over all rows of the device batch = one reference run with env_batch = B (training rollout);
  * per_instance = 1: over the rows of ONE instance = B independent reference runs with env_batch = 1, i.e. the greedy

@@ -110,3 +110,37 @@ def test_device_reward_weights_follow_the_reference_distribution():
         np.testing.assert_allclose(d.mean(0), ref.mean(0), atol=0.01)
         np.testing.assert_allclose(d.std(0), ref.std(0), atol=0.01)
         np.testing.assert_allclose(np.quantile(d, [0.1, 0.5, 0.9], axis=0), np.quantile(ref, [0.1, 0.5, 0.9], axis=0), atol=0.015)
+
+
+@pytest.mark.parametrize("obs", ["f32", "f64"])
+def test_one_launch_episode_reset_equals_the_three_calls(obs):
+    """mtfjsp_reset_episode (round 6: one launch per episode) against scaler_reset_returns + draw_reward_weights + reset: the drawn
+    weights, every observation, the scaler state and the first steps of the next episode, bit for bit — in the middle of a run, so
+    that the scaler carries statistics across the reset (pe:70-85) and only its returns R are zeroed (pt:123)."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    batch_env = import_module("e2e-mappo-for-mt-fjsp_amd.batch_env")
+    capi = import_module("e2e-mappo-for-mt-fjsp_amd.capi")
+    J, M, E, B = 6, 6, 2, 257
+    T = J * M
+    envs = []
+    for k in range(2):
+        env = batch_env.DeviceBatchEnv(J, M, E, B, obs_dtype=obs)
+        env.generate_instances(seed=5)
+        env.scaler_init()
+        envs.append(env)
+    a = torch.zeros(B, dtype=torch.int32, device=envs[0].device); m = torch.zeros_like(a)
+    for ep in range(3):
+        w_sep = envs[0].draw_reward_weights(21, ep)
+        envs[0].scaler_reset_returns()
+        envs[0].reset(w_sep)
+        w_one = envs[1].reset_episode(21, ep)
+        assert torch.equal(w_sep, w_one)
+        for s in range(T if ep < 2 else 7):
+            for k, env in enumerate(envs):
+                env.random_actions(9, ep * T + s, a, m)
+                env.step(a, m)
+            for name in ("tasks_fea", "ell_col", "ell_val", "m_fea2", "info", "raw", "candidate", "job_mask", "status"):
+                assert torch.equal(getattr(envs[0], name), getattr(envs[1], name)), (ep, s, name)
+        assert np.array_equal(envs[0].read_state(capi.STATE_SCALER), envs[1].read_state(capi.STATE_SCALER), equal_nan=True)
+        assert np.array_equal(envs[0].read_state(capi.STATE_W3), envs[1].read_state(capi.STATE_W3))

@@ -170,3 +170,42 @@ def test_three_launches_per_step_and_switch_off(monkeypatch):
     torch.cuda.synchronize()
     assert ro2.actor.enc.fused_launches() == 0
     ro2.check_finished_cleanly()
+
+
+@pytest.mark.parametrize("shape,nb", [((6, 6), 4096), ((6, 6), 1000), ((10, 10), 512)])
+def test_values_only_forward_pair_gives_the_full_pairs_values_bit_for_bit(shape, nb, monkeypatch):
+    """mtfjsp_encoder_arm_values_only (round 6: the post-terminal forward pair of Run.py:455-475 keeps only the two critics' values):
+    the values and the pooled embeddings of the armed pair are the full pair's, bit for bit; prob is left untouched; one-shot."""
+    import mtfjsp_amd  # noqa: F401
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    j, m = shape
+    ja, ma = enc_mod.random_init_weights(seed=31)
+    ro = rollout.Rollout(j, m, 2, nb, policy="actor", obs_dtype="f32", weights=(ja, ma), collect=False, seed=3)
+    for _ in range(j * m // 2 + 3):
+        ro.step()
+    env, act, e = ro.env, ro.actor, ro.actor.enc
+    torch.cuda.synchronize()
+    hm0 = e.h_pooled_m.clone()
+    mask = env.job_mask.clone()
+
+    def pair(armed):
+        e.h_pooled_m.copy_(hm0)
+        e.job_prob.fill_(-7.0); e.mch_prob.fill_(-7.0)
+        jv = torch.zeros(nb, 2, device="cuda"); mv = torch.zeros(nb, 2, device="cuda")
+        if armed:
+            e.arm_values_only()
+        _, h_o, _ = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, mask, e.h_pooled_m, v_out=jv)
+        e.machine_actor_forward(act.last_mfea1, env.m_fea2, h_o, act.last_mmask, v_out=mv)
+        torch.cuda.synchronize()
+        return jv.clone(), mv.clone(), h_o.clone(), e.h_pooled_m.clone(), e.job_prob.clone(), e.mch_prob.clone()
+
+    full = pair(False)
+    only = pair(True)
+    again = pair(False)                                            # one-shot: the next pair is a full one again
+    for k in range(4):
+        assert torch.equal(full[k], only[k]), k
+        assert torch.equal(full[k], again[k]), k
+    assert bool((only[4] == -7.0).all()) and bool((only[5] == -7.0).all())          # the scorer did not run
+    assert torch.equal(full[4], again[4]) and torch.equal(full[5], again[5]) and bool((full[4] >= 0).all())
+    e.check()                                                      # (raises on an asynchronous failure; its value only says which GIN kernel is in use)
