@@ -1775,7 +1775,9 @@ __device__ __forceinline__ void gat_prestage(const GatArgs &G, unsigned char *sm
 // rollout step.  Round 3's k_headsx_envstep lost to the separate launch because the tail's first loads were cold (the state was last
 // touched a rollout step ago); here one word of every line of the workgroup's state records is requested in front of the machine
 // heads' part, 13 us ahead of the tail, and waits in this XCD's L2.
-template <int ENV>
+// NLDS (round 6): the GAT part's node rows stay in LDS for the machine part (M <= 6: at most 12 tiles, each wave's tiles in buffers of their
+// own, and the machine part stages its rows by instance) — 12.6 MB per launch less written and 12.6 MB less read back.
+template <int ENV, bool NLDS>
 __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArgs GA, HeadArgs HM, XchgArgs XG, EnvParams EP)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1817,7 +1819,11 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
 #define GAT_XCHG 1
 #undef GAT_PRESTAGED
 #define GAT_PRESTAGED 1
+#undef GAT_NLDS
+#define GAT_NLDS NLDS
 #include "mtfjsp_gat3x_body.h"
+#undef GAT_NLDS
+#define GAT_NLDS false
 #undef GAT_PRESTAGED
 #define GAT_PRESTAGED 0
 #undef GAT_XCHG
@@ -1848,7 +1854,11 @@ __global__ __launch_bounds__(512) void k_headsx_gat3x_headsx(HeadArgs HA, GatArg
         const HeadArgs &A = HM;
 #undef HX_XCHG
 #define HX_XCHG 1
+#undef HX_NLDS
+#define HX_NLDS NLDS
 #include "mtfjsp_headsx_body.h"
+#undef HX_NLDS
+#define HX_NLDS false
 #undef HX_XCHG
 #define HX_XCHG 0
     }
@@ -2536,6 +2546,7 @@ struct mtfjsp_encoder {
     // profiles/r06_ab_env3.txt): the launch's 8 waves take the 16 instances in two rounds behind one another, which costs about 3 us
     // more than the launch boundary and the separate kernel's dispatch ramp together, warm state lines or not.
     bool fuse_env3 = getenv("MTFJSP_FUSED_ENV3") != nullptr;
+    bool nodes_lds = !getenv("MTFJSP_FUSED3_NODES_HBM");         // three-in-one launch: the GAT part's node rows stay in LDS for the machine part (round 6)
     bool warm_heads = !getenv("MTFJSP_NO_WARM_HEADS");          // k_gin_res requests the heads launch's weight lines in its last phase
     struct { bool armed = false, done = false; EnvParams P; } env_step;          // groups of 8 instances in k_headsx when groups of 16 fill at most half the CUs
     // streaming GIN launches: the two inner Linears of an MLP in one launch behind a statistics-only pass (mtfjsp_gemm_pair.h).
@@ -2739,9 +2750,12 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
                               (int)(headsx_lds_bytes() > gat3x_lds_bytes() ? headsx_lds_bytes() : gat3x_lds_bytes()));
 #if !MTFJSP_BODY_FUNCS
     (void)hipFuncSetAttribute((const void *)k_headsx_values, hipFuncAttributeMaxDynamicSharedMemorySize, (int)headsx_lds_bytes());
-    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
-    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
-    if (hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fused3_lds_bytes());
+    if (hipFuncSetAttribute((const void *)k_headsx_gat3x_headsx<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)fused3_lds_bytes()) != hipSuccess) e->fuse_mheads = false;
 #else
     e->fuse_mheads = false;
@@ -3595,9 +3609,16 @@ static void launch_heads(mtfjsp_encoder *e, HeadArgs &ha, const std::string &pol
             if (!d_st3) { (void)hipMalloc((void **)&d_st3, (size_t)2048 * 64 * 8); (void)hipMemset(d_st3, 0, (size_t)2048 * 64 * 8); }
             xg.stamps = d_st3;
 #endif
-            if (env_tail && env_tail->obs_f32) hipLaunchKernelGGL(k_headsx_gat3x_headsx<1>, dim3(grid), dim3(512), fused3_lds_bytes(), e->stream, ha, *fused_gat, *fused_mheads, xg, *env_tail);
-            else if (env_tail) hipLaunchKernelGGL(k_headsx_gat3x_headsx<2>, dim3(grid), dim3(512), fused3_lds_bytes(), e->stream, ha, *fused_gat, *fused_mheads, xg, *env_tail);
-            else hipLaunchKernelGGL(k_headsx_gat3x_headsx<0>, dim3(grid), dim3(512), fused3_lds_bytes(), e->stream, ha, *fused_gat, *fused_mheads, xg, EnvParams{});
+            // the node rows stay in LDS where every tile has a buffer of its own (<= 12 tiles per workgroup: M <= 6) and the machine part stages
+            // its rows by instance (R <= HCH); MTFJSP_FUSED3_NODES_HBM=1: the round-5 form (rows written to e->node and read back)
+            const int gtiles = (2 * ha.B * fused_mheads->R + 15) / 16, gper = (gtiles + grid - 1) / grid;
+            const bool nlds = e->nodes_lds && gper <= 12 && fused_mheads->R <= HCH && (fused3_lds_bytes() >= (size_t)(8 * 2 * 4 * 64 * 16 + gper * 16 * HD * 4));
+            const EnvParams ep0 = env_tail ? *env_tail : EnvParams{};
+            const int envm = !env_tail ? 0 : env_tail->obs_f32 ? 1 : 2;
+#define L3(EV, NL) hipLaunchKernelGGL((k_headsx_gat3x_headsx<EV, NL>), dim3(grid), dim3(512), fused3_lds_bytes(), e->stream, ha, *fused_gat, *fused_mheads, xg, ep0)
+            if (nlds) { if (envm == 0) L3(0, true); else if (envm == 1) L3(1, true); else L3(2, true); }
+            else { if (envm == 0) L3(0, false); else if (envm == 1) L3(1, false); else L3(2, false); }
+#undef L3
 #ifdef MTFJSP_STAMP3
             if (e->fused3_launches % 50 == 20 && getenv("MTFJSP_STAMP_PRINT")) {
                 (void)hipStreamSynchronize(e->stream);

@@ -6,6 +6,9 @@
 #ifndef GAT_ABL
 #define GAT_ABL 0                                                 // diagnostic timing ablations (wrong results): 1 the weight fragments are read from LDS once per pass, 2 no ELU
 #endif                                                            // exponentials, 4 no activation writes to LDS, 8 no split matrix products, 16 no row reductions
+#ifndef GAT_NLDS
+#define GAT_NLDS false                                            // k_headsx_gat3x_headsx<., true>: the node rows stay in LDS for the machine heads of this launch (round 6)
+#endif
     unsigned char *s_wf = smem;                                   // 8*2*4*64*16 B
     float *s_a = reinterpret_cast<float *>(smem + 8 * 2 * 4 * 64 * 16);   // 8 waves * 16 * 128, swizzled
     const int tid = BODY_TID, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -161,7 +164,10 @@
             }
         } else {
             const bool valid = row0 + r < N;
-            float *nd = A.node + (size_t)((row0 + r) >> 1) * HD + m;
+            // GAT_NLDS (round 6): the machine heads that follow in this launch are the ONLY reader of this workgroup's node rows, and
+            // workgroup g owns the same 16 instances in both parts — the rows go into the FIRST half of the tile's own buffer (dead once
+            // its last products have read it; 8 node rows x 128 f32 = 4 KB) instead of 12.6 MB per launch to memory and back.
+            float *nd = GAT_NLDS ? my_a + (size_t)(r >> 1) * HD + m : A.node + (size_t)((row0 + r) >> 1) * HD + m;
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const float z1 = acc[c][i + 1];
@@ -400,13 +406,14 @@
     // (round 5: every lane parks its 16 f32 partial sums in its wave's own tile buffer — free once the wave's last tile is done, so nothing
     // waits for the other waves first — and thread t < 256 adds up the 4 row quarters x 8 waves of its value in f64, in a fixed order; it
     // was 64 ds_bpermute round trips of f64 halves per wave between two workgroup barriers: 2.1 us from the last tile to the atomics)
-    for (int c = 0; c < 8; c++) { my_a[c * 64 + lane] = st_sum[c]; my_a[(8 + c) * 64 + lane] = st_sq[c]; }
-    __syncthreads();                                              // (also: this workgroup's node rows are in memory before its machine heads read them)
+    constexpr int fold_off = GAT_NLDS ? 8 * HD : 0;              // (GAT_NLDS: the first half of the wave's buffer holds its first tile's node rows)
+    for (int c = 0; c < 8; c++) { my_a[fold_off + c * 64 + lane] = st_sum[c]; my_a[fold_off + (8 + c) * 64 + lane] = st_sq[c]; }
+    __syncthreads();                                              // (also: this workgroup's node rows are in memory / in LDS before its machine heads read them)
     G3_RT(7);
     if (tid < 256) {
         double v = 0;
         {
-            const float *wf = s_a + ((tid >> 7) * 8 + ((tid & 127) >> 4)) * 64 + (tid & 15);
+            const float *wf = s_a + fold_off + ((tid >> 7) * 8 + ((tid & 127) >> 4)) * 64 + (tid & 15);
             for (int w = 0; w < 8; w++)
                 for (int qq = 0; qq < 4; qq++) v += (double)wf[w * 16 * HD + qq * 16];
         }

@@ -1,5 +1,8 @@
 // mtfjsp_headsx_body.h — the statements of k_headsx (csrc/mtfjsp_encoder.hip), included inside a kernel with `A` (HeadArgs) and `smem`
 // in scope: k_headsx and k_headsx_gat3x (see mtfjsp_gat3x_body.h for why this is textual).
+#ifndef HX_NLDS
+#define HX_NLDS false                      // k_headsx_gat3x_headsx<., true>, machine part: X (the node rows) is in LDS, left there by the GAT part of this launch
+#endif
 #ifndef HX_VALUES_ONLY
 #define HX_VALUES_ONLY 0                   // 1 (k_headsx_values): the critic values only — no scorer rows, no probabilities, no selection (the post-terminal forward pair keeps nothing else: Run.py:455-475)
 #endif
@@ -117,6 +120,10 @@
             for (int t = 0; t < HCH; t++) {
                 const int grow = by_inst ? sr * R + t : t * 16 + sr, gc = (grow < nrows && (!by_inst || t < R)) ? grow : nrows - 1;
                 const int il = (int)__umulhi((unsigned)gc, invR);
+                if (HX_NLDS) {                                      // node row gc of the workgroup = row gc & 7 of GAT tile gc >> 3: the first half of that tile's buffer (mtfjsp_gat3x_body.h)
+                    xr[t] = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(smem + 8 * 2 * 4 * 64 * 16) + ((gc >> 3) * 16 + (gc & 7)) * HD + sc4);
+                    continue;
+                }
                 const float *src = A.xgather ? A.X + ((size_t)(g0 + il) * A.xT + gi[t]) * HD + sc4 : A.X + ((size_t)g0 * R + gc) * HD + sc4;
                 xr[t] = *reinterpret_cast<const float4 *>(src);
             }
@@ -126,9 +133,12 @@
 #endif
         // (everything is in flight) the uniform number of this thread's instance's draw (pick_action): ten Philox rounds that need no memory
         const float u_pre = A.sample_mode == 1 ? pick_uniform(g0 + (tid >> 4), A.seed, A.counter) : 0.f;
-        // now the stores that only needed the first few words
-        if (tid < 2 * HD) s_wc2[tid] = r_wc2;
-        if (tid < HD) { s_vec[tid] = r_v0; s_vec[HD + tid] = r_v1; s_vec[2 * HD + tid] = r_v2; s_vec[3 * HD + tid] = r_v3; s_vec[4 * HD + tid] = r_v4; }
+        // now the stores that only needed the first few words (HX_NLDS: behind the first barrier — they lie where GAT tile 6 left node rows
+        // that other waves may not have read yet)
+        if (!HX_NLDS) {
+            if (tid < 2 * HD) s_wc2[tid] = r_wc2;
+            if (tid < HD) { s_vec[tid] = r_v0; s_vec[HD + tid] = r_v1; s_vec[2 * HD + tid] = r_v2; s_vec[3 * HD + tid] = r_v3; s_vec[4 * HD + tid] = r_v4; }
+        }
         if (A.zero_stats && blockIdx.x == 0) for (int i = tid; i < A.zero_count; i += 512) A.zero_stats[i] = 0.0;
         if (A.zero_stats2 && blockIdx.x == 0) for (int i = tid; i < A.zero_count2; i += 512) A.zero_stats2[i] = 0.0;
         if (A.xbn_stats) {
@@ -177,6 +187,10 @@
                              __builtin_ldexp((double)((long long)sc - (long long)nc * (long long)GR_FIX_BIAS), -6);
             }
             LDS_BARRIER();
+            if (HX_NLDS) {                                          // (every wave has its node rows in registers: LDS_BARRIER waits for the LDS reads first)
+                if (tid < 2 * HD) s_wc2[tid] = r_wc2;
+                if (tid < HD) { s_vec[tid] = r_v0; s_vec[HD + tid] = r_v1; s_vec[2 * HD + tid] = r_v2; s_vec[3 * HD + tid] = r_v3; s_vec[4 * HD + tid] = r_v4; }
+            }
 #endif
             if (tid < HD) {                                         // stage_bn() from the registers requested above; s_u is free until phase A
                 double su = 0, sq = 0;

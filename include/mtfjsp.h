@@ -400,7 +400,9 @@ int mtfjsp_encoder_check(mtfjsp_encoder_t e, int32_t *gin_resident_out);
  * *product_mode_out (may be NULL) = the product mode now in force. */
 int mtfjsp_encoder_range_fallbacks(mtfjsp_encoder_t e, int64_t *count_out, int32_t *product_mode_out);
 /* diagnostic (tools/first_launch): the first `count` floats of the machine path's node buffer [B*M,128] — the output of the three
- * GAT passes of ac:409-420 before the BatchNorm of ac:434 — copied to host memory after synchronising the stream */
+ * GAT passes of ac:409-420 before the BatchNorm of ac:434 — copied to host memory after synchronising the stream.  The buffer is
+ * written by the separate GAT launches (k_gat3x, k_headsx_gat3x) and by the global critic; the three-in-one launch keeps its node
+ * rows in LDS (round 6) and leaves the buffer alone unless MTFJSP_FUSED3_NODES_HBM=1. */
 int mtfjsp_encoder_peek_nodes_host(mtfjsp_encoder_t e, float *out_host, int64_t count);
 /* number of statistics-exchange time-outs of the single-launch kernels reported on this handle so far */
 int mtfjsp_encoder_resident_failures(mtfjsp_encoder_t e, int64_t *count_out);

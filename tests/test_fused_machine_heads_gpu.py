@@ -116,12 +116,13 @@ def test_contributions_beyond_the_fine_range_use_the_wide_words(monkeypatch, lim
     env, e = ro.env, ro.actor.enc
     assert _one_decision(ro) == 1
     fused = [x.clone() for x in (e.mch_prob, e.h_pooled_m, e.mach_v)]
+    mprob, h_m, mach_v = e.machine_actor_forward(env.m_fea1, env.m_fea2, e.h_pooled_o, env.mmask)
+    torch.cuda.synchronize()
+    # (the node rows: of the SEPARATE launches just made on the same inputs — the three-in-one launch keeps its rows in LDS since round 6)
     node = torch.as_tensor(e.peek_nodes())
     per_wg = (node.double() ** 2).reshape(B // 16, 16 * M, 128).sum(1)              # a workgroup's sum of squares per column
     frac_wide = float((per_wg >= float(limit)).double().mean())
     assert (frac_wide > 0.99) if limit == "100" else (0.2 < frac_wide < 0.8), frac_wide
-    mprob, h_m, mach_v = e.machine_actor_forward(env.m_fea1, env.m_fea2, e.h_pooled_o, env.mmask)
-    torch.cuda.synchronize()
     assert e.range_fallbacks()[0] == 0 and e.check()
     scale = max(1.0, float(h_m.abs().max()))
     assert float((fused[0] - mprob).abs().max()) <= 2e-4
