@@ -22,7 +22,6 @@ D = import_module("e2e-mappo-for-mt-fjsp_amd.dist")
 
 def run(exact, steps=720, B=4096):
     ro = rollout.Rollout(6, 6, 2, B, policy="actor", obs_dtype="f32", collect=True, seed=1)
-    n_red = [0]
     if exact:
         cb = D.bn_stats_allreduce()
         ro.actor.enc.set_stats_reduce(cb, B)
