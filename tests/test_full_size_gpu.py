@@ -157,6 +157,18 @@ def test_two_slot_register_kernel_other_shapes(monkeypatch):
         _run(J, M, E, B, 1, seed=6)
 
 
+@pytest.mark.parametrize("kernel", ["grp16", "grp4"])
+def test_one_slot_register_kernel_boundary_shapes(kernel, monkeypatch):
+    """The one-slot register kernels (T <= 64, M*M <= 64) at the edges of round 6's lane moves: T = 64 (J8M8, J16M4: every branch of the DPP /
+    v_permlane swap pairwise sum, 8 terms per accumulator, no ragged tail; M*M = 64 transport entries), T = 49 (J7M7: five terms + a tail
+    of 1), T = 45 (J9M5: tail of 5), T = 40 (J5M8: exactly five terms), T = 16 (J2M8), T = 6 (J3M2: no full block of 8), J = 1 (J1M8:
+    one job, every step appends to a fresh machine or inserts), M = 2 (J30M2: the fewest machines a handle takes, 30 jobs); every instance
+    against the oracle, 67 instances: a partly filled last group of 16 / of 4"""
+    monkeypatch.setenv("MTFJSP_ENV_KERNEL", kernel)
+    for J, M, E in ((8, 8, 2), (16, 4, 2), (7, 7, 1), (9, 5, 1), (5, 8, 2), (2, 8, 2), (3, 2, 1), (1, 8, 1), (30, 2, 1)):
+        _run(J, M, E, 67, 1, seed=11 + J)
+
+
 def test_encoder_full_batch_permutation_equivariance():
     """B=4096: permuting the instances of a batch permutes the actor outputs (training-mode BatchNorm statistics are
     permutation invariant; f64 atomics make the sums order-dependent only at 1e-16)."""
