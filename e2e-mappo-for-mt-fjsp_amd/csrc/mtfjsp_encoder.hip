@@ -34,7 +34,7 @@
 #define HD 128
 #define BN_EPS 1e-5
 
-enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2, PRO_GIN0 = 3 };
+enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2, PRO_GIN0 = 3, PRO_GIN0BN = 4 };
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2 };
 
 // All [rows,128] activation buffers the GEMM kernels read or write are INTERNAL workspaces allocated with the row count
@@ -57,6 +57,10 @@ struct GemmArgs {
     int T;                  // PRO_AGG: rows per instance
     const void *tfea;       // PRO_GIN0: raw task features [N,12] (f32 or f64), aggregated over the ELL adjacency and multiplied by the 12 -> 128 Linear
     int feat_f64;
+    const void *Wx6_0;      // PRO_GIN0BN: the 12 -> 128 first Linear's bf16 x 3-plane register image (what PRO_GIN0 takes as Wx6) and its bias: the producers form
+    const float *bias0;     // z0 = Linear0(aggregated raw features) of their tile themselves (f32 features), then BatchNorm + ReLU as PRO_BNRELU
+    const float *W0;        // PRO_GIN0BN, moments mode (non-NULL): the first Linear's weight [128,12]; pro_stats then holds k_gin0_moments' sums (MOM_* below) and the
+                            // BatchNorm statistics of z0 = W0 x + b follow from them: sum z = w.Sx + n b, sum z^2 = w'Sxx w + 2 b w.Sx + n b^2 (f64)
     double *epi_stats;      // EPI_STATS: [STAT_REP][256] accumulated with atomics (zeroed by the host per forward)
     unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
     int dbg;                // diagnostic build only: timing ablations of k_gemm16p (1 no stores/sums, 2 no row requests/transform)
@@ -67,6 +71,10 @@ struct GemmArgs {
     int rev, nt;
 };
 
+// k_gin0_moments' layout inside a [256]-double BatchNorm accumulator replica: the column sums of the aggregated raw features and their second moments
+#define MOM_SX 0            // [12]
+#define MOM_SXX 16          // [12][12] (full, symmetric)
+#define MOM_N 160
 #ifdef MTFJSP_STAMP
 #define STAMP(slot)                                                                      \
     do {                                                                                 \
@@ -597,6 +605,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     unsigned char *s_tiles = smem;                                // [2 buffers][4 tiles][NP planes][16 rows x 272 B]
     double *s_stat = reinterpret_cast<double *>(smem + 8 * X6_TILE);   // column sums | sums of squares of this workgroup
     float *s_bn = reinterpret_cast<float *>(s_stat + 2 * HD);     // scale | shift
+    float *s_b0 = reinterpret_cast<float *>(smem + 8 * X2_TILE);  // PRO_GIN0BN: the first Linear's bias (the two-plane tiles leave the rest of the tile area free)
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int ntiles = (A.N + 15) / 16;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -617,18 +626,58 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of the input first
     double bsu[STAT_REP], bsq[STAT_REP];
     float bga = 0.f, bbe = 0.f;
-    if (PRO != PRO_GIN0 && tid < HD) {
+    const bool mom = PRO == PRO_GIN0BN && A.W0 != nullptr;        // (workgroup-uniform)
+    double *s_mom = reinterpret_cast<double *>(smem + 8 * X2_TILE + HD * 4);      // PRO_GIN0BN, moments mode: [MOM_N] sums over the replicas
+    double msum = 0;
+    float w0r[12];
 #pragma unroll
-        for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.pro_stats[r * 256 + tid]; bsq[r] = A.pro_stats[r * 256 + HD + tid]; }
+    for (int k = 0; k < 12; k++) w0r[k] = 0.f;
+    if (PRO != PRO_GIN0 && tid < HD) {
+        if (!mom) {
+#pragma unroll
+            for (int r = 0; r < STAT_REP; r++) { bsu[r] = A.pro_stats[r * 256 + tid]; bsq[r] = A.pro_stats[r * 256 + HD + tid]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < STAT_REP; r++) { bsu[r] = 0; bsq[r] = 0; }
+#pragma unroll
+            for (int k4 = 0; k4 < 3; k4++) {
+                const float4 w = *reinterpret_cast<const float4 *>(A.W0 + tid * 12 + 4 * k4);
+                w0r[4 * k4] = w.x; w0r[4 * k4 + 1] = w.y; w0r[4 * k4 + 2] = w.z; w0r[4 * k4 + 3] = w.w;
+            }
+        }
         bga = A.pro_gamma[tid]; bbe = A.pro_beta[tid];
     }
-    auto stage_scale_shift = [&]() __attribute__((always_inline)) {   // stage_bn() from the registers requested above
+    if (mom && tid < MOM_N) {                                      // (threads of the consumer waves: the producers' call of stage_scale_shift stores nothing)
+#pragma unroll
+        for (int r = 0; r < STAT_REP; r++) msum += A.pro_stats[r * 256 + tid];
+    }
+    static_assert(MOM_N <= 256, "moments: collected by consumer threads");
+    auto stage_scale_shift = [&](auto Consc) __attribute__((always_inline)) {   // stage_bn() from the registers requested above; Consc: called by a consumer wave (threads
+        constexpr bool CONS = decltype(Consc)::value;             // 0..255, which hold those registers: in the producers' code they are dead, and so are their registers)
+        if (mom) {                                                // (every wave of the workgroup passes here exactly once)
+            if constexpr (CONS) { if (tid < MOM_N) s_mom[tid] = msum; }
+            LDS_BARRIER();
+        }
         if (PRO == PRO_GIN0) {                                    // the planes' k = 12..31 stay zero for the whole kernel
             for (int i = tid; i < 8 * XT / 16; i += 512) reinterpret_cast<float4 *>(s_tiles)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        } else if (tid < HD) {
+        } else if (CONS && tid < HD) {
             double su = 0, sq = 0;
 #pragma unroll
             for (int r = 0; r < STAT_REP; r++) { su += bsu[r]; sq += bsq[r]; }
+            if (mom) {                                            // column tid of z0 = W0 x + b from the moments of x
+                const double nrow = 1.0 / A.pro_inv_rows, b = A.bias0 ? (double)A.bias0[tid] : 0.0;
+                double wsx = 0, q = 0;
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    wsx = __builtin_fma((double)w0r[i], s_mom[MOM_SX + i], wsx);
+                    double row = 0;
+#pragma unroll
+                    for (int k = 0; k < 12; k++) row = __builtin_fma((double)w0r[k], s_mom[MOM_SXX + i * 12 + k], row);
+                    q = __builtin_fma((double)w0r[i], row, q);
+                }
+                su = wsx + nrow * b;
+                sq = q + 2.0 * b * wsx + nrow * b * b;
+            }
             if (A.range_flag && (su != su || sq != sq)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             const double mean = su * A.pro_inv_rows;
             double var = sq * A.pro_inv_rows - mean * mean;       // biased variance (training-mode BN)
@@ -638,7 +687,8 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             s_bn[tid] = sc;
             s_bn[HD + tid] = bbe - (float)mean * sc;
         }
-        if (tid < 2 * HD) s_stat[tid] = 0.0;
+        if (CONS && tid < 2 * HD) s_stat[tid] = 0.0;
+        if (CONS && PRO == PRO_GIN0BN && tid >= HD && tid < 2 * HD) s_b0[tid - HD] = A.bias0 ? A.bias0[tid - HD] : 0.f;
     };
     if (wave >= 4) {
         // ================================ producer ================================
@@ -738,13 +788,13 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                 feat3((size_t)(x.cc.x >= 0 ? base + x.cc.x : g), x.fx);
                 feat3((size_t)(x.cc.y >= 0 ? base + x.cc.y : g), x.fy);
             };
-            if (nsteps == 0) { stage_scale_shift(); LDS_BARRIER(); LDS_BARRIER(); }
+            if (nsteps == 0) { stage_scale_shift(std::false_type{}); LDS_BARRIER(); LDS_BARRIER(); }
             else {
 #pragma unroll
             for (int i = 0; i < 4; i++) req_ell(el[i], t0 + 4 * i);
 #pragma unroll
             for (int i = 0; i < 4; i++) { req_feat(st[i], el[i], t0 + 4 * i); req_ell(el[i], t0 + 4 * (i + 4)); }
-            stage_scale_shift();
+            stage_scale_shift(std::false_type{});
             LDS_BARRIER();
             STAMP(0);
             for (int s0 = 0; s0 < nsteps_c; s0 += 4) {
@@ -788,13 +838,126 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             }
             };
             if (A.feat_f64) gin0_producer(double{}); else gin0_producer(float{});
+        } else if constexpr (PRO == PRO_GIN0BN) {
+            // Round 6: the first Linear's output never goes to memory.  A statistics-only PRO_GIN0 launch (out == NULL) has left the BatchNorm
+            // sums of z0; here the producer forms z0 of its tile again — the same aggregation (gcn:125-153, f64 accumulate), the same exact
+            // 3-way bf16 split and the same six matrix instructions per column block in the same order as PRO_GIN0's consumers, so the
+            // same bits — adds the bias, and goes on as PRO_BNRELU's producer does (BatchNorm + ReLU, 2-way f16 split, planes).  The
+            // 419 MB write of z0 and its 419 MB read are replaced by a second read of the raw features (48 B per row).
+            // lane = (row m = lane & 15, k-quarter q = lane >> 4) holds the B operand fragment k = 8q..8q+7 of its row directly: features
+            // 0..7 (q = 0), 8..11 + zeros (q = 1), zeros (q >= 2: those lanes read what q = 0 reads) — no LDS round trip for the operand.
+            const int m = lane & 15, q = lane >> 4, fq = q < 2 ? q : 0;
+            float4 w0f[8][3];                                     // [column block][plane]: pieces of W0[16 cb + m][8q..8q+7]
+            {
+                const float4 *wi = reinterpret_cast<const float4 *>(A.Wx6_0) + lane;
+#pragma unroll
+                for (int cb = 0; cb < 8; cb++)
+#pragma unroll
+                    for (int p = 0; p < 3; p++) w0f[cb][p] = wi[(cb * 3 + p) * 64];
+            }
+            struct Stage { float4 fo[2], fx[2], fy[2]; int2 cc; float2 vv; int gt; } st[2];
+            struct Ell { int2 cc; float2 vv; } el[4];
+            const float *tf = reinterpret_cast<const float *>(A.tfea);
+            const int lastm1 = last - 1;
+            // (requests unconditional and clamped, as in the other producers: a request behind an `if` drains the queue at the join)
+            auto req_ell = [&](Ell &e, int tile) __attribute__((always_inline)) {
+                const int gt = PT(tile < lastm1 ? tile : lastm1) * 16 + m, g = gt < A.N ? gt : A.N - 1;
+                e.cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2);
+                e.vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2);
+            };
+            auto feat8 = [&](size_t row, float4 (&o)[2]) __attribute__((always_inline)) {
+                const float *p = tf + row * 12 + 8 * fq;
+                o[0] = *reinterpret_cast<const float4 *>(p);
+                o[1] = *reinterpret_cast<const float4 *>(p + (fq ? 0 : 4));      // (q = 1: features 12..15 do not exist; the duplicate is zeroed below)
+            };
+            auto req_feat = [&](Stage &x, const Ell &e, int tile) __attribute__((always_inline)) {
+                const int gt = PT(tile < lastm1 ? tile : lastm1) * 16 + m, g = gt < A.N ? gt : A.N - 1;
+                x.cc = e.cc; x.vv = e.vv; x.gt = gt;
+                const int base = (g / A.T) * A.T;
+                feat8((size_t)g, x.fo);
+                feat8((size_t)(x.cc.x >= 0 ? base + x.cc.x : g), x.fx);
+                feat8((size_t)(x.cc.y >= 0 ? base + x.cc.y : g), x.fy);
+            };
+            if (nsteps == 0) { stage_scale_shift(std::false_type{}); LDS_BARRIER(); LDS_BARRIER(); }
+            else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) req_ell(el[i], t0 + 4 * i);
+            req_feat(st[0], el[0], t0); req_ell(el[0], t0 + 16);
+            req_feat(st[1], el[1], t0 + 4); req_ell(el[1], t0 + 20);
+            stage_scale_shift(std::false_type{});
+            LDS_BARRIER();
+            STAMP(0);
+            const int nk = q == 0 ? 8 : q == 1 ? 4 : 0;           // features this lane's fragment holds
+            auto produce0 = [&](Stage &x, Ell &e, int s) __attribute__((always_inline)) {
+                const int tile = t0 + 4 * s;
+                if (tile < last) {
+                    const int deg = 1 + (x.cc.x >= 0) + (x.cc.y >= 0);
+                    const double inv = deg == 1 ? 1.0 : deg == 2 ? 0.5 : (1.0 / 3.0);
+                    const float fo[8] = {x.fo[0].x, x.fo[0].y, x.fo[0].z, x.fo[0].w, x.fo[1].x, x.fo[1].y, x.fo[1].z, x.fo[1].w};
+                    const float fx[8] = {x.fx[0].x, x.fx[0].y, x.fx[0].z, x.fx[0].w, x.fx[1].x, x.fx[1].y, x.fx[1].z, x.fx[1].w};
+                    const float fy[8] = {x.fy[0].x, x.fy[0].y, x.fy[0].z, x.fy[0].w, x.fy[1].x, x.fy[1].y, x.fy[1].z, x.fy[1].w};
+                    float va[4], vb[4];
+#pragma unroll
+                    for (int f = 0; f < 8; f++) {
+                        double acc = (double)fo[f];                   // (the same three f64 operations as PRO_GIN0's producer)
+                        acc += (double)x.vv.x * (double)fx[f];
+                        acc += (double)x.vv.y * (double)fy[f];
+                        const float v = (x.gt < A.N && f < nk) ? (float)(acc * inv) : 0.f;
+                        if (f < 4) va[f] = v; else vb[f - 4] = v;
+                    }
+                    uint2 a0, a1, a2, b0, b1, b2;
+                    split3x4(va, a0, a1, a2);
+                    split3x4(vb, b0, b1, b2);
+                    const bf16x8 xb[3] = {__builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y)), __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y)),
+                                          __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y))};
+                    unsigned char *dst = s_tiles + ((s & 1) * 4 + pw) * XT + m * X6_ROWB + 8 * q;
+#pragma unroll
+                    for (int cp = 0; cp < 4; cp++) {
+                        f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = c0;
+                        auto MB = [&](int wp, int xp) __attribute__((always_inline)) {
+                            c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0f[2 * cp][wp]), xb[xp], c0, 0, 0, 0);
+                            c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w0f[2 * cp + 1][wp]), xb[xp], c1, 0, 0, 0);
+                        };
+                        MB(0, 2); MB(2, 0); MB(1, 1); MB(0, 1); MB(1, 0); MB(0, 0);     // smallest terms first
+                        MFMA_SETTLE2(c0, c1);
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            const int col = 16 * (2 * cp + c) + 4 * q;
+                            const f32x4 z = c ? c1 : c0;
+                            const float4 bb = *reinterpret_cast<const float4 *>(s_b0 + col);
+                            const float4 sc = *reinterpret_cast<const float4 *>(s_bn + col), sh = *reinterpret_cast<const float4 *>(s_bn + HD + col);
+                            const f32x2 z01 = f32x2{z[0], z[1]} + f32x2{bb.x, bb.y}, z23 = f32x2{z[2], z[3]} + f32x2{bb.z, bb.w};      // Linear0's bias (PRO_GIN0's epilogue)
+                            const f32x2 a = __builtin_elementwise_fma(z01, f32x2{sc.x, sc.y}, f32x2{sh.x, sh.y});                   // PRO_BNRELU's bnr4
+                            const f32x2 b = __builtin_elementwise_fma(z23, f32x2{sc.z, sc.w}, f32x2{sh.z, sh.w});
+                            const float v[4] = {fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(b[0], 0.f), fmaxf(b[1], 0.f)};
+                            uint2 p0, p1;
+                            split2x4m(v, p0, p1);
+                            *reinterpret_cast<uint2 *>(dst + 2 * 16 * (2 * cp + c)) = p0;
+                            *reinterpret_cast<uint2 *>(dst + 2 * 16 * (2 * cp + c) + X6_PLANE) = p1;
+                        }
+                    }
+                }
+                req_feat(x, e, tile + 8);                         // step s + 2 (its ELL entries were requested four steps before it)
+                req_ell(e, tile + 24);                            // step s + 6
+                STAMP(1);
+                LDS_BARRIER();
+                STAMP(4);
+            };
+            for (int s = 0; s < nsteps_c; s += 4) {
+                produce0(st[0], el[2], s);
+                produce0(st[1], el[3], s + 1);
+                produce0(st[0], el[0], s + 2);
+                produce0(st[1], el[1], s + 3);
+            }
+            LDS_BARRIER();                                        // the consumers' last step
+            }
         } else {
         // Every step issues the SAME requests, unconditionally: a tile beyond the range is clamped to the last one (a few wasted
         // cache hits at the end of a range) and the steps are padded to a multiple of four (the consumers run the same number of
         // barriers).  With `if (tile < last)` around them, the compiler's wait counters had to assume the shorter path at every
         // join — "nothing younger in flight" — and drained ALL outstanding requests at the top of every step (s_waitcnt vmcnt(7..0)
         // in the ISA): the two-step prefetch was never in effect and the aggregation producer sat 8.6 k cycles per tile in here.
-        if (nsteps == 0) { stage_scale_shift(); LDS_BARRIER(); LDS_BARRIER(); }
+        if (nsteps == 0) { stage_scale_shift(std::false_type{}); LDS_BARRIER(); LDS_BARRIER(); }
         else {
         const int lastm1 = last - 1;
         auto CL = [&](int t) __attribute__((always_inline)) { return t < lastm1 ? t : lastm1; };
@@ -803,7 +966,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         if (PRO == PRO_AGG) request_nb(nbA, el[0], CL(t0));
         request_rows(preB, CL(t0 + 4));
         if (PRO == PRO_AGG && X6_NB_AHEAD == 2) request_nb(nbB, el[1], CL(t0 + 4));
-        stage_scale_shift();
+        stage_scale_shift(std::false_type{});
         LDS_BARRIER();
         STAMP(0);
         const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
@@ -885,7 +1048,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                 biasv[c] = f32x4{b.x, b.y, b.z, b.w};
             }
         }
-        stage_scale_shift();
+        stage_scale_shift(std::true_type{});
         LDS_BARRIER();
         STAMP(0);
         float ts[2][4], tq[2][4];                                 // per-lane column sums (row m of the tiles multiplied so far)
@@ -1999,6 +2162,106 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
 #ifndef POOL_INFLIGHT
 #define POOL_INFLIGHT 8                        // rows per batch and thread (two batches in flight)
 #endif
+// Sums and second moments of the aggregated raw features x (gcn:125-153 on the [N,12] task features, the first Linear's input) over all rows: the
+// BatchNorm statistics of z0 = W0 x + b follow from them exactly (k_gemm_x6<PRO_GIN0BN>, moments mode), so no launch has to form z0 for its sums alone.
+// A row is a quad of lanes: lane j < 3 of it reads features 4j..4j+3 of the row and of its <= 2 neighbours and aggregates them (the same f64 operations
+// and the same rounding to f32 as the product kernels' producers: the moments are those of the values the Linear multiplies); the quad exchanges the 12
+// values (DPP) and lane j accumulates rows 3j..3j+2 of x x' and of the sum in f64.  out: one [256]-double replica per workgroup % STAT_REP (MOM_*).
+__global__ __launch_bounds__(256) void k_gin0_moments(int N, int T, const float *tfea, const int *ell_col, const float *ell_val, double *out)
+{
+    __shared__ double s_part[4][4][40];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 3, rs = lane >> 2, jf = j < 3 ? j : 0;
+    double S[3][12], sx[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        sx[a] = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) S[a][k] = 0;
+    }
+    const int stride = (int)gridDim.x * 64;
+    const int niter = (N + stride - 1) / stride;
+    // requests run ahead of their use, unconditional and clamped (a request behind an `if` drains the queue at the join): the ELL entries two
+    // iterations ahead, the feature rows (whose addresses need them) one
+    struct Ell { int2 cc; float2 vv; } e1, e2;
+    struct Feat { float4 fo, fx, fy; int2 cc; float2 vv; int g; } f0, f1;
+    auto req_ell = [&](Ell &e, int it) __attribute__((always_inline)) {
+        const int g = it * stride + (int)blockIdx.x * 64 + wave * 16 + rs, gc = g < N ? g : N - 1;
+        e.cc = *reinterpret_cast<const int2 *>(ell_col + (size_t)gc * 2);
+        e.vv = *reinterpret_cast<const float2 *>(ell_val + (size_t)gc * 2);
+    };
+    auto req_feat = [&](Feat &f, const Ell &e, int it) __attribute__((always_inline)) {
+        const int g = it * stride + (int)blockIdx.x * 64 + wave * 16 + rs, gc = g < N ? g : N - 1;
+        const int base = (gc / T) * T;
+        f.cc = e.cc; f.vv = e.vv; f.g = g;
+        f.fo = *reinterpret_cast<const float4 *>(tfea + (size_t)gc * 12 + 4 * jf);
+        f.fx = *reinterpret_cast<const float4 *>(tfea + (size_t)(e.cc.x >= 0 ? base + e.cc.x : gc) * 12 + 4 * jf);
+        f.fy = *reinterpret_cast<const float4 *>(tfea + (size_t)(e.cc.y >= 0 ? base + e.cc.y : gc) * 12 + 4 * jf);
+    };
+    req_ell(e1, 0); req_ell(e2, 1);
+    req_feat(f0, e1, 0);
+    for (int it = 0; it < niter; it++) {
+        req_feat(f1, e2, it + 1);
+        e1 = e2;
+        req_ell(e2, it + 2);
+        const Feat &f = f0;
+        const int deg = 1 + (f.cc.x >= 0) + (f.cc.y >= 0);
+        const double inv = deg == 1 ? 1.0 : deg == 2 ? 0.5 : (1.0 / 3.0);
+        const float fo[4] = {f.fo.x, f.fo.y, f.fo.z, f.fo.w}, fx[4] = {f.fx.x, f.fx.y, f.fx.z, f.fx.w}, fy[4] = {f.fy.x, f.fy.y, f.fy.z, f.fy.w};
+        float x4[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            double acc = (double)fo[i];
+            acc += (double)f.vv.x * (double)fx[i];
+            acc += (double)f.vv.y * (double)fy[i];
+            x4[i] = (f.g < N && j < 3) ? (float)(acc * inv) : 0.f;
+        }
+        float xa[12];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int xi = __builtin_bit_cast(int, x4[i]);
+            xa[i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x00, 0xF, 0xF, true));        // quad_perm [0,0,0,0]
+            xa[4 + i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0x55, 0xF, 0xF, true));    // [1,1,1,1]
+            xa[8 + i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, xi, 0xAA, 0xF, 0xF, true));    // [2,2,2,2]
+        }
+        double xd[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) xd[k] = (double)xa[k];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const double xi = j == 0 ? xd[a] : j == 1 ? xd[3 + a] : j == 2 ? xd[6 + a] : xd[9 + a];
+            sx[a] += xi;
+#pragma unroll
+            for (int k = 0; k < 12; k++) S[a][k] = __builtin_fma(xi, xd[k], S[a][k]);
+        }
+        f0 = f1;
+    }
+    // the 16 rows of a wave (lane bits 2..5), then the four waves, then one atomic per entry and workgroup
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+#pragma unroll
+        for (int off = 4; off < 64; off <<= 1) sx[a] += __shfl_xor(sx[a], off);
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) S[a][k] += __shfl_xor(S[a][k], off);
+    }
+    if (lane < 4) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            s_part[wave][j][a] = sx[a];
+#pragma unroll
+            for (int k = 0; k < 12; k++) s_part[wave][j][3 + a * 12 + k] = S[a][k];
+        }
+    }
+    __syncthreads();
+    if (tid < 4 * 39) {
+        const int jj = tid / 39, idx = tid % 39;
+        const double v = (s_part[0][jj][idx] + s_part[1][jj][idx]) + (s_part[2][jj][idx] + s_part[3][jj][idx]);
+        const int slot = idx < 3 ? MOM_SX + 3 * jj + idx : MOM_SXX + (3 * jj + (idx - 3) / 12) * 12 + (idx - 3) % 12;
+        atomicAdd(&out[(blockIdx.x % STAT_REP) * 256 + slot], v);
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(256) void k_job_pool_gather(unsigned *range_flag, int rpr, int S, int B, int T, int J, const float *z, const double *stats, double inv_rows,
                                                         const float *gamma, const float *beta, const int *cand,
@@ -2557,6 +2820,7 @@ struct mtfjsp_encoder {
     // issue (~100 us per launch even with no output at all), not by memory
     int fuse_pair = getenv("MTFJSP_FUSE_PAIR") ? atoi(getenv("MTFJSP_FUSE_PAIR")) : 0;
     int stream_order = getenv("MTFJSP_NO_STREAM_ORDER") ? 0 : 1;   // streaming GIN launches: alternating row direction + non-temporal input reads (A/B switch)
+    int fuse_gin0 = getenv("MTFJSP_FUSE_GIN0") ? atoi(getenv("MTFJSP_FUSE_GIN0")) : 1;   // run_gin: the first Linear's output formed again by the second launch's producers instead of stored
     int pool_s = getenv("MTFJSP_POOL_S") ? atoi(getenv("MTFJSP_POOL_S")) : 4;      // k_job_pool_gather: blocks per row range of the last product (0: plain instance order)
     int stream_nt = getenv("MTFJSP_STREAM_NT") ? atoi(getenv("MTFJSP_STREAM_NT")) : 5;   // which readers use non-temporal loads: 1 BatchNorm+ReLU products, 2 aggregation product, 4 pool / gather
     mtfjsp_mfea1_ctx_t mf_ctx{}; bool mf_armed = false;
@@ -2737,6 +3001,7 @@ extern "C" int mtfjsp_encoder_create(const mtfjsp_encoder_config_t *cfg, mtfjsp_
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_BNRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_AGG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_GIN0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)k_gemm_x6<PRO_GIN0BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6_lds_bytes());
     if (hipFuncSetAttribute((const void *)k_gemm_x6f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)gemm_x6f_lds_bytes()) != hipSuccess) e->fuse_pair = 0;
     (void)hipFuncSetAttribute((const void *)k_gin_inst<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
     (void)hipFuncSetAttribute((const void *)k_gin_inst<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)inst_lds_bytes());
@@ -3091,7 +3356,7 @@ static void launch_gemm(mtfjsp_encoder *e, const GemmArgs &a, const char *name)
     b.stamps = d_st;
 #endif
     if constexpr (PRO == PRO_PLAIN) hipLaunchKernelGGL((k_gemm16<EPI, ACC>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
-    else if constexpr (PRO == PRO_GIN0) hipLaunchKernelGGL((k_gemm_x6<PRO>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
+    else if constexpr (PRO == PRO_GIN0 || PRO == PRO_GIN0BN) hipLaunchKernelGGL((k_gemm_x6<PRO>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
     else {
         if (b.Wx6 && !(e->f32_products & 1)) hipLaunchKernelGGL((k_gemm_x6<PRO>), dim3(grid), dim3(512), gemm_x6_lds_bytes(), e->stream, b);
         else hipLaunchKernelGGL((k_gemm16p<PRO>), dim3(grid), dim3(512), gemm16_lds_bytes(), e->stream, b);
@@ -3141,13 +3406,27 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     const double invN = 1.0 / ((double)N * e->reduce_scale);      // (exact multi-shard BatchNorm: rows of all shards)
     const int pgrid = e->num_cu * 8;
     int rrc = 0;
-    if (!(e->f32_products & 8)) {   // layer 0 / linear 0 with aggregation of the raw features, on the producer/consumer product kernel
-        GemmArgs a = gemm_args(nullptr, N, nullptr, W(P + "mlps.0.linears.0.bias"), e->zA);
+    // Two Linears per launch (mtfjsp_gemm_pair.h): split products only
+    const bool pair = !(e->f32_products & 1) && (e->fuse_pair > 0 || (e->fuse_pair < 0 && (size_t)N * HD * 4 > ((size_t)256 << 20)));
+    // Round 6 (e->fuse_gin0; MTFJSP_FUSE_GIN0=0 switches it off): z0 = Linear0(aggregated features) is not stored.  Its BatchNorm sums come from the second
+    // moments of the 12 aggregated features (k_gin0_moments; MTFJSP_FUSE_GIN0=2: from a PRO_GIN0 launch with out == NULL, the two-launch form's bits), and
+    // the producers of the second launch form z0 again from the raw features (PRO_GIN0BN): 838 MB of the forward's traffic at 819 200 rows replaced by
+    // two reads of 52 MB.  f32 observations, split products (tests/test_encoder_sizes_gpu.py holds the forms against each other).
+    const bool fuse0 = e->fuse_gin0 && !(e->f32_products & 9) && !pair && e->cfg.obs_dtype == MTFJSP_OBS_F32;
+    // (2: the sums by a statistics-only PRO_GIN0 launch — the two-launch form's bits; A/B and tests.  With a statistics reduction over several ranks
+    // slot 0 must hold the SAME quantities on every rank, and a rank that has left the split products after a range failure sums z0 itself: no moments then)
+    const bool mom0 = fuse0 && e->fuse_gin0 != 2 && !e->reduce_fn;
+    if (mom0) {
+        Timed t(e, "gin0_moments");
+        hipLaunchKernelGGL(k_gin0_moments, dim3(e->num_cu * 4), dim3(256), 0, e->stream, N, T, (const float *)tasks_fea, ell_col, ell_val, st + 0 * STAT_REP * 256);
+        if ((rrc = reduce_stats(e, st + 0 * STAT_REP * 256))) return rrc;
+    } else if (!(e->f32_products & 8)) {   // layer 0 / linear 0 with aggregation of the raw features, on the producer/consumer product kernel
+        GemmArgs a = gemm_args(nullptr, N, nullptr, W(P + "mlps.0.linears.0.bias"), fuse0 ? nullptr : e->zA);
         a.tfea = tasks_fea; a.feat_f64 = e->cfg.obs_dtype == MTFJSP_OBS_F64; a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
         a.epi_stats = st + 0 * STAT_REP * 256;
         a.rev = e->stream_order;
         a.Wx6 = e->wx6.at(P + "mlps.0.linears.0.weight"); a.w_sinv = 1.0f;
-        launch_gemm<PRO_GIN0, EPI_STATS>(e, a, "gin0_agg_linear12");
+        launch_gemm<PRO_GIN0, EPI_STATS>(e, a, fuse0 ? "gin0_stats_only" : "gin0_agg_linear12");
         if ((rrc = reduce_stats(e, st + 0 * STAT_REP * 256))) return rrc;
     } else {
         Timed t(e, "gin0_agg_linear12");
@@ -3173,8 +3452,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         if (!rrc) rrc = reduce_stats(e, st + sout * STAT_REP * 256);
     };
     // Two Linears per launch (mtfjsp_gemm_pair.h): pass 1 = the first product with no output (its BatchNorm sums only, slot `smid`),
-    // pass 2 = k_gemm_x6f: in -> bn(sin) -> lin1 -> bn(smid) -> lin2 -> out with the sums of slot `sout`.  Split products only.
-    const bool pair = !(e->f32_products & 1) && (e->fuse_pair > 0 || (e->fuse_pair < 0 && (size_t)N * HD * 4 > ((size_t)256 << 20)));
+    // pass 2 = k_gemm_x6f: in -> bn(sin) -> lin1 -> bn(smid) -> lin2 -> out with the sums of slot `sout`.
     auto bn_gemm_pair = [&](const float *in, float *out, int sin, const std::string &bn1, const std::string &lin1, int smid,
                             const std::string &bn2, const std::string &lin2, int sout, int rev) {
         {   // pass 1: statistics of z_b
@@ -3206,6 +3484,19 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     };
     if (pair) bn_gemm_pair(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1, "mlps.0.batch_norms.1", "mlps.0.linears.2", 2, 0);
     else {
+    if (fuse0) {
+        const std::string lin = "mlps.0.linears.1", bn = "mlps.0.batch_norms.0";
+        GemmArgs a = gemm_args(nullptr, N, WT(P + lin + ".weight"), W(P + lin + ".bias"), e->zB);
+        a.rev = 0; a.nt = 0;
+        a.tfea = tasks_fea; a.feat_f64 = 0; a.ell_col = ell_col; a.ell_val = ell_val; a.T = T;
+        a.Wx6_0 = e->wx6.at(P + "mlps.0.linears.0.weight"); a.bias0 = W(P + "mlps.0.linears.0.bias");
+        a.W0 = mom0 ? W(P + "mlps.0.linears.0.weight") : nullptr;
+        a.pro_stats = st + 0 * STAT_REP * 256; a.pro_gamma = W(P + bn + ".weight"); a.pro_beta = W(P + bn + ".bias"); a.pro_inv_rows = invN;
+        a.epi_stats = st + 1 * STAT_REP * 256;
+        a.Wx6 = e->wx6.at(P + lin + ".weight"); a.w_sinv = e->wx6_sinv.at(P + lin + ".weight");
+        launch_gemm<PRO_GIN0BN, EPI_STATS>(e, a, "gin0_bn_gemm");
+        if (!rrc) rrc = reduce_stats(e, st + 1 * STAT_REP * 256);
+    } else
     bn_gemm(e->zA, e->zB, 0, "mlps.0.batch_norms.0", "mlps.0.linears.1", 1, 0);
     bn_gemm(e->zB, e->zA, 1, "mlps.0.batch_norms.1", "mlps.0.linears.2", 2, 1);
     }

@@ -95,8 +95,12 @@ def test_streaming_order_switches_do_not_change_results(monkeypatch):
     env = ro.env
     hm = ro.actor.enc.h_pooled_m.clone()
     outs = []
-    for switches in ({}, {"MTFJSP_NO_STREAM_ORDER": "1"}, {"MTFJSP_POOL_S": "0", "MTFJSP_STREAM_NT": "0"}, {"MTFJSP_NO_HEADS_HG8": "1"}):
-        for k in ("MTFJSP_NO_STREAM_ORDER", "MTFJSP_POOL_S", "MTFJSP_STREAM_NT", "MTFJSP_NO_HEADS_HG8"):
+    # MTFJSP_FUSE_GIN0 — default 1: the first Linear's output is never stored; its BatchNorm sums come from the second moments of the 12 aggregated
+    # features (k_gin0_moments) and the second launch's producers form it again.  2: the sums by a statistics-only launch instead — the same matrix
+    # instructions on the same operands as 0, the two-launch form, so only the order of the sums' atomics differs: those two are held to a tenth of the bound.
+    for switches in ({}, {"MTFJSP_FUSE_GIN0": "0"}, {"MTFJSP_FUSE_GIN0": "2"}, {"MTFJSP_NO_STREAM_ORDER": "1"}, {"MTFJSP_POOL_S": "0", "MTFJSP_STREAM_NT": "0"},
+                     {"MTFJSP_NO_HEADS_HG8": "1"}):
+        for k in ("MTFJSP_NO_STREAM_ORDER", "MTFJSP_POOL_S", "MTFJSP_STREAM_NT", "MTFJSP_NO_HEADS_HG8", "MTFJSP_FUSE_GIN0"):
             monkeypatch.delenv(k, raising=False)
         for k, v in switches.items():
             monkeypatch.setenv(k, v)
@@ -107,6 +111,10 @@ def test_streaming_order_switches_do_not_change_results(monkeypatch):
         outs.append((prob.cpu().numpy().copy(), h_o.cpu().numpy().copy(), job_v.cpu().numpy().copy()))
         e.close()
     scale = max(1.0, float(np.abs(outs[0][1]).max()))
+    np.testing.assert_allclose(outs[2][1], outs[1][1], rtol=0, atol=2e-6 * scale)     # (measured: identical, tools/check_gin0_modes.py)
+    np.testing.assert_allclose(outs[2][0], outs[1][0], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=5e-6 * scale)     # statistics from the moments (measured: 0.3-1.3e-6 of the scale)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=5e-6)
     for o in outs[1:]:
         np.testing.assert_allclose(o[1], outs[0][1], rtol=0, atol=2e-5 * scale)
         np.testing.assert_allclose(o[0], outs[0][0], rtol=0, atol=2e-5)
