@@ -844,9 +844,12 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             // 3-way bf16 split and the same six matrix instructions per column block in the same order as PRO_GIN0's consumers, so the
             // same bits — adds the bias, and goes on as PRO_BNRELU's producer does (BatchNorm + ReLU, 2-way f16 split, planes).  The
             // 419 MB write of z0 and its 419 MB read are replaced by a second read of the raw features (48 B per row).
-            // lane = (row m = lane & 15, k-quarter q = lane >> 4) holds the B operand fragment k = 8q..8q+7 of its row directly: features
-            // 0..7 (q = 0), 8..11 + zeros (q = 1), zeros (q >= 2: those lanes read what q = 0 reads) — no LDS round trip for the operand.
-            const int m = lane & 15, q = lane >> 4, fq = q < 2 ? q : 0;
+            // lane = (row m = lane & 15, k-quarter q = lane >> 4) holds the B operand fragment k = 8q..8q+7 of its row directly — features 0..7 (q = 0),
+            // 8..11 + zeros (q = 1), zeros (q >= 2) — no LDS round trip for the operand.  The aggregation is spread over three quarters: q = 0 forms
+            // features 0..3, q = 1 features 8..11, q = 2 features 4..7, which q = 0 takes from lane + 32 after the split (v_permlane32_swap).
+            const int m = lane & 15, q = lane >> 4, fsel = q == 1 ? 8 : q == 2 ? 4 : 0;
+            const int keep_lo = q < 2 ? -1 : 0, keep_hi = q == 0 ? -1 : 0;
+            const float invT = 1.0f / (float)A.T;
             float4 w0f[8][3];                                     // [column block][plane]: pieces of W0[16 cb + m][8q..8q+7]
             {
                 const float4 *wi = reinterpret_cast<const float4 *>(A.Wx6_0) + lane;
@@ -855,7 +858,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 #pragma unroll
                     for (int p = 0; p < 3; p++) w0f[cb][p] = wi[(cb * 3 + p) * 64];
             }
-            struct Stage { float4 fo[2], fx[2], fy[2]; int2 cc; float2 vv; int gt; } st[2];
+            struct Stage { float4 fo, fx, fy; int2 cc; float2 vv; int gt; } st[2];
             struct Ell { int2 cc; float2 vv; } el[4];
             const float *tf = reinterpret_cast<const float *>(A.tfea);
             const int lastm1 = last - 1;
@@ -865,18 +868,16 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                 e.cc = *reinterpret_cast<const int2 *>(A.ell_col + (size_t)g * 2);
                 e.vv = *reinterpret_cast<const float2 *>(A.ell_val + (size_t)g * 2);
             };
-            auto feat8 = [&](size_t row, float4 (&o)[2]) __attribute__((always_inline)) {
-                const float *p = tf + row * 12 + 8 * fq;
-                o[0] = *reinterpret_cast<const float4 *>(p);
-                o[1] = *reinterpret_cast<const float4 *>(p + (fq ? 0 : 4));      // (q = 1: features 12..15 do not exist; the duplicate is zeroed below)
-            };
             auto req_feat = [&](Stage &x, const Ell &e, int tile) __attribute__((always_inline)) {
                 const int gt = PT(tile < lastm1 ? tile : lastm1) * 16 + m, g = gt < A.N ? gt : A.N - 1;
                 x.cc = e.cc; x.vv = e.vv; x.gt = gt;
-                const int base = (g / A.T) * A.T;
-                feat8((size_t)g, x.fo);
-                feat8((size_t)(x.cc.x >= 0 ? base + x.cc.x : g), x.fx);
-                feat8((size_t)(x.cc.y >= 0 ? base + x.cc.y : g), x.fy);
+                int qi = (int)((float)g * invT);                  // g / T for g < 2^24: the f32 quotient is off by at most one
+                int rem = g - qi * A.T;
+                qi += rem >= A.T ? 1 : rem < 0 ? -1 : 0;
+                const int base = qi * A.T;
+                x.fo = *reinterpret_cast<const float4 *>(tf + (size_t)g * 12 + fsel);
+                x.fx = *reinterpret_cast<const float4 *>(tf + (size_t)(x.cc.x >= 0 ? base + x.cc.x : g) * 12 + fsel);
+                x.fy = *reinterpret_cast<const float4 *>(tf + (size_t)(x.cc.y >= 0 ? base + x.cc.y : g) * 12 + fsel);
             };
             if (nsteps == 0) { stage_scale_shift(std::false_type{}); LDS_BARRIER(); LDS_BARRIER(); }
             else {
@@ -887,29 +888,29 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             stage_scale_shift(std::false_type{});
             LDS_BARRIER();
             STAMP(0);
-            const int nk = q == 0 ? 8 : q == 1 ? 4 : 0;           // features this lane's fragment holds
             auto produce0 = [&](Stage &x, Ell &e, int s) __attribute__((always_inline)) {
                 const int tile = t0 + 4 * s;
                 if (tile < last) {
                     const int deg = 1 + (x.cc.x >= 0) + (x.cc.y >= 0);
                     const double inv = deg == 1 ? 1.0 : deg == 2 ? 0.5 : (1.0 / 3.0);
-                    const float fo[8] = {x.fo[0].x, x.fo[0].y, x.fo[0].z, x.fo[0].w, x.fo[1].x, x.fo[1].y, x.fo[1].z, x.fo[1].w};
-                    const float fx[8] = {x.fx[0].x, x.fx[0].y, x.fx[0].z, x.fx[0].w, x.fx[1].x, x.fx[1].y, x.fx[1].z, x.fx[1].w};
-                    const float fy[8] = {x.fy[0].x, x.fy[0].y, x.fy[0].z, x.fy[0].w, x.fy[1].x, x.fy[1].y, x.fy[1].z, x.fy[1].w};
-                    float va[4], vb[4];
+                    const float fo[4] = {x.fo.x, x.fo.y, x.fo.z, x.fo.w}, fx[4] = {x.fx.x, x.fx.y, x.fx.z, x.fx.w}, fy[4] = {x.fy.x, x.fy.y, x.fy.z, x.fy.w};
+                    const int keep = x.gt < A.N ? -1 : 0;             // (a mask, not a select: hipcc turns the select into a branch around the f64 work)
+                    float va[4];
 #pragma unroll
-                    for (int f = 0; f < 8; f++) {
+                    for (int f = 0; f < 4; f++) {
                         double acc = (double)fo[f];                   // (the same three f64 operations as PRO_GIN0's producer)
                         acc += (double)x.vv.x * (double)fx[f];
                         acc += (double)x.vv.y * (double)fy[f];
-                        const float v = (x.gt < A.N && f < nk) ? (float)(acc * inv) : 0.f;
-                        if (f < 4) va[f] = v; else vb[f - 4] = v;
+                        va[f] = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)(acc * inv)) & keep);
                     }
-                    uint2 a0, a1, a2, b0, b1, b2;
-                    split3x4(va, a0, a1, a2);
-                    split3x4(vb, b0, b1, b2);
-                    const bf16x8 xb[3] = {__builtin_bit_cast(bf16x8, make_uint4(a0.x, a0.y, b0.x, b0.y)), __builtin_bit_cast(bf16x8, make_uint4(a1.x, a1.y, b1.x, b1.y)),
-                                          __builtin_bit_cast(bf16x8, make_uint4(a2.x, a2.y, b2.x, b2.y))};
+                    uint2 a[3];
+                    split3x4(va, a[0], a[1], a[2]);
+                    bf16x8 xb[3];
+#pragma unroll
+                    for (int p = 0; p < 3; p++) {                     // lanes 0..31 <- lanes 32..63: q = 0 receives q = 2's features 4..7
+                        const unsigned bx = __builtin_amdgcn_permlane32_swap(a[p].x, a[p].x, false, false)[1], by = __builtin_amdgcn_permlane32_swap(a[p].y, a[p].y, false, false)[1];
+                        xb[p] = __builtin_bit_cast(bf16x8, make_uint4(a[p].x & (unsigned)keep_lo, a[p].y & (unsigned)keep_lo, bx & (unsigned)keep_hi, by & (unsigned)keep_hi));
+                    }
                     unsigned char *dst = s_tiles + ((s & 1) * 4 + pw) * XT + m * X6_ROWB + 8 * q;
 #pragma unroll
                     for (int cp = 0; cp < 4; cp++) {
@@ -927,9 +928,9 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                             const float4 bb = *reinterpret_cast<const float4 *>(s_b0 + col);
                             const float4 sc = *reinterpret_cast<const float4 *>(s_bn + col), sh = *reinterpret_cast<const float4 *>(s_bn + HD + col);
                             const f32x2 z01 = f32x2{z[0], z[1]} + f32x2{bb.x, bb.y}, z23 = f32x2{z[2], z[3]} + f32x2{bb.z, bb.w};      // Linear0's bias (PRO_GIN0's epilogue)
-                            const f32x2 a = __builtin_elementwise_fma(z01, f32x2{sc.x, sc.y}, f32x2{sh.x, sh.y});                   // PRO_BNRELU's bnr4
-                            const f32x2 b = __builtin_elementwise_fma(z23, f32x2{sc.z, sc.w}, f32x2{sh.z, sh.w});
-                            const float v[4] = {fmaxf(a[0], 0.f), fmaxf(a[1], 0.f), fmaxf(b[0], 0.f), fmaxf(b[1], 0.f)};
+                            const f32x2 ya = __builtin_elementwise_fma(z01, f32x2{sc.x, sc.y}, f32x2{sh.x, sh.y});                  // PRO_BNRELU's bnr4
+                            const f32x2 yb = __builtin_elementwise_fma(z23, f32x2{sc.z, sc.w}, f32x2{sh.z, sh.w});
+                            const float v[4] = {fmaxf(ya[0], 0.f), fmaxf(ya[1], 0.f), fmaxf(yb[0], 0.f), fmaxf(yb[1], 0.f)};
                             uint2 p0, p1;
                             split2x4m(v, p0, p1);
                             *reinterpret_cast<uint2 *>(dst + 2 * 16 * (2 * cp + c)) = p0;
@@ -1051,11 +1052,12 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         stage_scale_shift(std::true_type{});
         LDS_BARRIER();
         STAMP(0);
-        float ts[2][4], tq[2][4];                                 // per-lane column sums (row m of the tiles multiplied so far)
+        f32x2 ts[2][2], tq[2][2];                                 // per-lane column sums (row m of the tiles multiplied so far), two columns per register pair
 #pragma unroll
         for (int c = 0; c < 2; c++)
 #pragma unroll
-            for (int i = 0; i < 4; i++) { ts[c][i] = 0.f; tq[c][i] = 0.f; }
+            for (int i = 0; i < 2; i++) { ts[c][i] = f32x2{0.f, 0.f}; tq[c][i] = f32x2{0.f, 0.f}; }
+        const f32x4 wsinv4 = {wsinv, wsinv, wsinv, wsinv};
         const unsigned char *xa0 = s_tiles + m * X6_ROWB + 16 * q; // operand fragment (slot t, plane p, k-step ks): + t*XT + p*X6_PLANE + 64*ks
         unsigned char *s_tr = smem + X6_TR_OFF + cg * 2 * X6_TRB;  // this wave's two output transposition buffers
         LDS_BARRIER();                                            // step 0: the producers fill buffer 0
@@ -1105,8 +1107,9 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 #ifdef MTFJSP_STAMP_TILE                       // diagnostic split of the consumer's tile: 5 = fragments + products, 1 = epilogue up to the LDS write + sums, 6 = LDS read-back + stores issued
                     STAMP(5);
 #endif
+                    // (one fused operation per pair: wsinv is a power of two, the product is exact either way — the same bits as a multiplication and an addition)
 #pragma unroll
-                    for (int c = 0; c < 2; c++) acc[c] = acc[c] * wsinv + biasv[c];
+                    for (int c = 0; c < 2; c++) acc[c] = __builtin_elementwise_fma(acc[c], wsinv4, biasv[c]);
                     const int ptile = FULL || tb + t < last ? PT(tb + t) : 0;
                     const int row = ptile * 16 + m;
                     const bool ok = FULL || row < A.N;
@@ -1120,7 +1123,10 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                         const f32x4 v = acc[c];
                         if (A.out) *reinterpret_cast<float4 *>(trb + m * 144 + 16 * (4 * c + q)) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
-                        for (int i = 0; i < 4; i++) { const float x = ok ? v[i] : 0.f; ts[c][i] += x; tq[c][i] = __builtin_fmaf(x, x, tq[c][i]); }
+                        for (int i = 0; i < 2; i++) {                 // two-wide: the same additions
+                            const f32x2 x = {ok ? v[2 * i] : 0.f, ok ? v[2 * i + 1] : 0.f};
+                            ts[c][i] = ts[c][i] + x; tq[c][i] = __builtin_elementwise_fma(x, x, tq[c][i]);
+                        }
                     }
 #ifdef MTFJSP_STAMP_TILE
                     STAMP(1);
@@ -1150,9 +1156,9 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                 for (int c = 0; c < 2; c++)
 #pragma unroll
                     for (int i = 0; i < 4; i++) {
-                        const float a = row_sum16(ts[c][i]), b = row_sum16(tq[c][i]);
+                        const float a = row_sum16(ts[c][i >> 1][i & 1]), b = row_sum16(tq[c][i >> 1][i & 1]);
                         if (m == 0) { atomicAdd(&s_stat[32 * cg + 16 * c + 4 * q + i], (double)a); atomicAdd(&s_stat[HD + 32 * cg + 16 * c + 4 * q + i], (double)b); }
-                        ts[c][i] = 0.f; tq[c][i] = 0.f;
+                        ts[c][i >> 1][i & 1] = 0.f; tq[c][i >> 1][i & 1] = 0.f;
                     }
             }
             STAMP(6);
@@ -2166,54 +2172,54 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
 // BatchNorm statistics of z0 = W0 x + b follow from them exactly (k_gemm_x6<PRO_GIN0BN>, moments mode), so no launch has to form z0 for its sums alone.
 // A row is a quad of lanes: lane j < 3 of it reads features 4j..4j+3 of the row and of its <= 2 neighbours and aggregates them (the same f64 operations
 // and the same rounding to f32 as the product kernels' producers: the moments are those of the values the Linear multiplies); the quad exchanges the 12
-// values (DPP) and lane j accumulates rows 3j..3j+2 of x x' and of the sum in f64.  out: one [256]-double replica per workgroup % STAT_REP (MOM_*).
+// values (DPP) and lane j accumulates its own rows 4j..4j+3 of x x' and of the sum in f64 (lane 3 of a quad adds zeros: no per-lane register choice,
+// no branch).  out: one [256]-double replica per workgroup % STAT_REP (MOM_*).
 __global__ __launch_bounds__(256) void k_gin0_moments(int N, int T, const float *tfea, const int *ell_col, const float *ell_val, double *out)
 {
-    __shared__ double s_part[4][4][40];
+    __shared__ double s_part[4][3][52];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 3, rs = lane >> 2, jf = j < 3 ? j : 0;
-    double S[3][12], sx[3];
+    double S[4][12], sx[4];
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
+    for (int a = 0; a < 4; a++) {
         sx[a] = 0;
 #pragma unroll
         for (int k = 0; k < 12; k++) S[a][k] = 0;
     }
     const int stride = (int)gridDim.x * 64;
     const int niter = (N + stride - 1) / stride;
-    // requests run ahead of their use, unconditional and clamped (a request behind an `if` drains the queue at the join): the ELL entries two
-    // iterations ahead, the feature rows (whose addresses need them) one
-    struct Ell { int2 cc; float2 vv; } e1, e2;
-    struct Feat { float4 fo, fx, fy; int2 cc; float2 vv; int g; } f0, f1;
-    auto req_ell = [&](Ell &e, int it) __attribute__((always_inline)) {
+    const float invT = 1.0f / (float)T;
+    // requests run ahead of their use, unconditional and clamped (a request behind an `if` drains the queue at the join): the feature rows two
+    // iterations ahead, the ELL entries their addresses need another four (an iteration is ~0.25 us of arithmetic, a memory round trip 1-2 us)
+    struct Ell { int2 cc; float2 vv; } e[4];
+    struct Feat { float4 fo, fx, fy; int2 cc; float2 vv; int g; } f[2];
+    auto req_ell = [&](Ell &el, int it) __attribute__((always_inline)) {
         const int g = it * stride + (int)blockIdx.x * 64 + wave * 16 + rs, gc = g < N ? g : N - 1;
-        e.cc = *reinterpret_cast<const int2 *>(ell_col + (size_t)gc * 2);
-        e.vv = *reinterpret_cast<const float2 *>(ell_val + (size_t)gc * 2);
+        el.cc = *reinterpret_cast<const int2 *>(ell_col + (size_t)gc * 2);
+        el.vv = *reinterpret_cast<const float2 *>(ell_val + (size_t)gc * 2);
     };
-    auto req_feat = [&](Feat &f, const Ell &e, int it) __attribute__((always_inline)) {
+    auto req_feat = [&](Feat &ft, const Ell &el, int it) __attribute__((always_inline)) {
         const int g = it * stride + (int)blockIdx.x * 64 + wave * 16 + rs, gc = g < N ? g : N - 1;
-        const int base = (gc / T) * T;
-        f.cc = e.cc; f.vv = e.vv; f.g = g;
-        f.fo = *reinterpret_cast<const float4 *>(tfea + (size_t)gc * 12 + 4 * jf);
-        f.fx = *reinterpret_cast<const float4 *>(tfea + (size_t)(e.cc.x >= 0 ? base + e.cc.x : gc) * 12 + 4 * jf);
-        f.fy = *reinterpret_cast<const float4 *>(tfea + (size_t)(e.cc.y >= 0 ? base + e.cc.y : gc) * 12 + 4 * jf);
+        int qi = (int)((float)gc * invT);                         // gc / T for gc < 2^24: the f32 quotient is off by at most one
+        const int rem = gc - qi * T;
+        qi += rem >= T ? 1 : rem < 0 ? -1 : 0;
+        const int base = qi * T;
+        ft.cc = el.cc; ft.vv = el.vv; ft.g = g;
+        ft.fo = *reinterpret_cast<const float4 *>(tfea + (size_t)gc * 12 + 4 * jf);
+        ft.fx = *reinterpret_cast<const float4 *>(tfea + (size_t)(el.cc.x >= 0 ? base + el.cc.x : gc) * 12 + 4 * jf);
+        ft.fy = *reinterpret_cast<const float4 *>(tfea + (size_t)(el.cc.y >= 0 ? base + el.cc.y : gc) * 12 + 4 * jf);
     };
-    req_ell(e1, 0); req_ell(e2, 1);
-    req_feat(f0, e1, 0);
-    for (int it = 0; it < niter; it++) {
-        req_feat(f1, e2, it + 1);
-        e1 = e2;
-        req_ell(e2, it + 2);
-        const Feat &f = f0;
-        const int deg = 1 + (f.cc.x >= 0) + (f.cc.y >= 0);
+    auto body = [&](Feat &ft, Ell &el, int it) __attribute__((always_inline)) {
+        const int deg = 1 + (ft.cc.x >= 0) + (ft.cc.y >= 0);
         const double inv = deg == 1 ? 1.0 : deg == 2 ? 0.5 : (1.0 / 3.0);
-        const float fo[4] = {f.fo.x, f.fo.y, f.fo.z, f.fo.w}, fx[4] = {f.fx.x, f.fx.y, f.fx.z, f.fx.w}, fy[4] = {f.fy.x, f.fy.y, f.fy.z, f.fy.w};
+        const float fo[4] = {ft.fo.x, ft.fo.y, ft.fo.z, ft.fo.w}, fx[4] = {ft.fx.x, ft.fx.y, ft.fx.z, ft.fx.w}, fy[4] = {ft.fy.x, ft.fy.y, ft.fy.z, ft.fy.w};
         float x4[4];
+        const int keep = (ft.g < N && j < 3) ? -1 : 0;                  // (a mask, not a select: hipcc turns the select into a branch around the f64 work)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             double acc = (double)fo[i];
-            acc += (double)f.vv.x * (double)fx[i];
-            acc += (double)f.vv.y * (double)fy[i];
-            x4[i] = (f.g < N && j < 3) ? (float)(acc * inv) : 0.f;
+            acc += (double)ft.vv.x * (double)fx[i];
+            acc += (double)ft.vv.y * (double)fy[i];
+            x4[i] = __builtin_bit_cast(float, __builtin_bit_cast(int, (float)(acc * inv)) & keep);
         }
         float xa[12];
 #pragma unroll
@@ -2227,17 +2233,28 @@ __global__ __launch_bounds__(256) void k_gin0_moments(int N, int T, const float 
 #pragma unroll
         for (int k = 0; k < 12; k++) xd[k] = (double)xa[k];
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const double xi = j == 0 ? xd[a] : j == 1 ? xd[3 + a] : j == 2 ? xd[6 + a] : xd[9 + a];
+        for (int a = 0; a < 4; a++) {
+            const double xi = (double)x4[a];
             sx[a] += xi;
 #pragma unroll
             for (int k = 0; k < 12; k++) S[a][k] = __builtin_fma(xi, xd[k], S[a][k]);
         }
-        f0 = f1;
+        req_feat(ft, el, it + 2);
+        req_ell(el, it + 6);
+    };
+#pragma unroll
+    for (int i = 0; i < 4; i++) req_ell(e[i], i);
+    req_feat(f[0], e[0], 0); req_ell(e[0], 4);
+    req_feat(f[1], e[1], 1); req_ell(e[1], 5);
+    for (int it = 0; it < niter; it += 4) {                       // (iterations past the last one see rows >= N only: zeros)
+        body(f[0], e[2], it);
+        body(f[1], e[3], it + 1);
+        body(f[0], e[0], it + 2);
+        body(f[1], e[1], it + 3);
     }
     // the 16 rows of a wave (lane bits 2..5), then the four waves, then one atomic per entry and workgroup
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
+    for (int a = 0; a < 4; a++) {
 #pragma unroll
         for (int off = 4; off < 64; off <<= 1) sx[a] += __shfl_xor(sx[a], off);
 #pragma unroll
@@ -2245,19 +2262,19 @@ __global__ __launch_bounds__(256) void k_gin0_moments(int N, int T, const float 
 #pragma unroll
             for (int off = 4; off < 64; off <<= 1) S[a][k] += __shfl_xor(S[a][k], off);
     }
-    if (lane < 4) {
+    if (lane < 3) {
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
+        for (int a = 0; a < 4; a++) {
             s_part[wave][j][a] = sx[a];
 #pragma unroll
-            for (int k = 0; k < 12; k++) s_part[wave][j][3 + a * 12 + k] = S[a][k];
+            for (int k = 0; k < 12; k++) s_part[wave][j][4 + a * 12 + k] = S[a][k];
         }
     }
     __syncthreads();
-    if (tid < 4 * 39) {
-        const int jj = tid / 39, idx = tid % 39;
+    if (tid < 3 * 52) {
+        const int jj = tid / 52, idx = tid % 52;
         const double v = (s_part[0][jj][idx] + s_part[1][jj][idx]) + (s_part[2][jj][idx] + s_part[3][jj][idx]);
-        const int slot = idx < 3 ? MOM_SX + 3 * jj + idx : MOM_SXX + (3 * jj + (idx - 3) / 12) * 12 + (idx - 3) % 12;
+        const int slot = idx < 4 ? MOM_SX + 4 * jj + idx : MOM_SXX + (4 * jj + (idx - 4) / 12) * 12 + (idx - 4) % 12;
         atomicAdd(&out[(blockIdx.x % STAT_REP) * 256 + slot], v);
     }
 }
@@ -3418,7 +3435,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     const bool mom0 = fuse0 && e->fuse_gin0 != 2 && !e->reduce_fn;
     if (mom0) {
         Timed t(e, "gin0_moments");
-        hipLaunchKernelGGL(k_gin0_moments, dim3(e->num_cu * 4), dim3(256), 0, e->stream, N, T, (const float *)tasks_fea, ell_col, ell_val, st + 0 * STAT_REP * 256);
+        hipLaunchKernelGGL(k_gin0_moments, dim3(e->num_cu * 2), dim3(256), 0, e->stream, N, T, (const float *)tasks_fea, ell_col, ell_val, st + 0 * STAT_REP * 256);
         if ((rrc = reduce_stats(e, st + 0 * STAT_REP * 256))) return rrc;
     } else if (!(e->f32_products & 8)) {   // layer 0 / linear 0 with aggregation of the raw features, on the producer/consumer product kernel
         GemmArgs a = gemm_args(nullptr, N, nullptr, W(P + "mlps.0.linears.0.bias"), fuse0 ? nullptr : e->zA);
