@@ -751,7 +751,11 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             const int tb = (PT(tile) * 16 - base_row) * HD + c4;  // (neighbour offsets are relative to the tile and may be negative; the row relative to base_row is not)
 #pragma unroll
             for (int p = 0; p < 8; p++) {
-                const int ox = row_pick(E.ox, p), oy = row_pick(E.oy, p);
+                int ox = row_pick(E.ox, p), oy = row_pick(E.oy, p);
+#ifdef X6_ABL_NB                            // timing ablation (wrong results): MTFJSP_GEMM_DBG & 32: the first neighbour is the row itself, & 64: the second
+                if (A.dbg & 32) ox = 2 * p + h;
+                if (A.dbg & 64) oy = 2 * p + h;
+#endif
                 nb.r0[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(inb + (unsigned)(tb + ox * HD) * 4u);
                 nb.r1[p < NA ? p : 0] = *reinterpret_cast<const float4 *>(inb + (unsigned)(tb + oy * HD) * 4u);
             }

@@ -11,7 +11,7 @@ import json
 import sys
 
 FAMILY = {
-    "void k_gemm_x6<1>": "gin_gemm_bn_relu", "void k_gemm_x6<2>": "gin_gemm_agg", "void k_gemm_x6<3>": "gin0_agg_linear12",
+    "void k_gemm_x6<1>": "gin_gemm_bn_relu", "void k_gemm_x6<2>": "gin_gemm_agg", "void k_gemm_x6<3>": "gin0_agg_linear12", "void k_gemm_x6<4>": "gin0_bn_gemm", "k_gin0_moments": "gin0_moments",
     "void k_gemm16p<1>": "gin_gemm_bn_relu", "void k_gemm16p<2>": "gin_gemm_agg", "void k_env_reg<float>": "env_step", "void k_env_grp16<float>": "env_step", "void k_env_grp4<float>": "env_step", "void k_env_grp16x2<float>": "env_step", "void k_env_grp4x2<float>": "env_step", "void k_env_step_grp<float>": "env_step",
     "void k_headsx_gat3x_headsx": "heads_gat3_heads", "k_headsx_gat3x_headsx": "heads_gat3_heads", "k_headsx_values": "heads_values", "k_headsx_gat3x": "heads_gat3", "k_heads": "heads", "k_gat3": "gat3", "void k_gin0<float>": "gin0_agg_linear12", "k_job_pool_gather": "job_pool_gather",
     "void k_mfea1<float>": "mfea1", "k_gin_res": "gin_resident", "void k_env_reset<float>": "env_reset", "k_gae": "gae", "k_snapshot": "snapshot",
