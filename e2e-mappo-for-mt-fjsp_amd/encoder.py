@@ -158,7 +158,7 @@ class Encoder:
     def set_product_mode(self, f32_instruction_mask=0):
         """0 (default): 128x128 products on the 16-bit matrix cores from split f32 operands (f32-accurate: include/mtfjsp.h);
         bits select the f32 matrix instruction instead (1 GIN products, 2 GAT passes, 4 heads, 8 first GIN Linear on the VALU) —
-        the A/B reference; 16 (not a numerics choice): the GIN encoder as six streaming launches even where the register-resident
+        the A/B reference; 16 (not a numerics choice): the GIN encoder as its streaming launches even where the register-resident
         single-launch kernel is eligible (check() tells which one runs)"""
         capi.check(self.L.mtfjsp_encoder_set_product_mode(self.h, int(f32_instruction_mask)), self.h, enc=True)
 
@@ -192,7 +192,7 @@ class Encoder:
         """synchronise and raise if a forward failed asynchronously (a bounded wait of the single-launch GIN kernel's grid-wide statistics exchange timed out:
         MtfjspError with code capi.ERR_RETRY — the handle has then switched to the streaming launches and whatever was enqueued
         since the failed launch has to be recomputed; the forwards poll the same condition on entry without synchronising);
-        -> True when that kernel is in use for this shape, False when the six streaming launches are"""
+        -> True when that kernel is in use for this shape, False when the streaming launches are"""
         r = C.c_int32(0)
         capi.check(self.L.mtfjsp_encoder_check(self.h, C.byref(r)), self.h, enc=True)
         return bool(r.value)

@@ -329,7 +329,7 @@ int mtfjsp_encoder_set_bn_mode(mtfjsp_encoder_t e, int32_t per_instance);
  * synchronises its stream and calls fn(user, sums, count): `sums` is DEVICE memory holding `count` doubles, which the callback
  * replaces by their element-wise sum over the shards (e.g. one all-reduce) and returns 0 once that is in place.
  * global_batch = instances of all shards together (>= this handle's batch).  7 calls per actor pair forward; the GIN encoder
- * then runs as its six streaming launches (the single-launch kernel cannot exchange data mid-launch).  fn = NULL: off.  Per-shard
+ * then runs as its streaming launches (the single-launch kernel cannot exchange data mid-launch).  fn = NULL: off.  Per-shard
  * statistics (the default) are what DESIGN.md §7 describes: each GPU behaves like a reference run with env_batch = its shard. */
 typedef int (*mtfjsp_stats_reduce_fn)(void *user, double *sums, int32_t count);
 int mtfjsp_encoder_set_stats_reduce(mtfjsp_encoder_t e, mtfjsp_stats_reduce_fn fn, void *user, int64_t global_batch);
@@ -382,7 +382,7 @@ int mtfjsp_hostgen_transport(uint32_t *key, int32_t *pos, int64_t samples, int32
  * resident at once (one per CU), which another process or another stream using the same GPU can prevent — not a hang but a
  * time-out.  The kernel then sets a host-mapped word that EVERY job-actor / global-critic forward polls on entry (a plain host
  * read, no synchronisation) and that this call reads after synchronising: the first call to see it returns MTFJSP_ERR_RETRY,
- * switches the handle to the six streaming launches (slower, no co-residency requirement) and leaves the caller to recompute what
+ * switches the handle to the streaming launches (slower, no co-residency requirement) and leaves the caller to recompute what
  * it enqueued since the failed launch (the Python rollout restarts the episode and discards the trajectory buffer).  A later
  * mtfjsp_encoder_check re-runs the residency census on the idle stream and re-enables the single launch when it passes.
  * *gin_resident_out (may be NULL) = 1 when the single-launch kernel is in use for this handle (shape eligible, census passed in
@@ -408,7 +408,8 @@ int mtfjsp_encoder_peek_nodes_host(mtfjsp_encoder_t e, float *out_host, int64_t 
 int mtfjsp_encoder_resident_failures(mtfjsp_encoder_t e, int64_t *count_out);
 int mtfjsp_encoder_timing_begin(mtfjsp_encoder_t e);
 int mtfjsp_encoder_timing_end(mtfjsp_encoder_t e, double *ms_total, int64_t *launches);
-/* per kernel family (between begin and the next begin): "gin0_agg_linear12", "gin_gemm_bn_relu", "gin_gemm_agg",
+/* per kernel family (between begin and the next begin): "gin0_agg_linear12" (or, round 6, "gin0_moments" / "gin0_stats_only" + "gin0_bn_gemm":
+ * the first Linear's output formed by the second launch's producers instead of stored), "gin_gemm_bn_relu", "gin_gemm_agg",
  * "job_pool_gather", "heads", "head_gemm", "gat3", "mach_bn_pool", "sample", "small", "gin_inst", "gat_inst", "gin_resident" */
 int mtfjsp_encoder_timing_query(mtfjsp_encoder_t e, const char *family, double *ms_total, int64_t *launches);
 
