@@ -61,7 +61,14 @@ struct GemmArgs {
     const float *bias0;     // z0 = Linear0(aggregated raw features) of their tile themselves (f32 features), then BatchNorm + ReLU as PRO_BNRELU
     const float *W0;        // PRO_GIN0BN, moments mode (non-NULL): the first Linear's weight [128,12]; pro_stats then holds k_gin0_moments' sums (MOM_* below) and the
                             // BatchNorm statistics of z0 = W0 x + b follow from them: sum z = w.Sx + n b, sum z^2 = w'Sxx w + 2 b w.Sx + n b^2 (f64)
-    double *epi_stats;      // EPI_STATS: [STAT_REP][256] accumulated with atomics (zeroed by the host per forward)
+    double *epi_stats;      // EPI_STATS: [STAT_REP][256] accumulated with atomics (zeroed by the host per forward); NULL: no sums
+    // PRO_BNRELU, pooling epilogue (round 6; out == NULL): the output is the LAST Linear's — it is normalised with the BatchNorm sums a statistics-only pass
+    // of the same product left in pool_stats, ReLU, and only its per-instance column means (gcn:192) and the candidates' rows (ac:197-207) leave the chip
+    float *pooled;          // [B,128], zero on entry: partial means are added (at most two contributions per element wherever a workgroup's rows span an instance)
+    float *cand_feat;       // [B*J,128] or NULL
+    const int *cand;        // [B,J]: candidate j of an instance is taken from job j's block of rows [j M, (j+1) M) (k_cand_fixup serves any other)
+    int pool_J;
+    const double *pool_stats; const float *pool_gamma, *pool_beta; double pool_inv_rows;
     unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
     int dbg;                // diagnostic build only: timing ablations of k_gemm16p (1 no stores/sums, 2 no row requests/transform)
     unsigned *range_flag;             // host-mapped word: raised when the BatchNorm sums this launch consumes are not numbers (an f16 operand piece overflowed upstream; ReLU would hide the NaN)
@@ -606,6 +613,8 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     double *s_stat = reinterpret_cast<double *>(smem + 8 * X6_TILE);   // column sums | sums of squares of this workgroup
     float *s_bn = reinterpret_cast<float *>(s_stat + 2 * HD);     // scale | shift
     float *s_b0 = reinterpret_cast<float *>(smem + 8 * X2_TILE);  // PRO_GIN0BN: the first Linear's bias (the two-plane tiles leave the rest of the tile area free)
+    float *s_bn2 = reinterpret_cast<float *>(smem + 8 * X2_TILE + 2048);   // PRO_BNRELU, pooling epilogue: scale | shift of the output's BatchNorm
+    int *s_cand = reinterpret_cast<int *>(smem + 8 * X2_TILE + 3072);      // ... and [2 buffers][4 tiles][16 rows]: the candidate (row inside its instance) of the job each row belongs to
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int ntiles = (A.N + 15) / 16;
     const int per = (ntiles + gridDim.x - 1) / gridDim.x;
@@ -686,6 +695,18 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             const float sc = rstd * bga;
             s_bn[tid] = sc;
             s_bn[HD + tid] = bbe - (float)mean * sc;
+        }
+        if (CONS && PRO == PRO_BNRELU && A.pooled && tid < HD) {  // the pooling epilogue's BatchNorm of this launch's OUTPUT (one exposed round trip per launch)
+            double su = 0, sq = 0;
+#pragma unroll
+            for (int r = 0; r < STAT_REP; r++) { su += A.pool_stats[r * 256 + tid]; sq += A.pool_stats[r * 256 + HD + tid]; }
+            if (A.range_flag && (su != su || sq != sq)) __hip_atomic_store(A.range_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const double mean = su * A.pool_inv_rows;
+            double var = sq * A.pool_inv_rows - mean * mean;
+            if (var < 0) var = 0;
+            const float sc = (1.0f / sqrtf((float)(var + BN_EPS))) * A.pool_gamma[tid];
+            s_bn2[tid] = sc;
+            s_bn2[HD + tid] = A.pool_beta[tid] - (float)mean * sc;
         }
         if (CONS && tid < 2 * HD) s_stat[tid] = 0.0;
         if (CONS && PRO == PRO_GIN0BN && tid >= HD && tid < 2 * HD) s_b0[tid - HD] = A.bias0 ? A.bias0[tid - HD] : 0.f;
@@ -967,21 +988,41 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         const int lastm1 = last - 1;
         auto CL = [&](int t) __attribute__((always_inline)) { return t < lastm1 ? t : lastm1; };
         if (PRO == PRO_AGG) { fetch_ell(el[0], CL(t0)); fetch_ell(el[1], CL(t0 + 4)); fetch_ell(el[2], CL(t0 + 8)); }
+        // pooling epilogue: the candidate index the consumers compare each row of a tile with travels with the tile — requested by the producers with the
+        // rows, handed over in LDS.  (In the consumers it would be a vector-memory load among their stores and atomics: every comparison would wait for
+        // all of them.)  Always requested, from a valid address, so that no request sits behind a branch.
+        const bool pcand = PRO == PRO_BNRELU && A.pooled && A.cand_feat;
+        const int *candp = pcand ? A.cand : reinterpret_cast<const int *>(A.in);
+        const int qT = A.T > 0 ? A.T : 1, qJ = pcand ? A.pool_J : 0, qM = qJ > 0 ? qT / qJ : qT;
+        const float qinvT = 1.0f / (float)qT;
+        const unsigned qinvM = (unsigned)((0x100000000ull + (unsigned)qM - 1) / (unsigned)qM);
+        auto request_cand = [&](int &cv, int tile) __attribute__((always_inline)) {
+            int row = PT(tile) * 16 + m; row = row < A.N ? row : A.N - 1;
+            int b = (int)((float)row * qinvT);
+            const int rem = row - b * qT;
+            b += rem >= qT ? 1 : rem < 0 ? -1 : 0;
+            const int v = row - b * qT;
+            cv = candp[pcand ? (size_t)b * qJ + (int)__umulhi((unsigned)v, qinvM) : (size_t)0];
+        };
+        int cndA = -1, cndB = -1;
         request_rows(preA, CL(t0));
+        if (PRO == PRO_BNRELU) request_cand(cndA, CL(t0));
         if (PRO == PRO_AGG) request_nb(nbA, el[0], CL(t0));
         request_rows(preB, CL(t0 + 4));
+        if (PRO == PRO_BNRELU) request_cand(cndB, CL(t0 + 4));
         if (PRO == PRO_AGG && X6_NB_AHEAD == 2) request_nb(nbB, el[1], CL(t0 + 4));
         stage_scale_shift(std::false_type{});
         LDS_BARRIER();
         STAMP(0);
         const float sc0 = s_bn[c4], sc1 = s_bn[c4 + 1], sc2 = s_bn[c4 + 2], sc3 = s_bn[c4 + 3];
         const float sh0 = s_bn[HD + c4], sh1 = s_bn[HD + c4 + 1], sh2 = s_bn[HD + c4 + 2], sh3 = s_bn[HD + c4 + 3];
-        auto produce = [&](float4 (&pre)[8], NbRows &nb, auto Kc, int s) __attribute__((always_inline)) {
+        auto produce = [&](float4 (&pre)[8], NbRows &nb, int &cv, auto Kc, int s) __attribute__((always_inline)) {
             constexpr int K = decltype(Kc)::value;                // s & 3: the step's ELL slot
             const EllSlot &E = el[K];
             const int tile = t0 + 4 * s;
             if (tile < last) {
                 unsigned char *dst = s_tiles + ((s & 1) * 4 + pw) * XT + h * X6_ROWB + j * 8;
+                if (PRO == PRO_BNRELU && pcand && lane < 16) s_cand[((s & 1) * 4 + pw) * 16 + lane] = cv;
 #pragma unroll
                 for (int p = 0; p < 8; p++) {
                     // BatchNorm of a row quad as two packed FMAs, ReLU per element (no packed f32 max on this target)
@@ -1016,16 +1057,17 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             if (PRO == PRO_AGG) fetch_ell(el[(K + 3) & 3], CL(tile + 12));
             if (PRO == PRO_AGG && X6_NB_AHEAD == 1) request_nb(nb, el[(K + 1) & 3], CL(tile + 4));    // (needed first at the next step: ahead of the rows of s+2)
             request_rows(pre, CL(tile + 8));
+            if (PRO == PRO_BNRELU) request_cand(cv, CL(tile + 8));
             if (PRO == PRO_AGG && X6_NB_AHEAD == 2) request_nb(nb, el[(K + 2) & 3], CL(tile + 8));
             STAMP(1);
             LDS_BARRIER();
             STAMP(4);
         };
         for (int s = 0; s < nsteps_c; s += 4) {
-            produce(preA, nbA, std::integral_constant<int, 0>{}, s);
-            produce(preB, nbB, std::integral_constant<int, 1>{}, s + 1);
-            produce(preA, nbA, std::integral_constant<int, 2>{}, s + 2);
-            produce(preB, nbB, std::integral_constant<int, 3>{}, s + 3);
+            produce(preA, nbA, cndA, std::integral_constant<int, 0>{}, s);
+            produce(preB, nbB, cndB, std::integral_constant<int, 1>{}, s + 1);
+            produce(preA, nbA, cndA, std::integral_constant<int, 2>{}, s + 2);
+            produce(preB, nbB, cndB, std::integral_constant<int, 3>{}, s + 3);
         }
         LDS_BARRIER();                                            // the consumers' last step
         }
@@ -1064,10 +1106,55 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
         const f32x4 wsinv4 = {wsinv, wsinv, wsinv, wsinv};
         const unsigned char *xa0 = s_tiles + m * X6_ROWB + 16 * q; // operand fragment (slot t, plane p, k-step ks): + t*XT + p*X6_PLANE + 64*ks
         unsigned char *s_tr = smem + X6_TR_OFF + cg * 2 * X6_TRB;  // this wave's two output transposition buffers
+        // ---- pooling epilogue (PRO_BNRELU, A.pooled): BatchNorm + ReLU of the output tile in registers; a lane keeps the running column sums of ITS row slot
+        // (m) for the instance the wave is in, the 16 slots are folded and added to pooled[] when the instance changes (and at the end of the range)
+        const bool pool = PRO == PRO_BNRELU && A.pooled != nullptr;
+        f32x4 sc2[2], sh2[2], psum[2];
+        int cur = 0, cur_lo = 0, cur_hi = 0;                        // the instance the wave is in and its rows [cur_lo, cur_hi) (wave-uniform)
+        const int pT = A.T > 0 ? A.T : 1, pJ = A.pool_J, pM = pJ > 0 ? pT / pJ : pT;
+        const float invTf = 1.0f / (float)pT;
+        const unsigned invMu = (unsigned)((0x100000000ull + (unsigned)pM - 1) / (unsigned)pM);      // v / M = umulhi(v, invMu) for v < 65536
+#pragma unroll
+        for (int c = 0; c < 2; c++) { sc2[c] = f32x4{0.f, 0.f, 0.f, 0.f}; sh2[c] = sc2[c]; psum[c] = sc2[c]; }
+        if (pool) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float4 a = *reinterpret_cast<const float4 *>(s_bn2 + 32 * cg + 16 * c + 4 * q), b = *reinterpret_cast<const float4 *>(s_bn2 + HD + 32 * cg + 16 * c + 4 * q);
+                sc2[c] = f32x4{a.x, a.y, a.z, a.w}; sh2[c] = f32x4{b.x, b.y, b.z, b.w};
+            }
+        }
+        // row -> (instance, row inside it) for rows < 2^24: the f32 quotient is off by at most one
+        auto inst_of = [&](int row, int &v) __attribute__((always_inline)) {
+            int b = (int)((float)row * invTf);
+            int rem = row - b * pT;
+            b += rem >= pT ? 1 : rem < 0 ? -1 : 0;
+            v = row - b * pT;
+            return b;
+        };
+        auto pool_flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const float t = row_sum16(psum[c][i]);
+                    if (m == 0) atomicAdd(&A.pooled[(size_t)cur * HD + 32 * cg + 16 * c + 4 * q + i], t * invTf);     // sparse mm with 1/T entries (gcn:192)
+                }
+        };
+        if (pool && nsteps > 0) {                                 // the instance of the first row this wave meets (rev: the last valid row of its last tile)
+            int r0 = PT(first) * 16 + (A.rev ? 15 : 0); r0 = r0 < A.N ? r0 : A.N - 1;
+            int v0;
+            cur = __builtin_amdgcn_readfirstlane(inst_of(r0, v0));
+            cur_lo = cur * pT; cur_hi = cur_lo + pT;
+        }
         LDS_BARRIER();                                            // step 0: the producers fill buffer 0
         STAMP(4);
         for (int s = 1; s <= nsteps_c; s++) {
             if (s > nsteps) { LDS_BARRIER(); continue; }           // padding step: nothing was produced
+            int cnd[4] = {-1, -1, -1, -1};                         // the candidates of this step's rows (from the producers, with the planes)
+            if (pool && A.cand_feat) {
+#pragma unroll
+                for (int t = 0; t < 4; t++) cnd[t] = s_cand[(((s - 1) & 1) * 4 + t) * 16 + m];
+            }
             const int tb = first + 4 * (s - 1);
             const unsigned char *xa = xa0 + ((s - 1) & 1) * 4 * XT;
             auto tiles4 = [&](auto FULLc) __attribute__((always_inline)) {
@@ -1117,6 +1204,41 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                     const int ptile = FULL || tb + t < last ? PT(tb + t) : 0;
                     const int row = ptile * 16 + m;
                     const bool ok = FULL || row < A.N;
+                    if (pool) {                                   // (workgroup-uniform)
+                        f32x4 hv[2];
+#pragma unroll
+                        for (int c = 0; c < 2; c++) {
+                            const f32x4 y = __builtin_elementwise_fma(acc[c], sc2[c], sh2[c]);
+                            hv[c] = f32x4{fmaxf(y[0], 0.f), fmaxf(y[1], 0.f), fmaxf(y[2], 0.f), fmaxf(y[3], 0.f)};
+                        }
+                        const int R0 = ptile * 16;
+                        int b = cur, v = row - cur_lo;
+                        if (FULL && R0 >= cur_lo && R0 + 16 <= cur_hi) {             // the whole tile inside the current instance (scalar test): plain sums
+#pragma unroll
+                            for (int c = 0; c < 2; c++) psum[c] = psum[c] + hv[c];
+                        } else {
+                            // T >= 16: a tile holds rows of the current instance and of at most one other — the next one in processing order
+                            const bool in_cur = row >= cur_lo && row < cur_hi;
+                            const float k0 = (ok && in_cur) ? 1.0f : 0.0f;
+#pragma unroll
+                            for (int c = 0; c < 2; c++) psum[c] = __builtin_elementwise_fma(hv[c], f32x4{k0, k0, k0, k0}, psum[c]);
+                            const bool other = A.rev ? R0 < cur_lo : (R0 + 16 > cur_hi && cur_hi < A.N);     // (wave-uniform; valid rows of it exist)
+                            if (other) {
+                                pool_flush();
+                                cur += A.rev ? -1 : 1; cur_lo = cur * pT; cur_hi = cur_lo + pT;
+                                const float k1 = (ok && !in_cur) ? 1.0f : 0.0f;
+#pragma unroll
+                                for (int c = 0; c < 2; c++) psum[c] = hv[c] * f32x4{k1, k1, k1, k1};
+                                if (!in_cur) { b = cur; v = row - cur_lo; }
+                            }
+                        }
+                        if (A.cand_feat && ok && cnd[t] == v) {                                      // candidate gather (ac:197-207)
+                            float *d = A.cand_feat + ((size_t)b * pJ + (int)__umulhi((unsigned)v, invMu)) * HD + 32 * cg + 4 * q;
+#pragma unroll
+                            for (int c = 0; c < 2; c++) *reinterpret_cast<float4 *>(d + 16 * c) = make_float4(hv[c][0], hv[c][1], hv[c][2], hv[c][3]);
+                        }
+                        continue;
+                    }
                     // stores as WHOLE 128-byte lines: the accumulator layout gives a lane two 16-byte chunks (q and 4 + q) of row m's 128
                     // bytes of this wave, i.e. 16 rows x 64 bytes per store instruction — measured 2.35 TB/s against 3.24 TB/s for 8
                     // rows x 128 bytes (tools/ubench/store_patterns.hip).  The wave's tile goes through a private LDS buffer
@@ -1169,8 +1291,9 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
             LDS_BARRIER();                                        // buffer (s-1)&1 may be overwritten; buffer s&1 is complete
             STAMP(7);
         }
+        if (pool && nsteps > 0) pool_flush();
     }
-    if (tid < 2 * HD) atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], s_stat[tid]);
+    if (A.epi_stats && tid < 2 * HD) atomicAdd(&A.epi_stats[(blockIdx.x % STAT_REP) * 256 + tid], s_stat[tid]);
 #ifdef MTFJSP_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_last)::"memory");
@@ -2172,6 +2295,50 @@ __global__ __launch_bounds__(256) void k_gin0(int N, int T, const OBS *tfea, con
 #ifndef POOL_INFLIGHT
 #define POOL_INFLIGHT 8                        // rows per batch and thread (two batches in flight)
 #endif
+// Pooling epilogue of the last streaming product (k_gemm_x6, GemmArgs::pooled): that launch takes candidate j of an instance from job j's block of rows
+// — where the environment's candidates always lie (ppo:306-309) — and its output is not stored.  A caller-made candidate outside its job's block is served
+// here, one thread per such slot, by forming that one row again with f32 instructions: h4 = relu(bn4(z4[row])), z5 = W5 h4 + b5, relu(bn5(z5)).  Never on the
+// rollout path (the launch then only reads the candidate array).
+__global__ __launch_bounds__(128) void k_cand_fixup(int B, int T, int J, const int *cand, const float *z4, const double *st4, const float *g4, const float *b4,
+                                                    const float *Wt5 /*[k][n]*/, const float *bias5, const double *st5, const float *g5, const float *b5,
+                                                    double inv_rows, float *cand_feat)
+{
+    __shared__ int s_need[128];
+    __shared__ float s_h4[HD];
+    const int tid = threadIdx.x, slot = blockIdx.x * 128 + tid, M = T / J;
+    int need = -1;
+    if (slot < B * J) {
+        const int b = slot / J, j = slot - b * J, c = cand[slot];
+        if (c >= 0 && c < T && c / M != j) need = b * T + c;      // the row this slot wants
+    }
+    s_need[tid] = need;
+    if (__syncthreads_or(need >= 0) == 0) return;                 // (the rollout path: nothing to do)
+    // column tid of both BatchNorms
+    float sc4, sh4, sc5, sh5;
+    {
+        double su = 0, sq = 0;
+        for (int r = 0; r < STAT_REP; r++) { su += st4[r * 256 + tid]; sq += st4[r * 256 + HD + tid]; }
+        double mean = su * inv_rows, var = sq * inv_rows - mean * mean;
+        if (var < 0) var = 0;
+        sc4 = (1.0f / sqrtf((float)(var + BN_EPS))) * g4[tid]; sh4 = b4[tid] - (float)mean * sc4;
+        su = 0; sq = 0;
+        for (int r = 0; r < STAT_REP; r++) { su += st5[r * 256 + tid]; sq += st5[r * 256 + HD + tid]; }
+        mean = su * inv_rows; var = sq * inv_rows - mean * mean;
+        if (var < 0) var = 0;
+        sc5 = (1.0f / sqrtf((float)(var + BN_EPS))) * g5[tid]; sh5 = b5[tid] - (float)mean * sc5;
+    }
+    for (int i = 0; i < 128; i++) {
+        const int row = s_need[i];                                // (uniform)
+        if (row < 0) continue;
+        __syncthreads();
+        s_h4[tid] = fmaxf(__builtin_fmaf(z4[(size_t)row * HD + tid], sc4, sh4), 0.f);
+        __syncthreads();
+        float z = bias5 ? bias5[tid] : 0.f;
+        for (int k = 0; k < HD; k++) z = __builtin_fmaf(s_h4[k], Wt5[k * HD + tid], z);
+        cand_feat[((size_t)blockIdx.x * 128 + i) * HD + tid] = fmaxf(__builtin_fmaf(z, sc5, sh5), 0.f);
+    }
+}
+
 // Sums and second moments of the aggregated raw features x (gcn:125-153 on the [N,12] task features, the first Linear's input) over all rows: the
 // BatchNorm statistics of z0 = W0 x + b follow from them exactly (k_gemm_x6<PRO_GIN0BN>, moments mode), so no launch has to form z0 for its sums alone.
 // A row is a quad of lanes: lane j < 3 of it reads features 4j..4j+3 of the row and of its <= 2 neighbours and aggregates them (the same f64 operations
@@ -2841,6 +3008,7 @@ struct mtfjsp_encoder {
     // issue (~100 us per launch even with no output at all), not by memory
     int fuse_pair = getenv("MTFJSP_FUSE_PAIR") ? atoi(getenv("MTFJSP_FUSE_PAIR")) : 0;
     int stream_order = getenv("MTFJSP_NO_STREAM_ORDER") ? 0 : 1;   // streaming GIN launches: alternating row direction + non-temporal input reads (A/B switch)
+    int fuse_pool = getenv("MTFJSP_FUSE_POOL") ? atoi(getenv("MTFJSP_FUSE_POOL")) : 1;   // run_gin: the last Linear's output pooled / gathered in a second pass' epilogue instead of stored
     int fuse_gin0 = getenv("MTFJSP_FUSE_GIN0") ? atoi(getenv("MTFJSP_FUSE_GIN0")) : 1;   // run_gin: the first Linear's output formed again by the second launch's producers instead of stored
     int pool_s = getenv("MTFJSP_POOL_S") ? atoi(getenv("MTFJSP_POOL_S")) : 4;      // k_job_pool_gather: blocks per row range of the last product (0: plain instance order)
     int stream_nt = getenv("MTFJSP_STREAM_NT") ? atoi(getenv("MTFJSP_STREAM_NT")) : 5;   // which readers use non-temporal loads: 1 BatchNorm+ReLU products, 2 aggregation product, 4 pool / gather
@@ -3536,6 +3704,35 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     if (pair) bn_gemm_pair(z3, e->zB, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5, 1);
     else {
     bn_gemm(e->zB, e->zA, 3, "mlps.1.batch_norms.0", "mlps.1.linears.1", 4, 1);
+    // Round 6 (e->fuse_pool; MTFJSP_FUSE_POOL=0 switches it off): the LAST Linear's output is not stored either.  A statistics-only pass of the product
+    // leaves its BatchNorm sums, a second pass forms it again and keeps only what the heads read — the per-instance means and the candidates' rows — in
+    // its epilogue: two passes without output instead of a product with output + k_job_pool_gather's read of it
+    const bool fuse_pool = e->fuse_pool && h_pooled && !h_nodes && T >= 16 && T < 65536 && (!candidate || (J > 0 && T % J == 0)) && (size_t)N < ((size_t)1 << 24) &&
+                           e->wx6.count(P + "mlps.1.linears.2.weight") && !(e->f32_products & 1);
+    if (fuse_pool) {
+        const std::string lin = "mlps.1.linears.2", bn = "mlps.1.batch_norms.1";
+        GemmArgs a = gemm_args(e->zA, N, WT(P + lin + ".weight"), W(P + lin + ".bias"), nullptr);
+        a.rev = 0; a.nt = 0;                                      // (read twice: plain loads; the second pass walks back from the end)
+        a.pro_stats = st + 4 * STAT_REP * 256; a.pro_gamma = W(P + bn + ".weight"); a.pro_beta = W(P + bn + ".bias"); a.pro_inv_rows = invN;
+        a.epi_stats = st + 5 * STAT_REP * 256;
+        a.Wx6 = e->wx6.at(P + lin + ".weight"); a.w_sinv = e->wx6_sinv.at(P + lin + ".weight");
+        launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_stats_only");
+        if (!rrc) rrc = reduce_stats(e, st + 5 * STAT_REP * 256);
+        if (rrc) return rrc;
+        HIPCHK(e, hipMemsetAsync(h_pooled, 0, (size_t)B * HD * sizeof(float), e->stream));
+        a.rev = so ? 1 : 0; a.nt = so && (e->stream_nt & 1);
+        a.epi_stats = nullptr;
+        a.T = T; a.pooled = h_pooled; a.cand_feat = candidate ? cand_feat : nullptr; a.cand = candidate; a.pool_J = candidate ? J : 0;
+        a.pool_stats = st + 5 * STAT_REP * 256; a.pool_gamma = W(P + "batch_norms.1.weight"); a.pool_beta = W(P + "batch_norms.1.bias"); a.pool_inv_rows = invN;
+        launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_pool");
+        if (candidate) {
+            Timed t(e, "cand_fixup");
+            hipLaunchKernelGGL(k_cand_fixup, dim3((B * J + 127) / 128), dim3(128), 0, e->stream, B, T, J, candidate, e->zA, st + 4 * STAT_REP * 256, W(P + bn + ".weight"), W(P + bn + ".bias"),
+                               WT(P + lin + ".weight"), W(P + lin + ".bias"), st + 5 * STAT_REP * 256, W(P + "batch_norms.1.weight"), W(P + "batch_norms.1.bias"), invN, cand_feat);
+        }
+        HIPCHK(e, hipGetLastError());
+        return MTFJSP_OK;
+    }
     bn_gemm(e->zA, e->zB, 4, "mlps.1.batch_norms.1", "mlps.1.linears.2", 5, 0);
     }
     if (rrc) return rrc;

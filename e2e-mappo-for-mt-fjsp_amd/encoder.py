@@ -15,7 +15,7 @@ import torch
 from . import capi
 
 H = 128
-FAMILIES = ["gin0_agg_linear12", "gin0_stats_only", "gin0_moments", "gin0_bn_gemm", "gin_gemm_bn_relu", "gin_gemm_stats_only", "gin_gemm_pair", "gin_gemm_agg", "job_pool_gather", "heads", "head_gemm", "gat3", "mach_bn_pool",
+FAMILIES = ["gin0_agg_linear12", "gin0_stats_only", "gin0_moments", "gin0_bn_gemm", "gin_gemm_bn_relu", "gin_gemm_stats_only", "gin_gemm_pool", "cand_fixup", "gin_gemm_pair", "gin_gemm_agg", "job_pool_gather", "heads", "head_gemm", "gat3", "mach_bn_pool",
             "sample", "small", "gin_inst", "gat_inst", "gin_resident", "heads_gat3", "heads_gat3_heads"]
 
 

@@ -98,9 +98,11 @@ def test_streaming_order_switches_do_not_change_results(monkeypatch):
     # MTFJSP_FUSE_GIN0 — default 1: the first Linear's output is never stored; its BatchNorm sums come from the second moments of the 12 aggregated
     # features (k_gin0_moments) and the second launch's producers form it again.  2: the sums by a statistics-only launch instead — the same matrix
     # instructions on the same operands as 0, the two-launch form, so only the order of the sums' atomics differs: those two are held to a tenth of the bound.
+    # MTFJSP_FUSE_POOL — default 1: the last Linear's output is not stored either; a second pass of the product pools and gathers in its epilogue
+    # (0: product with output + k_job_pool_gather).
     for switches in ({}, {"MTFJSP_FUSE_GIN0": "0"}, {"MTFJSP_FUSE_GIN0": "2"}, {"MTFJSP_NO_STREAM_ORDER": "1"}, {"MTFJSP_POOL_S": "0", "MTFJSP_STREAM_NT": "0"},
-                     {"MTFJSP_NO_HEADS_HG8": "1"}):
-        for k in ("MTFJSP_NO_STREAM_ORDER", "MTFJSP_POOL_S", "MTFJSP_STREAM_NT", "MTFJSP_NO_HEADS_HG8", "MTFJSP_FUSE_GIN0"):
+                     {"MTFJSP_NO_HEADS_HG8": "1"}, {"MTFJSP_FUSE_POOL": "0"}, {"MTFJSP_FUSE_POOL": "0", "MTFJSP_FUSE_GIN0": "0"}):
+        for k in ("MTFJSP_NO_STREAM_ORDER", "MTFJSP_POOL_S", "MTFJSP_STREAM_NT", "MTFJSP_NO_HEADS_HG8", "MTFJSP_FUSE_GIN0", "MTFJSP_FUSE_POOL"):
             monkeypatch.delenv(k, raising=False)
         for k, v in switches.items():
             monkeypatch.setenv(k, v)
@@ -119,3 +121,45 @@ def test_streaming_order_switches_do_not_change_results(monkeypatch):
         np.testing.assert_allclose(o[1], outs[0][1], rtol=0, atol=2e-5 * scale)
         np.testing.assert_allclose(o[0], outs[0][0], rtol=0, atol=2e-5)
         np.testing.assert_allclose(o[2], outs[0][2], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("J,M,E,B", [(10, 10, 2, 333), (4, 6, 2, 50)])
+def test_pooling_epilogue_serves_any_candidate(monkeypatch, J, M, E, B):
+    """The pooling epilogue of the last streaming product (MTFJSP_FUSE_POOL, default) takes candidate j from job j's block of rows, where the
+    environment's candidates lie; a caller-made candidate elsewhere — another job's row, a row two slots share, a finished job's -1 — goes through
+    k_cand_fixup.  Same forward as the stored-output path (k_job_pool_gather) on a candidate array with all of those; T = 24 (J4M6) puts up to two
+    instances into a 16-row tile and an instance across workgroup ranges."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    T = J * M
+    ja, ma = enc_mod.random_init_weights(seed=5 + J)
+    _perturb(ja, ma, 9)
+    monkeypatch.setenv("MTFJSP_NO_RESIDENT_GIN", "1")                # (J4M6 would otherwise take the single-launch kernel)
+    ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=(ja, ma), collect=False)
+    for _ in range(T // 3):
+        ro.step()
+    env = ro.env
+    hm = ro.actor.enc.h_pooled_m.clone()
+    cand = env.candidate.cpu().numpy().copy()
+    rs = np.random.RandomState(3)
+    for b in range(0, B, 2):
+        j = rs.randint(J)
+        cand[b, j] = ((j + 1) % J) * M + rs.randint(M)                # a row of another job's block
+        cand[b, (j + 2) % J] = cand[b, j]                             # ... shared by two slots
+    cand_t = torch.as_tensor(cand.astype(np.int32)).cuda()
+    mask = torch.zeros_like(env.job_mask)
+    outs = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("MTFJSP_FUSE_POOL", fuse)
+        e = enc_mod.Encoder(J, M, B, obs_dtype="f32")
+        e.load_weights(ja, ma)
+        prob, h_o, job_v = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, cand_t, mask, hm)
+        torch.cuda.synchronize()
+        outs.append((prob.cpu().numpy().copy(), h_o.cpu().numpy().copy(), job_v.cpu().numpy().copy()))
+        e.close()
+    scale = max(1.0, float(np.abs(outs[0][1]).max()))
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-4)
