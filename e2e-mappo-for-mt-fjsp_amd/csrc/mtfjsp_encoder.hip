@@ -2347,7 +2347,7 @@ __global__ __launch_bounds__(128) void k_cand_fixup(int B, int T, int J, const i
 // no branch).  out: one [256]-double replica per workgroup % STAT_REP (MOM_*).
 __global__ __launch_bounds__(256) void k_gin0_moments(int N, int T, const float *tfea, const int *ell_col, const float *ell_val, double *out)
 {
-    __shared__ double s_part[4][3][52];
+    __shared__ double s_part[16][3][52];                            // [wave x DPP row][j][4 sums | 4 x 12 products]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 3, rs = lane >> 2, jf = j < 3 ? j : 0;
     double S[4][12], sx[4];
 #pragma unroll
@@ -2423,28 +2423,36 @@ __global__ __launch_bounds__(256) void k_gin0_moments(int N, int T, const float 
         body(f[0], e[0], it + 2);
         body(f[1], e[1], it + 3);
     }
-    // the 16 rows of a wave (lane bits 2..5), then the four waves, then one atomic per entry and workgroup
+    // The 4 rows of a 16-lane DPP row (lane bits 2, 3) are folded in registers — row_ror:4, row_ror:8: partners with the same j —, the 4 DPP rows x 4
+    // waves through LDS, then one atomic per entry and workgroup.  (As four __shfl_xor steps per value — 416 ds_bpermute with a wait each — this fold
+    // was a quarter of the kernel's time.)
+    auto dpp_d = [&](double x, auto Ctrl) __attribute__((always_inline)) {
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), decltype(Ctrl)::value, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), decltype(Ctrl)::value, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    };
+    auto fold4 = [&](double x) __attribute__((always_inline)) {
+        x += dpp_d(x, std::integral_constant<int, 0x124>{});
+        x += dpp_d(x, std::integral_constant<int, 0x128>{});
+        return x;
+    };
+    const int drow = lane >> 4;
 #pragma unroll
     for (int a = 0; a < 4; a++) {
+        const double t = fold4(sx[a]);
+        if ((lane & 15) < 3) s_part[wave * 4 + drow][j][a] = t;
 #pragma unroll
-        for (int off = 4; off < 64; off <<= 1) sx[a] += __shfl_xor(sx[a], off);
-#pragma unroll
-        for (int k = 0; k < 12; k++)
-#pragma unroll
-            for (int off = 4; off < 64; off <<= 1) S[a][k] += __shfl_xor(S[a][k], off);
-    }
-    if (lane < 3) {
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            s_part[wave][j][a] = sx[a];
-#pragma unroll
-            for (int k = 0; k < 12; k++) s_part[wave][j][4 + a * 12 + k] = S[a][k];
+        for (int k = 0; k < 12; k++) {
+            const double u = fold4(S[a][k]);
+            if ((lane & 15) < 3) s_part[wave * 4 + drow][j][4 + a * 12 + k] = u;
         }
     }
     __syncthreads();
     if (tid < 3 * 52) {
         const int jj = tid / 52, idx = tid % 52;
-        const double v = (s_part[0][jj][idx] + s_part[1][jj][idx]) + (s_part[2][jj][idx] + s_part[3][jj][idx]);
+        double v = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) v += s_part[w][jj][idx];
         const int slot = idx < 4 ? MOM_SX + 4 * jj + idx : MOM_SXX + (4 * jj + (idx - 4) / 12) * 12 + (idx - 4) % 12;
         atomicAdd(&out[(blockIdx.x % STAT_REP) * 256 + slot], v);
     }
