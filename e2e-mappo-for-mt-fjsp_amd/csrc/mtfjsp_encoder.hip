@@ -1042,9 +1042,15 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
                         const float dg = __builtin_bit_cast(float, row_pick(__builtin_bit_cast(int, E.dg), p));
                         const float inv = dg == 1.f ? 1.0f : dg == 2.f ? 0.5f : (1.0f / 3.0f);
                         float n0[4], n1[4];
+#ifdef X6_ABL_NB                            // timing ablation (wrong results): MTFJSP_GEMM_DBG & 128: the neighbour rows are requested but not normalised or added
+                        if (A.dbg & 128) { asm volatile("" :: "v"(nb.r0[pp].x), "v"(nb.r0[pp].w), "v"(nb.r1[pp].x), "v"(nb.r1[pp].w), "v"(wx), "v"(wy), "v"(inv)); }
+                        else
+#endif
+                        {
                         bnr4(nb.r0[pp], n0); bnr4(nb.r1[pp], n1);
 #pragma unroll
                         for (int i = 0; i < 4; i++) v[i] = __builtin_fmaf(wy, n1[i], __builtin_fmaf(wx, n0[i], v[i])) * inv;
+                        }
                     }
                     uint2 p0, p1;
                     split2x4m(v, p0, p1);
