@@ -163,3 +163,30 @@ def test_pooling_epilogue_serves_any_candidate(monkeypatch, J, M, E, B):
     np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=0, atol=2e-5 * scale)
     np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=0, atol=2e-5)
     np.testing.assert_allclose(outs[0][2], outs[1][2], rtol=1e-4, atol=1e-4)
+
+
+def test_adjacency_entries_in_either_order():
+    """The two in-edge entries of a row may come in either order (the environment writes the job edge first): the same forward to rounding (the
+    aggregation adds the two products in the other order)."""
+    import torch
+    import mtfjsp_amd  # noqa: F401
+    enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
+    rollout = import_module("e2e-mappo-for-mt-fjsp_amd.rollout")
+    J, M, E, B = 10, 10, 2, 200
+    ja, ma = enc_mod.random_init_weights(seed=21)
+    _perturb(ja, ma, 4)
+    ro = rollout.Rollout(J, M, E, B, policy="actor", obs_dtype="f32", weights=(ja, ma), collect=False)
+    for _ in range(45):
+        ro.step()
+    env = ro.env
+    hm = ro.actor.enc.h_pooled_m.clone()
+    col = env.ell_col.clone().view(-1, 2); val = env.ell_val.clone().view(-1, 2)
+    assert int((col[:, 1] >= 0).sum()) > 0                           # (machine edges exist: the swap moves them into the first entry)
+    col_sw = col.flip(1).contiguous().view_as(env.ell_col); val_sw = val.flip(1).contiguous().view_as(env.ell_val)
+    e = ro.actor.enc
+    a = [x.cpu().numpy().copy() for x in e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, env.candidate, env.job_mask, hm)]
+    b = [x.cpu().numpy().copy() for x in e.job_actor_forward(env.tasks_fea, col_sw, val_sw, env.candidate, env.job_mask, hm)]
+    scale = max(1.0, float(np.abs(a[1]).max()))
+    np.testing.assert_allclose(b[1], a[1], rtol=0, atol=2e-5 * scale)
+    np.testing.assert_allclose(b[0], a[0], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(b[2], a[2], rtol=1e-4, atol=1e-4)
