@@ -69,6 +69,7 @@ struct GemmArgs {
     const int *cand;        // [B,J]: candidate j of an instance is taken from job j's block of rows [j M, (j+1) M) (k_cand_fixup serves any other)
     int pool_J;
     const double *pool_stats; const float *pool_gamma, *pool_beta; double pool_inv_rows;
+    float *zero_f32; int zero_count;        // a buffer this launch clears on the way (the statistics-only pass in front of the pooling pass: h_pooled)
     unsigned long long *stamps;   // diagnostic build only (-DMTFJSP_STAMP): per-wave phase cycle sums [waves][8]
     int dbg;                // diagnostic build only: timing ablations of k_gemm16p (1 no stores/sums, 2 no row requests/transform)
     unsigned *range_flag;             // host-mapped word: raised when the BatchNorm sums this launch consumes are not numbers (an f16 operand piece overflowed upstream; ReLU would hide the NaN)
@@ -635,6 +636,8 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
     // requests in the order their data is needed (vmcnt retires in order): BatchNorm sums of the input first
     double bsu[STAT_REP], bsq[STAT_REP];
     float bga = 0.f, bbe = 0.f;
+    if (PRO == PRO_BNRELU && A.zero_f32)
+        for (int i = blockIdx.x * 512 + tid; i < A.zero_count; i += (int)gridDim.x * 512) A.zero_f32[i] = 0.f;
     const bool mom = PRO == PRO_GIN0BN && A.W0 != nullptr;        // (workgroup-uniform)
     double *s_mom = reinterpret_cast<double *>(smem + 8 * X2_TILE + HD * 4);      // PRO_GIN0BN, moments mode: [MOM_N] sums over the replicas
     double msum = 0;
@@ -3730,10 +3733,11 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
         a.pro_stats = st + 4 * STAT_REP * 256; a.pro_gamma = W(P + bn + ".weight"); a.pro_beta = W(P + bn + ".bias"); a.pro_inv_rows = invN;
         a.epi_stats = st + 5 * STAT_REP * 256;
         a.Wx6 = e->wx6.at(P + lin + ".weight"); a.w_sinv = e->wx6_sinv.at(P + lin + ".weight");
+        a.zero_f32 = h_pooled; a.zero_count = B * HD;              // (the second pass adds into it; no launch of its own for the clearing)
         launch_gemm<PRO_BNRELU, EPI_STATS>(e, a, "gin_gemm_stats_only");
+        a.zero_f32 = nullptr; a.zero_count = 0;
         if (!rrc) rrc = reduce_stats(e, st + 5 * STAT_REP * 256);
         if (rrc) return rrc;
-        HIPCHK(e, hipMemsetAsync(h_pooled, 0, (size_t)B * HD * sizeof(float), e->stream));
         a.rev = so ? 1 : 0; a.nt = so && (e->stream_nt & 1);
         a.epi_stats = nullptr;
         a.T = T; a.pooled = h_pooled; a.cand_feat = candidate ? cand_feat : nullptr; a.cand = candidate; a.pool_J = candidate ? J : 0;
