@@ -3619,7 +3619,7 @@ static int run_gin(mtfjsp_encoder *e, const std::string &pre, const void *tasks_
     // the producers of the second launch form z0 again from the raw features (PRO_GIN0BN): 838 MB of the forward's traffic at 819 200 rows replaced by
     // two reads of 52 MB.  f32 observations, split products (tests/test_encoder_sizes_gpu.py holds the forms against each other).
     const bool fuse0 = e->fuse_gin0 && !(e->f32_products & 9) && !pair && e->cfg.obs_dtype == MTFJSP_OBS_F32 &&
-                       (size_t)N < ((size_t)1 << 24);              // (row -> instance by an f32 reciprocal in k_gin0_moments and the PRO_GIN0BN producers: exact below 2^24 rows)
+                       (size_t)N < ((size_t)1 << 24) && T >= 8;    // (row -> instance by an f32 reciprocal + one correction in k_gin0_moments and the PRO_GIN0BN producers: right for quotients below 2^21)
     // (2: the sums by a statistics-only PRO_GIN0 launch — the two-launch form's bits; A/B and tests.  With a statistics reduction over several ranks
     // slot 0 must hold the SAME quantities on every rank, and a rank that has left the split products after a range failure sums z0 itself: no moments then)
     const bool mom0 = fuse0 && e->fuse_gin0 != 2 && !e->reduce_fn;
