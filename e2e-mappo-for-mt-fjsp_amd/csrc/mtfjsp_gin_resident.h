@@ -1034,6 +1034,7 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 #pragma unroll
         for (int rt = 0; rt < GR_NT; rt++) slot[rt] = (GR_ABL & 32) ? -1 : s_rowcand[rt * 32 + n_l];
         LDS_BARRIER();                                                // the plane buffers are no longer read
+        GR_STAMP_AT(28);
         // gcn:192 for one tile: rows 16h .. 16h+15 of column c from the transposition buffer, split at the instance boundary
         // pool_load: the requests (a chunk's 16 values of column c, its weights) — issued a tile's BatchNorm + ReLU ahead of pool_math, which
         // would otherwise meet an LDS round trip with nothing to cover it (one wave per SIMD)
@@ -1097,13 +1098,25 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
         });
         if (!(GR_ABL & 16)) { pool_load(GR_NT - 1); pool_math(GR_NT - 1); }
         asm volatile("" :: "v"(warm_word));
+        GR_STAMP_AT(29);
         LDS_BARRIER();
         const float invT = 1.0f / (float)T;
+        // (Round 6: an instance spans at most five 16-row chunks (T <= 65); all five partial sums are requested together — clamped, the ones beyond the
+        // instance not added — instead of a loop with a run-time trip count whose reads each waited for the one before: 2.0 -> ~0.7 us of this phase's tail.
+        // Same additions in the same order.)
+        static_assert(GR_MAXT <= 65, "an instance spans at most five 16-row chunks");
         for (int item = tid; item < ninst * HD; item += 256) {
             const int inst = item >> 7, col = item & (HD - 1);
             const int r0 = inst * T, k0 = r0 >> 4, k1 = (r0 + T - 1) >> 4;
+            float pv[5];
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) {
+                const int k = k0 + kk < k1 ? k0 + kk : k1;
+                pv[kk] = s_part[(2 * k + (16 * k < r0 ? 1 : 0)) * HD + col];     // a chunk that began in the previous instance: second segment
+            }
             float sum = 0.f;
-            for (int k = k0; k <= k1; k++) sum += s_part[(2 * k + (16 * k < r0 ? 1 : 0)) * HD + col];     // a chunk that began in the previous instance: second segment
+#pragma unroll
+            for (int kk = 0; kk < 5; kk++) sum = k0 + kk <= k1 ? sum + pv[kk] : sum;
             A.pooled[(size_t)inst0 * HD + item] = sum * invT;
         }
         if (A.candidate && s_flag[1]) {                               // (malformed input) slots that share a row: copy from the slot that was written
