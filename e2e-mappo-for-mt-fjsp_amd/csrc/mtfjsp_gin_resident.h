@@ -83,6 +83,9 @@
 #ifndef GR_FOLD_DPP
 #define GR_FOLD_DPP 1                     // 1: the per-lane column sums of a layer are folded over the 32 row lanes in registers (DPP reduce-scatter); 0: through LDS
 #endif
+#ifndef GR_STAT_ASM
+#define GR_STAT_ASM 0                     // (see stat2)
+#endif
 #ifndef GR_PK
 #define GR_PK 1                           // 1: two-wide f32 vector arithmetic (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32); 0: one instruction per element
 #endif
@@ -438,8 +441,16 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     // the two statistics updates of a column pair, pinned where they are written (hipcc would sink a whole layer's sums to their use)
     auto stat2 = [&](int i, float x, float y) __attribute__((always_inline)) {
         const f32x2 v = {x, y};
+#if GR_STAT_ASM == 1                        // the two updates written out as packed instructions (hipcc splits about half of them into four scalar ones):
+        asm volatile("v_pk_add_f32 %0, %2, %0\n\tv_pk_fma_f32 %1, %2, %2, %1" : "+v"(ts[i]), "+v"(tq[i]) : "v"(v));      // measured SLOWER, 110.7 against 108.6 us per launch (A/B, one box)
+#elif GR_STAT_ASM == 2                      // ... all four as scalar instructions: 137.9 us (the pairs are taken apart and put together again)
+        float s0 = ts[i][0], s1 = ts[i][1], q0 = tq[i][0], q1 = tq[i][1];
+        asm volatile("v_add_f32 %0, %4, %0\n\tv_add_f32 %1, %5, %1\n\tv_fma_f32 %2, %4, %4, %2\n\tv_fma_f32 %3, %5, %5, %3" : "+v"(s0), "+v"(s1), "+v"(q0), "+v"(q1) : "v"(x), "v"(y));
+        ts[i] = f32x2{s0, s1}; tq[i] = f32x2{q0, q1};
+#else
         ts[i] = gr_add2(ts[i], v); tq[i] = gr_fma2(v, v, tq[i]);
         asm volatile("" : "+v"(ts[i]), "+v"(tq[i]));
+#endif
     };
     auto stats_all = [&](const f32x16 &a) __attribute__((always_inline)) {
         if (GR_ABL & 4) return;
