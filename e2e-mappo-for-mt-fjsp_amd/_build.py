@@ -6,10 +6,15 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmtfjsp.so")
-SOURCES = ["mtfjsp_env.hip", "mtfjsp_encoder.hip", "mtfjsp_hostgen.cpp"]
+SOURCES = ["mtfjsp_env.hip", "mtfjsp_encoder.hip", "mtfjsp_gin_res.hip", "mtfjsp_hostgen.cpp"]
 # -ffp-contract=off: the scheduling state must follow the reference's binary64 operation order exactly
-FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-         "-Wall"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall"]
+# per translation unit (round 6, A/B on one box with the whole library built either way): hipcc's max-ILP scheduling strategy shortens the step kernels
+# (10.3 -> 10.0 us by HIP events at the headline shape, 27.5 -> 26.7 at J10M10) and k_gin_res (108.9 -> 107.6 us), lengthens the streaming product
+# kernels (k_gemm_x6: +6 us per launch) and the heads (+0.3 us): the single-launch GIN kernel has a translation unit of its own for that
+SOURCE_FLAGS = {"mtfjsp_env.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "mtfjsp_gin_res.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+if os.environ.get("MTFJSP_NO_SOURCE_FLAGS"):                       # (A/B builds: every translation unit with the common flags)
+    SOURCE_FLAGS = {}
 
 
 def hipcc():
@@ -29,15 +34,32 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _compile_link(out, extra_flags, verbose=False):
+    """one object per source (its own flags, in parallel), then the shared library"""
+    import concurrent.futures
+    import tempfile
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    with tempfile.TemporaryDirectory(prefix="mtfjsp_build_") as tmp:
+        def one(src):
+            obj = os.path.join(tmp, src + ".o")
+            cmd = [hipcc()] + FLAGS + SOURCE_FLAGS.get(src, []) + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            return obj
+        with concurrent.futures.ThreadPoolExecutor(len(srcs)) as ex:
+            objs = list(ex.map(one, srcs))
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return out
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc()] + FLAGS + srcs + ["-o", LIB]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    return LIB
+    return _compile_link(LIB, [], verbose)
 
 
 def build_variant(tag, extra_flags, verbose=False):
@@ -47,16 +69,13 @@ def build_variant(tag, extra_flags, verbose=False):
     # a variant built in the build container ships with the snapshot: rebuilt only when a source or a flag changed (content hash —
     # file times do not survive the copy)
     import hashlib
-    hsh = hashlib.sha256(" ".join(FLAGS + list(extra_flags)).encode())
+    hsh = hashlib.sha256(" ".join(FLAGS + list(extra_flags) + [repr(sorted(SOURCE_FLAGS.items()))]).encode())
     for d in sorted(srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))] + [os.path.join(PKG, "..", "include", "mtfjsp.h")]):
         hsh.update(open(d, "rb").read())
     stamp = out + ".srchash"
     if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == hsh.hexdigest() and not os.environ.get("MTFJSP_REBUILD_VARIANTS"):
         return out
-    cmd = [hipcc()] + FLAGS + list(extra_flags) + srcs + ["-o", out]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    _compile_link(out, extra_flags, verbose)
     with open(stamp, "w") as f:
         f.write(hsh.hexdigest())
     return out

@@ -31,8 +31,8 @@
 
 #include "../../include/mtfjsp.h"
 
-#define HD 128
-#define BN_EPS 1e-5
+
+#include "mtfjsp_enc_shared.h"
 
 enum { PRO_PLAIN = 0, PRO_BNRELU = 1, PRO_AGG = 2, PRO_GIN0 = 3, PRO_GIN0BN = 4 };
 enum { EPI_PLAIN = 0, EPI_STATS = 1, EPI_TANH = 2 };
@@ -95,14 +95,6 @@ struct GemmArgs {
 #else
 #define STAMP(slot) do { } while (0)
 #endif
-// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it would wait for every
-// global prefetch in flight (the next weight block, the next tile) and serialise what is meant to overlap.
-#define LDS_BARRIER()                                              \
-    do {                                                           \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
-        __builtin_amdgcn_s_barrier();                              \
-        asm volatile("" ::: "memory");                             \
-    } while (0)
 
 // tanh(x) = 1 - 2/(exp(2x)+1) on the hardware exp2/rcp units: |error| < 3e-7 absolute (the scorer/critic heads are
 // checked against the reference at 1e-4); saturates correctly for |x| large, a NaN stays a NaN.  Five instructions: multiply, v_exp_f32, add,
@@ -115,39 +107,9 @@ __device__ __forceinline__ float fast_tanh(float x)
     return __builtin_fmaf(-2.0f, __builtin_amdgcn_rcpf(e + 1.0f), 1.0f);
 }
 
-// A vector instruction must not read the result of a matrix instruction before the matrix pipe has written it back, and gfx950 does NOT
-// interlock that: tools/ubench/mfma_raw.hip reads stale registers up to 6 wait states behind v_mfma_f32_16x16x32_f16 (5 when the
-// fillers are single-width vector instructions, where 15-45 % of the reads are still stale: a marginal regime that depends on how the
-// SIMD's two waves interleave) and up to 10 behind v_mfma_f32_32x32x16_f16.  hipcc's hazard recogniser inserts the required s_nops with
-// NO margin, counting every instruction in between as one wait state.  (This was the first suspect of the round-4 bisection of the
-// function-form GAT miscomputation; the culprit turned out to be another one — mtfjsp_gat3x_body.h — but the margin is cheap.)
-// MFMA_SETTLE puts four real wait states behind the last matrix instruction of a chain and ties the accumulators to them.
-#define MFMA_SETTLE1(a) asm volatile("s_nop 3" : "+v"(a))
-#define MFMA_SETTLE2(a, b) asm volatile("s_nop 3" : "+v"(a), "+v"(b))
-#define MFMA_SETTLE3(a, b, c) asm volatile("s_nop 3" : "+v"(a), "+v"(b), "+v"(c))
-#define MFMA_SETTLE8(a) asm volatile("s_nop 3" : "+v"((a)[0]), "+v"((a)[1]), "+v"((a)[2]), "+v"((a)[3]), "+v"((a)[4]), "+v"((a)[5]), "+v"((a)[6]), "+v"((a)[7]))
 
-// sum over the 16 lanes of a DPP row, result in every lane: xor 1, xor 2 (quad permutes), half-row mirror, row mirror —
-// four VALU instructions with DPP operands instead of four dependent ds_bpermute round trips
-__device__ __forceinline__ float row_sum16(float x)
-{
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));
-    return x;
-}
 
-__device__ __forceinline__ float bn_relu(float x, float mean, float rstd, float g, float b)
-{
-    float y = (x - mean) * rstd * g + b;
-    return y > 0.f ? y : 0.f;
-}
-// the same BatchNorm + ReLU as one FMA: y = max(x * sc + sh, 0) with sc = rstd * gamma, sh = beta - mean * sc (the form
-// torch's CPU kernel uses as well: alpha = invstd * weight, beta' = bias - mean * alpha)
-__device__ __forceinline__ float bn_relu_ss(float x, float sc, float sh) { return fmaxf(fmaf(x, sc, sh), 0.f); }
 
-#define STAT_REP 8            // replicated BatchNorm accumulators: <=32 adders per address keeps f64 atomics at full rate
 
 // ---- shared pieces of the matrix-core kernels -----------------------------------------------------------------
 // Layout of every matrix kernel below (v_mfma_f32_16x16x4_f32, 16-row tiles, 8 waves per workgroup = 2 per SIMD):
@@ -155,7 +117,6 @@ __device__ __forceinline__ float bn_relu_ss(float x, float sc, float sh) { retur
 //   W^T [k][n] in LDS, XOR-swizzled (n ^ 16*(k&1)) so the B reads of lane quarters q = 0/1 fall on opposite halves of the
 //   bank row; tile row stride LDA16 = 130 words makes the A reads conflict-free
 //   load/transform mapping: lane = (j = lane & 31, h = lane >> 5) owns rows 2p+h (p = 0..7), columns 4j..4j+3
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LDA16 130
 __device__ __forceinline__ void stage_w16(float *s_w, const float *Wt, int tid)
 {
@@ -529,34 +490,11 @@ __global__ __launch_bounds__(512) void k_gemm16p(GemmArgs A)
 //     (lane = row m, 4 consecutive columns: 16-byte stores) and keeps the BatchNorm column sums of the output.
 //   The two roles never hold each other's registers (weights vs. rows in flight), a transform's memory latency is covered
 //   by the consumer on the same SIMD, and the consumers are the older waves, which the issue arbiter favours.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define X6_ROWB 272
 #define X6_PLANE (16 * X6_ROWB)
 #define X6_TILE (3 * X6_PLANE)
 #define X6_TRB (16 * 144)                   // k_gemm_x6: a consumer wave's output transposition buffer (16 rows x 128 B, 144-byte pitch)
 #define X6_TR_OFF (8 * X6_TILE + 2 * HD * 8 + 2 * HD * 4 + 64)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// exact 3-way split of four f32 values into bf16 pieces (round-to-nearest-even), two packed dwords per plane
-__device__ __forceinline__ void split3x4(const float (&v)[4], uint2 &p0, uint2 &p1, uint2 &p2)
-{
-    unsigned o[3][2];
-#pragma unroll
-    for (int hlf = 0; hlf < 2; hlf++) {
-        float a = v[2 * hlf], b = v[2 * hlf + 1];
-#pragma unroll
-        for (int lvl = 0; lvl < 3; lvl++) {
-            const unsigned pk = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16x2));   // v_cvt_pk_bf16_f32
-            o[lvl][hlf] = pk;
-            if (lvl < 2) {                                        // remainders are exact: a - bf16(a) has <= 16 significant bits
-                a -= __builtin_bit_cast(float, pk << 16);
-                b -= __builtin_bit_cast(float, pk & 0xffff0000u);
-            }
-        }
-    }
-    p0 = make_uint2(o[0][0], o[0][1]); p1 = make_uint2(o[1][0], o[1][1]); p2 = make_uint2(o[2][0], o[2][1]);
-}
 // 2-way split into f16 pieces (round to nearest both times): v = hi + lo up to 2^-22 |v|; with the three significant piece
 // products as accurate as the exact bf16 split with six (tools/ubench/bf16x6.hip).  |v| < 65 504.
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
@@ -1315,6 +1253,7 @@ __global__ __launch_bounds__(512) void k_gemm_x6(GemmArgs A)
 static size_t gemm_x6_lds_bytes() { return (size_t)X6_TR_OFF + 4 * 2 * X6_TRB; }
 
 #include "mtfjsp_gemm_pair.h"
+#define MTFJSP_GIN_RES_DECL_ONLY          // (the kernel itself: mtfjsp_gin_res.hip, a translation unit with its own scheduling strategy)
 #include "mtfjsp_gin_resident.h"
 // the grouped environment step as a device function (k_headsx_envstep below)
 #define MTFJSP_ENV_GRP_NO_KERNELS

@@ -1,5 +1,6 @@
 // mtfjsp_gin_resident.h — the whole GIN encoder (gcn:109-197) of one forward as ONE launch whose activations never leave
-// the chip.  Included by mtfjsp_encoder.hip (uses split3x4, row_sum16, bn_relu_ss, LDS_BARRIER, STAT_REP, BN_EPS).
+// the chip.  Compiled in mtfjsp_gin_res.hip; mtfjsp_encoder.hip includes it with MTFJSP_GIN_RES_DECL_ONLY (arguments, sizes, helpers, the kernel's
+// declaration).  Uses mtfjsp_enc_shared.h (split3x4, row_sum16, bn_relu_ss, LDS_BARRIER, STAT_REP, BN_EPS).
 //
 // Why: with training-mode BatchNorm every one of the six Linear products needs the batch statistics of its output before the
 // next layer can start, so the streaming design (k_gemm_x6) writes and re-reads the [rows,128] f32 activations at every
@@ -275,6 +276,9 @@ __device__ __forceinline__ void gr_grid_barrier(unsigned long long *bar, unsigne
     __syncthreads();
 }
 
+#ifdef MTFJSP_GIN_RES_DECL_ONLY
+__global__ __launch_bounds__(256) void k_gin_res(GinResArgs A);
+#else
 __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1146,3 +1150,4 @@ __global__ __launch_bounds__(256) void k_gin_res(GinResArgs A)
     }
     GR_STAMP_AT(31);
 }
+#endif

@@ -24,7 +24,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "e2e-mappo-for-mt-fjsp_amd", "csrc")
-SOURCES = ["mtfjsp_env.hip", "mtfjsp_encoder.hip"]
+SOURCES = ["mtfjsp_env.hip", "mtfjsp_encoder.hip", "mtfjsp_gin_res.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-std=c++17", "-S", "--cuda-device-only", "-w"]
 PK_F32 = re.compile(r"^\s*(v_pk_(?:mul|add|fma)_f32)\b(.*)$")
 OP_SEL = re.compile(r"op_sel:\[([01]),([01])")
