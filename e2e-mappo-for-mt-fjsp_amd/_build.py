@@ -12,9 +12,15 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 # per translation unit (round 6, A/B on one box with the whole library built either way): hipcc's max-ILP scheduling strategy shortens the step kernels
 # (10.3 -> 10.0 us by HIP events at the headline shape, 27.5 -> 26.7 at J10M10) and k_gin_res (108.9 -> 107.6 us), lengthens the streaming product
 # kernels (k_gemm_x6: +6 us per launch) and the heads (+0.3 us): the single-launch GIN kernel has a translation unit of its own for that
-SOURCE_FLAGS = {"mtfjsp_env.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "mtfjsp_gin_res.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+# (other strategies for k_gin_res: iterative-ilp 110.8, max-memory-clause 108.7, max-ilp with the register-pressure trackers 111.7 us.)  The other encoder
+# kernels: no unclustered high-register-pressure rescheduling stage (the three-in-one heads launch 51.8 -> 51.2 us, the streaming launches unchanged)
+SOURCE_FLAGS = {"mtfjsp_env.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "mtfjsp_gin_res.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+                "mtfjsp_encoder.hip": ["-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"]}
 if os.environ.get("MTFJSP_NO_SOURCE_FLAGS"):                       # (A/B builds: every translation unit with the common flags)
     SOURCE_FLAGS = {}
+if os.environ.get("MTFJSP_SOURCE_FLAGS_JSON"):                     # (A/B builds: {"file": [flags]} replaces the table)
+    import json
+    SOURCE_FLAGS = json.loads(os.environ["MTFJSP_SOURCE_FLAGS_JSON"])
 
 
 def hipcc():
