@@ -12,10 +12,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-std=c++
 # per translation unit (round 6, A/B on one box with the whole library built either way): hipcc's max-ILP scheduling strategy shortens the step kernels
 # (10.3 -> 10.0 us by HIP events at the headline shape, 27.5 -> 26.7 at J10M10) and k_gin_res (108.9 -> 107.6 us), lengthens the streaming product
 # kernels (k_gemm_x6: +6 us per launch) and the heads (+0.3 us): the single-launch GIN kernel has a translation unit of its own for that
-# (other strategies for k_gin_res: iterative-ilp 110.8, max-memory-clause 108.7, max-ilp with the register-pressure trackers 111.7 us.)  The other encoder
-# kernels: no unclustered high-register-pressure rescheduling stage (the three-in-one heads launch 51.8 -> 51.2 us, the streaming launches unchanged)
-SOURCE_FLAGS = {"mtfjsp_env.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "mtfjsp_gin_res.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"],
-                "mtfjsp_encoder.hip": ["-mllvm", "-amdgpu-disable-unclustered-high-rp-reschedule"]}
+# (other strategies for k_gin_res: iterative-ilp 110.8, max-memory-clause 108.7, max-ilp with the register-pressure trackers 111.7 us; max-ilp also takes its 12 B
+# of scratch per lane to none.)  The rest of the encoder unit keeps the default: without the unclustered high-register-pressure rescheduling stage the three-in-one
+# heads launch is 0.6 us shorter but spills 88 instead of 36 B per lane — WRITE_SIZE 3.5 -> 6.9 MB per launch: not taken
+SOURCE_FLAGS = {"mtfjsp_env.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"], "mtfjsp_gin_res.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
 if os.environ.get("MTFJSP_NO_SOURCE_FLAGS"):                       # (A/B builds: every translation unit with the common flags)
     SOURCE_FLAGS = {}
 if os.environ.get("MTFJSP_SOURCE_FLAGS_JSON"):                     # (A/B builds: {"file": [flags]} replaces the table)
