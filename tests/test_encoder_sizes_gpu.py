@@ -123,12 +123,13 @@ def test_streaming_order_switches_do_not_change_results(monkeypatch):
         np.testing.assert_allclose(o[2], outs[0][2], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("J,M,E,B", [(10, 10, 2, 333), (4, 6, 2, 50)])
+@pytest.mark.parametrize("J,M,E,B", [(10, 10, 2, 333), (4, 6, 2, 50), (4, 4, 2, 97), (8, 4, 2, 53), (15, 10, 5, 11)])
 def test_pooling_epilogue_serves_any_candidate(monkeypatch, J, M, E, B):
     """The pooling epilogue of the last streaming product (MTFJSP_FUSE_POOL, default) takes candidate j from job j's block of rows, where the
     environment's candidates lie; a caller-made candidate elsewhere — another job's row, a row two slots share, a finished job's -1 — goes through
     k_cand_fixup.  Same forward as the stored-output path (k_job_pool_gather) on a candidate array with all of those; T = 24 (J4M6) puts up to two
-    instances into a 16-row tile and an instance across workgroup ranges."""
+    instances into a 16-row tile and an instance across workgroup ranges; T = 16 (J4M4) is the smallest the epilogue takes (every tile one instance), T = 150
+    with 11 instances a ragged last tile."""
     import torch
     import mtfjsp_amd  # noqa: F401
     enc_mod = import_module("e2e-mappo-for-mt-fjsp_amd.encoder")
@@ -153,6 +154,7 @@ def test_pooling_epilogue_serves_any_candidate(monkeypatch, J, M, E, B):
     outs = []
     for fuse in ("1", "0"):
         monkeypatch.setenv("MTFJSP_FUSE_POOL", fuse)
+        monkeypatch.setenv("MTFJSP_FUSE_GIN0", fuse)                  # (the second handle: every Linear's output stored, as in round 5)
         e = enc_mod.Encoder(J, M, B, obs_dtype="f32")
         e.load_weights(ja, ma)
         prob, h_o, job_v = e.job_actor_forward(env.tasks_fea, env.ell_col, env.ell_val, cand_t, mask, hm)
